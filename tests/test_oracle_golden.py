@@ -1,0 +1,260 @@
+"""Pins the CPU oracle (oracle/nmf_oracle.py) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  Masks / indices / counts must match bit-exactly, floats to
+<= 1e-5 relative.  CPU only (-m "not gpu")."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, assert_close
+from nmf_amd import synthetic
+from oracle import nmf_oracle as O
+
+
+def _cfg(grid, **kw):
+    return O.Cfg(grid=grid, **kw)
+
+
+def _unpack_volume(g, key, G):
+    return g.bits(key, (1, 1, G, G, G)).float()
+
+
+# ---------------------------------------------------------------------------------------------
+def test_sampler_eval_train_budget_and_secondary():
+    g = Golden("sampler")
+    G = g["grid"]
+    vol = _unpack_volume(g, "alpha_volume", G)
+    rays, focal = g["rays"], g["focal"]
+    N = g["N"]
+    B = rays.shape[0]
+    # eval
+    cfg = _cfg(G)
+    xyz, rv, n, z, dists, wv = O.sample(rays, focal, cfg, vol, O.Noise(), is_train=False)
+    assert n == N
+    assert torch.equal(rv, g.bits("eval_ray_valid", (B, N)))
+    assert torch.equal(xyz, g["eval_xyz"]) and torch.equal(z, g["eval_z"]) and torch.equal(dists, g["eval_dists"])
+    assert torch.equal(wv, g["eval_whole_valid"])
+    # train + budget
+    cfg = _cfg(G, max_samples=g["train_max_samples"])
+    tape = [("rand", g["train_jitter"])]
+    xyz, rv, n, z, dists, wv = O.sample(rays, focal, cfg, vol, O.Noise(tape), is_train=True)
+    assert torch.equal(wv, g["train_whole_valid"])
+    b = int(wv.sum())
+    assert 0 < b < B
+    assert torch.equal(rv, g.bits("train_ray_valid", (b, N)))
+    assert torch.equal(xyz, g["train_xyz"]) and torch.equal(z, g["train_z"]) and torch.equal(dists, g["train_dists"])
+    # secondary rays
+    srays = g["sec_rays"]
+    tape = [("rand", g["sec_jitter"])]
+    xyz, rv, n, z, dists, wv = O.sample(srays, focal, _cfg(G), vol, O.Noise(tape), is_train=True,
+                                        override_near=g["sec_near"], dynamic_batch_size=False)
+    assert torch.equal(rv, g.bits("sec_ray_valid", (srays.shape[0], N)))
+    assert torch.equal(xyz, g["sec_xyz"]) and torch.equal(z, g["sec_z"])
+
+
+def _field_sd(g, prefix="param/"):
+    sd = {}
+    for k in g.keys(prefix):
+        name = k[len(prefix):]
+        sd["rf." + name] = g[k].clone().requires_grad_(True)
+    return sd
+
+
+def test_field_values_normals_and_gradients():
+    g = Golden("field")
+    cfg = _cfg(g["grid"])
+    sd = _field_sd(g)
+    xyz = g["xyz"]
+    sf = O.density_feature(sd, cfg, xyz)
+    sg = O.density(sd, cfg, xyz)
+    app = O.app_feature(sd, cfg, xyz)
+    nrm = O.normals(sd, cfg, xyz)
+    assert_close(sf, g["sigma_feat"], what="sigma_feat")
+    assert_close(sg, g["sigma"], what="sigma")
+    assert_close(app, g["app"], what="app")
+    assert_close(nrm, g["normals"], rtol=1e-4, atol=1e-5, what="normals")
+    loss = (sg * g["ca"]).sum() + (app * g["cb"]).sum() + (nrm * g["cc"]).sum() + (sf * g["cd"]).sum()
+    names = [k for k in sd]
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    for k, gr in zip(names, grads):
+        ref = g["grad/" + k[3:]]
+        assert_close(gr, ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max()), what="grad " + k)
+
+
+def test_derivative_stencil_constants():
+    kx, ky = O.derivative_stencils()
+    # SURVEY Appendix B.1
+    row1 = torch.tensor([-0.061921, -0.102090, 0.0, 0.102090, 0.061921])
+    assert_close(kx[0, 0, 2], row1, rtol=1e-4, atol=1e-6)
+    assert torch.equal(kx[0, 0, 0], torch.zeros(5)) and torch.equal(kx[0, 0, 4], torch.zeros(5))
+    assert torch.equal(ky[0, 0], kx[0, 0].T)
+    assert abs(float(ky[0, 0, :, 2].abs().sum()) / 2 - 0.16401) < 1e-3
+
+
+def test_alpha_mask_rebuild():
+    g = Golden("alpha_mask")
+    G = g["grid"]
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=16, seed=0)
+    cfg = _cfg(G, density_shift=g["density_shift"])
+    v1 = O.dense_alpha_mask(sd, cfg)
+    assert int(v1.sum()) == g["n1"]
+    assert torch.equal(v1.bool(), g.bits("vol1", (1, 1, G, G, G)))
+    sd["rf.density_rf.app_plane.0"][0, 0] *= 0.5
+    v2 = O.dense_alpha_mask(sd, cfg, prev_volume=v1)
+    assert torch.equal(v2.bool(), g.bits("vol2", (1, 1, G, G, G)))
+
+
+def test_env_lookup_sat_wraps_poles_and_gradients():
+    g = Golden("env")
+    sd = {"bg_module.bg_mat": g["bg_mat"].clone().requires_grad_(True),
+          "bg_module.mipbias": torch.tensor(1.0, dtype=torch.float64, requires_grad=True),
+          "bg_module.brightness": torch.tensor(0.0, dtype=torch.float64),
+          "bg_module.mul": torch.tensor(1.0, dtype=torch.float64)}
+    dirs = g["dirs"].clone().requires_grad_(True)
+    vals = O.env_lookup(sd, dirs, g["sa"])
+    assert_close(vals, g["vals"], rtol=1e-5, atol=1e-6, what="env vals")
+    gb, gm, gd = torch.autograd.grad((vals * g["c"]).sum(), [sd["bg_module.bg_mat"], sd["bg_module.mipbias"], dirs])
+    assert_close(gb, g["grad_bg"], rtol=1e-4, atol=1e-5 * float(g["grad_bg"].abs().max()), what="grad bg")
+    assert_close(gm, g["grad_mipbias"], rtol=1e-4, atol=1e-6, what="grad mipbias")
+    assert_close(gd, g["grad_dirs"], rtol=1e-4, atol=1e-5 * float(g["grad_dirs"].abs().max()), what="grad dirs")
+    coeffs, conv = O.env_sh_irradiance(sd, O.Noise())
+    assert_close(coeffs, g["sh_coeffs"], what="sh coeffs")
+    assert_close(conv, g["sh_conv"], what="sh conv")
+    assert_close(O.env_activation(sd).reshape(-1, 3).mean(dim=0), g["mean_color"], what="mean color")
+
+
+def test_ggx_sobol_brdf_heads_select_composite():
+    g = Golden("shading_parts")
+    # GGX
+    N = g["ggx_N"].clone().requires_grad_(True)
+    r = g["ggx_r"].clone().requires_grad_(True)
+    u = g["ggx_u"]
+    L, basisT, logp = O.ggx_sample(u[..., 0], u[..., 1], g["ggx_V"], N, r, g["ggx_ray_mask"])
+    assert_close(L, g["ggx_L"], rtol=1e-5, atol=1e-6, what="ggx L")
+    assert_close(basisT, g["ggx_basisT"], what="ggx basis")
+    assert_close(logp, g["ggx_logp"], rtol=1e-5, atol=1e-5, what="ggx logp")
+    gN, gr = torch.autograd.grad((L * g["ggx_c"]).sum(), [N, r])
+    assert_close(gN, g["ggx_gN"], rtol=1e-4, atol=1e-4, what="ggx gN")
+    assert_close(gr, g["ggx_gr"], rtol=1e-4, atol=1e-4, what="ggx gr")
+    # Sobol
+    Mb, m = g["ggx_ray_mask"].shape
+    angs = O.sobol_draw(g["sobol_table"], Mb, m, O.Noise([("rand", g["sobol_offset"])]))
+    assert torch.equal(angs, g["sobol_out"])
+    # BRDF MLP
+    sd = {"model.brdf.mlp." + k[len("brdf_param/mlp."):]: g[k].clone().requires_grad_(True) for k in g.keys("brdf_param/")}
+    cfg = O.Cfg(brdf_bias=g["brdf_bias"])
+    feat = g["brdf_feat"].clone().requires_grad_(True)
+    w = O.brdf_mlp(sd, cfg, g["brdf_half"], g["brdf_diff"], feat, g["brdf_rough"])
+    assert_close(w, g["brdf_out"], rtol=1e-5, atol=1e-6, what="brdf out")
+    names = list(sd)
+    grads = torch.autograd.grad((w * g["brdf_c"]).sum(), [feat] + [sd[k] for k in names])
+    assert_close(grads[0], g["brdf_gfeat"], rtol=1e-4, atol=1e-6, what="brdf gfeat")
+    for k, gq in zip(names, grads[1:]):
+        assert_close(gq, g["brdf_grad/" + k[len("model.brdf."):]], rtol=1e-4, atol=1e-5, what=k)
+    # heads
+    sdh = {"model.diffuse_module." + k[len("heads_param/"):]: g[k] for k in g.keys("heads_param/")}
+    albedo, tint, f0, rr = O.material_heads(sdh, O.Cfg(), g["heads_feat"])
+    assert_close(albedo, g["heads_albedo"], what="albedo")
+    assert_close(tint, g["heads_tint"], what="tint")
+    assert_close(f0, g["heads_f0"], what="f0")
+    assert_close(rr[:, 0:1], g["heads_r1"], what="r1")
+    assert_close(rr[:, 1:2], g["heads_r2"], what="r2")
+    # select_bounces (three branches), bit exact
+    w_, am = g["sel_weights"], g["sel_app_mask"]
+    bm, rm = O.select_bounces(w_, am, 650000, 128, O.Noise([("rand_like", g["sel0_u"])]))
+    assert torch.equal(bm, g["sel0_bounce"]) and torch.equal(rm, g["sel0_ray_mask"])
+    bm, rm = O.select_bounces(w_, am, g["sel1_num"], None, O.Noise([("rand_like", g["sel1_u"])]))
+    assert torch.equal(bm, g["sel1_bounce"]) and torch.equal(rm, g["sel1_ray_mask"])
+    bm, rm = O.select_bounces(w_, am, g["sel2_num"], None, O.Noise([("rand_like", g["sel2_u"])]))
+    assert torch.equal(bm, g["sel2_bounce"]) and torch.equal(rm, g["sel2_ray_mask"])
+    # compositing + tonemap
+    wgt = O.raw2alpha(g["comp_sigma"], g["comp_dists"] * 25)
+    assert torch.equal(wgt, g["comp_weight"])
+    comp = O.row_mask_sum(wgt[am][..., None] * g["comp_rgb"], am)
+    assert torch.equal(comp, g["comp_out"])
+    assert_close(O.srgb_tonemap(g["tm_in"]), g["tm_clip"], what="tonemap")
+    assert_close(O.srgb_tonemap(g["tm_in"], noclip=True), g["tm_noclip"], what="tonemap noclip")
+
+
+# ---------------------------------------------------------------------------------------------
+def _e2e_setup(g, requires_grad):
+    G, BG = g["grid"], g["bg_res"]
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
+    if requires_grad:
+        for k, v in sd.items():
+            if k != "model.brdf_sampler.angs":
+                v.requires_grad_(True)
+    cfg = O.Cfg(grid=G, max_samples=g["max_samples"], max_retrace_rays=(g["max_retrace"],),
+                detach_N=bool(g["detach_N"]), brdf_bias=g["brdf_bias"], diffuse_bias=g["diffuse_bias"],
+                roughness_bias=g["roughness_bias"])
+    vol = g.bits("alpha_volume", (1, 1, G, G, G)).float()
+    return sd, cfg, vol
+
+
+@pytest.mark.parametrize("tag", ["train", "train_detachN"])
+def test_e2e_small_train_forward_backward(tag):
+    g = Golden("e2e_small_" + tag)
+    sd, cfg, vol = _e2e_setup(g, True)
+    # the fixture's alpha volume must also be what the oracle's own mask builder produces
+    assert torch.equal(O.dense_alpha_mask({k: v.detach() for k, v in sd.items()}, cfg).bool(), vol.bool())
+    noise = O.Noise(g.tape())
+    ims, st = O.render(sd, cfg, g["rays"], g["focal"], vol, noise, is_train=True, bg_col=torch.ones(3))
+    assert noise.pos == len(noise.tape), "oracle did not consume the reference's draws 1:1"
+    assert torch.equal(st["whole_valid"], g["whole_valid"])
+    assert list(st["n_samples"]) == list(g.np("n_samples"))
+    assert_close(ims["acc_map"], g["acc_map"], rtol=1e-5, atol=1e-6, what="acc_map")
+    assert_close(ims["rgb_map"], g["rgb_map"], rtol=1e-4, atol=1e-5, what="rgb_map")
+    assert_close(st["ori_loss"], g["ori_loss"], rtol=1e-4, what="ori_loss")
+    assert_close(st["prediction_loss"], g["prediction_loss"], rtol=1e-5, what="prediction_loss")
+    assert_close(st["diffuse_reg"], g["diffuse_reg"], rtol=1e-4, what="diffuse_reg")
+    assert_close(st["brdf_reg"], g["brdf_reg"], rtol=1e-4, what="brdf_reg")
+    for k in ("diffuse", "tint", "roughness", "spec", "albedo"):
+        assert_close(ims[k], g["debug/" + k], rtol=1e-4, atol=1e-5, what=k)
+    total, loss = O.training_loss(ims, st, g["gt"], 4096, sd)
+    assert_close(loss, g["loss"], rtol=1e-5, what="loss")
+    assert_close(total, g["total"], rtol=1e-5, what="total")
+    total.backward()
+    ref_names = {"rf.": "rf.", "model.": "model.", "bg_module.": "bg_module."}
+    checked = 0
+    for k in g.keys("gradnorm/"):
+        name = k[len("gradnorm/"):]
+        gr = sd[name].grad
+        assert gr is not None, name
+        ref = float(g[k])
+        assert abs(float(gr.norm()) - ref) <= 2e-3 * ref + 1e-9, (name, float(gr.norm()), ref)
+        if "grad/" + name in g:
+            assert_close(gr, g["grad/" + name], rtol=2e-3, atol=2e-2 * float(g["grad/" + name].abs().max()) + 1e-12,
+                         what="grad " + name)
+        checked += 1
+    assert checked >= 25
+    assert_close(sd["bg_module.bg_mat"].grad[0, :, ::4, ::4], g["grad_slice/bg_mat"], rtol=2e-3,
+                 atol=1e-4 * float(g["grad_slice/bg_mat"].abs().max()), what="bg slice")
+    assert_close(sd["rf.density_rf.app_plane.0"].grad[0, :, ::3, ::3], g["grad_slice/density_plane0"], rtol=2e-3,
+                 atol=1e-4 * float(g["grad_slice/density_plane0"].abs().max()), what="plane slice")
+    assert_close(sd["rf.app_rf.app_plane.1"].grad[0, :, ::3, ::3], g["grad_slice/app_plane1"], rtol=2e-3,
+                 atol=1e-4 * float(g["grad_slice/app_plane1"].abs().max()), what="app slice")
+
+
+def test_e2e_small_eval():
+    g = Golden("e2e_small_eval")
+    sd, cfg, vol = _e2e_setup(g, False)
+    noise = O.Noise(g.tape())
+    with torch.no_grad():
+        ims, st = O.render(sd, cfg, g["rays"], g["focal"], vol, noise, is_train=False, bg_col=torch.ones(3))
+    assert noise.pos == len(noise.tape)
+    assert list(st["n_samples"]) == list(g.np("n_samples"))
+    assert_close(ims["rgb_map"], g["rgb_map"], rtol=1e-4, atol=1e-5, what="rgb_map")
+    assert_close(ims["acc_map"], g["acc_map"], rtol=1e-5, atol=1e-6, what="acc_map")
+    assert_close(ims["depth"], g["depth"], rtol=1e-5, atol=1e-5, what="depth")
+    assert_close(ims["world_normal"], g["world_normal"], rtol=1e-4, atol=1e-5, what="world_normal")
+    for k in ("diffuse", "tint", "roughness", "spec", "albedo"):
+        assert_close(ims[k], g["debug/" + k], rtol=1e-4, atol=1e-5, what=k)
+
+
+def test_psnr_formula():
+    pred = torch.tensor([[0.5, 0.25, 1.2], [0.0, -0.1, 0.999]])
+    gt = torch.tensor([[0.5, 0.2, 1.0], [0.1, 0.0, 1.0]])
+    q = torch.floor(pred.clip(0, 1) * 255) / 255
+    want = -10 * math.log10(float(((q - gt) ** 2).mean()))
+    assert abs(float(O.psnr_8bit(pred, gt)) - want) < 1e-5
