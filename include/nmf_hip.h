@@ -1,0 +1,153 @@
+/*
+ * nmf_hip.h -- C ABI of libnmf_hip.so, the MI355X (gfx950) kernels beneath the
+ * microfacet_tensorf2 render/train hot path of half-potato/nmf.
+ *
+ * The reference has no FFI on this path (it is pure PyTorch); every entry point
+ * below replaces a span of reference Python that the host-side mirror classes in nmf_amd/ call
+ * instead (file:line of the reference given per function, relative to /root/reference).
+ *
+ * Conventions
+ *   - extern "C", plain pointers, int64_t sizes, hipStream_t passed as void*.
+ *   - The CALLER allocates every output (and zeroes the ones documented as "accumulated").
+ *   - The library never allocates persistent memory, never frees and never synchronises the
+ *     stream; one call = a fixed small number of kernel launches on the given stream.
+ *   - Return value: 0 = ok, negative = bad argument (NMF_E*), positive = hipError_t.
+ *     nmf_last_error_string() describes the last failure on the calling thread.
+ *   - All device pointers must be valid on the current device (hipSetDevice by the caller).
+ *   - fp32 throughout; tables are CHANNEL-LAST: plane [G_h][G_w][C], line [G][C]
+ *     (= torch.channels_last storage of the reference's [1,C,G,G] / [1,C,G,1] parameters).
+ */
+#ifndef NMF_HIP_H
+#define NMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMF_OK 0
+#define NMF_EINVAL (-1)   /* null pointer / bad size */
+#define NMF_ERANGE (-2)   /* size outside compiled limits (channels, steps ...) */
+
+#define NMF_DENSITY_C 16  /* density_n_comp, configs/field/tensorf_og.yaml */
+#define NMF_APP_C 24      /* appearance_n_comp */
+#define NMF_APP_DIM 24    /* app_dim (basis_mat rows) */
+#define NMF_MLP_IN 66     /* MLPBRDF input width, modules/brdf.py:73-120 */
+#define NMF_MLP_HID 64
+
+int nmf_version(void);
+const char* nmf_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler: AlphaGridSampler.sample / sample_ray / AlphaGridMask.sample_alpha
+ * (samplers/alphagrid.py:131-207, 23-45, 279-370).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float aabb_min[3], aabb_max[3];
+    float alpha_inv[3];   /* AlphaGridMask.invgrid_size = 1/aabbSize*2 (alphagrid.py:12)          */
+    float stepsize;       /* rf.stepsize (fp32)                                                   */
+    float half_step;      /* stepsize / 2 as torch computes it (alphagrid.py:171)                 */
+    float near_t, far_t;  /* near_far, near replaced by override_near for secondary rays          */
+    float focal;          /* 4th coordinate = t / focal (alphagrid.py:200)                        */
+    int32_t n_steps;      /* N = nSamples (<= 4096)                                               */
+    int32_t grid[3];      /* alpha volume size (x,y,z); 0 => no alpha mask                        */
+    int32_t is_train;     /* 1: cumulative jitter (alphagrid.py:168-173); 0: stepsize*k (:190)    */
+    uint64_t seed;        /* Philox seed used when jitter == NULL and is_train                    */
+    uint64_t offset;      /* Philox stream offset (advance per call)                              */
+} nmf_march_params;
+
+/* float 0/1 volume [gz][gy][gx] -> bitfield, bit i of word i/32 = volume[i] > 0
+ * (the ">0 after trilinear sampling" test of alphagrid.py:341-346 only needs occupancy bits). */
+int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* bits, void* stream);
+
+/* Pass 1: per-ray validity bitmask ([B][W] uint64, W = ceil(N/64), bit k = step k kept) and
+ * per-ray kept count.  jitter: [B][N] uniforms in [0,1) or NULL (Philox). */
+int nmf_march_count(const nmf_march_params* p, const float* rays /*[B][6]*/, int64_t B,
+                    const float* jitter, const uint32_t* alpha_bits, uint64_t* valid_bits,
+                    int32_t* counts, void* stream);
+
+/* Pass 2: exclusive scan of counts + the sample budget of alphagrid.py:353-364:
+ * if max_samples > 0 and sum(counts) > max_samples then whole_valid[i] = cumsum(counts)[i] < max_samples
+ * else all rays valid.  totals[0] = M (kept samples of valid rays), totals[1] = b (valid rays; they
+ * are always a prefix).  offsets has B+1 entries (entries past b are clamped to M). */
+int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
+                   uint8_t* whole_valid, int64_t* totals, void* stream);
+
+/* Pass 3: emit the compacted samples of the first b rays: xyzt [M][4] (world xyz, t/focal),
+ * ray_id [M], step_id [M], z [M], dist [M] (= z[k+1]-z[k] over ALL candidates, 0 for the last,
+ * alphagrid.py:348-350).  Any output pointer may be NULL. */
+int nmf_march_fill(const nmf_march_params* p, const float* rays, int64_t b, const float* jitter,
+                   const uint64_t* valid_bits, const int64_t* offsets, float* xyzt, int32_t* ray_id,
+                   int32_t* step_id, float* z, float* dist, void* stream);
+
+/* Dense views for API compatibility / parity tests: ray_valid [b][N] bool and z_vals [b][N]. */
+int nmf_march_dense(const nmf_march_params* p, const float* rays, int64_t b, const float* jitter,
+                    const uint64_t* valid_bits, uint8_t* ray_valid, float* z_vals, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TensoRF VM field: TensorVMSplit._compute_densityfeature / _compute_appfeature /
+ * TensorBase.compute_normals (fields/tensoRF.py:181-205,392-405; fields/tensor_base.py:66-129)
+ * with the derivative stencil of GridSampler2D.backward (modules/grid_sample_Cinf.py:109-325).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float aabb_min[3];
+    float inv_size[3];     /* rf.invaabbSize = 2/aabbSize (tensor_base.py:58)                     */
+    float density_shift;   /* tensor_base.py:85                                                    */
+    int32_t grid;          /* G (cubic)                                                            */
+    float stencil[5];      /* centre row of the 5x5 x-stencil; rows above/below via stencil_off   */
+    float stencil_off[5];  /* rows i=1 and i=3 of the x-stencil (grid_sample_Cinf.py:218-233)     */
+} nmf_vm_params;
+
+/* Derived density tables, rebuilt whenever the density factors change:
+ * dpk[i] [G][G][48] = (P | conv_x(P) | conv_y(P)) per texel, dlk[i] [G][32] = (L | conv(L)). */
+int nmf_vm_pack_density(const nmf_vm_params* p, const float* const planes[3],
+                        const float* const lines[3], float* const dpk[3], float* const dlk[3],
+                        void* stream);
+
+/* Forward query of M world-space samples.  Outputs (any may be NULL):
+ * sigma_feat [M], sigma [M] (softplus(clamp(f,-15,1e3)+shift)), grad [M][3] (d sigma_feat/d xyz,
+ * reference units), normal [M][3] = normalize(-grad), app [M][24], coef [M][72] (plane*line
+ * products, saved for the basis_mat gradient).  Density outputs need dpk/dlk, appearance outputs
+ * need app_planes/app_lines/basis ([24][72] row-major). */
+int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
+                     const float* const dpk[3], const float* const dlk[3],
+                     const float* const app_planes[3], const float* const app_lines[3],
+                     const float* basis, float* sigma_feat, float* sigma, float* grad, float* normal,
+                     float* app, float* coef, void* stream);
+
+/* Backward.  Upstream adjoints (any may be NULL): d_sigma [M] (wrt activated sigma), d_sigma_feat [M]
+ * (wrt the raw feature, added to the former's contribution), d_normal [M][3], d_app [M][24].
+ * sigma_feat / grad are the saved forward outputs.  Accumulates (atomics) into g_dpk[i] [G][G][48],
+ * g_dlk[i] [G][32], g_app_planes[i] [G][G][24], g_app_lines[i] [G][24] -- caller zeroes them. */
+int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
+                     const float* const dpk[3], const float* const dlk[3],
+                     const float* const app_planes[3], const float* const app_lines[3],
+                     const float* basis, const float* sigma_feat, const float* grad,
+                     const float* d_sigma, const float* d_sigma_feat, const float* d_normal,
+                     const float* d_app, float* const g_dpk[3], float* const g_dlk[3],
+                     float* const g_app_planes[3], float* const g_app_lines[3], void* stream);
+
+/* Folds the packed gradient back onto the factors (transpose of nmf_vm_pack_density):
+ * g_planes[i] [G][G][16], g_lines[i] [G][16] are OVERWRITTEN. */
+int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* const g_dpk[3],
+                               const float* const g_dlk[3], float* const g_planes[3],
+                               float* const g_lines[3], void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Compositing: raw2alpha (modules/tensor_nerf.py:19-35) and row_mask_sum
+ * (modules/row_mask_sum.py:15-22), segmented by the ray offsets of nmf_march_scan.
+ * ---------------------------------------------------------------------------------------- */
+int nmf_composite_fwd(const float* sigma, const float* dist, const int64_t* offsets, int64_t b,
+                      float distance_scale, float* weight /*[M]*/, float* acc /*[b]*/, void* stream);
+int nmf_composite_bwd(const float* sigma, const float* dist, const float* weight,
+                      const int64_t* offsets, int64_t b, float distance_scale,
+                      const float* d_weight /*[M]*/, float* d_sigma /*[M]*/, void* stream);
+/* out[r][d] = sum_{k in segment r} (scale ? scale[k] : 1) * vals[k][d], added in index order (fp32). */
+int nmf_segment_sum(const float* vals, const float* scale, const int64_t* offsets, int64_t n_seg,
+                    int32_t D, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMF_HIP_H */

@@ -1,0 +1,80 @@
+// Shared helpers for the gfx950 kernels of libnmf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nmf_hip.h"
+
+#define NMF_WAVE 64
+
+extern thread_local char nmf_err_buf[256];
+
+static inline int nmf_fail(int code, const char* what) {
+    snprintf(nmf_err_buf, sizeof(nmf_err_buf), "%s (code %d)", what, code);
+    return code;
+}
+
+#define NMF_REQUIRE(cond, code, what) \
+    do {                              \
+        if (!(cond)) return nmf_fail((code), (what)); \
+    } while (0)
+
+// Launch check: records a readable message and returns the hipError_t (positive) on failure.
+#define NMF_CHECK_LAUNCH(name)                                            \
+    do {                                                                  \
+        hipError_t e_ = hipGetLastError();                                \
+        if (e_ != hipSuccess) {                                           \
+            snprintf(nmf_err_buf, sizeof(nmf_err_buf), "%s: %s", (name), hipGetErrorString(e_)); \
+            return (int)e_;                                               \
+        }                                                                 \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Non-contracted fp32 arithmetic: bookkeeping that must be bit-exact against the CPU oracle
+// (sample positions, in-box / occupancy tests, bounce counts) uses these so the compiler can
+// never fuse a*b+c into an fma.
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
+// ---- Philox4x32-10 (counter-based RNG for in-kernel jitter) -------------------------------
+struct Philox {
+    uint32_t k0, k1;
+    __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ static void round_(uint32_t (&c)[4], uint32_t a, uint32_t b) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ a, n1 = lo1, n2 = hi0 ^ c[3] ^ b, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ void operator()(uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) const {
+        uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            round_(c, a, b);
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+__device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// ---- wave-level helpers (64 lanes) ------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}

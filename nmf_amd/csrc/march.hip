@@ -1,0 +1,350 @@
+// Ray marching, occupancy culling and compaction for gfx950.
+// Replaces AlphaGridSampler.sample / sample_ray / AlphaGridMask.sample_alpha
+// (reference: samplers/alphagrid.py:131-207, 23-45, 279-370).
+//
+// Mapping: ONE 64-lane wavefront per ray.  Lane l owns steps k = 64*j + l; the cumulative jitter
+// of alphagrid.py:168-173 is a wave-level inclusive scan carried across the j iterations in
+// float64 (torch's CPU cumsum accumulates in float64 and rounds each element to fp32 -- SURVEY
+// F14; the partial sums of <=4096 fp32 step lengths are exact in float64, so the parallel scan
+// is bit-identical to the sequential one).  The kept/culled decision of every step is a
+// wavefront ballot -> one 64-bit mask word per (ray, j); compaction indices are popcounts of
+// those words, so no atomics and the output order is (ray, step) exactly like
+// xyz_sampled[ray_valid] of the reference.  The dense [rays x N] tensors of the reference are
+// never materialised.
+#include "common.hpp"
+
+namespace {
+
+struct RayCtx {
+    float ox, oy, oz, dx, dy, dz, tmin;
+};
+
+__device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const float* rays, int64_t r) {
+    RayCtx c;
+    const float* q = rays + r * 6;
+    c.ox = q[0]; c.oy = q[1]; c.oz = q[2]; c.dx = q[3]; c.dy = q[4]; c.dz = q[5];
+    // alphagrid.py:149-152
+    float vx = c.dx == 0.f ? 1e-6f : c.dx, vy = c.dy == 0.f ? 1e-6f : c.dy, vz = c.dz == 0.f ? 1e-6f : c.dz;
+    float ax = fdiv(fsub(p.aabb_max[0], c.ox), vx), bx = fdiv(fsub(p.aabb_min[0], c.ox), vx);
+    float ay = fdiv(fsub(p.aabb_max[1], c.oy), vy), by = fdiv(fsub(p.aabb_min[1], c.oy), vy);
+    float az = fdiv(fsub(p.aabb_max[2], c.oz), vz), bz = fdiv(fsub(p.aabb_min[2], c.oz), vz);
+    float t = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    c.tmin = fminf(fmaxf(t, p.near_t), p.far_t);
+    return c;
+}
+
+// step length of candidate k (train) -- alphagrid.py:169-172
+__device__ __forceinline__ float step_len(const nmf_march_params& p, const float* jitter, const Philox& rng,
+                                          int64_t r, int k) {
+    float u;
+    if (jitter) {
+        u = jitter[r * p.n_steps + k];
+    } else {
+        uint32_t o[4];
+        rng((uint64_t)r * 1024u + (uint64_t)(k >> 2), p.offset, o);
+        u = u32_to_unit(o[k & 3]);
+    }
+    return fadd(fmul(u, p.stepsize), p.half_step);
+}
+
+// occupancy test of alphagrid.py:23-45 + ":343 alphas > 0": trilinear sample of a 0/1 volume with
+// zero padding is positive iff an in-range corner with a set bit has a positive weight product.
+__device__ __forceinline__ bool alpha_hit(const nmf_march_params& p, const uint32_t* bits, float x, float y, float z) {
+    const int gx = p.grid[0], gy = p.grid[1], gz = p.grid[2];
+    float cx = fsub(fmul(fsub(x, p.aabb_min[0]), p.alpha_inv[0]), 1.f);
+    float cy = fsub(fmul(fsub(y, p.aabb_min[1]), p.alpha_inv[1]), 1.f);
+    float cz = fsub(fmul(fsub(z, p.aabb_min[2]), p.alpha_inv[2]), 1.f);
+    // grid_sampler_unnormalize, align_corners=True: ((c + 1) / 2) * (size - 1)
+    float ix = fmul(fdiv(fadd(cx, 1.f), 2.f), (float)(gx - 1));
+    float iy = fmul(fdiv(fadd(cy, 1.f), 2.f), (float)(gy - 1));
+    float iz = fmul(fdiv(fadd(cz, 1.f), 2.f), (float)(gz - 1));
+    float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    float wx[2] = {fsub(fadd(fx0, 1.f), ix), fsub(ix, fx0)};
+    float wy[2] = {fsub(fadd(fy0, 1.f), iy), fsub(iy, fy0)};
+    float wz[2] = {fsub(fadd(fz0, 1.f), iz), fsub(iz, fz0)};
+    bool hit = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int bx = c & 1, by = (c >> 1) & 1, bz = c >> 2;
+        int X = x0 + bx, Y = y0 + by, Z = z0 + bz;
+        if (X < 0 || Y < 0 || Z < 0 || X >= gx || Y >= gy || Z >= gz) continue;
+        int64_t idx = ((int64_t)Z * gy + Y) * gx + X;
+        if (!((bits[idx >> 5] >> (idx & 31)) & 1u)) continue;
+        float w = fmul(fmul(wx[bx], wy[by]), wz[bz]);
+        hit |= (w > 0.f);
+    }
+    return hit;
+}
+
+// One j-iteration of the march for this lane: returns z (distance along the ray) of step k and
+// whether the step is kept.  `carry` holds the float64 cumulative sum of all previous steps.
+struct StepOut {
+    float z, px, py, pz;
+    bool keep;
+};
+
+__device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const RayCtx& c, const float* jitter,
+                                             const Philox& rng, const uint32_t* bits, int64_t r, int k,
+                                             double& carry, double* cum_out) {
+    const bool in_range = k < p.n_steps;
+    float step;
+    double cum = 0.0;
+    if (p.is_train) {
+        float s = in_range ? step_len(p, jitter, rng, r, k) : 0.f;
+        double incl = wave_incl_scan((double)s);
+        cum = carry + incl;
+        carry += __shfl(incl, 63, 64);
+        step = (float)cum;
+    } else {
+        step = fmul(p.stepsize, (float)k);   // alphagrid.py:190
+    }
+    if (cum_out) *cum_out = cum;
+    StepOut o;
+    o.z = fadd(c.tmin, step);                                              // :192
+    o.px = fadd(c.ox, fmul(c.dx, o.z));                                    // :194
+    o.py = fadd(c.oy, fmul(c.dy, o.z));
+    o.pz = fadd(c.oz, fmul(c.dz, o.z));
+    bool outside = (p.aabb_min[0] > o.px) | (o.px > p.aabb_max[0]) | (p.aabb_min[1] > o.py) |
+                   (o.py > p.aabb_max[1]) | (p.aabb_min[2] > o.pz) | (o.pz > p.aabb_max[2]);   // :195
+    o.keep = in_range && !outside;
+    if (o.keep && bits) o.keep = alpha_hit(p, bits, o.px, o.py, o.pz);    // :341-346
+    return o;
+}
+
+__global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const float* __restrict__ rays, int64_t B,
+                                                     const float* __restrict__ jitter,
+                                                     const uint32_t* __restrict__ bits,
+                                                     uint64_t* __restrict__ valid, int32_t* __restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const int lane = lane_id();
+    const int W = (p.n_steps + 63) >> 6;
+    RayCtx c = load_ray(p, rays, r);
+    Philox rng(p.seed);
+    double carry = 0.0;
+    int total = 0;
+    for (int j = 0; j < W; ++j) {
+        StepOut o = march_one(p, c, jitter, rng, bits, r, j * 64 + lane, carry, nullptr);
+        uint64_t m = __ballot(o.keep);
+        total += __popcll(m);
+        if (lane == 0) valid[r * W + j] = m;
+    }
+    if (lane == 0) counts[r] = total;
+}
+
+__global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const float* __restrict__ rays, int64_t b,
+                                                    const float* __restrict__ jitter,
+                                                    const uint64_t* __restrict__ valid,
+                                                    const int64_t* __restrict__ offsets, float4* __restrict__ xyzt,
+                                                    int32_t* __restrict__ ray_id, int32_t* __restrict__ step_id,
+                                                    float* __restrict__ zout, float* __restrict__ dist) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= b) return;
+    const int lane = lane_id();
+    const int W = (p.n_steps + 63) >> 6;
+    int64_t base = offsets[r];
+    if (offsets[r + 1] == base) return;       // wave-uniform: nothing kept on this ray
+    RayCtx c = load_ray(p, rays, r);
+    Philox rng(p.seed);
+    double carry = 0.0;
+    for (int j = 0; j < W; ++j) {
+        const int k = j * 64 + lane;
+        double cum;
+        // positions are recomputed (cheap) instead of being stored by pass 1
+        StepOut o = march_one(p, c, jitter, rng, nullptr, r, k, carry, &cum);
+        const uint64_t m = valid[r * W + j];
+        if ((m >> lane) & 1ull) {
+            int64_t idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (xyzt) xyzt[idx] = make_float4(o.px, o.py, o.pz, fdiv(o.z, p.focal));       // :200
+            if (ray_id) ray_id[idx] = (int32_t)r;
+            if (step_id) step_id[idx] = k;
+            if (zout) zout[idx] = o.z;
+            if (dist) {
+                float d = 0.f;                                                              // :348-350
+                if (k + 1 < p.n_steps) {
+                    float znext;
+                    if (p.is_train) {
+                        float s = step_len(p, jitter, rng, r, k + 1);
+                        znext = fadd(c.tmin, (float)(cum + (double)s));
+                    } else {
+                        znext = fadd(c.tmin, fmul(p.stepsize, (float)(k + 1)));
+                    }
+                    d = fsub(znext, o.z);
+                }
+                dist[idx] = d;
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_march_dense(nmf_march_params p, const float* __restrict__ rays, int64_t b,
+                                                     const float* __restrict__ jitter,
+                                                     const uint64_t* __restrict__ valid,
+                                                     uint8_t* __restrict__ ray_valid, float* __restrict__ z_vals) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= b) return;
+    const int lane = lane_id();
+    const int W = (p.n_steps + 63) >> 6;
+    RayCtx c = load_ray(p, rays, r);
+    Philox rng(p.seed);
+    double carry = 0.0;
+    for (int j = 0; j < W; ++j) {
+        const int k = j * 64 + lane;
+        StepOut o = march_one(p, c, jitter, rng, nullptr, r, k, carry, nullptr);
+        if (k < p.n_steps) {
+            if (ray_valid) ray_valid[r * p.n_steps + k] = (uint8_t)((valid[r * W + j] >> lane) & 1ull);
+            if (z_vals) z_vals[r * p.n_steps + k] = o.z;
+        }
+    }
+}
+
+__global__ void k_alpha_pack(const float* __restrict__ vol, int64_t n, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers ceil(n/256)*256
+    const bool on = i < n && vol[i] > 0.f;
+    const uint64_t m = __ballot(on);
+    const int lane = lane_id();
+    if ((lane & 31) == 0) {
+        const int64_t w = i >> 5;
+        if (w * 32 < n) bits[w] = lane == 0 ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}
+
+// Single-workgroup exclusive scan with the sample budget of alphagrid.py:353-364.
+__global__ void __launch_bounds__(1024) k_march_scan(const int32_t* __restrict__ counts, int64_t B, int64_t max_samples,
+                                                     int64_t* __restrict__ offsets, uint8_t* __restrict__ whole_valid,
+                                                     int64_t* __restrict__ totals) {
+    __shared__ int64_t wave_sums[16];
+    __shared__ int64_t s_carry;
+    __shared__ int64_t s_total;
+    __shared__ int64_t s_kept;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // pass A: total
+    int64_t local = 0;
+    for (int64_t i = tid; i < B; i += 1024) local += counts[i];
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if (lane == 0) wave_sums[wid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_sums[w];
+        s_total = t;
+        s_carry = 0;
+    }
+    __syncthreads();
+    const bool budget = max_samples > 0 && s_total > max_samples;
+    int64_t kept_rays = 0, kept_samples = 0;
+    // pass B: chunked exclusive scan
+    for (int64_t base = 0; base < B; base += 1024) {
+        const int64_t i = base + tid;
+        int64_t v = i < B ? counts[i] : 0;
+        int64_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            int64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_sums[wid] = incl;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_sums[w];
+        const int64_t carry = s_carry;
+        const int64_t cum = carry + woff + incl;          // inclusive cumsum(counts)[i]
+        if (i < B) {
+            const bool ok = !budget || cum < max_samples;  // strict '<' (alphagrid.py:359)
+            whole_valid[i] = ok ? 1 : 0;
+            offsets[i] = cum - v;
+            if (ok) {
+                // valid rays form a prefix; the last valid ray defines (b, M)
+                if (i + 1 > kept_rays) { kept_rays = i + 1; kept_samples = cum; }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = cum;
+        __syncthreads();
+    }
+    // reduce (kept_rays, kept_samples) = max over threads
+    for (int d = 32; d > 0; d >>= 1) {
+        int64_t r2 = __shfl_down(kept_rays, d, 64), s2 = __shfl_down(kept_samples, d, 64);
+        if (r2 > kept_rays) { kept_rays = r2; kept_samples = s2; }
+    }
+    __shared__ int64_t red_r[16], red_s[16];
+    if (lane == 0) { red_r[wid] = kept_rays; red_s[wid] = kept_samples; }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t br = 0, bs = 0;
+        for (int w = 0; w < 16; ++w) if (red_r[w] > br) { br = red_r[w]; bs = red_s[w]; }
+        totals[0] = bs;
+        totals[1] = br;
+        offsets[B] = s_total;
+        s_kept = bs;
+    }
+    __syncthreads();
+    // clamp offsets of dropped rays to M so segment r of a dropped ray is empty
+    if (budget) {
+        const int64_t Mk = s_kept;
+        for (int64_t i = tid; i <= B; i += 1024)
+            if (offsets[i] > Mk) offsets[i] = Mk;
+    }
+}
+
+}  // namespace
+
+extern "C" int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* bits, void* stream) {
+    NMF_REQUIRE(volume && bits && n_voxels > 0, NMF_EINVAL, "nmf_alpha_pack: null/empty");
+    hipLaunchKernelGGL(k_alpha_pack, dim3((unsigned)cdiv(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, volume,
+                       n_voxels, bits);
+    NMF_CHECK_LAUNCH("nmf_alpha_pack");
+    return NMF_OK;
+}
+
+static int check_params(const nmf_march_params* p) {
+    NMF_REQUIRE(p, NMF_EINVAL, "march: params null");
+    NMF_REQUIRE(p->n_steps > 0 && p->n_steps <= 4096, NMF_ERANGE, "march: n_steps outside (0,4096]");
+    return NMF_OK;
+}
+
+extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int64_t B, const float* jitter,
+                               const uint32_t* alpha_bits, uint64_t* valid_bits, int32_t* counts, void* stream) {
+    if (int e = check_params(p)) return e;
+    NMF_REQUIRE(B >= 0 && (B == 0 || (rays && valid_bits && counts)), NMF_EINVAL, "nmf_march_count: null");
+    if (B == 0) return NMF_OK;
+    nmf_march_params q = *p;
+    if (!alpha_bits) q.grid[0] = q.grid[1] = q.grid[2] = 0;
+    hipLaunchKernelGGL(k_march_count, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, q, rays, B, jitter,
+                       (q.grid[0] > 0 ? alpha_bits : nullptr), valid_bits, counts);
+    NMF_CHECK_LAUNCH("nmf_march_count");
+    return NMF_OK;
+}
+
+extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
+                              uint8_t* whole_valid, int64_t* totals, void* stream) {
+    NMF_REQUIRE(counts && offsets && whole_valid && totals && B > 0, NMF_EINVAL, "nmf_march_scan: null/empty");
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, B, max_samples, offsets,
+                       whole_valid, totals);
+    NMF_CHECK_LAUNCH("nmf_march_scan");
+    return NMF_OK;
+}
+
+extern "C" int nmf_march_fill(const nmf_march_params* p, const float* rays, int64_t b, const float* jitter,
+                              const uint64_t* valid_bits, const int64_t* offsets, float* xyzt, int32_t* ray_id,
+                              int32_t* step_id, float* z, float* dist, void* stream) {
+    if (int e = check_params(p)) return e;
+    NMF_REQUIRE(b >= 0 && (b == 0 || (rays && valid_bits && offsets)), NMF_EINVAL, "nmf_march_fill: null");
+    if (b == 0) return NMF_OK;
+    hipLaunchKernelGGL(k_march_fill, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
+                       valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
+    NMF_CHECK_LAUNCH("nmf_march_fill");
+    return NMF_OK;
+}
+
+extern "C" int nmf_march_dense(const nmf_march_params* p, const float* rays, int64_t b, const float* jitter,
+                               const uint64_t* valid_bits, uint8_t* ray_valid, float* z_vals, void* stream) {
+    if (int e = check_params(p)) return e;
+    NMF_REQUIRE(b >= 0 && (b == 0 || (rays && valid_bits)), NMF_EINVAL, "nmf_march_dense: null");
+    if (b == 0) return NMF_OK;
+    hipLaunchKernelGGL(k_march_dense, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
+                       valid_bits, ray_valid, z_vals);
+    NMF_CHECK_LAUNCH("nmf_march_dense");
+    return NMF_OK;
+}

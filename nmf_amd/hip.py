@@ -1,0 +1,280 @@
+"""ctypes binding of libnmf_hip.so (include/nmf_hip.h).  This is the ONLY way the host-side operator
+classes reach the GPU kernels; there is no CPU or PyTorch fallback: if the library is missing the
+import of any product operator raises.
+
+torch is used for what it is here for: device memory (tensors), the current HIP stream and
+torch.distributed.  Every wrapper takes torch tensors, checks dtype / contiguity / device and
+passes raw pointers + sizes + the current stream to the C ABI.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnmf_hip.so")
+
+
+class NmfHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NmfHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or nmf_amd/csrc/build.sh).  nmf_amd has no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+c_f32p = C.POINTER(C.c_float)
+c_vp = C.c_void_p
+
+
+class MarchParams(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("alpha_inv", C.c_float * 3),
+                ("stepsize", C.c_float), ("half_step", C.c_float), ("near_t", C.c_float), ("far_t", C.c_float),
+                ("focal", C.c_float), ("n_steps", C.c_int32), ("grid", C.c_int32 * 3), ("is_train", C.c_int32),
+                ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class VmParams(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("inv_size", C.c_float * 3), ("density_shift", C.c_float),
+                ("grid", C.c_int32), ("stencil", C.c_float * 5), ("stencil_off", C.c_float * 5)]
+
+
+EXPORTS = [
+    "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan",
+    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
+    "nmf_vm_unpack_density_grad", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
+]
+for _n in EXPORTS:
+    if not hasattr(_lib, _n):
+        raise NmfHipError(f"libnmf_hip.so does not export {_n}")
+_lib.nmf_last_error_string.restype = C.c_char_p
+_lib.nmf_version.restype = C.c_int
+
+
+def version():
+    return _lib.nmf_version()
+
+
+def _check(code, what):
+    if code != 0:
+        raise NmfHipError(f"{what} failed: {_lib.nmf_last_error_string().decode()} [{code}]")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    """device pointer of a contiguous tensor (None -> NULL)"""
+    if t is None:
+        return C.c_void_p(0)
+    if dtype is not None and t.dtype != dtype:
+        raise NmfHipError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise NmfHipError("nmf_amd operators need device tensors (no CPU path)")
+    if not t.is_contiguous():
+        raise NmfHipError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _p3(ts, dtype=torch.float32):
+    arr = (C.c_void_p * 3)()
+    if ts is None:
+        return None
+    for i in range(3):
+        arr[i] = _p(ts[i], dtype).value
+    return arr
+
+
+def channels_last_ptr_ok(t):
+    """True if a [1,C,H,W] tensor is stored [H][W][C] densely (what the kernels index)."""
+    _, Cn, H, W = t.shape
+    return t.stride(1) == 1 and t.stride(3) == Cn and t.stride(2) == W * Cn
+
+
+# ---- sampler ----------------------------------------------------------------------------------
+def march_params(aabb, alpha_inv, stepsize, near, far, focal, n_steps, grid, is_train, seed=0, offset=0):
+    p = MarchParams()
+    a = aabb.detach().float().cpu().numpy()
+    p.aabb_min[:] = a[0].tolist()
+    p.aabb_max[:] = a[1].tolist()
+    p.alpha_inv[:] = np.asarray(alpha_inv, dtype=np.float32).tolist() if alpha_inv is not None else [0, 0, 0]
+    st = np.float32(stepsize)
+    p.stepsize = float(st)
+    p.half_step = float(np.float32(st / np.float32(2)))
+    p.near_t = float(np.float32(near))
+    p.far_t = float(np.float32(far))
+    p.focal = float(np.float32(focal))
+    p.n_steps = int(n_steps)
+    p.grid[:] = [int(g) for g in grid] if grid is not None else [0, 0, 0]
+    p.is_train = 1 if is_train else 0
+    p.seed = int(seed)
+    p.offset = int(offset)
+    return p
+
+
+def alpha_pack(volume):
+    n = volume.numel()
+    bits = torch.zeros((n + 31) // 32, dtype=torch.int32, device=volume.device)
+    _check(_lib.nmf_alpha_pack(_p(volume.contiguous(), torch.float32), C.c_int64(n), _p(bits), _stream()), "nmf_alpha_pack")
+    return bits
+
+
+def march_count(p, rays, jitter, alpha_bits):
+    B = rays.shape[0]
+    W = (p.n_steps + 63) // 64
+    valid = torch.empty((B, W), dtype=torch.int64, device=rays.device)
+    counts = torch.empty(B, dtype=torch.int32, device=rays.device)
+    _check(_lib.nmf_march_count(C.byref(p), _p(rays, torch.float32), C.c_int64(B), _p(jitter), _p(alpha_bits),
+                                _p(valid), _p(counts), _stream()), "nmf_march_count")
+    return valid, counts
+
+
+def march_scan(counts, max_samples):
+    B = counts.shape[0]
+    offsets = torch.empty(B + 1, dtype=torch.int64, device=counts.device)
+    whole_valid = torch.empty(B, dtype=torch.uint8, device=counts.device)
+    totals = torch.empty(2, dtype=torch.int64, device=counts.device)
+    _check(_lib.nmf_march_scan(_p(counts, torch.int32), C.c_int64(B), C.c_int64(max_samples), _p(offsets),
+                               _p(whole_valid), _p(totals), _stream()), "nmf_march_scan")
+    return offsets, whole_valid, totals
+
+
+def march_fill(p, rays, b, M, jitter, valid, offsets, want_z=True):
+    dev = rays.device
+    xyzt = torch.empty((M, 4), dtype=torch.float32, device=dev)
+    ray_id = torch.empty(M, dtype=torch.int32, device=dev)
+    step_id = torch.empty(M, dtype=torch.int32, device=dev)
+    z = torch.empty(M, dtype=torch.float32, device=dev) if want_z else None
+    dist = torch.empty(M, dtype=torch.float32, device=dev)
+    _check(_lib.nmf_march_fill(C.byref(p), _p(rays, torch.float32), C.c_int64(b), _p(jitter), _p(valid), _p(offsets),
+                               _p(xyzt), _p(ray_id), _p(step_id), _p(z), _p(dist), _stream()), "nmf_march_fill")
+    return xyzt, ray_id, step_id, z, dist
+
+
+def march_dense(p, rays, b, jitter, valid):
+    ray_valid = torch.empty((b, p.n_steps), dtype=torch.uint8, device=rays.device)
+    z_vals = torch.empty((b, p.n_steps), dtype=torch.float32, device=rays.device)
+    _check(_lib.nmf_march_dense(C.byref(p), _p(rays, torch.float32), C.c_int64(b), _p(jitter), _p(valid),
+                                _p(ray_valid), _p(z_vals), _stream()), "nmf_march_dense")
+    return ray_valid.bool(), z_vals
+
+
+# ---- VM field ----------------------------------------------------------------------------------
+def derivative_stencil_rows():
+    """Rows of the 5x5 x-derivative stencil of GridSampler2D.backward (smoothing=1): a normalised 3x3
+    Gaussian (std 1) correlated with [-0.5, 0, 0.5]; computed in fp32 exactly like the reference does
+    (modules/grid_sample_Cinf.py:16-29,49-63,218-233): kx[i][j] = 0.5*(S[i-1][j-2] - S[i-1][j])."""
+    n = np.arange(3, dtype=np.float32) - np.float32(1.0)
+    g1 = np.exp(-(n ** 2) / np.float32(2.0)).astype(np.float32)
+    S = np.outer(g1, g1).astype(np.float32)
+    S = (S / S.sum(dtype=np.float32)).astype(np.float32)
+    rows = []
+    for i in (1, 2):          # S row 0 (== row 2) and S row 1
+        r = S[i - 1]
+        rows.append([-0.5 * r[0], -0.5 * r[1], 0.0, 0.5 * r[1], 0.5 * r[2]])
+    return np.asarray(rows[1], np.float32), np.asarray(rows[0], np.float32)   # centre row, off-centre rows
+
+
+def vm_params(aabb, inv_size, density_shift, grid):
+    p = VmParams()
+    p.aabb_min[:] = aabb[0].detach().float().cpu().numpy().tolist()
+    p.inv_size[:] = inv_size.detach().float().cpu().numpy().tolist()
+    p.density_shift = float(density_shift)
+    p.grid = int(grid)
+    c, o = derivative_stencil_rows()
+    p.stencil[:] = c.tolist()
+    p.stencil_off[:] = o.tolist()
+    return p
+
+
+def vm_pack_density(p, planes, lines):
+    """planes[i]: [G,G,16] channel-last storage, lines[i]: [G,16]."""
+    G = p.grid
+    dev = planes[0].device
+    dpk = [torch.empty((G, G, 48), dtype=torch.float32, device=dev) for _ in range(3)]
+    dlk = [torch.empty((G, 32), dtype=torch.float32, device=dev) for _ in range(3)]
+    _check(_lib.nmf_vm_pack_density(C.byref(p), _p3(planes), _p3(lines), _p3(dpk), _p3(dlk), _stream()),
+           "nmf_vm_pack_density")
+    return dpk, dlk
+
+
+def vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density=True, want_normal=True,
+                 want_app=True, want_coef=False):
+    M = xyzt.shape[0]
+    dev = xyzt.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    sf = f(M) if want_density else None
+    sg = f(M) if want_density else None
+    gr = f(M, 3) if want_normal else None
+    nr = f(M, 3) if want_normal else None
+    ap = f(M, 24) if want_app else None
+    cf = f(M, 72) if want_coef else None
+    need_d = want_density or want_normal
+    need_a = want_app or want_coef
+    _check(_lib.nmf_vm_query_fwd(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M),
+                                 _p3(dpk) if need_d else None, _p3(dlk) if need_d else None,
+                                 _p3(app_planes) if need_a else None, _p3(app_lines) if need_a else None,
+                                 _p(basis) if need_a else None, _p(sf), _p(sg), _p(gr), _p(nr), _p(ap), _p(cf),
+                                 _stream()), "nmf_vm_query_fwd")
+    return sf, sg, gr, nr, ap, cf
+
+
+def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, grad, d_sigma, d_sigma_feat,
+                 d_normal, d_app, g_dpk, g_dlk, g_app_planes, g_app_lines):
+    M = xyzt.shape[0]
+    want_d = d_sigma is not None or d_sigma_feat is not None or d_normal is not None
+    want_a = d_app is not None
+    _check(_lib.nmf_vm_query_bwd(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M),
+                                 _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
+                                 _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
+                                 _p(basis) if want_a else None, _p(sigma_feat), _p(grad), _p(d_sigma),
+                                 _p(d_sigma_feat), _p(d_normal), _p(d_app),
+                                 _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
+                                 _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
+                                 _stream()), "nmf_vm_query_bwd")
+
+
+def vm_unpack_density_grad(p, g_dpk, g_dlk):
+    G = p.grid
+    dev = g_dpk[0].device
+    gp = [torch.empty((G, G, 16), dtype=torch.float32, device=dev) for _ in range(3)]
+    gl = [torch.empty((G, 16), dtype=torch.float32, device=dev) for _ in range(3)]
+    _check(_lib.nmf_vm_unpack_density_grad(C.byref(p), _p3(g_dpk), _p3(g_dlk), _p3(gp), _p3(gl), _stream()),
+           "nmf_vm_unpack_density_grad")
+    return gp, gl
+
+
+# ---- compositing --------------------------------------------------------------------------------
+def composite_fwd(sigma, dist, offsets, b, distance_scale):
+    M = sigma.shape[0]
+    weight = torch.empty(M, dtype=torch.float32, device=sigma.device)
+    acc = torch.empty(b, dtype=torch.float32, device=sigma.device)
+    _check(_lib.nmf_composite_fwd(_p(sigma, torch.float32), _p(dist, torch.float32), _p(offsets, torch.int64),
+                                  C.c_int64(b), C.c_float(distance_scale), _p(weight), _p(acc), _stream()),
+           "nmf_composite_fwd")
+    return weight, acc
+
+
+def composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight):
+    d_sigma = torch.empty_like(sigma)
+    _check(_lib.nmf_composite_bwd(_p(sigma, torch.float32), _p(dist, torch.float32), _p(weight, torch.float32),
+                                  _p(offsets, torch.int64), C.c_int64(b), C.c_float(distance_scale),
+                                  _p(d_weight.contiguous(), torch.float32), _p(d_sigma), _stream()),
+           "nmf_composite_bwd")
+    return d_sigma
+
+
+def segment_sum(vals, scale, offsets, n_seg):
+    D = vals.shape[1]
+    out = torch.empty((n_seg, D), dtype=torch.float32, device=vals.device)
+    _check(_lib.nmf_segment_sum(_p(vals, torch.float32), _p(scale), _p(offsets, torch.int64), C.c_int64(n_seg),
+                                C.c_int32(D), _p(out), _stream()), "nmf_segment_sum")
+    return out

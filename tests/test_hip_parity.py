@@ -1,0 +1,265 @@
+"""GPU parity: the HIP kernels (through the C ABI, nmf_amd/hip.py) against the CPU oracle and against
+the reference's golden vectors.  Bit-exact for masks / indices / counts / sample positions;
+floats within the stated tolerances.  Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, assert_close
+from oracle import nmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _hip():
+    from nmf_amd import hip
+    return hip
+
+
+def _march(hip, cfg, rays, focal, vol, jitter, is_train, near=None, max_samples=-1):
+    d = cfg.derived()
+    G = cfg.grid
+    aabb = d["aabb"]
+    alpha_inv = (1.0 / (aabb[1] - aabb[0]) * 2).numpy()
+    p = hip.march_params(aabb, alpha_inv, float(d["stepsize"]), cfg.near_far[0] if near is None else float(near),
+                         cfg.near_far[1], focal, d["n_samples"], (G, G, G), is_train)
+    rays_d = rays.to(DEV).contiguous()
+    jit_d = jitter.to(DEV).contiguous() if jitter is not None else None
+    bits = hip.alpha_pack(vol.to(DEV).reshape(-1)) if vol is not None else None
+    valid, counts = hip.march_count(p, rays_d, jit_d, bits)
+    offsets, wv, totals = hip.march_scan(counts, max_samples)
+    M, b = [int(v) for v in totals.cpu()]
+    xyzt, ray_id, step_id, z, dist = hip.march_fill(p, rays_d, b, M, jit_d, valid, offsets)
+    rv, zd = hip.march_dense(p, rays_d, b, jit_d, valid)
+    return dict(xyz=xyzt.cpu(), ray_id=ray_id.cpu(), step_id=step_id.cpu(), z=z.cpu(), dist=dist.cpu(),
+                ray_valid=rv.cpu(), z_vals=zd.cpu(), whole_valid=wv.bool().cpu(), M=M, b=b, offsets=offsets.cpu(),
+                counts=counts.cpu())
+
+
+def _check_march(out, xyz, rv, z, dists, wv):
+    assert torch.equal(out["whole_valid"], wv)
+    assert torch.equal(out["ray_valid"], rv), "ray_valid differs"
+    assert out["M"] == xyz.shape[0]
+    assert torch.equal(out["xyz"], xyz), float((out["xyz"] - xyz).abs().max())
+    assert torch.equal(out["z_vals"], z)
+    assert torch.equal(out["z"], z[rv])
+    assert torch.equal(out["dist"], dists[rv])
+    ri, si = torch.where(rv)
+    assert torch.equal(out["ray_id"].long(), ri) and torch.equal(out["step_id"].long(), si)
+    assert torch.equal(out["counts"][: rv.shape[0]].long(), rv.sum(1))
+
+
+def test_march_golden_eval_train_budget_secondary():
+    hip = _hip()
+    g = Golden("sampler")
+    G, N = g["grid"], g["N"]
+    vol = g.bits("alpha_volume", (1, 1, G, G, G)).float()
+    rays, focal = g["rays"], g["focal"]
+    B = rays.shape[0]
+    out = _march(hip, O.Cfg(grid=G), rays, focal, vol, None, False)
+    rv = g.bits("eval_ray_valid", (B, N))
+    _check_march(out, g["eval_xyz"], rv, g["eval_z"], g["eval_dists"], g["eval_whole_valid"])
+    # train + budget
+    out = _march(hip, O.Cfg(grid=G), rays, focal, vol, g["train_jitter"], True, max_samples=g["train_max_samples"])
+    wv = g["train_whole_valid"]
+    b = int(wv.sum())
+    assert out["b"] == b
+    _check_march(out, g["train_xyz"], g.bits("train_ray_valid", (b, N)), g["train_z"], g["train_dists"], wv)
+    # secondary rays (origins inside, override_near, zero direction components)
+    srays = g["sec_rays"]
+    out = _march(hip, O.Cfg(grid=G), srays, focal, vol, g["sec_jitter"], True, near=g["sec_near"])
+    _check_march(out, g["sec_xyz"], g.bits("sec_ray_valid", (srays.shape[0], N)), g["sec_z"], g["sec_dists"],
+                 torch.ones(srays.shape[0], dtype=torch.bool))
+
+
+@pytest.mark.parametrize("B,G,seed", [(1, 16, 0), (257, 40, 1), (3000, 64, 2)])
+def test_march_vs_oracle_random(B, G, seed):
+    hip = _hip()
+    gen = torch.Generator().manual_seed(seed)
+    cfg = O.Cfg(grid=G, max_samples=B * 6)
+    vol = (torch.rand(1, 1, G, G, G, generator=gen) < 0.1).float()
+    o = (torch.rand(B, 3, generator=gen) * 2 - 1) * 3.5
+    tgt = (torch.rand(B, 3, generator=gen) * 2 - 1) * 1.0
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    rays = torch.cat([o, d], -1)
+    N = cfg.derived()["n_samples"]
+    jit = torch.rand(B, N, generator=gen)
+    xyz, rv, n, z, dists, wv = O.sample(rays, 1111.0, cfg, vol, O.Noise([("rand", jit)]), True)
+    out = _march(hip, cfg, rays, 1111.0, vol, jit, True, max_samples=cfg.max_samples)
+    _check_march(out, xyz, rv, z, dists, wv)
+    # empty alpha volume -> nothing kept, no alpha volume -> box test only
+    out = _march(hip, cfg, rays, 1111.0, torch.zeros_like(vol), jit, True)
+    assert out["M"] == 0
+    xyz, rv, n, z, dists, wv = O.sample(rays, 1111.0, O.Cfg(grid=G, max_samples=-1), None, O.Noise([("rand", jit)]), True)
+    out = _march(hip, cfg, rays, 1111.0, None, jit, True)
+    _check_march(out, xyz, rv, z, dists, wv)
+
+
+def test_march_philox_jitter_statistics():
+    hip = _hip()
+    cfg = O.Cfg(grid=32)
+    d = cfg.derived()
+    B = 512
+    rays = torch.cat([torch.tensor([[0.0, 0.0, -4.0]]).expand(B, 3), torch.tensor([[0.0, 0.0, 1.0]]).expand(B, 3)], -1)
+    p = hip.march_params(d["aabb"], (1.0 / (d["aabb"][1] - d["aabb"][0]) * 2).numpy(), float(d["stepsize"]), 2.5, 7.0,
+                         1000.0, d["n_samples"], None, True, seed=123, offset=7)
+    rays_d = rays.to(DEV).contiguous()
+    valid, counts = hip.march_count(p, rays_d, None, None)
+    rv, z = hip.march_dense(p, rays_d, B, None, valid)
+    steps = (z[:, 1:] - z[:, :-1]).cpu() / float(d["stepsize"])
+    assert float(steps.min()) >= 0.5 - 1e-3 and float(steps.max()) <= 1.5 + 1e-3
+    assert abs(float(steps.mean()) - 1.0) < 5e-3
+    assert float((z[0] - z[1]).abs().max()) > 0       # rays get different streams
+    p2 = hip.march_params(d["aabb"], (1.0 / (d["aabb"][1] - d["aabb"][0]) * 2).numpy(), float(d["stepsize"]), 2.5, 7.0,
+                          1000.0, d["n_samples"], None, True, seed=123, offset=7)
+    _, z2 = hip.march_dense(p2, rays_d, B, None, valid)
+    assert torch.equal(z, z2)                           # counter-based: reproducible
+
+
+# ---------------------------------------------------------------------------------------------
+def _cl(t):
+    """[1,C,H,W] -> channel-last storage [H,W,C] on the device"""
+    return t[0].permute(1, 2, 0).contiguous().to(DEV)
+
+
+def _field_tables(hip, sd, cfg):
+    d = cfg.derived()
+    p = hip.vm_params(d["aabb"], d["inv"], cfg.density_shift, cfg.grid)
+    dpl = [_cl(sd[f"rf.density_rf.app_plane.{i}"].detach()) for i in range(3)]
+    dli = [_cl(sd[f"rf.density_rf.app_line.{i}"].detach()).reshape(cfg.grid, 16) for i in range(3)]
+    apl = [_cl(sd[f"rf.app_rf.app_plane.{i}"].detach()) for i in range(3)]
+    ali = [_cl(sd[f"rf.app_rf.app_line.{i}"].detach()).reshape(cfg.grid, 24) for i in range(3)]
+    basis = sd["rf.basis_mat.weight"].detach().to(DEV).contiguous()
+    dpk, dlk = hip.vm_pack_density(p, dpl, dli)
+    return p, dpk, dlk, apl, ali, basis
+
+
+def _vm_backward(hip, p, xyz_d, tabs, sf, gr, d_sigma, d_sf, d_normal, d_app, coef):
+    _, dpk, dlk, apl, ali, basis = tabs
+    G = p.grid
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)  # noqa: E731
+    g_dpk = [z(G, G, 48) for _ in range(3)]
+    g_dlk = [z(G, 32) for _ in range(3)]
+    g_apl = [z(G, G, 24) for _ in range(3)]
+    g_ali = [z(G, 24) for _ in range(3)]
+    hip.vm_query_bwd(p, xyz_d, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, d_sf, d_normal, d_app, g_dpk, g_dlk,
+                     g_apl, g_ali)
+    gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+    g_basis = d_app.t() @ coef
+    out = {}
+    for i in range(3):
+        out[f"rf.density_rf.app_plane.{i}"] = gp[i].permute(2, 0, 1)[None].cpu()
+        out[f"rf.density_rf.app_line.{i}"] = gl[i].t().reshape(1, 16, G, 1).cpu()
+        out[f"rf.app_rf.app_plane.{i}"] = g_apl[i].permute(2, 0, 1)[None].cpu()
+        out[f"rf.app_rf.app_line.{i}"] = g_ali[i].t().reshape(1, 24, G, 1).cpu()
+    out["rf.basis_mat.weight"] = g_basis.cpu()
+    return out
+
+
+def test_vm_field_golden_values_normals_gradients():
+    hip = _hip()
+    g = Golden("field")
+    cfg = O.Cfg(grid=g["grid"])
+    sd = {"rf." + k[len("param/"):]: g[k] for k in g.keys("param/")}
+    tabs = _field_tables(hip, sd, cfg)
+    p = tabs[0]
+    xyz_d = g["xyz"].to(DEV).contiguous()
+    sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyz_d, *tabs[1:], want_coef=True)
+    assert_close(sf.cpu(), g["sigma_feat"], rtol=1e-5, atol=1e-5, what="sigma_feat")
+    assert_close(sg.cpu(), g["sigma"], rtol=1e-5, atol=1e-6, what="sigma")
+    assert_close(ap.cpu(), g["app"], rtol=1e-5, atol=1e-6, what="app")
+    assert_close(nr.cpu(), g["normals"], rtol=1e-4, atol=1e-5, what="normals")
+    grads = _vm_backward(hip, p, xyz_d, tabs, sf, gr, g["ca"].to(DEV), g["cd"].to(DEV), g["cc"].to(DEV).contiguous(),
+                         g["cb"].to(DEV).contiguous(), cf)
+    for k, gq in grads.items():
+        ref = g["grad/" + k[3:]]
+        assert_close(gq, ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max()), what="grad " + k)
+
+
+@pytest.mark.parametrize("G,M,seed", [(16, 1, 0), (33, 777, 1), (128, 60000, 2)])
+def test_vm_field_vs_oracle_random(G, M, seed):
+    hip = _hip()
+    gen = torch.Generator().manual_seed(seed)
+    cfg = O.Cfg(grid=G)
+    sd = {}
+    for i in range(3):
+        sd[f"rf.density_rf.app_plane.{i}"] = (0.3 * torch.randn(1, 16, G, G, generator=gen)).requires_grad_(True)
+        sd[f"rf.density_rf.app_line.{i}"] = (0.3 * torch.randn(1, 16, G, 1, generator=gen)).requires_grad_(True)
+        sd[f"rf.app_rf.app_plane.{i}"] = (0.3 * torch.randn(1, 24, G, G, generator=gen)).requires_grad_(True)
+        sd[f"rf.app_rf.app_line.{i}"] = (0.3 * torch.randn(1, 24, G, 1, generator=gen)).requires_grad_(True)
+    sd["rf.basis_mat.weight"] = (0.2 * torch.randn(24, 72, generator=gen)).requires_grad_(True)
+    xyz = torch.cat([(torch.rand(M, 3, generator=gen) * 2 - 1) * 1.5, torch.rand(M, 1, generator=gen)], -1)
+    sf_o = O.density_feature(sd, cfg, xyz)
+    sg_o = O.density(sd, cfg, xyz)
+    ap_o = O.app_feature(sd, cfg, xyz)
+    nr_o = O.normals(sd, cfg, xyz)
+    ca, cb, cc = torch.randn(M, generator=gen), torch.randn(M, 24, generator=gen), torch.randn(M, 3, generator=gen)
+    loss = (sg_o * ca).sum() + (ap_o * cb).sum() + (nr_o * cc).sum()
+    names = list(sd)
+    ref = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
+    tabs = _field_tables(hip, sd, cfg)
+    p = tabs[0]
+    xyz_d = xyz.to(DEV).contiguous()
+    sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyz_d, *tabs[1:], want_coef=True)
+    assert_close(sf.cpu(), sf_o.detach(), rtol=1e-5, atol=2e-5, what="sigma_feat")
+    assert_close(sg.cpu(), sg_o.detach(), rtol=2e-5, atol=1e-6, what="sigma")
+    assert_close(ap.cpu(), ap_o.detach(), rtol=1e-5, atol=2e-6, what="app")
+    assert_close(nr.cpu(), nr_o.detach(), rtol=1e-4, atol=2e-5, what="normals")
+    grads = _vm_backward(hip, p, xyz_d, tabs, sf, gr, ca.to(DEV), None, cc.to(DEV).contiguous(), cb.to(DEV).contiguous(), cf)
+    for k, gq in grads.items():
+        r = ref[k]
+        assert_close(gq, r, rtol=5e-4, atol=5e-5 * float(r.abs().max()), what="grad " + k)
+
+
+# ---------------------------------------------------------------------------------------------
+def _segments(mask):
+    counts = mask.sum(1)
+    off = torch.zeros(mask.shape[0] + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(counts, 0)
+    return off
+
+
+def test_composite_golden_and_backward():
+    hip = _hip()
+    g = Golden("shading_parts")
+    am = g["sel_app_mask"]
+    sigma, dists = g["comp_sigma"], g["comp_dists"]
+    off = _segments(am).to(DEV)
+    b = am.shape[0]
+    sig_c = sigma[am].to(DEV).contiguous()
+    dist_c = dists[am].to(DEV).contiguous()
+    # NOTE: in the product the culled steps have sigma == 0; the fixture zeroes sigma outside the mask too
+    w, acc = hip.composite_fwd(sig_c, dist_c, off, b, 25.0)
+    assert_close(w.cpu(), g["comp_weight"][am], rtol=2e-6, atol=1e-7, what="weights")
+    assert_close(acc.cpu(), g["comp_weight"].sum(1), rtol=1e-5, atol=1e-6, what="acc")
+    out = hip.segment_sum(g["comp_rgb"].to(DEV).contiguous(), w, off, b)
+    assert_close(out.cpu(), g["comp_out"], rtol=1e-5, atol=1e-6, what="rgb_map")
+    # with the oracle's own weights as the scale the segmented sum must be BIT exact (index-order adds)
+    out2 = hip.segment_sum(g["comp_rgb"].to(DEV).contiguous(), g["comp_weight"][am].to(DEV).contiguous(), off, b)
+    assert torch.equal(out2.cpu(), g["comp_out"])
+    # backward against autograd of the oracle
+    s = sigma.clone().requires_grad_(True)
+    wo = O.raw2alpha(s, dists * 25)
+    gen = torch.Generator().manual_seed(3)
+    dw = torch.randn(wo.shape, generator=gen)
+    (gs,) = torch.autograd.grad((wo * dw).sum(), s)
+    ds = hip.composite_bwd(sig_c, dist_c, w, off, b, 25.0, dw[am].to(DEV).contiguous())
+    assert_close(ds.cpu(), gs[am], rtol=1e-4, atol=1e-6 * float(gs.abs().max()), what="d_sigma")
+
+
+def test_composite_empty_and_long_segments():
+    hip = _hip()
+    gen = torch.Generator().manual_seed(5)
+    b, N = 300, 500
+    mask = torch.rand(b, N, generator=gen) < 0.4
+    mask[7] = False
+    mask[8] = True
+    sigma = (torch.rand(b, N, generator=gen) * 3) * mask
+    dists = torch.rand(b, N, generator=gen) * 0.01
+    wo = O.raw2alpha(sigma, dists * 25)
+    off = _segments(mask).to(DEV)
+    w, acc = hip.composite_fwd(sigma[mask].to(DEV).contiguous(), dists[mask].to(DEV).contiguous(), off, b, 25.0)
+    assert_close(w.cpu(), wo[mask], rtol=5e-6, atol=1e-8, what="weights")
+    assert float(acc[7]) == 0.0
