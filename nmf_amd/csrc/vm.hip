@@ -312,158 +312,314 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: one lane per sample, atomics into the packed gradient tables
+// backward: brick-binned LDS accumulation.
+//
+// A per-sample scatter with global atomics (768 density + 432 appearance adds per sample) runs at
+// ~14 G atomics/s on MI355X -- device-scope float atomics execute at the memory side -- i.e. ~90 ms
+// for the 1.1 M samples of a steady-state step.  Instead the samples are counting-sorted by the
+// 8x8x8-voxel brick of their lower corner (k_brick_hist / k_scan_bins / k_brick_scatter); one
+// workgroup then owns one brick, accumulates every gradient that brick can touch -- three 9x9
+// plane tiles (density: 48 ch, appearance: 24 ch) and three 9-entry line segments -- in 76 KB of
+// LDS with ds_add_f32, and flushes the non-zero entries once (~80x fewer global atomics).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_vm_bwd(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
-                                                Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
-                                                const float* __restrict__ basis,
-                                                const float* __restrict__ sigma_feat, const float* __restrict__ grad,
-                                                const float* __restrict__ d_sigma,
-                                                const float* __restrict__ d_sigma_feat,
-                                                const float* __restrict__ d_normal, const float* __restrict__ d_app,
-                                                MPtrs3 g_dpk, MPtrs3 g_dlk, MPtrs3 g_apl, MPtrs3 g_ali) {
+constexpr int BR = 8;             // brick edge in texels
+constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
+
+__device__ __forceinline__ int axis_floor(const nmf_vm_params& p, float xn_a) {
+    float ix = ((xn_a + 1.f) * 0.5f) * (float)(p.grid - 1);      // identical to make_tap*
+    return (int)floorf(ix);
+}
+
+__device__ __forceinline__ int brick_of(const nmf_vm_params& p, const float (&xn)[3], int nbx) {
+    int b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int x0 = axis_floor(p, xn[a]);
+        x0 = x0 < 0 ? 0 : (x0 > p.grid - 1 ? p.grid - 1 : x0);
+        b[a] = x0 / BR;
+    }
+    return (b[2] * nbx + b[1]) * nbx + b[0];
+}
+
+__global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
+                                                    int nbx, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ brick_id) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const int G = p.grid;
     float xn[3];
     normalized(p, xyzt[m], xn);
+    const int b = brick_of(p, xn, nbx);
+    brick_id[m] = b;
+    atomicAdd(counts + b, 1);
+}
 
+// single-workgroup exclusive scan of n int32 counts -> offsets[n+1]; also copies offsets into cursor[n]
+__global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ counts, int n,
+                                                    int32_t* __restrict__ offsets, int32_t* __restrict__ cursor) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        int v = i < n ? counts[i] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        const int excl = carry + woff + incl - v;
+        if (i < n) { offsets[i] = excl; cursor[i] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n] = carry_s;
+}
+
+__global__ void __launch_bounds__(256) k_brick_scatter(const int32_t* __restrict__ brick_id, int64_t M,
+                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int pos = atomicAdd(cursor + brick_id[m], 1);
+    perm[pos] = (int32_t)m;
+}
+
+// uniform (per-sample) footprint: global texel index or -1, tile-local cell, weight
+struct LTap2 {
+    int g[4];
+    int l[4];
+    float w[4];
+};
+
+__device__ __forceinline__ LTap2 make_ltap2(float u, float v, int G, int ox, int oy) {
+    float ix = ((u + 1.f) * 0.5f) * (float)(G - 1);
+    float iy = ((v + 1.f) * 0.5f) * (float)(G - 1);
+    float fx = floorf(ix), fy = floorf(iy);
+    float w = ix - fx, e = 1.f - w, n = iy - fy, s = 1.f - n;
+    int x0 = (int)fx, y0 = (int)fy;
+    LTap2 t;
+    t.w[0] = e * s; t.w[1] = w * s; t.w[2] = e * n; t.w[3] = w * n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int X = x0 + (k & 1), Y = y0 + (k >> 1);
+        bool in = X >= 0 && X < G && Y >= 0 && Y < G;
+        t.g[k] = in ? Y * G + X : -1;
+        t.l[k] = (Y - oy) * TL + (X - ox);
+    }
+    return t;
+}
+
+constexpr int LDS_DP = 3 * TL * TL * DP;   // 11664 floats
+constexpr int LDS_DL = 3 * TL * DL;        //   864
+constexpr int LDS_AP = 3 * TL * TL * CA;   //  5832
+constexpr int LDS_AL = 3 * TL * CA;        //   648
+constexpr int LDS_TOTAL = LDS_DP + LDS_DL + LDS_AP + LDS_AL;   // 19008 floats = 76 KB
+constexpr int BWD_THREADS = 512;
+constexpr int BWD_WAVES = BWD_THREADS / 64;
+
+// One workgroup per brick; each WAVE walks samples of the brick one at a time and its LANES are the
+// channels of a tap (density: 48 = P|DX|DY, appearance: 24).  Consequences:
+//   * every table read is one coalesced 96..192-byte run per tap,
+//   * the LDS accumulators are [cell][channel]: the 24..48 active lanes of a ds_add_f32 hit
+//     consecutive banks, so the atomic is conflict-free (a lane-per-sample mapping serialised
+//     up to 64 ways on hot texels and ran at 0.1 LDS atomics/clk/CU -- measured 19.7 ms / 1 M samples),
+//   * per-sample scalars (taps, adjoints) are wave-uniform.
+__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(
+    nmf_vm_params p, const float4* __restrict__ xyzt, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
+    const float* __restrict__ basis, const float* __restrict__ sigma_feat, const float* __restrict__ grad,
+    const float* __restrict__ d_sigma, const float* __restrict__ d_sigma_feat, const float* __restrict__ d_normal,
+    const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk, MPtrs3 g_apl, MPtrs3 g_ali) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int brick = blockIdx.x;
+    const int s = bin_off[brick], e = bin_off[brick + 1];
+    if (s == e) return;
+    const int G = p.grid;
+    const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
     const bool has_density = dpk.p[0] && (d_sigma || d_sigma_feat || d_normal);
-    if (has_density) {
-        // adjoint of the raw feature
-        float dsf = d_sigma_feat ? d_sigma_feat[m] : 0.f;
-        if (d_sigma) {
-            float f = sigma_feat[m];
-            float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
-            float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));             // softplus'
-            if (f < -15.f || f > 1e3f) ds = 0.f;                            // clamp'
-            dsf += d_sigma[m] * ds;
-        }
-        // adjoint of the raw gradient g (through n = -g / sqrt(max(|g|^2, eps)))
-        float dg[3] = {0.f, 0.f, 0.f};
-        if (d_normal) {
-            float g0 = grad[m * 3], g1 = grad[m * 3 + 1], g2 = grad[m * 3 + 2];
-            float dn0 = d_normal[m * 3], dn1 = d_normal[m * 3 + 1], dn2 = d_normal[m * 3 + 2];
-            float n2 = g0 * g0 + g1 * g1 + g2 * g2;
-            const float eps = 1.1920929e-07f;
-            float inv = 1.f / sqrtf(fmaxf(n2, eps));
-            // n = -g*inv ; d inv / d g = -g * inv^3 when n2 > eps else 0
-            float dot = dn0 * g0 + dn1 * g1 + dn2 * g2;
-            float k = n2 > eps ? dot * inv * inv * inv : 0.f;
-            dg[0] = -dn0 * inv + k * g0;
-            dg[1] = -dn1 * inv + k * g1;
-            dg[2] = -dn2 * inv + k * g2;
-            dg[0] *= p.inv_size[0]; dg[1] *= p.inv_size[1]; dg[2] *= p.inv_size[2];
-        }
+    const bool has_app = apl.p[0] && d_app;
+    float* l_dp = lds;
+    float* l_dl = l_dp + LDS_DP;
+    float* l_ap = l_dl + LDS_DL;
+    float* l_al = l_ap + LDS_AP;
+    for (int i = threadIdx.x; i < LDS_TOTAL; i += BWD_THREADS) lds[i] = 0.f;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // appearance: lane c (<24) keeps column (i*24+c) of basis_mat for the three planes
+    float Wc[3][AD];
+    if (has_app) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < AD; ++j) Wc[i][j] = lane < CA ? basis[j * (3 * CA) + i * CA + lane] : 0.f;
+    }
+    __syncthreads();
+
+    const int part = lane >> 4, ch = lane & 15;      // density lanes: part 0 = P, 1 = DX, 2 = DY
+    const int lane_dl = lane < DL ? lane : 0, lane_dp = lane < DP ? lane : 0, lane_a = lane < CA ? lane : 0;
+    for (int idx = s + wave; idx < e; idx += BWD_WAVES) {
+        const int m = __builtin_amdgcn_readfirstlane(perm[idx]);
+        float xn[3];
+        normalized(p, xyzt[m], xn);
+        // ---- footprints (wave-uniform).  Out-of-range taps are redirected to texel 0 / cell 0 with
+        // weight 0, so the whole sample is branch-free and all of its table reads are in flight at once
+        // (a per-tap branch + wait made this kernel latency-bound: ~40 serial round trips per sample).
+        Tap1 tl[3];
+        LTap2 tp[3];
+        int lcell[3][2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float dga = dg[MAT0[i]], dgb = dg[MAT1[i]], dgw = dg[VEC[i]];
-            const Tap1 tl = make_tap1(xn[VEC[i]], G);
-            const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
-            float Lc[CD], DLc[CD];
-#pragma unroll
-            for (int c = 0; c < CD; ++c) { Lc[c] = 0.f; DLc[c] = 0.f; }
+            tl[i] = make_tap1(xn[VEC[i]], G);
+            tp[i] = make_ltap2(xn[MAT0[i]], xn[MAT1[i]], G, org[MAT0[i]], org[MAT1[i]]);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if (tl.idx[t] < 0) continue;
-                float run[DL];
-                load_run<DL / 4>(dlk.p[i] + (int64_t)tl.idx[t] * DL, run);
-#pragma unroll
-                for (int c = 0; c < CD; ++c) { Lc[c] += tl.w[t] * run[c]; DLc[c] += tl.w[t] * run[CD + c]; }
+                const bool in = tl[i].idx[t] >= 0;
+                lcell[i][t] = in ? tl[i].idx[t] - org[VEC[i]] : 0;
+                tl[i].w[t] = in ? tl[i].w[t] : 0.f;
+                tl[i].idx[t] = in ? tl[i].idx[t] : 0;
             }
-            // line adjoints need the interpolated plane values; accumulate them while scattering the
-            // plane adjoints (which only need the line values)
-            float aL[CD], aDL[CD];
-#pragma unroll
-            for (int c = 0; c < CD; ++c) { aL[c] = 0.f; aDL[c] = 0.f; }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (tp.idx[t] < 0) continue;
-                const int64_t off = (int64_t)tp.idx[t] * DP;
-                float run[DP];
-                load_run<DP / 4>(dpk.p[i] + off, run);
-                float* gq = g_dpk.p[i] + off;
-                const float w = tp.w[t];
+                const bool in = tp[i].g[t] >= 0;
+                tp[i].w[t] = in ? tp[i].w[t] : 0.f;
+                tp[i].l[t] = in ? tp[i].l[t] : 0;
+                tp[i].g[t] = in ? tp[i].g[t] : 0;
+            }
+        }
+        // ---- issue every table read of this sample
+        float r_dl[3][2], r_dp[3][4], r_al[3][2], r_ap[3][4];
+        if (has_density) {
 #pragma unroll
-                for (int c = 0; c < CD; ++c) {
-                    aL[c] += w * (dsf * run[c] + dga * run[CD + c] + dgb * run[2 * CD + c]);
-                    aDL[c] += w * (dgw * run[c]);
-                    atomicAdd(gq + c, w * (dsf * Lc[c] + dgw * DLc[c]));
-                }
-                if (d_normal) {
+            for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                    for (int c = 0; c < CD; ++c) {
-                        atomicAdd(gq + CD + c, w * dga * Lc[c]);
-                        atomicAdd(gq + 2 * CD + c, w * dgb * Lc[c]);
-                    }
-                }
+                for (int t = 0; t < 2; ++t) r_dl[i][t] = dlk.p[i][(int64_t)tl[i].idx[t] * DL + lane_dl];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r_dp[i][t] = dpk.p[i][(int64_t)tp[i].g[t] * DP + lane_dp];
+            }
+        }
+        float da[AD];
+        if (has_app) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) r_al[i][t] = ali.p[i][(int64_t)tl[i].idx[t] * CA + lane_a];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r_ap[i][t] = apl.p[i][(int64_t)tp[i].g[t] * CA + lane_a];
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (tl.idx[t] < 0) continue;
-                float* gq = g_dlk.p[i] + (int64_t)tl.idx[t] * DL;
-                const float w = tl.w[t];
+            for (int j = 0; j < AD; ++j) da[j] = d_app[(int64_t)m * AD + j];     // uniform address
+        }
+        if (has_density) {
+            float dsf = d_sigma_feat ? d_sigma_feat[m] : 0.f;
+            if (d_sigma) {
+                float f = sigma_feat[m];
+                float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
+                float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));             // softplus'
+                if (f < -15.f || f > 1e3f) ds = 0.f;                            // clamp'
+                dsf += d_sigma[m] * ds;
+            }
+            float dg[3] = {0.f, 0.f, 0.f};
+            if (d_normal) {   // through n = -g / sqrt(max(|g|^2, eps))
+                float g0 = grad[m * 3], g1 = grad[m * 3 + 1], g2 = grad[m * 3 + 2];
+                float dn0 = d_normal[m * 3], dn1 = d_normal[m * 3 + 1], dn2 = d_normal[m * 3 + 2];
+                float n2 = g0 * g0 + g1 * g1 + g2 * g2;
+                const float eps = 1.1920929e-07f;
+                float inv = 1.f / sqrtf(fmaxf(n2, eps));
+                float dot = dn0 * g0 + dn1 * g1 + dn2 * g2;
+                float k = n2 > eps ? dot * inv * inv * inv : 0.f;
+                dg[0] = (-dn0 * inv + k * g0) * p.inv_size[0];
+                dg[1] = (-dn1 * inv + k * g1) * p.inv_size[1];
+                dg[2] = (-dn2 * inv + k * g2) * p.inv_size[2];
+            }
 #pragma unroll
-                for (int c = 0; c < CD; ++c) atomicAdd(gq + c, w * aL[c]);
-                if (d_normal) {
+            for (int i = 0; i < 3; ++i) {
+                const float dga = dg[MAT0[i]], dgb = dg[MAT1[i]], dgw = dg[VEC[i]];
+                // line: lanes 0..31 = (L | DL)
+                const float lv = tl[i].w[0] * r_dl[i][0] + tl[i].w[1] * r_dl[i][1];
+                const float Lc = __shfl(lv, ch, 64), DLc = __shfl(lv, CD + ch, 64);
+                // plane: lanes 0..47 = (P | DX | DY); adjoint of the table entry this lane owns
+                const float coefL = part == 0 ? (dsf * Lc + dgw * DLc) : (part == 1 ? dga * Lc : dgb * Lc);
+                float q = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CD; ++c) atomicAdd(gq + CD + c, w * aDL[c]);
+                for (int t = 0; t < 4; ++t) q += tp[i].w[t] * r_dp[i][t];
+                if (lane < DP) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        atomicAdd(l_dp + (i * TL * TL + tp[i].l[t]) * DP + lane, tp[i].w[t] * coefL);
+                }
+                // line adjoints: aL_c = dsf P_c + dga DX_c + dgb DY_c (lanes 0..15), aDL_c = dgw P_c (lanes 16..31)
+                const float q1 = __shfl(q, (lane + CD) & 63, 64), q2 = __shfl(q, (lane + 2 * CD) & 63, 64);
+                const float qm = __shfl(q, (lane - CD) & 63, 64);
+                const float la = lane < CD ? (dsf * q + dga * q1 + dgb * q2) : dgw * qm;
+                if (lane < DL) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        atomicAdd(l_dl + (i * TL + lcell[i][t]) * DL + lane, tl[i].w[t] * la);
+                }
+            }
+        }
+        if (has_app) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float dcoef = 0.f;
+#pragma unroll
+                for (int j = 0; j < AD; ++j) dcoef += Wc[i][j] * da[j];
+                const float La = tl[i].w[0] * r_al[i][0] + tl[i].w[1] * r_al[i][1];
+                float pa = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pa += tp[i].w[t] * r_ap[i][t];
+                if (lane < CA) {
+                    const float ap_adj = dcoef * La, al_adj = pa * dcoef;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        atomicAdd(l_ap + (i * TL * TL + tp[i].l[t]) * CA + lane, tp[i].w[t] * ap_adj);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        atomicAdd(l_al + (i * TL + lcell[i][t]) * CA + lane, tl[i].w[t] * al_adj);
                 }
             }
         }
     }
+    __syncthreads();
 
-    if (apl.p[0] && d_app) {
-        float da[AD];
-        load_run<AD / 4>(d_app + m * AD, da);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float dcoef[CA];
-#pragma unroll
-            for (int c = 0; c < CA; ++c) dcoef[c] = 0.f;
-#pragma unroll
-            for (int j = 0; j < AD; ++j) {
-                const float* wrow = basis + j * (3 * CA) + i * CA;
-#pragma unroll
-                for (int c = 0; c < CA; ++c) dcoef[c] += wrow[c] * da[j];
-            }
-            const Tap1 tl = make_tap1(xn[VEC[i]], G);
-            const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
-            float La[CA];
-#pragma unroll
-            for (int c = 0; c < CA; ++c) La[c] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (tl.idx[t] < 0) continue;
-                float run[CA];
-                load_run<CA / 4>(ali.p[i] + (int64_t)tl.idx[t] * CA, run);
-#pragma unroll
-                for (int c = 0; c < CA; ++c) La[c] += tl.w[t] * run[c];
-            }
-            float aLa[CA];
-#pragma unroll
-            for (int c = 0; c < CA; ++c) aLa[c] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (tp.idx[t] < 0) continue;
-                const int64_t off = (int64_t)tp.idx[t] * CA;
-                float run[CA];
-                load_run<CA / 4>(apl.p[i] + off, run);
-                float* gq = g_apl.p[i] + off;
-                const float w = tp.w[t];
-#pragma unroll
-                for (int c = 0; c < CA; ++c) {
-                    aLa[c] += w * run[c] * dcoef[c];
-                    atomicAdd(gq + c, w * dcoef[c] * La[c]);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (tl.idx[t] < 0) continue;
-                float* gq = g_ali.p[i] + (int64_t)tl.idx[t] * CA;
-#pragma unroll
-                for (int c = 0; c < CA; ++c) atomicAdd(gq + c, tl.w[t] * aLa[c]);
-            }
+    // flush the non-zero entries (tiles of neighbouring bricks overlap on their halo -> atomics)
+    if (has_density) {
+        for (int k = threadIdx.x; k < LDS_DP; k += BWD_THREADS) {
+            const float v = l_dp[k];
+            if (v == 0.f) continue;
+            const int c = k % DP, cell = (k / DP) % (TL * TL), i = k / (DP * TL * TL);
+            const int X = org[MAT0[i]] + cell % TL, Y = org[MAT1[i]] + cell / TL;
+            if (X < G && Y < G) atomicAdd(g_dpk.p[i] + ((int64_t)Y * G + X) * DP + c, v);
+        }
+        for (int k = threadIdx.x; k < LDS_DL; k += BWD_THREADS) {
+            const float v = l_dl[k];
+            if (v == 0.f) continue;
+            const int c = k % DL, cell = (k / DL) % TL, i = k / (DL * TL);
+            const int Z = org[VEC[i]] + cell;
+            if (Z < G) atomicAdd(g_dlk.p[i] + (int64_t)Z * DL + c, v);
+        }
+    }
+    if (has_app) {
+        for (int k = threadIdx.x; k < LDS_AP; k += BWD_THREADS) {
+            const float v = l_ap[k];
+            if (v == 0.f) continue;
+            const int c = k % CA, cell = (k / CA) % (TL * TL), i = k / (CA * TL * TL);
+            const int X = org[MAT0[i]] + cell % TL, Y = org[MAT1[i]] + cell / TL;
+            if (X < G && Y < G) atomicAdd(g_apl.p[i] + ((int64_t)Y * G + X) * CA + c, v);
+        }
+        for (int k = threadIdx.x; k < LDS_AL; k += BWD_THREADS) {
+            const float v = l_al[k];
+            if (v == 0.f) continue;
+            const int c = k % CA, cell = (k / CA) % TL, i = k / (CA * TL);
+            const int Z = org[VEC[i]] + cell;
+            if (Z < G) atomicAdd(g_ali.p[i] + (int64_t)Z * CA + c, v);
         }
     }
 }
@@ -536,16 +692,23 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
     return NMF_OK;
 }
 
+extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
+    const int64_t nbx = (grid + BR - 1) / BR;
+    const int64_t nb = nbx * nbx * nbx;
+    return (2 * M + 3 * (nb + 1)) * (int64_t)sizeof(int32_t);
+}
+
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
                                 const float* const dlk[3], const float* const app_planes[3],
                                 const float* const app_lines[3], const float* basis, const float* sigma_feat,
                                 const float* grad, const float* d_sigma, const float* d_sigma_feat,
                                 const float* d_normal, const float* d_app, float* const g_dpk[3],
                                 float* const g_dlk[3], float* const g_app_planes[3], float* const g_app_lines[3],
-                                void* stream) {
+                                void* workspace, int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: params");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(xyzt, NMF_EINVAL, "nmf_vm_query_bwd: xyzt null");
+    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_bwd: M >= 2^31");
     const bool want_d = d_sigma || d_sigma_feat || d_normal;
     const bool want_a = d_app != nullptr;
     NMF_REQUIRE(!want_d || (all3(dpk) && all3(dlk) && all3m(g_dpk) && all3m(g_dlk)), NMF_EINVAL,
@@ -554,12 +717,34 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     NMF_REQUIRE(!d_normal || grad, NMF_EINVAL, "nmf_vm_query_bwd: d_normal needs saved grad");
     NMF_REQUIRE(!want_a || (all3(app_planes) && all3(app_lines) && basis && all3m(g_app_planes) && all3m(g_app_lines)),
                 NMF_EINVAL, "nmf_vm_query_bwd: appearance tables missing");
-    hipLaunchKernelGGL(k_vm_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                       (const float4*)xyzt, M, want_d ? mk(dpk) : mk(nullptr), want_d ? mk(dlk) : mk(nullptr),
-                       want_a ? mk(app_planes) : mk(nullptr), want_a ? mk(app_lines) : mk(nullptr), basis, sigma_feat,
-                       grad, d_sigma, d_sigma_feat, d_normal, d_app, want_d ? mkm(g_dpk) : mkm(nullptr),
-                       want_d ? mkm(g_dlk) : mkm(nullptr), want_a ? mkm(g_app_planes) : mkm(nullptr),
-                       want_a ? mkm(g_app_lines) : mkm(nullptr));
+    NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
+                "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
+    if (!want_d && !want_a) return NMF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (p->grid + BR - 1) / BR;
+    const int nb = nbx * nbx * nbx;
+    int32_t* ws = (int32_t*)workspace;
+    int32_t* brick_id = ws;            // [M]
+    int32_t* perm = ws + M;            // [M]
+    int32_t* counts = ws + 2 * M;      // [nb+1]
+    int32_t* offsets = counts + nb + 1;   // [nb+1]
+    int32_t* cursor = offsets + nb + 1;   // [nb+1]
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1), st);
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
+    hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt, M, nbx,
+                       counts, brick_id);
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor);
+    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, brick_id, M, cursor, perm);
+    // 76 KB of dynamic LDS per workgroup (> the 64 KB default cap)
+    e = hipFuncSetAttribute((const void*)k_vm_bwd_brick, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(LDS_TOTAL * sizeof(float)));
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: hipFuncSetAttribute");
+    hipLaunchKernelGGL(k_vm_bwd_brick, dim3((unsigned)nb), dim3(BWD_THREADS), LDS_TOTAL * sizeof(float), st, *p,
+                       (const float4*)xyzt, perm, offsets, nbx, want_d ? mk(dpk) : mk(nullptr),
+                       want_d ? mk(dlk) : mk(nullptr), want_a ? mk(app_planes) : mk(nullptr),
+                       want_a ? mk(app_lines) : mk(nullptr), basis, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal,
+                       d_app, want_d ? mkm(g_dpk) : mkm(nullptr), want_d ? mkm(g_dlk) : mkm(nullptr),
+                       want_a ? mkm(g_app_planes) : mkm(nullptr), want_a ? mkm(g_app_lines) : mkm(nullptr));
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }

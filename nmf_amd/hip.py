@@ -49,13 +49,14 @@ class VmParams(C.Structure):
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
-    "nmf_vm_unpack_density_grad", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
+    "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
         raise NmfHipError(f"libnmf_hip.so does not export {_n}")
 _lib.nmf_last_error_string.restype = C.c_char_p
 _lib.nmf_version.restype = C.c_int
+_lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
 
 
 def version():
@@ -232,6 +233,8 @@ def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, gr
     M = xyzt.shape[0]
     want_d = d_sigma is not None or d_sigma_feat is not None or d_normal is not None
     want_a = d_app is not None
+    nbytes = _lib.nmf_vm_bwd_workspace_bytes(C.c_int64(M), C.c_int32(p.grid))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=xyzt.device)
     _check(_lib.nmf_vm_query_bwd(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M),
                                  _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
                                  _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
@@ -239,7 +242,7 @@ def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, gr
                                  _p(d_sigma_feat), _p(d_normal), _p(d_app),
                                  _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
                                  _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
-                                 _stream()), "nmf_vm_query_bwd")
+                                 _p(ws), C.c_int64(nbytes), _stream()), "nmf_vm_query_bwd")
 
 
 def vm_unpack_density_grad(p, g_dpk, g_dlk):
