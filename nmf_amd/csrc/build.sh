@@ -12,7 +12,7 @@ for f in "$here"/*.hip; do
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$here/common.hpp" -nt "$o" ] || [ "$here/../../include/nmf_hip.h" -nt "$o" ]; then
     extra=""
     # bookkeeping kernels must reproduce the CPU oracle bit-for-bit: no a*b+c -> fma contraction there
-    case "$(basename "$f")" in march.hip|select.hip|composite.hip) extra="-ffp-contract=off" ;; esac
+    case "$(basename "$f")" in march.hip|select.hip|composite.hip|env.hip) extra="-ffp-contract=off" ;; esac
     "$HIPCC" $FLAGS $extra -c "$f" -o "$o" &
   fi
   objs+=("$o")

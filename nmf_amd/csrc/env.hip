@@ -1,0 +1,470 @@
+// Prefiltered equirectangular environment map for gfx950: summed-area-table build, box lookup with
+// seam / pole wrapping, and the backward of both.
+// Replaces IntegralEquirect.forward / sa2mip / integrate_area* of the reference
+// (modules/integral_equirect.py:18-173, 373-504) and safemath.atan2 (modules/safemath.py:8-30).
+//
+// Numerics: the reference's fp32 SAT differences cancel catastrophically, so parity
+// needs the oracle's exact rounding: prefix sums carry a float64 running value rounded to fp32 per
+// element (H first, then W), the bilinear tap sum is ATen's fma chain nw,ne,sw,se and the four corner
+// samples combine as (tr + bl - tl - br) / size.  This file is compiled with -ffp-contract=off and
+// spells every fma explicitly.
+//
+// Backward: the table gradient is a scatter of +-weights into dSAT followed by two reverse prefix
+// sums; the gradient wrt the lookup direction and mipbias is obtained by running the SAME templated
+// forward on forward-mode dual numbers (4 tangents), which keeps the wrap/clip branch structure
+// identical to the forward by construction.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+constexpr float LN2_F = 0.69314718055994530942f;
+constexpr float EPS_F = 1.1920929e-07f;
+
+// ---- forward-mode dual number with N tangents -------------------------------------------------
+template <int N>
+struct Dual {
+    float v;
+    float d[N];
+};
+template <int N> __device__ __forceinline__ Dual<N> mk_const(float v) { Dual<N> r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = 0.f; return r; }
+
+__device__ __forceinline__ float val(float a) { return a; }
+template <int N> __device__ __forceinline__ float val(const Dual<N>& a) { return a.v; }
+
+#define DUAL_BIN(op, expr_v, expr_d)                                                                       \
+    template <int N> __device__ __forceinline__ Dual<N> op(const Dual<N>& a, const Dual<N>& b) {           \
+        Dual<N> r; r.v = expr_v;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) r.d[i] = expr_d; return r; }
+DUAL_BIN(operator+, a.v + b.v, a.d[i] + b.d[i])
+DUAL_BIN(operator-, a.v - b.v, a.d[i] - b.d[i])
+DUAL_BIN(operator*, a.v * b.v, a.d[i] * b.v + a.v * b.d[i])
+DUAL_BIN(operator/, a.v / b.v, (a.d[i] - (a.v / b.v) * b.d[i]) / b.v)
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, float b) { Dual<N> r = a; r.v = a.v + b; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, float b) { Dual<N> r = a; r.v = a.v - b; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(float a, const Dual<N>& b) { Dual<N> r; r.v = a - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = -b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& b) { return 0.f - b; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, float b) { Dual<N> r; r.v = a.v * b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(float b, const Dual<N>& a) { return a * b; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, float b) { Dual<N> r; r.v = a.v / b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / b; return r; }
+
+#define DUAL_UN(name, fv, fd)                                                       \
+    __device__ __forceinline__ float name(float a) { return fv; }                   \
+    template <int N> __device__ __forceinline__ Dual<N> name(const Dual<N>& A) {    \
+        const float a = A.v; Dual<N> r; r.v = fv; const float dv = fd;             \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) r.d[i] = A.d[i] * dv; return r; }
+DUAL_UN(d_sqrt, sqrtf(a), 0.5f / sqrtf(a))
+DUAL_UN(d_log, logf(a), 1.f / a)
+DUAL_UN(d_exp, expf(a), expf(a))
+DUAL_UN(d_pow2, powf(2.f, a), powf(2.f, a) * LN2_F)
+// clip: torch.clamp backward passes the gradient where min <= x <= max
+__device__ __forceinline__ float d_clipmin(float a, float lo) { return fmaxf(a, lo); }
+template <int N> __device__ __forceinline__ Dual<N> d_clipmin(const Dual<N>& a, float lo) { return a.v >= lo ? a : mk_const<N>(lo); }
+__device__ __forceinline__ float d_clip(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+template <int N> __device__ __forceinline__ Dual<N> d_clip(const Dual<N>& a, float lo, float hi) {
+    return a.v < lo ? mk_const<N>(lo) : (a.v > hi ? mk_const<N>(hi) : a); }
+// safemath.atan2: forward atan2(x, y); backward dx = g*y/(x^2+y^2+1e-5), dy = -g*x/(...)
+__device__ __forceinline__ float d_atan2(float x, float y) { return atan2f(x, y); }
+template <int N> __device__ __forceinline__ Dual<N> d_atan2(const Dual<N>& x, const Dual<N>& y) {
+    Dual<N> r; r.v = atan2f(x.v, y.v);
+    const float den = x.v * x.v + y.v * y.v + 1e-5f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (x.d[i] * y.v - y.d[i] * x.v) / den;
+    return r; }
+// torch.remainder(x, m) for m > 0 (derivative 1)
+__device__ __forceinline__ float d_rem(float a, float m) { float r = fmodf(a, m); if (r != 0.f && r < 0.f) r += m; return r; }
+template <int N> __device__ __forceinline__ Dual<N> d_rem(const Dual<N>& a, float m) { Dual<N> r = a; r.v = d_rem(a.v, m); return r; }
+template <class T> __device__ __forceinline__ T set_val(const T& like, float v);
+template <> __device__ __forceinline__ float set_val<float>(const float&, float v) { return v; }
+template <int N> __device__ __forceinline__ Dual<N> set_val(const Dual<N>&, float v) { return mk_const<N>(v); }
+
+struct EnvTab {
+    const float* sat;   // [3][H][W]
+    int H, W;
+};
+
+// bilinear sample of the SAT at normalised (x, y) in [-1,1] (already clipped): returns 3 channels.
+// ATen vectorised CPU kernel: ix = (x+1)*((W-1)/2); w = ix-floor; e = 1-w; nw=e*s ...;
+// out = fma(se_v,se, fma(sw_v,sw, fma(ne_v,ne, nw_v*nw)))
+template <class T>
+__device__ __forceinline__ void sat_sample(const EnvTab& t, const T& x, const T& y, T (&out)[3]) {
+    const T ix = (x + 1.f) * ((float)(t.W - 1) * 0.5f);
+    const T iy = (y + 1.f) * ((float)(t.H - 1) * 0.5f);
+    const float fx = floorf(val(ix)), fy = floorf(val(iy));
+    const T w = ix - fx, n = iy - fy;
+    const T e = 1.f - w, s = 1.f - n;
+    const T nw = e * s, ne = w * s, sw = e * n, se = w * n;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const bool xi0 = x0 >= 0 && x0 < t.W, xi1 = x0 + 1 >= 0 && x0 + 1 < t.W;
+    const bool yi0 = y0 >= 0 && y0 < t.H, yi1 = y0 + 1 >= 0 && y0 + 1 < t.H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = t.sat + (int64_t)c * t.H * t.W;
+        const float vnw = (xi0 && yi0) ? p[y0 * t.W + x0] : 0.f;
+        const float vne = (xi1 && yi0) ? p[y0 * t.W + x0 + 1] : 0.f;
+        const float vsw = (xi0 && yi1) ? p[(y0 + 1) * t.W + x0] : 0.f;
+        const float vse = (xi1 && yi1) ? p[(y0 + 1) * t.W + x0 + 1] : 0.f;
+        if constexpr (sizeof(T) == sizeof(float)) {
+            float r = vnw * nw;
+            r = fmaf(vne, ne, r);
+            r = fmaf(vsw, sw, r);
+            r = fmaf(vse, se, r);
+            out[c] = r;
+        } else {
+            out[c] = nw * vnw + ne * vne + sw * vsw + se * vse;
+        }
+    }
+}
+
+// scatter of the adjoint of sat_sample into dSAT (float path only)
+__device__ __forceinline__ void sat_scatter(float* dsat, int H, int W, float x, float y, const float (&g)[3]) {
+    const float ix = (x + 1.f) * ((float)(W - 1) * 0.5f);
+    const float iy = (y + 1.f) * ((float)(H - 1) * 0.5f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float w = ix - fx, n = iy - fy, e = 1.f - w, s = 1.f - n;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float* p = dsat + (int64_t)c * H * W;
+        if (xi0 && yi0) atomicAdd(p + y0 * W + x0, g[c] * (e * s));
+        if (xi1 && yi0) atomicAdd(p + y0 * W + x0 + 1, g[c] * (w * s));
+        if (xi0 && yi1) atomicAdd(p + (y0 + 1) * W + x0, g[c] * (e * n));
+        if (xi1 && yi1) atomicAdd(p + (y0 + 1) * W + x0 + 1, g[c] * (w * n));
+    }
+}
+
+template <class T>
+struct Rect {   // axis-aligned box in normalised coords
+    T x0, x1, y0, y1;   // left/right (bl.x, tr.x), bottom/top (bl.y, tr.y)
+};
+
+// Visitor pattern: `Acc` receives every (corner, sign) of every box that integrate_area_wrap adds.
+// integrate_area (:18-39): (S(tr) + S(bl) - S(tl) - S(br)) / size with corners clipped to [-1,1].
+template <class T, class Acc>
+__device__ __forceinline__ void box(const Rect<T>& r, Acc& acc) {
+    const T xl = d_clip(r.x0, -1.f, 1.f), xr = d_clip(r.x1, -1.f, 1.f);
+    const T yb = d_clip(r.y0, -1.f, 1.f), yt = d_clip(r.y1, -1.f, 1.f);
+    acc.begin();
+    acc.corner(xr, yt, 0);   // tr  (+)
+    acc.corner(xl, yb, 1);   // bl  (+)
+    acc.corner(xl, yt, 2);   // tl  (-)
+    acc.corner(xr, yb, 3);   // br  (-)
+    acc.end();
+}
+
+// integrate_area_wrap_lr (:42-93)
+template <class T, class Acc>
+__device__ __forceinline__ void box_lr(const Rect<T>& r, Acc& acc) {
+    box(r, acc);
+    if (val(r.x1) > 1.f) {
+        Rect<T> q = r;
+        q.x0 = set_val(r.x0, -1.f);
+        q.x1 = r.x1 - 2.f;
+        box(q, acc);
+    }
+    if (val(r.x0) < -1.f) {
+        Rect<T> q = r;
+        q.x0 = r.x0 + 2.f;
+        q.x1 = set_val(r.x1, 1.f);
+        box(q, acc);
+    }
+}
+
+// integrate_area_wrap (:96-173)
+template <class T, class Acc>
+__device__ __forceinline__ void box_wrap(const Rect<T>& r, Acc& acc) {
+    box_lr(r, acc);
+    if (val(r.y1) > 1.f) {            // tl.y > 1
+        const float rot = val(r.x0) > 0.f ? -1.f : 1.f;          // tl.x > 0
+        const T over = d_clip(r.y1 - 1.f, 0.f, 0.5f);
+        Rect<T> q;
+        q.x0 = r.x0 + rot; q.x1 = r.x1 + rot;
+        q.y1 = set_val(r.y1, 1.f);
+        q.y0 = 1.f - over;
+        box_lr(q, acc);
+    }
+    if (val(r.y0) < -1.f) {           // bl.y < -1
+        const float rot = val(r.x0) > 0.f ? -1.f : 1.f;
+        const T over = d_clip(-1.f - r.y0, 0.f, 0.5f);
+        Rect<T> q;
+        q.x0 = r.x0 + rot; q.x1 = r.x1 + rot;
+        q.y0 = set_val(r.y0, -1.f);
+        q.y1 = over - 1.f;            // -1 + over
+        box_lr(q, acc);
+    }
+}
+
+template <class T>
+struct Geometry {
+    Rect<T> rect;
+    T size;
+    float cy;    // latitude coordinate (pole test)
+};
+
+// sa2mip (:373-397) + forward (:409-480) up to the box corners
+template <class T>
+__device__ __forceinline__ Geometry<T> env_geometry(int H, int W, const T& a, const T& b, const T& c, float sa,
+                                                    const T& mipbias) {
+    const float h = (float)H;
+    const T cosv = d_sqrt(d_clipmin(1.f - c * c, EPS_F));
+    // h*w / x is int.__truediv__(tensor) == reciprocal(x) * (h*w)   (h*w is a power of two here)
+    const T den = d_clipmin(cosv * 19.739208802178716f, EPS_F);   // 2*math.pi**2 as fp32
+    const T d = (set_val(den, 1.f) / den) * (float)(H * W);
+    const T area = d_exp(d_log(d / 2.f) + sa);
+    const T hh = d_clipmin(d_sqrt(d_clipmin(area, EPS_F)) * cosv, EPS_F);
+    const T ww = area / hh;
+    const T mw = d_clip(d_log(ww) / LN2_F + mipbias, 0.f, 7.f);
+    const T mh = d_clip(d_log(hh) / LN2_F + mipbias, 0.f, 7.f);
+    const T sw = d_pow2(mw) / h / 2.f;
+    const T sh = d_pow2(mh) / h;
+    Geometry<T> g;
+    g.size = ((sw / 2.f) * (float)W) * ((sh / 2.f) * h);
+    const T norm2d = d_sqrt(a * a + b * b);
+    const T phi = d_atan2(b, a);
+    const T theta = d_atan2(c, norm2d);
+    const T cx = (d_rem(phi, TWO_PI_F) - PI_F) / PI_F;
+    const T cy = ((-theta) / PI_F) * 2.f;
+    g.cy = val(cy);
+    g.rect.x0 = cx - sw / 2.f; g.rect.x1 = cx + sw / 2.f;
+    g.rect.y0 = cy - sh / 2.f; g.rect.y1 = cy + sh / 2.f;
+    return g;
+}
+
+// ---- accumulators ----------------------------------------------------------------------------
+template <class T>
+struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL size
+    EnvTab tab;
+    T size;
+    T total[3];
+    T cur[3];
+    __device__ void begin() {}
+    __device__ void corner(const T& x, const T& y, int k) {
+        T s[3];
+        sat_sample(tab, x, y, s);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (k == 0) cur[c] = s[c];
+            else if (k == 1) cur[c] = cur[c] + s[c];
+            else cur[c] = cur[c] - s[c];
+        }
+    }
+    __device__ void end() {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) total[c] = total[c] + cur[c] / size;
+    }
+};
+
+struct ScatterAcc {   // table adjoint
+    float* dsat;
+    int H, W;
+    float g[3];       // d_vals * 1000 / size
+    __device__ void begin() {}
+    __device__ void corner(float x, float y, int k) {
+        const float sgn = k < 2 ? 1.f : -1.f;
+        const float gg[3] = {sgn * g[0], sgn * g[1], sgn * g[2]};
+        sat_scatter(dsat, H, W, x, y, gg);
+    }
+    __device__ void end() {}
+};
+
+// ---- kernels -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs,
+                                                        const float* __restrict__ sa, int64_t R, float mipbias,
+                                                        const float* __restrict__ pole_rows /*[2][3] top,bot*/,
+                                                        float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
+    Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
+    SumAcc<float> acc;
+    acc.tab = tab;
+    acc.size = g.size;
+    acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
+    box_wrap(g.rect, acc);
+    const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
+    float v[3] = {acc.total[0] * 1000.f, acc.total[1] * 1000.f, acc.total[2] * 1000.f};
+    if (g.cy > cutoff) { v[0] = pole_rows[3]; v[1] = pole_rows[4]; v[2] = pole_rows[5]; }
+    if (g.cy < -cutoff) { v[0] = pole_rows[0]; v[1] = pole_rows[1]; v[2] = pole_rows[2]; }
+    out[r * 3] = v[0]; out[r * 3 + 1] = v[1]; out[r * 3 + 2] = v[2];
+}
+
+__global__ void __launch_bounds__(256) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs,
+                                                        const float* __restrict__ sa, int64_t R, float mipbias,
+                                                        const float* __restrict__ d_out, float* __restrict__ d_sat,
+                                                        float* __restrict__ d_pole /*[2][3]*/,
+                                                        float* __restrict__ d_dirs, float* __restrict__ d_mipbias) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float dm = 0.f;
+    if (r < R) {
+        const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
+        const float go[3] = {d_out[r * 3], d_out[r * 3 + 1], d_out[r * 3 + 2]};
+        Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
+        const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
+        const bool bot = g.cy > cutoff, top = g.cy < -cutoff;
+        if (top || bot) {
+            // value = mean of a pole row of the activated map: no dependence on dirs / mipbias
+            float* q = d_pole + (top ? 0 : 3);
+            atomicAdd(q, go[0]); atomicAdd(q + 1, go[1]); atomicAdd(q + 2, go[2]);
+            if (d_dirs) { d_dirs[r * 3] = 0.f; d_dirs[r * 3 + 1] = 0.f; d_dirs[r * 3 + 2] = 0.f; }
+        } else {
+            if (d_sat) {
+                ScatterAcc sacc;
+                sacc.dsat = d_sat; sacc.H = tab.H; sacc.W = tab.W;
+                const float k = 1000.f / g.size;
+                sacc.g[0] = go[0] * k; sacc.g[1] = go[1] * k; sacc.g[2] = go[2] * k;
+                box_wrap(g.rect, sacc);
+            }
+            if (d_dirs || d_mipbias) {
+                typedef Dual<4> D;
+                D da = mk_const<4>(a), db = mk_const<4>(b), dc = mk_const<4>(c), dmb = mk_const<4>(mipbias);
+                da.d[0] = 1.f; db.d[1] = 1.f; dc.d[2] = 1.f; dmb.d[3] = 1.f;
+                Geometry<D> gd = env_geometry<D>(tab.H, tab.W, da, db, dc, sa[r], dmb);
+                SumAcc<D> acc;
+                acc.tab = tab;
+                acc.size = gd.size;
+                acc.total[0] = acc.total[1] = acc.total[2] = mk_const<4>(0.f);
+                box_wrap(gd.rect, acc);
+                float gsum[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gsum[i] = 1000.f * (go[0] * acc.total[0].d[i] + go[1] * acc.total[1].d[i] + go[2] * acc.total[2].d[i]);
+                if (d_dirs) { d_dirs[r * 3] = gsum[0]; d_dirs[r * 3 + 1] = gsum[1]; d_dirs[r * 3 + 2] = gsum[2]; }
+                dm = gsum[3];
+            }
+        }
+    }
+    if (d_mipbias) {   // wave reduction, one atomic per wave
+        for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
+        if (lane_id() == 0 && dm != 0.f) atomicAdd(d_mipbias, dm);
+    }
+}
+
+// activation + prefix sum down H: one lane per (channel, column), float64 running sum
+__global__ void __launch_bounds__(256) k_sat_cols(const float* __restrict__ bg, int H, int W, float brightness,
+                                                  float mul, float* __restrict__ act, float* __restrict__ sat) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * W) return;
+    const int c = t / W, x = t % W;
+    double run = 0.0;
+    for (int y = 0; y < H; ++y) {
+        const int64_t i = ((int64_t)c * H + y) * W + x;
+        const float a = expf(fminf(brightness + mul * bg[i], 20.f));     // activation_fn, :263-273
+        act[i] = a;
+        run += (double)(a / 1000.f);                                     // :432-433
+        sat[i] = (float)run;
+    }
+}
+
+// prefix sum across W, in place: one wave per (channel, row)
+__global__ void __launch_bounds__(256) k_sat_rows(float* __restrict__ sat, int H, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 3 * H) return;
+    const int lane = lane_id();
+    float* p = sat + (int64_t)row * W;
+    double carry = 0.0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const double v = x < W ? (double)p[x] : 0.0;
+        const double incl = wave_incl_scan(v);
+        if (x < W) p[x] = (float)(carry + incl);
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+// backward of the build: d_act = reverse-cumsum_H(reverse-cumsum_W(dSAT)) / 1000 (+ pole-row means);
+// d_bg = d_act * act * mul where the exp argument is not clipped.
+__global__ void __launch_bounds__(256) k_sat_rows_rev(float* __restrict__ dsat, int H, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= 3 * H) return;
+    const int lane = lane_id();
+    float* p = dsat + (int64_t)row * W;
+    double carry = 0.0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = W - 1 - (x0 + lane);
+        const double v = x >= 0 ? (double)p[x] : 0.0;
+        const double incl = wave_incl_scan(v);
+        if (x >= 0) p[x] = (float)(carry + incl);
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sat_cols_rev(const float* __restrict__ dsat, const float* __restrict__ bg,
+                                                      const float* __restrict__ act, int H, int W, float brightness,
+                                                      float mul, const float* __restrict__ d_pole,
+                                                      float* __restrict__ d_bg) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * W) return;
+    const int c = t / W, x = t % W;
+    double run = 0.0;
+    for (int y = H - 1; y >= 0; --y) {
+        const int64_t i = ((int64_t)c * H + y) * W + x;
+        run += (double)dsat[i];
+        float da = (float)run / 1000.f;
+        if (d_pole && y == 0) da += d_pole[c] / (float)W;
+        if (d_pole && y == H - 1) da += d_pole[3 + c] / (float)W;
+        const bool clipped = (brightness + mul * bg[i]) > 20.f;
+        d_bg[i] = clipped ? 0.f : da * act[i] * mul;
+    }
+}
+
+}  // namespace
+
+extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul, float* activated,
+                             float* sat, void* stream) {
+    NMF_REQUIRE(bg_mat && activated && sat && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build: null/size");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sat_cols, dim3((unsigned)cdiv(3 * W, 256)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
+                       activated, sat);
+    hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W);
+    NMF_CHECK_LAUNCH("nmf_sat_build");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float* activated, int32_t H, int32_t W,
+                                 float brightness, float mul, const float* d_pole, float* d_bg, void* stream) {
+    NMF_REQUIRE(d_sat && bg_mat && activated && d_bg && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build_bwd: null/size");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sat_rows_rev, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, d_sat, H, W);
+    hipLaunchKernelGGL(k_sat_cols_rev, dim3((unsigned)cdiv(3 * W, 256)), dim3(256), 0, st, d_sat, bg_mat, activated, H,
+                       W, brightness, mul, d_pole, d_bg);
+    NMF_CHECK_LAUNCH("nmf_sat_build_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
+                                  int64_t R, float mipbias, const float* pole_rows, float* out, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_fwd: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(sat && dirs && sa && pole_rows && out, NMF_EINVAL, "nmf_sat_lookup_fwd: null");
+    EnvTab tab{sat, H, W};
+    hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs, sa,
+                       R, mipbias, pole_rows, out);
+    NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
+                                  int64_t R, float mipbias, const float* d_out, float* d_sat, float* d_pole,
+                                  float* d_dirs, float* d_mipbias, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
+    EnvTab tab{sat, H, W};
+    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs, sa,
+                       R, mipbias, d_out, d_sat, d_pole, d_dirs, d_mipbias);
+    NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
+    return NMF_OK;
+}

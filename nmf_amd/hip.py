@@ -50,6 +50,7 @@ EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
+    "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -281,3 +282,47 @@ def segment_sum(vals, scale, offsets, n_seg):
     _check(_lib.nmf_segment_sum(_p(vals, torch.float32), _p(scale), _p(offsets, torch.int64), C.c_int64(n_seg),
                                 C.c_int32(D), _p(out), _stream()), "nmf_segment_sum")
     return out
+
+
+# ---- environment map ---------------------------------------------------------------------------
+def sat_build(bg_mat, brightness=0.0, mul=1.0):
+    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W]."""
+    bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
+    H, W = bg.shape[-2:]
+    act = torch.empty_like(bg)
+    sat = torch.empty_like(bg)
+    _check(_lib.nmf_sat_build(_p(bg.contiguous(), torch.float32), C.c_int32(H), C.c_int32(W), C.c_float(brightness),
+                              C.c_float(mul), _p(act), _p(sat), _stream()), "nmf_sat_build")
+    return act, sat
+
+
+def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0):
+    bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
+    H, W = bg.shape[-2:]
+    d_bg = torch.empty_like(bg)
+    _check(_lib.nmf_sat_build_bwd(_p(d_sat, torch.float32), _p(bg.contiguous(), torch.float32), _p(act), C.c_int32(H),
+                                  C.c_int32(W), C.c_float(brightness), C.c_float(mul), _p(d_pole), _p(d_bg), _stream()),
+           "nmf_sat_build_bwd")
+    return d_bg
+
+
+def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows):
+    R = dirs.shape[0]
+    H, W = sat.shape[-2:]
+    out = torch.empty((R, 3), dtype=torch.float32, device=dirs.device)
+    _check(_lib.nmf_sat_lookup_fwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
+                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(pole_rows), _p(out),
+                                   _stream()), "nmf_sat_lookup_fwd")
+    return out
+
+
+def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, want_dirs=True, want_mipbias=True):
+    R = dirs.shape[0]
+    H, W = sat.shape[-2:]
+    d_dirs = torch.empty((R, 3), dtype=torch.float32, device=dirs.device) if want_dirs else None
+    d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device) if want_mipbias else None
+    _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
+                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias),
+                                   _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
+                                   _stream()), "nmf_sat_lookup_bwd")
+    return d_dirs, d_mip

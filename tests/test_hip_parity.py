@@ -272,3 +272,93 @@ def test_composite_empty_and_long_segments():
     # alpha = 1 - exp(-x): one ulp of expf (GPU vs CPU libm) is 6e-8 absolute on alpha
     assert_close(w.cpu(), wo[mask], rtol=5e-6, atol=2e-7, what="weights")
     assert float(acc[7]) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+def _env_sd(bg):
+    return {"bg_module.bg_mat": bg, "bg_module.mipbias": torch.tensor(1.0, dtype=torch.float64),
+            "bg_module.brightness": torch.tensor(0.0, dtype=torch.float64),
+            "bg_module.mul": torch.tensor(1.0, dtype=torch.float64)}
+
+
+def _env_lookup_gpu(hip, bg, dirs, sa, mipbias=1.0):
+    act, sat = hip.sat_build(bg.to(DEV))
+    pole = torch.stack([act[:, 0, :].mean(-1), act[:, -1, :].mean(-1)]).contiguous()
+    vals = hip.sat_lookup_fwd(sat, dirs.to(DEV).contiguous(), sa.to(DEV).contiguous(), mipbias, pole)
+    return act, sat, pole, vals
+
+
+@pytest.mark.parametrize("H", [32, 512])
+def test_env_sat_build_matches_cpu_rounding(H):
+    hip = _hip()
+    gen = torch.Generator().manual_seed(H)
+    bg = -0.6 + 0.7 * torch.randn(1, 3, H, 2 * H, generator=gen)
+    act, sat = hip.sat_build(bg.to(DEV))
+    sd = _env_sd(bg)
+    act_o = O.env_activation(sd)[0]
+    assert_close(act.cpu(), act_o, rtol=2e-7, atol=0, what="activated")          # <= 1 ulp (GPU vs CPU expf)
+    # scan arithmetic itself must be bit exact: feed the oracle's scan the GPU's activation
+    sat_o = torch.cumsum(torch.cumsum(act.cpu()[None] / 1000, dim=2), dim=3)[0]
+    assert torch.equal(sat.cpu(), sat_o), "prefix sums do not reproduce the float64-accumulate/round-per-element order"
+    # and against the all-CPU table only rounding flips caused by 1-ulp exp differences remain
+    sat_ref = O.env_sat(sd)[0]
+    frac = float((sat.cpu() != sat_ref).float().mean())
+    assert frac < 0.05, frac
+    assert_close(sat.cpu(), sat_ref, rtol=3e-7, atol=0, what="sat vs cpu")
+
+
+def test_env_lookup_golden_and_gradients():
+    hip = _hip()
+    g = Golden("env")
+    bg, dirs, sa = g["bg_mat"], g["dirs"], g["sa"]
+    act, sat, pole, vals = _env_lookup_gpu(hip, bg, dirs, sa)
+    sd = _env_sd(bg.clone().requires_grad_(True))
+    sd["bg_module.mipbias"] = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+    d_or = dirs.clone().requires_grad_(True)
+    # (1) same table in, same numbers out: the oracle evaluated ON THE GPU-BUILT SAT
+    vals_o = O.env_lookup(sd, d_or, sa, sat=sat.cpu()[None]).detach()
+    # A box value is (S(tr)+S(bl)-S(tl)-S(br))*1000/size: four fp32 interpolations of magnitude |SAT|
+    # cancel, so ANY last-bit difference in the corner coordinates (GPU vs CPU atan2/log/pow) moves
+    # the result by a few ulp(|SAT|)*1000/size -- the reference's own conditioning.
+    mw, mh = O.env_mip_levels(sd, dirs, sa)
+    H = bg.shape[-2]
+    size = (((2 ** mw / H / 2) / 2 * (2 * H)) * ((2 ** mh / H) / 2 * H)).detach().float()
+    noise = (8 * 1.2e-7 * float(sat.abs().max()) * 1000 / size)[:, None]
+    err = (vals.cpu() - vals_o).abs()
+    assert bool((err <= 2e-5 * vals_o.abs() + noise).all()), float((err - noise).max())
+    wide = size > 16
+    assert int(wide.sum()) > 100
+    assert_close(vals.cpu()[wide], vals_o[wide], rtol=2e-4, atol=2e-5, what="wide lookups on identical SAT")
+    # (2) against the reference's own output (CPU-built SAT: ~1% of entries differ by 1 ulp through expf)
+    ref = g["vals"]
+    err = (vals.cpu() - ref).abs()
+    assert bool((err <= 1e-4 * ref.abs() + 4 * noise).all()), float((err - 4 * noise).max())
+    assert_close(vals.cpu()[wide], ref[wide], rtol=1e-3, atol=1e-4, what="wide lookups vs reference")
+    # (3) gradients (table, mipbias, directions) vs autograd of the oracle on the same SAT
+    c = g["c"]
+    gb_o, gm_o, gd_o = torch.autograd.grad((O.env_lookup(sd, d_or, sa) * c).sum(),
+                                           [sd["bg_module.bg_mat"], sd["bg_module.mipbias"], d_or])
+    d_sat = torch.zeros_like(sat)
+    d_pole = torch.zeros(2, 3, device=DEV)
+    d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs.to(DEV).contiguous(), sa.to(DEV).contiguous(), 1.0, c.to(DEV), d_sat, d_pole)
+    d_bg = hip.sat_build_bwd(d_sat, bg.to(DEV), act, d_pole)
+    assert_close(d_bg.cpu()[None], gb_o, rtol=2e-3, atol=2e-4 * float(gb_o.abs().max()), what="grad bg_mat")
+    assert_close(d_dirs.cpu(), gd_o, rtol=5e-3, atol=5e-4 * float(gd_o.abs().max()), what="grad dirs")
+    assert abs(float(d_mip) - float(gm_o)) <= 5e-3 * abs(float(gm_o)) + 1e-5, (float(d_mip), float(gm_o))
+
+
+def test_env_lookup_full_size_properties():
+    """512x1024 map: constant map integrates to the constant for every direction / footprint, and
+    the lookup is linear in the table (size-independent properties at BASELINE size)."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(1)
+    R = 200000
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    sa = torch.rand(R, generator=gen) * 12 - 10
+    const = torch.full((1, 3, 512, 1024), -0.6)
+    _, _, _, v = _env_lookup_gpu(hip, const, dirs, sa)
+    # the box is measured in (W-1)x(H-1) texel units but normalised by W*H (integral_equirect.py:438-442)
+    target = float(torch.exp(torch.tensor(-0.6))) * (511 / 512) * (1023 / 1024)
+    big = sa > -4        # wide footprints: cancellation noise is small
+    assert float((v.cpu()[big] - target).abs().max()) < 2e-2 * target
+    assert abs(float(v.cpu()[big].mean()) - target) < 1e-3 * target
