@@ -174,6 +174,26 @@ int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs
                        int64_t R, float mipbias, const float* d_out /*[R][3]*/, float* d_sat,
                        float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Shading helpers.
+ * ---------------------------------------------------------------------------------------- */
+/* select_bounces (modules/pt_selectors.py:5-60): counts[i] = clamp(floor(pt_i), 0, 400) with
+ *   mode 0 (recursion 0): pt = w*mul + u - 0.5                       (mul = rays_per_ray)
+ *   mode 1 (recursion>=1): pt = (w + 1e-3*u) / sum_w * mul + add     (sum_w = clip(sum(w + 1e-3 u), 1e-3))
+ * The dense ray_mask of the reference is the per-row prefix [0, counts[i]). */
+int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t mode, float mul,
+                       float add, float sum_w, int32_t* counts, void* stream);
+/* seg_id[r] / local[r] for r in [offsets[i], offsets[i+1]) = i / r - offsets[i]  (= torch.where(ray_mask)). */
+int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, int32_t* local,
+                        void* stream);
+/* MLPBRDF input rows X [R][66] = [feat_src[src_idx[r]] | ISH(half) | half | ISH(diff) | diff]
+ * (modules/brdf.py:177-261 with feape=0, dotpe=-1, ListISH degs [0,1,2,4]; kappa = 1/(rough+1e-3)). */
+int nmf_brdf_features(const float* half_vec, const float* diff_vec, const float* feat_src,
+                      const float* rough_src, const int32_t* src_idx, int64_t R, float* X, void* stream);
+/* out[s][0:D] = sum_{r in segment s} vals[r*row_stride + 0:D], D <= 64 (adjoint of the feature gather). */
+int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
+                         int64_t n_seg, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""Resolved configuration of `model=microfacet_tensorf2 field=tensorf_og` (reference:
+configs/model/microfacet_tensorf2.yaml, configs/field/tensorf_og.yaml) and a builder that instantiates the
+operator tree the way hydra's `_target_` / `_partial_` instantiation does in the reference (train.py:239)."""
+import copy
+import functools
+
+import torch
+
+FIELD = dict(
+    _target_="fields.tensoRF.TensorVMSplit", distance_scale=25, density_n_comp=16, appearance_n_comp=24, app_dim=24,
+    step_ratio=0.5, density_res_multi=1, contract_space=False, smoothing=1, activation="softplus",
+    interp_mode="bilinear", init_mode="rand", d_init_val=0.1, app_init_val=0.1, density_shift=-4, dbasis=False,
+    grid_size=[128, 128, 128], N_voxel_init=2097156, N_voxel_final=27000000, upsamp_list=[2000, 3000, 4000, 5500, 7000],
+    lr=2e-2, lr_net=1e-3, triplanar=False, num_pretrain=0, calibrate=False)
+
+MODEL = dict(
+    arch=dict(
+        _target_="modules.tensor_nerf.TensorNeRF", recur_alpha_thres=1e-3, lr_scale=1, infinity_border=False,
+        eval_batch_size=4096, recur_stepmul=0.5, hdr=False, bg_noise=0.0, bg_noise_decay=0.999,
+        use_predicted_normals=False, orient_world_normals=True, align_pred_norms=True, detach_inter=False,
+        geonorm_iters=-1, geonorm_interp_iters=1000, contraction="AABB",
+        tonemap=dict(_target_="modules.tonemap.SRGBTonemap"),
+        sampler=dict(_target_="samplers.alphagrid.AlphaGridSampler", enable_alpha_mask=True,
+                     update_list=[2000, 3000, 4000, 5500, 7000], max_samples=200000),
+        model=dict(
+            _target_="models.microfacet.Microfacet", percent_bright=0.0, min_rough_start=0.0, min_rough_decay=0.999,
+            max_brdf_rays=[650000, 450000], conserve_energy=True, target_num_samples=[1000000], russian_roulette=False,
+            max_retrace_rays=[1000], start_std=0.0, std_decay=1.0, cold_start_bg_iters=0, detach_N_iters=0, anoise=0.25,
+            no_emitters=True, diffuse_mixing_mode="fresnel", freeze=False, rays_per_ray=128, test_rays_per_ray=128,
+            brdf_sampler=dict(_target_="brdf_samplers.ggx.GGXSampler"),
+            brdf=dict(_target_="modules.brdf.MLPBRDF", mul_LdotN=False, feape=0, dotpe=-1,
+                      h_encoder=dict(_target_="modules.ish.ListISH", degs=[0, 1, 2, 4]),
+                      d_encoder=dict(_target_="modules.ish.ListISH", degs=[0, 1, 2, 4]),
+                      hidden_w=64, num_layers=3, initializer="kaiming", bias=0, activation="sigmoid", lr=1e-3),
+            diffuse_module=dict(_target_="modules.render_modules.RandHydraMLPDiffuse", pospe=-1, feape=0,
+                                roughness_view_encoder=None, roughness_cfg=dict(hidden_w=64, num_layers=1),
+                                hidden_w=64, num_layers=1, initializer="xavier_sigmoid", lr=1e-3, start_roughness=0.35,
+                                tint_bias=0, diffuse_bias=-0.619, diffuse_mul=1.5, roughness_bias=-1),
+            visibility_module=None),
+        bg_module=dict(_target_="modules.integral_equirect.IntegralEquirect", bg_resolution=512, mipbias=1,
+                       activation="exp", lr=0.02, init_val=-0.6, mul_lr=0, brightness_lr=0, betas=[0.9, 0.99],
+                       mul_betas=[0.9, 0.9], mipbias_lr=1e-4, mipnoise=0.0),
+        rf="placeholder"),
+    params=dict(
+        L1_weight_initial=8e-5, L1_weight_rest=4e-5, clip_grad=None, weight_decay=0, eps=1e-8, betas=[0.9, 0.99],
+        starting_batch_size=100, min_batch_size=4096, max_batch_size=8000, target_num_samples=200000,
+        pred_lambda=3e-4, ori_lambda=0.1, n_iters=30000, batch_size=4096, lr_init=1, lr_final=1e-3, lr_delay_mult=0.1,
+        lr_delay_steps=100, bg_col="white"))
+
+
+def resolved_config():
+    cfg = copy.deepcopy(MODEL)
+    cfg["arch"]["rf"] = copy.deepcopy(FIELD)          # train.py:911: cfg.model.arch.rf = cfg.field
+    return cfg
+
+
+def _classes():
+    from .brdf_samplers.ggx import GGXSampler
+    from .fields.tensoRF import TensorVMSplit
+    from .models.microfacet import Microfacet
+    from .modules.brdf import MLPBRDF, ListISH
+    from .modules.integral_equirect import IntegralEquirect
+    from .modules.render_modules import RandHydraMLPDiffuse
+    from .modules.tensor_nerf import TensorNeRF
+    from .modules.tonemap import SRGBTonemap
+    from .samplers.alphagrid import AlphaGridSampler
+    return {"fields.tensoRF.TensorVMSplit": TensorVMSplit, "samplers.alphagrid.AlphaGridSampler": AlphaGridSampler,
+            "models.microfacet.Microfacet": Microfacet, "brdf_samplers.ggx.GGXSampler": GGXSampler,
+            "modules.brdf.MLPBRDF": MLPBRDF, "modules.ish.ListISH": ListISH,
+            "modules.render_modules.RandHydraMLPDiffuse": RandHydraMLPDiffuse,
+            "modules.integral_equirect.IntegralEquirect": IntegralEquirect,
+            "modules.tensor_nerf.TensorNeRF": TensorNeRF, "modules.tonemap.SRGBTonemap": SRGBTonemap}
+
+
+PARTIAL = {"fields.tensoRF.TensorVMSplit", "samplers.alphagrid.AlphaGridSampler", "models.microfacet.Microfacet",
+           "brdf_samplers.ggx.GGXSampler", "modules.brdf.MLPBRDF", "modules.render_modules.RandHydraMLPDiffuse",
+           "modules.tensor_nerf.TensorNeRF"}
+
+
+def instantiate(node):
+    """hydra.utils.instantiate for the `_target_` strings this config uses (same import paths as the reference;
+    the nodes the reference marks `_partial_: True` become functools.partial objects)."""
+    if isinstance(node, dict) and "_target_" in node:
+        cls = _classes()[node["_target_"]]
+        kw = {k: instantiate(v) for k, v in node.items() if k not in ("_target_", "_partial_")}
+        return functools.partial(cls, **kw) if node["_target_"] in PARTIAL else cls(**kw)
+    if isinstance(node, dict):
+        return {k: instantiate(v) for k, v in node.items()}
+    return node
+
+
+def build_model(grid=128, bg_resolution=512, near_far=(2.5, 7.0), aabb_half=1.5, device="cuda", overrides=None):
+    cfg = resolved_config()
+    cfg["arch"]["rf"]["grid_size"] = [grid] * 3
+    cfg["arch"]["bg_module"]["bg_resolution"] = bg_resolution
+    for path, v in (overrides or {}).items():
+        node = cfg["arch"]
+        keys = path.split(".")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = v
+    aabb = torch.tensor([[-aabb_half] * 3, [aabb_half] * 3])
+    nerf = instantiate(cfg["arch"])(aabb=aabb, near_far=list(near_far))
+    nerf = nerf.to(device)
+    nerf.sampler.update(nerf.rf, init=True)
+    return nerf, cfg

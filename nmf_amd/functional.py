@@ -1,0 +1,135 @@
+"""Autograd glue between torch tensors and the HIP kernels (nmf_amd.hip).  Each Function is a thin
+forward/backward pair of C-ABI calls; there is no Python/torch re-implementation behind them."""
+import torch
+
+from . import hip
+
+
+class VMQuery(torch.autograd.Function):
+    """sigma, sigma_feat, app, normal = field(xyzt).  Gradients flow to the 12 factor tables and basis_mat
+    (incl. the second-order path through the normals); sample positions carry no gradient, exactly like
+    the reference (fields/tensor_base.py:109 detaches xyz)."""
+
+    @staticmethod
+    def forward(ctx, field, xyzt, want_app, want_normal, *params):
+        p, dpk, dlk, apl, ali, basis = field._tables()
+        sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
+                                                  want_normal=want_normal, want_app=want_app, want_coef=want_app)
+        ctx.field = field
+        ctx.flags = (want_app, want_normal)
+        ctx.save_for_backward(xyzt, sf, gr, cf)
+        ctx.mark_non_differentiable(sf)
+        outs = [sg, sf,
+                ap if want_app else xyzt.new_zeros((xyzt.shape[0], 24)),
+                nr if want_normal else xyzt.new_zeros((xyzt.shape[0], 3))]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_sigma, _d_sf, d_app, d_normal):
+        field = ctx.field
+        want_app, want_normal = ctx.flags
+        xyzt, sf, gr, cf = ctx.saved_tensors
+        p, dpk, dlk, apl, ali, basis = field._tables()
+        G = p.grid
+        dev = xyzt.device
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        g_dpk = [z(G, G, 48) for _ in range(3)]
+        g_dlk = [z(G, 32) for _ in range(3)]
+        g_apl = [z(G, G, 24) for _ in range(3)]
+        g_ali = [z(G, 24) for _ in range(3)]
+        d_sigma = d_sigma.contiguous() if d_sigma is not None else None
+        d_app_c = d_app.contiguous() if (want_app and d_app is not None) else None
+        d_nrm_c = d_normal.contiguous() if (want_normal and d_normal is not None) else None
+        hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
+                         g_dpk, g_dlk, g_apl, g_ali)
+        gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+        g_basis = d_app_c.t() @ cf if d_app_c is not None else None      # plain [24 x M] x [M x 72] library GEMM
+        grads = field._grads_to_param_layout(gp, gl, g_apl, g_ali, g_basis)
+        return (None, None, None, None) + tuple(grads)
+
+
+class Composite(torch.autograd.Function):
+    """weights = raw2alpha(sigma, dist * distance_scale) over ray segments (modules/tensor_nerf.py:19-35)."""
+
+    @staticmethod
+    def forward(ctx, sigma, dist, offsets, b, scale):
+        w, _acc = hip.composite_fwd(sigma.contiguous(), dist, offsets, b, scale)
+        ctx.save_for_backward(sigma, dist, w, offsets)
+        ctx.meta = (b, scale)
+        return w
+
+    @staticmethod
+    def backward(ctx, d_w):
+        sigma, dist, w, offsets = ctx.saved_tensors
+        b, scale = ctx.meta
+        return hip.composite_bwd(sigma.contiguous(), dist, w, offsets, b, scale, d_w.contiguous()), None, None, None, None
+
+
+class SegmentSum(torch.autograd.Function):
+    """out[r] = sum of vals rows in segment r, added in index order (modules/row_mask_sum.py:15-22)."""
+
+    @staticmethod
+    def forward(ctx, vals, offsets, seg_id, n_seg):
+        ctx.save_for_backward(seg_id)
+        return hip.segment_sum(vals.contiguous(), None, offsets, n_seg)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (seg_id,) = ctx.saved_tensors
+        return d_out.index_select(0, seg_id.long()), None, None, None
+
+
+def segment_sum(vals, offsets, seg_id, n_seg):
+    if vals.dim() == 1:
+        return SegmentSum.apply(vals[:, None], offsets, seg_id, n_seg)[:, 0]
+    return SegmentSum.apply(vals, offsets, seg_id, n_seg)
+
+
+class EnvLookup(torch.autograd.Function):
+    """IntegralEquirect.forward (modules/integral_equirect.py:409-504) on the cached SAT."""
+
+    @staticmethod
+    def forward(ctx, env, dirs, sa, bg_mat, mipbias, brightness, mul):
+        act, sat, pole = env._tables()
+        dirs_c = dirs.contiguous()
+        sa_c = sa.reshape(-1).contiguous()
+        out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, float(mipbias), pole)
+        ctx.env = env
+        ctx.save_for_backward(dirs_c, sa_c)
+        ctx.mip = float(mipbias)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        env = ctx.env
+        dirs, sa = ctx.saved_tensors
+        act, sat, pole = env._tables()
+        d_sat = torch.zeros_like(sat)
+        d_pole = torch.zeros((2, 3), dtype=torch.float32, device=sat.device)
+        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
+                                           want_dirs=ctx.needs_input_grad[1], want_mipbias=True)
+        _, br, mul = env._host_scalars()
+        d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, br, mul)
+        d_pre = d_bg / mul                                   # adjoint of (brightness + mul * bg_mat)
+        d_br = d_pre.sum(dtype=torch.float64)
+        d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
+        return None, d_dirs, None, d_bg.reshape(env.bg_mat.shape), d_mip.to(torch.float64).reshape(()), d_br, d_mul
+
+
+class BrdfFeatures(torch.autograd.Function):
+    """X[R,66] for the BRDF MLP; differentiable wrt the per-bounce-point feature rows only (the reference
+    detaches half/diff vectors and roughness, models/microfacet.py:461-472)."""
+
+    @staticmethod
+    def forward(ctx, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
+        X = hip.brdf_features(half_vec.contiguous(), diff_vec.contiguous(), feat_rows.contiguous(),
+                              rough_rows.contiguous(), row_of_ray)
+        ctx.save_for_backward(row_offsets)
+        ctx.n_rows = feat_rows.shape[0]
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        (row_offsets,) = ctx.saved_tensors
+        d_feat = hip.segment_sum_wide(dX.contiguous(), 24, row_offsets, ctx.n_rows)
+        return None, None, d_feat, None, None, None

@@ -51,6 +51,7 @@ EXPORTS = [
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
+    "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -326,3 +327,38 @@ def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, want_dirs=True,
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
                                    _stream()), "nmf_sat_lookup_bwd")
     return d_dirs, d_mip
+
+
+# ---- shading helpers -------------------------------------------------------------------------------
+def select_bounces(weights, u, mode, mul, add=0.0, sum_w=1.0):
+    M = weights.shape[0]
+    counts = torch.empty(M, dtype=torch.int32, device=weights.device)
+    _check(_lib.nmf_select_bounces(_p(weights, torch.float32), _p(u, torch.float32), C.c_int64(M), C.c_int32(mode),
+                                   C.c_float(mul), C.c_float(add), C.c_float(sum_w), _p(counts), _stream()),
+           "nmf_select_bounces")
+    return counts
+
+
+def expand_segments(offsets, n_seg, total):
+    seg = torch.empty(total, dtype=torch.int32, device=offsets.device)
+    loc = torch.empty(total, dtype=torch.int32, device=offsets.device)
+    _check(_lib.nmf_expand_segments(_p(offsets, torch.int64), C.c_int64(n_seg), _p(seg), _p(loc), _stream()),
+           "nmf_expand_segments")
+    return seg, loc
+
+
+def brdf_features(half_vec, diff_vec, feat_src, rough_src, src_idx):
+    R = half_vec.shape[0]
+    X = torch.empty((R, 66), dtype=torch.float32, device=half_vec.device)
+    _check(_lib.nmf_brdf_features(_p(half_vec, torch.float32), _p(diff_vec, torch.float32), _p(feat_src, torch.float32),
+                                  _p(rough_src, torch.float32), _p(src_idx, torch.int32), C.c_int64(R), _p(X), _stream()),
+           "nmf_brdf_features")
+    return X
+
+
+def segment_sum_wide(vals, D, offsets, n_seg):
+    out = torch.empty((n_seg, D), dtype=torch.float32, device=vals.device)
+    _check(_lib.nmf_segment_sum_wide(_p(vals, torch.float32), C.c_int64(vals.shape[1]), C.c_int32(D),
+                                     _p(offsets, torch.int64), C.c_int64(n_seg), _p(out), _stream()),
+           "nmf_segment_sum_wide")
+    return out

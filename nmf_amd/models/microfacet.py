@@ -1,0 +1,193 @@
+"""Microfacet shading model -- host-side mirror of the reference's models/microfacet.py (Microfacet :12-673)
+for diffuse_mixing_mode='fresnel', no_emitters=True, russian_roulette=False.
+
+Works on the compact sample list (weights [M] + ray offsets) instead of the dense [rays x N] matrices, and on
+a compact secondary-ray list (row_of_ray, j_of_ray) instead of the padded [bounce points x m] ray_mask."""
+import math
+
+import torch
+
+from .. import hip
+from ..functional import segment_sum
+from ..modules import sh
+from ..brdf_samplers.ggx import normalize
+
+
+class Microfacet(torch.nn.Module):
+    def __init__(self, app_dim, diffuse_module, brdf, brdf_sampler, anoise, max_brdf_rays, target_num_samples,
+                 russian_roulette, percent_bright, cold_start_bg_iters, detach_N_iters, min_rough_start=0,
+                 min_rough_decay=1, start_std=0, std_decay=1, std_decay_interval=10, conserve_energy=True,
+                 no_emitters=True, diffuse_mixing_mode="lambda", visibility_module=None, max_retrace_rays=(),
+                 bright_sampler=None, freeze=False, rays_per_ray=512, test_rays_per_ray=512):
+        super().__init__()
+        if diffuse_mixing_mode != "fresnel" or not no_emitters or russian_roulette or visibility_module is not None \
+                or start_std != 0 or percent_bright != 0:
+            raise NotImplementedError("implements the microfacet_tensorf2.yaml:52-72 configuration")
+        self.diffuse_module = diffuse_module(in_channels=app_dim)
+        self.brdf = brdf(in_channels=app_dim)
+        self.brdf_sampler = brdf_sampler(max_samples=1024)
+        self.freeze = freeze
+        self.needs_normals = lambda x: True
+        self.conserve_energy = conserve_energy
+        self.brdf.init_val = 0.5 if conserve_energy else 0.25
+        self.min_rough, self.min_rough_decay = min_rough_start, min_rough_decay
+        self.std, self.std_decay, self.std_decay_interval = start_std, std_decay, std_decay_interval
+        self.anoise = anoise
+        self.target_num_samples = list(target_num_samples)
+        self.max_brdf_rays = list(max_brdf_rays)
+        self.start_max_retrace_rays = list(max_retrace_rays)
+        self.max_retrace_rays = list(max_retrace_rays)
+        self.detach_N_iters = detach_N_iters
+        self.detach_N = True
+        self.rays_per_ray, self.test_rays_per_ray = rays_per_ray, test_rays_per_ray
+        self.outputs = {"diffuse": 3, "roughness": 1, "tint": 3, "spec": 3, "albedo": 3}
+        self.mean_ratios = None
+        self.ratio_list = None
+        self.trace = None            # tests: dict that receives intermediate tensors
+        self.forced = None           # tests: {'retrace_order<recur>': LongTensor} overrides the argsort below
+
+    # ---- controllers / bookkeeping (models/microfacet.py:79-121,236-269) --------------------------------
+    def calibrate(self, args, xyz, feat, bg_brightness, save_config=True):
+        self.diffuse_module.calibrate(bg_brightness, self.conserve_energy, xyz, None, feat)
+        self.brdf.calibrate(feat, bg_brightness)
+        return args
+
+    def get_optparam_groups(self, lr_scale=1):
+        if self.freeze:
+            return []
+        return [{"params": self.diffuse_module.parameters(), "lr": self.diffuse_module.lr * lr_scale},
+                {"params": self.brdf.parameters(), "lr": self.brdf.lr * lr_scale}]
+
+    def check_schedule(self, iter, batch_mul, **kwargs):
+        if iter % 10 == 0:
+            self.min_rough *= self.min_rough_decay
+        if iter > batch_mul * self.detach_N_iters:
+            self.detach_N = False
+        if iter % self.std_decay_interval == 0:
+            self.std *= self.std_decay
+        return False
+
+    def reset_counter(self):
+        self.max_retrace_rays = list(self.start_max_retrace_rays)
+        self.mean_ratios = None
+        self.ratio_list = None
+
+    def update_n_samples(self, n_samples):
+        if len(n_samples) != len(self.max_retrace_rays):
+            return
+        ratios = [(n_rays / n) if n > 0 else 1e-3 for n_rays, n in zip(self.max_retrace_rays, n_samples)]
+        if self.ratio_list is None:
+            self.ratio_list = [[r, 1e-3] for r in ratios]
+        else:
+            self.ratio_list = [([ratio] + rl)[:20] for ratio, rl in zip(ratios, self.ratio_list)]
+        self.mean_ratios = [min(rl) if len(rl) > 0 else None for rl in self.ratio_list]
+        self.max_retrace_rays = [min(int(t * r + 1), mx) if r is not None else prev for t, r, mx, prev in
+                                 zip(self.target_num_samples, self.mean_ratios, self.max_brdf_rays[:-1],
+                                     self.max_retrace_rays)]
+
+    # ---- shading ----------------------------------------------------------------------------------------
+    def forward(self, samples, app_features, viewdirs, normals, weights, render_reflection, bg_module, is_train,
+                recur, noise):
+        """samples: samplers.alphagrid.Samples; app_features [M,24]; viewdirs, normals [M,3]; weights [M].
+        Returns rgb [M,3] and the debug dict of the reference (models/microfacet.py:271-673)."""
+        M = samples.M
+        dev = app_features.device
+        noise_feat = app_features + noise.normal((M, app_features.shape[1])) * self.anoise        # :297
+        noise.skip("randn", (M, 3))
+        noise.skip("randn", (M, 2))
+        albedo, tint, matprop = self.diffuse_module(None, viewdirs, app_features, std=0)             # :299
+        with torch.no_grad():                                                                       # :304-315
+            noise.skip("rand", (5000,))
+            noise.skip("rand", (5000,))
+            _, conv = bg_module.get_spherical_harmonics(100)
+            E = (conv.reshape(1, -1, 3) * sh.eval_sh_bases(9, normals.detach()).reshape(M, -1, 1)).sum(dim=1)
+        diffuse = albedo * E
+
+        # ---- how many secondary rays per sample (:327-333, pt_selectors.py)
+        w_det = weights.detach().contiguous()
+        if recur == 0:
+            rpr = self.rays_per_ray if is_train else self.test_rays_per_ray
+            counts = hip.select_bounces(w_det, noise.uniform((M,)).contiguous(), 0, float(rpr))
+        else:
+            u, u_total = noise.select_dense(samples.b, samples.N, samples.ray_id, samples.step_id)
+            total = (w_det.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
+            Nbudget = self.max_brdf_rays[recur] - M
+            if Nbudget > 0:
+                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, float(total))
+            else:
+                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(self.max_brdf_rays[recur]), 0.5, float(total))
+        ray_off, _, tot = hip.march_scan(counts, -1)
+        R = int(tot[0])
+        zeros3 = torch.zeros_like(diffuse)
+        reflect_rgb, brdf_rgb, spec = zeros3, zeros3, zeros3
+        if R > 0:
+            bidx = torch.nonzero(counts > 0).reshape(-1)                      # bounce points (rows)
+            Mb = bidx.shape[0]
+            cnt_b = counts[bidx].long()
+            row_off = torch.zeros(Mb + 1, dtype=torch.int64, device=dev)
+            row_off[1:] = torch.cumsum(cnt_b, 0)
+            row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)        # = torch.where(ray_mask)
+            rows = row_of_ray.long()
+            bN = normals[bidx]
+            if self.detach_N:
+                bN = bN.detach()
+            bV = -viewdirs[bidx]
+            bN = bN * (bV * bN).sum(dim=-1, keepdim=True).sign()                                    # :356
+            r1 = matprop["r1"][bidx]
+            if is_train:
+                r1 = r1.clip(min=self.min_rough)
+            angs = self.brdf_sampler.draw_compact(Mb, row_of_ray, j_of_ray, noise)                  # :367
+            L, basisT, lpdf = self.brdf_sampler.sample_compact(angs[:, 0], angs[:, 1], bV, bN, r1, row_of_ray)
+            eV, eN = bV[rows], bN[rows]
+            H = normalize((eV + L) / 2)                                                             # :388
+            basis_rows = basisT.permute(0, 2, 1)
+            diffvec = torch.matmul(basis_rows, L.unsqueeze(-1)).squeeze(-1)
+            halfvec = torch.matmul(basis_rows, H.unsqueeze(-1)).squeeze(-1)
+            ecount = cnt_b.float()[rows]
+            mipval = -torch.log(ecount.clip(min=1)) - lpdf                                          # :448
+            bounce_rays = torch.cat([samples.xyzt[bidx][:, :3][rows] + L * 5e-3, L], dim=-1)         # :450
+            brdf_weight = self.brdf.forward_compact(halfvec, diffvec, noise_feat[bidx], r1, row_of_ray, row_off)
+            if self.trace is not None:
+                self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
+                                   f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,
+                                   f"lpdf{recur}": lpdf})
+            if len(self.max_retrace_rays) > recur:                                                  # :475-559
+                num_retrace = min(R, self.max_retrace_rays[recur])
+                with torch.no_grad():
+                    per_sample = w_det[bidx] / (cnt_b.float() + 1e-8)
+                    per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
+                    cc = per_ray * per_sample[rows]
+                    cc = cc / cc.sum() * num_retrace
+                    cc = cc + noise.uniform((R,))
+                    order = cc.argsort()
+                    if self.forced is not None and f"retrace_order{recur}" in self.forced:
+                        order = self.forced[f"retrace_order{recur}"].to(dev)
+                    if self.trace is not None:
+                        self.trace[f"retrace_score{recur}"] = cc
+                    cut = max(R - num_retrace, 0)
+                    idx_re, idx_no = order[cut:], order[:cut]
+                incoming = torch.zeros((R, 3), device=dev)
+                if idx_re.shape[0] > 0:
+                    inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
+                    incoming = incoming.index_put((idx_re,), inc)
+                if idx_no.shape[0] > 0:
+                    inc = render_reflection(bounce_rays[idx_no], mipval[idx_no], False)
+                    incoming = incoming.index_put((idx_no,), inc)
+            else:
+                incoming = render_reflection(bounce_rays, mipval, False)
+            if self.trace is not None:
+                self.trace[f"incoming{recur}"] = incoming
+            ec = ecount.clip(min=1)[:, None]
+            R0 = matprop["f0"][bidx][rows]                                                          # :596-613
+            ediff = diffuse[bidx][rows]
+            cos_t = (-eV * H).sum(dim=-1, keepdim=True).abs()
+            Fr = R0 + (1 - R0) * (1 - cos_t).clip(min=0, max=1) ** 5
+            comb = Fr * incoming * brdf_weight + (1 - Fr) * ediff
+            reflect_rgb = zeros3.index_put((bidx,), segment_sum(comb / ec, row_off, row_of_ray, Mb))
+            with torch.no_grad():
+                spec = zeros3.index_put((bidx,), segment_sum((incoming / ec).detach(), row_off, row_of_ray, Mb))
+            brdf_rgb = zeros3.index_put((bidx,), segment_sum(brdf_weight / ec, row_off, row_of_ray, Mb))
+        cos_t = (-viewdirs * normals).sum(dim=-1, keepdim=True).abs()                               # :642
+        Fr = matprop["f0"] + (1 - matprop["f0"]) * (1 - cos_t).clip(min=0, max=1) ** 5
+        debug = dict(diffuse=(1 - Fr) * diffuse, tint=Fr * brdf_rgb, roughness=matprop["r1"], spec=spec, albedo=albedo)
+        return reflect_rgb, debug

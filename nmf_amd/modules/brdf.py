@@ -1,0 +1,62 @@
+"""BRDF MLP -- host-side mirror of the reference's modules/brdf.py (MLPBRDF :72-261) for the
+microfacet_tensorf2 configuration (feape=0, dotpe=-1, h/d encoders = ListISH([0,1,2,4]), 66 -> 64 -> 64 -> 4).
+The 66-wide input rows (feature gather + ISH encodings) come from the HIP kernel nmf_brdf_features; the three
+dense layers are plain library GEMMs (rocBLAS through torch.nn.functional.linear) in round 1."""
+import torch
+import torch.nn.functional as F
+
+from ..functional import BrdfFeatures
+from .util import create_mlp
+
+
+class ListISH(torch.nn.Module):
+    """modules/ish.py:94-105 -- only its identity (degrees) matters here: the encoding is inside the kernel"""
+
+    def __init__(self, degs=(0, 1, 2, 4)):
+        super().__init__()
+        self.degs = list(degs)
+
+    def dim(self):
+        return sum(2 * d + 1 for d in self.degs)
+
+
+class MLPBRDF(torch.nn.Module):
+    def __init__(self, in_channels, h_encoder=None, d_encoder=None, v_encoder=None, n_encoder=None, l_encoder=None,
+                 feape=6, dotpe=0, activation="sigmoid", mul_LdotN=True, bias=0, lr=1e-4, shift=0, **kwargs):
+        super().__init__()
+        ok = (feape == 0 and dotpe < 0 and activation == "sigmoid" and not mul_LdotN and v_encoder is None
+              and n_encoder is None and l_encoder is None and h_encoder is not None and d_encoder is not None
+              and list(h_encoder.degs) == [0, 1, 2, 4] and list(d_encoder.degs) == [0, 1, 2, 4] and in_channels == 24)
+        if not ok:
+            raise NotImplementedError("HIP BRDF features implement the microfacet_tensorf2.yaml:86-104 configuration")
+        self.in_channels = in_channels
+        self.bias = bias
+        self.lr = lr
+        self.activation_name = activation
+        self.in_mlpC = in_channels + 2 * (h_encoder.dim() + 3)
+        self.h_encoder, self.d_encoder = h_encoder, d_encoder
+        self.mlp = create_mlp(self.in_mlpC, 4, **kwargs)
+        self.init_val = 0.25
+
+    def forward_compact(self, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
+        X = BrdfFeatures.apply(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
+                               row_of_ray, row_offsets)
+        out = self.mlp(X)
+        return torch.sigmoid(out[..., :3] + self.bias)
+
+    def calibrate(self, efeatures, bg_brightness):
+        # modules/brdf.py:141-175 (random unit vectors; only the mean of the output matters)
+        N = efeatures.shape[0]
+        dev = efeatures.device
+
+        def rv():
+            v = 2 * torch.rand((N, 3), device=dev) - 1
+            return v / v.norm(dim=-1, keepdim=True).clip(min=1e-8)
+
+        idx = torch.arange(N, device=dev, dtype=torch.int32)
+        off = torch.arange(N + 1, device=dev, dtype=torch.int64)
+        with torch.no_grad():
+            w = self.forward_compact(rv(), rv(), efeatures, torch.rand(N, device=dev), idx, off)
+        target = self.init_val / float(bg_brightness)
+        inv = lambda v: torch.log(v / (1 - v))  # noqa: E731
+        self.bias += float(torch.log(torch.tensor(target / (1 - target)))) - float(inv(w).mean())

@@ -1,0 +1,104 @@
+"""Learnable equirectangular environment map with summed-area-table prefiltering on HIP kernels --
+host-side mirror of the reference's modules/integral_equirect.py (IntegralEquirect :176-504).
+The SAT is rebuilt when bg_mat changes (once per optimiser step), not on every call (:431-433)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..functional import EnvLookup
+from . import sh
+
+
+class IntegralEquirect(torch.nn.Module):
+    def __init__(self, bg_resolution, init_val, activation="identity", mipbias=0, mipnoise=0, lr=0.15, mipbias_lr=1e-3,
+                 brightness_lr=0.01, mul_lr=0.01, mul_betas=(0.9, 0.999), betas=(0.9, 0.99)):
+        super().__init__()
+        if activation != "exp":
+            raise NotImplementedError("HIP env map implements activation='exp' (microfacet_tensorf2.yaml:147)")
+        if mipnoise != 0:
+            raise NotImplementedError("mipnoise != 0 is not used by this config")
+        self.bg_mat = nn.Parameter(init_val * torch.ones((1, 3, bg_resolution, 2 * bg_resolution)))
+        self.register_parameter("mipbias", nn.Parameter(torch.tensor(mipbias, dtype=float)))
+        self.register_parameter("brightness", nn.Parameter(torch.tensor(0.0, dtype=float)))
+        self.register_parameter("mul", nn.Parameter(torch.tensor(1.0, dtype=float)))
+        self.mipnoise = mipnoise
+        self.lr, self.mul_lr, self.mipbias_lr, self.brightness_lr = lr, mul_lr, mipbias_lr, brightness_lr
+        self.mul_betas, self.betas = list(mul_betas), list(betas)
+        self.activation = activation
+        self.register_buffer("sh_A", torch.tensor(sum([[sh.Al2(l)] * (2 * l + 1) for l in range(16)], []),
+                                                  dtype=torch.float32))
+        self._cache = None
+        self._sh_cache = None
+        self._scalars = None
+
+    def get_optparam_groups(self, lr_scale=1):
+        # modules/integral_equirect.py:232-257
+        return [{"params": self.bg_mat, "betas": self.betas, "lr": self.lr * lr_scale, "name": "bg"},
+                {"params": self.brightness, "lr": self.brightness_lr * lr_scale, "name": "bg"},
+                {"params": self.mul, "lr": self.mul_lr * lr_scale, "betas": self.mul_betas, "name": "bg"},
+                {"params": [self.mipbias], "lr": self.mipbias_lr * lr_scale, "name": "mipbias"}]
+
+    def hw(self):
+        return self.bg_mat.shape[-2], self.bg_mat.shape[-1]
+
+    @property
+    def bg_resolution(self):
+        return self.hw()[0]
+
+    def get_device(self):
+        return self.bg_mat.device
+
+    def _host_scalars(self):
+        key = (self.mipbias._version, self.brightness._version, self.mul._version)
+        if self._scalars is None or self._scalars[0] != key:
+            self._scalars = (key, (float(self.mipbias), float(self.brightness), float(self.mul)))
+        return self._scalars[1]
+
+    def _tables(self):
+        key = (self.bg_mat.data_ptr(), self.bg_mat._version) + self._host_scalars()[1:]
+        if self._cache is None or self._cache[0] != key:
+            _, br, mul = self._host_scalars()
+            act, sat = hip.sat_build(self.bg_mat.detach(), br, mul)
+            pole = torch.stack([act[:, 0, :].mean(-1), act[:, -1, :].mean(-1)]).contiguous()
+            self._cache = (key, (act, sat, pole))
+        return self._cache[1]
+
+    def activation_fn(self, x):
+        return torch.exp((self.brightness + self.mul * x).clip(max=20))
+
+    def mean_color(self):
+        return self.activation_fn(self.bg_mat).reshape(-1, 3).mean(dim=0)
+
+    def forward(self, viewdirs, saSample, max_level=None):
+        if viewdirs.shape[0] == 0:
+            return viewdirs.new_zeros((0, 3))
+        sa = saSample.reshape(-1).detach().float()
+        return EnvLookup.apply(self, viewdirs.float(), sa, self.bg_mat, self.mipbias, self.brightness, self.mul)
+
+    @torch.no_grad()
+    def get_spherical_harmonics(self, G, mipval=-5):
+        """modules/integral_equirect.py:324-360; cached per bg_mat version (the reference recomputes it)."""
+        key = (self.bg_mat.data_ptr(), self.bg_mat._version, G, mipval) + self._host_scalars()
+        if self._sh_cache is None or self._sh_cache[0] != key:
+            dev = self.get_device()
+            theta, phi = torch.meshgrid(torch.linspace(0, np.pi, G // 2, device=dev),
+                                        torch.linspace(0, 2 * np.pi, G, device=dev), indexing="ij")
+            dirs = torch.stack([torch.sin(theta) * torch.cos(phi), torch.sin(theta) * torch.sin(phi),
+                                torch.cos(theta)], dim=-1).reshape(-1, 3)
+            SB = dirs.shape[0]
+            act, sat, pole = self._tables()
+            bg = hip.sat_lookup_fwd(sat, dirs.contiguous(), torch.full((SB,), float(mipval), device=dev),
+                                    self._host_scalars()[0], pole)
+            ev = sh.eval_sh_bases(9, dirs)
+            coeffs = 2 * np.pi ** 2 * (bg.reshape(SB, 1, 3) * ev.reshape(SB, -1, 1)
+                                       * torch.sin(theta.reshape(SB, 1, 1))).mean(dim=0)
+            conv = self.sh_A.reshape(-1, 1)[: coeffs.shape[0]] * coeffs
+            self._sh_cache = (key, (coeffs, conv / np.pi))
+        return self._sh_cache[1]
+
+    def _load_from_state_dict(self, *a, **k):
+        self._cache = self._sh_cache = self._scalars = None
+        super()._load_from_state_dict(*a, **k)

@@ -1,0 +1,45 @@
+"""Material heads -- host-side mirror of the reference's RandHydraMLPDiffuse
+(modules/render_modules.py:447-574) for pospe=-1, feape=0, num_layers=1: four Linear(24 -> 3,3,3,2) heads.
+These are 24x11 products per sample (plain library GEMMs through torch.nn.functional.linear)."""
+import torch
+
+from .util import create_mlp
+
+
+def inv_sigmoid(v):
+    return torch.log(v / (1 - v))
+
+
+class RandHydraMLPDiffuse(torch.nn.Module):
+    def __init__(self, in_channels, pospe=12, view_encoder=None, roughness_view_encoder=None, roughness_cfg=None,
+                 feape=6, allocation=0, unlit_tint=False, lr=1e-4, tint_bias=-1, diffuse_bias=-2, diffuse_mul=1,
+                 roughness_bias=1, start_roughness=0.35, f0_bias=0, **kwargs):
+        super().__init__()
+        if pospe >= 0 or feape != 0 or view_encoder is not None or roughness_view_encoder is not None or allocation > 0:
+            raise NotImplementedError("implements the microfacet_tensorf2.yaml:106-131 configuration")
+        self.in_mlpC = in_channels
+        self.tint_bias, self.diffuse_bias, self.roughness_bias = tint_bias, diffuse_bias, roughness_bias
+        self.lr = lr
+        self.diffuse_mul = diffuse_mul
+        self.start_roughness = start_roughness
+        self.f0_bias = f0_bias
+        self.diffuse_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
+        self.tint_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
+        self.f0_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
+        self.roughness_mlp = create_mlp(self.in_mlpC, 2, **(roughness_cfg if roughness_cfg is not None else kwargs))
+
+    def forward(self, pts, viewdirs, features, std=0, **kwargs):
+        diffuse = torch.sigmoid(self.diffuse_mul * self.diffuse_mlp(features) + self.diffuse_bias).clip(min=0, max=1)
+        r = (torch.sigmoid(self.roughness_mlp(features) + self.roughness_bias) / 2).clip(min=1e-2, max=1)
+        tint = torch.sigmoid(self.tint_mlp(features) + self.tint_bias)
+        f0 = torch.sigmoid(self.f0_mlp(features) + self.f0_bias)
+        return diffuse, tint, dict(diffuse=diffuse, r1=r[:, 0:1], r2=r[:, 1:2], f0=f0, tint=tint)
+
+    def calibrate(self, mean_brightness, conserve_energy, *args, **kwargs):
+        # modules/render_modules.py:505-515
+        with torch.no_grad():
+            diffuse, tint, extra = self(*args, **kwargs)
+            v = (0.25 if not conserve_energy else 0.5) / float(mean_brightness)
+            self.diffuse_bias += float(inv_sigmoid(torch.tensor(v))) - float(inv_sigmoid(diffuse).mean())
+            rough = (extra["r1"] + extra["r2"]) / 2 / 2
+            self.roughness_bias += float(inv_sigmoid(torch.tensor(self.start_roughness))) - float(inv_sigmoid(rough).mean())

@@ -1,0 +1,147 @@
+"""Scene module -- host-side mirror of the reference's modules/tensor_nerf.py (TensorNeRF :38-674):
+sample -> density -> weights -> appearance + normals -> microfacet shading (recursive) -> composite ->
+tonemap, with the same constructor keywords, __call__ signature, returned image / statistics keys and
+state_dict layout.  Every stage runs on the compact sample list produced by the HIP sampler."""
+import torch
+
+from ..functional import Composite, segment_sum
+from ..noise import DeviceNoise
+from .tonemap import SRGBTonemap
+
+
+class TensorNeRF(torch.nn.Module):
+    def __init__(self, rf, model, aabb, near_far, sampler, tonemap=None, bg_module=None, normal_module=None,
+                 alphaMask=None, infinity_border=False, recur_stepmul=1, recur_alpha_thres=1e-3, detach_inter=False,
+                 hdr=False, bg_noise=0, bg_noise_decay=0.999, use_predicted_normals=True, orient_world_normals=False,
+                 align_pred_norms=True, eval_batch_size=512, geonorm_iters=-1, geonorm_interp_iters=1, lr_scale=1,
+                 contraction="AABB", **kwargs):
+        super().__init__()
+        if normal_module is not None or hdr or detach_inter or geonorm_iters > 0:
+            raise NotImplementedError("implements the microfacet_tensorf2.yaml:1-27 configuration")
+        self.rf = rf(aabb=aabb)
+        self.normal_module = None
+        self.sampler = sampler(near_far=near_far, aabb=aabb)
+        self.model = model(self.rf.app_dim)
+        self.bg_module = bg_module
+        self.tonemap = SRGBTonemap() if tonemap is None else tonemap
+        self.lr_scale = lr_scale
+        self.hdr = hdr
+        self.bg_noise, self.bg_noise_decay = bg_noise, bg_noise_decay
+        self.recur_alpha_thres = recur_alpha_thres
+        self.eval_batch_size = eval_batch_size
+        self.recur_stepmul = recur_stepmul
+        self.use_predicted_normals = False
+        self.align_pred_norms = use_predicted_normals | align_pred_norms
+        self.orient_world_normals = orient_world_normals | (not self.align_pred_norms)
+        self._noise = None
+
+    def get_device(self):
+        return self.rf.units.device
+
+    def get_optparam_groups(self):
+        g = self.rf.get_optparam_groups(self.lr_scale) + self.model.get_optparam_groups(self.lr_scale)
+        if isinstance(self.bg_module, torch.nn.Module):
+            g += self.bg_module.get_optparam_groups(self.lr_scale)
+        return g
+
+    def save(self, path, config):
+        config["use_predicted_normals"] = self.use_predicted_normals
+        sd = {k: (v.contiguous() if v.dim() == 4 else v) for k, v in self.state_dict().items()}
+        torch.save({"config": config, "state_dict": sd}, path)
+
+    def check_schedule(self, iter, batch_mul):
+        # modules/tensor_nerf.py:177-195 (mask rebuild BEFORE the field upsamples on the same iteration)
+        req = self.model.check_schedule(iter, batch_mul)
+        req |= self.sampler.check_schedule(iter, batch_mul, self.rf)
+        req |= self.rf.check_schedule(iter, batch_mul)
+        if req:
+            self.sampler.update(self.rf, init=True)
+        self.bg_noise *= self.bg_noise_decay
+        return req
+
+    def render_just_bg(self, viewdirs, roughness):
+        if viewdirs.shape[0] == 0:
+            return torch.empty((0, 3), device=viewdirs.device)
+        return self.bg_module(viewdirs, roughness).reshape(-1, 3)
+
+    def forward(self, rays, focal, start_mipval=None, bg_col=torch.tensor([1, 1, 1]), stepmul=1, recur=0,
+                override_near=None, output_alpha=None, dynamic_batch_size=True, gt_normals=None,
+                override_alpha_thres=None, is_train=False, ndc_ray=False, N_samples=-1, tonemap=True, draw_debug=True,
+                max_weight_N=-1, noise=None):
+        dev = rays.device
+        if noise is None:
+            if self._noise is None:
+                self._noise = DeviceNoise(dev, seed=20211200)
+            noise = self._noise
+        S = self.sampler.sample_compact(rays, focal, rf=self.rf, override_near=override_near, is_train=is_train,
+                                        dynamic_batch_size=dynamic_batch_size, noise=noise)
+        B, M = S.b, S.M
+        n_samples = [M]
+        wv = S.whole_valid
+        rid = S.ray_id.long()
+        ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
+        viewdirs = ray_dirs[rid]
+        offsets = S.offsets[: B + 1]
+
+        sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=True, want_normal=True)       # :286,386,393
+        weight = Composite.apply(sigma, S.dist, offsets, B, float(self.rf.distance_scale))          # :366
+
+        def render_reflection(brays, mipval, retrace):                                               # :291-317
+            if retrace:
+                ims, st = self(brays, focal, recur=recur + 1, bg_col=None, dynamic_batch_size=False,
+                               stepmul=self.recur_stepmul, start_mipval=mipval.reshape(-1),
+                               override_near=3 * float(self.sampler.stepsize), is_train=is_train, ndc_ray=False,
+                               tonemap=False, draw_debug=False, noise=noise)
+                n_samples.extend(st["n_samples"])
+                return ims["rgb_map"]
+            noise.skip("rand", (brays.shape[0],))
+            noise.skip("rand", (brays.shape[0],))
+            return self.render_just_bg(brays[..., 3:6], mipval.reshape(-1))
+
+        if M > 0:
+            rgb, debug = self.model(S, app, viewdirs, world_normal, weight, render_reflection, self.bg_module,
+                                    is_train, recur, noise)
+        else:
+            rgb = torch.empty((0, 3), device=dev)
+            debug = {k: torch.empty((0, v), device=dev) for k, v in self.model.outputs.items()}
+
+        acc_map = segment_sum(weight, offsets, S.ray_id, B)                                          # :448
+        rgb_map = segment_sum(weight[:, None] * rgb, offsets, S.ray_id, B)                           # :452
+        images = {}
+        stats = dict(recur=recur, whole_valid=wv, n_samples=n_samples)
+        if self.bg_module is not None and bg_col is None:                                            # :460-468
+            rough = -100 * torch.ones(B, device=dev) if start_mipval is None else start_mipval[:B]
+            noise.skip("rand", (B,))
+            noise.skip("rand", (B,))
+            bg = self.render_just_bg(ray_dirs, rough).reshape(-1, 3)
+            if tonemap:
+                bg = self.tonemap(bg, noclip=True)
+        else:
+            bg = bg_col.to(dev).reshape(1, 3)
+
+        if not is_train and draw_debug:                                                              # :480-566
+            with torch.no_grad():
+                images["depth"] = segment_sum(weight * S.z, offsets, S.ray_id, B)
+                wn = segment_sum(world_normal * weight[:, None], offsets, S.ray_id, B)
+                images["world_normal"] = acc_map[..., None] * wn + (1 - acc_map[..., None])
+                images["surf_width"] = (offsets[1:] - offsets[:-1])
+                for k, v in debug.items():
+                    images[k] = segment_sum(v * weight[:, None], offsets, S.ray_id, B) + (1 - acc_map[..., None]) * bg
+        elif recur == 0:                                                                             # :567-649
+            ndv = (-viewdirs.detach() * world_normal).sum(dim=-1)
+            stats["ori_loss"] = (weight * (ndv.clamp(max=0) ** 2)).sum()
+            # normal_module is None: pred_norms == 0 -> align_world_loss == 2
+            stats["prediction_loss"] = (weight * 2.0).sum()
+            stats["distortion_loss"] = torch.tensor(0.0, device=dev)
+            stats["envmap_reg"] = (self.bg_module.mean_color().mean() - 0.05).clip(min=0)
+            stats["brdf_reg"] = debug["tint"].mean().clip(min=0) if M > 0 else torch.tensor(0.0, device=dev)
+            stats["diffuse_reg"] = ((weight.detach().reshape(-1, 1) * debug["diffuse"]).sum() / 3
+                                    if M > 0 else torch.tensor(0.0, device=dev))
+            for k, v in debug.items():
+                images[k] = v
+        if tonemap:
+            rgb_map = self.tonemap(rgb_map, noclip=self.hdr)                                         # :658
+        rgb_map = rgb_map + (1 - acc_map[..., None]) * bg                                            # :659
+        images["rgb_map"] = rgb_map
+        images["acc_map"] = acc_map.detach()
+        return images, stats

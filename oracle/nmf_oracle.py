@@ -705,7 +705,7 @@ def retrace_select(brdf_weight, eV, eN, samp_prob, w_bounce, ray_count, ray_mask
         cc = cc + noise.draw("rand", cc.shape)
         order = cc.argsort()
         M = max(order.shape[0] - num_retrace, 0)
-        return order[M:], order[:M], cc
+        return order[M:], order[:M], (cc, order)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -763,7 +763,8 @@ def shade(sd, cfg: Cfg, xyzs, app_features, viewdirs, nrm, weights, app_mask, re
                                                 weights[app_mask][bounce_mask], ray_count, ray_mask,
                                                 num_retrace, noise)
             if trace is not None:
-                trace.update({f"retrace_idx{recur}": idx_re, f"retrace_score{recur}": cc})
+                trace.update({f"retrace_idx{recur}": idx_re, f"retrace_score{recur}": cc[0],
+                              f"retrace_order{recur}": cc[1]})
             incoming = torch.zeros((bounce_rays.shape[0], 3))
             if len(idx_re) > 0:
                 inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)

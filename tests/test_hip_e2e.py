@@ -1,0 +1,143 @@
+"""GPU end-to-end parity: the HIP-backed operator tree (nmf_amd/) against the reference's golden vectors and
+the CPU oracle on the same inputs and the same recorded noise.  Counts / masks bit-exact, radiance within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, assert_close
+from nmf_amd import synthetic
+from oracle import nmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(g, is_train=True):
+    from nmf_amd.config import build_model
+    from nmf_amd.samplers.alphagrid import AlphaGridMask
+    G, BG = g["grid"], g["bg_res"]
+    nerf, _ = build_model(grid=G, bg_resolution=BG, device=DEV,
+                          overrides={"sampler.max_samples": g["max_samples"], "model.max_retrace_rays": [g["max_retrace"]]})
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
+    missing = nerf.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    nerf.model.detach_N = bool(g["detach_N"])
+    nerf.model.brdf.bias = g["brdf_bias"]
+    nerf.model.diffuse_module.diffuse_bias = g["diffuse_bias"]
+    nerf.model.diffuse_module.roughness_bias = g["roughness_bias"]
+    nerf.train(is_train)
+    nerf.sampler.update(nerf.rf, init=True)
+    return nerf, sd
+
+
+def _oracle_trace(g, is_train=True):
+    """Runs the CPU oracle on the fixture (it is pinned against the reference by tests/test_oracle_golden.py)
+    and returns its intermediate tensors."""
+    G, BG = g["grid"], g["bg_res"]
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
+    cfg = O.Cfg(grid=G, max_samples=g["max_samples"], max_retrace_rays=(g["max_retrace"],),
+                detach_N=bool(g["detach_N"]), brdf_bias=g["brdf_bias"], diffuse_bias=g["diffuse_bias"],
+                roughness_bias=g["roughness_bias"])
+    vol = g.bits("alpha_volume", (1, 1, G, G, G)).float()
+    trace = {}
+    with torch.no_grad():
+        O.render(sd, cfg, g["rays"], g["focal"], vol, O.Noise(g.tape()), is_train=is_train, bg_col=torch.ones(3),
+                 trace=trace)
+    return trace
+
+
+def _pin_retrace_decision(nerf, trace):
+    """Which secondary rays get re-traced is an argsort over importance scores that contain exp(log-pdf) of very
+    sharp GGX lobes: a last-bit difference in one score reorders neighbours and swaps which ray meets which
+    jitter row.  The decision is bookkeeping ("bit-exact GIVEN the scores"), so the e2e radiance
+    comparison pins it to the oracle's order; the scores themselves are compared separately below."""
+    nerf.model.forced = {"retrace_order0": trace["retrace_order0"]}
+    nerf.model.trace = {}
+
+
+def _check_retrace_scores(nerf, trace):
+    got, ref = nerf.model.trace["retrace_score0"].cpu(), trace["retrace_score0"]
+    # scores = normalised contribution + U(0,1); all but the few ill-conditioned lobes agree tightly
+    close = (got - ref).abs() <= 1e-4
+    assert float(close.float().mean()) > 0.9, float(close.float().mean())
+    # GPU argsort == CPU argsort on identical inputs
+    assert torch.equal(ref.to(DEV).argsort().cpu(), ref.argsort())
+
+
+def test_alpha_mask_rebuild_matches_reference():
+    g = Golden("e2e_small_train")
+    nerf, _ = _build(g)
+    nerf.sampler.update(nerf.rf, init=False)
+    G = g["grid"]
+    assert torch.equal(nerf.sampler.alphaMask.alpha_volume.bool().cpu(), g.bits("alpha_volume", (1, 1, G, G, G)))
+
+
+@pytest.mark.parametrize("tag", ["train", "train_detachN"])
+def test_e2e_small_train_forward_backward(tag):
+    from nmf_amd.noise import ReplayNoise
+    g = Golden("e2e_small_" + tag)
+    nerf, _ = _build(g)
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    noise = ReplayNoise(DEV, g.tape())
+    rays = g["rays"].to(DEV)
+    trace = _oracle_trace(g)
+    _pin_retrace_decision(nerf, trace)
+    ims, st = nerf(rays, g["focal"], bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=noise)
+    _check_retrace_scores(nerf, trace)
+    assert noise.pos == len(noise.tape), "draws not consumed 1:1 with the reference"
+    assert torch.equal(st["whole_valid"].cpu(), g["whole_valid"])
+    assert list(st["n_samples"]) == list(g.np("n_samples"))
+    assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-6, what="acc_map")
+    assert_close(ims["rgb_map"].detach().cpu(), g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
+    assert_close(st["ori_loss"].detach().cpu(), g["ori_loss"], rtol=2e-4, what="ori_loss")
+    assert_close(st["prediction_loss"].detach().cpu(), g["prediction_loss"], rtol=1e-5, what="prediction_loss")
+    for k in ("tint", "roughness", "albedo"):
+        assert_close(ims[k].detach().cpu(), g["debug/" + k], rtol=1e-4, atol=1e-5, what=k)
+    # diffuse = albedo * irradiance; the irradiance is an SH projection of 5000 prefiltered env lookups on the
+    # fixture's tiny 32x64 map, i.e. it inherits the SAT cancellation noise (see test_hip_parity env tests)
+    assert_close(ims["diffuse"].detach().cpu(), g["debug/diffuse"], rtol=2e-3, atol=5e-4, what="diffuse")
+    assert_close(ims["spec"].detach().cpu(), g["debug/spec"], rtol=1e-3, atol=1e-3, what="spec")
+    # loss + backward (train.py:598-708)
+    gt = g["gt"].to(DEV)
+    wv = st["whole_valid"]
+    loss = ((ims["rgb_map"].clip(max=1).clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
+    total = (loss + 0.1 * st["ori_loss"] + 3e-4 * st["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 4096
+    assert_close(loss.detach().cpu(), g["loss"], rtol=1e-4, what="loss")
+    assert_close(total.detach().cpu(), g["total"], rtol=1e-4, what="total")
+    total.backward()
+    params = dict(nerf.named_parameters())
+    worst = {}
+    for k in g.keys("gradnorm/"):
+        name = k[len("gradnorm/"):]
+        gr = params[name].grad
+        assert gr is not None, name
+        ref = float(g[k])
+        got = float(gr.norm())
+        worst[name] = got / ref - 1
+        tol = 2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3
+        assert abs(got - ref) <= tol * ref + 1e-9, (name, got, ref)
+    gref = g["grad_slice/density_plane0"]
+    assert_close(params["rf.density_rf.app_plane.0"].grad[0, :, ::3, ::3].cpu(), gref, rtol=5e-3,
+                 atol=5e-3 * float(gref.abs().max()), what="density plane grad slice")
+    gref = g["grad_slice/bg_mat"]
+    assert_close(params["bg_module.bg_mat"].grad[0, :, ::4, ::4].cpu(), gref, rtol=5e-3,
+                 atol=5e-3 * float(gref.abs().max()), what="bg_mat grad slice")
+
+
+def test_e2e_small_eval():
+    from nmf_amd.noise import ReplayNoise
+    g = Golden("e2e_small_eval")
+    nerf, _ = _build(g, is_train=False)
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    noise = ReplayNoise(DEV, g.tape())
+    _pin_retrace_decision(nerf, _oracle_trace(g, is_train=False))
+    with torch.no_grad():
+        ims, st = nerf(g["rays"].to(DEV), g["focal"], bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=noise)
+    assert noise.pos == len(noise.tape)
+    assert list(st["n_samples"]) == list(g.np("n_samples"))
+    assert_close(ims["rgb_map"].cpu(), g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
+    assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-6, what="acc_map")
+    assert_close(ims["depth"].cpu(), g["depth"], rtol=1e-5, atol=1e-5, what="depth")
+    assert_close(ims["world_normal"].cpu(), g["world_normal"], rtol=1e-4, atol=2e-5, what="world_normal")
