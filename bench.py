@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the microfacet_tensorf2 hot path on MI355X (see BASELINE.json / SURVEY.md 8d).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one optimizer step (forward + backward + Adam) over a 4096-ray batch per GPU of the synthetic
+scene S1 (solid cube in the 128^3 TensoRF grid, 512x1024 env map, 800x800 camera; nerf_synthetic/lego is not
+available offline) in the STEADY-STATE phase of the reference (every secondary ray re-traced).
+Ray batches are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RAYS_PER_GPU = 4096
+GRID = 128
+BG_RES = 512
+G_S = 4800            # algorithmic bytes per kept sample, forward: 18 taps x (16+2*16+24... ) fp32
+BWD_BYTES = 3 * G_S   # backward = recompute read + read-modify-write of the gradients (fwd+bwd = 4 G_s)
+HBM_PEAK_GBS = 8000.0
+
+
+def build(device):
+    from nmf_amd import synthetic
+    from nmf_amd.config import build_model, resolved_config
+    nerf, cfg = build_model(grid=GRID, bg_resolution=BG_RES, device=device)
+    nerf.load_state_dict(synthetic.state_dict_s1(grid=GRID, bg_resolution=BG_RES, seed=0), strict=False)
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=False)          # alpha mask from the density field (alphagrid.py:250-276)
+    nerf.sampler.update(nerf.rf, init=True)
+    nerf.model.detach_N = False                        # state after the first check_schedule (microfacet.py:117)
+    nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]   # steady state: all secondary rays re-traced
+    return nerf, resolved_config()["params"]
+
+
+class KernelTimer:
+    """HIP events around every nmf_vm_query_bwd call (issued on torch's current stream, which is the stream the
+    C ABI launches on) -> per-launch duration of the dominant kernel inside the timed region."""
+
+    def __init__(self):
+        from nmf_amd import hip, functional
+        self.hip = hip
+        self.records = []
+        self.enabled = False
+        orig = hip.vm_query_bwd
+
+        def wrapped(p, xyzt, *a, **k):
+            if not self.enabled:
+                return orig(p, xyzt, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(p, xyzt, *a, **k)
+            e.record()
+            self.records.append((s, e, int(xyzt.shape[0])))
+            return r
+
+        hip.vm_query_bwd = wrapped
+        functional.hip.vm_query_bwd = wrapped
+
+    def summary(self):
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        samples = sum(m for _, _, m in self.records)
+        return ms, samples, len(self.records)
+
+
+def cpu_baseline(n_rays=512):
+    """The CPU oracle (validated against the reference, tests/test_oracle_golden.py) timed on the host cores:
+    forward + backward of one steady-state chunk on a bounded sample of the same workload."""
+    from nmf_amd import synthetic
+    from oracle import nmf_oracle as O
+    torch.manual_seed(0)
+    sd = synthetic.state_dict_s1(grid=GRID, bg_resolution=BG_RES, seed=0)
+    for k, v in sd.items():
+        if k != "model.brdf_sampler.angs":
+            v.requires_grad_(True)
+    cfg = O.Cfg(grid=GRID, detach_N=False, max_retrace_rays=(650000,))
+    vol = O.dense_alpha_mask({k: v.detach() for k, v in sd.items()}, cfg)
+    rays, focal = synthetic.camera_rays(n_rays, seed=123)
+    gt = torch.rand(n_rays, 3)
+    t0 = time.time()
+    ims, st = O.render(sd, cfg, rays, focal, vol, O.Noise(), is_train=True, bg_col=torch.ones(3))
+    total, _ = O.training_loss(ims, st, gt, n_rays, sd)
+    total.backward()
+    dt = time.time() - t0
+    return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 steady-state chunk of {n_rays} rays (S1, 128^3, all {st['n_samples']} samples incl. re-traced "
+                       f"secondary rays), forward+backward, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (see the module docstring)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "nmf_amd", "lib", "libnmf_hip.so")):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from nmf_amd import synthetic
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+
+    torch.manual_seed(20211200)
+    nerf, params = build(device)
+    trainer = Trainer(nerf, params, world_size=world, rank=rank)
+    noise = DeviceNoise(device, seed=1000 + rank)
+    timer = KernelTimer()
+
+    n_steps = args.warmup + args.steps
+    batches = []
+    g = torch.Generator().manual_seed(77 + rank)
+    for i in range(n_steps):                       # disjoint random pixels per rank and step, resident in HBM
+        rays, focal = synthetic.camera_rays(RAYS_PER_GPU, seed=10007 * (rank + 1) + i)
+        batches.append((rays.to(device), torch.rand(RAYS_PER_GPU, 3, generator=g).to(device)))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(*batches[i], focal, noise=noise, update_controllers=False, fixed_chunk=RAYS_PER_GPU)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    rays_done, last = 0, None
+    for i in range(args.warmup, n_steps):
+        last = trainer.step(*batches[i], focal, noise=noise, update_controllers=False, fixed_chunk=RAYS_PER_GPU)
+        rays_done += last["rays"]
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+
+    tt = torch.tensor([dt, float(rays_done)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = float(tmax[0]), float(tt[1])
+    else:
+        dt_max, rays_all = dt, float(rays_done)
+
+    if rank == 0:
+        k_ms, k_samples, k_launches = timer.summary()
+        achieved = (BWD_BYTES * k_samples) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_vm_bwd.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "train rays/sec (microfacet_tensorf2, 4096-ray batch per GPU, steady state)",
+            "value": rays_all / dt_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S1 solid-cube scene, TensoRF 128^3 (16+24 comps), env 512x1024, 800x800 camera, "
+                                   "4096 rays/GPU/step, fwd+bwd+Adam, all secondary rays re-traced (steady state); "
+                                   "stands in for BASELINE configs[1] (lego is not available offline)",
+                       "rays_per_gpu": RAYS_PER_GPU, "grid": GRID, "samples_per_step": last["n_samples"],
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd (k_vm_bwd_brick + binning)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "launches": k_launches,
+                         "avg_launch_ms": k_ms / max(k_launches, 1), "bytes_per_sample": BWD_BYTES},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
