@@ -72,7 +72,9 @@ int nmf_march_count(const nmf_march_params* p, const float* rays /*[B][6]*/, int
  * else all rays valid.  totals[0] = M (kept samples of valid rays), totals[1] = b (valid rays; they
  * are always a prefix).  offsets has B+1 entries (entries past b are clamped to M). */
 int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
-                   uint8_t* whole_valid, int64_t* totals, void* stream);
+                   uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+int64_t nmf_march_scan_workspace_bytes(int64_t B);
 
 /* Pass 3: emit the compacted samples of the first b rays: xyzt [M][4] (world xyz, t/focal),
  * ray_id [M], step_id [M], z [M], dist [M] (= z[k+1]-z[k] over ALL candidates, 0 for the last,
@@ -190,6 +192,21 @@ int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, 
  * (modules/brdf.py:177-261 with feape=0, dotpe=-1, ListISH degs [0,1,2,4]; kappa = 1/(rough+1e-3)). */
 int nmf_brdf_features(const float* half_vec, const float* diff_vec, const float* feat_src,
                       const float* rough_src, const int32_t* src_idx, int64_t R, float* X, void* stream);
+/* Fused MLPBRDF (modules/brdf.py:177-261): out[r] = sigmoid(MLP(X[r])[0:3] + out_bias) with X as above and
+ * MLP = Linear(66,64) ReLU Linear(64,64) ReLU Linear(64,4) (weights row-major [out][in], torch layout).
+ * Dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).  Nothing but out [R][3] is written. */
+int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
+                     const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
+                     const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
+                     void* stream);
+/* Backward (recomputes the forward per 64-ray tile).  d_xfeat [R][24] = adjoint of the gathered feature
+ * columns (overwritten; reduce it per bounce point with nmf_segment_sum_wide); gW* / gb* are ACCUMULATED
+ * (caller zeroes): gW0 [64][66], gb0 [64], gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4]. */
+int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
+                     const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
+                     const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias,
+                     const float* d_out, float* d_xfeat, float* gW0, float* gb0, float* gW2, float* gb2,
+                     float* gW4, float* gb4, void* stream);
 /* out[s][0:D] = sum_{r in segment s} vals[r*row_stride + 0:D], D <= 64 (adjoint of the feature gather). */
 int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
                          int64_t n_seg, float* out, void* stream);

@@ -213,81 +213,109 @@ __global__ void k_alpha_pack(const float* __restrict__ vol, int64_t n, uint32_t*
     }
 }
 
-// Single-workgroup exclusive scan with the sample budget of alphagrid.py:353-364.
-__global__ void __launch_bounds__(1024) k_march_scan(const int32_t* __restrict__ counts, int64_t B, int64_t max_samples,
-                                                     int64_t* __restrict__ offsets, uint8_t* __restrict__ whole_valid,
-                                                     int64_t* __restrict__ totals) {
-    __shared__ int64_t wave_sums[16];
-    __shared__ int64_t s_carry;
-    __shared__ int64_t s_total;
-    __shared__ int64_t s_kept;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // pass A: total
-    int64_t local = 0;
-    for (int64_t i = tid; i < B; i += 1024) local += counts[i];
-    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
-    if (lane == 0) wave_sums[wid] = local;
+// Exclusive scan with the sample budget of alphagrid.py:353-364, three launches:
+//   k_scan_partial : sum of each 1024-element chunk
+//   k_scan_top     : one workgroup scans the chunk sums (<= 4096 chunks = 4 M elements), derives the total and
+//                    whether the budget is active, and initialises totals = {0, 0}
+//   k_scan_final   : every chunk scans itself, adds its base, applies the budget and finds (M, b)
+constexpr int SCAN_CHUNK = 1024;
+
+__global__ void __launch_bounds__(SCAN_CHUNK) k_scan_partial(const int32_t* __restrict__ counts, int64_t B,
+                                                             int64_t* __restrict__ chunk_sum) {
+    __shared__ int64_t ws[16];
+    const int64_t i = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    int64_t v = i < B ? counts[i] : 0;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         int64_t t = 0;
-        for (int w = 0; w < 16; ++w) t += wave_sums[w];
-        s_total = t;
-        s_carry = 0;
+        for (int w = 0; w < 16; ++w) t += ws[w];
+        chunk_sum[blockIdx.x] = t;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_top(int64_t* __restrict__ chunk_sum, int n_chunks, int64_t B,
+                                                   int64_t max_samples, int64_t* __restrict__ offsets,
+                                                   int64_t* __restrict__ totals, int64_t* __restrict__ meta) {
+    __shared__ int64_t ws[16];
+    __shared__ int64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    const bool budget = max_samples > 0 && s_total > max_samples;
-    int64_t kept_rays = 0, kept_samples = 0;
-    // pass B: chunked exclusive scan
-    for (int64_t base = 0; base < B; base += 1024) {
-        const int64_t i = base + tid;
-        int64_t v = i < B ? counts[i] : 0;
+    for (int base = 0; base < n_chunks; base += 1024) {
+        const int i = base + tid;
+        const int64_t v = i < n_chunks ? chunk_sum[i] : 0;
         int64_t incl = v;
         for (int d = 1; d < 64; d <<= 1) {
             int64_t t = __shfl_up(incl, d, 64);
             if (lane >= d) incl += t;
         }
-        if (lane == 63) wave_sums[wid] = incl;
+        if (lane == 63) ws[wid] = incl;
         __syncthreads();
         int64_t woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wave_sums[w];
-        const int64_t carry = s_carry;
-        const int64_t cum = carry + woff + incl;          // inclusive cumsum(counts)[i]
-        if (i < B) {
-            const bool ok = !budget || cum < max_samples;  // strict '<' (alphagrid.py:359)
-            whole_valid[i] = ok ? 1 : 0;
-            offsets[i] = cum - v;
-            if (ok) {
-                // valid rays form a prefix; the last valid ray defines (b, M)
-                if (i + 1 > kept_rays) { kept_rays = i + 1; kept_samples = cum; }
-            }
-        }
+        for (int w = 0; w < wid; ++w) woff += ws[w];
+        const int64_t excl = carry_s + woff + incl - v;
+        if (i < n_chunks) chunk_sum[i] = excl;           // becomes the chunk base
         __syncthreads();
-        if (tid == 1023) s_carry = cum;
+        if (tid == 1023) carry_s = excl + v;
         __syncthreads();
     }
-    // reduce (kept_rays, kept_samples) = max over threads
-    for (int d = 32; d > 0; d >>= 1) {
-        int64_t r2 = __shfl_down(kept_rays, d, 64), s2 = __shfl_down(kept_samples, d, 64);
-        if (r2 > kept_rays) { kept_rays = r2; kept_samples = s2; }
-    }
-    __shared__ int64_t red_r[16], red_s[16];
-    if (lane == 0) { red_r[wid] = kept_rays; red_s[wid] = kept_samples; }
-    __syncthreads();
     if (tid == 0) {
-        int64_t br = 0, bs = 0;
-        for (int w = 0; w < 16; ++w) if (red_r[w] > br) { br = red_r[w]; bs = red_s[w]; }
-        totals[0] = bs;
-        totals[1] = br;
-        offsets[B] = s_total;
-        s_kept = bs;
+        const int64_t total = carry_s;
+        const bool budget = max_samples > 0 && total > max_samples;
+        meta[0] = total;
+        meta[1] = budget ? 1 : 0;
+        offsets[B] = total;                              // clamped by k_scan_final when the budget is active
+        totals[0] = budget ? 0 : total;
+        totals[1] = budget ? 0 : B;
     }
+}
+
+__global__ void __launch_bounds__(SCAN_CHUNK) k_scan_final(const int32_t* __restrict__ counts, int64_t B,
+                                                           int64_t max_samples, const int64_t* __restrict__ chunk_base,
+                                                           const int64_t* __restrict__ meta,
+                                                           int64_t* __restrict__ offsets,
+                                                           uint8_t* __restrict__ whole_valid,
+                                                           int64_t* __restrict__ totals) {
+    __shared__ int64_t ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * SCAN_CHUNK + tid;
+    const int64_t v = i < B ? counts[i] : 0;
+    int64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) ws[wid] = incl;
     __syncthreads();
-    // clamp offsets of dropped rays to M so segment r of a dropped ray is empty
-    if (budget) {
-        const int64_t Mk = s_kept;
-        for (int64_t i = tid; i <= B; i += 1024)
-            if (offsets[i] > Mk) offsets[i] = Mk;
+    int64_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += ws[w];
+    const int64_t cum = chunk_base[blockIdx.x] + woff + incl;       // inclusive cumsum(counts)[i]
+    const bool budget = meta[1] != 0;
+    if (i < B) {
+        if (!budget) {
+            whole_valid[i] = 1;
+            offsets[i] = cum - v;
+        } else {
+            const bool ok = cum < max_samples;                          // strict '<' (alphagrid.py:359)
+            whole_valid[i] = ok ? 1 : 0;
+            // valid rays form a prefix; the last valid one defines (M, b)
+            const int64_t next = (i + 1 < B) ? cum + counts[i + 1] : max_samples;
+            if (ok && !(next < max_samples)) { totals[0] = cum; totals[1] = i + 1; }
+            // kept total M is the largest cum < max_samples; offsets of dropped rays are clamped to it below
+            offsets[i] = ok ? cum - v : -1;
+        }
     }
+}
+
+// budget active: offsets of dropped rays (marked -1) and offsets[B] become M
+__global__ void k_scan_clamp(int64_t* __restrict__ offsets, int64_t B, const int64_t* __restrict__ meta,
+                             const int64_t* __restrict__ totals) {
+    if (meta[1] == 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > B) return;
+    if (i == B || offsets[i] < 0) offsets[i] = totals[0];
 }
 
 }  // namespace
@@ -319,11 +347,27 @@ extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int
     return NMF_OK;
 }
 
+extern "C" int64_t nmf_march_scan_workspace_bytes(int64_t B) {
+    return (cdiv(B, SCAN_CHUNK) + 2) * (int64_t)sizeof(int64_t);
+}
+
 extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
-                              uint8_t* whole_valid, int64_t* totals, void* stream) {
+                              uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
     NMF_REQUIRE(counts && offsets && whole_valid && totals && B > 0, NMF_EINVAL, "nmf_march_scan: null/empty");
-    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, B, max_samples, offsets,
-                       whole_valid, totals);
+    const int64_t n_chunks = cdiv(B, SCAN_CHUNK);
+    NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_march_scan: B too large");
+    NMF_REQUIRE(workspace && workspace_bytes >= nmf_march_scan_workspace_bytes(B), NMF_EINVAL,
+                "nmf_march_scan: workspace too small (see nmf_march_scan_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t* chunk = (int64_t*)workspace;
+    int64_t* meta = chunk + n_chunks;
+    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk, (int)n_chunks, B, max_samples, offsets, totals,
+                       meta);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples, chunk,
+                       meta, offsets, whole_valid, totals);
+    hipLaunchKernelGGL(k_scan_clamp, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, st, offsets, B, meta, totals);
     NMF_CHECK_LAUNCH("nmf_march_scan");
     return NMF_OK;
 }

@@ -133,3 +133,25 @@ class BrdfFeatures(torch.autograd.Function):
         (row_offsets,) = ctx.saved_tensors
         d_feat = hip.segment_sum_wide(dX.contiguous(), 24, row_offsets, ctx.n_rows)
         return None, None, d_feat, None, None, None
+
+
+class BrdfMLP(torch.autograd.Function):
+    """sigmoid(MLP([feat | ISH(half) | half | ISH(diff) | diff])[:3] + bias) in one fused MFMA kernel
+    (modules/brdf.py:177-261).  Differentiable wrt the per-bounce-point feature rows and the six MLP tensors."""
+
+    @staticmethod
+    def forward(ctx, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, *weights):
+        hv, dv = half_vec.contiguous(), diff_vec.contiguous()
+        fr, rr = feat_rows.contiguous(), rough_rows.contiguous()
+        ws = [w.contiguous() for w in weights]
+        out = hip.brdf_mlp_fwd(ws, hv, dv, fr, rr, row_of_ray, out_bias)
+        ctx.save_for_backward(hv, dv, fr, rr, row_of_ray, row_offsets, *ws)
+        ctx.out_bias = out_bias
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        hv, dv, fr, rr, row_of_ray, row_offsets, *ws = ctx.saved_tensors
+        d_xfeat, grads = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out)
+        d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
+        return (None, None, d_feat, None, None, None, None) + tuple(grads)

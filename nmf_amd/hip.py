@@ -47,11 +47,12 @@ class VmParams(C.Structure):
 
 
 EXPORTS = [
-    "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan",
+    "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -59,6 +60,7 @@ for _n in EXPORTS:
 _lib.nmf_last_error_string.restype = C.c_char_p
 _lib.nmf_version.restype = C.c_int
 _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
+_lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 
 
 def version():
@@ -145,8 +147,10 @@ def march_scan(counts, max_samples):
     offsets = torch.empty(B + 1, dtype=torch.int64, device=counts.device)
     whole_valid = torch.empty(B, dtype=torch.uint8, device=counts.device)
     totals = torch.empty(2, dtype=torch.int64, device=counts.device)
+    nbytes = _lib.nmf_march_scan_workspace_bytes(C.c_int64(B))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=counts.device)
     _check(_lib.nmf_march_scan(_p(counts, torch.int32), C.c_int64(B), C.c_int64(max_samples), _p(offsets),
-                               _p(whole_valid), _p(totals), _stream()), "nmf_march_scan")
+                               _p(whole_valid), _p(totals), _p(ws), C.c_int64(nbytes), _stream()), "nmf_march_scan")
     return offsets, whole_valid, totals
 
 
@@ -362,3 +366,27 @@ def segment_sum_wide(vals, D, offsets, n_seg):
                                      _p(offsets, torch.int64), C.c_int64(n_seg), _p(out), _stream()),
            "nmf_segment_sum_wide")
     return out
+
+
+def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias):
+    """weights = (W0 [64,66], b0, W2 [64,64], b2, W4 [4,64], b4)"""
+    R = half_vec.shape[0]
+    out = torch.empty((R, 3), dtype=torch.float32, device=half_vec.device)
+    _check(_lib.nmf_brdf_mlp_fwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
+                                 _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
+                                 _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias), _p(out), _stream()),
+           "nmf_brdf_mlp_fwd")
+    return out
+
+
+def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out):
+    R = half_vec.shape[0]
+    dev = half_vec.device
+    d_xfeat = torch.empty((R, 24), dtype=torch.float32, device=dev)
+    grads = [torch.zeros_like(w) for w in weights]
+    _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
+                                 _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
+                                 _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias),
+                                 _p(d_out.contiguous(), torch.float32), _p(d_xfeat), *[_p(g) for g in grads], _stream()),
+           "nmf_brdf_mlp_bwd")
+    return d_xfeat, grads

@@ -5,7 +5,7 @@ dense layers are plain library GEMMs (rocBLAS through torch.nn.functional.linear
 import torch
 import torch.nn.functional as F
 
-from ..functional import BrdfFeatures
+from ..functional import BrdfFeatures, BrdfMLP
 from .util import create_mlp
 
 
@@ -37,8 +37,15 @@ class MLPBRDF(torch.nn.Module):
         self.h_encoder, self.d_encoder = h_encoder, d_encoder
         self.mlp = create_mlp(self.in_mlpC, 4, **kwargs)
         self.init_val = 0.25
+        self.fused = kwargs.get("hidden_w", 128) == 64 and kwargs.get("num_layers", 0) == 3
 
     def forward_compact(self, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
+        if self.fused:
+            m = self.mlp
+            return BrdfMLP.apply(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
+                                 row_of_ray, row_offsets, float(self.bias), m[0].weight, m[0].bias, m[2].weight,
+                                 m[2].bias, m[4].weight, m[4].bias)
+        # unfused path (library GEMMs), kept for A/B measurements: features from the HIP kernel + rocBLAS layers
         X = BrdfFeatures.apply(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
                                row_of_ray, row_offsets)
         out = self.mlp(X)

@@ -41,6 +41,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     p = hip.MarchParams()
     p.n_steps = 100000
     assert lib.nmf_march_count(C.byref(p), None, C.c_int64(1), None, None, None, None, None) == -2
+    assert lib.nmf_march_scan(None, C.c_int64(5), C.c_int64(-1), None, None, None, None, C.c_int64(0), None) == -1
     assert lib.nmf_segment_sum(None, None, None, C.c_int64(0), C.c_int32(3), None, None) == 0   # empty is ok
     assert lib.nmf_composite_fwd(None, None, None, C.c_int64(4), C.c_float(25.0), None, None, None) == -1
 

@@ -362,3 +362,80 @@ def test_env_lookup_full_size_properties():
     big = sa > -4        # wide footprints: cancellation noise is small
     assert float((v.cpu()[big] - target).abs().max()) < 2e-2 * target
     assert abs(float(v.cpu()[big].mean()) - target) < 1e-3 * target
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R", [1, 257, 5000])
+def test_brdf_mlp_fused_matches_oracle(R):
+    hip = _hip()
+    from nmf_amd.functional import BrdfMLP
+    g = Golden("shading_parts")
+    gen = torch.Generator().manual_seed(R)
+    sd = {"model.brdf.mlp." + k[len("brdf_param/mlp."):]: g[k].clone().requires_grad_(True) for k in g.keys("brdf_param/")}
+    Mb = max(R // 7, 1)
+    counts = torch.ones(Mb, dtype=torch.int64)
+    extra = R - Mb
+    if extra > 0:
+        counts += torch.bincount(torch.randint(0, Mb, (extra,), generator=gen), minlength=Mb)
+    row_off = torch.zeros(Mb + 1, dtype=torch.int64)
+    row_off[1:] = counts.cumsum(0)
+    rows = torch.repeat_interleave(torch.arange(Mb), counts)
+    hv = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    dv = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    feat = torch.randn(Mb, 24, generator=gen).requires_grad_(True)
+    rough = torch.rand(Mb, generator=gen) * 0.49 + 0.01
+    cfg = O.Cfg(brdf_bias=0.37)
+    ref = O.brdf_mlp(sd, cfg, hv, dv, feat[rows], rough[rows])
+    c = torch.randn(R, 3, generator=gen)
+    names = list(sd)
+    gref = torch.autograd.grad((ref * c).sum(), [feat] + [sd[k] for k in names])
+    # HIP
+    order = ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+    ws = [sd["model.brdf.mlp." + k].detach().to(DEV).requires_grad_(True) for k in order]
+    feat_d = feat.detach().to(DEV).requires_grad_(True)
+    out = BrdfMLP.apply(hv.to(DEV), dv.to(DEV), feat_d, rough.to(DEV), rows.int().to(DEV), row_off.to(DEV), 0.37, *ws)
+    assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="brdf mlp out")
+    gh = torch.autograd.grad((out * c.to(DEV)).sum(), [feat_d] + ws)
+    assert_close(gh[0].cpu(), gref[0], rtol=1e-4, atol=1e-5 * float(gref[0].abs().max() + 1), what="d feat")
+    for k, gq in zip(order, gh[1:]):
+        r = gref[1 + names.index("model.brdf.mlp." + k)]
+        assert_close(gq.cpu(), r, rtol=2e-4, atol=2e-5 * float(r.abs().max() + 1e-3), what="d " + k)
+    if R == 257:      # golden (reference) values for exactly this input set
+        w = BrdfMLP.apply(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
+                          g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
+                          torch.arange(258, dtype=torch.int64, device=DEV), g["brdf_bias"], *[x.detach() for x in ws])
+        assert_close(w.cpu(), g["brdf_out"], rtol=1e-5, atol=1e-6, what="brdf vs reference")
+
+
+def test_select_bounces_golden_bit_exact():
+    hip = _hip()
+    g = Golden("shading_parts")
+    w_, am = g["sel_weights"], g["sel_app_mask"]
+    wk = w_[am].to(DEV).contiguous()
+
+    def check(counts, bounce, ray_mask):
+        c = counts.cpu().long()
+        assert torch.equal(c > 0, bounce)
+        assert torch.equal(c[c > 0], ray_mask.sum(1))
+        m = ray_mask.shape[1]
+        assert torch.equal(torch.arange(m)[None] < c[c > 0][:, None], ray_mask)      # rows are prefixes
+
+    check(hip.select_bounces(wk, g["sel0_u"].to(DEV).contiguous(), 0, 128.0), g["sel0_bounce"], g["sel0_ray_mask"])
+    for tag in ("sel1", "sel2"):
+        U = g[tag + "_u"]
+        wp = w_ + 1e-3 * U
+        S = float(wp.sum().clip(min=1e-3))
+        num = g[tag + "_num"]
+        N = num - int(am.sum())
+        mul, add = (float(N), 1.0) if N > 0 else (float(num), 0.5)
+        cnt = hip.select_bounces(wk, U[am].to(DEV).contiguous(), 1, mul, add, S)
+        check(cnt, g[tag + "_bounce"], g[tag + "_ray_mask"])
+    # expand_segments == torch.where(ray_mask)
+    c = hip.select_bounces(wk, g["sel0_u"].to(DEV).contiguous(), 0, 128.0)
+    off, _, tot = hip.march_scan(c, -1)
+    seg, loc = hip.expand_segments(off, c.shape[0], int(tot[0]))
+    cb = c.cpu().long()
+    ri = torch.repeat_interleave(torch.arange(cb.shape[0]), cb)
+    assert torch.equal(seg.cpu().long(), ri)
+    rj = torch.cat([torch.arange(int(n)) for n in cb]) if int(cb.sum()) else torch.zeros(0, dtype=torch.long)
+    assert torch.equal(loc.cpu().long(), rj)
