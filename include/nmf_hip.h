@@ -188,6 +188,15 @@ int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t 
 /* seg_id[r] / local[r] for r in [offsets[i], offsets[i+1]) = i / r - offsets[i]  (= torch.where(ray_mask)). */
 int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, int32_t* local,
                         void* stream);
+/* RandHydraMLPDiffuse heads (modules/render_modules.py:519-574; pospe=-1, feape=0, one Linear each, std=0):
+ * out [M][11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied; W [11][24] / b [11] are
+ * the four Linear layers stacked in that order. */
+int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
+                  float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, float* out, void* stream);
+/* d_feat [M][24] overwritten; gW [11][24], gb [11] ACCUMULATED (caller zeroes). */
+int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
+                  float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, const float* d_out,
+                  float* d_feat, float* gW, float* gb, void* stream);
 /* MLPBRDF input rows X [R][66] = [feat_src[src_idx[r]] | ISH(half) | half | ISH(diff) | diff]
  * (modules/brdf.py:177-261 with feape=0, dotpe=-1, ListISH degs [0,1,2,4]; kappa = 1/(rough+1e-3)). */
 int nmf_brdf_features(const float* half_vec, const float* diff_vec, const float* feat_src,

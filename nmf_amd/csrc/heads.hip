@@ -1,0 +1,159 @@
+// Material heads for gfx950: the four single-layer heads of RandHydraMLPDiffuse
+// (reference: modules/render_modules.py:519-574 with pospe=-1, feape=0, num_layers=1, std=0) evaluated
+// as ONE 24 -> 11 product per kept sample with the activations fused:
+//   albedo = clip(sigmoid(diffuse_mul * a[0:3] + diffuse_bias), 0, 1)      tint = sigmoid(a[3:6] + tint_bias)
+//   f0     = sigmoid(a[6:9] + f0_bias)                                     r = clip(sigmoid(a[9:11] + rough_bias)/2, 0.01, 1)
+// rocBLAS runs these N=3 GEMMs over ~1 M samples at ~1.6 ms each (12 calls per level, profiles/r01_b);
+// here the forward is one streaming pass and the weight gradient is reduced per workgroup through LDS.
+#include "common.hpp"
+
+namespace {
+
+constexpr int F = NMF_APP_DIM;   // 24
+constexpr int O = 11;
+
+struct HeadP {
+    float diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ void load_feat(const float* __restrict__ feat, int64_t m, float (&f)[F]) {
+    const float4* q = reinterpret_cast<const float4*>(feat + m * F);
+#pragma unroll
+    for (int i = 0; i < F / 4; ++i) {
+        const float4 v = q[i];
+        f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+    }
+}
+
+// W [11][24] row-major (rows: diffuse 0-2, tint 3-5, f0 6-8, roughness 9-10), b [11]
+__global__ void __launch_bounds__(256) k_heads_fwd(const float* __restrict__ feat, int64_t M, const float* __restrict__ W,
+                                                   const float* __restrict__ b, HeadP hp, float* __restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float f[F];
+    load_feat(feat, m, f);
+    float* o = out + m * O;
+#pragma unroll
+    for (int j = 0; j < O; ++j) {
+        float a = b[j];
+#pragma unroll
+        for (int k = 0; k < F; ++k) a += W[j * F + k] * f[k];          // uniform addresses -> scalar loads
+        float v;
+        if (j < 3) v = fminf(fmaxf(sigm(hp.diffuse_mul * a + hp.diffuse_bias), 0.f), 1.f);
+        else if (j < 6) v = sigm(a + hp.tint_bias);
+        else if (j < 9) v = sigm(a + hp.f0_bias);
+        else v = fminf(fmaxf(sigm(a + hp.rough_bias) * 0.5f, 1e-2f), 1.f);
+        o[j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ feat, int64_t M, const float* __restrict__ W,
+                                                   const float* __restrict__ b, HeadP hp,
+                                                   const float* __restrict__ d_out, float* __restrict__ d_feat,
+                                                   float* __restrict__ gW, float* __restrict__ gb) {
+    __shared__ float s_da[256 * (O + 1)];
+    __shared__ float s_f[256 * (F + 1)];
+    const int t = threadIdx.x;
+    // gW has 11*24 = 264 entries: thread t owns entry t and (t < 8) entry t + 256; thread t < 11 owns gb[t]
+    const int oi0 = t / F, fj0 = t % F, oi1 = (t + 256) / F, fj1 = (t + 256) % F;
+    float acc = 0.f, acc1 = 0.f, accb = 0.f;
+    const int64_t n_it = (M + 255) / 256;
+    for (int64_t it = blockIdx.x; it < n_it; it += gridDim.x) {
+        const int64_t m = it * 256 + t;
+        float f[F], da[O];
+        if (m < M) {
+            load_feat(feat, m, f);
+#pragma unroll
+            for (int j = 0; j < O; ++j) {
+                float a = b[j];
+#pragma unroll
+                for (int k = 0; k < F; ++k) a += W[j * F + k] * f[k];
+                const float g = d_out[m * O + j];
+                float d;
+                if (j < 3) {
+                    const float s = sigm(hp.diffuse_mul * a + hp.diffuse_bias);
+                    d = g * s * (1.f - s) * hp.diffuse_mul;             // clip(0,1) never binds on a sigmoid
+                } else if (j < 9) {
+                    const float s = sigm(a + (j < 6 ? hp.tint_bias : hp.f0_bias));
+                    d = g * s * (1.f - s);
+                } else {
+                    const float s = sigm(a + hp.rough_bias);
+                    const float r = 0.5f * s;
+                    d = (r >= 1e-2f && r <= 1.f) ? g * 0.5f * s * (1.f - s) : 0.f;
+                }
+                da[j] = d;
+            }
+            float df[F];
+#pragma unroll
+            for (int k = 0; k < F; ++k) df[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < O; ++j)
+#pragma unroll
+                for (int k = 0; k < F; ++k) df[k] += da[j] * W[j * F + k];
+            float4* q = reinterpret_cast<float4*>(d_feat + m * F);
+#pragma unroll
+            for (int i = 0; i < F / 4; ++i) q[i] = make_float4(df[4 * i], df[4 * i + 1], df[4 * i + 2], df[4 * i + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < F; ++k) f[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < O; ++j) da[j] = 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < O; ++j) s_da[t * (O + 1) + j] = da[j];
+#pragma unroll
+        for (int k = 0; k < F; ++k) s_f[t * (F + 1) + k] = f[k];
+        __syncthreads();
+        {
+            float a = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + oi0] * s_f[s * (F + 1) + fj0];
+            acc += a;
+        }
+        if (t < O * F - 256) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + oi1] * s_f[s * (F + 1) + fj1];
+            acc1 += a;
+        }
+        if (t < O) {
+            float a = 0.f;
+            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + t];
+            accb += a;
+        }
+    }
+    atomicAdd(gW + t, acc);
+    if (t < O * F - 256) atomicAdd(gW + t + 256, acc1);
+    if (t < O) atomicAdd(gb + t, accb);
+}
+
+}  // namespace
+
+extern "C" int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
+                             float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, float* out,
+                             void* stream) {
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_heads_fwd: M < 0");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(feat && W && b && out, NMF_EINVAL, "nmf_heads_fwd: null");
+    HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
+    hipLaunchKernelGGL(k_heads_fwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, out);
+    NMF_CHECK_LAUNCH("nmf_heads_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
+                             float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, const float* d_out,
+                             float* d_feat, float* gW, float* gb, void* stream) {
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_heads_bwd: M < 0");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(feat && W && b && d_out && d_feat && gW && gb, NMF_EINVAL, "nmf_heads_bwd: null");
+    HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
+    const int64_t n_it = cdiv(M, 256);
+    const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
+    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat, gW, gb);
+    NMF_CHECK_LAUNCH("nmf_heads_bwd");
+    return NMF_OK;
+}

@@ -155,3 +155,23 @@ class BrdfMLP(torch.autograd.Function):
         d_xfeat, grads = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
         return (None, None, d_feat, None, None, None, None) + tuple(grads)
+
+
+class MaterialHeads(torch.autograd.Function):
+    """(albedo | tint | f0 | roughness) [M,11] from the app features (modules/render_modules.py:519-574)."""
+
+    @staticmethod
+    def forward(ctx, feat, hp, wd, bd, wt, bt, wf, bf, wr, br):
+        W = torch.cat([wd, wt, wf, wr], 0).contiguous()
+        b = torch.cat([bd, bt, bf, br], 0).contiguous()
+        feat_c = feat.contiguous()
+        out = hip.heads_fwd(feat_c, W, b, hp)
+        ctx.save_for_backward(feat_c, W, b)
+        ctx.hp = hp
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        feat, W, b = ctx.saved_tensors
+        d_feat, gW, gb = hip.heads_bwd(feat, W, b, ctx.hp, d_out)
+        return (d_feat, None, gW[0:3], gb[0:3], gW[3:6], gb[3:6], gW[6:9], gb[6:9], gW[9:11], gb[9:11])

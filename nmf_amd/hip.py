@@ -52,7 +52,7 @@ EXPORTS = [
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
-    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -390,3 +390,22 @@ def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_
                                  _p(d_out.contiguous(), torch.float32), _p(d_xfeat), *[_p(g) for g in grads], _stream()),
            "nmf_brdf_mlp_bwd")
     return d_xfeat, grads
+
+
+def heads_fwd(feat, W, b, hp):
+    """hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)"""
+    M = feat.shape[0]
+    out = torch.empty((M, 11), dtype=torch.float32, device=feat.device)
+    _check(_lib.nmf_heads_fwd(_p(feat, torch.float32), C.c_int64(M), _p(W, torch.float32), _p(b, torch.float32),
+                              *[C.c_float(v) for v in hp], _p(out), _stream()), "nmf_heads_fwd")
+    return out
+
+
+def heads_bwd(feat, W, b, hp, d_out):
+    M = feat.shape[0]
+    d_feat = torch.empty_like(feat)
+    gW, gb = torch.zeros_like(W), torch.zeros_like(b)
+    _check(_lib.nmf_heads_bwd(_p(feat, torch.float32), C.c_int64(M), _p(W, torch.float32), _p(b, torch.float32),
+                              *[C.c_float(v) for v in hp], _p(d_out.contiguous(), torch.float32), _p(d_feat), _p(gW),
+                              _p(gb), _stream()), "nmf_heads_bwd")
+    return d_feat, gW, gb

@@ -3,6 +3,7 @@
 These are 24x11 products per sample (plain library GEMMs through torch.nn.functional.linear)."""
 import torch
 
+from ..functional import MaterialHeads
 from .util import create_mlp
 
 
@@ -29,6 +30,14 @@ class RandHydraMLPDiffuse(torch.nn.Module):
         self.roughness_mlp = create_mlp(self.in_mlpC, 2, **(roughness_cfg if roughness_cfg is not None else kwargs))
 
     def forward(self, pts, viewdirs, features, std=0, **kwargs):
+        if features.is_cuda and features.shape[0] > 0:
+            hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
+                  float(self.roughness_bias))
+            o = MaterialHeads.apply(features, hp, self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias,
+                                    self.tint_mlp[0].weight, self.tint_mlp[0].bias, self.f0_mlp[0].weight,
+                                    self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
+            diffuse, tint, f0, r = o[:, 0:3], o[:, 3:6], o[:, 6:9], o[:, 9:11]
+            return diffuse, tint, dict(diffuse=diffuse, r1=r[:, 0:1], r2=r[:, 1:2], f0=f0, tint=tint)
         diffuse = torch.sigmoid(self.diffuse_mul * self.diffuse_mlp(features) + self.diffuse_bias).clip(min=0, max=1)
         r = (torch.sigmoid(self.roughness_mlp(features) + self.roughness_bias) / 2).clip(min=1e-2, max=1)
         tint = torch.sigmoid(self.tint_mlp(features) + self.tint_bias)

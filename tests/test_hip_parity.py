@@ -439,3 +439,26 @@ def test_select_bounces_golden_bit_exact():
     assert torch.equal(seg.cpu().long(), ri)
     rj = torch.cat([torch.arange(int(n)) for n in cb]) if int(cb.sum()) else torch.zeros(0, dtype=torch.long)
     assert torch.equal(loc.cpu().long(), rj)
+
+
+@pytest.mark.parametrize("M", [1, 100, 70001])
+def test_material_heads_fused(M):
+    from nmf_amd.functional import MaterialHeads
+    g = Golden("shading_parts")
+    gen = torch.Generator().manual_seed(M)
+    sdh = {"model.diffuse_module." + k[len("heads_param/"):]: g[k].clone().requires_grad_(True) for k in g.keys("heads_param/")}
+    feat = (g["heads_feat"][:M] if M <= 100 else torch.randn(M, 24, generator=gen) * 2).clone().requires_grad_(True)
+    cfg = O.Cfg(diffuse_bias=-0.4, roughness_bias=-0.7, tint_bias=0.1, f0_bias=-0.2)
+    albedo, tint, f0, rr = O.material_heads(sdh, cfg, feat)
+    ref = torch.cat([albedo, tint, f0, rr], 1)
+    c = torch.randn(ref.shape, generator=gen)
+    order = ["diffuse", "tint", "f0", "roughness"]
+    ps = [sdh[f"model.diffuse_module.{n}_mlp.0.{w}"] for n in order for w in ("weight", "bias")]
+    gref = torch.autograd.grad((ref * c).sum(), [feat] + ps)
+    feat_d = feat.detach().to(DEV).requires_grad_(True)
+    ps_d = [p.detach().to(DEV).requires_grad_(True) for p in ps]
+    out = MaterialHeads.apply(feat_d, (cfg.diffuse_mul, cfg.diffuse_bias, cfg.tint_bias, cfg.f0_bias, cfg.roughness_bias), *ps_d)
+    assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="heads out")
+    gh = torch.autograd.grad((out * c.to(DEV)).sum(), [feat_d] + ps_d)
+    for a, b, n in zip(gh, gref, ["feat"] + [f"{x}.{w}" for x in order for w in ("W", "b")]):
+        assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max() + 1e-3), what="heads grad " + n)
