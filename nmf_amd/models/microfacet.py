@@ -10,7 +10,7 @@ import torch
 from .. import hip
 from ..functional import segment_sum
 from ..modules import sh
-from ..brdf_samplers.ggx import normalize
+from ..brdf_samplers.ggx import mat3T_vec, normalize
 
 
 class Microfacet(torch.nn.Module):
@@ -140,9 +140,8 @@ class Microfacet(torch.nn.Module):
             L, basisT, lpdf = self.brdf_sampler.sample_compact(angs[:, 0], angs[:, 1], bV, bN, r1, row_of_ray)
             eV, eN = bV[rows], bN[rows]
             H = normalize((eV + L) / 2)                                                             # :388
-            basis_rows = basisT.permute(0, 2, 1)
-            diffvec = torch.matmul(basis_rows, L.unsqueeze(-1)).squeeze(-1)
-            halfvec = torch.matmul(basis_rows, H.unsqueeze(-1)).squeeze(-1)
+            diffvec = mat3T_vec(basisT, L)                     # basis rows . L  (models/microfacet.py:406)
+            halfvec = mat3T_vec(basisT, H)
             ecount = cnt_b.float()[rows]
             mipval = -torch.log(ecount.clip(min=1)) - lpdf                                          # :448
             bounce_rays = torch.cat([samples.xyzt[bidx][:, :3][rows] + L * 5e-3, L], dim=-1)         # :450

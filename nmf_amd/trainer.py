@@ -26,6 +26,13 @@ def psnr_8bit(pred, gt):
     return -10.0 * torch.log10(((q - gt.clip(0, 1)) ** 2).mean())
 
 
+def rank_slice(n_total, world_size, rank):
+    """Contiguous, disjoint, complete partition of a global ray batch over ranks (first ranks take the remainder)."""
+    base, rem = divmod(n_total, world_size)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
+
+
 class FlatGradAllReduce:
     """One collective per optimizer step: gradients are packed into a flat fp32 buffer (14 MB at 128^3, 50 MB at
     300^3), summed over ranks (RCCL over xGMI when backend='nccl', gloo on CPU) and unpacked.  A single bucket:

@@ -1,0 +1,80 @@
+"""Data-parallel plumbing on CPU: world_size-2 gloo processes exercise the flat-gradient all-reduce and the
+ray sharding used by nmf_amd/trainer.py (the HIP compute itself needs a GPU and is covered by -m gpu tests)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_amd.trainer import FlatGradAllReduce, rank_slice
+    torch.manual_seed(0)                       # identical replicas
+    params = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)),
+              torch.nn.Parameter(torch.randn(1, 4, 6, 6).contiguous(memory_format=torch.channels_last)),
+              torch.nn.Parameter(torch.tensor(1.0, dtype=torch.float64)), torch.nn.Parameter(torch.randn(2))]
+    rays = torch.arange(10 * 6, dtype=torch.float32).reshape(10, 6)
+    mine = rays[rank_slice(10, world, rank)]
+    # a "loss" whose gradient depends on the local shard only; params[4] gets no gradient at all
+    loss = (params[0].sum() * mine.sum() + (params[1] ** 2).sum() * (rank + 1) + params[2].mean() * mine[:, 0].sum()
+            + params[3] * float(mine.shape[0]))
+    loss.backward()
+    local = [p.grad.clone() if p.grad is not None else None for p in params]
+    nbytes = FlatGradAllReduce(params)()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    ok = nbytes == 4 * sum(p.numel() for p in params[:4])
+    for i, p in enumerate(params[:4]):
+        want = sum(g[i].double() for g in gathered)
+        ok &= bool(torch.allclose(p.grad.double(), want, rtol=1e-6, atol=1e-6))
+        ok &= p.grad.shape == p.shape and p.grad.dtype == p.dtype
+    ok &= params[4].grad is None
+    ok &= params[2].grad.is_contiguous(memory_format=torch.channels_last)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_rank_slice_partitions_every_batch():
+    from nmf_amd.trainer import rank_slice
+    for n in (0, 1, 7, 4096, 32768 * 8 + 3):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                s = rank_slice(n, w, r)
+                seen += list(range(n))[s] if n < 100 else [(s.start, s.stop)]
+            if n < 100:
+                assert seen == list(range(n))
+            else:
+                assert seen[0][0] == 0 and seen[-1][1] == n and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+
+
+def test_single_process_is_a_noop():
+    from nmf_amd.trainer import FlatGradAllReduce
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.ones(3)
+    assert FlatGradAllReduce([p])() == 0 and torch.equal(p.grad, torch.ones(3))

@@ -262,3 +262,33 @@ def test_psnr_formula():
     q = torch.floor(pred.clip(0, 1) * 255) / 255
     want = -10 * math.log10(float(((q - gt) ** 2).mean()))
     assert abs(float(O.psnr_8bit(pred, gt)) - want) < 1e-5
+
+
+def test_full_size_replay_by_seed():
+    """BASELINE size (4096 rays, 128^3, 512x1024 env): the reference's noise is re-created from torch's seeded
+    global CPU generator (same call order and shapes, unused draws included); only per-ray outputs, counts and
+    gradient norms are stored in the fixture."""
+    g = Golden("e2e_full_seeded")
+    G, BG, B = g["grid"], g["bg_res"], g["n_rays"]
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
+    for k, v in sd.items():
+        if k != "model.brdf_sampler.angs":
+            v.requires_grad_(True)
+    cfg = O.Cfg(grid=G, detach_N=False)
+    vol = O.dense_alpha_mask({k: v.detach() for k, v in sd.items()}, cfg)
+    assert int(vol.sum()) == g["n_alpha"]
+    rays, focal = synthetic.camera_rays(B, seed=0)
+    torch.manual_seed(g["noise_seed"])
+    ims, st = O.render(sd, cfg, rays, focal, vol, O.Noise(draw_unused=True), is_train=True, bg_col=torch.ones(3))
+    assert list(st["n_samples"]) == list(g.np("n_samples"))
+    assert torch.equal(st["whole_valid"], g["whole_valid"])
+    assert_close(ims["rgb_map"], g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
+    assert_close(ims["acc_map"], g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
+    gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(9))
+    total, loss = O.training_loss(ims, st, gt, 4096, sd)
+    assert_close(loss, g["loss"], rtol=1e-5, what="loss")
+    total.backward()
+    for k in g.keys("gradnorm/"):
+        name = k[len("gradnorm/"):]
+        ref = float(g[k])
+        assert abs(float(sd[name].grad.norm()) - ref) <= 2e-3 * ref + 1e-12, (name, float(sd[name].grad.norm()), ref)
