@@ -44,7 +44,7 @@ class Microfacet(torch.nn.Module):
         self.mean_ratios = None
         self.ratio_list = None
         self.trace = None            # tests: dict that receives intermediate tensors
-        self.forced = None           # tests: {'retrace_order<recur>': LongTensor} overrides the argsort below
+        self.forced = None           # tests: {'retrace_order<r>': LongTensor, 'counts<r>': IntTensor} pin bookkeeping decisions
 
     # ---- controllers / bookkeeping (models/microfacet.py:79-121,236-269) --------------------------------
     def calibrate(self, args, xyz, feat, bg_brightness, save_config=True):
@@ -116,6 +116,12 @@ class Microfacet(torch.nn.Module):
                 counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, float(total))
             else:
                 counts = hip.select_bounces(w_det, u.contiguous(), 1, float(self.max_brdf_rays[recur]), 0.5, float(total))
+        if self.trace is not None:
+            self.trace[f"counts_own{recur}"] = counts
+        if self.forced is not None and f"counts{recur}" in self.forced and self.forced[f"counts{recur}"].shape[0] == M:
+            counts = self.forced[f"counts{recur}"].to(dev).int().contiguous()
+        if self.trace is not None:
+            self.trace[f"counts{recur}"] = counts
         ray_off, _, tot = hip.march_scan(counts, -1)
         R = int(tot[0])
         zeros3 = torch.zeros_like(diffuse)

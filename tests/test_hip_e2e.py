@@ -52,6 +52,14 @@ def _pin_retrace_decision(nerf, trace):
     jitter row.  The decision is bookkeeping ("bit-exact GIVEN the scores"), so the e2e radiance
     comparison pins it to the oracle's order; the scores themselves are compared separately below."""
     nerf.model.forced = {"retrace_order0": trace["retrace_order0"]}
+    # bounce counts are floor(w*128 + U - 0.5): w differs from the CPU in the last bits (expf), so at 170 k samples
+    # one or two floors flip, which shifts every later ray index.  Pinned as well; the kernel that computes them is
+    # bit-exact on equal inputs (test_select_bounces_golden_bit_exact) and the pinned counts are compared below.
+    for lvl in (0, 1):
+        if f"bounce_mask{lvl}" in trace:
+            c = torch.zeros(trace[f"bounce_mask{lvl}"].shape[0], dtype=torch.int32)
+            c[trace[f"bounce_mask{lvl}"]] = trace[f"ray_mask{lvl}"].sum(1).int()
+            nerf.model.forced[f"counts{lvl}"] = c
     nerf.model.trace = {}
 
 
@@ -171,6 +179,9 @@ def test_e2e_full_size_seeded_vs_reference():
     ims, st = nerf(rays.to(DEV), focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=ReplayNoise(DEV, None))
     assert list(st["n_samples"]) == list(g.np("n_samples"))
     assert torch.equal(st["whole_valid"].cpu(), g["whole_valid"])
+    # the HIP path's own bounce counts vs the pinned (reference) ones: only last-bit floor() flips may differ
+    own, pinned = nerf.model.trace["counts_own0"].cpu(), nerf.model.forced["counts0"]
+    assert int((own != pinned).sum()) <= 8 and int((own - pinned).abs().max()) <= 1, int((own != pinned).sum())
     assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     assert_close(ims["rgb_map"].detach().cpu(), g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
     gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(9)).to(DEV)
