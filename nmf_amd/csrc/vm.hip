@@ -318,9 +318,9 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 // ~14 G atomics/s on MI355X -- device-scope float atomics execute at the memory side -- i.e. ~90 ms
 // for the 1.1 M samples of a steady-state step.  Instead the samples are counting-sorted by the
 // 8x8x8-voxel brick of their lower corner (k_brick_hist / k_scan_bins / k_brick_scatter); one
-// workgroup then owns one brick, accumulates every gradient that brick can touch -- three 9x9
-// plane tiles (density: 48 ch, appearance: 24 ch) and three 9-entry line segments -- in 76 KB of
-// LDS with ds_add_f32, and flushes the non-zero entries once (~80x fewer global atomics).
+// workgroup then owns one brick and accumulates every gradient that brick can touch -- three 9x9
+// plane tiles (density: 48 ch, appearance: 24 ch) and three 9-entry line segments -- ON THE MATRIX
+// CORES (see k_vm_bwd_brick), flushing the non-zero entries once (~80x fewer global atomics).
 // ------------------------------------------------------------------------------------------------
 constexpr int BR = 8;             // brick edge in texels
 constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
@@ -383,12 +383,45 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
     if (tid == 0) offsets[n] = carry_s;
 }
 
-__global__ void __launch_bounds__(256) k_brick_scatter(const int32_t* __restrict__ brick_id, int64_t M,
-                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+// Scatter into brick order.  Besides the permutation, the per-sample inputs of the backward walk are written in
+// SORTED order so that the brick kernels stream them without an indirection: rec0 = xyzt, rec1 = (adjoint of the raw
+// density feature, adjoint of the raw density gradient in normalised-coordinate units).  The softplus / normalize
+// backward is evaluated here, once per sample, fully parallel.
+__global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const float4* __restrict__ xyzt,
+                                                       const int32_t* __restrict__ brick_id, int64_t M,
+                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
+                                                       const float* __restrict__ sigma_feat,
+                                                       const float* __restrict__ grad, const float* __restrict__ d_sigma,
+                                                       const float* __restrict__ d_sigma_feat,
+                                                       const float* __restrict__ d_normal, float4* __restrict__ rec0,
+                                                       float4* __restrict__ rec1) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int pos = atomicAdd(cursor + brick_id[m], 1);
     perm[pos] = (int32_t)m;
+    rec0[pos] = xyzt[m];
+    float dsf = d_sigma_feat ? d_sigma_feat[m] : 0.f;
+    if (d_sigma) {
+        const float f = sigma_feat[m];
+        const float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
+        float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));          // softplus'
+        if (f < -15.f || f > 1e3f) ds = 0.f;                         // clamp'
+        dsf += d_sigma[m] * ds;
+    }
+    float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
+    if (d_normal) {   // through n = -g / sqrt(max(|g|^2, eps))
+        const float g0 = grad[m * 3], g1 = grad[m * 3 + 1], g2 = grad[m * 3 + 2];
+        const float dn0 = d_normal[m * 3], dn1 = d_normal[m * 3 + 1], dn2 = d_normal[m * 3 + 2];
+        const float n2 = g0 * g0 + g1 * g1 + g2 * g2;
+        const float eps = 1.1920929e-07f;
+        const float inv = 1.f / sqrtf(fmaxf(n2, eps));
+        const float dot = dn0 * g0 + dn1 * g1 + dn2 * g2;
+        const float kk = n2 > eps ? dot * inv * inv * inv : 0.f;
+        dg0 = (-dn0 * inv + kk * g0) * p.inv_size[0];
+        dg1 = (-dn1 * inv + kk * g1) * p.inv_size[1];
+        dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
+    }
+    rec1[pos] = make_float4(dsf, dg0, dg1, dg2);
 }
 
 // uniform (per-sample) footprint: global texel index or -1, tile-local cell, weight
@@ -416,210 +449,252 @@ __device__ __forceinline__ LTap2 make_ltap2(float u, float v, int G, int ox, int
     return t;
 }
 
-constexpr int LDS_DP = 3 * TL * TL * DP;   // 11664 floats
-constexpr int LDS_DL = 3 * TL * DL;        //   864
-constexpr int LDS_AP = 3 * TL * TL * CA;   //  5832
-constexpr int LDS_AL = 3 * TL * CA;        //   648
-constexpr int LDS_TOTAL = LDS_DP + LDS_DL + LDS_AP + LDS_AL;   // 19008 floats = 76 KB
-constexpr int BWD_THREADS = 512;
-constexpr int BWD_WAVES = BWD_THREADS / 64;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// One workgroup per brick; each WAVE walks samples of the brick one at a time and its LANES are the
-// channels of a tap (density: 48 = P|DX|DY, appearance: 24).  Consequences:
-//   * every table read is one coalesced 96..192-byte run per tap,
-//   * the LDS accumulators are [cell][channel]: the 24..48 active lanes of a ds_add_f32 hit
-//     consecutive banks, so the atomic is conflict-free (a lane-per-sample mapping serialised
-//     up to 64 ways on hot texels and ran at 0.1 LDS atomics/clk/CU -- measured 19.7 ms / 1 M samples),
-//   * per-sample scalars (taps, adjoints) are wave-uniform.
-__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(
-    nmf_vm_params p, const float4* __restrict__ xyzt, const int32_t* __restrict__ perm,
-    const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
-    const float* __restrict__ basis, const float* __restrict__ sigma_feat, const float* __restrict__ grad,
-    const float* __restrict__ d_sigma, const float* __restrict__ d_sigma_feat, const float* __restrict__ d_normal,
-    const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk, MPtrs3 g_apl, MPtrs3 g_ali) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+constexpr int BWD_WAVES = 3;                 // one wave per plane/line pair
+constexpr int BWD_THREADS = BWD_WAVES * 64;
+constexpr int NRB = 6;                       // 81 tile cells -> 6 row blocks of 16
+constexpr int BWD_CHUNK = 256;               // samples per (brick, part) work item
+constexpr int BWD_PARTS = 8;
+
+// Scatter-add on the matrix cores.
+//
+// Inside one 8^3 brick every gradient tile is small and dense (a 9x9 plane tile x 48 / 24 channels, a 9-entry line
+// segment x 32 / 24 channels), and the update   G[cell][ch] += w(sample, cell) * adj(sample, ch)   is the product of a
+// sparse [cells x samples] weight matrix (4 non-zeros per column) with a dense [samples x channels] adjoint matrix.
+// LDS float atomics run at ~0.2 lane-ops/clk/CU on gfx950 (measured: 17 ms per 1 M samples, 36 ds_add_f32 per sample),
+// so the accumulation is done with v_mfma_f32_16x16x4_f32 instead: exact fp32, K = 4 samples per instruction, the
+// 18 (+2) accumulator tiles of a plane live in VGPRs for the whole work item, no LDS and no atomics until the final
+// flush.  The 95 % zero products are free: the matrix pipe is otherwise idle here.
+//
+// Lane mapping of a wave: k = lane >> 4 is the sample of the current group of 4, j = lane & 15 is a channel (B operand)
+// and, for the A operand, a tile cell.  Each of the three waves of a workgroup owns one plane/line pair and walks the
+// samples of its (brick, part) in sorted order; the next group's sample records are prefetched one iteration ahead.
+struct FootPrint {
+    LTap2 tp;
+    float lw[2];
+    int lidx[2], lcell[2];
+};
+
+__device__ __forceinline__ FootPrint footprint(const nmf_vm_params& p, const float4& x, int a0, int a1, int av, int ox,
+                                               int oy, int oz) {
+    float xn[3];
+    normalized(p, x, xn);
+    FootPrint f;
+    const Tap1 tl = make_tap1(xn[av], p.grid);
+    f.tp = make_ltap2(xn[a0], xn[a1], p.grid, ox, oy);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bool in = tl.idx[t] >= 0;
+        f.lcell[t] = in ? tl.idx[t] - oz : -1;
+        f.lw[t] = in ? tl.w[t] : 0.f;
+        f.lidx[t] = in ? tl.idx[t] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool in = f.tp.g[t] >= 0;
+        f.tp.w[t] = in ? f.tp.w[t] : 0.f;
+        f.tp.l[t] = in ? f.tp.l[t] : -1;
+        f.tp.g[t] = in ? f.tp.g[t] : 0;
+    }
+    return f;
+}
+
+__device__ __forceinline__ float cell_weight(const LTap2& tp, int cell) {
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a += (tp.l[t] == cell) ? tp.w[t] : 0.f;
+    return a;
+}
+
+// C layout of 16x16x4: column (channel) = lane & 15, row (cell) = 4 * (lane >> 4) + reg
+__device__ __forceinline__ void flush_plane_tile(const floatx4 (&acc)[NRB], float* __restrict__ g, int nch, int ch,
+                                                 bool ch_ok, int ox, int oy, int G, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cell = 16 * rb + 4 * (lane >> 4) + r;
+            const float v = acc[rb][r];
+            if (cell < TL * TL && ch_ok && v != 0.f) {
+                const int X = ox + cell % TL, Y = oy + cell / TL;
+                if (X < G && Y < G) atomicAdd(g + ((int64_t)Y * G + X) * nch + ch, v);
+            }
+        }
+    }
+}
+
+template <bool WITH_NORMAL>
+__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_density(nmf_vm_params p, const float4* __restrict__ rec0,
+                                                                const float4* __restrict__ rec1,
+                                                                const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk,
+                                                                Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk) {
     const int brick = blockIdx.x;
-    const int s = bin_off[brick], e = bin_off[brick + 1];
-    if (s == e) return;
+    const int s0 = bin_off[brick], e = bin_off[brick + 1];
+    // heavy bricks are shared by up to gridDim.y workgroups: part y takes the 256-sample chunks y, y+gridDim.y, ...
+    const int s = s0 + (int)blockIdx.y * BWD_CHUNK;
+    if (s >= e) return;
+    const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
     const int G = p.grid;
     const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
-    const bool has_density = dpk.p[0] && (d_sigma || d_sigma_feat || d_normal);
-    const bool has_app = apl.p[0] && d_app;
-    float* l_dp = lds;
-    float* l_dl = l_dp + LDS_DP;
-    float* l_ap = l_dl + LDS_DL;
-    float* l_al = l_ap + LDS_AP;
-    for (int i = threadIdx.x; i < LDS_TOTAL; i += BWD_THREADS) lds[i] = 0.f;
+    const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;       // i = plane / line index of this wave
+    const int k = lane >> 4, j = lane & 15;
+    const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
+    const int ox = org[a0], oy = org[a1], oz = org[av];
+    const float* __restrict__ T = dpk.p[i];
+    const float* __restrict__ TLn = dlk.p[i];
+    floatx4 accP[NRB], accX[NRB], accY[NRB];
+    floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { accP[rb] = accX[rb] = accY[rb] = floatx4{0, 0, 0, 0}; }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // appearance: lane c (<24) keeps column (i*24+c) of basis_mat for the three planes
-    float Wc[3][AD];
-    if (has_app) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < AD; ++j) Wc[i][j] = lane < CA ? basis[j * (3 * CA) + i * CA + lane] : 0.f;
-    }
-    __syncthreads();
-
-    const int part = lane >> 4, ch = lane & 15;      // density lanes: part 0 = P, 1 = DX, 2 = DY
-    const int lane_dl = lane < DL ? lane : 0, lane_dp = lane < DP ? lane : 0, lane_a = lane < CA ? lane : 0;
-    for (int idx = s + wave; idx < e; idx += BWD_WAVES) {
-        const int m = __builtin_amdgcn_readfirstlane(perm[idx]);
-        float xn[3];
-        normalized(p, xyzt[m], xn);
-        // ---- footprints (wave-uniform).  Out-of-range taps are redirected to texel 0 / cell 0 with
-        // weight 0, so the whole sample is branch-free and all of its table reads are in flight at once
-        // (a per-tap branch + wait made this kernel latency-bound: ~40 serial round trips per sample).
-        Tap1 tl[3];
-        LTap2 tp[3];
-        int lcell[3][2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            tl[i] = make_tap1(xn[VEC[i]], G);
-            tp[i] = make_ltap2(xn[MAT0[i]], xn[MAT1[i]], G, org[MAT0[i]], org[MAT1[i]]);
+    for (int cbase = s; cbase < e; cbase += chunk_stride) {
+        const int cend = min(cbase + BWD_CHUNK, e);
+        float4 x_nx = rec0[min(cbase + k, cend - 1)], a_nx = rec1[min(cbase + k, cend - 1)];
+        for (int base = cbase; base < cend; base += 4) {
+            const bool valid = base + k < cend;
+            const float4 x = x_nx, adj = a_nx;
+            const int nidx = min(base + 4 + k, cend - 1);            // prefetch the next group's records
+            x_nx = rec0[nidx];
+            a_nx = rec1[nidx];
+            const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
+            const float dga = ((const float*)&adj)[1 + a0], dgb = ((const float*)&adj)[1 + a1];
+            const float dgw = ((const float*)&adj)[1 + av], dsf = adj.x;
+            // table values of (sample k, channel j)
+            float Lc = 0.f, DLc = 0.f, Pq = 0.f, Xq = 0.f, Yq = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const bool in = tl[i].idx[t] >= 0;
-                lcell[i][t] = in ? tl[i].idx[t] - org[VEC[i]] : 0;
-                tl[i].w[t] = in ? tl[i].w[t] : 0.f;
-                tl[i].idx[t] = in ? tl[i].idx[t] : 0;
+                const float* q = TLn + (int64_t)f.lidx[t] * DL + j;
+                Lc += f.lw[t] * q[0];
+                DLc += f.lw[t] * q[CD];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const bool in = tp[i].g[t] >= 0;
-                tp[i].w[t] = in ? tp[i].w[t] : 0.f;
-                tp[i].l[t] = in ? tp[i].l[t] : 0;
-                tp[i].g[t] = in ? tp[i].g[t] : 0;
-            }
-        }
-        // ---- issue every table read of this sample
-        float r_dl[3][2], r_dp[3][4], r_al[3][2], r_ap[3][4];
-        if (has_density) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) r_dl[i][t] = dlk.p[i][(int64_t)tl[i].idx[t] * DL + lane_dl];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) r_dp[i][t] = dpk.p[i][(int64_t)tp[i].g[t] * DP + lane_dp];
-            }
-        }
-        float da[AD];
-        if (has_app) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) r_al[i][t] = ali.p[i][(int64_t)tl[i].idx[t] * CA + lane_a];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) r_ap[i][t] = apl.p[i][(int64_t)tp[i].g[t] * CA + lane_a];
-            }
-#pragma unroll
-            for (int j = 0; j < AD; ++j) da[j] = d_app[(int64_t)m * AD + j];     // uniform address
-        }
-        if (has_density) {
-            float dsf = d_sigma_feat ? d_sigma_feat[m] : 0.f;
-            if (d_sigma) {
-                float f = sigma_feat[m];
-                float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
-                float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));             // softplus'
-                if (f < -15.f || f > 1e3f) ds = 0.f;                            // clamp'
-                dsf += d_sigma[m] * ds;
-            }
-            float dg[3] = {0.f, 0.f, 0.f};
-            if (d_normal) {   // through n = -g / sqrt(max(|g|^2, eps))
-                float g0 = grad[m * 3], g1 = grad[m * 3 + 1], g2 = grad[m * 3 + 2];
-                float dn0 = d_normal[m * 3], dn1 = d_normal[m * 3 + 1], dn2 = d_normal[m * 3 + 2];
-                float n2 = g0 * g0 + g1 * g1 + g2 * g2;
-                const float eps = 1.1920929e-07f;
-                float inv = 1.f / sqrtf(fmaxf(n2, eps));
-                float dot = dn0 * g0 + dn1 * g1 + dn2 * g2;
-                float k = n2 > eps ? dot * inv * inv * inv : 0.f;
-                dg[0] = (-dn0 * inv + k * g0) * p.inv_size[0];
-                dg[1] = (-dn1 * inv + k * g1) * p.inv_size[1];
-                dg[2] = (-dn2 * inv + k * g2) * p.inv_size[2];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float dga = dg[MAT0[i]], dgb = dg[MAT1[i]], dgw = dg[VEC[i]];
-                // line: lanes 0..31 = (L | DL)
-                const float lv = tl[i].w[0] * r_dl[i][0] + tl[i].w[1] * r_dl[i][1];
-                const float Lc = __shfl(lv, ch, 64), DLc = __shfl(lv, CD + ch, 64);
-                // plane: lanes 0..47 = (P | DX | DY); adjoint of the table entry this lane owns
-                const float coefL = part == 0 ? (dsf * Lc + dgw * DLc) : (part == 1 ? dga * Lc : dgb * Lc);
-                float q = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) q += tp[i].w[t] * r_dp[i][t];
-                if (lane < DP) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        atomicAdd(l_dp + (i * TL * TL + tp[i].l[t]) * DP + lane, tp[i].w[t] * coefL);
-                }
-                // line adjoints: aL_c = dsf P_c + dga DX_c + dgb DY_c (lanes 0..15), aDL_c = dgw P_c (lanes 16..31)
-                const float q1 = __shfl(q, (lane + CD) & 63, 64), q2 = __shfl(q, (lane + 2 * CD) & 63, 64);
-                const float qm = __shfl(q, (lane - CD) & 63, 64);
-                const float la = lane < CD ? (dsf * q + dga * q1 + dgb * q2) : dgw * qm;
-                if (lane < DL) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        atomicAdd(l_dl + (i * TL + lcell[i][t]) * DL + lane, tl[i].w[t] * la);
+                const float* q = T + (int64_t)f.tp.g[t] * DP + j;
+                Pq += f.tp.w[t] * q[0];
+                if (WITH_NORMAL) {
+                    Xq += f.tp.w[t] * q[CD];
+                    Yq += f.tp.w[t] * q[2 * CD];
                 }
             }
-        }
-        if (has_app) {
+            const float vz = valid ? 1.f : 0.f;
+            // B operands [sample k][channel j]
+            const float bP = vz * (dsf * Lc + dgw * DLc), bX = vz * dga * Lc, bY = vz * dgb * Lc;
+            const float bL = vz * (dsf * Pq + dga * Xq + dgb * Yq), bDL = vz * dgw * Pq;
+            // A operands [cell][sample k]: bilinear weight of the sample on tile cell 16*rb + j
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float dcoef = 0.f;
-#pragma unroll
-                for (int j = 0; j < AD; ++j) dcoef += Wc[i][j] * da[j];
-                const float La = tl[i].w[0] * r_al[i][0] + tl[i].w[1] * r_al[i][1];
-                float pa = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) pa += tp[i].w[t] * r_ap[i][t];
-                if (lane < CA) {
-                    const float ap_adj = dcoef * La, al_adj = pa * dcoef;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        atomicAdd(l_ap + (i * TL * TL + tp[i].l[t]) * CA + lane, tp[i].w[t] * ap_adj);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        atomicAdd(l_al + (i * TL + lcell[i][t]) * CA + lane, tl[i].w[t] * al_adj);
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float a = cell_weight(f.tp, 16 * rb + j);
+                accP[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP, accP[rb], 0, 0, 0);
+                if (WITH_NORMAL) {
+                    accX[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bX, accX[rb], 0, 0, 0);
+                    accY[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bY, accY[rb], 0, 0, 0);
                 }
             }
+            const float al = (f.lcell[0] == j ? f.lw[0] : 0.f) + (f.lcell[1] == j ? f.lw[1] : 0.f);
+            accL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL, accL, 0, 0, 0);
+            if (WITH_NORMAL) accDL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bDL, accDL, 0, 0, 0);
         }
     }
-    __syncthreads();
+    flush_plane_tile(accP, g_dpk.p[i], DP, j, true, ox, oy, G, lane);
+    if (WITH_NORMAL) {
+        flush_plane_tile(accX, g_dpk.p[i], DP, CD + j, true, ox, oy, G, lane);
+        flush_plane_tile(accY, g_dpk.p[i], DP, 2 * CD + j, true, ox, oy, G, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cell = 4 * (lane >> 4) + r;
+        if (cell < TL && oz + cell < G) {
+            if (accL[r] != 0.f) atomicAdd(g_dlk.p[i] + (int64_t)(oz + cell) * DL + j, accL[r]);
+            if (WITH_NORMAL && accDL[r] != 0.f) atomicAdd(g_dlk.p[i] + (int64_t)(oz + cell) * DL + CD + j, accDL[r]);
+        }
+    }
+}
 
-    // flush the non-zero entries (tiles of neighbouring bricks overlap on their halo -> atomics)
-    if (has_density) {
-        for (int k = threadIdx.x; k < LDS_DP; k += BWD_THREADS) {
-            const float v = l_dp[k];
-            if (v == 0.f) continue;
-            const int c = k % DP, cell = (k / DP) % (TL * TL), i = k / (DP * TL * TL);
-            const int X = org[MAT0[i]] + cell % TL, Y = org[MAT1[i]] + cell / TL;
-            if (X < G && Y < G) atomicAdd(g_dpk.p[i] + ((int64_t)Y * G + X) * DP + c, v);
-        }
-        for (int k = threadIdx.x; k < LDS_DL; k += BWD_THREADS) {
-            const float v = l_dl[k];
-            if (v == 0.f) continue;
-            const int c = k % DL, cell = (k / DL) % TL, i = k / (DL * TL);
-            const int Z = org[VEC[i]] + cell;
-            if (Z < G) atomicAdd(g_dlk.p[i] + (int64_t)Z * DL + c, v);
+__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_app(nmf_vm_params p, const float4* __restrict__ rec0,
+                                                            const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ bin_off, int nbx, Ptrs3 apl,
+                                                            Ptrs3 ali, const float* __restrict__ basis,
+                                                            const float* __restrict__ d_app, MPtrs3 g_apl,
+                                                            MPtrs3 g_ali) {
+    const int brick = blockIdx.x;
+    const int s0 = bin_off[brick], e = bin_off[brick + 1];
+    const int s = s0 + (int)blockIdx.y * BWD_CHUNK;
+    if (s >= e) return;
+    const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
+    const int G = p.grid;
+    const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
+    const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;
+    const int k = lane >> 4, j = lane & 15;
+    const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
+    const int ox = org[a0], oy = org[a1], oz = org[av];
+    const float* __restrict__ T = apl.p[i];
+    const float* __restrict__ TLn = ali.p[i];
+    // channel halves: j (0..15) and 16 + j (valid for j < 8); basis_mat columns of this plane for both
+    const bool hi_ok = j < CA - 16;
+    const int jh = hi_ok ? 16 + j : j;
+    float W0c[AD], W1c[AD];
+#pragma unroll
+    for (int q = 0; q < AD; ++q) {
+        W0c[q] = basis[q * (3 * CA) + i * CA + j];
+        W1c[q] = hi_ok ? basis[q * (3 * CA) + i * CA + 16 + j] : 0.f;
+    }
+    floatx4 acc0[NRB], acc1[NRB];
+    floatx4 accL0 = {0, 0, 0, 0}, accL1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { acc0[rb] = acc1[rb] = floatx4{0, 0, 0, 0}; }
+    for (int cbase = s; cbase < e; cbase += chunk_stride) {
+        const int cend = min(cbase + BWD_CHUNK, e);
+        float4 x_nx = rec0[min(cbase + k, cend - 1)];
+        int m_nx = perm[min(cbase + k, cend - 1)];
+        for (int base = cbase; base < cend; base += 4) {
+            const bool valid = base + k < cend;
+            const float4 x = x_nx;
+            const int64_t m = m_nx;
+            const int nidx = min(base + 4 + k, cend - 1);
+            x_nx = rec0[nidx];
+            m_nx = perm[nidx];
+            float da[AD];
+            load_run<AD / 4>(d_app + m * AD, da);
+            const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
+            float La0 = 0.f, La1 = 0.f, Pa0 = 0.f, Pa1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* q = TLn + (int64_t)f.lidx[t] * CA;
+                La0 += f.lw[t] * q[j];
+                La1 += f.lw[t] * q[jh];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* q = T + (int64_t)f.tp.g[t] * CA;
+                Pa0 += f.tp.w[t] * q[j];
+                Pa1 += f.tp.w[t] * q[jh];
+            }
+            float dc0 = 0.f, dc1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < AD; ++q) { dc0 += W0c[q] * da[q]; dc1 += W1c[q] * da[q]; }
+            if (!valid) { dc0 = 0.f; dc1 = 0.f; }
+            const float bP0 = dc0 * La0, bP1 = hi_ok ? dc1 * La1 : 0.f;     // adjoint of the plane entries
+            const float bL0 = dc0 * Pa0, bL1 = hi_ok ? dc1 * Pa1 : 0.f;     // adjoint of the line entries
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float a = cell_weight(f.tp, 16 * rb + j);
+                acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP0, acc0[rb], 0, 0, 0);
+                acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP1, acc1[rb], 0, 0, 0);
+            }
+            const float al = (f.lcell[0] == j ? f.lw[0] : 0.f) + (f.lcell[1] == j ? f.lw[1] : 0.f);
+            accL0 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL0, accL0, 0, 0, 0);
+            accL1 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL1, accL1, 0, 0, 0);
         }
     }
-    if (has_app) {
-        for (int k = threadIdx.x; k < LDS_AP; k += BWD_THREADS) {
-            const float v = l_ap[k];
-            if (v == 0.f) continue;
-            const int c = k % CA, cell = (k / CA) % (TL * TL), i = k / (CA * TL * TL);
-            const int X = org[MAT0[i]] + cell % TL, Y = org[MAT1[i]] + cell / TL;
-            if (X < G && Y < G) atomicAdd(g_apl.p[i] + ((int64_t)Y * G + X) * CA + c, v);
-        }
-        for (int k = threadIdx.x; k < LDS_AL; k += BWD_THREADS) {
-            const float v = l_al[k];
-            if (v == 0.f) continue;
-            const int c = k % CA, cell = (k / CA) % TL, i = k / (CA * TL);
-            const int Z = org[VEC[i]] + cell;
-            if (Z < G) atomicAdd(g_ali.p[i] + (int64_t)Z * CA + c, v);
+    flush_plane_tile(acc0, g_apl.p[i], CA, j, true, ox, oy, G, lane);
+    flush_plane_tile(acc1, g_apl.p[i], CA, 16 + j, hi_ok, ox, oy, G, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cell = 4 * (lane >> 4) + r;
+        if (cell < TL && oz + cell < G) {
+            if (accL0[r] != 0.f) atomicAdd(g_ali.p[i] + (int64_t)(oz + cell) * CA + j, accL0[r]);
+            if (hi_ok && accL1[r] != 0.f) atomicAdd(g_ali.p[i] + (int64_t)(oz + cell) * CA + 16 + j, accL1[r]);
         }
     }
 }
@@ -695,7 +770,7 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
 extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nbx = (grid + BR - 1) / BR;
     const int64_t nb = nbx * nbx * nbx;
-    return (2 * M + 3 * (nb + 1)) * (int64_t)sizeof(int32_t);
+    return (2 * M + 3 * (nb + 1) + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4);
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
@@ -734,17 +809,24 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt, M, nbx,
                        counts, brick_id);
     hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor);
-    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, brick_id, M, cursor, perm);
-    // 76 KB of dynamic LDS per workgroup (> the 64 KB default cap)
-    e = hipFuncSetAttribute((const void*)k_vm_bwd_brick, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(LDS_TOTAL * sizeof(float)));
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: hipFuncSetAttribute");
-    hipLaunchKernelGGL(k_vm_bwd_brick, dim3((unsigned)nb), dim3(BWD_THREADS), LDS_TOTAL * sizeof(float), st, *p,
-                       (const float4*)xyzt, perm, offsets, nbx, want_d ? mk(dpk) : mk(nullptr),
-                       want_d ? mk(dlk) : mk(nullptr), want_a ? mk(app_planes) : mk(nullptr),
-                       want_a ? mk(app_lines) : mk(nullptr), basis, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal,
-                       d_app, want_d ? mkm(g_dpk) : mkm(nullptr), want_d ? mkm(g_dlk) : mkm(nullptr),
-                       want_a ? mkm(g_app_planes) : mkm(nullptr), want_a ? mkm(g_app_lines) : mkm(nullptr));
+    // 16-byte aligned record arrays behind the integer scratch
+    uintptr_t rp = ((uintptr_t)(cursor + nb + 1) + 15) & ~(uintptr_t)15;
+    float4* rec0 = (float4*)rp;
+    float4* rec1 = rec0 + M;
+    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt,
+                       brick_id, M, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1);
+    const dim3 grid((unsigned)nb, BWD_PARTS), block(BWD_THREADS);
+    if (want_d) {
+        if (d_normal)
+            hipLaunchKernelGGL(k_vm_bwd_density<true>, grid, block, 0, st, *p, rec0, rec1, offsets, nbx, mk(dpk), mk(dlk),
+                               mkm(g_dpk), mkm(g_dlk));
+        else
+            hipLaunchKernelGGL(k_vm_bwd_density<false>, grid, block, 0, st, *p, rec0, rec1, offsets, nbx, mk(dpk),
+                               mk(dlk), mkm(g_dpk), mkm(g_dlk));
+    }
+    if (want_a)
+        hipLaunchKernelGGL(k_vm_bwd_app, grid, block, 0, st, *p, rec0, perm, offsets, nbx, mk(app_planes), mk(app_lines),
+                           basis, d_app, mkm(g_app_planes), mkm(g_app_lines));
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }
