@@ -188,6 +188,31 @@ int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t 
 /* seg_id[r] / local[r] for r in [offsets[i], offsets[i+1]) = i / r - offsets[i]  (= torch.where(ray_mask)). */
 int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, int32_t* local,
                         void* stream);
+/* Secondary rays of the compact ray list (ray i belongs to bounce row row_of_ray[i], is its j_of_ray[i]-th ray):
+ * PseudoRandomSampler.draw + GGXSampler.sample/compute_prob + the per-ray glue of Microfacet.forward
+ * (brdf_samplers/base.py:11-20, brdf_samplers/ggx.py:61-268, models/microfacet.py:377-456).
+ * Rows: V (to viewer), N (flipped to the viewer), r (roughness), x (bounce point), off [Mb][2] (uniform draws, the
+ * 0.25 scale is applied inside), cnt (rays per row); sobol [1024][2].  Outputs per ray: L [R][3], half/diff vectors in
+ * the local frame [R][3], lpdf [R], mipval [R] = -log(cnt) - lpdf, rays [R][6] = (x + 5e-3 L, L). */
+int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* x_rows,
+                     const float* off_rows, const int32_t* cnt_rows, const float* sobol,
+                     const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R, float* L,
+                     float* half_local, float* diff_local, float* lpdf, float* mipval, float* rays, void* stream);
+/* d_nr [R][4] = (dL/dN)^T dL | (dL/dr)^T dL per ray (dual-number evaluation of the same sampler); reduce per row. */
+int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
+                     const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
+                     const float* dL, float* d_nr, void* stream);
+/* Fresnel-Schlick mix (models/microfacet.py:595-613): contrib [R][3] = (F Li brdf + (1-F) diffuse) / cnt with
+ * F = f0 + (1-f0)(1-|V.H|)^5, H = normalize((V+L)/2); sum contrib per row for reflect_rgb. */
+int nmf_shade_mix_fwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
+                      const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
+                      const float* incoming, const float* brdf, float* contrib, void* stream);
+/* d_rows [Mb][3] = adjoint of the row sums.  d_incoming, d_brdf [R][3] overwritten; dL [R][3] ADDED TO;
+ * d_f0diff [R][6] = per-ray (d f0 | d diffuse), reduce per row. */
+int nmf_shade_mix_bwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
+                      const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
+                      const float* incoming, const float* brdf, const float* d_rows, float* d_incoming,
+                      float* d_brdf, float* dL, float* d_f0diff, void* stream);
 /* RandHydraMLPDiffuse heads (modules/render_modules.py:519-574; pospe=-1, feape=0, one Linear each, std=0):
  * out [M][11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied; W [11][24] / b [11] are
  * the four Linear layers stacked in that order. */

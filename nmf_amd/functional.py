@@ -175,3 +175,47 @@ class MaterialHeads(torch.autograd.Function):
         feat, W, b = ctx.saved_tensors
         d_feat, gW, gb = hip.heads_bwd(feat, W, b, ctx.hp, d_out)
         return (d_feat, None, gW[0:3], gb[0:3], gW[3:6], gb[3:6], gW[6:9], gb[6:9], gW[9:11], gb[9:11])
+
+
+class GgxRays(torch.autograd.Function):
+    """Secondary rays from GGX visible-normal sampling (brdf_samplers/ggx.py:61-268 + models/microfacet.py:377-456).
+    Differentiable wrt the row normals and roughness through L (and through rays[:, 3:6] = L, rays[:, :3] = x + 5e-3 L)."""
+
+    @staticmethod
+    def forward(ctx, V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray, row_off):
+        V, N, r, x, off = V.contiguous(), N.contiguous(), r.reshape(-1).contiguous(), x.contiguous(), off.contiguous()
+        L, hl, dl, lpdf, mip, rays = hip.ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray)
+        ctx.save_for_backward(V, N, r, off, sobol, row_of_ray, j_of_ray, row_off)
+        ctx.mark_non_differentiable(hl, dl, lpdf, mip)
+        return L, hl, dl, lpdf, mip, rays
+
+    @staticmethod
+    def backward(ctx, dL, _hl, _dl, _lp, _mip, d_rays):
+        V, N, r, off, sobol, row_of_ray, j_of_ray, row_off = ctx.saved_tensors
+        g = torch.zeros((row_of_ray.shape[0], 3), dtype=torch.float32, device=V.device)
+        if dL is not None:
+            g = g + dL
+        if d_rays is not None:
+            g = g + d_rays[:, 3:6] + 5e-3 * d_rays[:, 0:3]
+        d_nr = hip.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, g.contiguous())
+        rows = hip.segment_sum(d_nr, None, row_off, V.shape[0])
+        return None, rows[:, 0:3], rows[:, 3:4], None, None, None, None, None, None, None
+
+
+class ShadeMix(torch.autograd.Function):
+    """reflect_rgb rows = sum over the row's rays of (F Li brdf + (1-F) diffuse) / count (microfacet.py:595-613)."""
+
+    @staticmethod
+    def forward(ctx, V, f0, diff, cnt, row_of_ray, row_off, L, inc, brdf):
+        V, f0, diff = V.contiguous(), f0.contiguous(), diff.contiguous()
+        L, inc, brdf = L.contiguous(), inc.contiguous(), brdf.contiguous()
+        contrib = hip.shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf)
+        ctx.save_for_backward(V, f0, diff, cnt, row_of_ray, row_off, L, inc, brdf)
+        return hip.segment_sum(contrib, None, row_off, V.shape[0])
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        V, f0, diff, cnt, row_of_ray, row_off, L, inc, brdf = ctx.saved_tensors
+        d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows.contiguous())
+        rows = hip.segment_sum_wide(d_fd, 6, row_off, V.shape[0])
+        return None, rows[:, 0:3], rows[:, 3:6], None, None, None, dL, d_inc, d_brdf

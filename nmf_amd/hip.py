@@ -52,7 +52,7 @@ EXPORTS = [
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
-    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -409,3 +409,47 @@ def heads_bwd(feat, W, b, hp, d_out):
                               *[C.c_float(v) for v in hp], _p(d_out.contiguous(), torch.float32), _p(d_feat), _p(gW),
                               _p(gb), _stream()), "nmf_heads_bwd")
     return d_feat, gW, gb
+
+
+def ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray):
+    R = row_of_ray.shape[0]
+    dev = V.device
+    f = lambda *s_: torch.empty(s_, dtype=torch.float32, device=dev)  # noqa: E731
+    L, hl, dl, lpdf, mip, rays = f(R, 3), f(R, 3), f(R, 3), f(R), f(R), f(R, 6)
+    _check(_lib.nmf_ggx_rays_fwd(_p(V, torch.float32), _p(N, torch.float32), _p(r, torch.float32), _p(x, torch.float32),
+                                 _p(off, torch.float32), _p(cnt, torch.int32), _p(sobol, torch.float32),
+                                 _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32), C.c_int64(R), _p(L), _p(hl),
+                                 _p(dl), _p(lpdf), _p(mip), _p(rays), _stream()), "nmf_ggx_rays_fwd")
+    return L, hl, dl, lpdf, mip, rays
+
+
+def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL):
+    R = row_of_ray.shape[0]
+    d_nr = torch.empty((R, 4), dtype=torch.float32, device=V.device)
+    _check(_lib.nmf_ggx_rays_bwd(_p(V, torch.float32), _p(N, torch.float32), _p(r, torch.float32), _p(off, torch.float32),
+                                 _p(sobol, torch.float32), _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32),
+                                 C.c_int64(R), _p(dL, torch.float32), _p(d_nr), _stream()), "nmf_ggx_rays_bwd")
+    return d_nr
+
+
+def shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf):
+    R = row_of_ray.shape[0]
+    contrib = torch.empty((R, 3), dtype=torch.float32, device=V.device)
+    _check(_lib.nmf_shade_mix_fwd(_p(V, torch.float32), _p(f0, torch.float32), _p(diff, torch.float32), _p(cnt, torch.int32),
+                                  _p(row_of_ray, torch.int32), C.c_int64(R), _p(L, torch.float32), _p(inc, torch.float32),
+                                  _p(brdf, torch.float32), _p(contrib), _stream()), "nmf_shade_mix_fwd")
+    return contrib
+
+
+def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
+    R = row_of_ray.shape[0]
+    dev = V.device
+    d_inc = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    d_brdf = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    dL = torch.zeros((R, 3), dtype=torch.float32, device=dev)
+    d_fd = torch.empty((R, 6), dtype=torch.float32, device=dev)
+    _check(_lib.nmf_shade_mix_bwd(_p(V, torch.float32), _p(f0, torch.float32), _p(diff, torch.float32), _p(cnt, torch.int32),
+                                  _p(row_of_ray, torch.int32), C.c_int64(R), _p(L, torch.float32), _p(inc, torch.float32),
+                                  _p(brdf, torch.float32), _p(d_rows, torch.float32), _p(d_inc), _p(d_brdf), _p(dL),
+                                  _p(d_fd), _stream()), "nmf_shade_mix_bwd")
+    return d_inc, d_brdf, dL, d_fd

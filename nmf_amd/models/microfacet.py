@@ -8,7 +8,7 @@ import math
 import torch
 
 from .. import hip
-from ..functional import segment_sum
+from ..functional import GgxRays, ShadeMix, segment_sum
 from ..modules import sh
 from ..brdf_samplers.ggx import mat3T_vec, normalize
 
@@ -142,15 +142,13 @@ class Microfacet(torch.nn.Module):
             r1 = matprop["r1"][bidx]
             if is_train:
                 r1 = r1.clip(min=self.min_rough)
-            angs = self.brdf_sampler.draw_compact(Mb, row_of_ray, j_of_ray, noise)                  # :367
-            L, basisT, lpdf = self.brdf_sampler.sample_compact(angs[:, 0], angs[:, 1], bV, bN, r1, row_of_ray)
+            off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                          # base.py:18
+            cnt32 = cnt_b.int()
+            L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
+                bV, bN, r1, samples.xyzt[bidx][:, :3], off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray,
+                row_off)
             eV, eN = bV[rows], bN[rows]
-            H = normalize((eV + L) / 2)                                                             # :388
-            diffvec = mat3T_vec(basisT, L)                     # basis rows . L  (models/microfacet.py:406)
-            halfvec = mat3T_vec(basisT, H)
             ecount = cnt_b.float()[rows]
-            mipval = -torch.log(ecount.clip(min=1)) - lpdf                                          # :448
-            bounce_rays = torch.cat([samples.xyzt[bidx][:, :3][rows] + L * 5e-3, L], dim=-1)         # :450
             brdf_weight = self.brdf.forward_compact(halfvec, diffvec, noise_feat[bidx], r1, row_of_ray, row_off)
             if self.trace is not None:
                 self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
@@ -183,15 +181,12 @@ class Microfacet(torch.nn.Module):
             if self.trace is not None:
                 self.trace[f"incoming{recur}"] = incoming
             ec = ecount.clip(min=1)[:, None]
-            R0 = matprop["f0"][bidx][rows]                                                          # :596-613
-            ediff = diffuse[bidx][rows]
-            cos_t = (-eV * H).sum(dim=-1, keepdim=True).abs()
-            Fr = R0 + (1 - R0) * (1 - cos_t).clip(min=0, max=1) ** 5
-            comb = Fr * incoming * brdf_weight + (1 - Fr) * ediff
-            reflect_rgb = zeros3.index_put((bidx,), segment_sum(comb / ec, row_off, row_of_ray, Mb))
+            refl_rows = ShadeMix.apply(bV, matprop["f0"][bidx], diffuse[bidx], cnt32, row_of_ray, row_off, L, incoming,
+                                       brdf_weight)                                                 # :596-613
+            reflect_rgb = zeros3.index_put((bidx,), refl_rows)
             with torch.no_grad():
-                spec = zeros3.index_put((bidx,), segment_sum((incoming / ec).detach(), row_off, row_of_ray, Mb))
-            brdf_rgb = zeros3.index_put((bidx,), segment_sum(brdf_weight / ec, row_off, row_of_ray, Mb))
+                spec = zeros3.index_put((bidx,), hip.segment_sum((incoming / ec).contiguous(), None, row_off, Mb))
+                brdf_rgb = zeros3.index_put((bidx,), hip.segment_sum((brdf_weight / ec).contiguous(), None, row_off, Mb))
         cos_t = (-viewdirs * normals).sum(dim=-1, keepdim=True).abs()                               # :642
         Fr = matprop["f0"] + (1 - matprop["f0"]) * (1 - cos_t).clip(min=0, max=1) ** 5
         debug = dict(diffuse=(1 - Fr) * diffuse, tint=Fr * brdf_rgb, roughness=matprop["r1"], spec=spec, albedo=albedo)
