@@ -121,7 +121,8 @@ int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
 /* Backward.  Upstream adjoints (any may be NULL): d_sigma [M] (wrt activated sigma), d_sigma_feat [M]
  * (wrt the raw feature, added to the former's contribution), d_normal [M][3], d_app [M][24].
  * sigma_feat / grad are the saved forward outputs.  Accumulates into g_dpk[i] [G][G][48],
- * g_dlk[i] [G][32], g_app_planes[i] [G][G][24], g_app_lines[i] [G][24] -- caller zeroes them.
+ * g_dlk[i] [G][32], g_app_planes[i] [G][G][24], g_app_lines[i] [G][24], g_basis [24][72] (basis_mat, may be NULL)
+ * -- caller zeroes them.
  * Samples are counting-sorted by 8^3-voxel brick and reduced in LDS per brick (see vm.hip). */
 int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
                      const float* const dpk[3], const float* const dlk[3],
@@ -129,8 +130,8 @@ int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
                      const float* basis, const float* sigma_feat, const float* grad,
                      const float* d_sigma, const float* d_sigma_feat, const float* d_normal,
                      const float* d_app, float* const g_dpk[3], float* const g_dlk[3],
-                     float* const g_app_planes[3], float* const g_app_lines[3], void* workspace,
-                     int64_t workspace_bytes, void* stream);
+                     float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 /* Scratch the backward needs (brick ids, permutation, bin counters); contents are undefined on return. */
 int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid);
 

@@ -653,7 +653,7 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
                                                             const int32_t* __restrict__ bin_off, int nbx, Ptrs3 apl,
                                                             Ptrs3 ali, const float* __restrict__ basis,
                                                             const float* __restrict__ d_app, MPtrs3 g_apl,
-                                                            MPtrs3 g_ali) {
+                                                            MPtrs3 g_ali, float* __restrict__ g_basis) {
     const int brick = blockIdx.x;
     const int s0 = bin_off[brick], e = bin_off[brick + 1];
     const int s = s0 + (int)blockIdx.y * BWD_CHUNK;
@@ -678,6 +678,9 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     }
     floatx4 acc0[NRB], acc1[NRB];
     floatx4 accL0 = {0, 0, 0, 0}, accL1 = {0, 0, 0, 0};
+    // basis_mat gradient  dW[q][i*24 + c] = sum_s d_app[s][q] * coef[s][c]  (2 x 2 blocks of 16): the [24 x M] x [M x 72]
+    // GEMM of the reference's autograd, folded into the same MFMA stream
+    floatx4 accW00 = {0, 0, 0, 0}, accW01 = {0, 0, 0, 0}, accW10 = {0, 0, 0, 0}, accW11 = {0, 0, 0, 0};
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) { acc0[rb] = acc1[rb] = floatx4{0, 0, 0, 0}; }
     for (int cbase = s; cbase < e; cbase += chunk_stride) {
@@ -722,6 +725,29 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
             const float al = (f.lcell[0] == j ? f.lw[0] : 0.f) + (f.lcell[1] == j ? f.lw[1] : 0.f);
             accL0 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL0, accL0, 0, 0, 0);
             accL1 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL1, accL1, 0, 0, 0);
+            if (g_basis) {
+                const float vz = valid ? 1.f : 0.f;
+                const float aq0 = vz * d_app[m * AD + j], aq1 = hi_ok ? vz * d_app[m * AD + 16 + j] : 0.f;
+                const float c0 = Pa0 * La0, c1 = hi_ok ? Pa1 * La1 : 0.f;          // coefficient (tensoRF.py:204)
+                accW00 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0, c0, accW00, 0, 0, 0);
+                accW01 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0, c1, accW01, 0, 0, 0);
+                accW10 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c0, accW10, 0, 0, 0);
+                accW11 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c1, accW11, 0, 0, 0);
+            }
+        }
+    }
+    if (g_basis) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 4 * (lane >> 4) + r;                 // row of the 16x16 tile, column = j
+            float* w0 = g_basis + (int64_t)q * (3 * CA) + i * CA;
+            float* w1 = g_basis + (int64_t)(16 + q) * (3 * CA) + i * CA;
+            if (accW00[r] != 0.f) atomicAdd(w0 + j, accW00[r]);
+            if (hi_ok && accW01[r] != 0.f) atomicAdd(w0 + 16 + j, accW01[r]);
+            if (q < AD - 16) {
+                if (accW10[r] != 0.f) atomicAdd(w1 + j, accW10[r]);
+                if (hi_ok && accW11[r] != 0.f) atomicAdd(w1 + 16 + j, accW11[r]);
+            }
         }
     }
     flush_plane_tile(acc0, g_apl.p[i], CA, j, true, ox, oy, G, lane);
@@ -745,9 +771,11 @@ __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, c
                                                               Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
                                                               const float* __restrict__ basis,
                                                               const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
-                                                              MPtrs3 g_apl, MPtrs3 g_ali, int z_density, int z_app) {
+                                                              MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
+                                                              int z_density, int z_app) {
     if ((int)blockIdx.z == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, bin_off, nbx, dpk, dlk, g_dpk, g_dlk);
-    else if ((int)blockIdx.z == z_app) vm_bwd_app(p, rec0, perm, bin_off, nbx, apl, ali, basis, d_app, g_apl, g_ali);
+    else if ((int)blockIdx.z == z_app)
+        vm_bwd_app(p, rec0, perm, bin_off, nbx, apl, ali, basis, d_app, g_apl, g_ali, g_basis);
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -830,7 +858,7 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
                                 const float* grad, const float* d_sigma, const float* d_sigma_feat,
                                 const float* d_normal, const float* d_app, float* const g_dpk[3],
                                 float* const g_dlk[3], float* const g_app_planes[3], float* const g_app_lines[3],
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                float* g_basis, void* workspace, int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: params");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(xyzt, NMF_EINVAL, "nmf_vm_query_bwd: xyzt null");
@@ -872,11 +900,11 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     if (d_normal)
         hipLaunchKernelGGL(k_vm_bwd_brick<true>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
                            mk(app_planes), mk(app_lines), basis, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), z_density, z_app);
+                           mkm(g_app_lines), g_basis, z_density, z_app);
     else
         hipLaunchKernelGGL(k_vm_bwd_brick<false>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
                            mk(app_planes), mk(app_lines), basis, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), z_density, z_app);
+                           mkm(g_app_lines), g_basis, z_density, z_app);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }

@@ -14,7 +14,7 @@ class VMQuery(torch.autograd.Function):
     def forward(ctx, field, xyzt, want_app, want_normal, *params):
         p, dpk, dlk, apl, ali, basis = field._tables()
         sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
-                                                  want_normal=want_normal, want_app=want_app, want_coef=want_app)
+                                                  want_normal=want_normal, want_app=want_app, want_coef=False)
         ctx.field = field
         ctx.flags = (want_app, want_normal)
         ctx.save_for_backward(xyzt, sf, gr, cf)
@@ -40,10 +40,10 @@ class VMQuery(torch.autograd.Function):
         d_sigma = d_sigma.contiguous() if d_sigma is not None else None
         d_app_c = d_app.contiguous() if (want_app and d_app is not None) else None
         d_nrm_c = d_normal.contiguous() if (want_normal and d_normal is not None) else None
+        g_basis = z(24, 72) if d_app_c is not None else None
         hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
-                         g_dpk, g_dlk, g_apl, g_ali)
+                         g_dpk, g_dlk, g_apl, g_ali, g_basis)
         gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
-        g_basis = d_app_c.t() @ cf if d_app_c is not None else None      # plain [24 x M] x [M x 72] library GEMM
         grads = field._grads_to_param_layout(gp, gl, g_apl, g_ali, g_basis)
         return (None, None, None, None) + tuple(grads)
 

@@ -235,7 +235,7 @@ def vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density=T
 
 
 def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, grad, d_sigma, d_sigma_feat,
-                 d_normal, d_app, g_dpk, g_dlk, g_app_planes, g_app_lines):
+                 d_normal, d_app, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis=None):
     M = xyzt.shape[0]
     want_d = d_sigma is not None or d_sigma_feat is not None or d_normal is not None
     want_a = d_app is not None
@@ -248,7 +248,7 @@ def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, gr
                                  _p(d_sigma_feat), _p(d_normal), _p(d_app),
                                  _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
                                  _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
-                                 _p(ws), C.c_int64(nbytes), _stream()), "nmf_vm_query_bwd")
+                                 _p(g_basis if want_a else None), _p(ws), C.c_int64(nbytes), _stream()), "nmf_vm_query_bwd")
 
 
 def vm_unpack_density_grad(p, g_dpk, g_dlk):

@@ -147,7 +147,6 @@ class Microfacet(torch.nn.Module):
             L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
                 bV, bN, r1, samples.xyzt[bidx][:, :3], off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray,
                 row_off)
-            eV, eN = bV[rows], bN[rows]
             ecount = cnt_b.float()[rows]
             brdf_weight = self.brdf.forward_compact(halfvec, diffvec, noise_feat[bidx], r1, row_of_ray, row_off)
             if self.trace is not None:
@@ -156,26 +155,35 @@ class Microfacet(torch.nn.Module):
                                    f"lpdf{recur}": lpdf})
             if len(self.max_retrace_rays) > recur:                                                  # :475-559
                 num_retrace = min(R, self.max_retrace_rays[recur])
-                with torch.no_grad():
-                    per_sample = w_det[bidx] / (cnt_b.float() + 1e-8)
-                    per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
-                    cc = per_ray * per_sample[rows]
-                    cc = cc / cc.sum() * num_retrace
-                    cc = cc + noise.uniform((R,))
-                    order = cc.argsort()
-                    if self.forced is not None and f"retrace_order{recur}" in self.forced:
-                        order = self.forced[f"retrace_order{recur}"].to(dev)
-                    if self.trace is not None:
-                        self.trace[f"retrace_score{recur}"] = cc
-                    cut = max(R - num_retrace, 0)
-                    idx_re, idx_no = order[cut:], order[:cut]
-                incoming = torch.zeros((R, 3), device=dev)
-                if idx_re.shape[0] > 0:
-                    inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
-                    incoming = incoming.index_put((idx_re,), inc)
-                if idx_no.shape[0] > 0:
-                    inc = render_reflection(bounce_rays[idx_no], mipval[idx_no], False)
-                    incoming = incoming.index_put((idx_no,), inc)
+                pinned = self.forced is not None and f"retrace_order{recur}" in self.forced
+                if num_retrace >= R and not pinned and self.trace is None:
+                    # steady state: every secondary ray is re-traced.  The reference still argsorts the
+                    # scores, which only permutes the rays before they meet their i.i.d. jitter rows; the draw is
+                    # consumed for stream parity and the identity order is used (same distribution, no 250 k-key sort).
+                    noise.skip("rand", (R,))
+                    incoming = render_reflection(bounce_rays, mipval, True)
+                else:
+                    with torch.no_grad():
+                        eV, eN = bV[rows], bN[rows]
+                        per_sample = w_det[bidx] / (cnt_b.float() + 1e-8)
+                        per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
+                        cc = per_ray * per_sample[rows]
+                        cc = cc / cc.sum() * num_retrace
+                        cc = cc + noise.uniform((R,))
+                        order = cc.argsort()
+                        if pinned:
+                            order = self.forced[f"retrace_order{recur}"].to(dev)
+                        if self.trace is not None:
+                            self.trace[f"retrace_score{recur}"] = cc
+                        cut = max(R - num_retrace, 0)
+                        idx_re, idx_no = order[cut:], order[:cut]
+                    incoming = torch.zeros((R, 3), device=dev)
+                    if idx_re.shape[0] > 0:
+                        inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
+                        incoming = incoming.index_put((idx_re,), inc)
+                    if idx_no.shape[0] > 0:
+                        inc = render_reflection(bounce_rays[idx_no], mipval[idx_no], False)
+                        incoming = incoming.index_put((idx_no,), inc)
             else:
                 incoming = render_reflection(bounce_rays, mipval, False)
             if self.trace is not None:

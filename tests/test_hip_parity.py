@@ -144,10 +144,13 @@ def _vm_backward(hip, p, xyz_d, tabs, sf, gr, d_sigma, d_sf, d_normal, d_app, co
     g_dlk = [z(G, 32) for _ in range(3)]
     g_apl = [z(G, G, 24) for _ in range(3)]
     g_ali = [z(G, 24) for _ in range(3)]
+    g_basis = z(24, 72)
     hip.vm_query_bwd(p, xyz_d, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, d_sf, d_normal, d_app, g_dpk, g_dlk,
-                     g_apl, g_ali)
+                     g_apl, g_ali, g_basis)
     gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
-    g_basis = d_app.t() @ coef
+    # the kernel's basis_mat gradient must equal the plain GEMM d_app^T x coef
+    ref_basis = d_app.t() @ coef
+    assert float((g_basis - ref_basis).abs().max()) <= 2e-4 * float(ref_basis.abs().max()) + 1e-6
     out = {}
     for i in range(3):
         out[f"rf.density_rf.app_plane.{i}"] = gp[i].permute(2, 0, 1)[None].cpu()
