@@ -19,6 +19,7 @@
 // and the backward is a pure scatter of (weight x adjoint) into the packed gradient tables, which
 // nmf_vm_unpack_density_grad folds back through the transposed stencil.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -425,7 +426,8 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
                                                        const float* __restrict__ grad, const float* __restrict__ d_sigma,
                                                        const float* __restrict__ d_sigma_feat,
                                                        const float* __restrict__ d_normal, float4* __restrict__ rec0,
-                                                       float4* __restrict__ rec1) {
+                                                       float4* __restrict__ rec1, const float* __restrict__ d_app,
+                                                       const float* __restrict__ basis, float* __restrict__ dcoef) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = m < M;
     const int b = active ? brick_id[m] : -1;
@@ -459,6 +461,21 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
         dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
     }
     rec1[pos] = make_float4(dsf, dg0, dg1, dg2);
+    if (d_app) {   // adjoint of the 72 plane*line coefficients: dcoef = d_app x basis_mat (weights via scalar loads)
+        float da[AD];
+        load_run<AD / 4>(d_app + m * AD, da);
+        float4* out = reinterpret_cast<float4*>(dcoef + (int64_t)pos * (3 * CA));
+#pragma unroll
+        for (int c4 = 0; c4 < 3 * CA / 4; ++c4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < AD; ++q) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += basis[q * (3 * CA) + 4 * c4 + u] * da[q];
+            }
+            out[c4] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
 }
 
 // uniform (per-sample) footprint: global texel index or -1, tile-local cell, weight
@@ -488,8 +505,7 @@ __device__ __forceinline__ LTap2 make_ltap2(float u, float v, int G, int ox, int
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int BWD_WAVES = 3;                 // one wave per plane/line pair
-constexpr int BWD_THREADS = BWD_WAVES * 64;
+constexpr int BWD_THREADS = 64;               // one single-wave workgroup per (brick, part, plane/line pair)
 constexpr int NRB = 6;                       // 81 tile cells -> 6 row blocks of 16
 constexpr int BWD_CHUNK = 256;               // samples per (brick, part) work item
 constexpr int BWD_PARTS = 8;
@@ -574,7 +590,7 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
     const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
     const int G = p.grid;
     const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
-    const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;       // i = plane / line index of this wave
+    const int lane = threadIdx.x & 63, i = (int)blockIdx.z % 3;    // i = plane / line index of this wave
     const int k = lane >> 4, j = lane & 15;
     const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
     const int ox = org[a0], oy = org[a1], oz = org[av];
@@ -651,7 +667,7 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
 __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __restrict__ rec0,
                                                             const int32_t* __restrict__ perm,
                                                             const int32_t* __restrict__ bin_off, int nbx, Ptrs3 apl,
-                                                            Ptrs3 ali, const float* __restrict__ basis,
+                                                            Ptrs3 ali, const float* __restrict__ dcoef,
                                                             const float* __restrict__ d_app, MPtrs3 g_apl,
                                                             MPtrs3 g_ali, float* __restrict__ g_basis) {
     const int brick = blockIdx.x;
@@ -661,21 +677,15 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
     const int G = p.grid;
     const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
-    const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, i = (int)blockIdx.z % 3;
     const int k = lane >> 4, j = lane & 15;
     const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
     const int ox = org[a0], oy = org[a1], oz = org[av];
     const float* __restrict__ T = apl.p[i];
     const float* __restrict__ TLn = ali.p[i];
-    // channel halves: j (0..15) and 16 + j (valid for j < 8); basis_mat columns of this plane for both
+    // channel halves: j (0..15) and 16 + j (valid for j < 8)
     const bool hi_ok = j < CA - 16;
     const int jh = hi_ok ? 16 + j : j;
-    float W0c[AD], W1c[AD];
-#pragma unroll
-    for (int q = 0; q < AD; ++q) {
-        W0c[q] = basis[q * (3 * CA) + i * CA + j];
-        W1c[q] = hi_ok ? basis[q * (3 * CA) + i * CA + 16 + j] : 0.f;
-    }
     floatx4 acc0[NRB], acc1[NRB];
     floatx4 accL0 = {0, 0, 0, 0}, accL1 = {0, 0, 0, 0};
     // basis_mat gradient  dW[q][i*24 + c] = sum_s d_app[s][q] * coef[s][c]  (2 x 2 blocks of 16): the [24 x M] x [M x 72]
@@ -694,8 +704,9 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
             const int nidx = min(base + 4 + k, cend - 1);
             x_nx = rec0[nidx];
             m_nx = perm[nidx];
-            float da[AD];
-            load_run<AD / 4>(d_app + m * AD, da);
+            const int pos = min(base + k, cend - 1);
+            // adjoint of this sample's coefficients (precomputed in sorted order by k_brick_scatter)
+            float dc0 = dcoef[(int64_t)pos * (3 * CA) + i * CA + j], dc1 = dcoef[(int64_t)pos * (3 * CA) + i * CA + jh];
             const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
             float La0 = 0.f, La1 = 0.f, Pa0 = 0.f, Pa1 = 0.f;
 #pragma unroll
@@ -710,9 +721,6 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
                 Pa0 += f.tp.w[t] * q[j];
                 Pa1 += f.tp.w[t] * q[jh];
             }
-            float dc0 = 0.f, dc1 = 0.f;
-#pragma unroll
-            for (int q = 0; q < AD; ++q) { dc0 += W0c[q] * da[q]; dc1 += W1c[q] * da[q]; }
             if (!valid) { dc0 = 0.f; dc1 = 0.f; }
             const float bP0 = dc0 * La0, bP1 = hi_ok ? dc1 * La1 : 0.f;     // adjoint of the plane entries
             const float bL0 = dc0 * Pa0, bL1 = hi_ok ? dc1 * Pa1 : 0.f;     // adjoint of the line entries
@@ -762,20 +770,21 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     }
 }
 
-// one launch for both halves (blockIdx.z: 0 = density, 1 = appearance) so the two latency-bound walks overlap
+// one launch for both halves (blockIdx.z / 3: density or appearance, blockIdx.z % 3: plane) so all six latency-bound
+// walks overlap; single-wave workgroups pack up to 3 per SIMD
 template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
                                                               const int32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk,
                                                               Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
-                                                              const float* __restrict__ basis,
+                                                              const float* __restrict__ dcoef,
                                                               const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
                                                               MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
                                                               int z_density, int z_app) {
-    if ((int)blockIdx.z == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, bin_off, nbx, dpk, dlk, g_dpk, g_dlk);
-    else if ((int)blockIdx.z == z_app)
-        vm_bwd_app(p, rec0, perm, bin_off, nbx, apl, ali, basis, d_app, g_apl, g_ali, g_basis);
+    if ((int)blockIdx.z / 3 == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, bin_off, nbx, dpk, dlk, g_dpk, g_dlk);
+    else if ((int)blockIdx.z / 3 == z_app)
+        vm_bwd_app(p, rec0, perm, bin_off, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis);
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -849,7 +858,8 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
 extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nbx = (grid + BR - 1) / BR;
     const int64_t nb = nbx * nbx * nbx;
-    return (2 * M + 3 * (nb + 1) + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4);
+    return (2 * M + 3 * (nb + 1) + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
+           M * 3 * CA * (int64_t)sizeof(float) + 16;
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
@@ -892,18 +902,22 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     uintptr_t rp = ((uintptr_t)(cursor + nb + 1) + 15) & ~(uintptr_t)15;
     float4* rec0 = (float4*)rp;
     float4* rec1 = rec0 + M;
+    float* dcoef = (float*)(rec1 + M);
     hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt,
-                       brick_id, M, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1);
+                       brick_id, M, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1,
+                       want_a ? d_app : nullptr, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    const dim3 grid((unsigned)nb, BWD_PARTS, (unsigned)nz), block(BWD_THREADS);
+    int parts = BWD_PARTS;
+    if (const char* ev = getenv("NMF_BWD_PARTS")) parts = atoi(ev) > 0 ? atoi(ev) : parts;   // tuning knob
+    const dim3 grid((unsigned)nb, (unsigned)parts, (unsigned)(3 * nz)), block(BWD_THREADS);
     if (d_normal)
         hipLaunchKernelGGL(k_vm_bwd_brick<true>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
-                           mk(app_planes), mk(app_lines), basis, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
+                           mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
                            mkm(g_app_lines), g_basis, z_density, z_app);
     else
         hipLaunchKernelGGL(k_vm_bwd_brick<false>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
-                           mk(app_planes), mk(app_lines), basis, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
+                           mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
                            mkm(g_app_lines), g_basis, z_density, z_app);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;

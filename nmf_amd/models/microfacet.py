@@ -134,21 +134,22 @@ class Microfacet(torch.nn.Module):
             row_off[1:] = torch.cumsum(cnt_b, 0)
             row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)        # = torch.where(ray_mask)
             rows = row_of_ray.long()
-            bN = normals[bidx]
+            isel = lambda t: torch.index_select(t, 0, bidx)     # backward = index_add (no sort), unlike t[bidx]
+            bN = isel(normals)
             if self.detach_N:
                 bN = bN.detach()
-            bV = -viewdirs[bidx]
+            bV = -isel(viewdirs)
             bN = bN * (bV * bN).sum(dim=-1, keepdim=True).sign()                                    # :356
-            r1 = matprop["r1"][bidx]
+            r1 = isel(matprop["r1"])
             if is_train:
                 r1 = r1.clip(min=self.min_rough)
             off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                          # base.py:18
             cnt32 = cnt_b.int()
             L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
-                bV, bN, r1, samples.xyzt[bidx][:, :3], off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray,
+                bV, bN, r1, isel(samples.xyzt)[:, :3], off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray,
                 row_off)
             ecount = cnt_b.float()[rows]
-            brdf_weight = self.brdf.forward_compact(halfvec, diffvec, noise_feat[bidx], r1, row_of_ray, row_off)
+            brdf_weight = self.brdf.forward_compact(halfvec, diffvec, isel(noise_feat), r1, row_of_ray, row_off)
             if self.trace is not None:
                 self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
                                    f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,
@@ -189,7 +190,7 @@ class Microfacet(torch.nn.Module):
             if self.trace is not None:
                 self.trace[f"incoming{recur}"] = incoming
             ec = ecount.clip(min=1)[:, None]
-            refl_rows = ShadeMix.apply(bV, matprop["f0"][bidx], diffuse[bidx], cnt32, row_of_ray, row_off, L, incoming,
+            refl_rows = ShadeMix.apply(bV, isel(matprop["f0"]), isel(diffuse), cnt32, row_of_ray, row_off, L, incoming,
                                        brdf_weight)                                                 # :596-613
             reflect_rgb = zeros3.index_put((bidx,), refl_rows)
             with torch.no_grad():

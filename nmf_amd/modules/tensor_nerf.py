@@ -80,7 +80,7 @@ class TensorNeRF(torch.nn.Module):
         wv = S.whole_valid
         rid = S.ray_id.long()
         ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
-        viewdirs = ray_dirs[rid]
+        viewdirs = torch.index_select(ray_dirs, 0, rid)
         offsets = S.offsets[: B + 1]
 
         sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=True, want_normal=True)       # :286,386,393
