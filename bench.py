@@ -111,10 +111,18 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (see the module docstring)")
+    # NMF_BENCH_SHARE_GPU=1 + NMF_BENCH_BACKEND=gloo: functional test of the multi-process path on a 1-GPU box
+    # (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL/xGMI.
+    if os.environ.get("NMF_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("NMF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "nmf_amd", "lib", "libnmf_hip.so")):
