@@ -266,6 +266,8 @@ def composite_fwd(sigma, dist, offsets, b, distance_scale):
     M = sigma.shape[0]
     weight = torch.empty(M, dtype=torch.float32, device=sigma.device)
     acc = torch.empty(b, dtype=torch.float32, device=sigma.device)
+    if M == 0:                      # no kept sample at all: nothing to launch (empty tensors have no storage)
+        return weight, acc.zero_()
     _check(_lib.nmf_composite_fwd(_p(sigma, torch.float32), _p(dist, torch.float32), _p(offsets, torch.int64),
                                   C.c_int64(b), C.c_float(distance_scale), _p(weight), _p(acc), _stream()),
            "nmf_composite_fwd")
@@ -274,6 +276,8 @@ def composite_fwd(sigma, dist, offsets, b, distance_scale):
 
 def composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight):
     d_sigma = torch.empty_like(sigma)
+    if sigma.shape[0] == 0:
+        return d_sigma
     _check(_lib.nmf_composite_bwd(_p(sigma, torch.float32), _p(dist, torch.float32), _p(weight, torch.float32),
                                   _p(offsets, torch.int64), C.c_int64(b), C.c_float(distance_scale),
                                   _p(d_weight.contiguous(), torch.float32), _p(d_sigma), _stream()),
@@ -284,6 +288,8 @@ def composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight):
 def segment_sum(vals, scale, offsets, n_seg):
     D = vals.shape[1]
     out = torch.empty((n_seg, D), dtype=torch.float32, device=vals.device)
+    if vals.shape[0] == 0:
+        return out.zero_()
     _check(_lib.nmf_segment_sum(_p(vals, torch.float32), _p(scale), _p(offsets, torch.int64), C.c_int64(n_seg),
                                 C.c_int32(D), _p(out), _stream()), "nmf_segment_sum")
     return out
@@ -362,6 +368,8 @@ def brdf_features(half_vec, diff_vec, feat_src, rough_src, src_idx):
 
 def segment_sum_wide(vals, D, offsets, n_seg):
     out = torch.empty((n_seg, D), dtype=torch.float32, device=vals.device)
+    if vals.shape[0] == 0:
+        return out.zero_()
     _check(_lib.nmf_segment_sum_wide(_p(vals, torch.float32), C.c_int64(vals.shape[1]), C.c_int32(D),
                                      _p(offsets, torch.int64), C.c_int64(n_seg), _p(out), _stream()),
            "nmf_segment_sum_wide")

@@ -196,3 +196,91 @@ def test_e2e_full_size_seeded_vs_reference():
         ref, got = float(g[k]), float(params[name].grad.norm())
         tol = 2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3
         assert abs(got - ref) <= tol * ref + 1e-12, (name, got, ref)
+
+
+def test_edge_cases_all_rays_miss_and_single_ray():
+    """Rays that never enter the AABB / hit only empty space give M = 0 at level 0; a single ray batch works."""
+    from nmf_amd.config import build_model
+    from nmf_amd.noise import DeviceNoise
+    G = 32
+    nerf, _ = build_model(grid=G, bg_resolution=32, device=DEV)
+    nerf.load_state_dict(synthetic.state_dict_s1(grid=G, bg_resolution=32, seed=0), strict=False)
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    o = torch.tensor([[4.0, 4.0, 4.0]]).expand(37, 3)
+    d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.2, 0.1]]), dim=-1).expand(37, 3)      # pointing away
+    rays = torch.cat([o, d], -1).to(DEV).contiguous()
+    ims, st = nerf(rays, 1000.0, bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=DeviceNoise(DEV, 1))
+    assert st["n_samples"] == [0] and bool(st["whole_valid"].all())
+    assert torch.equal(ims["acc_map"].cpu(), torch.zeros(37))
+    assert_close(ims["rgb_map"].detach().cpu(), torch.ones(37, 3), what="background only")       # white bg_col
+    loss = ims["rgb_map"].sum() + st["ori_loss"] + st["prediction_loss"]
+    assert not loss.requires_grad or loss.backward() is None     # train.py:567 skips such chunks (n_samples[0] == 0)
+    with torch.no_grad():
+        ims, st = nerf(rays, 1000.0, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=DeviceNoise(DEV, 1))
+    assert ims["depth"].shape == (37,) and float(ims["depth"].abs().max()) == 0.0
+    # one ray through the cube centre
+    r1, focal = synthetic.camera_rays(1, seed=5)
+    r1[0, 3:6] = torch.nn.functional.normalize(-r1[0, 0:3], dim=0)
+    ims, st = nerf(r1.to(DEV), focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=DeviceNoise(DEV, 2))
+    assert st["n_samples"][0] > 0 and ims["rgb_map"].shape == (1, 3) and bool(torch.isfinite(ims["rgb_map"]).all())
+    (ims["rgb_map"].sum() + st["ori_loss"]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in nerf.parameters() if p.grad is not None)
+
+
+def test_short_training_curve_matches_oracle():
+    """Five optimizer steps (Adam, per-group learning rates, LambdaLR) of the HIP trainer against the same loop
+    written on the CPU oracle, with the noise of every step replayed by seed: the losses must track each other."""
+    from nmf_amd.config import build_model, resolved_config
+    from nmf_amd.noise import ReplayNoise
+    from nmf_amd.trainer import Trainer, learning_rate_decay
+    G, BG, B = 32, 32, 96
+    nerf, _ = build_model(grid=G, bg_resolution=BG, device=DEV, overrides={"model.max_retrace_rays": [200]})
+    sd0 = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
+    nerf.load_state_dict(sd0, strict=False)
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    params = resolved_config()["params"]
+    tr = Trainer(nerf, params)
+    # ---- oracle side
+    sd = {k: v.clone() for k, v in synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0).items()}
+    for k, v in sd.items():
+        if k != "model.brdf_sampler.angs":
+            v.requires_grad_(True)
+    cfg = O.Cfg(grid=G, max_retrace_rays=(200,))
+    vol = nerf.sampler.alphaMask.alpha_volume.cpu()
+    f = "rf."
+    groups = [dict(params=[sd[f + "basis_mat.weight"]], lr=1e-3),
+              dict(params=[sd[f + f"density_rf.app_plane.{i}"] for i in range(3)], lr=2e-2),
+              dict(params=[sd[f + f"density_rf.app_line.{i}"] for i in range(3)], lr=2e-2),
+              dict(params=[sd[f + f"app_rf.app_plane.{i}"] for i in range(3)], lr=2e-2),
+              dict(params=[sd[f + f"app_rf.app_line.{i}"] for i in range(3)], lr=2e-2),
+              dict(params=[v for k, v in sd.items() if k.startswith("model.diffuse_module")], lr=1e-3),
+              dict(params=[v for k, v in sd.items() if k.startswith("model.brdf.mlp")], lr=1e-3),
+              dict(params=[sd["bg_module.bg_mat"]], lr=0.02), dict(params=[sd["bg_module.mipbias"]], lr=1e-4)]
+    opt = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: float(learning_rate_decay(s, 1, 1e-3, 30000, 100, 0.1)))
+    rays, focal = synthetic.camera_rays(B, seed=11)
+    gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(3)) * 0.5 + 0.25
+    lo, lh = [], []
+    for it in range(5):
+        cfg.detach_N = it == 0
+        nerf.model.detach_N = it == 0
+        torch.manual_seed(100 + it)
+        opt.zero_grad()
+        ims, st = O.render(sd, cfg, rays, focal, vol, O.Noise(draw_unused=True), is_train=True, bg_col=torch.ones(3))
+        total, loss = O.training_loss(ims, st, gt, B, sd)
+        total.backward()
+        opt.step()
+        sched.step()
+        lo.append(float(loss))
+        torch.manual_seed(100 + it)
+        out = tr.step(rays.to(DEV), gt.to(DEV), focal, noise=ReplayNoise(DEV, None), update_controllers=False,
+                      fixed_chunk=B)
+        lh.append(out["loss"])
+    lo, lh = np.asarray(lo), np.asarray(lh)
+    assert lo[-1] < lo[0] and lh[-1] < lh[0], (lo, lh)                  # both are learning
+    assert np.all(np.abs(lh - lo) <= 2e-2 * lo), (lo, lh)              # and stay together
+    assert abs(lh[0] - lo[0]) <= 2e-3 * lo[0], (lo[0], lh[0])          # identical noise on the first step
