@@ -93,3 +93,23 @@ def camera_rays(n_rays, seed=0, eye=(2.4, -2.8, 1.6), wh=IMG_WH, all_pixels=Fals
     d = d / d.norm(dim=-1, keepdim=True)
     o = eye_t[None].expand_as(d)
     return torch.cat([o, d], dim=-1).contiguous(), focal
+
+
+def orbit_cameras(n_views, radius=4.0, seed=0):
+    """S2 "orbit": camera positions on the upper hemisphere of a sphere around the origin."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n_views, generator=g)
+    phi = 2 * math.pi * torch.rand(n_views, generator=g)
+    z = 0.15 + 0.8 * u                                  # elevation: avoid the horizon and the pole
+    rxy = torch.sqrt(1 - z * z)
+    return torch.stack([radius * rxy * torch.cos(phi), radius * rxy * torch.sin(phi), radius * z], -1)
+
+
+def orbit_rays(n_views, wh, seed=0, radius=4.0):
+    """All pixel rays of `n_views` wh x wh pinhole cameras looking at the origin -> [n_views*wh*wh, 6], focal."""
+    eyes = orbit_cameras(n_views, radius, seed)
+    out, focal = [], None
+    for e in eyes:
+        r, focal = camera_rays(0, eye=tuple(e.tolist()), wh=wh, all_pixels=True)
+        out.append(r)
+    return torch.cat(out, 0), focal

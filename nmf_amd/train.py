@@ -1,0 +1,108 @@
+"""Training entry point -- counterpart of the reference's train.py:191-901 for `model=microfacet_tensorf2` on the
+synthetic "S2 orbit" data set (nerf_synthetic is not available offline): ground-truth images are
+rendered from the S1 scene itself (eval mode), then a freshly initialised model is fitted to them.
+
+    python -m nmf_amd.train --iters 200 --views 24 --res 64 [--grid 64] [--eval-every 100]
+    python -m torch.distributed.run --nproc-per-node N -m nmf_amd.train ...        (data parallel, RCCL)
+
+Prints one JSON line per evaluation: iteration, train PSNR proxy (train.py:609-613), test PSNR with the reference's
+8-bit formula (renderer.py:399-401), rays/s.
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from . import synthetic
+from .config import build_model, resolved_config
+from .noise import DeviceNoise
+from .trainer import Trainer, psnr_8bit, rank_slice
+
+
+@torch.no_grad()
+def render_images(nerf, rays, focal, chunk, noise):
+    """chunk_renderer with render2completion (renderer.py:56-106) in eval mode -> rgb [n,3]"""
+    out = []
+    for i in range(0, rays.shape[0], chunk):
+        ims, _ = nerf(rays[i:i + chunk], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=noise)
+        out.append(ims["rgb_map"])
+    return torch.cat(out, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--views", type=int, default=24)
+    ap.add_argument("--test-views", type=int, default=4)
+    ap.add_argument("--res", type=int, default=64)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--bg", type=int, default=128)
+    ap.add_argument("--eval-every", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=20211200)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend=os.environ.get("NMF_BACKEND", "nccl"))
+
+    # ---- ground truth from the S1 scene
+    torch.manual_seed(args.seed)
+    teacher, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
+    teacher.load_state_dict(synthetic.state_dict_s1(grid=args.grid, bg_resolution=args.bg, seed=0), strict=False)
+    teacher.eval()
+    teacher.sampler.update(teacher.rf, init=False)
+    teacher.sampler.update(teacher.rf, init=True)
+    rays_tr, focal = synthetic.orbit_rays(args.views, args.res, seed=1)
+    rays_te, _ = synthetic.orbit_rays(args.test_views, args.res, seed=2)
+    rays_tr, rays_te = rays_tr.to(dev), rays_te.to(dev)
+    gt_noise = DeviceNoise(dev, seed=7)
+    rgb_tr = render_images(teacher, rays_tr, focal, 4096, gt_noise)
+    rgb_te = render_images(teacher, rays_te, focal, 4096, gt_noise)
+    del teacher
+
+    # ---- student: fresh initialisation, calibration (train.py:429-437)
+    torch.manual_seed(args.seed)                  # identical replicas on every rank
+    nerf, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
+    nerf.train()
+    params = resolved_config()["params"]
+    with torch.no_grad():
+        xyz = torch.rand(100000, 4, device=dev) * 2 - 1
+        xyz[:, 3] *= 0
+        feat = nerf.rf.compute_appfeature(xyz)
+        nerf.model.calibrate(None, xyz, feat, nerf.bg_module.mean_color().mean())
+    trainer = Trainer(nerf, params, world_size=world, rank=rank)
+    noise = DeviceNoise(dev, seed=1000 + rank)
+    g = torch.Generator(device=dev).manual_seed(args.seed)        # same permutation on every rank
+    n_total = rays_tr.shape[0]
+    perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
+    t0, rays_seen = time.time(), 0
+    for it in range(args.iters):
+        nb = trainer.lbatch_size()
+        if cur + nb > n_total:
+            perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
+        ids = perm[cur:cur + nb][rank_slice(nb, world, rank)]      # SimpleSampler (train.py:36-51), sharded over ranks
+        cur += nb
+        out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise)
+        rays_seen += out["rays"] * world
+        if (it + 1) % args.eval_every == 0 or it + 1 == args.iters:
+            nerf.eval()
+            pred = render_images(nerf, rays_te, focal, 4096, noise)
+            nerf.train()
+            psnr = float(psnr_8bit(pred.reshape(args.test_views, -1, 3), rgb_te.reshape(args.test_views, -1, 3)))
+            if rank == 0:
+                print(json.dumps(dict(iteration=it + 1, train_psnr=round(out["psnr"], 3), test_psnr=round(psnr, 3),
+                                      rays_per_s=round(rays_seen / (time.time() - t0), 1), num_rays=trainer.num_rays,
+                                      retrace=nerf.model.max_retrace_rays, n_samples=out["n_samples"])), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
