@@ -19,6 +19,7 @@ namespace {
 
 struct RayCtx {
     float ox, oy, oz, dx, dy, dz, tmin;
+    float tfar;   // distance at which the ray leaves the AABB (used only to stop marching early, with a margin)
 };
 
 __device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const float* rays, int64_t r) {
@@ -32,6 +33,7 @@ __device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const floa
     float az = fdiv(fsub(p.aabb_max[2], c.oz), vz), bz = fdiv(fsub(p.aabb_min[2], c.oz), vz);
     float t = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     c.tmin = fminf(fmaxf(t, p.near_t), p.far_t);
+    c.tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return c;
 }
 
@@ -126,12 +128,18 @@ __global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const f
     Philox rng(p.seed);
     double carry = 0.0;
     int total = 0;
-    for (int j = 0; j < W; ++j) {
+    int j = 0;
+    for (; j < W; ++j) {
         StepOut o = march_one(p, c, jitter, rng, bits, r, j * 64 + lane, carry, nullptr);
         uint64_t m = __ballot(o.keep);
         total += __popcll(m);
         if (lane == 0) valid[r * W + j] = m;
+        // z grows monotonically along the ray: once the last step of this chunk is clearly beyond the AABB exit
+        // every later step fails the in-box test (:195) too.  The 1e-2 margin dwarfs the fp32 error of the positions.
+        const float z_last = __shfl(o.z, 63, 64);
+        if (z_last > c.tfar + 1e-2f) { ++j; break; }
     }
+    for (int jj = j + lane; jj < W; jj += 64) valid[r * W + jj] = 0ull;
     if (lane == 0) counts[r] = total;
 }
 
@@ -146,7 +154,8 @@ __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const fl
     const int lane = lane_id();
     const int W = (p.n_steps + 63) >> 6;
     int64_t base = offsets[r];
-    if (offsets[r + 1] == base) return;       // wave-uniform: nothing kept on this ray
+    const int64_t end = offsets[r + 1];
+    if (end == base) return;                  // wave-uniform: nothing kept on this ray
     RayCtx c = load_ray(p, rays, r);
     Philox rng(p.seed);
     double carry = 0.0;
@@ -178,6 +187,7 @@ __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const fl
             }
         }
         base += __popcll(m);
+        if (base >= end) break;               // every kept sample of this ray has been written
     }
 }
 

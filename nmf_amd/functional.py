@@ -85,35 +85,54 @@ def segment_sum(vals, offsets, seg_id, n_seg):
     return SegmentSum.apply(vals, offsets, seg_id, n_seg)
 
 
+class SatBuild(torch.autograd.Function):
+    """Graph node for the cached summed-area table: sat = cumsum_W(cumsum_H(exp(brightness + mul*bg_mat)/1000))
+    (modules/integral_equirect.py:431-433).  All lookups of one backward pass feed their table adjoints into this
+    single node, so the two reverse prefix sums run once per step instead of once per lookup."""
+
+    @staticmethod
+    def forward(ctx, env, bg_mat, brightness, mul):
+        act, sat, pole = env._tables()
+        ctx.env = env
+        return sat.detach().view_as(sat)
+
+    @staticmethod
+    def backward(ctx, d_sat):
+        env = ctx.env
+        act, sat, pole = env._tables()
+        _, br, mul = env._host_scalars()
+        d_pole = env._d_pole
+        d_bg = hip.sat_build_bwd(d_sat.contiguous().clone(), env.bg_mat.detach(), act, d_pole, br, mul)
+        env._graph = None                                    # the node is consumed; the next forward makes a new one
+        d_pre = d_bg / mul                                   # adjoint of (brightness + mul * bg_mat)
+        d_br = d_pre.sum(dtype=torch.float64)
+        d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
+        return None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul
+
+
 class EnvLookup(torch.autograd.Function):
     """IntegralEquirect.forward (modules/integral_equirect.py:409-504) on the cached SAT."""
 
     @staticmethod
-    def forward(ctx, env, dirs, sa, bg_mat, mipbias, brightness, mul):
-        act, sat, pole = env._tables()
+    def forward(ctx, env, dirs, sa, sat, mipbias):
+        act, _, pole = env._tables()
         dirs_c = dirs.contiguous()
         sa_c = sa.reshape(-1).contiguous()
-        out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, float(mipbias), pole)
+        mip = env._host_scalars()[0]
+        out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, mip, pole)
         ctx.env = env
-        ctx.save_for_backward(dirs_c, sa_c)
-        ctx.mip = float(mipbias)
+        ctx.save_for_backward(dirs_c, sa_c, sat)
+        ctx.mip = mip
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         env = ctx.env
-        dirs, sa = ctx.saved_tensors
-        act, sat, pole = env._tables()
+        dirs, sa, sat = ctx.saved_tensors
         d_sat = torch.zeros_like(sat)
-        d_pole = torch.zeros((2, 3), dtype=torch.float32, device=sat.device)
-        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
+        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, env._d_pole,
                                            want_dirs=ctx.needs_input_grad[1], want_mipbias=True)
-        _, br, mul = env._host_scalars()
-        d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, br, mul)
-        d_pre = d_bg / mul                                   # adjoint of (brightness + mul * bg_mat)
-        d_br = d_pre.sum(dtype=torch.float64)
-        d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
-        return None, d_dirs, None, d_bg.reshape(env.bg_mat.shape), d_mip.to(torch.float64).reshape(()), d_br, d_mul
+        return None, d_dirs, None, d_sat, d_mip.to(torch.float64).reshape(())
 
 
 class BrdfFeatures(torch.autograd.Function):
