@@ -246,6 +246,25 @@ int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const fl
 int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
                          int64_t n_seg, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam over the per-module param groups (train.py:443-469), every tensor in one launch.
+ * `slots` is a HOST array (copied into kernel arguments); hyper-parameters per slot are the group's, with the
+ * bias corrections computed by the host in double precision exactly as torch/optim/adam.py does:
+ *   step_size = lr / (1 - beta1^t),  bc2_sqrt = sqrt(1 - beta2^t).
+ * param/grad/exp_avg/exp_avg_sq share one dense layout of `numel` elements (fp32, or fp64 when is_f64).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    void* param;
+    const void* grad;
+    void* exp_avg;
+    void* exp_avg_sq;
+    int64_t numel;
+    double beta1, beta2, eps, weight_decay, step_size, bc2_sqrt;
+    int32_t is_f64;
+    int32_t reserved;
+} nmf_adam_slot;
+int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+// Adam step for every parameter tensor of the scene in ONE launch (reference: train.py:443-469 builds a
+// torch.optim.Adam over ~31 tensors in 11 param groups; its foreach implementation issues ~13 kernels per group
+// = ~160 launches per optimizer step, more host time than the 14 MB of state deserves).
+//
+// The host passes a table of slots (pointers + per-group hyper-parameters, already bias-corrected as torch does
+// on the host in double precision); slots travel BY VALUE in the kernel argument buffer, so there is no H2D copy
+// and no lifetime problem.  blockIdx.y = slot, blockIdx.x grid-strides over the tensor.  The update is torch's
+// _multi_tensor_adam (optim/adam.py, amsgrad=False, maximize=False, capturable=False):
+//   g   = grad + weight_decay * p
+//   m   = m + (g - m) * (1 - beta1)                          (lerp_)
+//   v   = v * beta2 + (1 - beta2) * g * g                    (mul_, addcmul_)
+//   p   = p - step_size * m / (sqrt(v) / bc2_sqrt + eps)     (sqrt, div_, add_, addcdiv_)
+// in the parameter's own dtype (fp32 tables, fp64 for the three env-map scalars).
+#include "common.hpp"
+
+namespace {
+
+constexpr int SLOTS_PER_LAUNCH = 40;
+
+struct Batch {
+    nmf_adam_slot s[SLOTS_PER_LAUNCH];
+};
+
+template <typename T>
+__device__ __forceinline__ void adam_one(T& p, T g, T& m, T& v, T wd, T omb1, T b2, T omb2, T step, T bc2s, T eps) {
+    if (wd != T(0)) g = g + wd * p;
+    // at::lerp: weight < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+    const T diff = g - m;
+    m = (omb1 < T(0.5)) ? m + omb1 * diff : g - diff * (T(1) - omb1);
+    v = v * b2 + omb2 * g * g;
+    const T denom = sqrt(v) / bc2s + eps;
+    p = p + (-step) * (m / denom);
+}
+
+template <typename T>
+__device__ void adam_slot(const nmf_adam_slot& s) {
+    T* __restrict__ p = static_cast<T*>(s.param);
+    const T* __restrict__ g = static_cast<const T*>(s.grad);
+    T* __restrict__ m = static_cast<T*>(s.exp_avg);
+    T* __restrict__ v = static_cast<T*>(s.exp_avg_sq);
+    const T wd = (T)s.weight_decay, omb1 = (T)(1.0 - (double)s.beta1), b2 = (T)s.beta2,
+            omb2 = (T)(1.0 - (double)s.beta2), step = (T)s.step_size, bc2s = (T)s.bc2_sqrt, eps = (T)s.eps;
+    const int64_t n = s.numel;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T pp = p[i], mm = m[i], vv = v[i];
+        adam_one<T>(pp, g[i], mm, vv, wd, omb1, b2, omb2, step, bc2s, eps);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_adam(Batch b) {
+    const nmf_adam_slot& s = b.s[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;
+    if (s.is_f64) adam_slot<double>(s);
+    else adam_slot<float>(s);
+}
+
+}  // namespace
+
+extern "C" int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream) {
+    NMF_REQUIRE(slots != nullptr || n_slots == 0, NMF_EINVAL, "nmf_adam_step: null slot table");
+    NMF_REQUIRE(n_slots >= 0, NMF_EINVAL, "nmf_adam_step: negative slot count");
+    for (int32_t i = 0; i < n_slots; ++i) {
+        const nmf_adam_slot& s = slots[i];
+        NMF_REQUIRE(s.numel >= 0, NMF_EINVAL, "nmf_adam_step: negative numel");
+        NMF_REQUIRE(s.numel == 0 || (s.param && s.grad && s.exp_avg && s.exp_avg_sq), NMF_EINVAL,
+                    "nmf_adam_step: null tensor pointer");
+    }
+    for (int32_t base = 0; base < n_slots; base += SLOTS_PER_LAUNCH) {
+        const int32_t n = (n_slots - base < SLOTS_PER_LAUNCH) ? n_slots - base : SLOTS_PER_LAUNCH;
+        Batch b;
+        memset(&b, 0, sizeof(b));
+        int64_t biggest = 0;
+        for (int32_t i = 0; i < n; ++i) {
+            b.s[i] = slots[base + i];
+            if (b.s[i].numel > biggest) biggest = b.s[i].numel;
+        }
+        if (biggest == 0) continue;
+        int64_t bx = cdiv(biggest, 256 * 4);
+        if (bx > 1024) bx = 1024;
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        NMF_CHECK_LAUNCH("k_adam");
+    }
+    return NMF_OK;
+}

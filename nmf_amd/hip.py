@@ -46,6 +46,13 @@ class VmParams(C.Structure):
                 ("grid", C.c_int32), ("stencil", C.c_float * 5), ("stencil_off", C.c_float * 5)]
 
 
+class AdamSlot(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("step_size", C.c_double), ("bc2_sqrt", C.c_double),
+                ("is_f64", C.c_int32), ("reserved", C.c_int32)]
+
+
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
@@ -53,6 +60,7 @@ EXPORTS = [
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
+    "nmf_adam_step",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -461,3 +469,9 @@ def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
                                   _p(brdf, torch.float32), _p(d_rows, torch.float32), _p(d_inc), _p(d_brdf), _p(dL),
                                   _p(d_fd), _stream()), "nmf_shade_mix_bwd")
     return d_inc, d_brdf, dL, d_fd
+
+
+# ---- optimizer ----------------------------------------------------------------------------------
+def adam_step(slots, n):
+    """slots: (AdamSlot * k) host array, the first n entries are applied in one launch (nmf_adam_step)."""
+    _check(_lib.nmf_adam_step(slots, C.c_int32(n), _stream()), "nmf_adam_step")

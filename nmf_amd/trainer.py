@@ -9,6 +9,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .optim import FusedAdam
+
 
 def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
     # utils.py:327-359
@@ -76,7 +78,7 @@ class Trainer:
         # train.py:443-469: Adam over the per-module param groups, LambdaLR(learning_rate_decay) from step 0
         p = self.p
         groups = self.nerf.get_optparam_groups()
-        self.optimizer = torch.optim.Adam(groups, betas=tuple(p["betas"]), eps=p["eps"], weight_decay=p["weight_decay"])
+        self.optimizer = FusedAdam(groups, betas=tuple(p["betas"]), eps=p["eps"], weight_decay=p["weight_decay"])
         lam = lambda s: float(learning_rate_decay(s, p["lr_init"], p["lr_final"], p["n_iters"], p["lr_delay_steps"],  # noqa: E731
                                                   p["lr_delay_mult"]))
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lam)

@@ -554,3 +554,44 @@ def test_ggx_rays_and_mix_vs_oracle():
     g_h = torch.autograd.grad((out * d(cc)).sum(), td)
     for a, b, n in zip(g_h, g_o, ["f0", "diffuse", "L", "incoming", "brdf"]):
         assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), what="mix d" + n)
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam():
+    """nmf_adam_step (one launch for every tensor) against torch.optim.Adam (train.py:443-469): per-group lr / betas,
+    fp64 scalars, channels-last tables, a parameter without gradient, LambdaLR between steps."""
+    from nmf_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(5)
+
+    def make():
+        g = torch.Generator().manual_seed(11)
+        ps = [torch.randn(1, 16, 33, 33, generator=g).to(memory_format=torch.channels_last), torch.randn(70001, generator=g),
+              torch.randn(64, 66, generator=g), torch.tensor(1.0, dtype=torch.float64), torch.randn(5, generator=g),
+              torch.randn(3, 7, generator=g)]
+        return [torch.nn.Parameter(p.to(DEV)) for p in ps]
+
+    pa, pb = make(), make()
+    groups = lambda ps: [dict(params=ps[:2], lr=0.02), dict(params=ps[2:3], lr=1e-3, betas=(0.9, 0.9)),  # noqa: E731
+                         dict(params=ps[3:4], lr=1e-4), dict(params=ps[4:], lr=0.5, weight_decay=0.01)]
+    oa = torch.optim.Adam(groups(pa), betas=(0.9, 0.99), eps=1e-8)
+    ob = FusedAdam(groups(pb), betas=(0.9, 0.99), eps=1e-8)
+    sa = torch.optim.lr_scheduler.LambdaLR(oa, lambda s: 0.9 ** s)
+    sb = torch.optim.lr_scheduler.LambdaLR(ob, lambda s: 0.9 ** s)
+    for it in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 5 and it < 2:
+                a.grad = b.grad = None           # no gradient yet: state must start at the first real step
+                continue
+            scale = 10.0 ** torch.randint(-4, 2, (1,), generator=gen).item()
+            g = (torch.randn(a.shape, generator=gen, dtype=a.dtype) * scale).to(DEV)
+            if a.dim() == 4:
+                g = g.to(memory_format=torch.channels_last)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert a.stride() == b.stride()
+        assert_close(b.detach().cpu(), a.detach().cpu(), rtol=2e-6, atol=2e-7, what=f"adam param {i}")
+        assert int(ob.state[b]["step"]) == int(oa.state[a]["step"])
+        assert_close(ob.state[b]["exp_avg_sq"].cpu(), oa.state[a]["exp_avg_sq"].cpu(), rtol=2e-6, atol=1e-12, what=f"v {i}")
+    ob2 = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-8)
+    ob2.load_state_dict(ob.state_dict())             # state_dict is interchangeable with torch.optim.Adam
