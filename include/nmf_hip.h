@@ -247,6 +247,47 @@ int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const
                          int64_t n_seg, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Shading glue (csrc/shade.hip): the per-sample / per-ray spans between the big operators.
+ * ---------------------------------------------------------------------------------------- */
+/* models/microfacet.py:333-350.  counts [M] = secondary rays per sample (nmf_select_bounces).  Outputs:
+ * bidx [>=Mb] samples with counts > 0 in order ("rows"), row_off [>=Mb+1] exclusive scan of their counts
+ * (row_off[Mb] = R), cnt_rows [>=Mb] their counts, inv [M] row of each sample or -1, totals = {R, Mb}.
+ * bidx / row_off / cnt_rows are sized by the caller for the worst case (M, M+1, M). */
+int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off, int32_t* cnt_rows,
+                     int32_t* inv, int64_t* totals, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t nmf_bounce_index_workspace_bytes(int64_t M);
+/* Per bounce row (models/microfacet.py:297,304-316,352-361): V = -ray direction, N = normal facing V
+ * (n * sign(V.n)), r1 = max(roughness, min_rough), f0, diffuse = albedo * E(n) with E the 9-term SH irradiance
+ * (conv [9][3] DEVICE pointer, modules/sh.py:97-142), feat = app + anoise * feat_noise (feat_noise may be NULL),
+ * xyz.  heads [M][11] is nmf_heads_fwd's output, rays [b][6], ray_id [M]. */
+int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* app, const float* heads,
+                        const float* xyzt, const int32_t* ray_id, const float* rays, const float* conv,
+                        const float* feat_noise, float anoise, float min_rough, float* V, float* N, float* r1,
+                        float* f0, float* diffuse, float* feat, float* xyz, void* stream);
+/* Adjoint, written for ALL M samples (zeros where inv < 0): d_normals [M][3] (zero when detach_normals),
+ * d_heads [M][11], d_app [M][24].  Row gradients may be NULL (= zero). */
+int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
+                        const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
+                        int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
+                        const float* ddiffuse, const float* dfeat, float* d_normals, float* d_heads, float* d_app,
+                        void* stream);
+/* modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py:34-55, one thread per ray in sample order:
+ * acc = sum w, rgb_lin = sum w * refl_rows[inv], ori = sum w * min(-d.n, 0)^2 (ori / normals may be NULL),
+ * rgb_map = (tonemap ? srgb(rgb_lin) : rgb_lin) + (1 - acc) * bg;  bg [3] or [B][3] (bg_per_ray). */
+int nmf_ray_compose_fwd(const float* weight, const float* refl_rows, const int32_t* inv, const float* normals,
+                        const float* rays, const int64_t* offsets, int64_t B, const float* bg, int32_t bg_per_ray,
+                        int32_t tonemap, int32_t noclip, float* rgb_map, float* acc, float* rgb_lin, float* ori,
+                        void* stream);
+/* Adjoint, one thread per sample: d_weight [M], d_refl [Mb][3] (every row written), d_normals [M][3] (may be NULL).
+ * d_rgb_map [B][3], d_acc [B], d_ori [B] may each be NULL.  The background gradient (1 - acc) * d_rgb_map is
+ * left to the caller. */
+int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, const int32_t* inv, const float* normals,
+                        const float* rays, const int32_t* ray_id, int64_t M, const float* bg, int32_t bg_per_ray,
+                        int32_t tonemap, int32_t noclip, const float* rgb_lin, const float* d_rgb_map,
+                        const float* d_acc, const float* d_ori, float* d_weight, float* d_refl, float* d_normals,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam over the per-module param groups (train.py:443-469), every tensor in one launch.
  * `slots` is a HOST array (copied into kernel arguments); hyper-parameters per slot are the group's, with the
  * bias corrections computed by the host in double precision exactly as torch/optim/adam.py does:

@@ -1,0 +1,423 @@
+// Per-sample / per-ray glue of the shading step for gfx950 -- the spans of models/microfacet.py and
+// modules/tensor_nerf.py that sit between the big operators, each fused into one streaming pass:
+//
+//   nmf_bounce_index      which samples spawn secondary rays: compact row list, ray offsets per row, inverse map
+//                         (models/microfacet.py:333-350: ray_mask / bounce_mask / torch.where bookkeeping)
+//   nmf_bounce_prep_*     everything the secondary-ray kernels need per bounce row, gathered in one pass: view
+//                         vector, facing normal (:356), clipped roughness (:361), f0, diffuse = albedo * SH irradiance
+//                         (:304-316, modules/sh.py:97-142), noised appearance feature (:297), position
+//   nmf_ray_compose_*     weights x radiance -> pixel: acc / rgb segment sums (modules/tensor_nerf.py:448-452), the
+//                         orientation loss term (:583-587), sRGB tonemap (modules/tonemap.py:34-55) and background
+//                         blend (:658-659)
+//
+// All three are HBM streaming kernels (a few hundred bytes per sample); their point is launch count: the torch
+// formulation is ~150 elementwise / index launches per level and as many again in the backward.
+#include "common.hpp"
+
+namespace {
+
+// ---- bounce index ------------------------------------------------------------------------------------------------
+constexpr int IDX_CHUNK = 1024;
+constexpr int FLAG_SHIFT = 40;   // packed scan value = count + (count > 0) << 40
+
+__device__ __forceinline__ int64_t wave_scan_i64(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// inclusive scan over a 1024-thread block; returns the inclusive value, *total = block sum
+__device__ __forceinline__ int64_t block_scan_i64(int64_t v, int64_t* ws /*[17]*/, int64_t* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int64_t incl = wave_scan_i64(v, lane);
+    if (lane == 63) ws[wid] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int w = 0; w < IDX_CHUNK / 64; ++w) {
+            int64_t t = ws[w];
+            ws[w] = run;
+            run += t;
+        }
+        ws[16] = run;
+    }
+    __syncthreads();
+    incl += ws[wid];
+    *total = ws[16];
+    __syncthreads();
+    return incl;
+}
+
+__global__ void __launch_bounds__(IDX_CHUNK) k_idx_partial(const int32_t* __restrict__ counts, int64_t M,
+                                                          int64_t* __restrict__ chunk_sum) {
+    __shared__ int64_t ws[17];
+    const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + threadIdx.x;
+    const int32_t c = i < M ? counts[i] : 0;
+    const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
+    int64_t total;
+    block_scan_i64(v, ws, &total);
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(IDX_CHUNK) k_idx_top(int64_t* __restrict__ chunk_sum, int n_chunks,
+                                                      int64_t* __restrict__ totals) {
+    __shared__ int64_t ws[17];
+    int64_t carry = 0;
+    for (int base = 0; base < n_chunks; base += IDX_CHUNK) {
+        const int i = base + threadIdx.x;
+        const int64_t v = i < n_chunks ? chunk_sum[i] : 0;
+        int64_t total;
+        const int64_t incl = block_scan_i64(v, ws, &total);
+        if (i < n_chunks) chunk_sum[i] = carry + incl - v;   // exclusive base of chunk i
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry & (((int64_t)1 << FLAG_SHIFT) - 1);   // R  = secondary rays
+        totals[1] = carry >> FLAG_SHIFT;                        // Mb = samples with at least one
+    }
+}
+
+__global__ void __launch_bounds__(IDX_CHUNK) k_idx_final(const int32_t* __restrict__ counts, int64_t M,
+                                                        const int64_t* __restrict__ chunk_base,
+                                                        const int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
+                                                        int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
+                                                        int32_t* __restrict__ inv) {
+    __shared__ int64_t ws[17];
+    const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + threadIdx.x;
+    const int32_t c = i < M ? counts[i] : 0;
+    const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
+    int64_t total;
+    const int64_t excl = chunk_base[blockIdx.x] + block_scan_i64(v, ws, &total) - v;
+    if (i < M) {
+        if (c > 0) {
+            const int64_t row = excl >> FLAG_SHIFT;
+            bidx[row] = (int32_t)i;
+            cnt_rows[row] = c;
+            row_off[row] = excl & (((int64_t)1 << FLAG_SHIFT) - 1);
+            inv[i] = (int32_t)row;
+        } else {
+            inv[i] = -1;
+        }
+    }
+    if (i == 0) row_off[totals[1]] = totals[0];
+}
+
+// ---- bounce prep -------------------------------------------------------------------------------------------------
+constexpr int HEADS = 11;       // albedo 3 | tint 3 | f0 3 | roughness 2 (nmf_heads_fwd)
+constexpr int FEAT = NMF_APP_DIM;
+
+struct Conv {
+    const float* c;   // [9][3] device pointer, uniform -> scalar loads
+};
+
+// the 9 real SH bases of modules/sh.py:97-142 (all-positive SH_C2 table of :67-73)
+__device__ __forceinline__ void sh9(float x, float y, float z, float (&Y)[9]) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
+    Y[0] = C0;
+    Y[1] = C1 * y;
+    Y[2] = C1 * z;
+    Y[3] = C1 * x;
+    Y[4] = C20 * (x * y);
+    Y[5] = C20 * (y * z);
+    Y[6] = C22 * (3.f * (z * z) - 1.f);
+    Y[7] = C20 * (x * z);
+    Y[8] = C24 * (x * x - y * y);
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(256) k_bounce_prep_fwd(
+    const int32_t* __restrict__ bidx, int64_t Mb, const float* __restrict__ normals, const float* __restrict__ app,
+    const float* __restrict__ heads, const float4* __restrict__ xyzt, const int32_t* __restrict__ ray_id,
+    const float* __restrict__ rays, Conv conv, const float* __restrict__ feat_noise, float anoise, float min_rough,
+    float* __restrict__ V, float* __restrict__ N, float* __restrict__ r1, float* __restrict__ f0,
+    float* __restrict__ diffuse, float* __restrict__ feat, float* __restrict__ xyz) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Mb) return;
+    const int64_t m = bidx[row];
+    const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
+    const float vx = -d[0], vy = -d[1], vz = -d[2];
+    const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
+    const float s = sgn(vx * nx + vy * ny + vz * nz);                       // models/microfacet.py:356
+    V[row * 3] = vx; V[row * 3 + 1] = vy; V[row * 3 + 2] = vz;
+    N[row * 3] = nx * s; N[row * 3 + 1] = ny * s; N[row * 3 + 2] = nz * s;
+    const float* h = heads + m * HEADS;
+    r1[row] = fmaxf(h[9], min_rough);
+    float Y[9];
+    sh9(nx, ny, nz, Y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float E = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
+        diffuse[row * 3 + c] = h[c] * E;
+        f0[row * 3 + c] = h[6 + c];
+    }
+    const float4 p = xyzt[m];
+    xyz[row * 3] = p.x; xyz[row * 3 + 1] = p.y; xyz[row * 3 + 2] = p.z;
+    const float4* a4 = reinterpret_cast<const float4*>(app + m * FEAT);
+    const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + m * FEAT) : nullptr;
+    float4* o4 = reinterpret_cast<float4*>(feat + row * FEAT);
+#pragma unroll
+    for (int i = 0; i < FEAT / 4; ++i) {
+        float4 a = a4[i];
+        if (n4) {
+            const float4 z = n4[i];
+            a.x += z.x * anoise; a.y += z.y * anoise; a.z += z.z * anoise; a.w += z.w * anoise;
+        }
+        o4[i] = a;
+    }
+}
+
+// one thread per SAMPLE: rows scatter back through the inverse map, everything else is written as zero, so the
+// three gradient tensors need no separate fill
+__global__ void __launch_bounds__(256) k_bounce_prep_bwd(
+    const int32_t* __restrict__ inv, int64_t M, const float* __restrict__ normals, const float* __restrict__ heads,
+    const int32_t* __restrict__ ray_id, const float* __restrict__ rays, Conv conv, float min_rough, int detach_n,
+    const float* __restrict__ dN, const float* __restrict__ dr1, const float* __restrict__ df0,
+    const float* __restrict__ ddiff, const float* __restrict__ dfeat, float* __restrict__ d_normals,
+    float* __restrict__ d_heads, float* __restrict__ d_app) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int64_t row = inv[m];
+    float gn[3] = {0.f, 0.f, 0.f};
+    float gh[HEADS];
+#pragma unroll
+    for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
+    float4* o4 = reinterpret_cast<float4*>(d_app + m * FEAT);
+    if (row >= 0) {
+        const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
+        if (!detach_n && dN) {
+            const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
+            const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
+            gn[0] = dN[row * 3] * s; gn[1] = dN[row * 3 + 1] * s; gn[2] = dN[row * 3 + 2] * s;
+        }
+        const float* h = heads + m * HEADS;
+        float Y[9];
+        sh9(nx, ny, nz, Y);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float E = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
+            gh[c] = ddiff ? ddiff[row * 3 + c] * E : 0.f;
+            gh[6 + c] = df0 ? df0[row * 3 + c] : 0.f;
+        }
+        gh[9] = (dr1 && h[9] >= min_rough) ? dr1[row] : 0.f;
+        const float4* g4 = dfeat ? reinterpret_cast<const float4*>(dfeat + row * FEAT) : nullptr;
+#pragma unroll
+        for (int i = 0; i < FEAT / 4; ++i) o4[i] = g4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < FEAT / 4; ++i) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    d_normals[m * 3] = gn[0]; d_normals[m * 3 + 1] = gn[1]; d_normals[m * 3 + 2] = gn[2];
+#pragma unroll
+    for (int j = 0; j < HEADS; ++j) d_heads[m * HEADS + j] = gh[j];
+}
+
+// ---- ray compose -------------------------------------------------------------------------------------------------
+constexpr float SRGB_LIMIT = 0.0031308f;
+
+__device__ __forceinline__ float srgb(float x, int noclip) {
+    // modules/tonemap.py:34-55: where(x > limit, 1.055 * clip(x, min=limit)^(1/2.4) - 0.055, 12.92 x), clip(0, 1)
+    float o = x > SRGB_LIMIT ? 1.055f * powf(fmaxf(x, SRGB_LIMIT), 1.0f / 2.4f) - 0.055f : 12.92f * x;
+    return noclip ? o : fminf(fmaxf(o, 0.f), 1.f);
+}
+
+__device__ __forceinline__ float srgb_grad(float x, int noclip) {
+    float o, g;
+    if (x > SRGB_LIMIT) {
+        const float p = powf(x, 1.0f / 2.4f);
+        o = 1.055f * p - 0.055f;
+        g = 1.055f * (1.0f / 2.4f) * p / x;
+    } else {
+        o = 12.92f * x;
+        g = 12.92f;
+    }
+    if (!noclip && (o < 0.f || o > 1.f)) g = 0.f;
+    return g;
+}
+
+__global__ void __launch_bounds__(256) k_ray_compose_fwd(
+    const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
+    const float* __restrict__ normals, const float* __restrict__ rays, const int64_t* __restrict__ offsets, int64_t B,
+    const float* __restrict__ bg, int bg_per_ray, int tonemap, int noclip, float* __restrict__ rgb_map,
+    float* __restrict__ acc_out, float* __restrict__ rgb_lin, float* __restrict__ ori_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const int64_t s = offsets[r], e = offsets[r + 1];
+    const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+    float acc = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, ori = 0.f;
+    for (int64_t k = s; k < e; ++k) {
+        const float w = weight[k];
+        acc += w;
+        if (inv && refl_rows) {
+            const int64_t row = inv[k];
+            if (row >= 0) {
+                c0 += w * refl_rows[row * 3];
+                c1 += w * refl_rows[row * 3 + 1];
+                c2 += w * refl_rows[row * 3 + 2];
+            }
+        }
+        if (ori_out) {
+            const float ndv = fminf(-(dx * normals[k * 3] + dy * normals[k * 3 + 1] + dz * normals[k * 3 + 2]), 0.f);
+            ori += w * (ndv * ndv);
+        }
+    }
+    rgb_lin[r * 3] = c0; rgb_lin[r * 3 + 1] = c1; rgb_lin[r * 3 + 2] = c2;
+    acc_out[r] = acc;
+    if (ori_out) ori_out[r] = ori;
+    const float* b = bg + (bg_per_ray ? r * 3 : 0);
+    const float t = 1.f - acc;
+    rgb_map[r * 3] = (tonemap ? srgb(c0, noclip) : c0) + t * b[0];
+    rgb_map[r * 3 + 1] = (tonemap ? srgb(c1, noclip) : c1) + t * b[1];
+    rgb_map[r * 3 + 2] = (tonemap ? srgb(c2, noclip) : c2) + t * b[2];
+}
+
+// one thread per sample
+__global__ void __launch_bounds__(256) k_ray_compose_bwd(
+    const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
+    const float* __restrict__ normals, const float* __restrict__ rays, const int32_t* __restrict__ ray_id, int64_t M,
+    const float* __restrict__ bg, int bg_per_ray, int tonemap, int noclip, const float* __restrict__ rgb_lin,
+    const float* __restrict__ d_rgb_map, const float* __restrict__ d_acc, const float* __restrict__ d_ori,
+    float* __restrict__ d_weight, float* __restrict__ d_refl, float* __restrict__ d_normals) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int64_t r = ray_id[m];
+    const float w = weight[m];
+    float g[3] = {0.f, 0.f, 0.f};
+    float ga = d_acc ? d_acc[r] : 0.f;
+    if (d_rgb_map) {
+        const float* b = bg + (bg_per_ray ? r * 3 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float dm = d_rgb_map[r * 3 + c];
+            g[c] = tonemap ? dm * srgb_grad(rgb_lin[r * 3 + c], noclip) : dm;
+            ga -= dm * b[c];
+        }
+    }
+    float dw = ga;
+    const int64_t row = (inv && refl_rows) ? inv[m] : -1;
+    if (row >= 0) {
+        dw += g[0] * refl_rows[row * 3] + g[1] * refl_rows[row * 3 + 1] + g[2] * refl_rows[row * 3 + 2];
+        d_refl[row * 3] = w * g[0]; d_refl[row * 3 + 1] = w * g[1]; d_refl[row * 3 + 2] = w * g[2];
+    }
+    float gn[3] = {0.f, 0.f, 0.f};
+    if (d_ori) {
+        const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+        const float ndv = -(dx * normals[m * 3] + dy * normals[m * 3 + 1] + dz * normals[m * 3 + 2]);
+        if (ndv < 0.f) {
+            const float go = d_ori[r];
+            dw += go * ndv * ndv;
+            const float k = go * w * 2.f * ndv;
+            gn[0] = -k * dx; gn[1] = -k * dy; gn[2] = -k * dz;
+        }
+    }
+    d_weight[m] = dw;
+    if (d_normals) {
+        d_normals[m * 3] = gn[0]; d_normals[m * 3 + 1] = gn[1]; d_normals[m * 3 + 2] = gn[2];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t nmf_bounce_index_workspace_bytes(int64_t M) { return (cdiv(M > 0 ? M : 1, IDX_CHUNK) + 1) * 8; }
+
+extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
+                                int32_t* cnt_rows, int32_t* inv, int64_t* totals, void* workspace, int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_index: M < 0");
+    NMF_REQUIRE(totals && row_off, NMF_EINVAL, "nmf_bounce_index: null");
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(totals, 0, 16, st);
+        if (e == hipSuccess) e = hipMemsetAsync(row_off, 0, 8, st);
+        return e == hipSuccess ? NMF_OK : nmf_fail((int)e, "nmf_bounce_index: memset");
+    }
+    NMF_REQUIRE(counts && bidx && cnt_rows && inv && workspace, NMF_EINVAL, "nmf_bounce_index: null");
+    const int64_t n_chunks = cdiv(M, IDX_CHUNK);
+    NMF_REQUIRE(workspace_bytes >= nmf_bounce_index_workspace_bytes(M), NMF_EINVAL, "nmf_bounce_index: workspace too small");
+    NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
+    int64_t* chunk = static_cast<int64_t*>(workspace);
+    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk);
+    hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
+    hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
+                       row_off, cnt_rows, inv);
+    NMF_CHECK_LAUNCH("nmf_bounce_index");
+    return NMF_OK;
+}
+
+static Conv load_conv(const float* conv) {
+    Conv c;
+    c.c = conv;
+    return c;
+}
+
+extern "C" int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* app,
+                                   const float* heads, const float* xyzt, const int32_t* ray_id, const float* rays,
+                                   const float* conv, const float* feat_noise, float anoise, float min_rough,
+                                   float* V, float* N, float* r1, float* f0, float* diffuse, float* feat, float* xyz,
+                                   void* stream) {
+    NMF_REQUIRE(Mb >= 0, NMF_EINVAL, "nmf_bounce_prep_fwd: Mb < 0");
+    if (Mb == 0) return NMF_OK;
+    NMF_REQUIRE(bidx && normals && app && heads && xyzt && ray_id && rays && conv && V && N && r1 && f0 &&
+                    diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd: null");
+    hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
+                       normals, app, heads, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
+                       feat_noise, anoise, min_rough, V, N, r1, f0, diffuse, feat, xyz);
+    NMF_CHECK_LAUNCH("nmf_bounce_prep_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
+                                   const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
+                                   int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
+                                   const float* ddiffuse, const float* dfeat, float* d_normals, float* d_heads,
+                                   float* d_app, void* stream) {
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_prep_bwd: M < 0");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(inv && normals && heads && ray_id && rays && conv && d_normals && d_heads && d_app, NMF_EINVAL,
+                "nmf_bounce_prep_bwd: null");
+    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, inv, M,
+                       normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, dN, dr1, df0,
+                       ddiffuse, dfeat, d_normals, d_heads, d_app);
+    NMF_CHECK_LAUNCH("nmf_bounce_prep_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_ray_compose_fwd(const float* weight, const float* refl_rows, const int32_t* inv, const float* normals,
+                                   const float* rays, const int64_t* offsets, int64_t B, const float* bg,
+                                   int32_t bg_per_ray, int32_t tonemap, int32_t noclip, float* rgb_map, float* acc,
+                                   float* rgb_lin, float* ori, void* stream) {
+    NMF_REQUIRE(B >= 0, NMF_EINVAL, "nmf_ray_compose_fwd: B < 0");
+    if (B == 0) return NMF_OK;
+    // weight may be NULL when no ray has a sample (every segment empty)
+    NMF_REQUIRE(rays && offsets && bg && rgb_map && acc && rgb_lin, NMF_EINVAL, "nmf_ray_compose_fwd: null");
+    NMF_REQUIRE(!ori || normals, NMF_EINVAL, "nmf_ray_compose_fwd: ori needs normals");
+    hipLaunchKernelGGL(k_ray_compose_fwd, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip, rgb_map,
+                       acc, rgb_lin, ori);
+    NMF_CHECK_LAUNCH("nmf_ray_compose_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, const int32_t* inv, const float* normals,
+                                   const float* rays, const int32_t* ray_id, int64_t M, const float* bg,
+                                   int32_t bg_per_ray, int32_t tonemap, int32_t noclip, const float* rgb_lin,
+                                   const float* d_rgb_map, const float* d_acc, const float* d_ori, float* d_weight,
+                                   float* d_refl, float* d_normals, void* stream) {
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_ray_compose_bwd: M < 0");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(weight && rays && ray_id && bg && rgb_lin && d_weight, NMF_EINVAL, "nmf_ray_compose_bwd: null");
+    NMF_REQUIRE(!(inv && refl_rows) || d_refl, NMF_EINVAL, "nmf_ray_compose_bwd: d_refl missing");
+    NMF_REQUIRE(!d_ori || normals, NMF_EINVAL, "nmf_ray_compose_bwd: d_ori needs normals");
+    hipLaunchKernelGGL(k_ray_compose_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       refl_rows, inv, normals, rays, ray_id, M, bg, (int)bg_per_ray, (int)tonemap, (int)noclip, rgb_lin,
+                       d_rgb_map, d_acc, d_ori, d_weight, d_refl, d_normals);
+    NMF_CHECK_LAUNCH("nmf_ray_compose_bwd");
+    return NMF_OK;
+}

@@ -184,9 +184,9 @@ class TensorVMSplit(torch.nn.Module):
 
     def _tables(self):
         ps = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (int(self.grid_size[0]), float(self.density_shift))
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (int(hip.host(self.grid_size)[0]), float(self.density_shift))
         if self._cache is None or self._cache[0] != key:
-            G = int(self.grid_size[0])
+            G = int(hip.host(self.grid_size)[0])
             vp = hip.vm_params(self.aabb, self.invaabbSize, self.density_shift, G)
             dpl, dli = self.density_rf.tables()
             apl, ali = self.app_rf.tables()

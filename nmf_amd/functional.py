@@ -202,9 +202,11 @@ class GgxRays(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray, row_off):
+        r_shape = r.shape
         V, N, r, x, off = V.contiguous(), N.contiguous(), r.reshape(-1).contiguous(), x.contiguous(), off.contiguous()
         L, hl, dl, lpdf, mip, rays = hip.ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray)
         ctx.save_for_backward(V, N, r, off, sobol, row_of_ray, j_of_ray, row_off)
+        ctx.r_shape = r_shape
         ctx.mark_non_differentiable(hl, dl, lpdf, mip)
         return L, hl, dl, lpdf, mip, rays
 
@@ -218,7 +220,7 @@ class GgxRays(torch.autograd.Function):
             g = g + d_rays[:, 3:6] + 5e-3 * d_rays[:, 0:3]
         d_nr = hip.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, g.contiguous())
         rows = hip.segment_sum(d_nr, None, row_off, V.shape[0])
-        return None, rows[:, 0:3], rows[:, 3:4], None, None, None, None, None, None, None
+        return None, rows[:, 0:3], rows[:, 3].reshape(ctx.r_shape), None, None, None, None, None, None, None
 
 
 class ShadeMix(torch.autograd.Function):
@@ -238,3 +240,67 @@ class ShadeMix(torch.autograd.Function):
         d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows.contiguous())
         rows = hip.segment_sum_wide(d_fd, 6, row_off, V.shape[0])
         return None, rows[:, 0:3], rows[:, 3:6], None, None, None, dL, d_inc, d_brdf
+
+
+class BouncePrep(torch.autograd.Function):
+    """Per bounce row, one pass (models/microfacet.py:297,304-316,352-361): V, facing N, clipped roughness, f0,
+    diffuse = albedo * SH irradiance, noised feature, position.  The adjoint is written for all M samples through
+    the inverse map (zeros elsewhere), so no index_add / zero fill is needed."""
+
+    @staticmethod
+    def forward(ctx, normals, app, heads, bidx, inv, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, detach_n):
+        normals, app, heads = normals.contiguous(), app.contiguous(), heads.contiguous()
+        outs = hip.bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough)
+        ctx.save_for_backward(normals, heads, inv, ray_id, rays, conv)
+        ctx.cfg = (min_rough, detach_n)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(outs[0], outs[6])
+        return outs
+
+    @staticmethod
+    def backward(ctx, _dV, dN, dr1, df0, ddiff, dfeat, _dxyz):
+        normals, heads, inv, ray_id, rays, conv = ctx.saved_tensors
+        min_rough, detach_n = ctx.cfg
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_normals, d_heads, d_app = hip.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n,
+                                                        c(dN), c(dr1), c(df0), c(ddiff), c(dfeat))
+        return (None if detach_n else d_normals, d_app, d_heads) + (None,) * 10
+
+
+class RayCompose(torch.autograd.Function):
+    """weights x row radiance -> pixels in one pass per ray: acc / rgb sums (modules/tensor_nerf.py:448-452), the
+    orientation-loss term (:583-587), tonemap (modules/tonemap.py:34-55) and background blend (:658-659).
+    Returns (rgb_map [B,3], acc [B], ori [B] or None)."""
+
+    @staticmethod
+    def forward(ctx, weight, refl_rows, normals, bg, inv, offsets, ray_id, rays, B, bg_per_ray, tonemap, noclip,
+                want_ori):
+        weight = weight.contiguous()
+        refl = refl_rows.contiguous() if refl_rows is not None else None
+        normals = normals.contiguous() if normals is not None else None
+        bg = bg.contiguous()
+        rgb_map, acc, rgb_lin, ori = hip.ray_compose_fwd(weight, refl, inv if refl is not None else None,
+                                                         normals if want_ori else None, rays, offsets, B, bg,
+                                                         bg_per_ray, tonemap, noclip, want_ori)
+        ctx.save_for_backward(weight, refl, normals, bg, inv, ray_id, rays, rgb_lin, acc)
+        ctx.cfg = (bg_per_ray, tonemap, noclip, want_ori)
+        ctx.set_materialize_grads(False)
+        return rgb_map, acc, ori
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, d_ori):
+        weight, refl, normals, bg, inv, ray_id, rays, rgb_lin, acc = ctx.saved_tensors
+        bg_per_ray, tonemap, noclip, want_ori = ctx.cfg
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_rgb, d_acc, d_ori = c(d_rgb), c(d_acc), c(d_ori) if want_ori else None
+        want_dn = d_ori is not None and ctx.needs_input_grad[2]
+        d_weight, d_refl, d_normals = hip.ray_compose_bwd(weight, refl, inv if refl is not None else None,
+                                                          normals if d_ori is not None else None, rays, ray_id, bg,
+                                                          bg_per_ray, tonemap, noclip, rgb_lin, d_rgb, d_acc, d_ori,
+                                                          want_dn)
+        d_bg = None
+        if ctx.needs_input_grad[3] and d_rgb is not None:
+            d_bg = (1 - acc)[:, None] * d_rgb
+            if not bg_per_ray:
+                d_bg = d_bg.sum(0).reshape(bg.shape)
+        return (d_weight, d_refl if ctx.needs_input_grad[1] else None, d_normals, d_bg) + (None,) * 9

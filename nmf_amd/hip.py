@@ -60,7 +60,8 @@ EXPORTS = [
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
-    "nmf_adam_step",
+    "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
+    "nmf_ray_compose_fwd", "nmf_ray_compose_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -69,6 +70,7 @@ _lib.nmf_last_error_string.restype = C.c_char_p
 _lib.nmf_version.restype = C.c_int
 _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
 _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
+_lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
 
 
 def version():
@@ -112,10 +114,30 @@ def channels_last_ptr_ok(t):
     return t.stride(1) == 1 and t.stride(3) == Cn and t.stride(2) == W * Cn
 
 
+_host_mirror = {}
+
+
+def host(t):
+    """numpy copy of a small tensor, cached per (storage, version): geometry constants (aabb, grid size, step size)
+    live in module buffers on the device; reading them back costs a stream sync each, so it is done once per value."""
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.detach().numpy()
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    v = _host_mirror.get(id(t))
+    if v is None or v[0] != key:
+        if len(_host_mirror) > 256:
+            _host_mirror.clear()
+        v = (key, t.detach().cpu().numpy(), t)          # keeps t alive so id(t) stays unique
+        _host_mirror[id(t)] = v
+    return v[1]
+
+
 # ---- sampler ----------------------------------------------------------------------------------
 def march_params(aabb, alpha_inv, stepsize, near, far, focal, n_steps, grid, is_train, seed=0, offset=0):
     p = MarchParams()
-    a = aabb.detach().float().cpu().numpy()
+    a = host(aabb).astype(np.float32)
     p.aabb_min[:] = a[0].tolist()
     p.aabb_max[:] = a[1].tolist()
     p.alpha_inv[:] = np.asarray(alpha_inv, dtype=np.float32).tolist() if alpha_inv is not None else [0, 0, 0]
@@ -200,8 +222,8 @@ def derivative_stencil_rows():
 
 def vm_params(aabb, inv_size, density_shift, grid):
     p = VmParams()
-    p.aabb_min[:] = aabb[0].detach().float().cpu().numpy().tolist()
-    p.inv_size[:] = inv_size.detach().float().cpu().numpy().tolist()
+    p.aabb_min[:] = host(aabb).astype(np.float32)[0].tolist()
+    p.inv_size[:] = host(inv_size).astype(np.float32).tolist()
     p.density_shift = float(density_shift)
     p.grid = int(grid)
     c, o = derivative_stencil_rows()
@@ -475,3 +497,82 @@ def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
 def adam_step(slots, n):
     """slots: (AdamSlot * k) host array, the first n entries are applied in one launch (nmf_adam_step)."""
     _check(_lib.nmf_adam_step(slots, C.c_int32(n), _stream()), "nmf_adam_step")
+
+
+# ---- shading glue --------------------------------------------------------------------------------
+def bounce_index(counts):
+    """counts [M] int32 -> (bidx [M] int32, row_off [M+1] int64, cnt_rows [M] int32, inv [M] int32,
+    totals [2] int64 = (R, Mb)); the caller slices bidx[:Mb] / row_off[:Mb+1] / cnt_rows[:Mb] once it has read totals."""
+    M = counts.shape[0]
+    dev = counts.device
+    bidx = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    row_off = torch.empty(M + 1, dtype=torch.int64, device=dev)
+    inv = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    cnt_rows = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    nbytes = _lib.nmf_bounce_index_workspace_bytes(C.c_int64(M))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    _check(_lib.nmf_bounce_index(_p(counts, torch.int32) if M else C.c_void_p(0), C.c_int64(M), _p(bidx), _p(row_off),
+                                 _p(cnt_rows), _p(inv), _p(totals), _p(ws), C.c_int64(nbytes), _stream()), "nmf_bounce_index")
+    return bidx, row_off, cnt_rows, inv[:M], totals
+
+
+def bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough):
+    Mb = bidx.shape[0]
+    dev = normals.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    V, N, r1, f0, diff, feat, xyz = f(Mb, 3), f(Mb, 3), f(Mb), f(Mb, 3), f(Mb, 3), f(Mb, 24), f(Mb, 3)
+    if Mb:
+        _check(_lib.nmf_bounce_prep_fwd(_p(bidx, torch.int32), C.c_int64(Mb), _p(normals, torch.float32),
+                                        _p(app, torch.float32), _p(heads, torch.float32), _p(xyzt, torch.float32),
+                                        _p(ray_id, torch.int32), _p(rays, torch.float32), _p(conv, torch.float32),
+                                        _p(feat_noise), C.c_float(anoise), C.c_float(min_rough), _p(V), _p(N), _p(r1),
+                                        _p(f0), _p(diff), _p(feat), _p(xyz), _stream()), "nmf_bounce_prep_fwd")
+    return V, N, r1, f0, diff, feat, xyz
+
+
+def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat):
+    M = inv.shape[0]
+    dev = normals.device
+    d_normals = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    d_heads = torch.empty((M, 11), dtype=torch.float32, device=dev)
+    d_app = torch.empty((M, 24), dtype=torch.float32, device=dev)
+    if M:
+        _check(_lib.nmf_bounce_prep_bwd(_p(inv, torch.int32), C.c_int64(M), _p(normals, torch.float32),
+                                        _p(heads, torch.float32), _p(ray_id, torch.int32), _p(rays, torch.float32),
+                                        _p(conv, torch.float32), C.c_float(min_rough), C.c_int32(1 if detach_n else 0),
+                                        _p(dN), _p(dr1), _p(df0), _p(ddiff), _p(dfeat), _p(d_normals), _p(d_heads),
+                                        _p(d_app), _stream()), "nmf_bounce_prep_bwd")
+    return d_normals, d_heads, d_app
+
+
+def ray_compose_fwd(weight, refl_rows, inv, normals, rays, offsets, B, bg, bg_per_ray, tonemap, noclip, want_ori):
+    dev = weight.device
+    rgb_map = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty(B, dtype=torch.float32, device=dev)
+    rgb_lin = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    ori = torch.empty(B, dtype=torch.float32, device=dev) if want_ori else None
+    if B:
+        _check(_lib.nmf_ray_compose_fwd(_p(weight, torch.float32), _p(refl_rows), _p(inv), _p(normals),
+                                        _p(rays, torch.float32), _p(offsets, torch.int64), C.c_int64(B),
+                                        _p(bg, torch.float32), C.c_int32(1 if bg_per_ray else 0),
+                                        C.c_int32(1 if tonemap else 0), C.c_int32(1 if noclip else 0), _p(rgb_map),
+                                        _p(acc), _p(rgb_lin), _p(ori), _stream()), "nmf_ray_compose_fwd")
+    return rgb_map, acc, rgb_lin, ori
+
+
+def ray_compose_bwd(weight, refl_rows, inv, normals, rays, ray_id, bg, bg_per_ray, tonemap, noclip, rgb_lin, d_rgb_map,
+                    d_acc, d_ori, want_d_normals):
+    M = weight.shape[0]
+    dev = weight.device
+    d_weight = torch.empty(M, dtype=torch.float32, device=dev)
+    d_refl = torch.empty_like(refl_rows) if refl_rows is not None else None
+    d_normals = torch.empty((M, 3), dtype=torch.float32, device=dev) if want_d_normals else None
+    if M:
+        _check(_lib.nmf_ray_compose_bwd(_p(weight, torch.float32), _p(refl_rows), _p(inv), _p(normals),
+                                        _p(rays, torch.float32), _p(ray_id, torch.int32), C.c_int64(M),
+                                        _p(bg, torch.float32), C.c_int32(1 if bg_per_ray else 0),
+                                        C.c_int32(1 if tonemap else 0), C.c_int32(1 if noclip else 0), _p(rgb_lin),
+                                        _p(d_rgb_map), _p(d_acc), _p(d_ori), _p(d_weight), _p(d_refl), _p(d_normals),
+                                        _stream()), "nmf_ray_compose_bwd")
+    return d_weight, d_refl, d_normals

@@ -8,7 +8,7 @@ import math
 import torch
 
 from .. import hip
-from ..functional import GgxRays, ShadeMix, segment_sum
+from ..functional import BouncePrep, GgxRays, ShadeMix
 from ..modules import sh
 from ..brdf_samplers.ggx import mat3T_vec, normalize
 
@@ -88,20 +88,29 @@ class Microfacet(torch.nn.Module):
     # ---- shading ----------------------------------------------------------------------------------------
     def forward(self, samples, app_features, viewdirs, normals, weights, render_reflection, bg_module, is_train,
                 recur, noise):
-        """samples: samplers.alphagrid.Samples; app_features [M,24]; viewdirs, normals [M,3]; weights [M].
-        Returns rgb [M,3] and the debug dict of the reference (models/microfacet.py:271-673)."""
+        """Reference interface (models/microfacet.py:271-673): rgb [M,3] and the debug dict.  The hot path
+        (TensorNeRF.forward) uses shade_compact() directly and never materialises the [M,3] radiance."""
+        sh_ = self.shade_compact(samples, app_features, normals, weights, render_reflection, bg_module, is_train,
+                                 recur, noise)
+        return sh_.rgb(), sh_.debug()
+
+    def shade_compact(self, samples, app_features, normals, weights, render_reflection, bg_module, is_train, recur,
+                      noise):
+        """samples: samplers.alphagrid.Samples; app_features [M,24]; normals [M,3]; weights [M].
+        Returns a Shaded record: radiance per BOUNCE ROW (samples that spawned secondary rays; every other sample
+        has zero radiance, models/microfacet.py:596-613) + the inverse map, with the debug maps computed on demand."""
         M = samples.M
         dev = app_features.device
-        noise_feat = app_features + noise.normal((M, app_features.shape[1])) * self.anoise        # :297
+        feat_noise = noise.normal((M, app_features.shape[1]))                                       # :297
+        if feat_noise is not None:
+            feat_noise = feat_noise.contiguous()
         noise.skip("randn", (M, 3))
         noise.skip("randn", (M, 2))
-        albedo, tint, matprop = self.diffuse_module(None, viewdirs, app_features, std=0)             # :299
-        with torch.no_grad():                                                                       # :304-315
-            noise.skip("rand", (5000,))
-            noise.skip("rand", (5000,))
-            _, conv = bg_module.get_spherical_harmonics(100)
-            E = (conv.reshape(1, -1, 3) * sh.eval_sh_bases(9, normals.detach()).reshape(M, -1, 1)).sum(dim=1)
-        diffuse = albedo * E
+        heads = self.diffuse_module.heads(app_features)                                              # :299
+        noise.skip("rand", (5000,))                                                                 # :304-315
+        noise.skip("rand", (5000,))
+        _, conv = bg_module.get_spherical_harmonics(100)
+        conv = conv.reshape(9, 3)
 
         # ---- how many secondary rays per sample (:327-333, pt_selectors.py)
         w_det = weights.detach().contiguous()
@@ -122,81 +131,104 @@ class Microfacet(torch.nn.Module):
             counts = self.forced[f"counts{recur}"].to(dev).int().contiguous()
         if self.trace is not None:
             self.trace[f"counts{recur}"] = counts
-        ray_off, _, tot = hip.march_scan(counts, -1)
-        R = int(tot[0])
-        zeros3 = torch.zeros_like(diffuse)
-        reflect_rgb, brdf_rgb, spec = zeros3, zeros3, zeros3
-        if R > 0:
-            bidx = torch.nonzero(counts > 0).reshape(-1)                      # bounce points (rows)
-            Mb = bidx.shape[0]
-            cnt_b = counts[bidx].long()
-            row_off = torch.zeros(Mb + 1, dtype=torch.int64, device=dev)
-            row_off[1:] = torch.cumsum(cnt_b, 0)
-            row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)        # = torch.where(ray_mask)
-            rows = row_of_ray.long()
-            isel = lambda t: torch.index_select(t, 0, bidx)     # backward = index_add (no sort), unlike t[bidx]
-            bN = isel(normals)
-            if self.detach_N:
-                bN = bN.detach()
-            bV = -isel(viewdirs)
-            bN = bN * (bV * bN).sum(dim=-1, keepdim=True).sign()                                    # :356
-            r1 = isel(matprop["r1"])
-            if is_train:
-                r1 = r1.clip(min=self.min_rough)
-            off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                          # base.py:18
-            cnt32 = cnt_b.int()
-            L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
-                bV, bN, r1, isel(samples.xyzt)[:, :3], off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray,
-                row_off)
-            ecount = cnt_b.float()[rows]
-            brdf_weight = self.brdf.forward_compact(halfvec, diffvec, isel(noise_feat), r1, row_of_ray, row_off)
-            if self.trace is not None:
-                self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
-                                   f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,
-                                   f"lpdf{recur}": lpdf})
-            if len(self.max_retrace_rays) > recur:                                                  # :475-559
-                num_retrace = min(R, self.max_retrace_rays[recur])
-                pinned = self.forced is not None and f"retrace_order{recur}" in self.forced
-                if num_retrace >= R and not pinned and self.trace is None:
-                    # steady state: every secondary ray is re-traced.  The reference still argsorts the
-                    # scores, which only permutes the rays before they meet their i.i.d. jitter rows; the draw is
-                    # consumed for stream parity and the identity order is used (same distribution, no 250 k-key sort).
-                    noise.skip("rand", (R,))
-                    incoming = render_reflection(bounce_rays, mipval, True)
-                else:
-                    with torch.no_grad():
-                        eV, eN = bV[rows], bN[rows]
-                        per_sample = w_det[bidx] / (cnt_b.float() + 1e-8)
-                        per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
-                        cc = per_ray * per_sample[rows]
-                        cc = cc / cc.sum() * num_retrace
-                        cc = cc + noise.uniform((R,))
-                        order = cc.argsort()
-                        if pinned:
-                            order = self.forced[f"retrace_order{recur}"].to(dev)
-                        if self.trace is not None:
-                            self.trace[f"retrace_score{recur}"] = cc
-                        cut = max(R - num_retrace, 0)
-                        idx_re, idx_no = order[cut:], order[:cut]
-                    incoming = torch.zeros((R, 3), device=dev)
-                    if idx_re.shape[0] > 0:
-                        inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
-                        incoming = incoming.index_put((idx_re,), inc)
-                    if idx_no.shape[0] > 0:
-                        inc = render_reflection(bounce_rays[idx_no], mipval[idx_no], False)
-                        incoming = incoming.index_put((idx_no,), inc)
+        bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)                                    # :333-350
+        R, Mb = (int(v) for v in tot.cpu())
+        out = Shaded(self, samples, heads, normals, conv, w_det, inv, M)
+        if R == 0:
+            return out
+        bidx, row_off, cnt32 = bidx[:Mb], row_off[:Mb + 1], cnt32[:Mb]
+        row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)            # = torch.where(ray_mask)
+        off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                              # base.py:18
+        bV, bN, r1, f0, diffuse, feat, xyz = BouncePrep.apply(
+            normals, app_features, heads, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,
+            float(self.anoise), float(self.min_rough) if is_train else -1e30, bool(self.detach_N))   # :352-361
+        L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                             # :367-456
+            bV, bN, r1, xyz, off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray, row_off)
+        brdf_weight = self.brdf.forward_compact(halfvec, diffvec, feat, r1, row_of_ray, row_off)
+        if self.trace is not None:
+            self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
+                               f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,
+                               f"lpdf{recur}": lpdf})
+        if len(self.max_retrace_rays) > recur:                                                      # :475-559
+            num_retrace = min(R, self.max_retrace_rays[recur])
+            pinned = self.forced is not None and f"retrace_order{recur}" in self.forced
+            if num_retrace >= R and not pinned and self.trace is None:
+                # steady state: every secondary ray is re-traced.  The reference still argsorts the
+                # scores, which only permutes the rays before they meet their i.i.d. jitter rows; the draw is
+                # consumed for stream parity and the identity order is used (same distribution, no 250 k-key sort).
+                noise.skip("rand", (R,))
+                incoming = render_reflection(bounce_rays, mipval, True)
             else:
-                incoming = render_reflection(bounce_rays, mipval, False)
-            if self.trace is not None:
-                self.trace[f"incoming{recur}"] = incoming
-            ec = ecount.clip(min=1)[:, None]
-            refl_rows = ShadeMix.apply(bV, isel(matprop["f0"]), isel(diffuse), cnt32, row_of_ray, row_off, L, incoming,
-                                       brdf_weight)                                                 # :596-613
-            reflect_rgb = zeros3.index_put((bidx,), refl_rows)
+                with torch.no_grad():
+                    rows = row_of_ray.long()
+                    eV, eN = bV[rows], bN[rows]
+                    per_sample = w_det[bidx.long()] / (cnt32.float() + 1e-8)
+                    per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
+                    cc = per_ray * per_sample[rows]
+                    cc = cc / cc.sum() * num_retrace
+                    cc = cc + noise.uniform((R,))
+                    order = cc.argsort()
+                    if pinned:
+                        order = self.forced[f"retrace_order{recur}"].to(dev)
+                    if self.trace is not None:
+                        self.trace[f"retrace_score{recur}"] = cc
+                    cut = max(R - num_retrace, 0)
+                    idx_re, idx_no = order[cut:], order[:cut]
+                incoming = torch.zeros((R, 3), device=dev)
+                if idx_re.shape[0] > 0:
+                    inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
+                    incoming = incoming.index_put((idx_re,), inc)
+                if idx_no.shape[0] > 0:
+                    inc = render_reflection(bounce_rays[idx_no], mipval[idx_no], False)
+                    incoming = incoming.index_put((idx_no,), inc)
+        else:
+            incoming = render_reflection(bounce_rays, mipval, False)
+        if self.trace is not None:
+            self.trace[f"incoming{recur}"] = incoming
+        out.refl_rows = ShadeMix.apply(bV, f0, diffuse, cnt32, row_of_ray, row_off, L, incoming, brdf_weight)  # :596-613
+        out.rows = (bidx, row_off, cnt32, row_of_ray, incoming.detach(), brdf_weight.detach())
+        return out
+
+
+class Shaded:
+    """Result of Microfacet.shade_compact: refl_rows [Mb,3] (radiance of the samples that spawned secondary rays,
+    None when there are none), inv [M] (row of each sample or -1) and, on demand, the reference's per-sample
+    outputs: rgb() [M,3] and debug() = {diffuse, tint, roughness, spec, albedo} (models/microfacet.py:642-673).
+    Training only reads refl_rows; the on-demand tensors are plain torch expressions of the graph tensors, so a
+    caller that puts them into a loss still gets their gradients."""
+
+    def __init__(self, model, samples, heads, normals, conv, w_det, inv, M):
+        self.model, self.samples, self.heads, self.normals, self.conv = model, samples, heads, normals, conv
+        self.w_det, self.inv, self.M = w_det, inv, M
+        self.refl_rows = None
+        self.rows = None
+        self._debug = None
+
+    def rgb(self):
+        z = torch.zeros((self.M, 3), device=self.heads.device)
+        if self.refl_rows is None:
+            return z
+        return z.index_put((self.rows[0].long(),), self.refl_rows)
+
+    def debug(self):
+        if self._debug is None:
+            S, h, n = self.samples, self.heads, self.normals
+            albedo, f0, r1 = h[:, 0:3], h[:, 6:9], h[:, 9:10]
+            viewdirs = torch.index_select(S.rays[:, 3:6], 0, S.ray_id.long())
             with torch.no_grad():
-                spec = zeros3.index_put((bidx,), hip.segment_sum((incoming / ec).contiguous(), None, row_off, Mb))
-                brdf_rgb = zeros3.index_put((bidx,), hip.segment_sum((brdf_weight / ec).contiguous(), None, row_off, Mb))
-        cos_t = (-viewdirs * normals).sum(dim=-1, keepdim=True).abs()                               # :642
-        Fr = matprop["f0"] + (1 - matprop["f0"]) * (1 - cos_t).clip(min=0, max=1) ** 5
-        debug = dict(diffuse=(1 - Fr) * diffuse, tint=Fr * brdf_rgb, roughness=matprop["r1"], spec=spec, albedo=albedo)
-        return reflect_rgb, debug
+                E = (self.conv.reshape(1, -1, 3) * sh.eval_sh_bases(9, n.detach()).reshape(self.M, -1, 1)).sum(dim=1)
+            diffuse = albedo * E                                                                    # :316
+            z = torch.zeros_like(diffuse)
+            spec, brdf_rgb = z, z
+            if self.rows is not None:
+                bidx, row_off, cnt32, row_of_ray, incoming, brdf_weight = self.rows
+                with torch.no_grad():
+                    ec = cnt32.float().clip(min=1)[row_of_ray.long()][:, None]
+                    Mb = bidx.shape[0]
+                    spec = z.index_put((bidx.long(),), hip.segment_sum((incoming / ec).contiguous(), None, row_off, Mb))
+                    brdf_rgb = z.index_put((bidx.long(),),
+                                           hip.segment_sum((brdf_weight / ec).contiguous(), None, row_off, Mb))
+            cos_t = (-viewdirs * n).sum(dim=-1, keepdim=True).abs()                                 # :642
+            Fr = f0 + (1 - f0) * (1 - cos_t).clip(min=0, max=1) ** 5
+            self._debug = dict(diffuse=(1 - Fr) * diffuse, tint=Fr * brdf_rgb, roughness=r1, spec=spec, albedo=albedo)
+        return self._debug

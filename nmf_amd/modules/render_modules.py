@@ -1,6 +1,6 @@
 """Material heads -- host-side mirror of the reference's RandHydraMLPDiffuse
 (modules/render_modules.py:447-574) for pospe=-1, feape=0, num_layers=1: four Linear(24 -> 3,3,3,2) heads.
-These are 24x11 products per sample (plain library GEMMs through torch.nn.functional.linear)."""
+Evaluated as one 24 -> 11 product per sample by nmf_heads_fwd/bwd (csrc/heads.hip); there is no CPU path."""
 import torch
 
 from ..functional import MaterialHeads
@@ -29,19 +29,19 @@ class RandHydraMLPDiffuse(torch.nn.Module):
         self.f0_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
         self.roughness_mlp = create_mlp(self.in_mlpC, 2, **(roughness_cfg if roughness_cfg is not None else kwargs))
 
+    def heads(self, features):
+        """[M,11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied (nmf_heads_fwd)."""
+        if features.shape[0] == 0:
+            return features.new_zeros((0, 11))
+        hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
+              float(self.roughness_bias))
+        return MaterialHeads.apply(features, hp, self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias,
+                                   self.tint_mlp[0].weight, self.tint_mlp[0].bias, self.f0_mlp[0].weight,
+                                   self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
+
     def forward(self, pts, viewdirs, features, std=0, **kwargs):
-        if features.is_cuda and features.shape[0] > 0:
-            hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
-                  float(self.roughness_bias))
-            o = MaterialHeads.apply(features, hp, self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias,
-                                    self.tint_mlp[0].weight, self.tint_mlp[0].bias, self.f0_mlp[0].weight,
-                                    self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
-            diffuse, tint, f0, r = o[:, 0:3], o[:, 3:6], o[:, 6:9], o[:, 9:11]
-            return diffuse, tint, dict(diffuse=diffuse, r1=r[:, 0:1], r2=r[:, 1:2], f0=f0, tint=tint)
-        diffuse = torch.sigmoid(self.diffuse_mul * self.diffuse_mlp(features) + self.diffuse_bias).clip(min=0, max=1)
-        r = (torch.sigmoid(self.roughness_mlp(features) + self.roughness_bias) / 2).clip(min=1e-2, max=1)
-        tint = torch.sigmoid(self.tint_mlp(features) + self.tint_bias)
-        f0 = torch.sigmoid(self.f0_mlp(features) + self.f0_bias)
+        o = self.heads(features)
+        diffuse, tint, f0, r = o[:, 0:3], o[:, 3:6], o[:, 6:9], o[:, 9:11]
         return diffuse, tint, dict(diffuse=diffuse, r1=r[:, 0:1], r2=r[:, 1:2], f0=f0, tint=tint)
 
     def calibrate(self, mean_brightness, conserve_energy, *args, **kwargs):

@@ -4,7 +4,8 @@ tonemap, with the same constructor keywords, __call__ signature, returned image 
 state_dict layout.  Every stage runs on the compact sample list produced by the HIP sampler."""
 import torch
 
-from ..functional import Composite, segment_sum
+from .. import hip
+from ..functional import Composite, RayCompose, segment_sum
 from ..noise import DeviceNoise
 from .tonemap import SRGBTonemap
 
@@ -24,6 +25,8 @@ class TensorNeRF(torch.nn.Module):
         self.model = model(self.rf.app_dim)
         self.bg_module = bg_module
         self.tonemap = SRGBTonemap() if tonemap is None else tonemap
+        if not isinstance(self.tonemap, SRGBTonemap):
+            raise NotImplementedError("nmf_ray_compose implements modules.tonemap.SRGBTonemap (microfacet_tensorf2.yaml:26)")
         self.lr_scale = lr_scale
         self.hdr = hdr
         self.bg_noise, self.bg_noise_decay = bg_noise, bg_noise_decay
@@ -78,10 +81,8 @@ class TensorNeRF(torch.nn.Module):
         B, M = S.b, S.M
         n_samples = [M]
         wv = S.whole_valid
-        rid = S.ray_id.long()
-        ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
-        viewdirs = torch.index_select(ray_dirs, 0, rid)
         offsets = S.offsets[: B + 1]
+        ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
 
         sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=True, want_normal=True)       # :286,386,393
         weight = Composite.apply(sigma, S.dist, offsets, B, float(self.rf.distance_scale))          # :366
@@ -90,26 +91,23 @@ class TensorNeRF(torch.nn.Module):
             if retrace:
                 ims, st = self(brays, focal, recur=recur + 1, bg_col=None, dynamic_batch_size=False,
                                stepmul=self.recur_stepmul, start_mipval=mipval.reshape(-1),
-                               override_near=3 * float(self.sampler.stepsize), is_train=is_train, ndc_ray=False,
-                               tonemap=False, draw_debug=False, noise=noise)
+                               override_near=3 * float(hip.host(self.sampler.stepsize)), is_train=is_train,
+                               ndc_ray=False, tonemap=False, draw_debug=False, noise=noise)
                 n_samples.extend(st["n_samples"])
                 return ims["rgb_map"]
             noise.skip("rand", (brays.shape[0],))
             noise.skip("rand", (brays.shape[0],))
             return self.render_just_bg(brays[..., 3:6], mipval.reshape(-1))
 
+        shaded = None
         if M > 0:
-            rgb, debug = self.model(S, app, viewdirs, world_normal, weight, render_reflection, self.bg_module,
-                                    is_train, recur, noise)
-        else:
-            rgb = torch.empty((0, 3), device=dev)
-            debug = {k: torch.empty((0, v), device=dev) for k, v in self.model.outputs.items()}
+            shaded = self.model.shade_compact(S, app, world_normal, weight, render_reflection, self.bg_module,
+                                              is_train, recur, noise)
 
-        acc_map = segment_sum(weight, offsets, S.ray_id, B)                                          # :448
-        rgb_map = segment_sum(weight[:, None] * rgb, offsets, S.ray_id, B)                           # :452
         images = {}
         stats = dict(recur=recur, whole_valid=wv, n_samples=n_samples)
-        if self.bg_module is not None and bg_col is None:                                            # :460-468
+        per_ray_bg = self.bg_module is not None and bg_col is None
+        if per_ray_bg:                                                                               # :460-468
             rough = -100 * torch.ones(B, device=dev) if start_mipval is None else start_mipval[:B]
             noise.skip("rand", (B,))
             noise.skip("rand", (B,))
@@ -117,31 +115,86 @@ class TensorNeRF(torch.nn.Module):
             if tonemap:
                 bg = self.tonemap(bg, noclip=True)
         else:
-            bg = bg_col.to(dev).reshape(1, 3)
+            bg = bg_col.to(device=dev, dtype=torch.float32).reshape(1, 3)
+
+        want_stats = recur == 0 and (is_train or not draw_debug)
+        # one pass per ray: acc (:448), rgb (:452), orientation term (:583-587), tonemap (:658), background (:659)
+        rgb_map, acc_map, ori = RayCompose.apply(
+            weight, shaded.refl_rows if shaded is not None else None, world_normal if M > 0 else None, bg,
+            shaded.inv if shaded is not None else None, offsets, S.ray_id, S.rays, B, per_ray_bg, bool(tonemap),
+            bool(self.hdr), bool(want_stats and M > 0))
 
         if not is_train and draw_debug:                                                              # :480-566
             with torch.no_grad():
+                acc_d = acc_map.detach()
                 images["depth"] = segment_sum(weight * S.z, offsets, S.ray_id, B)
                 wn = segment_sum(world_normal * weight[:, None], offsets, S.ray_id, B)
-                images["world_normal"] = acc_map[..., None] * wn + (1 - acc_map[..., None])
+                images["world_normal"] = acc_d[..., None] * wn + (1 - acc_d[..., None])
                 images["surf_width"] = (offsets[1:] - offsets[:-1])
+                debug = shaded.debug() if shaded is not None else \
+                    {k: torch.empty((0, v), device=dev) for k, v in self.model.outputs.items()}
                 for k, v in debug.items():
-                    images[k] = segment_sum(v * weight[:, None], offsets, S.ray_id, B) + (1 - acc_map[..., None]) * bg
+                    images[k] = segment_sum(v * weight[:, None], offsets, S.ray_id, B) + (1 - acc_d[..., None]) * bg
         elif recur == 0:                                                                             # :567-649
-            ndv = (-viewdirs.detach() * world_normal).sum(dim=-1)
-            stats["ori_loss"] = (weight * (ndv.clamp(max=0) ** 2)).sum()
+            zero = torch.zeros((), device=dev)
+            stats["ori_loss"] = ori.sum() if ori is not None else zero
             # normal_module is None: pred_norms == 0 -> align_world_loss == 2
-            stats["prediction_loss"] = (weight * 2.0).sum()
-            stats["distortion_loss"] = torch.tensor(0.0, device=dev)
-            stats["envmap_reg"] = (self.bg_module.mean_color().mean() - 0.05).clip(min=0)
-            stats["brdf_reg"] = debug["tint"].mean().clip(min=0) if M > 0 else torch.tensor(0.0, device=dev)
-            stats["diffuse_reg"] = ((weight.detach().reshape(-1, 1) * debug["diffuse"]).sum() / 3
-                                    if M > 0 else torch.tensor(0.0, device=dev))
-            for k, v in debug.items():
-                images[k] = v
-        if tonemap:
-            rgb_map = self.tonemap(rgb_map, noclip=self.hdr)                                         # :658
-        rgb_map = rgb_map + (1 - acc_map[..., None]) * bg                                            # :659
+            stats["prediction_loss"] = 2.0 * acc_map.sum()
+            stats["distortion_loss"] = zero
+            stats = LazyStats(stats, self, shaded, weight, M)
+            images = LazyImages(shaded)
         images["rgb_map"] = rgb_map
         images["acc_map"] = acc_map.detach()
         return images, stats
+
+
+class LazyStats(dict):
+    """Statistics dict of TensorNeRF.forward whose regulariser entries (envmap_reg, brdf_reg, diffuse_reg,
+    modules/tensor_nerf.py:600-649) are evaluated when first read: the default params give them zero weight
+    (train.py:650-654), so the training step never pays for them, while a caller that does read them gets the same
+    differentiable tensors as before."""
+
+    _LAZY = ("envmap_reg", "brdf_reg", "diffuse_reg")
+
+    def __init__(self, base, nerf, shaded, weight, M):
+        super().__init__(base)
+        self._src = (nerf, shaded, weight, M)
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        nerf, shaded, weight, M = self._src
+        dev = weight.device
+        if key == "envmap_reg":
+            v = (nerf.bg_module.mean_color().mean() - 0.05).clip(min=0)
+        elif key == "brdf_reg":
+            v = shaded.debug()["tint"].mean().clip(min=0) if M > 0 else torch.tensor(0.0, device=dev)
+        else:
+            v = ((weight.detach().reshape(-1, 1) * shaded.debug()["diffuse"]).sum() / 3
+                 if M > 0 else torch.tensor(0.0, device=dev))
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._LAZY
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._LAZY if not dict.__contains__(self, k)]
+
+
+class LazyImages(dict):
+    """images dict of a training forward: rgb_map / acc_map plus the per-sample debug maps of the shading model
+    (modules/tensor_nerf.py:646-648), the latter built on first access."""
+
+    def __init__(self, shaded):
+        super().__init__()
+        self._shaded = shaded
+
+    def __missing__(self, key):
+        if self._shaded is None:
+            raise KeyError(key)
+        d = self._shaded.debug()
+        if key not in d:
+            raise KeyError(key)
+        self[key] = d[key]
+        return d[key]

@@ -134,9 +134,10 @@ class AlphaGridSampler(torch.nn.Module):
                 seed, off = 0x9E3779B9, self._calls
             else:
                 jitter, (seed, off) = noise.jitter(B, N)
-        p = hip.march_params(self.aabb, self.alphaMask.invgrid_size.cpu().numpy() if use_mask else None,
-                             float(self.stepsize), near, far, focal, N,
-                             [int(g) for g in self.alphaMask.grid_size] if use_mask else None, is_train, seed, off)
+        p = hip.march_params(self.aabb, hip.host(self.alphaMask.invgrid_size) if use_mask else None,
+                             float(hip.host(self.stepsize)), near, far, focal, N,
+                             [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train,
+                             seed, off)
         rays = rays_chunk.contiguous()
         valid, counts = hip.march_count(p, rays, jitter, self.alphaMask.bits() if use_mask else None)
         budget = self.max_samples if (self.max_samples > 0 and is_train and dynamic_batch_size) else -1

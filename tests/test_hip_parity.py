@@ -595,3 +595,127 @@ def test_fused_adam_matches_torch_adam():
         assert_close(ob.state[b]["exp_avg_sq"].cpu(), oa.state[a]["exp_avg_sq"].cpu(), rtol=2e-6, atol=1e-12, what=f"v {i}")
     ob2 = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-8)
     ob2.load_state_dict(ob.state_dict())             # state_dict is interchangeable with torch.optim.Adam
+
+
+@pytest.mark.parametrize("M,p", [(1, 1.0), (5, 0.0), (1023, 0.3), (1025, 0.5), (300001, 0.07)])
+def test_bounce_index_bit_exact(M, p):
+    """nmf_bounce_index against the torch bookkeeping of models/microfacet.py:333-350 (nonzero / cumsum)."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(M)
+    counts = (torch.randint(1, 200, (M,), generator=gen) * (torch.rand(M, generator=gen) < p)).int()
+    bidx, row_off, cnt, inv, tot = hip.bounce_index(counts.to(DEV))
+    R, Mb = [int(v) for v in tot.cpu()]
+    ref_idx = torch.nonzero(counts > 0).reshape(-1)
+    assert Mb == ref_idx.shape[0] and R == int(counts.sum())
+    assert torch.equal(bidx[:Mb].cpu().long(), ref_idx)
+    assert torch.equal(cnt[:Mb].cpu(), counts[ref_idx])
+    ro = torch.zeros(Mb + 1, dtype=torch.int64)
+    ro[1:] = torch.cumsum(counts[ref_idx].long(), 0)
+    assert torch.equal(row_off[:Mb + 1].cpu(), ro)
+    inv_ref = torch.full((M,), -1, dtype=torch.int32)
+    inv_ref[ref_idx] = torch.arange(Mb, dtype=torch.int32)
+    assert torch.equal(inv.cpu(), inv_ref)
+    if R:
+        row_of_ray, j_of_ray = hip.expand_segments(row_off[:Mb + 1], Mb, R)
+        rows_ref = torch.repeat_interleave(torch.arange(Mb), counts[ref_idx].long())
+        assert torch.equal(row_of_ray.cpu().long(), rows_ref)
+
+
+def test_bounce_index_empty():
+    hip = _hip()
+    bidx, row_off, cnt, inv, tot = hip.bounce_index(torch.zeros(0, dtype=torch.int32, device=DEV))
+    assert tot.cpu().tolist() == [0, 0] and int(row_off[0]) == 0 and inv.shape[0] == 0
+
+
+@pytest.mark.parametrize("M,detach_n", [(1, False), (4099, False), (4099, True)])
+def test_bounce_prep_vs_torch(M, detach_n):
+    """nmf_bounce_prep_fwd/bwd against the torch expressions of models/microfacet.py:297,304-316,352-361."""
+    from nmf_amd.functional import BouncePrep
+    hip = _hip()
+    gen = torch.Generator().manual_seed(3 + M)
+    B = max(M // 7, 1)
+    normals = torch.randn(M, 3, generator=gen)
+    normals[0] = 0.0                                   # sign(0) = 0 -> zero normal, like torch.sign
+    app = torch.randn(M, 24, generator=gen)
+    heads = torch.rand(M, 11, generator=gen)
+    xyzt = torch.randn(M, 4, generator=gen)
+    ray_id = torch.randint(0, B, (M,), generator=gen).int()
+    rays = torch.randn(B, 6, generator=gen)
+    conv = torch.randn(9, 3, generator=gen)
+    nz = torch.randn(M, 24, generator=gen)
+    counts = (torch.rand(M, generator=gen) < 0.4).int() * 3
+    counts[0] = 2
+    anoise, min_rough = 0.25, 0.3
+    d = lambda t: t.to(DEV)  # noqa: E731
+    bidx, row_off, cnt, inv, tot = hip.bounce_index(d(counts))
+    Mb = int(tot[1])
+    td = [d(t).requires_grad_(True) for t in (normals, app, heads)]
+    outs = BouncePrep.apply(td[0], td[1], td[2], bidx[:Mb], inv, d(xyzt), d(ray_id), d(rays), d(conv), d(nz), anoise,
+                            min_rough, detach_n)
+    tr = [t.clone().requires_grad_(True) for t in (normals, app, heads)]
+    idx = torch.nonzero(counts > 0).reshape(-1)
+    n, a, h = (t[idx] for t in tr)
+    V = -rays[ray_id.long()][idx][:, 3:6]
+    nn = n.detach() if detach_n else n
+    N = nn * (V * nn).sum(-1, keepdim=True).sign()
+    r1 = h[:, 9].clip(min=min_rough)
+    E = (conv.reshape(1, 9, 3) * O.eval_sh9(n.detach()).reshape(-1, 9, 1)).sum(1)
+    ref = (V, N, r1, h[:, 6:9], h[:, 0:3] * E, a + nz[idx] * anoise, xyzt[idx][:, :3])
+    names = ["V", "N", "r1", "f0", "diffuse", "feat", "xyz"]
+    for o, r, nme in zip(outs, ref, names):
+        assert_close(o.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6, what="bounce prep " + nme)
+    cs = [torch.randn(r.shape, generator=gen) for r in ref]
+    loss_r = sum((r * c).sum() for r, c, nme in zip(ref, cs, names) if nme not in ("V", "xyz"))
+    loss_h = sum((o * d(c)).sum() for o, c, nme in zip(outs, cs, names) if nme not in ("V", "xyz"))
+    g_r = torch.autograd.grad(loss_r, tr, allow_unused=True)
+    g_h = torch.autograd.grad(loss_h, td, allow_unused=True)
+    for a_, b_, nme in zip(g_h, g_r, ["normals", "app", "heads"]):
+        if b_ is None:
+            assert a_ is None or float(a_.abs().max()) == 0.0
+            continue
+        assert_close(a_.cpu(), b_, rtol=1e-5, atol=1e-6, what="bounce prep d" + nme)
+
+
+@pytest.mark.parametrize("B,per_ray_bg,tonemap", [(1, False, True), (700, False, True), (700, True, False), (5, True, True)])
+def test_ray_compose_vs_torch(B, per_ray_bg, tonemap):
+    """nmf_ray_compose_fwd/bwd against modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py in torch."""
+    from nmf_amd.functional import RayCompose
+    hip = _hip()
+    gen = torch.Generator().manual_seed(B)
+    lens = torch.randint(0, 40, (B,), generator=gen)
+    lens[0] = 3
+    offsets = torch.zeros(B + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(lens, 0)
+    M = int(offsets[-1])
+    ray_id = torch.repeat_interleave(torch.arange(B), lens).int()
+    weight = torch.rand(M, generator=gen) * 0.2
+    counts = (torch.rand(M, generator=gen) < 0.5).int()
+    counts[0] = 1
+    idx = torch.nonzero(counts > 0).reshape(-1)
+    refl = torch.rand(idx.shape[0], 3, generator=gen) * 2
+    refl[0] = 1e-4                                     # below the sRGB knee
+    normals = torch.randn(M, 3, generator=gen)
+    rays = torch.randn(B, 6, generator=gen)
+    bg = torch.rand(B, 3, generator=gen) if per_ray_bg else torch.ones(1, 3)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    _, _, _, inv, _ = hip.bounce_index(d(counts))
+    td = [d(t).requires_grad_(True) for t in (weight, refl, normals, bg)]
+    rgb_map, acc, ori = RayCompose.apply(td[0], td[1], td[2], td[3], inv, d(offsets), d(ray_id), d(rays), B, per_ray_bg,
+                                         tonemap, False, True)
+    tr = [t.clone().requires_grad_(True) for t in (weight, refl, normals, bg)]
+    w, rf, n, b = tr
+    rgb = torch.zeros(M, 3).index_put((idx,), rf)
+    rid = ray_id.long()
+    acc_r = torch.zeros(B).index_add(0, rid, w)
+    lin = torch.zeros(B, 3).index_add(0, rid, w[:, None] * rgb)
+    ndv = (-rays[rid][:, 3:6] * n).sum(-1)
+    ori_r = torch.zeros(B).index_add(0, rid, w * ndv.clamp(max=0) ** 2)
+    out_r = (O.srgb_tonemap(lin, noclip=False) if tonemap else lin) + (1 - acc_r[:, None]) * b
+    assert_close(rgb_map.detach().cpu(), out_r.detach(), rtol=2e-5, atol=2e-6, what="rgb_map")
+    assert_close(acc.detach().cpu(), acc_r.detach(), rtol=2e-5, atol=1e-6, what="acc")
+    assert_close(ori.detach().cpu(), ori_r.detach(), rtol=2e-5, atol=1e-6, what="ori")
+    c1, c2, c3 = torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+    g_r = torch.autograd.grad((out_r * c1).sum() + (acc_r * c2).sum() + (ori_r * c3).sum(), tr)
+    g_h = torch.autograd.grad((rgb_map * d(c1)).sum() + (acc * d(c2)).sum() + (ori * d(c3)).sum(), td)
+    for a_, b_, nme in zip(g_h, g_r, ["weight", "refl", "normals", "bg"]):
+        assert_close(a_.cpu(), b_, rtol=1e-4, atol=1e-5 * max(float(b_.abs().max()), 1.0), what="ray compose d" + nme)
