@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..functional import VMQuery
+from ..functional import FieldGrads, GradPass, VMQuery
 
 
 def N_to_reso(n_voxels, bbox):
@@ -149,6 +149,7 @@ class TensorVMSplit(torch.nn.Module):
         self.basis_mat = torch.nn.Linear(self.app_rf.dim(), app_dim, bias=False)
         self.dbasis_mat = torch.nn.Linear(self.density_rf.dim(), 1, bias=False)
         self._cache = None
+        self._pass, self._pass_open = None, False
 
     # ---- geometry bookkeeping (fields/tensor_base.py:55-64,219-232) ---------------------------------
     def set_register(self, name, val):
@@ -219,7 +220,27 @@ class TensorVMSplit(torch.nn.Module):
         xyz = xyz_sampled.detach()
         if xyz.shape[-1] == 3:
             xyz = torch.cat([xyz, torch.zeros_like(xyz[:, :1])], -1)
-        return VMQuery.apply(self, xyz.contiguous(), want_app, want_normal, *self._param_list())
+        holder, token = self._pass_token()
+        return VMQuery.apply(self, xyz.contiguous(), want_app, want_normal, holder, token)
+
+    # ---- gradient pass: all queries between begin_pass() and end_pass() share one FieldGrads node -----------
+    def begin_pass(self):
+        self._pass, self._pass_open = None, True
+
+    def end_pass(self):
+        self._pass, self._pass_open = None, False
+
+    def _pass_token(self):
+        ps = self._param_list()
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in ps)):
+            return None, None
+        if self._pass_open and self._pass is not None:
+            return self._pass
+        holder = GradPass()
+        token = FieldGrads.apply(holder, self, *ps)
+        if self._pass_open:
+            self._pass = (holder, token)
+        return holder, token
 
     def compute_densityfeature(self, xyz_sampled, activate=True):
         sg, sf, _, _ = self.query(xyz_sampled, want_app=False, want_normal=False)

@@ -1,24 +1,57 @@
 """Autograd glue between torch tensors and the HIP kernels (nmf_amd.hip).  Each Function is a thin
 forward/backward pair of C-ABI calls; there is no Python/torch re-implementation behind them."""
+import math
+
 import torch
 
 from . import hip
 
 
-class VMQuery(torch.autograd.Function):
-    """sigma, sigma_feat, app, normal = field(xyzt).  Gradients flow to the 12 factor tables and basis_mat
-    (incl. the second-order path through the normals); sample positions carry no gradient, exactly like
-    the reference (fields/tensor_base.py:109 detaches xyz)."""
+class GradPass:
+    """Gradient accumulators shared by every operator call of ONE forward/backward pass over a parameter set (the
+    primary and the re-traced secondary rays query the same tables).  The per-call backward kernels
+    accumulate into `bufs`; the pass's graph node (FieldGrads / SatBuild) converts them to parameter gradients once."""
+
+    def __init__(self):
+        self.bufs = None
+
+
+class FieldGrads(torch.autograd.Function):
+    """Graph node that owns the table gradients of a pass: forward hands out a scalar token every VMQuery of the pass
+    takes as an input, so autograd runs this backward exactly once, after the last VMQuery backward."""
 
     @staticmethod
-    def forward(ctx, field, xyzt, want_app, want_normal, *params):
+    def forward(ctx, holder, field, *params):
+        ctx.holder, ctx.field = holder, field
+        return params[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _d_token):
+        holder, field = ctx.holder, ctx.field
+        if holder.bufs is None:
+            return (None, None) + (None,) * len(field._param_list())
+        g_dpk, g_dlk, g_apl, g_ali, g_basis = holder.bufs
+        holder.bufs = None
+        p = field._tables()[0]
+        gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+        return (None, None) + tuple(field._grads_to_param_layout(gp, gl, g_apl, g_ali, g_basis))
+
+
+class VMQuery(torch.autograd.Function):
+    """sigma, sigma_feat, app, normal = field(xyzt).  Gradients flow to the 12 factor tables and basis_mat
+    (incl. the second-order path through the normals) through the pass's FieldGrads node; sample positions carry
+    no gradient, exactly like the reference (fields/tensor_base.py:109 detaches xyz)."""
+
+    @staticmethod
+    def forward(ctx, field, xyzt, want_app, want_normal, holder, token):
         p, dpk, dlk, apl, ali, basis = field._tables()
         sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
                                                   want_normal=want_normal, want_app=want_app, want_coef=False)
-        ctx.field = field
+        ctx.field, ctx.holder = field, holder
         ctx.flags = (want_app, want_normal)
         ctx.save_for_backward(xyzt, sf, gr, cf)
         ctx.mark_non_differentiable(sf)
+        ctx.set_materialize_grads(False)
         outs = [sg, sf,
                 ap if want_app else xyzt.new_zeros((xyzt.shape[0], 24)),
                 nr if want_normal else xyzt.new_zeros((xyzt.shape[0], 3))]
@@ -26,26 +59,26 @@ class VMQuery(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_sigma, _d_sf, d_app, d_normal):
-        field = ctx.field
+        field, holder = ctx.field, ctx.holder
         want_app, want_normal = ctx.flags
         xyzt, sf, gr, cf = ctx.saved_tensors
         p, dpk, dlk, apl, ali, basis = field._tables()
         G = p.grid
         dev = xyzt.device
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
-        g_dpk = [z(G, G, 48) for _ in range(3)]
-        g_dlk = [z(G, 32) for _ in range(3)]
-        g_apl = [z(G, G, 24) for _ in range(3)]
-        g_ali = [z(G, 24) for _ in range(3)]
+        if holder.bufs is None:
+            shapes = [(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]
+            sizes = [math.prod(sh) for sh in shapes]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)          # one fill for all 13 tables
+            v = [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)]
+            holder.bufs = (v[0:3], v[3:6], v[6:9], v[9:12], v[12])
+        g_dpk, g_dlk, g_apl, g_ali, g_basis = holder.bufs
         d_sigma = d_sigma.contiguous() if d_sigma is not None else None
         d_app_c = d_app.contiguous() if (want_app and d_app is not None) else None
         d_nrm_c = d_normal.contiguous() if (want_normal and d_normal is not None) else None
-        g_basis = z(24, 72) if d_app_c is not None else None
-        hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
-                         g_dpk, g_dlk, g_apl, g_ali, g_basis)
-        gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
-        grads = field._grads_to_param_layout(gp, gl, g_apl, g_ali, g_basis)
-        return (None, None, None, None) + tuple(grads)
+        if d_sigma is not None or d_app_c is not None or d_nrm_c is not None:
+            hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
+                             g_dpk, g_dlk, g_apl, g_ali, g_basis if d_app_c is not None else None)
+        return None, None, None, None, None, xyzt.new_zeros(())
 
 
 class Composite(torch.autograd.Function):
@@ -87,52 +120,57 @@ def segment_sum(vals, offsets, seg_id, n_seg):
 
 class SatBuild(torch.autograd.Function):
     """Graph node for the cached summed-area table: sat = cumsum_W(cumsum_H(exp(brightness + mul*bg_mat)/1000))
-    (modules/integral_equirect.py:431-433).  All lookups of one backward pass feed their table adjoints into this
-    single node, so the two reverse prefix sums run once per step instead of once per lookup."""
+    (modules/integral_equirect.py:431-433).  Hands out a scalar token; all lookups of the pass accumulate their table
+    adjoints into holder.bufs = (d_sat, d_pole), and the two reverse prefix sums run once here."""
 
     @staticmethod
-    def forward(ctx, env, bg_mat, brightness, mul):
-        act, sat, pole = env._tables()
-        ctx.env = env
-        return sat.detach().view_as(sat)
+    def forward(ctx, holder, env, bg_mat, brightness, mul):
+        ctx.env, ctx.holder = env, holder
+        return bg_mat.new_zeros(())
 
     @staticmethod
-    def backward(ctx, d_sat):
-        env = ctx.env
+    def backward(ctx, _d_token):
+        env, holder = ctx.env, ctx.holder
+        if holder.bufs is None:
+            return None, None, None, None, None
+        d_sat, d_pole = holder.bufs
+        holder.bufs = None
         act, sat, pole = env._tables()
         _, br, mul = env._host_scalars()
-        d_pole = env._d_pole
-        d_bg = hip.sat_build_bwd(d_sat.contiguous().clone(), env.bg_mat.detach(), act, d_pole, br, mul)
-        env._graph = None                                    # the node is consumed; the next forward makes a new one
+        d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, br, mul)    # d_sat is consumed in place
         d_pre = d_bg / mul                                   # adjoint of (brightness + mul * bg_mat)
         d_br = d_pre.sum(dtype=torch.float64)
         d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
-        return None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul
+        return None, None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul
 
 
 class EnvLookup(torch.autograd.Function):
     """IntegralEquirect.forward (modules/integral_equirect.py:409-504) on the cached SAT."""
 
     @staticmethod
-    def forward(ctx, env, dirs, sa, sat, mipbias):
-        act, _, pole = env._tables()
+    def forward(ctx, env, dirs, sa, mipbias, holder, token):
+        act, sat, pole = env._tables()
         dirs_c = dirs.contiguous()
         sa_c = sa.reshape(-1).contiguous()
         mip = env._host_scalars()[0]
         out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, mip, pole)
-        ctx.env = env
+        ctx.env, ctx.holder = env, holder
         ctx.save_for_backward(dirs_c, sa_c, sat)
         ctx.mip = mip
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        env = ctx.env
+        holder = ctx.holder
         dirs, sa, sat = ctx.saved_tensors
-        d_sat = torch.zeros_like(sat)
-        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, env._d_pole,
-                                           want_dirs=ctx.needs_input_grad[1], want_mipbias=True)
-        return None, d_dirs, None, d_sat, d_mip.to(torch.float64).reshape(())
+        want_tab = holder is not None and ctx.needs_input_grad[5]
+        if want_tab and holder.bufs is None:
+            holder.bufs = (torch.zeros_like(sat), torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
+        d_sat, d_pole = holder.bufs if want_tab else (None, torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
+        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
+                                           want_dirs=ctx.needs_input_grad[1], want_mipbias=ctx.needs_input_grad[3])
+        return (None, d_dirs, None, d_mip.to(torch.float64).reshape(()) if d_mip is not None else None, None,
+                d_out.new_zeros(()) if want_tab else None)
 
 
 class BrdfFeatures(torch.autograd.Function):

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from ..functional import EnvLookup, SatBuild
+from ..functional import EnvLookup, GradPass, SatBuild
 from . import sh
 
 
@@ -33,8 +33,7 @@ class IntegralEquirect(torch.nn.Module):
         self._cache = None
         self._sh_cache = None
         self._scalars = None
-        self._graph = None          # (key, graph-attached SAT) of the current forward/backward pass
-        self._d_pole = None         # adjoint of the two pole-row means, accumulated by the lookups of the pass
+        self._pass, self._pass_open = None, False   # (GradPass, token) shared by the lookups of a forward/backward pass
 
     def get_optparam_groups(self, lr_scale=1):
         # modules/integral_equirect.py:232-257
@@ -78,17 +77,27 @@ class IntegralEquirect(torch.nn.Module):
         if viewdirs.shape[0] == 0:
             return viewdirs.new_zeros((0, 3))
         sa = saSample.reshape(-1).detach().float()
-        return EnvLookup.apply(self, viewdirs.float(), sa, self._graph_sat(), self.mipbias)
+        holder, token = self._pass_token()
+        return EnvLookup.apply(self, viewdirs.float(), sa, self.mipbias, holder, token)
 
-    def _graph_sat(self):
-        act, sat, pole = self._tables()
-        if not (torch.is_grad_enabled() and self.bg_mat.requires_grad):
-            return sat
-        key = (self.bg_mat.data_ptr(), self.bg_mat._version)
-        if self._graph is None or self._graph[0] != key:
-            self._d_pole = torch.zeros((2, 3), dtype=torch.float32, device=sat.device)
-            self._graph = (key, SatBuild.apply(self, self.bg_mat, self.brightness, self.mul))
-        return self._graph[1]
+    # ---- gradient pass: every lookup between begin_pass() and end_pass() shares one SatBuild node ---------------
+    def begin_pass(self):
+        self._pass, self._pass_open = None, True
+
+    def end_pass(self):
+        self._pass, self._pass_open = None, False
+
+    def _pass_token(self):
+        if not (torch.is_grad_enabled() and (self.bg_mat.requires_grad or self.brightness.requires_grad
+                                             or self.mul.requires_grad)):
+            return None, None
+        if self._pass_open and self._pass is not None:
+            return self._pass
+        holder = GradPass()
+        token = SatBuild.apply(holder, self, self.bg_mat, self.brightness, self.mul)
+        if self._pass_open:
+            self._pass = (holder, token)
+        return holder, token
 
     @torch.no_grad()
     def get_spherical_harmonics(self, G, mipval=-5):
@@ -112,5 +121,5 @@ class IntegralEquirect(torch.nn.Module):
         return self._sh_cache[1]
 
     def _load_from_state_dict(self, *a, **k):
-        self._cache = self._sh_cache = self._scalars = self._graph = None
+        self._cache = self._sh_cache = self._scalars = self._pass = None
         super()._load_from_state_dict(*a, **k)

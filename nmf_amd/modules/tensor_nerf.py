@@ -71,6 +71,24 @@ class TensorNeRF(torch.nn.Module):
                 override_near=None, output_alpha=None, dynamic_batch_size=True, gt_normals=None,
                 override_alpha_thres=None, is_train=False, ndc_ray=False, N_samples=-1, tonemap=True, draw_debug=True,
                 max_weight_N=-1, noise=None):
+        if recur == 0:          # one gradient pass: primary and re-traced rays share the table-gradient nodes
+            passes = [m for m in (self.rf, self.bg_module) if hasattr(m, "begin_pass")]
+            for m in passes:
+                m.begin_pass()
+            try:
+                return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
+                                    dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples,
+                                    tonemap, draw_debug, max_weight_N, noise)
+            finally:
+                for m in passes:
+                    m.end_pass()
+        return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
+                            dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples, tonemap,
+                            draw_debug, max_weight_N, noise)
+
+    def _render(self, rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
+                dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples, tonemap, draw_debug,
+                max_weight_N, noise):
         dev = rays.device
         if noise is None:
             if self._noise is None:
