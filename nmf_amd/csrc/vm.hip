@@ -385,34 +385,48 @@ __global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float
     if (r.head) atomicAdd(counts + b, r.len);
 }
 
-// single-workgroup exclusive scan of n int32 counts -> offsets[n+1]; also copies offsets into cursor[n]
+// single-workgroup exclusive scan of n int32 counts -> offsets[n+1]; also copies offsets into cursor[n] and builds the
+// work-item list of the backward walk: brick b with c samples becomes ceil(c / item) items (b, t) covering samples
+// [offsets[b] + t*item, +item).  Only non-empty bricks produce items, items are equally sized, and consecutive items
+// (= consecutive workgroups) land on consecutive XCDs, so the hot surface bricks are spread over the whole chip
+// instead of following the brick index -> XCD round-robin of a dense (brick, part) grid.
 __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ counts, int n,
-                                                    int32_t* __restrict__ offsets, int32_t* __restrict__ cursor) {
-    __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
+                                                    int32_t* __restrict__ offsets, int32_t* __restrict__ cursor,
+                                                    int item, int2* __restrict__ items, int32_t* __restrict__ n_items) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
-        int v = i < n ? counts[i] : 0;
-        int incl = v;
+        const int c = i < n ? counts[i] : 0;
+        const int ni = (c + item - 1) / item;
+        const int64_t v = (int64_t)c | ((int64_t)ni << 32);          // low word: samples, high word: items
+        int64_t incl = v;
         for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
+            int64_t t = __shfl_up(incl, d, 64);
             if (lane >= d) incl += t;
         }
         if (lane == 63) wsum[wid] = incl;
         __syncthreads();
-        int woff = 0;
+        int64_t woff = 0;
         for (int w = 0; w < wid; ++w) woff += wsum[w];
-        const int carry = carry_s;
-        const int excl = carry + woff + incl - v;
-        if (i < n) { offsets[i] = excl; cursor[i] = excl; }
+        const int64_t excl = carry_s + woff + incl - v;
+        const int so = (int)(excl & 0xffffffffll), io = (int)(excl >> 32);
+        if (i < n) {
+            offsets[i] = so;
+            cursor[i] = so;
+            for (int t = 0; t < ni; ++t) items[io + t] = make_int2(i, t);
+        }
         __syncthreads();
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
     }
-    if (tid == 0) offsets[n] = carry_s;
+    if (tid == 0) {
+        offsets[n] = (int)(carry_s & 0xffffffffll);
+        *n_items = (int)(carry_s >> 32);
+    }
 }
 
 // Scatter into brick order.  Besides the permutation, the per-sample inputs of the backward walk are written in
@@ -507,8 +521,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BWD_THREADS = 64;               // one single-wave workgroup per (brick, part, plane/line pair)
 constexpr int NRB = 6;                       // 81 tile cells -> 6 row blocks of 16
-constexpr int BWD_CHUNK = 256;               // samples per (brick, part) work item
-constexpr int BWD_PARTS = 8;
+constexpr int BWD_ITEM = 256;                // samples per work item (brick slice); 128 below 400 k samples
+constexpr int BWD_ITEM_MIN = 64;             // smallest item size the workspace is sized for (tuning knob)
 
 // Scatter-add on the matrix cores.
 //
@@ -534,8 +548,11 @@ __device__ __forceinline__ FootPrint footprint(const nmf_vm_params& p, const flo
     float xn[3];
     normalized(p, x, xn);
     FootPrint f;
-    const Tap1 tl = make_tap1(xn[av], p.grid);
-    f.tp = make_ltap2(xn[a0], xn[a1], p.grid, ox, oy);
+    // uniform selects instead of xn[a0] / xn[a1] / xn[av]: a dynamically indexed local array would go to scratch
+    const float u = a0 == 0 ? xn[0] : xn[1], v = a1 == 1 ? xn[1] : xn[2];
+    const float w = av == 2 ? xn[2] : (av == 1 ? xn[1] : xn[0]);
+    const Tap1 tl = make_tap1(w, p.grid);
+    f.tp = make_ltap2(u, v, p.grid, ox, oy);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const bool in = tl.idx[t] >= 0;
@@ -580,20 +597,16 @@ __device__ __forceinline__ void flush_plane_tile(const floatx4 (&acc)[NRB], floa
 template <bool WITH_NORMAL>
 __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __restrict__ rec0,
                                                                 const float4* __restrict__ rec1,
-                                                                const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk,
-                                                                Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk) {
-    const int brick = blockIdx.x;
-    const int s0 = bin_off[brick], e = bin_off[brick + 1];
-    // heavy bricks are shared by up to gridDim.y workgroups: part y takes the 256-sample chunks y, y+gridDim.y, ...
-    const int s = s0 + (int)blockIdx.y * BWD_CHUNK;
-    if (s >= e) return;
-    const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
+                                                                int brick, int s, int e, int i, int nbx, Ptrs3 dpk,
+                                                                Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, int ablate) {
     const int G = p.grid;
-    const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
-    const int lane = threadIdx.x & 63, i = (int)blockIdx.z % 3;    // i = plane / line index of this wave
+    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
+    const int lane = threadIdx.x & 63;                              // i = plane / line index of this wave
     const int k = lane >> 4, j = lane & 15;
-    const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
-    const int ox = org[a0], oy = org[a1], oz = org[av];
+    // plane i spans axes (a0, a1) = (0,1), (0,2), (1,2); its line runs along av = 2, 1, 0 (uniform selects, no
+    // dynamically indexed arrays: those would live in scratch / LDS)
+    const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
+    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
     const float* __restrict__ T = dpk.p[i];
     const float* __restrict__ TLn = dlk.p[i];
     floatx4 accP[NRB], accX[NRB], accY[NRB];
@@ -601,8 +614,8 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) { accP[rb] = accX[rb] = accY[rb] = floatx4{0, 0, 0, 0}; }
 
-    for (int cbase = s; cbase < e; cbase += chunk_stride) {
-        const int cend = min(cbase + BWD_CHUNK, e);
+    {
+        const int cbase = s, cend = e;
         float4 x_nx = rec0[min(cbase + k, cend - 1)], a_nx = rec1[min(cbase + k, cend - 1)];
         for (int base = cbase; base < cend; base += 4) {
             const bool valid = base + k < cend;
@@ -611,10 +624,11 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
             x_nx = rec0[nidx];
             a_nx = rec1[nidx];
             const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
-            const float dga = ((const float*)&adj)[1 + a0], dgb = ((const float*)&adj)[1 + a1];
-            const float dgw = ((const float*)&adj)[1 + av], dsf = adj.x;
+            const float dga = i == 2 ? adj.z : adj.y, dgb = i == 0 ? adj.z : adj.w;
+            const float dgw = i == 0 ? adj.w : (i == 1 ? adj.z : adj.y), dsf = adj.x;
             // table values of (sample k, channel j)
             float Lc = 0.f, DLc = 0.f, Pq = 0.f, Xq = 0.f, Yq = 0.f;
+            if (ablate & 4) { Lc = DLc = Pq = Xq = Yq = f.lw[0]; } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float* q = TLn + (int64_t)f.lidx[t] * DL + j;
@@ -630,10 +644,17 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
                     Yq += f.tp.w[t] * q[2 * CD];
                 }
             }
+            }
             const float vz = valid ? 1.f : 0.f;
             // B operands [sample k][channel j]
             const float bP = vz * (dsf * Lc + dgw * DLc), bX = vz * dga * Lc, bY = vz * dgb * Lc;
             const float bL = vz * (dsf * Pq + dga * Xq + dgb * Yq), bDL = vz * dgw * Pq;
+            if (ablate & 2) {
+                float a = 0.f;
+                for (int rb = 0; rb < NRB; ++rb) a += cell_weight(f.tp, 16 * rb + j);
+                accP[0][0] += a * (bP + bX + bY + bL + bDL);
+                continue;
+            }
             // A operands [cell][sample k]: bilinear weight of the sample on tile cell 16*rb + j
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -648,6 +669,12 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
             accL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL, accL, 0, 0, 0);
             if (WITH_NORMAL) accDL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bDL, accDL, 0, 0, 0);
         }
+    }
+    if (ablate & 1) {
+        float t = accL[0] + accDL[0];
+        for (int rb = 0; rb < NRB; ++rb) t += accP[rb][0] + accX[rb][1] + accY[rb][2];
+        if (t == 123.456f) g_dlk.p[i][0] = t;
+        return;
     }
     flush_plane_tile(accP, g_dpk.p[i], DP, j, true, ox, oy, G, lane);
     if (WITH_NORMAL) {
@@ -665,22 +692,17 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
 }
 
 __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __restrict__ rec0,
-                                                            const int32_t* __restrict__ perm,
-                                                            const int32_t* __restrict__ bin_off, int nbx, Ptrs3 apl,
+                                                            const int32_t* __restrict__ perm, int brick, int s, int e,
+                                                            int i, int nbx, Ptrs3 apl,
                                                             Ptrs3 ali, const float* __restrict__ dcoef,
                                                             const float* __restrict__ d_app, MPtrs3 g_apl,
-                                                            MPtrs3 g_ali, float* __restrict__ g_basis) {
-    const int brick = blockIdx.x;
-    const int s0 = bin_off[brick], e = bin_off[brick + 1];
-    const int s = s0 + (int)blockIdx.y * BWD_CHUNK;
-    if (s >= e) return;
-    const int chunk_stride = (int)gridDim.y * BWD_CHUNK;
+                                                            MPtrs3 g_ali, float* __restrict__ g_basis, int ablate) {
     const int G = p.grid;
-    const int org[3] = {(brick % nbx) * BR, ((brick / nbx) % nbx) * BR, (brick / (nbx * nbx)) * BR};
-    const int lane = threadIdx.x & 63, i = (int)blockIdx.z % 3;
+    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
+    const int lane = threadIdx.x & 63;
     const int k = lane >> 4, j = lane & 15;
-    const int a0 = MAT0[i], a1 = MAT1[i], av = VEC[i];
-    const int ox = org[a0], oy = org[a1], oz = org[av];
+    const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
+    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
     const float* __restrict__ T = apl.p[i];
     const float* __restrict__ TLn = ali.p[i];
     // channel halves: j (0..15) and 16 + j (valid for j < 8)
@@ -693,8 +715,8 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     floatx4 accW00 = {0, 0, 0, 0}, accW01 = {0, 0, 0, 0}, accW10 = {0, 0, 0, 0}, accW11 = {0, 0, 0, 0};
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) { acc0[rb] = acc1[rb] = floatx4{0, 0, 0, 0}; }
-    for (int cbase = s; cbase < e; cbase += chunk_stride) {
-        const int cend = min(cbase + BWD_CHUNK, e);
+    {
+        const int cbase = s, cend = e;
         float4 x_nx = rec0[min(cbase + k, cend - 1)];
         int m_nx = perm[min(cbase + k, cend - 1)];
         for (int base = cbase; base < cend; base += 4) {
@@ -709,6 +731,7 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
             float dc0 = dcoef[(int64_t)pos * (3 * CA) + i * CA + j], dc1 = dcoef[(int64_t)pos * (3 * CA) + i * CA + jh];
             const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
             float La0 = 0.f, La1 = 0.f, Pa0 = 0.f, Pa1 = 0.f;
+            if (ablate & 4) { La0 = La1 = Pa0 = Pa1 = f.lw[0]; } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float* q = TLn + (int64_t)f.lidx[t] * CA;
@@ -721,7 +744,14 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
                 Pa0 += f.tp.w[t] * q[j];
                 Pa1 += f.tp.w[t] * q[jh];
             }
+            }
             if (!valid) { dc0 = 0.f; dc1 = 0.f; }
+            if (ablate & 2) {
+                float a = 0.f;
+                for (int rb = 0; rb < NRB; ++rb) a += cell_weight(f.tp, 16 * rb + j);
+                acc0[0][0] += a * (dc0 * La0 + dc1 * La1 + dc0 * Pa0 + dc1 * Pa1);
+                continue;
+            }
             const float bP0 = dc0 * La0, bP1 = hi_ok ? dc1 * La1 : 0.f;     // adjoint of the plane entries
             const float bL0 = dc0 * Pa0, bL1 = hi_ok ? dc1 * Pa1 : 0.f;     // adjoint of the line entries
 #pragma unroll
@@ -743,6 +773,12 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
                 accW11 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c1, accW11, 0, 0, 0);
             }
         }
+    }
+    if (ablate & 1) {
+        float t = accL0[0] + accL1[0] + accW00[0] + accW01[0] + accW10[0] + accW11[0];
+        for (int rb = 0; rb < NRB; ++rb) t += acc0[rb][0] + acc1[rb][1];
+        if (t == 123.456f) g_ali.p[i][0] = t;
+        return;
     }
     if (g_basis) {
 #pragma unroll
@@ -770,21 +806,28 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     }
 }
 
-// one launch for both halves (blockIdx.z / 3: density or appearance, blockIdx.z % 3: plane) so all six latency-bound
-// walks overlap; single-wave workgroups pack up to 3 per SIMD
+// one launch for both halves: blockIdx.x = work item (brick, 512-sample slice), blockIdx.y = density planes 0-2 /
+// appearance planes 3-5, so all six latency-bound walks of an item overlap; single-wave workgroups
 template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
                                                               const int32_t* __restrict__ perm,
-                                                              const int32_t* __restrict__ bin_off, int nbx, Ptrs3 dpk,
-                                                              Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
+                                                              const int32_t* __restrict__ bin_off,
+                                                              const int2* __restrict__ items,
+                                                              const int32_t* __restrict__ n_items, int item_size, int nbx,
+                                                              Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
                                                               const float* __restrict__ dcoef,
                                                               const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
                                                               MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
-                                                              int z_density, int z_app) {
-    if ((int)blockIdx.z / 3 == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, bin_off, nbx, dpk, dlk, g_dpk, g_dlk);
-    else if ((int)blockIdx.z / 3 == z_app)
-        vm_bwd_app(p, rec0, perm, bin_off, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis);
+                                                              int z_density, int z_app, int ablate) {
+    if ((int)blockIdx.x >= *n_items) return;
+    const int2 it = items[blockIdx.x];
+    const int brick = it.x;
+    const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
+    const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
+    if (half == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, ablate);
+    else if (half == z_app)
+        vm_bwd_app(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, ablate);
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -858,8 +901,9 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
 extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nbx = (grid + BR - 1) / BR;
     const int64_t nb = nbx * nbx * nbx;
-    return (2 * M + 3 * (nb + 1) + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
-           M * 3 * CA * (int64_t)sizeof(float) + 16;
+    const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
+    return (2 * M + 3 * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
+           M * 3 * CA * (int64_t)sizeof(float) + 32;
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
@@ -893,13 +937,19 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     int32_t* counts = ws + 2 * M;      // [nb+1]
     int32_t* offsets = counts + nb + 1;   // [nb+1]
     int32_t* cursor = offsets + nb + 1;   // [nb+1]
+    int32_t* n_items = cursor + nb + 1;   // [2] (8-byte aligned start of the item list follows)
+    int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
+    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
+    item_size = (item_size + 3) & ~3;
+    const int64_t max_items = M / item_size + nb + 1;
+    int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt, M, nbx,
                        counts, brick_id);
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor);
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor, item_size, items, n_items);
     // 16-byte aligned record arrays behind the integer scratch
-    uintptr_t rp = ((uintptr_t)(cursor + nb + 1) + 15) & ~(uintptr_t)15;
+    uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
     float4* rec0 = (float4*)rp;
     float4* rec1 = rec0 + M;
     float* dcoef = (float*)(rec1 + M);
@@ -908,17 +958,17 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
                        want_a ? d_app : nullptr, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    int parts = BWD_PARTS;
-    if (const char* ev = getenv("NMF_BWD_PARTS")) parts = atoi(ev) > 0 ? atoi(ev) : parts;   // tuning knob
-    const dim3 grid((unsigned)nb, (unsigned)parts, (unsigned)(3 * nz)), block(BWD_THREADS);
+    int ablate = 0;
+    if (const char* ev = getenv("NMF_BWD_ABLATE")) ablate = atoi(ev);
+    const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
     if (d_normal)
-        hipLaunchKernelGGL(k_vm_bwd_brick<true>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
+        hipLaunchKernelGGL(k_vm_bwd_brick<true>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items, item_size, nbx, mk(dpk), mk(dlk),
                            mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), g_basis, z_density, z_app);
+                           mkm(g_app_lines), g_basis, z_density, z_app, ablate);
     else
-        hipLaunchKernelGGL(k_vm_bwd_brick<false>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, nbx, mk(dpk), mk(dlk),
+        hipLaunchKernelGGL(k_vm_bwd_brick<false>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items, item_size, nbx, mk(dpk), mk(dlk),
                            mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), g_basis, z_density, z_app);
+                           mkm(g_app_lines), g_basis, z_density, z_app, ablate);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }
