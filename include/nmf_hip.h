@@ -183,9 +183,10 @@ int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs
 /* select_bounces (modules/pt_selectors.py:5-60): counts[i] = clamp(floor(pt_i), 0, 400) with
  *   mode 0 (recursion 0): pt = w*mul + u - 0.5                       (mul = rays_per_ray)
  *   mode 1 (recursion>=1): pt = (w + 1e-3*u) / sum_w * mul + add     (sum_w = clip(sum(w + 1e-3 u), 1e-3))
+ * sum_w_dev (optional DEVICE scalar) overrides sum_w, so the host need not read the sum back.
  * The dense ray_mask of the reference is the per-row prefix [0, counts[i]). */
 int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t mode, float mul,
-                       float add, float sum_w, int32_t* counts, void* stream);
+                       float add, float sum_w, const float* sum_w_dev, int32_t* counts, void* stream);
 /* seg_id[r] / local[r] for r in [offsets[i], offsets[i+1]) = i / r - offsets[i]  (= torch.where(ray_mask)). */
 int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, int32_t* local,
                         void* stream);

@@ -12,9 +12,10 @@ namespace {
 
 __global__ void __launch_bounds__(256) k_select_bounces(const float* __restrict__ w, const float* __restrict__ u,
                                                         int64_t M, int mode, float mul, float add, float S,
-                                                        int32_t* __restrict__ counts) {
+                                                        const float* __restrict__ S_dev, int32_t* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
+    if (S_dev) S = *S_dev;
     float pt;
     if (mode == 0) {
         // recursion level 0 (:20-22): pt = w * rays_per_ray + U - 0.5
@@ -44,13 +45,13 @@ __global__ void __launch_bounds__(256) k_expand_segments(const int64_t* __restri
 }  // namespace
 
 extern "C" int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t mode, float mul, float add,
-                                  float sum_w, int32_t* counts, void* stream) {
+                                  float sum_w, const float* sum_w_dev, int32_t* counts, void* stream) {
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_select_bounces: M < 0");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(weights && u && counts, NMF_EINVAL, "nmf_select_bounces: null");
     NMF_REQUIRE(mode == 0 || mode == 1, NMF_EINVAL, "nmf_select_bounces: mode");
     hipLaunchKernelGGL(k_select_bounces, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weights, u, M,
-                       mode, mul, add, sum_w, counts);
+                       mode, mul, add, sum_w, sum_w_dev, counts);
     NMF_CHECK_LAUNCH("nmf_select_bounces");
     return NMF_OK;
 }

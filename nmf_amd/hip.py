@@ -83,7 +83,9 @@ def _check(code, what):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device (what torch.cuda.current_stream().cuda_stream
+    # returns, without building the Stream object: this runs ~100 times per training step)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t, dtype=None):
@@ -371,10 +373,13 @@ def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, want_dirs=True,
 
 # ---- shading helpers -------------------------------------------------------------------------------
 def select_bounces(weights, u, mode, mul, add=0.0, sum_w=1.0):
+    """sum_w: python float, or a 0-d fp32 DEVICE tensor (read by the kernel: no host sync)."""
     M = weights.shape[0]
     counts = torch.empty(M, dtype=torch.int32, device=weights.device)
+    dev_sum = sum_w if isinstance(sum_w, torch.Tensor) else None
     _check(_lib.nmf_select_bounces(_p(weights, torch.float32), _p(u, torch.float32), C.c_int64(M), C.c_int32(mode),
-                                   C.c_float(mul), C.c_float(add), C.c_float(sum_w), _p(counts), _stream()),
+                                   C.c_float(mul), C.c_float(add), C.c_float(1.0 if dev_sum is not None else sum_w),
+                                   _p(dev_sum, torch.float32), _p(counts), _stream()),
            "nmf_select_bounces")
     return counts
 

@@ -122,9 +122,9 @@ class Microfacet(torch.nn.Module):
             total = (w_det.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
             Nbudget = self.max_brdf_rays[recur] - M
             if Nbudget > 0:
-                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, float(total))
+                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, total)
             else:
-                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(self.max_brdf_rays[recur]), 0.5, float(total))
+                counts = hip.select_bounces(w_det, u.contiguous(), 1, float(self.max_brdf_rays[recur]), 0.5, total)
         if self.trace is not None:
             self.trace[f"counts_own{recur}"] = counts
         if self.forced is not None and f"counts{recur}" in self.forced and self.forced[f"counts{recur}"].shape[0] == M:

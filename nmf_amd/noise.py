@@ -8,6 +8,7 @@ replay the reference's draws:
                generator (same call order, same shapes, including the unused draws).
 """
 import math
+import random
 
 import torch
 
@@ -41,7 +42,7 @@ class DeviceNoise:
         M = ray_id.shape[0]
         u = self.uniform((M,))
         n_drop = b * N - M
-        extra = 0.5 * n_drop + math.sqrt(max(n_drop, 0) / 12.0) * float(torch.randn((), generator=torch.Generator().manual_seed(self.calls + self.seed)))
+        extra = 0.5 * n_drop + math.sqrt(max(n_drop, 0) / 12.0) * random.Random(self.calls * 1000003 + self.seed).gauss(0.0, 1.0)
         self.calls += 1
         return u, u.sum(dtype=torch.float64) + extra
 
