@@ -200,10 +200,11 @@ int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const float* r_ro
                      const float* off_rows, const int32_t* cnt_rows, const float* sobol,
                      const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R, float* L,
                      float* half_local, float* diff_local, float* lpdf, float* mipval, float* rays, void* stream);
-/* d_nr [R][4] = (dL/dN)^T dL | (dL/dr)^T dL per ray (dual-number evaluation of the same sampler); reduce per row. */
+/* d_nr [R][4] = (dL/dN)^T g | (dL/dr)^T g per ray (dual-number evaluation of the same sampler); reduce per row.
+ * g = dL + d_rays[:,3:6] + 5e-3 d_rays[:,0:3]  (adjoints of L [R][3] and of the bounce rays [R][6]; either may be NULL). */
 int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
                      const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
-                     const float* dL, float* d_nr, void* stream);
+                     const float* dL, const float* d_rays, float* d_nr, void* stream);
 /* Fresnel-Schlick mix (models/microfacet.py:595-613): contrib [R][3] = (F Li brdf + (1-F) diffuse) / cnt with
  * F = f0 + (1-f0)(1-|V.H|)^5, H = normalize((V+L)/2); sum contrib per row for reflect_rgb. */
 int nmf_shade_mix_fwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
@@ -266,12 +267,13 @@ int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, c
                         const float* feat_noise, float anoise, float min_rough, float* V, float* N, float* r1,
                         float* f0, float* diffuse, float* feat, float* xyz, void* stream);
 /* Adjoint, written for ALL M samples (zeros where inv < 0): d_normals [M][3] (zero when detach_normals),
- * d_heads [M][11], d_app [M][24].  Row gradients may be NULL (= zero). */
+ * d_heads [M][11], d_app [M][24].  Row gradients may be NULL (= zero).  row_strides = row pitch in floats of
+ * (dN, dr1, df0, ddiffuse), so column slices of wider row tensors are read in place (NULL = dense 3,1,3,3). */
 int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
                         const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
                         int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
-                        const float* ddiffuse, const float* dfeat, float* d_normals, float* d_heads, float* d_app,
-                        void* stream);
+                        const float* ddiffuse, const int32_t row_strides[4], const float* dfeat, float* d_normals,
+                        float* d_heads, float* d_app, void* stream);
 /* modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py:34-55, one thread per ray in sample order:
  * acc = sum w, rgb_lin = sum w * refl_rows[inv], ori = sum w * min(-d.n, 0)^2 (ori / normals may be NULL),
  * rgb_map = (tonemap ? srgb(rgb_lin) : rgb_lin) + (1 - acc) * bg;  bg [3] or [B][3] (bg_per_ray). */

@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(256) k_ggx_rays_fwd(RowIn in, const float* __r
 __global__ void __launch_bounds__(256) k_ggx_rays_bwd(RowIn in, const float* __restrict__ sobol,
                                                       const int32_t* __restrict__ row_of_ray,
                                                       const int32_t* __restrict__ j_of_ray, int64_t R,
-                                                      const float* __restrict__ dL, float* __restrict__ d_nr) {
+                                                      const float* __restrict__ dL, const float* __restrict__ d_rays,
+                                                      float* __restrict__ d_nr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const int32_t row = row_of_ray[i];
@@ -161,7 +162,13 @@ __global__ void __launch_bounds__(256) k_ggx_rays_bwd(RowIn in, const float* __r
     D r = mk_const<4>(rf);
     N.x.d[0] = 1.f; N.y.d[1] = 1.f; N.z.d[2] = 1.f; r.d[3] = 1.f;
     const GgxOut<D> o = ggx_sample<D>(V, N, r, u1, u2);
-    const float g0 = dL[i * 3], g1 = dL[i * 3 + 1], g2 = dL[i * 3 + 2];
+    // adjoint of L itself plus of the bounce ray (origin x + 5e-3 L | direction L), either may be absent
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (dL) { g0 = dL[i * 3]; g1 = dL[i * 3 + 1]; g2 = dL[i * 3 + 2]; }
+    if (d_rays) {
+        const float* q = d_rays + i * 6;
+        g0 += q[3] + 5e-3f * q[0]; g1 += q[4] + 5e-3f * q[1]; g2 += q[5] + 5e-3f * q[2];
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) d_nr[i * 4 + t] = g0 * o.L.x.d[t] + g1 * o.L.y.d[t] + g2 * o.L.z.d[t];
 }
@@ -269,13 +276,13 @@ extern "C" int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const 
 
 extern "C" int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
                                 const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
-                                const float* dL, float* d_nr, void* stream) {
+                                const float* dL, const float* d_rays, float* d_nr, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_ggx_rays_bwd: R < 0");
     if (R == 0) return NMF_OK;
-    NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && dL && d_nr, NMF_EINVAL,
+    NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && d_nr, NMF_EINVAL,
                 "nmf_ggx_rays_bwd: null");
     hipLaunchKernelGGL(k_ggx_rays_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
-                       mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL,
+                       mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL, d_rays,
                        d_nr);
     NMF_CHECK_LAUNCH("nmf_ggx_rays_bwd");
     return NMF_OK;

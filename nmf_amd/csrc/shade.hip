@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     const int32_t* __restrict__ inv, int64_t M, const float* __restrict__ normals, const float* __restrict__ heads,
     const int32_t* __restrict__ ray_id, const float* __restrict__ rays, Conv conv, float min_rough, int detach_n,
     const float* __restrict__ dN, const float* __restrict__ dr1, const float* __restrict__ df0,
-    const float* __restrict__ ddiff, const float* __restrict__ dfeat, float* __restrict__ d_normals,
-    float* __restrict__ d_heads, float* __restrict__ d_app) {
+    const float* __restrict__ ddiff, int sN, int sr, int sf, int sd, const float* __restrict__ dfeat,
+    float* __restrict__ d_normals, float* __restrict__ d_heads, float* __restrict__ d_app) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int64_t row = inv[m];
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
         if (!detach_n && dN) {
             const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
             const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
-            gn[0] = dN[row * 3] * s; gn[1] = dN[row * 3 + 1] * s; gn[2] = dN[row * 3 + 2] * s;
+            gn[0] = dN[row * sN] * s; gn[1] = dN[row * sN + 1] * s; gn[2] = dN[row * sN + 2] * s;
         }
         const float* h = heads + m * HEADS;
         float Y[9];
@@ -204,10 +204,10 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
             float E = 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
-            gh[c] = ddiff ? ddiff[row * 3 + c] * E : 0.f;
-            gh[6 + c] = df0 ? df0[row * 3 + c] : 0.f;
+            gh[c] = ddiff ? ddiff[row * sd + c] * E : 0.f;
+            gh[6 + c] = df0 ? df0[row * sf + c] : 0.f;
         }
-        gh[9] = (dr1 && h[9] >= min_rough) ? dr1[row] : 0.f;
+        gh[9] = (dr1 && h[9] >= min_rough) ? dr1[row * sr] : 0.f;
         const float4* g4 = dfeat ? reinterpret_cast<const float4*>(dfeat + row * FEAT) : nullptr;
 #pragma unroll
         for (int i = 0; i < FEAT / 4; ++i) o4[i] = g4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -376,15 +376,17 @@ extern "C" int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float*
 extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
                                    const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
                                    int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
-                                   const float* ddiffuse, const float* dfeat, float* d_normals, float* d_heads,
-                                   float* d_app, void* stream) {
+                                   const float* ddiffuse, const int32_t row_strides[4], const float* dfeat,
+                                   float* d_normals, float* d_heads, float* d_app, void* stream) {
+    const int sN = row_strides ? row_strides[0] : 3, sr = row_strides ? row_strides[1] : 1;
+    const int sf = row_strides ? row_strides[2] : 3, sd = row_strides ? row_strides[3] : 3;
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_prep_bwd: M < 0");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(inv && normals && heads && ray_id && rays && conv && d_normals && d_heads && d_app, NMF_EINVAL,
                 "nmf_bounce_prep_bwd: null");
     hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, inv, M,
                        normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, dN, dr1, df0,
-                       ddiffuse, dfeat, d_normals, d_heads, d_app);
+                       ddiffuse, sN, sr, sf, sd, dfeat, d_normals, d_heads, d_app);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_bwd");
     return NMF_OK;
 }

@@ -16,6 +16,58 @@ class GradPass:
         self.bufs = None
 
 
+class ParamGrads(torch.autograd.Function):
+    """Pass node for a plain parameter list (BRDF MLP, material heads): the operator backwards of the pass accumulate into
+    one zero-initialised flat buffer (grad_views) and this node returns its per-parameter views once."""
+
+    @staticmethod
+    def forward(ctx, holder, *params):
+        ctx.holder, ctx.n = holder, len(params)
+        return params[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _d_token):
+        holder = ctx.holder
+        if holder.bufs is None:
+            return (None,) * (1 + ctx.n)
+        views = holder.bufs[1]
+        holder.bufs = None
+        return (None,) + tuple(views)
+
+
+def grad_views(holder, params):
+    """fp32 gradient accumulators shaped like `params`, carved from one flat zero buffer owned by the pass."""
+    if holder.bufs is None:
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=params[0].device)
+        holder.bufs = (flat, [v.view(p.shape) for v, p in zip(flat.split(sizes), params)])
+    return holder.bufs[1]
+
+
+class PassMixin:
+    """begin_pass()/end_pass() bracket one forward/backward pass; every operator call in between shares one
+    (GradPass, token) pair, i.e. one gradient node per parameter set (TensorNeRF.forward opens it at recursion 0)."""
+    _pass = None
+    _pass_open = False
+
+    def begin_pass(self):
+        self._pass, self._pass_open = None, True
+
+    def end_pass(self):
+        self._pass, self._pass_open = None, False
+
+    def _param_pass(self, params):
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+            return None, None
+        if self._pass_open and self._pass is not None:
+            return self._pass
+        holder = GradPass()
+        token = ParamGrads.apply(holder, *params)
+        if self._pass_open:
+            self._pass = (holder, token)
+        return holder, token
+
+
 class FieldGrads(torch.autograd.Function):
     """Graph node that owns the table gradients of a pass: forward hands out a scalar token every VMQuery of the pass
     takes as an input, so autograd runs this backward exactly once, after the last VMQuery backward."""
@@ -194,44 +246,67 @@ class BrdfFeatures(torch.autograd.Function):
 
 class BrdfMLP(torch.autograd.Function):
     """sigmoid(MLP([feat | ISH(half) | half | ISH(diff) | diff])[:3] + bias) in one fused MFMA kernel
-    (modules/brdf.py:177-261).  Differentiable wrt the per-bounce-point feature rows and the six MLP tensors."""
+    (modules/brdf.py:177-261).  Differentiable wrt the per-bounce-point feature rows and, through the pass's ParamGrads
+    node, the six MLP tensors."""
 
     @staticmethod
-    def forward(ctx, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, *weights):
+    def forward(ctx, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, holder, token,
+                *weights):
         hv, dv = half_vec.contiguous(), diff_vec.contiguous()
         fr, rr = feat_rows.contiguous(), rough_rows.contiguous()
-        ws = [w.contiguous() for w in weights]
+        ws = [w.detach().contiguous() for w in weights]
         out = hip.brdf_mlp_fwd(ws, hv, dv, fr, rr, row_of_ray, out_bias)
         ctx.save_for_backward(hv, dv, fr, rr, row_of_ray, row_offsets, *ws)
-        ctx.out_bias = out_bias
+        ctx.out_bias, ctx.holder = out_bias, holder
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         hv, dv, fr, rr, row_of_ray, row_offsets, *ws = ctx.saved_tensors
-        d_xfeat, grads = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out)
+        grads = grad_views(ctx.holder, ws) if ctx.holder is not None else [torch.zeros_like(w) for w in ws]
+        d_xfeat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out, grads)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
-        return (None, None, d_feat, None, None, None, None) + tuple(grads)
+        return (None, None, d_feat, None, None, None, None, None,
+                d_out.new_zeros(()) if ctx.holder is not None else None) + (None,) * len(ws)
 
 
 class MaterialHeads(torch.autograd.Function):
-    """(albedo | tint | f0 | roughness) [M,11] from the app features (modules/render_modules.py:519-574)."""
+    """(albedo | tint | f0 | roughness) [M,11] from the app features (modules/render_modules.py:519-574).
+    W [11,24] / b [11] are the four Linear layers stacked (cached per parameter version by the module); their
+    gradients go through the pass's ParamGrads node in the same stacked layout."""
 
     @staticmethod
-    def forward(ctx, feat, hp, wd, bd, wt, bt, wf, bf, wr, br):
-        W = torch.cat([wd, wt, wf, wr], 0).contiguous()
-        b = torch.cat([bd, bt, bf, br], 0).contiguous()
+    def forward(ctx, feat, hp, W, b, holder, token):
         feat_c = feat.contiguous()
         out = hip.heads_fwd(feat_c, W, b, hp)
         ctx.save_for_backward(feat_c, W, b)
-        ctx.hp = hp
+        ctx.hp, ctx.holder = hp, holder
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         feat, W, b = ctx.saved_tensors
-        d_feat, gW, gb = hip.heads_bwd(feat, W, b, ctx.hp, d_out)
-        return (d_feat, None, gW[0:3], gb[0:3], gW[3:6], gb[3:6], gW[6:9], gb[6:9], gW[9:11], gb[9:11])
+        gW, gb = grad_views(ctx.holder, [W, b]) if ctx.holder is not None else (torch.zeros_like(W), torch.zeros_like(b))
+        d_feat = hip.heads_bwd(feat, W, b, ctx.hp, d_out, gW, gb)
+        return d_feat, None, None, None, None, d_out.new_zeros(()) if ctx.holder is not None else None
+
+
+class StackedHeadGrads(torch.autograd.Function):
+    """ParamGrads for the stacked head weights: returns the row blocks of gW [11,24] / gb [11] to the four Linear layers."""
+
+    @staticmethod
+    def forward(ctx, holder, wd, bd, wt, bt, wf, bf, wr, br):
+        ctx.holder = holder
+        return wd.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _d_token):
+        holder = ctx.holder
+        if holder.bufs is None:
+            return (None,) * 9
+        gW, gb = holder.bufs[1]
+        holder.bufs = None
+        return (None, gW[0:3], gb[0:3], gW[3:6], gb[3:6], gW[6:9], gb[6:9], gW[9:11], gb[9:11])
 
 
 class GgxRays(torch.autograd.Function):
@@ -245,18 +320,18 @@ class GgxRays(torch.autograd.Function):
         L, hl, dl, lpdf, mip, rays = hip.ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray)
         ctx.save_for_backward(V, N, r, off, sobol, row_of_ray, j_of_ray, row_off)
         ctx.r_shape = r_shape
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(hl, dl, lpdf, mip)
         return L, hl, dl, lpdf, mip, rays
 
     @staticmethod
     def backward(ctx, dL, _hl, _dl, _lp, _mip, d_rays):
         V, N, r, off, sobol, row_of_ray, j_of_ray, row_off = ctx.saved_tensors
-        g = torch.zeros((row_of_ray.shape[0], 3), dtype=torch.float32, device=V.device)
-        if dL is not None:
-            g = g + dL
-        if d_rays is not None:
-            g = g + d_rays[:, 3:6] + 5e-3 * d_rays[:, 0:3]
-        d_nr = hip.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, g.contiguous())
+        if dL is None and d_rays is None:
+            return (None,) * 10
+        d_nr = hip.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray,
+                                dL.contiguous() if dL is not None else None,
+                                d_rays.contiguous() if d_rays is not None else None)
         rows = hip.segment_sum(d_nr, None, row_off, V.shape[0])
         return None, rows[:, 0:3], rows[:, 3].reshape(ctx.r_shape), None, None, None, None, None, None, None
 
@@ -301,7 +376,7 @@ class BouncePrep(torch.autograd.Function):
         min_rough, detach_n = ctx.cfg
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         d_normals, d_heads, d_app = hip.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n,
-                                                        c(dN), c(dr1), c(df0), c(ddiff), c(dfeat))
+                                                        dN, dr1, df0, ddiff, c(dfeat))      # column slices read in place
         return (None if detach_n else d_normals, d_app, d_heads) + (None,) * 10
 
 
@@ -342,3 +417,34 @@ class RayCompose(torch.autograd.Function):
             if not bg_per_ray:
                 d_bg = d_bg.sum(0).reshape(bg.shape)
         return (d_weight, d_refl if ctx.needs_input_grad[1] else None, d_normals, d_bg) + (None,) * 9
+
+
+def brdf_mlp(half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, weights, owner=None):
+    """BrdfMLP with its gradient pass: `owner` (a PassMixin module) shares one ParamGrads node per forward/backward pass;
+    without an owner the call gets a node of its own."""
+    if owner is not None:
+        holder, token = owner._param_pass(weights)
+    elif torch.is_grad_enabled() and any(w.requires_grad for w in weights):
+        holder = GradPass()
+        token = ParamGrads.apply(holder, *weights)
+    else:
+        holder, token = None, None
+    return BrdfMLP.apply(half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, holder, token,
+                         *weights)
+
+
+def material_heads(feat, hp, params, owner=None, stacked=None):
+    """MaterialHeads over the eight head tensors (wd, bd, wt, bt, wf, bf, wr, br); `stacked` = cached (W [11,24], b [11])."""
+    if stacked is None:
+        stacked = (torch.cat([p.detach() for p in params[0::2]], 0).contiguous(),
+                   torch.cat([p.detach() for p in params[1::2]], 0).contiguous())
+    holder, token = None, None
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if owner is not None and owner._pass_open and owner._pass is not None:
+            holder, token = owner._pass
+        else:
+            holder = GradPass()
+            token = StackedHeadGrads.apply(holder, *params)
+            if owner is not None and owner._pass_open:
+                owner._pass = (holder, token)
+    return MaterialHeads.apply(feat, hp, stacked[0], stacked[1], holder, token)

@@ -422,17 +422,17 @@ def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_
     return out
 
 
-def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out):
+def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads):
+    """grads: six fp32 tensors shaped like `weights`, ACCUMULATED into (caller zeroes them once per pass)."""
     R = half_vec.shape[0]
     dev = half_vec.device
     d_xfeat = torch.empty((R, 24), dtype=torch.float32, device=dev)
-    grads = [torch.zeros_like(w) for w in weights]
     _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
                                  _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
                                  _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias),
                                  _p(d_out.contiguous(), torch.float32), _p(d_xfeat), *[_p(g) for g in grads], _stream()),
            "nmf_brdf_mlp_bwd")
-    return d_xfeat, grads
+    return d_xfeat
 
 
 def heads_fwd(feat, W, b, hp):
@@ -444,14 +444,14 @@ def heads_fwd(feat, W, b, hp):
     return out
 
 
-def heads_bwd(feat, W, b, hp, d_out):
+def heads_bwd(feat, W, b, hp, d_out, gW, gb):
+    """gW [11,24] / gb [11] are ACCUMULATED into."""
     M = feat.shape[0]
     d_feat = torch.empty_like(feat)
-    gW, gb = torch.zeros_like(W), torch.zeros_like(b)
     _check(_lib.nmf_heads_bwd(_p(feat, torch.float32), C.c_int64(M), _p(W, torch.float32), _p(b, torch.float32),
                               *[C.c_float(v) for v in hp], _p(d_out.contiguous(), torch.float32), _p(d_feat), _p(gW),
                               _p(gb), _stream()), "nmf_heads_bwd")
-    return d_feat, gW, gb
+    return d_feat
 
 
 def ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray):
@@ -466,12 +466,12 @@ def ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray):
     return L, hl, dl, lpdf, mip, rays
 
 
-def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL):
+def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
     R = row_of_ray.shape[0]
     d_nr = torch.empty((R, 4), dtype=torch.float32, device=V.device)
     _check(_lib.nmf_ggx_rays_bwd(_p(V, torch.float32), _p(N, torch.float32), _p(r, torch.float32), _p(off, torch.float32),
                                  _p(sobol, torch.float32), _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32),
-                                 C.c_int64(R), _p(dL, torch.float32), _p(d_nr), _stream()), "nmf_ggx_rays_bwd")
+                                 C.c_int64(R), _p(dL), _p(d_rays), _p(d_nr), _stream()), "nmf_ggx_rays_bwd")
     return d_nr
 
 
@@ -536,6 +536,19 @@ def bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_no
     return V, N, r1, f0, diff, feat, xyz
 
 
+def _rows(t, width):
+    """(pointer, row pitch in floats) of a [n,width] / [n] fp32 tensor whose rows are dense but may be a column slice of
+    a wider tensor; anything else is made contiguous first."""
+    if t is None:
+        return C.c_void_p(0), width
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise NmfHipError("expected a float32 device tensor")
+    ok = (t.dim() == 2 and t.shape[1] == width and t.stride(1) == 1) or (t.dim() == 1 and width == 1)
+    if not ok or t.stride(0) < width:
+        t = t.contiguous()
+    return C.c_void_p(t.data_ptr()), (t.stride(0) if t.shape[0] > 1 else width)
+
+
 def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat):
     M = inv.shape[0]
     dev = normals.device
@@ -543,11 +556,13 @@ def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n
     d_heads = torch.empty((M, 11), dtype=torch.float32, device=dev)
     d_app = torch.empty((M, 24), dtype=torch.float32, device=dev)
     if M:
+        (pN, sN), (pr, sr), (pf, sf), (pd, sd) = _rows(dN, 3), _rows(dr1, 1), _rows(df0, 3), _rows(ddiff, 3)
+        strides = (C.c_int32 * 4)(sN, sr, sf, sd)
         _check(_lib.nmf_bounce_prep_bwd(_p(inv, torch.int32), C.c_int64(M), _p(normals, torch.float32),
                                         _p(heads, torch.float32), _p(ray_id, torch.int32), _p(rays, torch.float32),
                                         _p(conv, torch.float32), C.c_float(min_rough), C.c_int32(1 if detach_n else 0),
-                                        _p(dN), _p(dr1), _p(df0), _p(ddiff), _p(dfeat), _p(d_normals), _p(d_heads),
-                                        _p(d_app), _stream()), "nmf_bounce_prep_bwd")
+                                        pN, pr, pf, pd, strides, _p(dfeat), _p(d_normals), _p(d_heads), _p(d_app),
+                                        _stream()), "nmf_bounce_prep_bwd")
     return d_normals, d_heads, d_app
 
 

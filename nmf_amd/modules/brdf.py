@@ -5,7 +5,7 @@ dense layers are plain library GEMMs (rocBLAS through torch.nn.functional.linear
 import torch
 import torch.nn.functional as F
 
-from ..functional import BrdfFeatures, BrdfMLP
+from ..functional import BrdfFeatures, PassMixin, brdf_mlp
 from .util import create_mlp
 
 
@@ -20,7 +20,7 @@ class ListISH(torch.nn.Module):
         return sum(2 * d + 1 for d in self.degs)
 
 
-class MLPBRDF(torch.nn.Module):
+class MLPBRDF(PassMixin, torch.nn.Module):
     def __init__(self, in_channels, h_encoder=None, d_encoder=None, v_encoder=None, n_encoder=None, l_encoder=None,
                  feape=6, dotpe=0, activation="sigmoid", mul_LdotN=True, bias=0, lr=1e-4, shift=0, **kwargs):
         super().__init__()
@@ -42,9 +42,9 @@ class MLPBRDF(torch.nn.Module):
     def forward_compact(self, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
         if self.fused:
             m = self.mlp
-            return BrdfMLP.apply(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
-                                 row_of_ray, row_offsets, float(self.bias), m[0].weight, m[0].bias, m[2].weight,
-                                 m[2].bias, m[4].weight, m[4].bias)
+            ws = (m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+            return brdf_mlp(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
+                            row_of_ray, row_offsets, float(self.bias), ws, owner=self)
         # unfused path (library GEMMs), kept for A/B measurements: features from the HIP kernel + rocBLAS layers
         X = BrdfFeatures.apply(half_vec.detach(), diff_vec.detach(), feat_rows, rough_rows.detach().reshape(-1),
                                row_of_ray, row_offsets)

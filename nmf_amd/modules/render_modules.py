@@ -3,7 +3,7 @@
 Evaluated as one 24 -> 11 product per sample by nmf_heads_fwd/bwd (csrc/heads.hip); there is no CPU path."""
 import torch
 
-from ..functional import MaterialHeads
+from ..functional import PassMixin, material_heads
 from .util import create_mlp
 
 
@@ -11,7 +11,7 @@ def inv_sigmoid(v):
     return torch.log(v / (1 - v))
 
 
-class RandHydraMLPDiffuse(torch.nn.Module):
+class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
     def __init__(self, in_channels, pospe=12, view_encoder=None, roughness_view_encoder=None, roughness_cfg=None,
                  feape=6, allocation=0, unlit_tint=False, lr=1e-4, tint_bias=-1, diffuse_bias=-2, diffuse_mul=1,
                  roughness_bias=1, start_roughness=0.35, f0_bias=0, **kwargs):
@@ -28,6 +28,11 @@ class RandHydraMLPDiffuse(torch.nn.Module):
         self.tint_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
         self.f0_mlp = create_mlp(self.in_mlpC, 3, **kwargs)
         self.roughness_mlp = create_mlp(self.in_mlpC, 2, **(roughness_cfg if roughness_cfg is not None else kwargs))
+        self._stacked = None
+
+    def _head_params(self):
+        return (self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias, self.tint_mlp[0].weight, self.tint_mlp[0].bias,
+                self.f0_mlp[0].weight, self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
 
     def heads(self, features):
         """[M,11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied (nmf_heads_fwd)."""
@@ -35,9 +40,12 @@ class RandHydraMLPDiffuse(torch.nn.Module):
             return features.new_zeros((0, 11))
         hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
               float(self.roughness_bias))
-        return MaterialHeads.apply(features, hp, self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias,
-                                   self.tint_mlp[0].weight, self.tint_mlp[0].bias, self.f0_mlp[0].weight,
-                                   self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
+        ps = self._head_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._stacked is None or self._stacked[0] != key:      # the four Linear layers stacked, once per update
+            self._stacked = (key, (torch.cat([p.detach() for p in ps[0::2]], 0).contiguous(),
+                                   torch.cat([p.detach() for p in ps[1::2]], 0).contiguous()))
+        return material_heads(features, hp, ps, owner=self, stacked=self._stacked[1])
 
     def forward(self, pts, viewdirs, features, std=0, **kwargs):
         o = self.heads(features)

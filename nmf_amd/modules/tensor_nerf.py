@@ -72,7 +72,8 @@ class TensorNeRF(torch.nn.Module):
                 override_alpha_thres=None, is_train=False, ndc_ray=False, N_samples=-1, tonemap=True, draw_debug=True,
                 max_weight_N=-1, noise=None):
         if recur == 0:          # one gradient pass: primary and re-traced rays share the table-gradient nodes
-            passes = [m for m in (self.rf, self.bg_module) if hasattr(m, "begin_pass")]
+            passes = [m for m in (self.rf, self.bg_module, getattr(self.model, "brdf", None),
+                                  getattr(self.model, "diffuse_module", None)) if hasattr(m, "begin_pass")]
             for m in passes:
                 m.begin_pass()
             try:

@@ -371,7 +371,7 @@ def test_env_lookup_full_size_properties():
 @pytest.mark.parametrize("R", [1, 257, 5000])
 def test_brdf_mlp_fused_matches_oracle(R):
     hip = _hip()
-    from nmf_amd.functional import BrdfMLP
+    from nmf_amd.functional import brdf_mlp
     g = Golden("shading_parts")
     gen = torch.Generator().manual_seed(R)
     sd = {"model.brdf.mlp." + k[len("brdf_param/mlp."):]: g[k].clone().requires_grad_(True) for k in g.keys("brdf_param/")}
@@ -396,7 +396,7 @@ def test_brdf_mlp_fused_matches_oracle(R):
     order = ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
     ws = [sd["model.brdf.mlp." + k].detach().to(DEV).requires_grad_(True) for k in order]
     feat_d = feat.detach().to(DEV).requires_grad_(True)
-    out = BrdfMLP.apply(hv.to(DEV), dv.to(DEV), feat_d, rough.to(DEV), rows.int().to(DEV), row_off.to(DEV), 0.37, *ws)
+    out = brdf_mlp(hv.to(DEV), dv.to(DEV), feat_d, rough.to(DEV), rows.int().to(DEV), row_off.to(DEV), 0.37, ws)
     assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="brdf mlp out")
     gh = torch.autograd.grad((out * c.to(DEV)).sum(), [feat_d] + ws)
     assert_close(gh[0].cpu(), gref[0], rtol=1e-4, atol=1e-5 * float(gref[0].abs().max() + 1), what="d feat")
@@ -404,9 +404,9 @@ def test_brdf_mlp_fused_matches_oracle(R):
         r = gref[1 + names.index("model.brdf.mlp." + k)]
         assert_close(gq.cpu(), r, rtol=2e-4, atol=2e-5 * float(r.abs().max() + 1e-3), what="d " + k)
     if R == 257:      # golden (reference) values for exactly this input set
-        w = BrdfMLP.apply(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
-                          g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
-                          torch.arange(258, dtype=torch.int64, device=DEV), g["brdf_bias"], *[x.detach() for x in ws])
+        w = brdf_mlp(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
+                     g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
+                     torch.arange(258, dtype=torch.int64, device=DEV), g["brdf_bias"], [x.detach() for x in ws])
         assert_close(w.cpu(), g["brdf_out"], rtol=1e-5, atol=1e-6, what="brdf vs reference")
 
 
@@ -446,7 +446,7 @@ def test_select_bounces_golden_bit_exact():
 
 @pytest.mark.parametrize("M", [1, 100, 70001])
 def test_material_heads_fused(M):
-    from nmf_amd.functional import MaterialHeads
+    from nmf_amd.functional import material_heads
     g = Golden("shading_parts")
     gen = torch.Generator().manual_seed(M)
     sdh = {"model.diffuse_module." + k[len("heads_param/"):]: g[k].clone().requires_grad_(True) for k in g.keys("heads_param/")}
@@ -460,7 +460,7 @@ def test_material_heads_fused(M):
     gref = torch.autograd.grad((ref * c).sum(), [feat] + ps)
     feat_d = feat.detach().to(DEV).requires_grad_(True)
     ps_d = [p.detach().to(DEV).requires_grad_(True) for p in ps]
-    out = MaterialHeads.apply(feat_d, (cfg.diffuse_mul, cfg.diffuse_bias, cfg.tint_bias, cfg.f0_bias, cfg.roughness_bias), *ps_d)
+    out = material_heads(feat_d, (cfg.diffuse_mul, cfg.diffuse_bias, cfg.tint_bias, cfg.f0_bias, cfg.roughness_bias), ps_d)
     assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="heads out")
     gh = torch.autograd.grad((out * c.to(DEV)).sum(), [feat_d] + ps_d)
     for a, b, n in zip(gh, gref, ["feat"] + [f"{x}.{w}" for x in order for w in ("W", "b")]):
