@@ -1,0 +1,144 @@
+// Loss terms of the training step for gfx950 (reference: train.py:598-601 photometric term, fields/tensoRF.py:332-340
+// density L1 regulariser).  Both are tiny reductions that cost the reference ~60 elementwise launches per step
+// (clip / sub / pow / sum and abs / mean over six tensors, plus their autograd mirrors); here each is one launch per
+// direction.
+#include "common.hpp"
+
+namespace {
+
+constexpr int L1_MAX = 8;
+
+struct L1Tab {
+    const float* x[L1_MAX];
+    float* g[L1_MAX];
+    int64_t n[L1_MAX];
+};
+
+__device__ __forceinline__ float block_sum(float v, float* ws) {
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) ws[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
+    return t;   // valid on thread 0
+}
+
+// out += sum_i mean(|x_i|): blockIdx.y = tensor, grid-stride over its elements
+__global__ void __launch_bounds__(256) k_l1_fwd(L1Tab tab, float* __restrict__ out) {
+    __shared__ float ws[4];
+    const int i = blockIdx.y;
+    const int64_t n = tab.n[i];
+    const float* __restrict__ x = tab.x[i];
+    float a = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        a += fabsf(x[k]);
+    const float t = block_sum(a, ws);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t / (float)n);
+}
+
+// g_i = d_out * sgn(x_i) / n_i
+__global__ void __launch_bounds__(256) k_l1_bwd(L1Tab tab, const float* __restrict__ d_out) {
+    const int i = blockIdx.y;
+    const int64_t n = tab.n[i];
+    const float* __restrict__ x = tab.x[i];
+    float* __restrict__ g = tab.g[i];
+    const float s = d_out[0] / (float)n;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[k];
+        g[k] = v > 0.f ? s : (v < 0.f ? -s : 0.f);
+    }
+}
+
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// out += sum (clip(pred, 0, 1) - clip(gt, 0, 1))^2  over n floats
+__global__ void __launch_bounds__(256) k_sqerr_fwd(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                   int64_t n, float* __restrict__ out) {
+    __shared__ float ws[4];
+    float a = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const float d = clip01(pred[k]) - clip01(gt[k]);
+        a += d * d;
+    }
+    const float t = block_sum(a, ws);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t);
+}
+
+__global__ void __launch_bounds__(256) k_sqerr_bwd(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                   int64_t n, const float* __restrict__ d_out,
+                                                   float* __restrict__ d_pred) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float p = pred[k];
+    const bool pass = p >= 0.f && p <= 1.f;            // clamp backward passes the closed interval (ATen)
+    d_pred[k] = pass ? 2.f * (p - clip01(gt[k])) * d_out[0] : 0.f;
+}
+
+static int fill_tab(L1Tab& t, const float* const x[], float* const g[], const int64_t n[], int count, bool need_g) {
+    for (int i = 0; i < count; ++i) {
+        if (n[i] < 0 || (n[i] > 0 && (!x[i] || (need_g && !g[i])))) return -1;
+        t.x[i] = x[i];
+        t.g[i] = g ? g[i] : nullptr;
+        t.n[i] = n[i];
+    }
+    return 0;
+}
+
+static unsigned blocks_for(const int64_t n[], int count) {
+    int64_t big = 1;
+    for (int i = 0; i < count; ++i) big = n[i] > big ? n[i] : big;
+    const int64_t b = cdiv(big, 256 * 8);
+    return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+}  // namespace
+
+extern "C" int nmf_l1_mean_fwd(const float* const x[], const int64_t numel[], int32_t count, float* out, void* stream) {
+    NMF_REQUIRE(count >= 0 && count <= L1_MAX, NMF_ERANGE, "nmf_l1_mean_fwd: at most 8 tensors");
+    NMF_REQUIRE(out && (count == 0 || (x && numel)), NMF_EINVAL, "nmf_l1_mean_fwd: null");
+    if (count == 0) return NMF_OK;
+    L1Tab t;
+    memset(&t, 0, sizeof(t));
+    NMF_REQUIRE(fill_tab(t, x, nullptr, numel, count, false) == 0, NMF_EINVAL, "nmf_l1_mean_fwd: bad tensor");
+    hipLaunchKernelGGL(k_l1_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t, out);
+    NMF_CHECK_LAUNCH("nmf_l1_mean_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], int32_t count, const float* d_out,
+                               float* const g[], void* stream) {
+    NMF_REQUIRE(count >= 0 && count <= L1_MAX, NMF_ERANGE, "nmf_l1_mean_bwd: at most 8 tensors");
+    NMF_REQUIRE(d_out && (count == 0 || (x && numel && g)), NMF_EINVAL, "nmf_l1_mean_bwd: null");
+    if (count == 0) return NMF_OK;
+    L1Tab t;
+    memset(&t, 0, sizeof(t));
+    NMF_REQUIRE(fill_tab(t, x, g, numel, count, true) == 0, NMF_EINVAL, "nmf_l1_mean_bwd: bad tensor");
+    hipLaunchKernelGGL(k_l1_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+                       d_out);
+    NMF_CHECK_LAUNCH("nmf_l1_mean_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sqerr_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream) {
+    NMF_REQUIRE(n >= 0 && out, NMF_EINVAL, "nmf_sqerr_fwd: bad argument");
+    if (n == 0) return NMF_OK;
+    NMF_REQUIRE(pred && gt, NMF_EINVAL, "nmf_sqerr_fwd: null");
+    int64_t b = cdiv(n, 256 * 4);
+    b = b > 256 ? 256 : b;
+    hipLaunchKernelGGL(k_sqerr_fwd, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, pred, gt, n, out);
+    NMF_CHECK_LAUNCH("nmf_sqerr_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sqerr_bwd(const float* pred, const float* gt, int64_t n, const float* d_out, float* d_pred,
+                             void* stream) {
+    NMF_REQUIRE(n >= 0, NMF_EINVAL, "nmf_sqerr_bwd: n < 0");
+    if (n == 0) return NMF_OK;
+    NMF_REQUIRE(pred && gt && d_out && d_pred, NMF_EINVAL, "nmf_sqerr_bwd: null");
+    hipLaunchKernelGGL(k_sqerr_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
+                       d_pred);
+    NMF_CHECK_LAUNCH("nmf_sqerr_bwd");
+    return NMF_OK;
+}

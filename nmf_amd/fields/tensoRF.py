@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..functional import FieldGrads, GradPass, VMQuery
+from ..functional import FieldGrads, GradPass, L1Mean, VMQuery
 
 
 def N_to_reso(n_voxels, bbox):
@@ -264,11 +264,7 @@ class TensorVMSplit(torch.nn.Module):
 
     def density_L1(self):
         # fields/tensoRF.py:332-340
-        total = 0
-        for i in range(3):
-            total = total + torch.mean(torch.abs(self.density_rf.app_plane[i])) + torch.mean(
-                torch.abs(self.density_rf.app_line[i]))
-        return total
+        return L1Mean.apply(*self.density_rf.app_plane, *self.density_rf.app_line)
 
     def vector_comp_diffs(self):
         total = 0

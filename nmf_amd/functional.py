@@ -448,3 +448,31 @@ def material_heads(feat, hp, params, owner=None, stacked=None):
             if owner is not None and owner._pass_open:
                 owner._pass = (holder, token)
     return MaterialHeads.apply(feat, hp, stacked[0], stacked[1], holder, token)
+
+
+class L1Mean(torch.autograd.Function):
+    """sum_i mean(|x_i|) over a list of dense tensors in one launch (fields/tensoRF.py:332-340)."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.save_for_backward(*tensors)
+        return hip.l1_mean_fwd([t.detach() for t in tensors])
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return tuple(hip.l1_mean_bwd(list(ctx.saved_tensors), d_out.contiguous()))
+
+
+class SquaredError(torch.autograd.Function):
+    """sum (clip(pred,0,1) - clip(gt,0,1))^2 (train.py:598-601); differentiable wrt pred."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        ctx.save_for_backward(pred, gt)
+        return hip.sqerr_fwd(pred, gt)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pred, gt = ctx.saved_tensors
+        return hip.sqerr_bwd(pred, gt, d_out.contiguous()), None

@@ -61,7 +61,7 @@ EXPORTS = [
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
-    "nmf_ray_compose_fwd", "nmf_ray_compose_bwd",
+    "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -596,3 +596,47 @@ def ray_compose_bwd(weight, refl_rows, inv, normals, rays, ray_id, bg, bg_per_ra
                                         _p(d_rgb_map), _p(d_acc), _p(d_ori), _p(d_weight), _p(d_refl), _p(d_normals),
                                         _stream()), "nmf_ray_compose_bwd")
     return d_weight, d_refl, d_normals
+
+
+# ---- loss terms ------------------------------------------------------------------------------------
+def _dense_f32(t):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise NmfHipError("expected a float32 device tensor")
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        raise NmfHipError("tensor storage must be dense")
+    return t.data_ptr()
+
+
+def l1_mean_fwd(tensors):
+    n = len(tensors)
+    out = torch.zeros((), dtype=torch.float32, device=tensors[0].device)
+    ptrs = (C.c_void_p * n)(*[_dense_f32(t) for t in tensors])
+    numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    _check(_lib.nmf_l1_mean_fwd(ptrs, numel, C.c_int32(n), _p(out), _stream()), "nmf_l1_mean_fwd")
+    return out
+
+
+def l1_mean_bwd(tensors, d_out):
+    n = len(tensors)
+    grads = [torch.empty_like(t, memory_format=torch.preserve_format) for t in tensors]
+    ptrs = (C.c_void_p * n)(*[_dense_f32(t) for t in tensors])
+    gptrs = (C.c_void_p * n)(*[_dense_f32(g) for g in grads])
+    numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    _check(_lib.nmf_l1_mean_bwd(ptrs, numel, C.c_int32(n), _p(d_out, torch.float32), gptrs, _stream()), "nmf_l1_mean_bwd")
+    return grads
+
+
+def sqerr_fwd(pred, gt):
+    out = torch.zeros((), dtype=torch.float32, device=pred.device)
+    if pred.numel():
+        _check(_lib.nmf_sqerr_fwd(_p(pred, torch.float32), _p(gt, torch.float32), C.c_int64(pred.numel()), _p(out),
+                                  _stream()), "nmf_sqerr_fwd")
+    return out
+
+
+def sqerr_bwd(pred, gt, d_out):
+    d_pred = torch.empty_like(pred)
+    if pred.numel():
+        _check(_lib.nmf_sqerr_bwd(_p(pred, torch.float32), _p(gt, torch.float32), C.c_int64(pred.numel()),
+                                  _p(d_out, torch.float32), _p(d_pred), _stream()), "nmf_sqerr_bwd")
+    return d_pred

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .functional import SquaredError
 from .optim import FusedAdam
 
 
@@ -96,7 +97,7 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         n_total = rays.shape[0]
         lbatch = n_total * self.world_size          # the loss normaliser is the GLOBAL ray count
-        pos, used_rays, loss_sum, n_samples_last = 0, 0, 0.0, None
+        pos, used_rays, losses, n_samples_last = 0, 0, [], None
         bg = torch.ones(3, device=rays.device)
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
@@ -108,15 +109,15 @@ class Trainer:
             if n_samples[0] == 0:
                 continue
             wv = st["whole_valid"]
-            rgb_map = ims["rgb_map"].clip(max=1)
-            loss = ((rgb_map.clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()                         # train.py:598-601
+            rgb_map = ims["rgb_map"]                 # valid rays are a prefix of the chunk (alphagrid.py:353-364)
+            loss = SquaredError.apply(rgb_map, gt[: rgb_map.shape[0]])                           # train.py:598-601
             total = loss + p["ori_lambda"] * st["ori_loss"] + p["pred_lambda"] * st["prediction_loss"]
             total = total + p["L1_weight_initial"] * nerf.rf.density_L1()                        # train.py:670-677
             total = total / lbatch
             total.backward()
-            kept = int(wv.sum())
+            kept = rgb_map.shape[0]                  # = number of valid rays (no device read-back)
             used_rays += kept
-            loss_sum += float(loss.detach())
+            losses.append(loss.detach())             # read back after the optimizer step has been queued
             n_samples_last = n_samples
             if update_controllers:                                                               # train.py:618-627
                 ratio = kept / n_samples[0]
@@ -132,5 +133,6 @@ class Trainer:
             self.num_rays = p["starting_batch_size"]
             nerf.model.reset_counter()
         self.iteration += 1
+        loss_sum = float(torch.stack(losses).sum()) if losses else 0.0
         return dict(rays=used_rays, loss=loss_sum, n_samples=n_samples_last, comm_bytes=comm_bytes,
                     psnr=(-10.0 * math.log10(max(loss_sum / max(used_rays * 3, 1), 1e-12))))

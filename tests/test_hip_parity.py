@@ -719,3 +719,33 @@ def test_ray_compose_vs_torch(B, per_ray_bg, tonemap):
     g_h = torch.autograd.grad((rgb_map * d(c1)).sum() + (acc * d(c2)).sum() + (ori * d(c3)).sum(), td)
     for a_, b_, nme in zip(g_h, g_r, ["weight", "refl", "normals", "bg"]):
         assert_close(a_.cpu(), b_, rtol=1e-4, atol=1e-5 * max(float(b_.abs().max()), 1.0), what="ray compose d" + nme)
+
+
+def test_loss_kernels_vs_torch():
+    """nmf_l1_mean_* (fields/tensoRF.py:332-340) and nmf_sqerr_* (train.py:598-601) against the torch expressions."""
+    from nmf_amd.functional import L1Mean, SquaredError
+    gen = torch.Generator().manual_seed(9)
+    ts = [torch.randn(1, 16, 37, 37, generator=gen).to(memory_format=torch.channels_last), torch.randn(1, 16, 37, 1, generator=gen),
+          torch.randn(5, generator=gen), torch.zeros(3)]
+    ts[0][0, 0, 0, 0] = 0.0
+    td = [t.to(DEV).requires_grad_(True) for t in ts]
+    tr = [t.clone().requires_grad_(True) for t in ts]
+    out = L1Mean.apply(*td)
+    ref = sum(t.abs().mean() for t in tr)
+    assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-7, what="l1 mean")
+    g_h = torch.autograd.grad(out * 3.0, td)
+    g_r = torch.autograd.grad(ref * 3.0, tr)
+    for a, b, t in zip(g_h, g_r, td):
+        assert a.stride() == t.stride()
+        assert_close(a.cpu(), b, rtol=1e-6, atol=1e-9, what="l1 grad")
+    pred = (torch.rand(1000, 3, generator=gen) * 1.6 - 0.3)
+    pred[0, 0], pred[0, 1] = 0.0, 1.0                  # closed-interval clamp backward
+    gt = torch.rand(1000, 3, generator=gen) * 1.2
+    pd = pred.to(DEV).requires_grad_(True)
+    pr = pred.clone().requires_grad_(True)
+    out = SquaredError.apply(pd, gt.to(DEV))
+    ref = ((pr.clip(max=1).clip(0, 1) - gt.clip(0, 1)) ** 2).sum()
+    assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, what="sq err")
+    (g_h,) = torch.autograd.grad(out * 0.5, pd)
+    (g_r,) = torch.autograd.grad(ref * 0.5, pr)
+    assert_close(g_h.cpu(), g_r, rtol=1e-6, atol=1e-7, what="sq err grad")
