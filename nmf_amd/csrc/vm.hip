@@ -87,6 +87,9 @@ struct Ptrs3 {
 struct MPtrs3 {
     float* p[3];
 };
+// uniform select instead of p[i]: indexing a by-value kernel argument dynamically would spill it to scratch
+__device__ __forceinline__ const float* pick3(const Ptrs3& a, int i) { return i == 0 ? a.p[0] : (i == 1 ? a.p[1] : a.p[2]); }
+__device__ __forceinline__ float* pick3(const MPtrs3& a, int i) { return i == 0 ? a.p[0] : (i == 1 ? a.p[1] : a.p[2]); }
 
 // ------------------------------------------------------------------------------------------------
 // pack: dpk[y][x] = (P, conv_x P, conv_y P), dlk[k] = (L, conv L)
@@ -607,8 +610,8 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
     // dynamically indexed arrays: those would live in scratch / LDS)
     const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
     const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
-    const float* __restrict__ T = dpk.p[i];
-    const float* __restrict__ TLn = dlk.p[i];
+    const float* __restrict__ T = pick3(dpk, i);
+    const float* __restrict__ TLn = pick3(dlk, i);
     floatx4 accP[NRB], accX[NRB], accY[NRB];
     floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
 #pragma unroll
@@ -673,20 +676,20 @@ __device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __
     if (ablate & 1) {
         float t = accL[0] + accDL[0];
         for (int rb = 0; rb < NRB; ++rb) t += accP[rb][0] + accX[rb][1] + accY[rb][2];
-        if (t == 123.456f) g_dlk.p[i][0] = t;
+        if (t == 123.456f) pick3(g_dlk, i)[0] = t;
         return;
     }
-    flush_plane_tile(accP, g_dpk.p[i], DP, j, true, ox, oy, G, lane);
+    flush_plane_tile(accP, pick3(g_dpk, i), DP, j, true, ox, oy, G, lane);
     if (WITH_NORMAL) {
-        flush_plane_tile(accX, g_dpk.p[i], DP, CD + j, true, ox, oy, G, lane);
-        flush_plane_tile(accY, g_dpk.p[i], DP, 2 * CD + j, true, ox, oy, G, lane);
+        flush_plane_tile(accX, pick3(g_dpk, i), DP, CD + j, true, ox, oy, G, lane);
+        flush_plane_tile(accY, pick3(g_dpk, i), DP, 2 * CD + j, true, ox, oy, G, lane);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cell = 4 * (lane >> 4) + r;
         if (cell < TL && oz + cell < G) {
-            if (accL[r] != 0.f) atomicAdd(g_dlk.p[i] + (int64_t)(oz + cell) * DL + j, accL[r]);
-            if (WITH_NORMAL && accDL[r] != 0.f) atomicAdd(g_dlk.p[i] + (int64_t)(oz + cell) * DL + CD + j, accDL[r]);
+            if (accL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + j, accL[r]);
+            if (WITH_NORMAL && accDL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + CD + j, accDL[r]);
         }
     }
 }
@@ -703,8 +706,8 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     const int k = lane >> 4, j = lane & 15;
     const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
     const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
-    const float* __restrict__ T = apl.p[i];
-    const float* __restrict__ TLn = ali.p[i];
+    const float* __restrict__ T = pick3(apl, i);
+    const float* __restrict__ TLn = pick3(ali, i);
     // channel halves: j (0..15) and 16 + j (valid for j < 8)
     const bool hi_ok = j < CA - 16;
     const int jh = hi_ok ? 16 + j : j;
@@ -777,7 +780,7 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
     if (ablate & 1) {
         float t = accL0[0] + accL1[0] + accW00[0] + accW01[0] + accW10[0] + accW11[0];
         for (int rb = 0; rb < NRB; ++rb) t += acc0[rb][0] + acc1[rb][1];
-        if (t == 123.456f) g_ali.p[i][0] = t;
+        if (t == 123.456f) pick3(g_ali, i)[0] = t;
         return;
     }
     if (g_basis) {
@@ -794,21 +797,342 @@ __device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __rest
             }
         }
     }
-    flush_plane_tile(acc0, g_apl.p[i], CA, j, true, ox, oy, G, lane);
-    flush_plane_tile(acc1, g_apl.p[i], CA, 16 + j, hi_ok, ox, oy, G, lane);
+    flush_plane_tile(acc0, pick3(g_apl, i), CA, j, true, ox, oy, G, lane);
+    flush_plane_tile(acc1, pick3(g_apl, i), CA, 16 + j, hi_ok, ox, oy, G, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cell = 4 * (lane >> 4) + r;
         if (cell < TL && oz + cell < G) {
-            if (accL0[r] != 0.f) atomicAdd(g_ali.p[i] + (int64_t)(oz + cell) * CA + j, accL0[r]);
-            if (hi_ok && accL1[r] != 0.f) atomicAdd(g_ali.p[i] + (int64_t)(oz + cell) * CA + 16 + j, accL1[r]);
+            if (accL0[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + j, accL0[r]);
+            if (hi_ok && accL1[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + 16 + j, accL1[r]);
+        }
+    }
+}
+
+// ---- second-generation walk: footprints computed ONCE per sample ------------------------------------------------
+// In the walk above the 16 channel lanes of a sample all recompute its footprint (~330 VALU instructions per group of 4
+// samples against 19 MFMA: the kernel was VALU-bound, PMC in profiles/README.md).  Here a wave first takes 64 samples,
+// ONE PER LANE (coalesced record loads), computes each footprint once -- bilinear weights, tile-local cell of the
+// top-left tap, clamped table offsets, line taps, adjoints -- and parks 16 floats per sample in LDS; the 16 groups of 4
+// samples then fetch their sample's record with four broadcast ds_read_b128 and only build the MFMA operands.
+struct FpRec {          // 4 x float4 per sample in LDS
+    float4 w;           // bilinear weights nw, ne, sw, se (0 for taps outside the grid)
+    float4 q;           // bits: c00 (tile cell of the nw tap) | g00 (clamped nw texel) | flags (1: ne step, 2: sw step, 4: valid) | lcell
+    float4 l;           // l0, l1 | bits: z0c, z1c (clamped line taps)
+    float4 a;           // density: dsf, dga, dgb, dgw (0 when invalid)   appearance: bits m (sample id), -, -, -
+};
+
+__device__ __forceinline__ void fp_prologue(const nmf_vm_params& p, const float4& x, bool valid, int i, int ox, int oy,
+                                            int oz, float4& W, float4& Q, float4& L) {
+    float xn[3];
+    normalized(p, x, xn);
+    const int G = p.grid;
+    const float u = i == 2 ? xn[1] : xn[0], v = i == 0 ? xn[1] : xn[2];
+    const float w = i == 0 ? xn[2] : (i == 1 ? xn[1] : xn[0]);
+    const float gm = (float)(G - 1);
+    const float ix = ((u + 1.f) * 0.5f) * gm, iy = ((v + 1.f) * 0.5f) * gm, iz = ((w + 1.f) * 0.5f) * gm;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx = ix - fx, ex = 1.f - wx, wy = iy - fy, ey = 1.f - wy, wz = iz - fz, ez = 1.f - wz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const bool xi0 = x0 >= 0 && x0 < G, xi1 = x0 + 1 >= 0 && x0 + 1 < G;
+    const bool yi0 = y0 >= 0 && y0 < G, yi1 = y0 + 1 >= 0 && y0 + 1 < G;
+    W = make_float4((xi0 && yi0) ? ex * ey : 0.f, (xi1 && yi0) ? wx * ey : 0.f, (xi0 && yi1) ? ex * wy : 0.f,
+                    (xi1 && yi1) ? wx * wy : 0.f);
+    const int xc0 = min(max(x0, 0), G - 1), xc1 = min(max(x0 + 1, 0), G - 1);
+    const int yc0 = min(max(y0, 0), G - 1), yc1 = min(max(y0 + 1, 0), G - 1);
+    const int c00 = (y0 - oy) * TL + (x0 - ox);
+    const int flags = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (valid ? 4 : 0);
+    const bool zi0 = z0 >= 0 && z0 < G, zi1 = z0 + 1 >= 0 && z0 + 1 < G;
+    Q = make_float4(__int_as_float(c00), __int_as_float(yc0 * G + xc0), __int_as_float(flags), __int_as_float(z0 - oz));
+    L = make_float4(zi0 ? ez : 0.f, zi1 ? wz : 0.f, __int_as_float(min(max(z0, 0), G - 1)),
+                    __int_as_float(min(max(z0 + 1, 0), G - 1)));
+}
+
+// A operand of row block rb for lane j: bilinear weight of the sample on tile cell 16*rb + j
+__device__ __forceinline__ float a_weight(const float4& W, int jc /* = j - c00 */, int rb) {
+    const int d = jc + 16 * rb;
+    float a = d == 0 ? W.x : 0.f;
+    a = d == 1 ? W.y : a;
+    a = d == TL ? W.z : a;
+    a = d == TL + 1 ? W.w : a;
+    return a;
+}
+
+// one pipeline stage of the density walk: a sample's record (broadcast LDS reads) and its 12 + 4 table taps
+template <bool WITH_NORMAL>
+struct DGrp {
+    float4 W, A;
+    int c00, lcell;
+    float l0, l1;
+    float t[12];   // P, X, Y at the nw, ne, sw, se texels
+    float u[4];    // L (2 taps), DL (2 taps)
+    __device__ __forceinline__ void load(const float4* lds, int k, int g, const float* __restrict__ T,
+                                         const float* __restrict__ TLn, int G) {
+        const float4* r = lds + (4 * g + k) * 4;
+        W = r[0];
+        const float4 Q = r[1], L = r[2];
+        A = r[3];
+        c00 = __float_as_int(Q.x);
+        lcell = __float_as_int(Q.w);
+        l0 = L.x; l1 = L.y;
+        const int fl = __float_as_int(Q.z);
+        const int sxo = (fl & 1) ? DP : 0, syo = (fl & 2) ? G * DP : 0;
+        const float* q = T + (int64_t)__float_as_int(Q.y) * DP;
+        t[0] = q[0]; t[1] = q[sxo]; t[2] = q[syo]; t[3] = q[syo + sxo];
+        if (WITH_NORMAL) {
+            t[4] = q[CD]; t[5] = q[sxo + CD]; t[6] = q[syo + CD]; t[7] = q[syo + sxo + CD];
+            t[8] = q[2 * CD]; t[9] = q[sxo + 2 * CD]; t[10] = q[syo + 2 * CD]; t[11] = q[syo + sxo + 2 * CD];
+        }
+        const float* a0 = TLn + (int64_t)__float_as_int(L.z) * DL;
+        const float* a1 = TLn + (int64_t)__float_as_int(L.w) * DL;
+        u[0] = a0[0]; u[1] = a1[0]; u[2] = a0[CD]; u[3] = a1[CD];
+    }
+};
+
+template <bool WITH_NORMAL>
+__device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* __restrict__ rec0,
+                                                const float4* __restrict__ rec1, int brick, int s, int e, int i, int nbx,
+                                                Ptrs3 dpk, Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, float4* __restrict__ lds, int ablate) {
+    const int G = p.grid;
+    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15;
+    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
+    const float* __restrict__ T = pick3(dpk, i) + j;
+    const float* __restrict__ TLn = pick3(dlk, i) + j;
+    floatx4 accP[NRB], accX[NRB], accY[NRB];
+    floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { accP[rb] = accX[rb] = accY[rb] = floatx4{0, 0, 0, 0}; }
+
+    for (int base = s; base < e; base += 64) {
+        {   // one sample per lane
+            const int idx = base + lane;
+            const bool valid = idx < e;
+            const float4 x = rec0[min(idx, e - 1)];
+            float4 adj = rec1[min(idx, e - 1)];
+            float4 W, Q, L;
+            fp_prologue(p, x, valid, i, ox, oy, oz, W, Q, L);
+            const float dga = i == 2 ? adj.z : adj.y, dgb = i == 0 ? adj.z : adj.w;
+            const float dgw = i == 0 ? adj.w : (i == 1 ? adj.z : adj.y);
+            const float vz = valid ? 1.f : 0.f;
+            lds[lane * 4 + 0] = W;
+            lds[lane * 4 + 1] = Q;
+            lds[lane * 4 + 2] = L;
+            lds[lane * 4 + 3] = make_float4(vz * adj.x, vz * dga, vz * dgb, vz * dgw);
+        }
+        __syncthreads();
+        const int ng = min(16, (e - base + 3) >> 2);
+        // software pipeline (ping-pong stages, scheduling barriers keep the order): the record + table taps of group g+1
+        // are in flight while group g feeds the matrix pipe
+        DGrp<WITH_NORMAL> st0, st1;
+        auto step = [&](DGrp<WITH_NORMAL>& cur, DGrp<WITH_NORMAL>& nxt, int g) {
+            nxt.load(lds, k, min(g + 1, 15), T, TLn, G);      // branch-free: slots past the end hold zero adjoints
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 W = cur.W, A = cur.A;
+            const float Pq = W.x * cur.t[0] + W.y * cur.t[1] + W.z * cur.t[2] + W.w * cur.t[3];
+            float Xq = 0.f, Yq = 0.f;
+            if (WITH_NORMAL) {
+                Xq = W.x * cur.t[4] + W.y * cur.t[5] + W.z * cur.t[6] + W.w * cur.t[7];
+                Yq = W.x * cur.t[8] + W.y * cur.t[9] + W.z * cur.t[10] + W.w * cur.t[11];
+            }
+            const float Lc = cur.l0 * cur.u[0] + cur.l1 * cur.u[1];
+            const float DLc = cur.l0 * cur.u[2] + cur.l1 * cur.u[3];
+            const float dsf = A.x, dga = A.y, dgb = A.z, dgw = A.w;
+            const float bP = dsf * Lc + dgw * DLc, bX = dga * Lc, bY = dgb * Lc;
+            const float bL = dsf * Pq + dga * Xq + dgb * Yq, bDL = dgw * Pq;
+            const int jc = j - cur.c00;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float a = a_weight(W, jc, rb);
+                accP[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP, accP[rb], 0, 0, 0);
+                if (WITH_NORMAL) {
+                    accX[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bX, accX[rb], 0, 0, 0);
+                    accY[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bY, accY[rb], 0, 0, 0);
+                }
+            }
+            const int dl = j - cur.lcell;
+            const float al = dl == 0 ? cur.l0 : (dl == 1 ? cur.l1 : 0.f);
+            accL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL, accL, 0, 0, 0);
+            if (WITH_NORMAL) accDL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bDL, accDL, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        st0.load(lds, k, 0, T, TLn, G);
+        for (int g = 0; g < ng; g += 2) {       // an odd tail stage runs on a slot whose adjoints are zero
+            step(st0, st1, g);
+            step(st1, st0, g + 1);
+        }
+        __syncthreads();
+    }
+    flush_plane_tile(accP, pick3(g_dpk, i), DP, j, true, ox, oy, G, lane);
+    if (WITH_NORMAL) {
+        flush_plane_tile(accX, pick3(g_dpk, i), DP, CD + j, true, ox, oy, G, lane);
+        flush_plane_tile(accY, pick3(g_dpk, i), DP, 2 * CD + j, true, ox, oy, G, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cell = 4 * (lane >> 4) + r;
+        if (cell < TL && oz + cell < G) {
+            if (accL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + j, accL[r]);
+            if (WITH_NORMAL && accDL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + CD + j, accDL[r]);
+        }
+    }
+}
+
+// one pipeline stage of the appearance walk
+struct AGrp {
+    float4 W;
+    int c00, lcell;
+    float l0, l1, dc0, dc1, aq0, aq1;
+    float t[8];    // plane taps nw, ne, sw, se for channel j, then for channel jh
+    float u[4];    // line taps (2) for channel j, then jh
+    __device__ __forceinline__ void load(const float4* lds, const float* ldc, const float* lda, int k, int j, int jh,
+                                         int g, const float* __restrict__ T, const float* __restrict__ TLn, int G,
+                                         bool want_basis) {
+        const int sl = 4 * g + k;                       // sample slot of this lane's group member
+        const float4* r = lds + sl * 4;
+        W = r[0];
+        const float4 Q = r[1], L = r[2];
+        c00 = __float_as_int(Q.x);
+        lcell = __float_as_int(Q.w);
+        l0 = L.x; l1 = L.y;
+        dc0 = ldc[sl * CA + j]; dc1 = ldc[sl * CA + jh];            // zero for slots past the end
+        aq0 = 0.f; aq1 = 0.f;
+        if (want_basis) { aq0 = lda[sl * AD + j]; aq1 = lda[sl * AD + jh]; }
+        const int fl = __float_as_int(Q.z);
+        const int sxo = (fl & 1) ? CA : 0, syo = (fl & 2) ? G * CA : 0;
+        const float* q = T + (int64_t)__float_as_int(Q.y) * CA;
+        t[0] = q[j]; t[1] = q[sxo + j]; t[2] = q[syo + j]; t[3] = q[syo + sxo + j];
+        t[4] = q[jh]; t[5] = q[sxo + jh]; t[6] = q[syo + jh]; t[7] = q[syo + sxo + jh];
+        const float* a0 = TLn + (int64_t)__float_as_int(L.z) * CA;
+        const float* a1 = TLn + (int64_t)__float_as_int(L.w) * CA;
+        u[0] = a0[j]; u[1] = a1[j]; u[2] = a0[jh]; u[3] = a1[jh];
+    }
+};
+
+__device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __restrict__ rec0,
+                                            const int32_t* __restrict__ perm, int brick, int s, int e, int i, int nbx,
+                                            Ptrs3 apl, Ptrs3 ali, const float* __restrict__ dcoef,
+                                            const float* __restrict__ d_app, MPtrs3 g_apl, MPtrs3 g_ali,
+                                            float* __restrict__ g_basis, float4* __restrict__ lds, int ablate) {
+    if (ablate & 32) return;
+    const int G = p.grid;
+    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15;
+    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
+    const bool hi_ok = j < CA - 16;                   // channel halves: j (0..15) and 16 + j (valid for j < 8)
+    const int jh = hi_ok ? 16 + j : j;
+    const float* __restrict__ T = pick3(apl, i);
+    const float* __restrict__ TLn = pick3(ali, i);
+    // LDS: [0,256) footprint records, [256,640) coefficient adjoints (24 per sample), [640,1024) d_app rows (24 per sample)
+    float4* lds_dc = lds + 256;
+    float4* lds_da = lds + 640;
+    const float* ldc = reinterpret_cast<const float*>(lds_dc);
+    const float* lda = reinterpret_cast<const float*>(lds_da);
+    floatx4 acc0[NRB], acc1[NRB];
+    floatx4 accL0 = {0, 0, 0, 0}, accL1 = {0, 0, 0, 0};
+    floatx4 accW00 = {0, 0, 0, 0}, accW01 = {0, 0, 0, 0}, accW10 = {0, 0, 0, 0}, accW11 = {0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { acc0[rb] = acc1[rb] = floatx4{0, 0, 0, 0}; }
+
+    for (int base = s; base < e; base += 64) {
+        {   // one sample per lane: footprint + its streaming inputs (coefficient adjoints, d_app row) fetched with six
+            // 16-byte loads each, all in flight together -- the inner loop then only touches LDS and the cached tables
+            const int idx = min(base + lane, e - 1);
+            const bool valid = base + lane < e;
+            const float4 x = rec0[idx];
+            const int64_t m = perm[idx];
+            const float4* dc = reinterpret_cast<const float4*>(dcoef + (int64_t)idx * (3 * CA) + i * CA);
+            const float4* da = reinterpret_cast<const float4*>(d_app + m * AD);
+            float4 c[6], a[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) c[q] = valid ? dc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_basis) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) a[q] = valid ? da[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 W, Q, L;
+            fp_prologue(p, x, valid, i, ox, oy, oz, W, Q, L);
+            lds[lane * 4 + 0] = W;
+            lds[lane * 4 + 1] = Q;
+            lds[lane * 4 + 2] = L;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) lds_dc[lane * 6 + q] = c[q];
+            if (g_basis) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) lds_da[lane * 6 + q] = a[q];
+            }
+        }
+        __syncthreads();
+        const int ng = min(16, (e - base + 3) >> 2);
+        AGrp st0, st1;
+        auto step = [&](AGrp& cur, AGrp& nxt, int g) {
+            nxt.load(lds, ldc, lda, k, j, jh, min(g + 1, 15), T, TLn, G, g_basis != nullptr);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 W = cur.W;
+            const float Pa0 = W.x * cur.t[0] + W.y * cur.t[1] + W.z * cur.t[2] + W.w * cur.t[3];
+            const float Pa1 = W.x * cur.t[4] + W.y * cur.t[5] + W.z * cur.t[6] + W.w * cur.t[7];
+            const float La0 = cur.l0 * cur.u[0] + cur.l1 * cur.u[1], La1 = cur.l0 * cur.u[2] + cur.l1 * cur.u[3];
+            const float bP0 = cur.dc0 * La0, bP1 = hi_ok ? cur.dc1 * La1 : 0.f;     // adjoint of the plane entries
+            const float bL0 = cur.dc0 * Pa0, bL1 = hi_ok ? cur.dc1 * Pa1 : 0.f;     // adjoint of the line entries
+            const int jc = j - cur.c00;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float a = a_weight(W, jc, rb);
+                acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP0, acc0[rb], 0, 0, 0);
+                acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP1, acc1[rb], 0, 0, 0);
+            }
+            const int dl = j - cur.lcell;
+            const float al = dl == 0 ? cur.l0 : (dl == 1 ? cur.l1 : 0.f);
+            accL0 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL0, accL0, 0, 0, 0);
+            accL1 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL1, accL1, 0, 0, 0);
+            if (g_basis) {
+                const float aq1 = hi_ok ? cur.aq1 : 0.f;
+                const float c0 = Pa0 * La0, c1 = hi_ok ? Pa1 * La1 : 0.f;          // coefficient (tensoRF.py:204)
+                accW00 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aq0, c0, accW00, 0, 0, 0);
+                accW01 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aq0, c1, accW01, 0, 0, 0);
+                accW10 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c0, accW10, 0, 0, 0);
+                accW11 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c1, accW11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        st0.load(lds, ldc, lda, k, j, jh, 0, T, TLn, G, g_basis != nullptr);
+        for (int g = 0; g < ng; g += 2) {       // an odd tail stage runs on a slot whose adjoints are zero
+            step(st0, st1, g);
+            step(st1, st0, g + 1);
+        }
+        __syncthreads();
+    }
+    if (g_basis) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 4 * (lane >> 4) + r;                 // row of the 16x16 tile, column = j
+            float* w0 = g_basis + (int64_t)q * (3 * CA) + i * CA;
+            float* w1 = g_basis + (int64_t)(16 + q) * (3 * CA) + i * CA;
+            if (accW00[r] != 0.f) atomicAdd(w0 + j, accW00[r]);
+            if (hi_ok && accW01[r] != 0.f) atomicAdd(w0 + 16 + j, accW01[r]);
+            if (q < AD - 16) {
+                if (accW10[r] != 0.f) atomicAdd(w1 + j, accW10[r]);
+                if (hi_ok && accW11[r] != 0.f) atomicAdd(w1 + 16 + j, accW11[r]);
+            }
+        }
+    }
+    flush_plane_tile(acc0, pick3(g_apl, i), CA, j, true, ox, oy, G, lane);
+    flush_plane_tile(acc1, pick3(g_apl, i), CA, 16 + j, hi_ok, ox, oy, G, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cell = 4 * (lane >> 4) + r;
+        if (cell < TL && oz + cell < G) {
+            if (accL0[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + j, accL0[r]);
+            if (hi_ok && accL1[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + 16 + j, accL1[r]);
         }
     }
 }
 
 // one launch for both halves: blockIdx.x = work item (brick, 512-sample slice), blockIdx.y = density planes 0-2 /
 // appearance planes 3-5, so all six latency-bound walks of an item overlap; single-wave workgroups
-template <bool WITH_NORMAL>
+template <bool WITH_NORMAL, int GEN>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
                                                               const int32_t* __restrict__ perm,
@@ -825,9 +1149,16 @@ __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, c
     const int brick = it.x;
     const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
     const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
-    if (half == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, ablate);
-    else if (half == z_app)
-        vm_bwd_app(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, ablate);
+    if (GEN == 1) {       // first-generation walk (A/B measurements: NMF_BWD_ABLATE=8)
+        if (half == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, ablate);
+        else if (half == z_app)
+            vm_bwd_app(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, ablate);
+    } else {
+        __shared__ float4 lds[64 * 16];
+        if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds, ablate);
+        else if (half == z_app)
+            vm_bwd_app2(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds, ablate);
+    }
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -961,14 +1292,18 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     int ablate = 0;
     if (const char* ev = getenv("NMF_BWD_ABLATE")) ablate = atoi(ev);
     const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
-    if (d_normal)
-        hipLaunchKernelGGL(k_vm_bwd_brick<true>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items, item_size, nbx, mk(dpk), mk(dlk),
-                           mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), g_basis, z_density, z_app, ablate);
-    else
-        hipLaunchKernelGGL(k_vm_bwd_brick<false>, grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items, item_size, nbx, mk(dpk), mk(dlk),
-                           mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk), mkm(g_dlk), mkm(g_app_planes),
-                           mkm(g_app_lines), g_basis, z_density, z_app, ablate);
+#define NMF_LAUNCH_BWD(WN, GEN)                                                                                       \
+    hipLaunchKernelGGL((k_vm_bwd_brick<WN, GEN>), grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items,     \
+                       item_size, nbx, mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk),        \
+                       mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app, ablate)
+    if (ablate & 8) {
+        if (d_normal) NMF_LAUNCH_BWD(true, 1);
+        else NMF_LAUNCH_BWD(false, 1);
+    } else {
+        if (d_normal) NMF_LAUNCH_BWD(true, 2);
+        else NMF_LAUNCH_BWD(false, 2);
+    }
+#undef NMF_LAUNCH_BWD
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }
