@@ -495,31 +495,6 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
     }
 }
 
-// uniform (per-sample) footprint: global texel index or -1, tile-local cell, weight
-struct LTap2 {
-    int g[4];
-    int l[4];
-    float w[4];
-};
-
-__device__ __forceinline__ LTap2 make_ltap2(float u, float v, int G, int ox, int oy) {
-    float ix = ((u + 1.f) * 0.5f) * (float)(G - 1);
-    float iy = ((v + 1.f) * 0.5f) * (float)(G - 1);
-    float fx = floorf(ix), fy = floorf(iy);
-    float w = ix - fx, e = 1.f - w, n = iy - fy, s = 1.f - n;
-    int x0 = (int)fx, y0 = (int)fy;
-    LTap2 t;
-    t.w[0] = e * s; t.w[1] = w * s; t.w[2] = e * n; t.w[3] = w * n;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int X = x0 + (k & 1), Y = y0 + (k >> 1);
-        bool in = X >= 0 && X < G && Y >= 0 && Y < G;
-        t.g[k] = in ? Y * G + X : -1;
-        t.l[k] = (Y - oy) * TL + (X - ox);
-    }
-    return t;
-}
-
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BWD_THREADS = 64;               // one single-wave workgroup per (brick, part, plane/line pair)
@@ -534,52 +509,12 @@ constexpr int BWD_ITEM_MIN = 64;             // smallest item size the workspace
 // sparse [cells x samples] weight matrix (4 non-zeros per column) with a dense [samples x channels] adjoint matrix.
 // LDS float atomics run at ~0.2 lane-ops/clk/CU on gfx950 (measured: 17 ms per 1 M samples, 36 ds_add_f32 per sample),
 // so the accumulation is done with v_mfma_f32_16x16x4_f32 instead: exact fp32, K = 4 samples per instruction, the
-// 18 (+2) accumulator tiles of a plane live in VGPRs for the whole work item, no LDS and no atomics until the final
-// flush.  The 95 % zero products are free: the matrix pipe is otherwise idle here.
+// 18 (+2) accumulator tiles of a plane live in AGPRs for the whole work item, no atomics until the final flush.
+// The 95 % zero products are free: the matrix pipe is otherwise idle here.
 //
 // Lane mapping of a wave: k = lane >> 4 is the sample of the current group of 4, j = lane & 15 is a channel (B operand)
-// and, for the A operand, a tile cell.  Each of the three waves of a workgroup owns one plane/line pair and walks the
-// samples of its (brick, part) in sorted order; the next group's sample records are prefetched one iteration ahead.
-struct FootPrint {
-    LTap2 tp;
-    float lw[2];
-    int lidx[2], lcell[2];
-};
-
-__device__ __forceinline__ FootPrint footprint(const nmf_vm_params& p, const float4& x, int a0, int a1, int av, int ox,
-                                               int oy, int oz) {
-    float xn[3];
-    normalized(p, x, xn);
-    FootPrint f;
-    // uniform selects instead of xn[a0] / xn[a1] / xn[av]: a dynamically indexed local array would go to scratch
-    const float u = a0 == 0 ? xn[0] : xn[1], v = a1 == 1 ? xn[1] : xn[2];
-    const float w = av == 2 ? xn[2] : (av == 1 ? xn[1] : xn[0]);
-    const Tap1 tl = make_tap1(w, p.grid);
-    f.tp = make_ltap2(u, v, p.grid, ox, oy);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const bool in = tl.idx[t] >= 0;
-        f.lcell[t] = in ? tl.idx[t] - oz : -1;
-        f.lw[t] = in ? tl.w[t] : 0.f;
-        f.lidx[t] = in ? tl.idx[t] : 0;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const bool in = f.tp.g[t] >= 0;
-        f.tp.w[t] = in ? f.tp.w[t] : 0.f;
-        f.tp.l[t] = in ? f.tp.l[t] : -1;
-        f.tp.g[t] = in ? f.tp.g[t] : 0;
-    }
-    return f;
-}
-
-__device__ __forceinline__ float cell_weight(const LTap2& tp, int cell) {
-    float a = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a += (tp.l[t] == cell) ? tp.w[t] : 0.f;
-    return a;
-}
-
+// and, for the A operand, a tile cell.  One single-wave workgroup owns one (work item, plane/line pair, density or
+// appearance) and walks the item's samples in sorted order.
 // C layout of 16x16x4: column (channel) = lane & 15, row (cell) = 4 * (lane >> 4) + reg
 __device__ __forceinline__ void flush_plane_tile(const floatx4 (&acc)[NRB], float* __restrict__ g, int nch, int ch,
                                                  bool ch_ok, int ox, int oy, int G, int lane) {
@@ -593,218 +528,6 @@ __device__ __forceinline__ void flush_plane_tile(const floatx4 (&acc)[NRB], floa
                 const int X = ox + cell % TL, Y = oy + cell / TL;
                 if (X < G && Y < G) atomicAdd(g + ((int64_t)Y * G + X) * nch + ch, v);
             }
-        }
-    }
-}
-
-template <bool WITH_NORMAL>
-__device__ __forceinline__ void vm_bwd_density(nmf_vm_params p, const float4* __restrict__ rec0,
-                                                                const float4* __restrict__ rec1,
-                                                                int brick, int s, int e, int i, int nbx, Ptrs3 dpk,
-                                                                Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, int ablate) {
-    const int G = p.grid;
-    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
-    const int lane = threadIdx.x & 63;                              // i = plane / line index of this wave
-    const int k = lane >> 4, j = lane & 15;
-    // plane i spans axes (a0, a1) = (0,1), (0,2), (1,2); its line runs along av = 2, 1, 0 (uniform selects, no
-    // dynamically indexed arrays: those would live in scratch / LDS)
-    const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
-    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
-    const float* __restrict__ T = pick3(dpk, i);
-    const float* __restrict__ TLn = pick3(dlk, i);
-    floatx4 accP[NRB], accX[NRB], accY[NRB];
-    floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) { accP[rb] = accX[rb] = accY[rb] = floatx4{0, 0, 0, 0}; }
-
-    {
-        const int cbase = s, cend = e;
-        float4 x_nx = rec0[min(cbase + k, cend - 1)], a_nx = rec1[min(cbase + k, cend - 1)];
-        for (int base = cbase; base < cend; base += 4) {
-            const bool valid = base + k < cend;
-            const float4 x = x_nx, adj = a_nx;
-            const int nidx = min(base + 4 + k, cend - 1);            // prefetch the next group's records
-            x_nx = rec0[nidx];
-            a_nx = rec1[nidx];
-            const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
-            const float dga = i == 2 ? adj.z : adj.y, dgb = i == 0 ? adj.z : adj.w;
-            const float dgw = i == 0 ? adj.w : (i == 1 ? adj.z : adj.y), dsf = adj.x;
-            // table values of (sample k, channel j)
-            float Lc = 0.f, DLc = 0.f, Pq = 0.f, Xq = 0.f, Yq = 0.f;
-            if (ablate & 4) { Lc = DLc = Pq = Xq = Yq = f.lw[0]; } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float* q = TLn + (int64_t)f.lidx[t] * DL + j;
-                Lc += f.lw[t] * q[0];
-                DLc += f.lw[t] * q[CD];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* q = T + (int64_t)f.tp.g[t] * DP + j;
-                Pq += f.tp.w[t] * q[0];
-                if (WITH_NORMAL) {
-                    Xq += f.tp.w[t] * q[CD];
-                    Yq += f.tp.w[t] * q[2 * CD];
-                }
-            }
-            }
-            const float vz = valid ? 1.f : 0.f;
-            // B operands [sample k][channel j]
-            const float bP = vz * (dsf * Lc + dgw * DLc), bX = vz * dga * Lc, bY = vz * dgb * Lc;
-            const float bL = vz * (dsf * Pq + dga * Xq + dgb * Yq), bDL = vz * dgw * Pq;
-            if (ablate & 2) {
-                float a = 0.f;
-                for (int rb = 0; rb < NRB; ++rb) a += cell_weight(f.tp, 16 * rb + j);
-                accP[0][0] += a * (bP + bX + bY + bL + bDL);
-                continue;
-            }
-            // A operands [cell][sample k]: bilinear weight of the sample on tile cell 16*rb + j
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                const float a = cell_weight(f.tp, 16 * rb + j);
-                accP[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP, accP[rb], 0, 0, 0);
-                if (WITH_NORMAL) {
-                    accX[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bX, accX[rb], 0, 0, 0);
-                    accY[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bY, accY[rb], 0, 0, 0);
-                }
-            }
-            const float al = (f.lcell[0] == j ? f.lw[0] : 0.f) + (f.lcell[1] == j ? f.lw[1] : 0.f);
-            accL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL, accL, 0, 0, 0);
-            if (WITH_NORMAL) accDL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bDL, accDL, 0, 0, 0);
-        }
-    }
-    if (ablate & 1) {
-        float t = accL[0] + accDL[0];
-        for (int rb = 0; rb < NRB; ++rb) t += accP[rb][0] + accX[rb][1] + accY[rb][2];
-        if (t == 123.456f) pick3(g_dlk, i)[0] = t;
-        return;
-    }
-    flush_plane_tile(accP, pick3(g_dpk, i), DP, j, true, ox, oy, G, lane);
-    if (WITH_NORMAL) {
-        flush_plane_tile(accX, pick3(g_dpk, i), DP, CD + j, true, ox, oy, G, lane);
-        flush_plane_tile(accY, pick3(g_dpk, i), DP, 2 * CD + j, true, ox, oy, G, lane);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int cell = 4 * (lane >> 4) + r;
-        if (cell < TL && oz + cell < G) {
-            if (accL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + j, accL[r]);
-            if (WITH_NORMAL && accDL[r] != 0.f) atomicAdd(pick3(g_dlk, i) + (int64_t)(oz + cell) * DL + CD + j, accDL[r]);
-        }
-    }
-}
-
-__device__ __forceinline__ void vm_bwd_app(nmf_vm_params p, const float4* __restrict__ rec0,
-                                                            const int32_t* __restrict__ perm, int brick, int s, int e,
-                                                            int i, int nbx, Ptrs3 apl,
-                                                            Ptrs3 ali, const float* __restrict__ dcoef,
-                                                            const float* __restrict__ d_app, MPtrs3 g_apl,
-                                                            MPtrs3 g_ali, float* __restrict__ g_basis, int ablate) {
-    const int G = p.grid;
-    const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
-    const int lane = threadIdx.x & 63;
-    const int k = lane >> 4, j = lane & 15;
-    const int a0 = i == 2 ? 1 : 0, a1 = i == 0 ? 1 : 2, av = 2 - i;
-    const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
-    const float* __restrict__ T = pick3(apl, i);
-    const float* __restrict__ TLn = pick3(ali, i);
-    // channel halves: j (0..15) and 16 + j (valid for j < 8)
-    const bool hi_ok = j < CA - 16;
-    const int jh = hi_ok ? 16 + j : j;
-    floatx4 acc0[NRB], acc1[NRB];
-    floatx4 accL0 = {0, 0, 0, 0}, accL1 = {0, 0, 0, 0};
-    // basis_mat gradient  dW[q][i*24 + c] = sum_s d_app[s][q] * coef[s][c]  (2 x 2 blocks of 16): the [24 x M] x [M x 72]
-    // GEMM of the reference's autograd, folded into the same MFMA stream
-    floatx4 accW00 = {0, 0, 0, 0}, accW01 = {0, 0, 0, 0}, accW10 = {0, 0, 0, 0}, accW11 = {0, 0, 0, 0};
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) { acc0[rb] = acc1[rb] = floatx4{0, 0, 0, 0}; }
-    {
-        const int cbase = s, cend = e;
-        float4 x_nx = rec0[min(cbase + k, cend - 1)];
-        int m_nx = perm[min(cbase + k, cend - 1)];
-        for (int base = cbase; base < cend; base += 4) {
-            const bool valid = base + k < cend;
-            const float4 x = x_nx;
-            const int64_t m = m_nx;
-            const int nidx = min(base + 4 + k, cend - 1);
-            x_nx = rec0[nidx];
-            m_nx = perm[nidx];
-            const int pos = min(base + k, cend - 1);
-            // adjoint of this sample's coefficients (precomputed in sorted order by k_brick_scatter)
-            float dc0 = dcoef[(int64_t)pos * (3 * CA) + i * CA + j], dc1 = dcoef[(int64_t)pos * (3 * CA) + i * CA + jh];
-            const FootPrint f = footprint(p, x, a0, a1, av, ox, oy, oz);
-            float La0 = 0.f, La1 = 0.f, Pa0 = 0.f, Pa1 = 0.f;
-            if (ablate & 4) { La0 = La1 = Pa0 = Pa1 = f.lw[0]; } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float* q = TLn + (int64_t)f.lidx[t] * CA;
-                La0 += f.lw[t] * q[j];
-                La1 += f.lw[t] * q[jh];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float* q = T + (int64_t)f.tp.g[t] * CA;
-                Pa0 += f.tp.w[t] * q[j];
-                Pa1 += f.tp.w[t] * q[jh];
-            }
-            }
-            if (!valid) { dc0 = 0.f; dc1 = 0.f; }
-            if (ablate & 2) {
-                float a = 0.f;
-                for (int rb = 0; rb < NRB; ++rb) a += cell_weight(f.tp, 16 * rb + j);
-                acc0[0][0] += a * (dc0 * La0 + dc1 * La1 + dc0 * Pa0 + dc1 * Pa1);
-                continue;
-            }
-            const float bP0 = dc0 * La0, bP1 = hi_ok ? dc1 * La1 : 0.f;     // adjoint of the plane entries
-            const float bL0 = dc0 * Pa0, bL1 = hi_ok ? dc1 * Pa1 : 0.f;     // adjoint of the line entries
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                const float a = cell_weight(f.tp, 16 * rb + j);
-                acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP0, acc0[rb], 0, 0, 0);
-                acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP1, acc1[rb], 0, 0, 0);
-            }
-            const float al = (f.lcell[0] == j ? f.lw[0] : 0.f) + (f.lcell[1] == j ? f.lw[1] : 0.f);
-            accL0 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL0, accL0, 0, 0, 0);
-            accL1 = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bL1, accL1, 0, 0, 0);
-            if (g_basis) {
-                const float vz = valid ? 1.f : 0.f;
-                const float aq0 = vz * d_app[m * AD + j], aq1 = hi_ok ? vz * d_app[m * AD + 16 + j] : 0.f;
-                const float c0 = Pa0 * La0, c1 = hi_ok ? Pa1 * La1 : 0.f;          // coefficient (tensoRF.py:204)
-                accW00 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0, c0, accW00, 0, 0, 0);
-                accW01 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq0, c1, accW01, 0, 0, 0);
-                accW10 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c0, accW10, 0, 0, 0);
-                accW11 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq1, c1, accW11, 0, 0, 0);
-            }
-        }
-    }
-    if (ablate & 1) {
-        float t = accL0[0] + accL1[0] + accW00[0] + accW01[0] + accW10[0] + accW11[0];
-        for (int rb = 0; rb < NRB; ++rb) t += acc0[rb][0] + acc1[rb][1];
-        if (t == 123.456f) pick3(g_ali, i)[0] = t;
-        return;
-    }
-    if (g_basis) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 4 * (lane >> 4) + r;                 // row of the 16x16 tile, column = j
-            float* w0 = g_basis + (int64_t)q * (3 * CA) + i * CA;
-            float* w1 = g_basis + (int64_t)(16 + q) * (3 * CA) + i * CA;
-            if (accW00[r] != 0.f) atomicAdd(w0 + j, accW00[r]);
-            if (hi_ok && accW01[r] != 0.f) atomicAdd(w0 + 16 + j, accW01[r]);
-            if (q < AD - 16) {
-                if (accW10[r] != 0.f) atomicAdd(w1 + j, accW10[r]);
-                if (hi_ok && accW11[r] != 0.f) atomicAdd(w1 + 16 + j, accW11[r]);
-            }
-        }
-    }
-    flush_plane_tile(acc0, pick3(g_apl, i), CA, j, true, ox, oy, G, lane);
-    flush_plane_tile(acc1, pick3(g_apl, i), CA, 16 + j, hi_ok, ox, oy, G, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int cell = 4 * (lane >> 4) + r;
-        if (cell < TL && oz + cell < G) {
-            if (accL0[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + j, accL0[r]);
-            if (hi_ok && accL1[r] != 0.f) atomicAdd(pick3(g_ali, i) + (int64_t)(oz + cell) * CA + 16 + j, accL1[r]);
         }
     }
 }
@@ -892,7 +615,7 @@ struct DGrp {
 template <bool WITH_NORMAL>
 __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* __restrict__ rec0,
                                                 const float4* __restrict__ rec1, int brick, int s, int e, int i, int nbx,
-                                                Ptrs3 dpk, Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, float4* __restrict__ lds, int ablate) {
+                                                Ptrs3 dpk, Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, float4* __restrict__ lds) {
     const int G = p.grid;
     const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
     const int lane = threadIdx.x & 63;
@@ -1014,8 +737,7 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
                                             const int32_t* __restrict__ perm, int brick, int s, int e, int i, int nbx,
                                             Ptrs3 apl, Ptrs3 ali, const float* __restrict__ dcoef,
                                             const float* __restrict__ d_app, MPtrs3 g_apl, MPtrs3 g_ali,
-                                            float* __restrict__ g_basis, float4* __restrict__ lds, int ablate) {
-    if (ablate & 32) return;
+                                            float* __restrict__ g_basis, float4* __restrict__ lds) {
     const int G = p.grid;
     const int bx = (brick % nbx) * BR, by = ((brick / nbx) % nbx) * BR, bz = (brick / (nbx * nbx)) * BR;
     const int lane = threadIdx.x & 63;
@@ -1132,7 +854,7 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
 
 // one launch for both halves: blockIdx.x = work item (brick, 512-sample slice), blockIdx.y = density planes 0-2 /
 // appearance planes 3-5, so all six latency-bound walks of an item overlap; single-wave workgroups
-template <bool WITH_NORMAL, int GEN>
+template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
                                                               const int32_t* __restrict__ perm,
@@ -1143,21 +865,17 @@ __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, c
                                                               const float* __restrict__ dcoef,
                                                               const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
                                                               MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
-                                                              int z_density, int z_app, int ablate) {
+                                                              int z_density, int z_app) {
     if ((int)blockIdx.x >= *n_items) return;
     const int2 it = items[blockIdx.x];
     const int brick = it.x;
     const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
     const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
-    if (GEN == 1) {       // first-generation walk (A/B measurements: NMF_BWD_ABLATE=8)
-        if (half == z_density) vm_bwd_density<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, ablate);
-        else if (half == z_app)
-            vm_bwd_app(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, ablate);
-    } else {
+    {
         __shared__ float4 lds[64 * 16];
-        if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds, ablate);
+        if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
         else if (half == z_app)
-            vm_bwd_app2(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds, ablate);
+            vm_bwd_app2(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
     }
 }
 
@@ -1289,20 +1007,13 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
                        want_a ? d_app : nullptr, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    int ablate = 0;
-    if (const char* ev = getenv("NMF_BWD_ABLATE")) ablate = atoi(ev);
     const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
-#define NMF_LAUNCH_BWD(WN, GEN)                                                                                       \
-    hipLaunchKernelGGL((k_vm_bwd_brick<WN, GEN>), grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items,     \
+#define NMF_LAUNCH_BWD(WN)                                                                                            \
+    hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items,     \
                        item_size, nbx, mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk),        \
-                       mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app, ablate)
-    if (ablate & 8) {
-        if (d_normal) NMF_LAUNCH_BWD(true, 1);
-        else NMF_LAUNCH_BWD(false, 1);
-    } else {
-        if (d_normal) NMF_LAUNCH_BWD(true, 2);
-        else NMF_LAUNCH_BWD(false, 2);
-    }
+                       mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app)
+    if (d_normal) NMF_LAUNCH_BWD(true);
+    else NMF_LAUNCH_BWD(false);
 #undef NMF_LAUNCH_BWD
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
