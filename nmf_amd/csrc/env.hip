@@ -62,22 +62,36 @@ __device__ __forceinline__ void sat_sample(const EnvTab& t, const T& x, const T&
     }
 }
 
-// scatter of the adjoint of sat_sample into dSAT (float path only)
-__device__ __forceinline__ void sat_scatter(float* dsat, int H, int W, float x, float y, const float (&g)[3]) {
+// Table adjoint.  Device-scope float atomics cost ~one L2 operation per distinct cache line touched by an instruction
+// (measured on MI355X: 21 G line-ops/s whatever the table size; 8 lanes on one 32-byte run = 156 G lane-ops/s).  A
+// lane-per-lookup scatter touches 64 lines per instruction (3 channel planes x 4 taps x 4..8 corners = 48-96
+// instructions per wave).  Instead every lookup parks its box corners in LDS and the wave replays them with 8 lanes per
+// corner on a CHANNEL-INTERLEAVED adjoint table dSAT4 [H][W][4]: lane t of a group owns (texel x0 + (t >> 2), channel
+// t & 3), so one instruction covers 8 lookups with one 32-byte run each; two instructions (rows y0, y0+1) per corner.
+constexpr int MAXC = 16;     // corners parked per lookup (2 wrap boxes x 2 wrap boxes x 4); more fall back to the direct path
+
+__device__ __forceinline__ void corner_taps(int H, int W, float x, float y, int& x0, int& y0, float& w, float& n) {
     const float ix = (x + 1.f) * ((float)(W - 1) * 0.5f);
     const float iy = (y + 1.f) * ((float)(H - 1) * 0.5f);
     const float fx = floorf(ix), fy = floorf(iy);
-    const float w = ix - fx, n = iy - fy, e = 1.f - w, s = 1.f - n;
-    const int x0 = (int)fx, y0 = (int)fy;
+    w = ix - fx; n = iy - fy;
+    x0 = (int)fx; y0 = (int)fy;
+}
+
+// direct (lane-per-corner) scatter into the interleaved table: overflow path only
+__device__ __forceinline__ void sat_scatter4(float* dsat4, int H, int W, float x, float y, const float (&g)[3]) {
+    int x0, y0;
+    float w, n;
+    corner_taps(H, W, x, y, x0, y0, w, n);
+    const float e = 1.f - w, s = 1.f - n;
     const bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float* p = dsat + (int64_t)c * H * W;
-        if (xi0 && yi0) atomicAdd(p + y0 * W + x0, g[c] * (e * s));
-        if (xi1 && yi0) atomicAdd(p + y0 * W + x0 + 1, g[c] * (w * s));
-        if (xi0 && yi1) atomicAdd(p + (y0 + 1) * W + x0, g[c] * (e * n));
-        if (xi1 && yi1) atomicAdd(p + (y0 + 1) * W + x0 + 1, g[c] * (w * n));
+        if (xi0 && yi0) atomicAdd(dsat4 + ((int64_t)y0 * W + x0) * 4 + c, g[c] * (e * s));
+        if (xi1 && yi0) atomicAdd(dsat4 + ((int64_t)y0 * W + x0 + 1) * 4 + c, g[c] * (w * s));
+        if (xi0 && yi1) atomicAdd(dsat4 + ((int64_t)(y0 + 1) * W + x0) * 4 + c, g[c] * (e * n));
+        if (xi1 && yi1) atomicAdd(dsat4 + ((int64_t)(y0 + 1) * W + x0 + 1) * 4 + c, g[c] * (w * n));
     }
 }
 
@@ -202,15 +216,24 @@ struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL s
     }
 };
 
-struct ScatterAcc {   // table adjoint
-    float* dsat;
-    int H, W;
+struct ListAcc {   // table adjoint, phase 1: park (texel, fractions, sign) of every corner in this lane's LDS list
+    float4* list;     // [MAXC] records of this lane
+    float* dsat4;     // overflow path
+    int H, W, n;
     float g[3];       // d_vals * 1000 / size
     __device__ void begin() {}
     __device__ void corner(float x, float y, int k) {
         const float sgn = k < 2 ? 1.f : -1.f;
-        const float gg[3] = {sgn * g[0], sgn * g[1], sgn * g[2]};
-        sat_scatter(dsat, H, W, x, y, gg);
+        if (n < MAXC) {
+            int x0, y0;
+            float w, nn;
+            corner_taps(H, W, x, y, x0, y0, w, nn);
+            list[n] = make_float4(__int_as_float((x0 + 1) | ((y0 + 1) << 16)), w, nn, sgn);
+            ++n;
+        } else {
+            const float gg[3] = {sgn * g[0], sgn * g[1], sgn * g[2]};
+            sat_scatter4(dsat4, H, W, x, y, gg);
+        }
     }
     __device__ void end() {}
 };
@@ -236,13 +259,19 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
     out[r * 3] = v[0]; out[r * 3 + 1] = v[1]; out[r * 3 + 2] = v[2];
 }
 
-__global__ void __launch_bounds__(256) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs,
-                                                        const float* __restrict__ sa, int64_t R, float mipbias,
-                                                        const float* __restrict__ d_out, float* __restrict__ d_sat,
-                                                        float* __restrict__ d_pole /*[2][3]*/,
-                                                        float* __restrict__ d_dirs, float* __restrict__ d_mipbias) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs,
+                                                       const float* __restrict__ sa, int64_t R, float mipbias,
+                                                       const float* __restrict__ d_out, float* __restrict__ d_sat4,
+                                                       float* __restrict__ d_pole /*[2][3]*/,
+                                                       float* __restrict__ d_dirs, float* __restrict__ d_mipbias) {
+    __shared__ float4 s_list[64 * (MAXC + 1)];     // +1: odd record pitch against LDS bank conflicts in phase 2
+    __shared__ float4 s_g[64];
+    __shared__ int s_n[64];
+    const int lane = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
     float dm = 0.f;
+    int n_corner = 0;
+    float gk[3] = {0.f, 0.f, 0.f};
     if (r < R) {
         const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
         const float go[3] = {d_out[r * 3], d_out[r * 3 + 1], d_out[r * 3 + 2]};
@@ -255,12 +284,14 @@ __global__ void __launch_bounds__(256) k_env_lookup_bwd(EnvTab tab, const float*
             atomicAdd(q, go[0]); atomicAdd(q + 1, go[1]); atomicAdd(q + 2, go[2]);
             if (d_dirs) { d_dirs[r * 3] = 0.f; d_dirs[r * 3 + 1] = 0.f; d_dirs[r * 3 + 2] = 0.f; }
         } else {
-            if (d_sat) {
-                ScatterAcc sacc;
-                sacc.dsat = d_sat; sacc.H = tab.H; sacc.W = tab.W;
+            if (d_sat4) {
+                ListAcc lacc;
+                lacc.list = s_list + lane * (MAXC + 1);
+                lacc.dsat4 = d_sat4; lacc.H = tab.H; lacc.W = tab.W; lacc.n = 0;
                 const float k = 1000.f / g.size;
-                sacc.g[0] = go[0] * k; sacc.g[1] = go[1] * k; sacc.g[2] = go[2] * k;
-                box_wrap(g.rect, sacc);
+                lacc.g[0] = gk[0] = go[0] * k; lacc.g[1] = gk[1] = go[1] * k; lacc.g[2] = gk[2] = go[2] * k;
+                box_wrap(g.rect, lacc);
+                n_corner = lacc.n;
             }
             if (d_dirs || d_mipbias) {
                 typedef Dual<4> D;
@@ -278,6 +309,31 @@ __global__ void __launch_bounds__(256) k_env_lookup_bwd(EnvTab tab, const float*
                     gsum[i] = 1000.f * (go[0] * acc.total[0].d[i] + go[1] * acc.total[1].d[i] + go[2] * acc.total[2].d[i]);
                 if (d_dirs) { d_dirs[r * 3] = gsum[0]; d_dirs[r * 3 + 1] = gsum[1]; d_dirs[r * 3 + 2] = gsum[2]; }
                 dm = gsum[3];
+            }
+        }
+    }
+    if (d_sat4) {   // phase 2: 8 lanes per corner
+        s_n[lane] = n_corner;
+        s_g[lane] = make_float4(gk[0], gk[1], gk[2], 0.f);
+        __syncthreads();
+        const int grp = lane >> 3, t = lane & 7, dx = t >> 2, ch = t & 3;
+        const int H = tab.H, W = tab.W;
+        for (int q = 0; q < 8; ++q) {
+            const int src = grp * 8 + q;
+            const int n = s_n[src];
+            const float gv = reinterpret_cast<const float*>(&s_g[src])[ch];
+            const float4* rec = s_list + src * (MAXC + 1);
+            for (int c = 0; c < n; ++c) {
+                const float4 rc = rec[c];
+                const int pk = __float_as_int(rc.x);
+                const int x = (pk & 0xffff) - 1 + dx, y0 = (pk >> 16) - 1;
+                const float v = gv * rc.w * (dx ? rc.y : 1.f - rc.y);
+                if (x >= 0 && x < W && v != 0.f) {
+                    float* p = d_sat4 + ((int64_t)y0 * W + x) * 4 + ch;
+                    const float v0 = v * (1.f - rc.z), v1 = v * rc.z;
+                    if (y0 >= 0 && y0 < H && v0 != 0.f) atomicAdd(p, v0);
+                    if (y0 + 1 >= 0 && y0 + 1 < H && v1 != 0.f) atomicAdd(p + (int64_t)W * 4, v1);
+                }
             }
         }
     }
@@ -330,17 +386,19 @@ __global__ void __launch_bounds__(256) k_sat_rows(float* __restrict__ sat, int H
 
 // backward of the build: d_act = reverse-cumsum_H(reverse-cumsum_W(dSAT)) / 1000 (+ pole-row means);
 // d_bg = d_act * act * mul where the exp argument is not clipped.
-__global__ void __launch_bounds__(256) k_sat_rows_rev(float* __restrict__ dsat, int H, int W) {
+// dsat4 is the channel-interleaved adjoint table [H][W][4] filled by k_env_lookup_bwd
+__global__ void __launch_bounds__(256) k_sat_rows_rev(float* __restrict__ dsat4, int H, int W) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 3 * H) return;
     const int lane = lane_id();
-    float* p = dsat + (int64_t)row * W;
+    const int c = row / H, y = row % H;
+    float* p = dsat4 + (int64_t)y * W * 4 + c;
     double carry = 0.0;
     for (int x0 = 0; x0 < W; x0 += 64) {
         const int x = W - 1 - (x0 + lane);
-        const double v = x >= 0 ? (double)p[x] : 0.0;
+        const double v = x >= 0 ? (double)p[(int64_t)x * 4] : 0.0;
         const double incl = wave_incl_scan(v);
-        if (x >= 0) p[x] = (float)(carry + incl);
+        if (x >= 0) p[(int64_t)x * 4] = (float)(carry + incl);
         carry += __shfl(incl, 63, 64);
     }
 }
@@ -356,7 +414,7 @@ __global__ void __launch_bounds__(256) k_sat_cols_rev(const float* __restrict__ 
     for (int y0 = 0; y0 < H; y0 += 64) {
         const int y = H - 1 - (y0 + lane);
         const int64_t i = y >= 0 ? ((int64_t)c * H + y) * W + x : 0;
-        const double v = y >= 0 ? (double)dsat[i] : 0.0;
+        const double v = y >= 0 ? (double)dsat[((int64_t)y * W + x) * 4 + c] : 0.0;
         const double incl = wave_incl_scan(v);
         if (y >= 0) {
             float da = (float)(carry + incl) / 1000.f;
@@ -412,7 +470,7 @@ extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const 
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
     EnvTab tab{sat, H, W};
-    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs, sa,
+    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, tab, dirs, sa,
                        R, mipbias, d_out, d_sat, d_pole, d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
     return NMF_OK;

@@ -217,7 +217,8 @@ class EnvLookup(torch.autograd.Function):
         dirs, sa, sat = ctx.saved_tensors
         want_tab = holder is not None and ctx.needs_input_grad[5]
         if want_tab and holder.bufs is None:
-            holder.bufs = (torch.zeros_like(sat), torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
+            holder.bufs = (torch.zeros(sat.shape[-2:] + (4,), dtype=torch.float32, device=sat.device),   # [H][W][4]
+                           torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
         d_sat, d_pole = holder.bufs if want_tab else (None, torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
         d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
                                            want_dirs=ctx.needs_input_grad[1], want_mipbias=ctx.needs_input_grad[3])

@@ -341,7 +341,7 @@ def test_env_lookup_golden_and_gradients():
     c = g["c"]
     gb_o, gm_o, gd_o = torch.autograd.grad((O.env_lookup(sd, d_or, sa) * c).sum(),
                                            [sd["bg_module.bg_mat"], sd["bg_module.mipbias"], d_or])
-    d_sat = torch.zeros_like(sat)
+    d_sat = torch.zeros(sat.shape[-2:] + (4,), device=sat.device)        # channel-interleaved adjoint table
     d_pole = torch.zeros(2, 3, device=DEV)
     d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs.to(DEV).contiguous(), sa.to(DEV).contiguous(), 1.0, c.to(DEV), d_sat, d_pole)
     d_bg = hip.sat_build_bwd(d_sat, bg.to(DEV), act, d_pole)
