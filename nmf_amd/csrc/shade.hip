@@ -279,6 +279,48 @@ __global__ void __launch_bounds__(256) k_ray_compose_fwd(
     rgb_map[r * 3 + 2] = (tonemap ? srgb(c2, noclip) : c2) + t * b[2];
 }
 
+// wave-per-ray variant for small batches of long segments (primary rays): lanes stride the ray's samples, wave reduction
+__global__ void __launch_bounds__(256) k_ray_compose_fwd_wave(
+    const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
+    const float* __restrict__ normals, const float* __restrict__ rays, const int64_t* __restrict__ offsets, int64_t B,
+    const float* __restrict__ bg, int bg_per_ray, int tonemap, int noclip, float* __restrict__ rgb_map,
+    float* __restrict__ acc_out, float* __restrict__ rgb_lin, float* __restrict__ ori_out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = offsets[r], e = offsets[r + 1];
+    const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // acc, c0, c1, c2, ori
+    for (int64_t k = s + lane; k < e; k += 64) {
+        const float w = weight[k];
+        v[0] += w;
+        if (inv && refl_rows) {
+            const int64_t row = inv[k];
+            if (row >= 0) {
+                v[1] += w * refl_rows[row * 3];
+                v[2] += w * refl_rows[row * 3 + 1];
+                v[3] += w * refl_rows[row * 3 + 2];
+            }
+        }
+        if (ori_out) {
+            const float ndv = fminf(-(dx * normals[k * 3] + dy * normals[k * 3 + 1] + dz * normals[k * 3 + 2]), 0.f);
+            v[4] += w * (ndv * ndv);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        for (int d = 32; d > 0; d >>= 1) v[q] += __shfl_down(v[q], d, 64);
+    if (lane != 0) return;
+    rgb_lin[r * 3] = v[1]; rgb_lin[r * 3 + 1] = v[2]; rgb_lin[r * 3 + 2] = v[3];
+    acc_out[r] = v[0];
+    if (ori_out) ori_out[r] = v[4];
+    const float* b = bg + (bg_per_ray ? r * 3 : 0);
+    const float t = 1.f - v[0];
+    rgb_map[r * 3] = (tonemap ? srgb(v[1], noclip) : v[1]) + t * b[0];
+    rgb_map[r * 3 + 1] = (tonemap ? srgb(v[2], noclip) : v[2]) + t * b[1];
+    rgb_map[r * 3 + 2] = (tonemap ? srgb(v[3], noclip) : v[3]) + t * b[2];
+}
+
 // one thread per sample
 __global__ void __launch_bounds__(256) k_ray_compose_bwd(
     const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
@@ -400,9 +442,14 @@ extern "C" int nmf_ray_compose_fwd(const float* weight, const float* refl_rows, 
     // weight may be NULL when no ray has a sample (every segment empty)
     NMF_REQUIRE(rays && offsets && bg && rgb_map && acc && rgb_lin, NMF_EINVAL, "nmf_ray_compose_fwd: null");
     NMF_REQUIRE(!ori || normals, NMF_EINVAL, "nmf_ray_compose_fwd: ori needs normals");
-    hipLaunchKernelGGL(k_ray_compose_fwd, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip, rgb_map,
-                       acc, rgb_lin, ori);
+    if (B <= 16384)      // few rays with long segments (primary rays): one wave per ray
+        hipLaunchKernelGGL(k_ray_compose_fwd_wave, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, weight,
+                           refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
+                           rgb_map, acc, rgb_lin, ori);
+    else
+        hipLaunchKernelGGL(k_ray_compose_fwd, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                           refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
+                           rgb_map, acc, rgb_lin, ori);
     NMF_CHECK_LAUNCH("nmf_ray_compose_fwd");
     return NMF_OK;
 }

@@ -260,21 +260,28 @@ def test_composite_golden_and_backward():
     assert_close(ds.cpu(), gs[am], rtol=1e-4, atol=1e-6 * float(gs.abs().max()), what="d_sigma")
 
 
-def test_composite_empty_and_long_segments():
+@pytest.mark.parametrize("b,N,p", [(300, 500, 0.4), (20000, 24, 0.3)])
+def test_composite_empty_and_long_segments(b, N, p):
+    """b = 300: wave-per-ray kernels (few rays, long segments); b = 20000: lane-per-ray kernels (many short rays)."""
     hip = _hip()
     gen = torch.Generator().manual_seed(5)
-    b, N = 300, 500
-    mask = torch.rand(b, N, generator=gen) < 0.4
+    mask = torch.rand(b, N, generator=gen) < p
     mask[7] = False
     mask[8] = True
-    sigma = (torch.rand(b, N, generator=gen) * 3) * mask
+    sigma = ((torch.rand(b, N, generator=gen) * 3) * mask).requires_grad_(True)
     dists = torch.rand(b, N, generator=gen) * 0.01
     wo = O.raw2alpha(sigma, dists * 25)
     off = _segments(mask).to(DEV)
-    w, acc = hip.composite_fwd(sigma[mask].to(DEV).contiguous(), dists[mask].to(DEV).contiguous(), off, b, 25.0)
+    sig_c, dist_c = sigma.detach()[mask].to(DEV).contiguous(), dists[mask].to(DEV).contiguous()
+    w, acc = hip.composite_fwd(sig_c, dist_c, off, b, 25.0)
     # alpha = 1 - exp(-x): one ulp of expf (GPU vs CPU libm) is 6e-8 absolute on alpha
-    assert_close(w.cpu(), wo[mask], rtol=5e-6, atol=2e-7, what="weights")
+    assert_close(w.cpu(), wo.detach()[mask], rtol=5e-6, atol=2e-7, what="weights")
     assert float(acc[7]) == 0.0
+    assert_close(acc.cpu(), wo.detach().sum(1), rtol=1e-5, atol=1e-6, what="acc")
+    dw = torch.randn(wo.shape, generator=gen)
+    (gs,) = torch.autograd.grad((wo * dw).sum(), sigma)
+    ds = hip.composite_bwd(sig_c, dist_c, w, off, b, 25.0, dw[mask].to(DEV).contiguous())
+    assert_close(ds.cpu(), gs[mask], rtol=2e-4, atol=2e-6 * float(gs.abs().max()), what="d_sigma")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -676,7 +683,8 @@ def test_bounce_prep_vs_torch(M, detach_n):
         assert_close(a_.cpu(), b_, rtol=1e-5, atol=1e-6, what="bounce prep d" + nme)
 
 
-@pytest.mark.parametrize("B,per_ray_bg,tonemap", [(1, False, True), (700, False, True), (700, True, False), (5, True, True)])
+@pytest.mark.parametrize("B,per_ray_bg,tonemap", [(1, False, True), (700, False, True), (700, True, False), (5, True, True),
+                                                  (17000, True, True)])
 def test_ray_compose_vs_torch(B, per_ray_bg, tonemap):
     """nmf_ray_compose_fwd/bwd against modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py in torch."""
     from nmf_amd.functional import RayCompose
