@@ -27,6 +27,10 @@ BG_RES = 512
 G_S = 4800            # algorithmic bytes per kept sample, forward: 18 taps x (16+2*16+24... ) fp32
 BWD_BYTES = 3 * G_S   # backward = recompute read + read-modify-write of the gradients (fwd+bwd = 4 G_s)
 HBM_PEAK_GBS = 8000.0
+# the same kernel seen from the matrix pipe: per 4 samples 3 x (20 + 18) v_mfma_f32_16x16x4_f32 of 2048 FLOP each
+# (dense-equivalent, ~95 % of the products are structural zeros of the scatter matrix); fp32 MFMA peak 157.3 TFLOP/s
+BWD_MFMA_FLOP = 3 * (20 + 18) * 2048 / 4
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def build(device):
@@ -193,7 +197,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd (k_vm_bwd_brick + binning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": k_launches,
-                         "avg_launch_ms": k_ms / max(k_launches, 1), "bytes_per_sample": BWD_BYTES},
+                         "avg_launch_ms": k_ms / max(k_launches, 1), "bytes_per_sample": BWD_BYTES,
+                         "note": "algorithmic bytes assume every tap is read from HBM (SURVEY 8d); the tables are "
+                                 "L2/MALL-resident and tiles accumulate in registers, so frac can exceed 1 -- compare "
+                                 "`traffic` (PMC) and `mfma_frac` (dense-equivalent fp32 MFMA rate / 157.3 TFLOP/s)",
+                         "mfma_frac": (BWD_MFMA_FLOP * k_samples / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if k_ms > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
