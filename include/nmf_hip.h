@@ -292,6 +292,17 @@ int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, const int32
                         const float* d_acc, const float* d_ori, float* d_weight, float* d_refl, float* d_normals,
                         void* stream);
 
+/* Retrace selection (models/microfacet.py:475-537, csrc/retrace.hip).
+ * score[r] = max_c(brdf[r][c]) * [V.N > 0 of the ray's row] * exp(lpdf[r]) * w_rows[row] / (cnt_rows[row] + 1e-8). */
+int nmf_retrace_scores(const float* brdf /*[R][3]*/, const float* V_rows, const float* N_rows /*[Mb][3]*/,
+                       const float* lpdf /*[R]*/, const float* w_rows /*[Mb]*/, const int32_t* cnt_rows,
+                       const int32_t* row_of_ray, int64_t R, float* score, void* stream);
+/* order = argsort(keys) ascending (= torch.argsort of microfacet.py:522; ties in unspecified order), radix sort of
+ * (key, index) pairs on the caller's workspace. */
+int nmf_argsort_f32(const float* keys, int64_t n, int32_t* order, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+int64_t nmf_argsort_workspace_bytes(int64_t n);
+
 /* ------------------------------------------------------------------------------------------
  * Loss terms (csrc/loss.hip).  `out` scalars are ACCUMULATED into (caller zeroes).
  * ---------------------------------------------------------------------------------------- */

@@ -62,6 +62,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -71,6 +72,7 @@ _lib.nmf_version.restype = C.c_int
 _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
 _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 _lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
+_lib.nmf_argsort_workspace_bytes.restype = C.c_int64
 
 
 def version():
@@ -640,3 +642,27 @@ def sqerr_bwd(pred, gt, d_out):
         _check(_lib.nmf_sqerr_bwd(_p(pred, torch.float32), _p(gt, torch.float32), C.c_int64(pred.numel()),
                                   _p(d_out, torch.float32), _p(d_pred), _stream()), "nmf_sqerr_bwd")
     return d_pred
+
+
+# ---- retrace selection ------------------------------------------------------------------------------
+def retrace_scores(brdf, V_rows, N_rows, lpdf, w_rows, cnt_rows, row_of_ray):
+    R = row_of_ray.shape[0]
+    score = torch.empty(R, dtype=torch.float32, device=brdf.device)
+    if R:
+        _check(_lib.nmf_retrace_scores(_p(brdf, torch.float32), _p(V_rows, torch.float32), _p(N_rows, torch.float32),
+                                       _p(lpdf, torch.float32), _p(w_rows, torch.float32), _p(cnt_rows, torch.int32),
+                                       _p(row_of_ray, torch.int32), C.c_int64(R), _p(score), _stream()),
+               "nmf_retrace_scores")
+    return score
+
+
+def argsort_f32(keys):
+    """ascending argsort of a 1-D fp32 device tensor -> int32 indices"""
+    n = keys.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=keys.device)
+    if n:
+        nbytes = _lib.nmf_argsort_workspace_bytes(C.c_int64(n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=keys.device)
+        _check(_lib.nmf_argsort_f32(_p(keys, torch.float32), C.c_int64(n), _p(order), _p(ws), C.c_int64(nbytes),
+                                    _stream()), "nmf_argsort_f32")
+    return order

@@ -160,14 +160,12 @@ class Microfacet(torch.nn.Module):
                 incoming = render_reflection(bounce_rays, mipval, True)
             else:
                 with torch.no_grad():
-                    rows = row_of_ray.long()
-                    eV, eN = bV[rows], bN[rows]
-                    per_sample = w_det[bidx.long()] / (cnt32.float() + 1e-8)
-                    per_ray = brdf_weight.max(dim=-1).values * ((eV * eN).sum(dim=-1) > 0) * lpdf.exp()
-                    cc = per_ray * per_sample[rows]
+                    w_rows = torch.index_select(w_det, 0, bidx.long())
+                    cc = hip.retrace_scores(brdf_weight.detach().contiguous(), bV, bN.detach().contiguous(),
+                                            lpdf.contiguous(), w_rows, cnt32, row_of_ray)           # :480-500
                     cc = cc / cc.sum() * num_retrace
                     cc = cc + noise.uniform((R,))
-                    order = cc.argsort()
+                    order = hip.argsort_f32(cc.contiguous()).long()                                  # :522
                     if pinned:
                         order = self.forced[f"retrace_order{recur}"].to(dev)
                     if self.trace is not None:

@@ -757,3 +757,30 @@ def test_loss_kernels_vs_torch():
     (g_h,) = torch.autograd.grad(out * 0.5, pd)
     (g_r,) = torch.autograd.grad(ref * 0.5, pr)
     assert_close(g_h.cpu(), g_r, rtol=1e-6, atol=1e-7, what="sq err grad")
+
+
+@pytest.mark.parametrize("R", [1, 1000, 250001])
+def test_retrace_scores_and_argsort(R):
+    """nmf_retrace_scores / nmf_argsort_f32 against the torch expressions of models/microfacet.py:480-537."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(R)
+    Mb = max(R // 9, 1)
+    counts = torch.randint(1, 20, (Mb,), generator=gen)
+    rows = torch.repeat_interleave(torch.arange(Mb), counts)[:R]
+    if rows.shape[0] < R:
+        rows = torch.cat([rows, torch.full((R - rows.shape[0],), Mb - 1)])
+    V, N = torch.randn(Mb, 3, generator=gen), torch.randn(Mb, 3, generator=gen)
+    brdf = torch.rand(R, 3, generator=gen)
+    lpdf = torch.randn(R, generator=gen)
+    w = torch.rand(Mb, generator=gen)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    sc = hip.retrace_scores(d(brdf), d(V), d(N), d(lpdf), d(w), d(counts.int()), d(rows.int()))
+    ref = brdf.max(-1).values * ((V[rows] * N[rows]).sum(-1) > 0) * lpdf.exp() * (w / (counts.float() + 1e-8))[rows]
+    assert_close(sc.cpu(), ref, rtol=1e-5, atol=1e-9, what="retrace scores")
+    keys = torch.rand(R, generator=gen) * 3 - 1
+    keys[0] = -0.0
+    order = hip.argsort_f32(d(keys)).cpu().long()
+    assert torch.equal(torch.sort(order).values, torch.arange(R))          # a permutation
+    ks = keys[order]
+    assert bool((ks[1:] >= ks[:-1]).all())                                  # ascending
+    assert torch.equal(ks, torch.sort(keys).values)
