@@ -64,8 +64,13 @@ int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* bits, void* 
 /* Pass 1: per-ray validity bitmask ([B][W] uint64, W = ceil(N/64), bit k = step k kept) and
  * per-ray kept count.  jitter: [B][N] uniforms in [0,1) or NULL (Philox). */
 int nmf_march_count(const nmf_march_params* p, const float* rays /*[B][6]*/, int64_t B,
-                    const float* jitter, const uint32_t* alpha_bits, uint64_t* valid_bits,
-                    int32_t* counts, void* stream);
+                    const float* jitter, const uint32_t* alpha_bits, const uint32_t* alpha_coarse,
+                    uint64_t* valid_bits, int32_t* counts, void* stream);
+/* Optional accelerator of the occupancy test: one bit per 8^3-voxel cell = OR of the 9^3 fine bits any point of the
+ * cell can touch (nmf_alpha_coarse_words(grid) uint32 words).  nmf_march_count stages it in LDS and skips the 8-corner
+ * test where it is clear; results are unchanged.  alpha_coarse may be NULL. */
+int nmf_alpha_coarse(const uint32_t* alpha_bits, const int32_t grid[3], uint32_t* coarse, void* stream);
+int64_t nmf_alpha_coarse_words(const int32_t grid[3]);
 
 /* Pass 2: exclusive scan of counts + the sample budget of alphagrid.py:353-364:
  * if max_samples > 0 and sum(counts) > max_samples then whole_valid[i] = cumsum(counts)[i] < max_samples

@@ -53,32 +53,55 @@ __device__ __forceinline__ float step_len(const nmf_march_params& p, const float
 
 // occupancy test of alphagrid.py:23-45 + ":343 alphas > 0": trilinear sample of a 0/1 volume with
 // zero padding is positive iff an in-range corner with a set bit has a positive weight product.
-__device__ __forceinline__ bool alpha_hit(const nmf_march_params& p, const uint32_t* bits, float x, float y, float z) {
+constexpr int CB = 8;     // coarse occupancy cell = 8^3 fine voxels (+1 halo: the 8-corner footprint of any point inside)
+
+__device__ __forceinline__ bool alpha_hit(const nmf_march_params& p, const uint32_t* bits, const uint32_t* coarse,
+                                          float x, float y, float z) {
     const int gx = p.grid[0], gy = p.grid[1], gz = p.grid[2];
     float cx = fsub(fmul(fsub(x, p.aabb_min[0]), p.alpha_inv[0]), 1.f);
     float cy = fsub(fmul(fsub(y, p.aabb_min[1]), p.alpha_inv[1]), 1.f);
     float cz = fsub(fmul(fsub(z, p.aabb_min[2]), p.alpha_inv[2]), 1.f);
     // grid_sampler_unnormalize, align_corners=True: ((c + 1) / 2) * (size - 1)
-    float ix = fmul(fdiv(fadd(cx, 1.f), 2.f), (float)(gx - 1));
-    float iy = fmul(fdiv(fadd(cy, 1.f), 2.f), (float)(gy - 1));
-    float iz = fmul(fdiv(fadd(cz, 1.f), 2.f), (float)(gz - 1));
+    // (c + 1) / 2 == (c + 1) * 0.5 exactly (power of two)
+    float ix = fmul(fmul(fadd(cx, 1.f), 0.5f), (float)(gx - 1));
+    float iy = fmul(fmul(fadd(cy, 1.f), 0.5f), (float)(gy - 1));
+    float iz = fmul(fmul(fadd(cz, 1.f), 0.5f), (float)(gz - 1));
     float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
     int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
     float wx[2] = {fsub(fadd(fx0, 1.f), ix), fsub(ix, fx0)};
     float wy[2] = {fsub(fadd(fy0, 1.f), iy), fsub(iy, fy0)};
     float wz[2] = {fsub(fadd(fz0, 1.f), iz), fsub(iz, fz0)};
-    bool hit = false;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        int bx = c & 1, by = (c >> 1) & 1, bz = c >> 2;
-        int X = x0 + bx, Y = y0 + by, Z = z0 + bz;
-        if (X < 0 || Y < 0 || Z < 0 || X >= gx || Y >= gy || Z >= gz) continue;
-        int64_t idx = ((int64_t)Z * gy + Y) * gx + X;
-        if (!((bits[idx >> 5] >> (idx & 31)) & 1u)) continue;
-        float w = fmul(fmul(wx[bx], wy[by]), wz[bz]);
-        hit |= (w > 0.f);
+    if (coarse) {   // LDS-resident coarse mask: clear = no set bit among the 8 corners of ANY point of the cell
+        const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB;
+        const int cx0 = min(max(x0, 0), gx - 1) / CB, cy0 = min(max(y0, 0), gy - 1) / CB, cz0 = min(max(z0, 0), gz - 1) / CB;
+        const int ci = (cz0 * cgy + cy0) * cgx + cx0;
+        if (!((coarse[ci >> 5] >> (ci & 31)) & 1u)) return false;
     }
-    return hit;
+    // Branch-free: the two x-neighbours of a (y, z) row are adjacent bits, fetched as one 64-bit window (two words, all
+    // eight loads independent and in flight together); a corner counts when it is inside the volume, its bit is set
+    // and its weight product is positive.
+    const int n_words = (int)(((int64_t)gx * gy * gz + 31) >> 5);     // volumes up to 2^31 voxels (checked on the host)
+    const bool okx0 = x0 >= 0 && x0 < gx, okx1 = x0 + 1 >= 0 && x0 + 1 < gx;
+    unsigned any = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int by = c & 1, bz = c >> 1;
+        const int Y = y0 + by, Z = z0 + bz;
+        const bool okyz = Y >= 0 && Z >= 0 && Y < gy && Z < gz;
+        const int Yc = min(max(Y, 0), gy - 1), Zc = min(max(Z, 0), gz - 1);
+        const int idx = (Zc * gy + Yc) * gx + min(max(x0, 0), gx - 1);                  // bit of (x0 clamped, Y, Z)
+        const int wi = idx >> 5;
+        const uint64_t lo = bits[wi], hi = bits[min(wi + 1, n_words - 1)];
+        const unsigned two = (unsigned)(((lo | (hi << 32)) >> (idx & 31)) & 3u);         // bit0: x0, bit1: x0 + 1
+        const float wyz = fmul(wy[by], wz[bz]);
+        const bool h0 = okx0 && (two & 1u) && fmul(fmul(wx[0], wy[by]), wz[bz]) > 0.f;
+        // when x0 < 0 the clamped window starts at x = 0 = x0 + 1: its bit 0 is the x0+1 corner
+        const unsigned b1 = x0 < 0 ? (two & 1u) : ((two >> 1) & 1u);
+        const bool h1 = okx1 && b1 && fmul(fmul(wx[1], wy[by]), wz[bz]) > 0.f;
+        (void)wyz;
+        any |= (okyz && (h0 || h1)) ? 1u : 0u;
+    }
+    return any != 0;
 }
 
 // One j-iteration of the march for this lane: returns z (distance along the ray) of step k and
@@ -89,8 +112,8 @@ struct StepOut {
 };
 
 __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const RayCtx& c, const float* jitter,
-                                             const Philox& rng, const uint32_t* bits, int64_t r, int k,
-                                             double& carry, double* cum_out) {
+                                             const Philox& rng, const uint32_t* bits, const uint32_t* coarse, int64_t r,
+                                             int k, double& carry, double* cum_out) {
     const bool in_range = k < p.n_steps;
     float step;
     double cum = 0.0;
@@ -112,35 +135,67 @@ __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const Ra
     bool outside = (p.aabb_min[0] > o.px) | (o.px > p.aabb_max[0]) | (p.aabb_min[1] > o.py) |
                    (o.py > p.aabb_max[1]) | (p.aabb_min[2] > o.pz) | (o.pz > p.aabb_max[2]);   // :195
     o.keep = in_range && !outside;
-    if (o.keep && bits) o.keep = alpha_hit(p, bits, o.px, o.py, o.pz);    // :341-346
+    if (o.keep && bits) o.keep = alpha_hit(p, bits, coarse, o.px, o.py, o.pz);    // :341-346
     return o;
 }
 
+// Pass 1: one wave per ray, lane = step within the current group of 64 candidates.  Workgroups are persistent
+// (grid-stride over rays) so the coarse occupancy mask is staged into LDS once per workgroup.
 __global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const float* __restrict__ rays, int64_t B,
                                                      const float* __restrict__ jitter,
                                                      const uint32_t* __restrict__ bits,
+                                                     const uint32_t* __restrict__ coarse, int coarse_words,
                                                      uint64_t* __restrict__ valid, int32_t* __restrict__ counts) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= B) return;
+    extern __shared__ uint32_t s_coarse_buf[];
+    const uint32_t* s_coarse = nullptr;
+    if (coarse && bits) {
+        for (int i = threadIdx.x; i < coarse_words; i += blockDim.x) s_coarse_buf[i] = coarse[i];
+        __syncthreads();
+        s_coarse = s_coarse_buf;
+    }
     const int lane = lane_id();
     const int W = (p.n_steps + 63) >> 6;
-    RayCtx c = load_ray(p, rays, r);
     Philox rng(p.seed);
-    double carry = 0.0;
-    int total = 0;
-    int j = 0;
-    for (; j < W; ++j) {
-        StepOut o = march_one(p, c, jitter, rng, bits, r, j * 64 + lane, carry, nullptr);
-        uint64_t m = __ballot(o.keep);
-        total += __popcll(m);
-        if (lane == 0) valid[r * W + j] = m;
-        // z grows monotonically along the ray: once the last step of this chunk is clearly beyond the AABB exit
-        // every later step fails the in-box test (:195) too.  The 1e-2 margin dwarfs the fp32 error of the positions.
-        const float z_last = __shfl(o.z, 63, 64);
-        if (z_last > c.tfar + 1e-2f) { ++j; break; }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < B; r += (int64_t)gridDim.x * 4) {
+        RayCtx c = load_ray(p, rays, r);
+        double carry = 0.0;
+        int total = 0;
+        int j = 0;
+        for (; j < W; ++j) {
+            StepOut o = march_one(p, c, jitter, rng, bits, s_coarse, r, j * 64 + lane, carry, nullptr);
+            uint64_t m = __ballot(o.keep);
+            total += __popcll(m);
+            if (lane == 0) valid[r * W + j] = m;
+            // z grows monotonically along the ray: once the last step of this chunk is clearly beyond the AABB exit
+            // every later step fails the in-box test (:195) too.  The 1e-2 margin dwarfs the fp32 error of the positions.
+            const float z_last = __shfl(o.z, 63, 64);
+            if (z_last > c.tfar + 1e-2f) { ++j; break; }
+        }
+        for (int jj = j + lane; jj < W; jj += 64) valid[r * W + jj] = 0ull;
+        if (lane == 0) counts[r] = total;
     }
-    for (int jj = j + lane; jj < W; jj += 64) valid[r * W + jj] = 0ull;
-    if (lane == 0) counts[r] = total;
+}
+
+// coarse[c] = OR of the fine bits of the 9^3 voxels [8c, 8c+8]^3 (clamped): the union of the 8-corner footprints of all
+// points whose floor coordinates fall into coarse cell c
+__global__ void __launch_bounds__(256) k_alpha_coarse(const uint32_t* __restrict__ bits, int gx, int gy, int gz,
+                                                      uint32_t* __restrict__ coarse) {
+    const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, cgz = (gz + CB - 1) / CB;
+    const int n = cgx * cgy * cgz;
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = false;
+    if (ci < n) {
+        const int cx = ci % cgx, cy = (ci / cgx) % cgy, cz = ci / (cgx * cgy);
+        for (int z = cz * CB; z <= min(cz * CB + CB, gz - 1) && !on; ++z)
+            for (int y = cy * CB; y <= min(cy * CB + CB, gy - 1) && !on; ++y)
+                for (int x = cx * CB; x <= min(cx * CB + CB, gx - 1); ++x) {
+                    const int64_t idx = ((int64_t)z * gy + y) * gx + x;
+                    if ((bits[idx >> 5] >> (idx & 31)) & 1u) { on = true; break; }
+                }
+    }
+    const uint64_t m = __ballot(on);
+    const int lane = lane_id();
+    if ((lane & 31) == 0 && (ci >> 5) * 32 < n) coarse[ci >> 5] = lane == 0 ? (uint32_t)m : (uint32_t)(m >> 32);
 }
 
 __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const float* __restrict__ rays, int64_t b,
@@ -163,7 +218,7 @@ __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const fl
         const int k = j * 64 + lane;
         double cum;
         // positions are recomputed (cheap) instead of being stored by pass 1
-        StepOut o = march_one(p, c, jitter, rng, nullptr, r, k, carry, &cum);
+        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, &cum);
         const uint64_t m = valid[r * W + j];
         if ((m >> lane) & 1ull) {
             int64_t idx = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -204,7 +259,7 @@ __global__ void __launch_bounds__(256) k_march_dense(nmf_march_params p, const f
     double carry = 0.0;
     for (int j = 0; j < W; ++j) {
         const int k = j * 64 + lane;
-        StepOut o = march_one(p, c, jitter, rng, nullptr, r, k, carry, nullptr);
+        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, nullptr);
         if (k < p.n_steps) {
             if (ray_valid) ray_valid[r * p.n_steps + k] = (uint8_t)((valid[r * W + j] >> lane) & 1ull);
             if (z_vals) z_vals[r * p.n_steps + k] = o.z;
@@ -341,18 +396,37 @@ extern "C" int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* b
 static int check_params(const nmf_march_params* p) {
     NMF_REQUIRE(p, NMF_EINVAL, "march: params null");
     NMF_REQUIRE(p->n_steps > 0 && p->n_steps <= 4096, NMF_ERANGE, "march: n_steps outside (0,4096]");
+    NMF_REQUIRE((int64_t)p->grid[0] * p->grid[1] * p->grid[2] < (1ll << 31), NMF_ERANGE, "march: alpha volume >= 2^31 voxels");
+    return NMF_OK;
+}
+
+extern "C" int64_t nmf_alpha_coarse_words(const int32_t grid[3]) {
+    if (!grid) return 0;
+    const int64_t n = (int64_t)((grid[0] + CB - 1) / CB) * ((grid[1] + CB - 1) / CB) * ((grid[2] + CB - 1) / CB);
+    return (n + 31) / 32;
+}
+
+extern "C" int nmf_alpha_coarse(const uint32_t* bits, const int32_t grid[3], uint32_t* coarse, void* stream) {
+    NMF_REQUIRE(bits && grid && coarse && grid[0] > 0 && grid[1] > 0 && grid[2] > 0, NMF_EINVAL, "nmf_alpha_coarse: null/size");
+    const int64_t words = nmf_alpha_coarse_words(grid);
+    hipLaunchKernelGGL(k_alpha_coarse, dim3((unsigned)cdiv(words * 32, 256)), dim3(256), 0, (hipStream_t)stream, bits,
+                       grid[0], grid[1], grid[2], coarse);
+    NMF_CHECK_LAUNCH("nmf_alpha_coarse");
     return NMF_OK;
 }
 
 extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int64_t B, const float* jitter,
-                               const uint32_t* alpha_bits, uint64_t* valid_bits, int32_t* counts, void* stream) {
+                               const uint32_t* alpha_bits, const uint32_t* alpha_coarse, uint64_t* valid_bits,
+                               int32_t* counts, void* stream) {
     if (int e = check_params(p)) return e;
     NMF_REQUIRE(B >= 0 && (B == 0 || (rays && valid_bits && counts)), NMF_EINVAL, "nmf_march_count: null");
     if (B == 0) return NMF_OK;
-    nmf_march_params q = *p;
-    if (!alpha_bits) q.grid[0] = q.grid[1] = q.grid[2] = 0;
-    hipLaunchKernelGGL(k_march_count, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, q, rays, B, jitter,
-                       (q.grid[0] > 0 ? alpha_bits : nullptr), valid_bits, counts);
+    int64_t words = (alpha_bits && alpha_coarse) ? nmf_alpha_coarse_words(p->grid) : 0;
+    if (words * 4 > 60 * 1024) { alpha_coarse = nullptr; words = 0; }        // mask larger than the LDS budget: skip it
+    int64_t blocks = cdiv(B, 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;                                 // persistent: 16 workgroups per CU
+    hipLaunchKernelGGL(k_march_count, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p, rays,
+                       B, jitter, alpha_bits, alpha_coarse, (int)words, valid_bits, counts);
     NMF_CHECK_LAUNCH("nmf_march_count");
     return NMF_OK;
 }

@@ -62,7 +62,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -73,6 +73,7 @@ _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
 _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 _lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
 _lib.nmf_argsort_workspace_bytes.restype = C.c_int64
+_lib.nmf_alpha_coarse_words.restype = C.c_int64
 
 
 def version():
@@ -166,13 +167,23 @@ def alpha_pack(volume):
     return bits
 
 
-def march_count(p, rays, jitter, alpha_bits):
+def alpha_coarse(bits, grid):
+    """coarse occupancy mask (one bit per 8^3 voxels) for nmf_march_count; grid = (gx, gy, gz) of the alpha volume"""
+    g = (C.c_int32 * 3)(*[int(v) for v in grid])
+    words = _lib.nmf_alpha_coarse_words(g)
+    coarse = torch.zeros(max(words, 1), dtype=torch.int32, device=bits.device)
+    _check(_lib.nmf_alpha_coarse(_p(bits, torch.int32), g, _p(coarse), _stream()), "nmf_alpha_coarse")
+    return coarse
+
+
+def march_count(p, rays, jitter, alpha_bits, alpha_coarse=None):
     B = rays.shape[0]
     W = (p.n_steps + 63) // 64
     valid = torch.empty((B, W), dtype=torch.int64, device=rays.device)
     counts = torch.empty(B, dtype=torch.int32, device=rays.device)
     _check(_lib.nmf_march_count(C.byref(p), _p(rays, torch.float32), C.c_int64(B), _p(jitter), _p(alpha_bits),
-                                _p(valid), _p(counts), _stream()), "nmf_march_count")
+                                _p(alpha_coarse if alpha_bits is not None else None), _p(valid), _p(counts), _stream()),
+           "nmf_march_count")
     return valid, counts
 
 

@@ -44,11 +44,21 @@ class AlphaGridMask(torch.nn.Module):
         self.register_buffer("alpha_volume", alpha_volume.view(1, 1, *alpha_volume.shape[-3:]))
         self._bits = None
 
-    def bits(self):
+    def _packed(self):
         if self._bits is None or self._bits[0] != (self.alpha_volume.data_ptr(), self.alpha_volume._version):
-            self._bits = ((self.alpha_volume.data_ptr(), self.alpha_volume._version),
-                          hip.alpha_pack(self.alpha_volume.reshape(-1).float()))
-        return self._bits[1]
+            bits = hip.alpha_pack(self.alpha_volume.reshape(-1).float())
+            gz, gy, gx = self.alpha_volume.shape[-3:]
+            self._bits = ((self.alpha_volume.data_ptr(), self.alpha_volume._version), bits,
+                          hip.alpha_coarse(bits, (gx, gy, gz)))
+        return self._bits
+
+    def bits(self):
+        """occupancy bit per voxel (nmf_alpha_pack)"""
+        return self._packed()[1]
+
+    def coarse_bits(self):
+        """occupancy bit per 8^3 voxels (nmf_alpha_coarse): lets the marcher skip the 8-corner test in empty space"""
+        return self._packed()[2]
 
 
 class AlphaGridSampler(torch.nn.Module):
@@ -139,7 +149,8 @@ class AlphaGridSampler(torch.nn.Module):
                              [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train,
                              seed, off)
         rays = rays_chunk.contiguous()
-        valid, counts = hip.march_count(p, rays, jitter, self.alphaMask.bits() if use_mask else None)
+        valid, counts = hip.march_count(p, rays, jitter, self.alphaMask.bits() if use_mask else None,
+                                        self.alphaMask.coarse_bits() if use_mask else None)
         budget = self.max_samples if (self.max_samples > 0 and is_train and dynamic_batch_size) else -1
         offsets, wv, totals = hip.march_scan(counts, budget)
         M, b = (int(v) for v in totals.cpu())            # the one host sync of the sampler

@@ -784,3 +784,33 @@ def test_retrace_scores_and_argsort(R):
     ks = keys[order]
     assert bool((ks[1:] >= ks[:-1]).all())                                  # ascending
     assert torch.equal(ks, torch.sort(keys).values)
+
+
+@pytest.mark.parametrize("G,B", [(16, 300), (40, 2000), (67, 3000)])
+def test_march_coarse_mask_is_exact(G, B):
+    """The coarse occupancy mask (nmf_alpha_coarse) only skips work: valid bits and counts equal the plain 8-corner test,
+    and the coarse bits equal the OR of the 9^3 fine voxels of each cell."""
+    hip = _hip()
+    cfg = O.Cfg(grid=G)
+    d = cfg.derived()
+    gen = torch.Generator().manual_seed(G)
+    vol = (torch.rand(G, G, G, generator=gen) < 0.02).float()
+    vol[G // 2:, :, :] = 0                                   # a large empty region
+    rays = torch.cat([torch.randn(B, 3, generator=gen) * 2.5, torch.randn(B, 3, generator=gen)], -1)
+    rays[:, 3:] /= rays[:, 3:].norm(dim=-1, keepdim=True)
+    aabb = d["aabb"]
+    alpha_inv = (1.0 / (aabb[1] - aabb[0]) * 2).numpy()
+    p = hip.march_params(aabb, alpha_inv, float(d["stepsize"]), cfg.near_far[0], cfg.near_far[1], 700.0, d["n_samples"],
+                         (G, G, G), True, seed=3, offset=5)
+    bits = hip.alpha_pack(vol.to(DEV).reshape(-1))
+    coarse = hip.alpha_coarse(bits, (G, G, G))
+    v0, c0 = hip.march_count(p, rays.to(DEV).contiguous(), None, bits, None)
+    v1, c1 = hip.march_count(p, rays.to(DEV).contiguous(), None, bits, coarse)
+    assert torch.equal(v0, v1) and torch.equal(c0, c1) and int(c0.sum()) > 0
+    cg = (G + 7) // 8
+    pad = torch.zeros(cg * 8 + 1, cg * 8 + 1, cg * 8 + 1)
+    pad[:G, :G, :G] = vol
+    ref = torch.nn.functional.max_pool3d(pad[None, None], kernel_size=9, stride=8)[0, 0].reshape(-1) > 0    # [cz][cy][cx]
+    words = coarse.cpu().numpy().view(np.uint32)
+    got = torch.tensor([(int(words[i >> 5]) >> (i & 31)) & 1 for i in range(cg ** 3)], dtype=torch.bool)
+    assert torch.equal(got, ref)
