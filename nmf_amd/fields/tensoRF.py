@@ -149,6 +149,7 @@ class TensorVMSplit(torch.nn.Module):
         self.basis_mat = torch.nn.Linear(self.app_rf.dim(), app_dim, bias=False)
         self.dbasis_mat = torch.nn.Linear(self.density_rf.dim(), 1, bias=False)
         self._cache = None
+        self._plist = None
         self._pass, self._pass_open = None, False
 
     # ---- geometry bookkeeping (fields/tensor_base.py:55-64,219-232) ---------------------------------
@@ -180,21 +181,24 @@ class TensorVMSplit(torch.nn.Module):
 
     # ---- kernel tables ---------------------------------------------------------------------------------
     def _param_list(self):
-        return (list(self.density_rf.app_plane) + list(self.density_rf.app_line) + list(self.app_rf.app_plane)
-                + list(self.app_rf.app_line) + [self.basis_mat.weight])
+        """the 13 tensors of the field (cached: the Parameter objects only change on upsample / load_state_dict)"""
+        if self._plist is None:
+            self._plist = (list(self.density_rf.app_plane) + list(self.density_rf.app_line)
+                           + list(self.app_rf.app_plane) + list(self.app_rf.app_line) + [self.basis_mat.weight])
+        return self._plist
 
     def _tables(self):
         ps = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (int(hip.host(self.grid_size)[0]), float(self.density_shift))
-        if self._cache is None or self._cache[0] != key:
+        key = [p._version for p in ps]
+        if self._cache is None or self._cache[0] != key or self._cache[2] != [p.data_ptr() for p in ps]:
             G = int(hip.host(self.grid_size)[0])
             vp = hip.vm_params(self.aabb, self.invaabbSize, self.density_shift, G)
             dpl, dli = self.density_rf.tables()
             apl, ali = self.app_rf.tables()
             dpk, dlk = hip.vm_pack_density(vp, dpl, dli)
             basis = self.basis_mat.weight.detach().contiguous()
-            key = tuple((p.data_ptr(), p._version) for p in ps) + (G, float(self.density_shift))
-            self._cache = (key, (vp, dpk, dlk, apl, ali, basis))
+            # the pack may re-layout a parameter in place (channel-last): take versions / pointers afterwards
+            self._cache = ([p._version for p in ps], (vp, dpk, dlk, apl, ali, basis), [p.data_ptr() for p in ps])
         return self._cache[1]
 
     def _grads_to_param_layout(self, gp, gl, g_apl, g_ali, g_basis):
@@ -288,6 +292,7 @@ class TensorVMSplit(torch.nn.Module):
         self.density_rf.upsample(res_target)
         self.update_stepSize(res_target)
         self._cache = None
+        self._plist = None
 
     def check_schedule(self, iter, batch_mul):
         # fields/tensor_base.py:234-243
@@ -306,6 +311,7 @@ class TensorVMSplit(torch.nn.Module):
         if k in state_dict:
             self.update_stepSize(state_dict[k])
         self._cache = None
+        self._plist = None
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
