@@ -23,7 +23,7 @@ class FusedAdam(torch.optim.Optimizer):
         n_params = sum(len(g["params"]) for g in self.param_groups)
         if self._slots is None or len(self._slots) < n_params:
             self._slots = (hip.AdamSlot * max(n_params, 1))()
-        slots, n, keep = self._slots, 0, []
+        slots, n, keep, touched = self._slots, 0, [], []
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr, eps, wd = float(group["lr"]), float(group["eps"]), float(group["weight_decay"])
@@ -55,8 +55,12 @@ class FusedAdam(torch.optim.Optimizer):
                 s.bc2_sqrt = math.sqrt(1 - beta2 ** t)
                 s.is_f64 = 1 if p.dtype == torch.float64 else 0
                 n += 1
+                touched.append(p)
         if n:
             hip.adam_step(slots, n)
+            # the kernel writes through raw pointers: tell autograd (and every cache keyed on Tensor._version -- packed
+            # density tables, SAT, stacked head weights, host mirrors of scalars) that the parameters changed
+            torch.autograd.graph.increment_version(touched)
         return None
 
 

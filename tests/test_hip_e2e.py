@@ -280,6 +280,14 @@ def test_short_training_curve_matches_oracle():
         out = tr.step(rays.to(DEV), gt.to(DEV), focal, noise=ReplayNoise(DEV, None), update_controllers=False,
                       fixed_chunk=B)
         lh.append(out["loss"])
+    # the parameters themselves must have moved together (this also catches caches of derived tables -- packed density
+    # planes, SAT, stacked head weights -- that miss an optimizer update: the losses alone are too forgiving)
+    hsd = nerf.state_dict()
+    for k in ("rf.density_rf.app_plane.0", "rf.app_rf.app_plane.1", "rf.density_rf.app_line.2", "bg_module.bg_mat",
+              "model.brdf.mlp.0.weight", "model.diffuse_module.diffuse_mlp.0.weight"):
+        moved = (sd[k].detach() - sd0[k]).norm()
+        diff = (hsd[k].detach().cpu().reshape(sd[k].shape) - sd[k].detach()).norm()
+        assert float(moved) > 0 and float(diff) <= 0.15 * float(moved), (k, float(diff), float(moved))
     lo, lh = np.asarray(lo), np.asarray(lh)
     assert lo[-1] < lo[0] and lh[-1] < lh[0], (lo, lh)                  # both are learning
     assert np.all(np.abs(lh - lo) <= 2e-2 * lo), (lo, lh)              # and stay together

@@ -594,7 +594,10 @@ def test_fused_adam_matches_torch_adam():
             if a.dim() == 4:
                 g = g.to(memory_format=torch.channels_last)
             a.grad, b.grad = g.clone(), g.clone()
+        va = [b._version for b in pb]
         oa.step(); ob.step(); sa.step(); sb.step()
+        for i, (b, v0) in enumerate(zip(pb, va)):          # in-place update must be visible to version-keyed caches
+            assert (b._version > v0) == (b.grad is not None), i
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert a.stride() == b.stride()
         assert_close(b.detach().cpu(), a.detach().cpu(), rtol=2e-6, atol=2e-7, what=f"adam param {i}")
