@@ -69,6 +69,18 @@ class KernelTimer:
 
         hip.vm_query_bwd = wrapped
         functional.hip.vm_query_bwd = wrapped
+        # per-step derived tables must be rebuilt after every optimizer update (packed density planes, SAT): count the
+        # rebuilds inside the timed region so a stale cache (= skipped work) shows up in the report
+        self.rebuilds = {"vm_pack_density": 0, "sat_build": 0}
+        for name in self.rebuilds:
+            fn = getattr(hip, name)
+
+            def counted(*a, _fn=fn, _name=name, **k):
+                if self.enabled:
+                    self.rebuilds[_name] += 1
+                return _fn(*a, **k)
+
+            setattr(hip, name, counted)
 
     def summary(self):
         ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
@@ -177,6 +189,8 @@ def main():
     else:
         dt_max, rays_all = dt, float(rays_done)
 
+    if min(timer.rebuilds.values()) < args.steps:
+        raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
     if rank == 0:
         k_ms, k_samples, k_launches = timer.summary()
         achieved = (BWD_BYTES * k_samples) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -193,6 +207,7 @@ def main():
                                    "4096 rays/GPU/step, fwd+bwd+Adam, all secondary rays re-traced (steady state); "
                                    "stands in for BASELINE configs[1] (lego is not available offline)",
                        "rays_per_gpu": RAYS_PER_GPU, "grid": GRID, "samples_per_step": last["n_samples"],
+                       "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd (k_vm_bwd_brick + binning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

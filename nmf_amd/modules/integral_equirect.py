@@ -32,6 +32,7 @@ class IntegralEquirect(torch.nn.Module):
                                                   dtype=torch.float32))
         self._cache = None
         self._sh_cache = None
+        self._sh_const = None
         self._scalars = None
         self._pass, self._pass_open = None, False   # (GradPass, token) shared by the lookups of a forward/backward pass
 
@@ -55,7 +56,9 @@ class IntegralEquirect(torch.nn.Module):
     def _host_scalars(self):
         key = (self.mipbias._version, self.brightness._version, self.mul._version)
         if self._scalars is None or self._scalars[0] != key:
-            self._scalars = (key, (float(self.mipbias), float(self.brightness), float(self.mul)))
+            # one read-back for the three 0-d parameters
+            vals = torch.stack([self.mipbias.detach(), self.brightness.detach(), self.mul.detach()]).tolist()
+            self._scalars = (key, tuple(float(v) for v in vals))
         return self._scalars[1]
 
     def _tables(self):
@@ -105,19 +108,23 @@ class IntegralEquirect(torch.nn.Module):
         key = (self.bg_mat.data_ptr(), self.bg_mat._version, G, mipval) + self._host_scalars()
         if self._sh_cache is None or self._sh_cache[0] != key:
             dev = self.get_device()
-            theta, phi = torch.meshgrid(torch.linspace(0, np.pi, G // 2, device=dev),
-                                        torch.linspace(0, 2 * np.pi, G, device=dev), indexing="ij")
-            dirs = torch.stack([torch.sin(theta) * torch.cos(phi), torch.sin(theta) * torch.sin(phi),
-                                torch.cos(theta)], dim=-1).reshape(-1, 3)
-            SB = dirs.shape[0]
+            ck = (G, float(mipval), str(dev))
+            if self._sh_const is None or self._sh_const[0] != ck:
+                # everything that does not depend on the map: the direction lattice, its log-solid-angle argument and the
+                # quadrature weights 2 pi^2 sin(theta) Y_k / SB (so that the projection is one weighted sum per update)
+                theta, phi = torch.meshgrid(torch.linspace(0, np.pi, G // 2, device=dev),
+                                            torch.linspace(0, 2 * np.pi, G, device=dev), indexing="ij")
+                dirs = torch.stack([torch.sin(theta) * torch.cos(phi), torch.sin(theta) * torch.sin(phi),
+                                    torch.cos(theta)], dim=-1).reshape(-1, 3).contiguous()
+                SB = dirs.shape[0]
+                wq = (2 * np.pi ** 2 / SB) * sh.eval_sh_bases(9, dirs) * torch.sin(theta.reshape(SB, 1))     # [SB, 9]
+                self._sh_const = (ck, dirs, torch.full((SB,), float(mipval), device=dev), wq.reshape(SB, 9, 1).contiguous())
+            _, dirs, mips, wq = self._sh_const
             act, sat, pole = self._tables()
-            bg = hip.sat_lookup_fwd(sat, dirs.contiguous(), torch.full((SB,), float(mipval), device=dev),
-                                    self._host_scalars()[0], pole)
-            ev = sh.eval_sh_bases(9, dirs)
-            coeffs = 2 * np.pi ** 2 * (bg.reshape(SB, 1, 3) * ev.reshape(SB, -1, 1)
-                                       * torch.sin(theta.reshape(SB, 1, 1))).mean(dim=0)
+            bg = hip.sat_lookup_fwd(sat, dirs, mips, self._host_scalars()[0], pole)
+            coeffs = (wq * bg.reshape(-1, 1, 3)).sum(dim=0)
             conv = self.sh_A.reshape(-1, 1)[: coeffs.shape[0]] * coeffs
-            self._sh_cache = (key, (coeffs, conv / np.pi))
+            self._sh_cache = (key, (coeffs, (conv / np.pi).contiguous()))
         return self._sh_cache[1]
 
     def _load_from_state_dict(self, *a, **k):
