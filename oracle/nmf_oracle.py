@@ -195,6 +195,41 @@ MAT_MODE = ((0, 1), (0, 2), (1, 2))   # fields/tensoRF.py:40
 VEC_MODE = (2, 1, 0)                  # fields/tensoRF.py:41
 
 
+# ----------------------------------------------------------------------------------------------
+# a25: grid schedule, step size and factor upsampling
+# ----------------------------------------------------------------------------------------------
+def n_to_reso(n_voxels, aabb):
+    """utils.py:55-58"""
+    size = aabb[1] - aabb[0]
+    voxel = (size.prod() / n_voxels).pow(1 / 3)
+    return (size / voxel).long().tolist()
+
+
+def voxel_schedule(n_init, n_final, n_upsamples):
+    """fields/tensor_base.py:194-203: voxel counts after each scheduled upsample"""
+    return (torch.round(torch.linspace(n_init ** (1 / 3), n_final ** (1 / 3), n_upsamples + 1) ** 3).long()).tolist()[1:]
+
+
+def step_size(aabb, grid_size, step_ratio=0.5):
+    """TensorVoxelBase.update_stepSize (fields/tensor_base.py:219-232) -> units [3], stepsize (0-d fp32), nSamples"""
+    gs = torch.as_tensor(grid_size, dtype=torch.long)
+    size = aabb[1] - aabb[0]
+    units = size / (gs - 1)
+    stepsize = torch.min(units) * step_ratio
+    diag = torch.sqrt(torch.sum(torch.square(size)))
+    return units, stepsize, int((diag / stepsize).item()) + 1
+
+
+def upsample_factors(planes, lines, res_target):
+    """TensoRF.upsample (fields/tensoRF.py:207-227): bilinear, align_corners=True; plane i spans
+    (matMode[i][1], matMode[i][0]) = (H, W), line i runs along vecMode[i]."""
+    mat, vec = [[0, 1], [0, 2], [1, 2]], [2, 1, 0]
+    new_p = [F.interpolate(planes[i], size=(res_target[mat[i][1]], res_target[mat[i][0]]), mode="bilinear",
+                           align_corners=True) for i in range(3)]
+    new_l = [F.interpolate(lines[i], size=(res_target[vec[i]], 1), mode="bilinear", align_corners=True) for i in range(3)]
+    return new_p, new_l
+
+
 def normalize_coord(cfg: Cfg, xyz):
     # fields/tensor_base.py:66-69
     d = cfg.derived()

@@ -337,7 +337,34 @@ def case_e2e_full():
     save("e2e_full_seeded", out)
 
 
-CASES = dict(sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
+def case_upsample():
+    """a25: TensoRF.upsample + update_stepSize + the voxel schedule (fields/tensoRF.py:207-227,
+    fields/tensor_base.py:194-243, utils.py:55-58): factors before / after one scheduled upsample."""
+    nerf, _ = small_reference(grid=16, bg_res=16)
+    random_field_state(nerf, 5)
+    rf = nerf.rf
+    out = dict(N_voxel_list=np.asarray(rf.N_voxel_list), upsamp_list=np.asarray(rf.upsamp_list),
+               grid0=rf.grid_size, stepsize0=rf.stepsize, nSamples0=np.asarray(rf.nSamples), units0=rf.units)
+    for i in range(3):
+        out[f"d_plane{i}_0"], out[f"d_line{i}_0"] = rf.density_rf.app_plane[i], rf.density_rf.app_line[i]
+        out[f"a_plane{i}_0"], out[f"a_line{i}_0"] = rf.app_rf.app_plane[i], rf.app_rf.app_line[i]
+    target = [21, 21, 21]
+    rf.upsample_volume_grid(target)
+    out.update(target=np.asarray(target), grid1=rf.grid_size, stepsize1=rf.stepsize, nSamples1=np.asarray(rf.nSamples),
+               units1=rf.units)
+    for i in range(3):
+        out[f"d_plane{i}_1"], out[f"d_line{i}_1"] = rf.density_rf.app_plane[i], rf.density_rf.app_line[i]
+        out[f"a_plane{i}_1"], out[f"a_line{i}_1"] = rf.app_rf.app_plane[i], rf.app_rf.app_line[i]
+    # the production schedule (128^3 -> 300^3): resolutions the reference derives for each upsample iteration
+    import utils as ref_utils
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    nv = (torch.round(torch.linspace(2097156 ** (1 / 3), 27000000 ** (1 / 3), 6) ** 3).long()).tolist()
+    out["sched_voxels"] = np.asarray(nv)
+    out["sched_reso"] = np.asarray([ref_utils.N_to_reso(n, aabb) for n in nv])
+    save("upsample", out)
+
+
+CASES = dict(upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full)
 
 if __name__ == "__main__":

@@ -9,6 +9,11 @@ from nmf_amd import synthetic
 from oracle import nmf_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+def hip_host(t):
+    from nmf_amd import hip
+    return hip.host(t)
 DEV = "cuda"
 
 
@@ -292,3 +297,49 @@ def test_short_training_curve_matches_oracle():
     assert lo[-1] < lo[0] and lh[-1] < lh[0], (lo, lh)                  # both are learning
     assert np.all(np.abs(lh - lo) <= 2e-2 * lo), (lo, lh)              # and stay together
     assert abs(lh[0] - lo[0]) <= 2e-3 * lo[0], (lo[0], lh[0])          # identical noise on the first step
+
+
+def test_upsample_matches_reference_and_training_continues():
+    """a25 on the device: TensorVMSplit.upsample_volume_grid against the reference fixture, then a scheduled upsample
+    inside Trainer.step (train.py:806-813: optimizer and lr schedule restart, alpha mask rebuilt, batch controller reset)
+    with forward/backward on the new grid size (21 is not a multiple of the 8-texel bricks)."""
+    from nmf_amd.config import build_model, resolved_config
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    g = Golden("upsample")
+    nerf, _ = build_model(grid=16, bg_resolution=16, device=DEV)
+    rf = nerf.rf
+    sd = {}
+    for i in range(3):
+        sd[f"rf.density_rf.app_plane.{i}"], sd[f"rf.density_rf.app_line.{i}"] = g[f"d_plane{i}_0"], g[f"d_line{i}_0"]
+        sd[f"rf.app_rf.app_plane.{i}"], sd[f"rf.app_rf.app_line.{i}"] = g[f"a_plane{i}_0"], g[f"a_line{i}_0"]
+    nerf.load_state_dict(sd, strict=False)
+    assert float(hip_host(rf.stepsize)) == np.float32(g.np("stepsize0")).item() and rf.nSamples == int(g["nSamples0"])
+    rf.upsample_volume_grid(g["target"].tolist())
+    assert float(hip_host(rf.stepsize)) == np.float32(g.np("stepsize1")).item() and rf.nSamples == int(g["nSamples1"])
+    for i in range(3):
+        for pre, mod in (("d", rf.density_rf), ("a", rf.app_rf)):
+            assert_close(mod.app_plane[i].detach().cpu(), g[f"{pre}_plane{i}_1"], rtol=1e-6, atol=1e-7, what="plane")
+            assert_close(mod.app_line[i].detach().cpu(), g[f"{pre}_line{i}_1"], rtol=1e-6, atol=1e-7, what="line")
+    # ---- a scheduled upsample inside the training loop
+    nerf, _ = build_model(grid=16, bg_resolution=16, device=DEV,
+                          overrides={"rf.upsamp_list": [2], "rf.N_voxel_final": 21 ** 3, "sampler.update_list": [2]})
+    nerf.load_state_dict(synthetic.state_dict_s1(grid=16, bg_resolution=16, seed=0), strict=False)
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    tr = Trainer(nerf, resolved_config()["params"])
+    rays, focal = synthetic.camera_rays(256, seed=4)
+    gt = torch.rand(256, 3, generator=torch.Generator().manual_seed(1))
+    noise = DeviceNoise(DEV, 3)
+    grids, lrs, opts = [], [], []
+    for it in range(5):
+        out = tr.step(rays.to(DEV), gt.to(DEV), focal, noise=noise)
+        grids.append(int(nerf.rf.density_rf.app_plane[0].shape[-1]))
+        lrs.append(tr.optimizer.param_groups[1]["lr"])
+        opts.append(id(tr.optimizer))
+        assert np.isfinite(out["loss"]) and out["rays"] > 0
+    assert grids[1] == 16 and grids[2] > 16 and grids[-1] == grids[2], grids        # upsampled at iteration 2
+    assert opts[2] != opts[1] and opts[3] == opts[2]                                   # optimizer rebuilt exactly once
+    assert lrs[2] < lrs[1]                                                             # lr schedule restarted (delay ramp)
+    assert all(torch.isfinite(p).all() for p in nerf.parameters())

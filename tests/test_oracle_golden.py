@@ -292,3 +292,23 @@ def test_full_size_replay_by_seed():
         name = k[len("gradnorm/"):]
         ref = float(g[k])
         assert abs(float(sd[name].grad.norm()) - ref) <= 2e-3 * ref + 1e-12, (name, float(sd[name].grad.norm()), ref)
+
+
+def test_upsample_schedule_and_step_size():
+    """a25: factor upsampling, update_stepSize and the voxel schedule against the reference (tests/golden/upsample.npz)."""
+    g = Golden("upsample")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    units, step, n = O.step_size(aabb, g["grid0"].tolist())
+    assert torch.equal(units, g["units0"]) and step.item() == np.float32(g.np("stepsize0")).item() and n == int(g["nSamples0"])
+    tgt = g["target"].tolist()
+    units, step, n = O.step_size(aabb, tgt)
+    assert torch.equal(units, g["units1"]) and step.item() == np.float32(g.np("stepsize1")).item() and n == int(g["nSamples1"])
+    assert g["grid1"].tolist() == tgt
+    for pre in ("d", "a"):
+        new_p, new_l = O.upsample_factors([g[f"{pre}_plane{i}_0"] for i in range(3)], [g[f"{pre}_line{i}_0"] for i in range(3)], tgt)
+        for i in range(3):
+            assert torch.equal(new_p[i], g[f"{pre}_plane{i}_1"]) and torch.equal(new_l[i], g[f"{pre}_line{i}_1"])
+    assert O.voxel_schedule(2097156, 27000000, 5) == g["sched_voxels"].tolist()[1:]
+    assert [O.n_to_reso(v, aabb) for v in g["sched_voxels"].tolist()] == g["sched_reso"].tolist()
+    # Appendix A of SURVEY.md: 128 -> 162 -> 196 -> 231 -> 265 -> 300
+    assert [r[0] for r in g["sched_reso"].tolist()] == [128, 162, 196, 231, 265, 300]
