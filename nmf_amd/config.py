@@ -51,25 +51,7 @@ MODEL = dict(
 def resolved_config():
     cfg = copy.deepcopy(MODEL)
     cfg["arch"]["rf"] = copy.deepcopy(FIELD)          # train.py:911: cfg.model.arch.rf = cfg.field
-    return cfg
-
-
-def _classes():
-    from .brdf_samplers.ggx import GGXSampler
-    from .fields.tensoRF import TensorVMSplit
-    from .models.microfacet import Microfacet
-    from .modules.brdf import MLPBRDF, ListISH
-    from .modules.integral_equirect import IntegralEquirect
-    from .modules.render_modules import RandHydraMLPDiffuse
-    from .modules.tensor_nerf import TensorNeRF
-    from .modules.tonemap import SRGBTonemap
-    from .samplers.alphagrid import AlphaGridSampler
-    return {"fields.tensoRF.TensorVMSplit": TensorVMSplit, "samplers.alphagrid.AlphaGridSampler": AlphaGridSampler,
-            "models.microfacet.Microfacet": Microfacet, "brdf_samplers.ggx.GGXSampler": GGXSampler,
-            "modules.brdf.MLPBRDF": MLPBRDF, "modules.ish.ListISH": ListISH,
-            "modules.render_modules.RandHydraMLPDiffuse": RandHydraMLPDiffuse,
-            "modules.integral_equirect.IntegralEquirect": IntegralEquirect,
-            "modules.tensor_nerf.TensorNeRF": TensorNeRF, "modules.tonemap.SRGBTonemap": SRGBTonemap}
+    return _mark_partial(cfg)
 
 
 PARTIAL = {"fields.tensoRF.TensorVMSplit", "samplers.alphagrid.AlphaGridSampler", "models.microfacet.Microfacet",
@@ -77,16 +59,20 @@ PARTIAL = {"fields.tensoRF.TensorVMSplit", "samplers.alphagrid.AlphaGridSampler"
            "modules.tensor_nerf.TensorNeRF"}
 
 
-def instantiate(node):
-    """hydra.utils.instantiate for the `_target_` strings this config uses (same import paths as the reference;
-    the nodes the reference marks `_partial_: True` become functools.partial objects)."""
-    if isinstance(node, dict) and "_target_" in node:
-        cls = _classes()[node["_target_"]]
-        kw = {k: instantiate(v) for k, v in node.items() if k not in ("_target_", "_partial_")}
-        return functools.partial(cls, **kw) if node["_target_"] in PARTIAL else cls(**kw)
+def _mark_partial(node):
+    """the nodes the reference's YAML marks `_partial_: True` (constructed later with aabb / in_channels / ...)"""
     if isinstance(node, dict):
-        return {k: instantiate(v) for k, v in node.items()}
+        if node.get("_target_") in PARTIAL:
+            node["_partial_"] = True
+        for v in node.values():
+            _mark_partial(v)
     return node
+
+
+def instantiate(node):
+    """hydra.utils.instantiate for the `_target_` strings this config uses (nmf_amd/yaml_config.py)."""
+    from .yaml_config import instantiate as _inst
+    return _inst(node)
 
 
 def build_model(grid=128, bg_resolution=512, near_far=(2.5, 7.0), aabb_half=1.5, device="cuda", overrides=None):

@@ -52,6 +52,43 @@ class TensorNeRF(torch.nn.Module):
         sd = {k: (v.contiguous() if v.dim() == 4 else v) for k, v in self.state_dict().items()}
         torch.save({"config": config, "state_dict": sd}, path)
 
+    @staticmethod
+    def load(ckpt, config=None, near_far=None, device="cuda", **kwargs):
+        """modules/tensor_nerf.py:136-175: rebuild the scene module from a checkpoint written by save() -- {"config":
+        arch config (the `model.arch` node, `_target_` strings of the reference), "state_dict": ...} -- with the grid size
+        and AABB stored in the state_dict, the calibrated biases taken from the checkpoint's config, then load the weights.
+        Checkpoints written by the reference itself pickle an OmegaConf object and need `omegaconf` to be importable."""
+        from ..yaml_config import instantiate
+        if not isinstance(ckpt, dict):
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        saved = ckpt["config"]
+        if config is not None:
+            config = dict(config)
+            config["model"]["brdf"]["bias"] = saved["model"]["brdf"]["bias"]
+            for k in ("diffuse_bias", "roughness_bias"):
+                config["model"]["diffuse_module"][k] = saved["model"]["diffuse_module"][k]
+        else:
+            config = saved
+        sd = dict(ckpt["state_dict"])
+        aabb = sd["rf.aabb"]
+        near_far = near_far if near_far is not None else [1, 6]
+        grid_size = sd["rf.grid_size"].tolist() if "rf.grid_size" in sd else [300, 300, 300]
+        cfg = {k: v for k, v in config.items() if k != "use_predicted_normals"}
+        cfg["rf"] = dict(cfg["rf"], grid_size=grid_size)
+        nerf = instantiate(cfg)(aabb=aabb, near_far=list(near_far)).to(device)
+        if "sampler.alphaMask.alpha_volume" in sd:            # give the mask module the stored shape before loading
+            from ..samplers.alphagrid import AlphaGridMask
+            nerf.sampler.alphaMask = AlphaGridMask(sd["sampler.alphaMask.aabb"].to(device),
+                                                   sd["sampler.alphaMask.alpha_volume"].to(device))
+        # the reference drops the stored Sobol table and keeps the freshly scrambled one (:151); here the stored table is
+        # kept when it fits, so that a reloaded model reproduces the renders of the saved one
+        own = nerf.model.brdf_sampler.angs
+        if "model.brdf_sampler.angs" not in sd or sd["model.brdf_sampler.angs"].shape != own.shape:
+            sd["model.brdf_sampler.angs"] = own
+        nerf.load_state_dict(sd, **kwargs)
+        nerf.sampler.update(nerf.rf, init=True)               # step size / sample count of the loaded grid
+        return nerf
+
     def check_schedule(self, iter, batch_mul):
         # modules/tensor_nerf.py:177-195 (mask rebuild BEFORE the field upsamples on the same iteration)
         req = self.model.check_schedule(iter, batch_mul)

@@ -343,3 +343,33 @@ def test_upsample_matches_reference_and_training_continues():
     assert opts[2] != opts[1] and opts[3] == opts[2]                                   # optimizer rebuilt exactly once
     assert lrs[2] < lrs[1]                                                             # lr schedule restarted (delay ramp)
     assert all(torch.isfinite(p).all() for p in nerf.parameters())
+
+
+def test_checkpoint_save_load_round_trip(tmp_path):
+    """TensorNeRF.save / TensorNeRF.load (modules/tensor_nerf.py:120-175): same state_dict keys as the reference
+    (SURVEY Appendix C), plain NCHW tensors on disk, identical renders after the round trip."""
+    from nmf_amd.config import build_model
+    from nmf_amd.modules.tensor_nerf import TensorNeRF
+    from nmf_amd.noise import DeviceNoise
+    nerf, cfg = build_model(grid=32, bg_resolution=32, device=DEV)
+    nerf.load_state_dict(synthetic.state_dict_s1(grid=32, bg_resolution=32, seed=0), strict=False)
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias = 0.123, -0.456            # "calibrated" biases
+    cfg["arch"]["model"]["brdf"]["bias"], cfg["arch"]["model"]["diffuse_module"]["diffuse_bias"] = 0.123, -0.456
+    nerf.eval()
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    path = str(tmp_path / "ckpt.th")
+    nerf.save(path, cfg["arch"])
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"config", "state_dict"}
+    for k in ("rf.density_rf.app_plane.0", "rf.app_rf.app_line.2", "rf.basis_mat.weight", "bg_module.bg_mat",
+              "model.brdf.mlp.0.weight", "rf.grid_size", "rf.aabb", "sampler.alphaMask.alpha_volume"):
+        assert k in ck["state_dict"], k
+    assert ck["state_dict"]["rf.density_rf.app_plane.0"].is_contiguous()                    # NCHW on disk
+    other = TensorNeRF.load(path, near_far=[2.5, 7.0], device=DEV)
+    other.eval()
+    rays, focal = synthetic.camera_rays(300, seed=2)
+    a, _ = nerf(rays.to(DEV), focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=DeviceNoise(DEV, 5))
+    b, _ = other(rays.to(DEV), focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=DeviceNoise(DEV, 5))
+    assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["acc_map"], b["acc_map"])
+    assert other.model.brdf.bias == 0.123 and other.model.diffuse_module.diffuse_bias == -0.456
