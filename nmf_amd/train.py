@@ -3,7 +3,12 @@ synthetic "S2 orbit" data set (nerf_synthetic is not available off
 rendered from the S1 scene itself (eval mode), then a freshly initialised model is fitted to them.
 
     python -m nmf_amd.train --iters 200 --views 24 --res 64 [--grid 64] [--eval-every 100]
+    python -m nmf_amd.train --datadir /data/nerf_synthetic/lego --near-far 2.5 7 --iters 30000 --grid 128 --bg 512
     python -m torch.distributed.run --nproc-per-node N -m nmf_amd.train ...        (data parallel, RCCL)
+
+With --datadir the rays and colours come from a Blender / nerf_synthetic scene directory (nmf_amd/dataLoader/blender.py,
+RGBA frames blended onto the white background as train.py:525-530 does); --save writes a checkpoint readable by
+TensorNeRF.load.
 
 Prints one JSON line per evaluation: iteration, train PSNR proxy (train.py:609-613), test PSNR with the reference's
 8-bit formula (renderer.py:399-401), rays/s.
@@ -31,7 +36,7 @@ def render_images(nerf, rays, focal, chunk, noise):
     return torch.cat(out, 0)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--views", type=int, default=24)
@@ -41,7 +46,11 @@ def main():
     ap.add_argument("--bg", type=int, default=128)
     ap.add_argument("--eval-every", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20211200)
-    args = ap.parse_args()
+    ap.add_argument("--datadir", type=str, default=None, help="Blender scene directory (transforms_*.json + frames)")
+    ap.add_argument("--near-far", type=float, nargs=2, default=None)
+    ap.add_argument("--downsample", type=float, default=1.0)
+    ap.add_argument("--save", type=str, default=None, help="write a checkpoint (TensorNeRF.save) at the end")
+    args = ap.parse_args(argv)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,24 +61,38 @@ def main():
     if world > 1:
         dist.init_process_group(backend=os.environ.get("NMF_BACKEND", "nccl"))
 
-    # ---- ground truth from the S1 scene
-    torch.manual_seed(args.seed)
-    teacher, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
-    teacher.load_state_dict(synthetic.state_dict_s1(grid=args.grid, bg_resolution=args.bg, seed=0), strict=False)
-    teacher.eval()
-    teacher.sampler.update(teacher.rf, init=False)
-    teacher.sampler.update(teacher.rf, init=True)
-    rays_tr, focal = synthetic.orbit_rays(args.views, args.res, seed=1)
-    rays_te, _ = synthetic.orbit_rays(args.test_views, args.res, seed=2)
-    rays_tr, rays_te = rays_tr.to(dev), rays_te.to(dev)
-    gt_noise = DeviceNoise(dev, seed=7)
-    rgb_tr = render_images(teacher, rays_tr, focal, 4096, gt_noise)
-    rgb_te = render_images(teacher, rays_te, focal, 4096, gt_noise)
-    del teacher
+    near_far = (2.5, 7.0)
+    if args.datadir:
+        # ---- real data: Blender scene (dataLoader/blender.py), colours blended onto white (train.py:525-530)
+        from .dataLoader import BlenderDataset
+        tr_set = BlenderDataset(args.datadir, split="train", downsample=args.downsample, is_stack=False)
+        te_set = BlenderDataset(args.datadir, split="test", downsample=args.downsample, is_stack=True, N_vis=args.test_views)
+        near_far = tuple(args.near_far) if args.near_far else tuple(tr_set.near_far)
+        rays_tr, rgba = tr_set.all_rays.to(dev), tr_set.all_rgbs.to(dev)
+        rgb_tr = rgba[:, :3] * rgba[:, 3:] + (1 - rgba[:, 3:]) if rgba.shape[1] == 4 else rgba
+        rays_te = te_set.all_rays.reshape(-1, 6).to(dev)
+        rgb_te = te_set.all_rgbs.reshape(-1, 3).to(dev)
+        focal = float(tr_set.fx)
+        args.test_views = te_set.all_rays.shape[0]
+    else:
+        # ---- ground truth from the S1 scene
+        torch.manual_seed(args.seed)
+        teacher, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
+        teacher.load_state_dict(synthetic.state_dict_s1(grid=args.grid, bg_resolution=args.bg, seed=0), strict=False)
+        teacher.eval()
+        teacher.sampler.update(teacher.rf, init=False)
+        teacher.sampler.update(teacher.rf, init=True)
+        rays_tr, focal = synthetic.orbit_rays(args.views, args.res, seed=1)
+        rays_te, _ = synthetic.orbit_rays(args.test_views, args.res, seed=2)
+        rays_tr, rays_te = rays_tr.to(dev), rays_te.to(dev)
+        gt_noise = DeviceNoise(dev, seed=7)
+        rgb_tr = render_images(teacher, rays_tr, focal, 4096, gt_noise)
+        rgb_te = render_images(teacher, rays_te, focal, 4096, gt_noise)
+        del teacher
 
     # ---- student: fresh initialisation, calibration (train.py:429-437)
     torch.manual_seed(args.seed)                  # identical replicas on every rank
-    nerf, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
+    nerf, cfg = build_model(grid=args.grid, bg_resolution=args.bg, near_far=near_far, device=dev)
     nerf.train()
     params = resolved_config()["params"]
     with torch.no_grad():
@@ -100,6 +123,11 @@ def main():
                 print(json.dumps(dict(iteration=it + 1, train_psnr=round(out["psnr"], 3), test_psnr=round(psnr, 3),
                                       rays_per_s=round(rays_seen / (time.time() - t0), 1), num_rays=trainer.num_rays,
                                       retrace=nerf.model.max_retrace_rays, n_samples=out["n_samples"])), flush=True)
+    if args.save and rank == 0:
+        cfg["arch"]["model"]["brdf"]["bias"] = nerf.model.brdf.bias                        # calibrated values
+        cfg["arch"]["model"]["diffuse_module"]["diffuse_bias"] = nerf.model.diffuse_module.diffuse_bias
+        cfg["arch"]["model"]["diffuse_module"]["roughness_bias"] = nerf.model.diffuse_module.roughness_bias
+        nerf.save(args.save, cfg["arch"])
     if world > 1:
         dist.destroy_process_group()
 

@@ -364,7 +364,42 @@ def case_upsample():
     save("upsample", out)
 
 
-CASES = dict(upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
+def case_blender_rays():
+    """(f) Blender loader: the reference's pinhole ray construction (dataLoader/ray_utils.py:23-41,65-85 as used by
+    dataLoader/blender.py:97-173) for a small image; kornia.create_meshgrid (pixel lattice, absent here) is restated."""
+    import types
+    kornia = sys.modules.get("kornia") or types.ModuleType("kornia")
+
+    def create_meshgrid(H, W, normalized_coordinates=False):
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        return torch.stack([xs, ys], -1)[None]
+
+    kornia.create_meshgrid = create_meshgrid
+    sys.modules["kornia"] = kornia
+    rh.install_stubs()
+    sys.path.insert(0, "/root/reference")
+    from dataLoader import ray_utils as ru
+    ru.create_meshgrid = create_meshgrid
+    H, W = 5, 7
+    angle = 0.6911112
+    fx = 0.5 * W / np.tan(0.5 * angle)
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(3, 3, generator=g)
+    Q, _ = torch.linalg.qr(A)
+    tm = torch.eye(4)
+    tm[:3, :3] = Q
+    tm[:3, 3] = torch.tensor([2.0, -1.5, 3.0])
+    blender2opencv = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
+    pose = np.array(tm.numpy().tolist()) @ blender2opencv
+    c2w = torch.FloatTensor(pose)
+    dirs = ru.get_ray_directions(H, W, [fx, fx])
+    dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+    ro, rd = ru.get_rays(dirs, c2w)
+    save("blender_rays", dict(H=np.asarray(H), W=np.asarray(W), camera_angle_x=np.asarray(angle), fx=np.asarray(fx),
+                              transform_matrix=tm, rays=torch.cat([ro, rd], 1)))
+
+
+CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full)
 
 if __name__ == "__main__":
