@@ -268,17 +268,21 @@ int64_t nmf_bounce_index_workspace_bytes(int64_t M);
 /* Per bounce row (models/microfacet.py:297,304-316,352-361): V = -ray direction, N = normal facing V
  * (n * sign(V.n)), r1 = max(roughness, min_rough), f0, diffuse = albedo * E(n) with E the 9-term SH irradiance
  * (conv [9][3] DEVICE pointer, modules/sh.py:97-142), feat = app + anoise * feat_noise (feat_noise may be NULL),
- * xyz.  heads [M][11] is nmf_heads_fwd's output, rays [b][6], ray_id [M]. */
+ * xyz.  heads is nmf_heads_fwd's output, rays [b][6], ray_id [M].  app / heads / feat_noise are indexed by SAMPLE
+ * ([M][24], [M][11], [M][24]) or, with row_inputs != 0, by BOUNCE ROW ([Mb][.]: appearance evaluated only where it is
+ * used -- in training that is ~5-20 % of the samples). */
 int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* app, const float* heads,
                         const float* xyzt, const int32_t* ray_id, const float* rays, const float* conv,
-                        const float* feat_noise, float anoise, float min_rough, float* V, float* N, float* r1,
-                        float* f0, float* diffuse, float* feat, float* xyz, void* stream);
-/* Adjoint, written for ALL M samples (zeros where inv < 0): d_normals [M][3] (zero when detach_normals),
- * d_heads [M][11], d_app [M][24].  Row gradients may be NULL (= zero).  row_strides = row pitch in floats of
- * (dN, dr1, df0, ddiffuse), so column slices of wider row tensors are read in place (NULL = dense 3,1,3,3). */
-int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
-                        const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
-                        int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
+                        const float* feat_noise, float anoise, float min_rough, int32_t row_inputs, float* V, float* N,
+                        float* r1, float* f0, float* diffuse, float* feat, float* xyz, void* stream);
+/* Adjoint: d_normals [M][3] written for ALL samples (zeros where inv < 0 or detach_normals); d_heads / d_app written for
+ * all M samples ([M][11], [M][24], zeros where inv < 0) or, with row_inputs, per bounce row ([Mb][11], [Mb][24]; bidx
+ * required).  Row gradients may be NULL (= zero).  row_strides = row pitch in floats of (dN, dr1, df0, ddiffuse), so
+ * column slices of wider row tensors are read in place (NULL = dense 3,1,3,3). */
+int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t* bidx, int64_t Mb, const float* normals,
+                        const float* heads, const int32_t* ray_id, const float* rays, const float* conv,
+                        float min_rough, int32_t detach_normals, int32_t row_inputs, const float* dN,
+                        const float* dr1, const float* df0,
                         const float* ddiffuse, const int32_t row_strides[4], const float* dfeat, float* d_normals,
                         float* d_heads, float* d_app, void* stream);
 /* modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py:34-55, one thread per ray in sample order:

@@ -134,18 +134,19 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     const int32_t* __restrict__ bidx, int64_t Mb, const float* __restrict__ normals, const float* __restrict__ app,
     const float* __restrict__ heads, const float4* __restrict__ xyzt, const int32_t* __restrict__ ray_id,
     const float* __restrict__ rays, Conv conv, const float* __restrict__ feat_noise, float anoise, float min_rough,
-    float* __restrict__ V, float* __restrict__ N, float* __restrict__ r1, float* __restrict__ f0,
+    int row_inputs, float* __restrict__ V, float* __restrict__ N, float* __restrict__ r1, float* __restrict__ f0,
     float* __restrict__ diffuse, float* __restrict__ feat, float* __restrict__ xyz) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= Mb) return;
     const int64_t m = bidx[row];
+    const int64_t ia = row_inputs ? row : m;       // app / heads / noise given per bounce row or per sample
     const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
     const float vx = -d[0], vy = -d[1], vz = -d[2];
     const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
     const float s = sgn(vx * nx + vy * ny + vz * nz);                       // models/microfacet.py:356
     V[row * 3] = vx; V[row * 3 + 1] = vy; V[row * 3 + 2] = vz;
     N[row * 3] = nx * s; N[row * 3 + 1] = ny * s; N[row * 3 + 2] = nz * s;
-    const float* h = heads + m * HEADS;
+    const float* h = heads + ia * HEADS;
     r1[row] = fmaxf(h[9], min_rough);
     float Y[9];
     sh9(nx, ny, nz, Y);
@@ -159,8 +160,8 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     }
     const float4 p = xyzt[m];
     xyz[row * 3] = p.x; xyz[row * 3 + 1] = p.y; xyz[row * 3 + 2] = p.z;
-    const float4* a4 = reinterpret_cast<const float4*>(app + m * FEAT);
-    const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + m * FEAT) : nullptr;
+    const float4* a4 = reinterpret_cast<const float4*>(app + ia * FEAT);
+    const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + ia * FEAT) : nullptr;
     float4* o4 = reinterpret_cast<float4*>(feat + row * FEAT);
 #pragma unroll
     for (int i = 0; i < FEAT / 4; ++i) {
@@ -174,29 +175,39 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
 }
 
 // one thread per SAMPLE: rows scatter back through the inverse map, everything else is written as zero, so the
-// three gradient tensors need no separate fill
+// three gradient tensors need no separate fill.  With row_inputs the head / feature adjoints stay per bounce row
+// ([Mb][11], [Mb][24], written by the first Mb threads) and only d_normals covers all samples.
 __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
-    const int32_t* __restrict__ inv, int64_t M, const float* __restrict__ normals, const float* __restrict__ heads,
+    const int32_t* __restrict__ inv, int64_t M, const int32_t* __restrict__ bidx, int64_t Mb,
+    const float* __restrict__ normals, const float* __restrict__ heads,
     const int32_t* __restrict__ ray_id, const float* __restrict__ rays, Conv conv, float min_rough, int detach_n,
-    const float* __restrict__ dN, const float* __restrict__ dr1, const float* __restrict__ df0,
+    int row_inputs, const float* __restrict__ dN, const float* __restrict__ dr1, const float* __restrict__ df0,
     const float* __restrict__ ddiff, int sN, int sr, int sf, int sd, const float* __restrict__ dfeat,
     float* __restrict__ d_normals, float* __restrict__ d_heads, float* __restrict__ d_app) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int64_t row = inv[m];
-    float gn[3] = {0.f, 0.f, 0.f};
-    float gh[HEADS];
-#pragma unroll
-    for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
-    float4* o4 = reinterpret_cast<float4*>(d_app + m * FEAT);
-    if (row >= 0) {
-        const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
-        if (!detach_n && dN) {
-            const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) {          // normal adjoint of sample t
+        const int64_t row = inv[t];
+        float gn[3] = {0.f, 0.f, 0.f};
+        if (row >= 0 && !detach_n && dN) {
+            const float nx = normals[t * 3], ny = normals[t * 3 + 1], nz = normals[t * 3 + 2];
+            const float* d = rays + (int64_t)ray_id[t] * 6 + 3;
             const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
             gn[0] = dN[row * sN] * s; gn[1] = dN[row * sN + 1] * s; gn[2] = dN[row * sN + 2] * s;
         }
-        const float* h = heads + m * HEADS;
+        d_normals[t * 3] = gn[0]; d_normals[t * 3 + 1] = gn[1]; d_normals[t * 3 + 2] = gn[2];
+    }
+    // head / feature adjoints: slot t of the output belongs to sample t (dense) or to bounce row t (row_inputs)
+    const int64_t n_out = row_inputs ? Mb : M;
+    if (t >= n_out) return;
+    const int64_t row = row_inputs ? t : inv[t];
+    const int64_t m = row_inputs ? (int64_t)bidx[t] : t;
+    float gh[HEADS];
+#pragma unroll
+    for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
+    float4* o4 = reinterpret_cast<float4*>(d_app + t * FEAT);
+    if (row >= 0) {
+        const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
+        const float* h = heads + t * HEADS;
         float Y[9];
         sh9(nx, ny, nz, Y);
 #pragma unroll
@@ -215,9 +226,8 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
 #pragma unroll
         for (int i = 0; i < FEAT / 4; ++i) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    d_normals[m * 3] = gn[0]; d_normals[m * 3 + 1] = gn[1]; d_normals[m * 3 + 2] = gn[2];
 #pragma unroll
-    for (int j = 0; j < HEADS; ++j) d_heads[m * HEADS + j] = gh[j];
+    for (int j = 0; j < HEADS; ++j) d_heads[t * HEADS + j] = gh[j];
 }
 
 // ---- ray compose -------------------------------------------------------------------------------------------------
@@ -402,33 +412,36 @@ static Conv load_conv(const float* conv) {
 extern "C" int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* app,
                                    const float* heads, const float* xyzt, const int32_t* ray_id, const float* rays,
                                    const float* conv, const float* feat_noise, float anoise, float min_rough,
-                                   float* V, float* N, float* r1, float* f0, float* diffuse, float* feat, float* xyz,
-                                   void* stream) {
+                                   int32_t row_inputs, float* V, float* N, float* r1, float* f0, float* diffuse,
+                                   float* feat, float* xyz, void* stream) {
     NMF_REQUIRE(Mb >= 0, NMF_EINVAL, "nmf_bounce_prep_fwd: Mb < 0");
     if (Mb == 0) return NMF_OK;
     NMF_REQUIRE(bidx && normals && app && heads && xyzt && ray_id && rays && conv && V && N && r1 && f0 &&
                     diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd: null");
     hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
                        normals, app, heads, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
-                       feat_noise, anoise, min_rough, V, N, r1, f0, diffuse, feat, xyz);
+                       feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_fwd");
     return NMF_OK;
 }
 
-extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const float* normals, const float* heads,
-                                   const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
-                                   int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
+extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t* bidx, int64_t Mb, const float* normals,
+                                   const float* heads, const int32_t* ray_id, const float* rays, const float* conv,
+                                   float min_rough, int32_t detach_normals, int32_t row_inputs, const float* dN,
+                                   const float* dr1, const float* df0,
                                    const float* ddiffuse, const int32_t row_strides[4], const float* dfeat,
                                    float* d_normals, float* d_heads, float* d_app, void* stream) {
     const int sN = row_strides ? row_strides[0] : 3, sr = row_strides ? row_strides[1] : 1;
     const int sf = row_strides ? row_strides[2] : 3, sd = row_strides ? row_strides[3] : 3;
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_prep_bwd: M < 0");
     if (M == 0) return NMF_OK;
-    NMF_REQUIRE(inv && normals && heads && ray_id && rays && conv && d_normals && d_heads && d_app, NMF_EINVAL,
-                "nmf_bounce_prep_bwd: null");
-    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, inv, M,
-                       normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, dN, dr1, df0,
-                       ddiffuse, sN, sr, sf, sd, dfeat, d_normals, d_heads, d_app);
+    NMF_REQUIRE(inv && normals && ray_id && rays && conv && d_normals, NMF_EINVAL, "nmf_bounce_prep_bwd: null");
+    NMF_REQUIRE(Mb >= 0 && Mb <= M, NMF_EINVAL, "nmf_bounce_prep_bwd: Mb outside [0, M]");
+    NMF_REQUIRE((row_inputs ? Mb == 0 : false) || (heads && d_heads && d_app), NMF_EINVAL, "nmf_bounce_prep_bwd: null");
+    NMF_REQUIRE(!row_inputs || Mb == 0 || bidx, NMF_EINVAL, "nmf_bounce_prep_bwd: row_inputs needs bidx");
+    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, inv, M, bidx,
+                       Mb, normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, (int)row_inputs,
+                       dN, dr1, df0, ddiffuse, sN, sr, sf, sd, dfeat, d_normals, d_heads, d_app);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_bwd");
     return NMF_OK;
 }

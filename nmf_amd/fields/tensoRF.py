@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..functional import FieldGrads, GradPass, L1Mean, VMQuery
+from ..functional import FieldGrads, GradPass, L1Mean, VMAppQuery, VMQuery
 
 
 def N_to_reso(n_voxels, bbox):
@@ -251,7 +251,14 @@ class TensorVMSplit(torch.nn.Module):
         return sg if activate else sf.detach()
 
     def compute_appfeature(self, xyz_sampled):
-        return self.query(xyz_sampled, want_app=True, want_normal=False)[2]
+        """[M,24] appearance features only (one launch without the density branch)"""
+        if xyz_sampled.shape[0] == 0:
+            return xyz_sampled.new_zeros((0, self.app_dim))
+        xyz = xyz_sampled.detach()
+        if xyz.shape[-1] == 3:
+            xyz = torch.cat([xyz, torch.zeros_like(xyz[:, :1])], -1)
+        holder, token = self._pass_token()
+        return VMAppQuery.apply(self, xyz.contiguous(), holder, token)
 
     def compute_normals(self, xyz):
         return self.query(xyz, want_app=False, want_normal=True)[3]

@@ -68,6 +68,17 @@ class PassMixin:
         return holder, token
 
 
+def field_grad_buffers(holder, G, dev):
+    """packed gradient tables of the pass (one zero fill for all 13), created by the first backward that needs them"""
+    if holder.bufs is None:
+        shapes = [(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]
+        sizes = [math.prod(sh) for sh in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        v = [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)]
+        holder.bufs = (v[0:3], v[3:6], v[6:9], v[9:12], v[12])
+    return holder.bufs
+
+
 class FieldGrads(torch.autograd.Function):
     """Graph node that owns the table gradients of a pass: forward hands out a scalar token every VMQuery of the pass
     takes as an input, so autograd runs this backward exactly once, after the last VMQuery backward."""
@@ -117,13 +128,7 @@ class VMQuery(torch.autograd.Function):
         p, dpk, dlk, apl, ali, basis = field._tables()
         G = p.grid
         dev = xyzt.device
-        if holder.bufs is None:
-            shapes = [(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]
-            sizes = [math.prod(sh) for sh in shapes]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)          # one fill for all 13 tables
-            v = [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)]
-            holder.bufs = (v[0:3], v[3:6], v[6:9], v[9:12], v[12])
-        g_dpk, g_dlk, g_apl, g_ali, g_basis = holder.bufs
+        g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, G, dev)
         d_sigma = d_sigma.contiguous() if d_sigma is not None else None
         d_app_c = d_app.contiguous() if (want_app and d_app is not None) else None
         d_nrm_c = d_normal.contiguous() if (want_normal and d_normal is not None) else None
@@ -131,6 +136,29 @@ class VMQuery(torch.autograd.Function):
             hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
                              g_dpk, g_dlk, g_apl, g_ali, g_basis if d_app_c is not None else None)
         return None, None, None, None, None, xyzt.new_zeros(())
+
+
+class VMAppQuery(torch.autograd.Function):
+    """app = field appearance features at xyzt, nothing else (fields/tensoRF.py:402-405).  Used on the bounce rows only:
+    in training the appearance branch is needed where a secondary ray starts, not at every kept sample."""
+
+    @staticmethod
+    def forward(ctx, field, xyzt, holder, token):
+        p, dpk, dlk, apl, ali, basis = field._tables()
+        ap = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
+        ctx.field, ctx.holder = field, holder
+        ctx.save_for_backward(xyzt)
+        return ap
+
+    @staticmethod
+    def backward(ctx, d_app):
+        field, holder = ctx.field, ctx.holder
+        (xyzt,) = ctx.saved_tensors
+        p, dpk, dlk, apl, ali, basis = field._tables()
+        g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, p.grid, xyzt.device)
+        hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, None, None, None, None, None, d_app.contiguous(),
+                         g_dpk, g_dlk, g_apl, g_ali, g_basis)
+        return None, None, None, xyzt.new_zeros(())
 
 
 class Composite(torch.autograd.Function):
@@ -362,23 +390,26 @@ class BouncePrep(torch.autograd.Function):
     the inverse map (zeros elsewhere), so no index_add / zero fill is needed."""
 
     @staticmethod
-    def forward(ctx, normals, app, heads, bidx, inv, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, detach_n):
+    def forward(ctx, normals, app, heads, bidx, inv, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, detach_n,
+                row_inputs=False):
         normals, app, heads = normals.contiguous(), app.contiguous(), heads.contiguous()
-        outs = hip.bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough)
-        ctx.save_for_backward(normals, heads, inv, ray_id, rays, conv)
-        ctx.cfg = (min_rough, detach_n)
+        outs = hip.bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough,
+                                   row_inputs)
+        ctx.save_for_backward(normals, heads, inv, ray_id, rays, conv, bidx)
+        ctx.cfg = (min_rough, detach_n, row_inputs)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(outs[0], outs[6])
         return outs
 
     @staticmethod
     def backward(ctx, _dV, dN, dr1, df0, ddiff, dfeat, _dxyz):
-        normals, heads, inv, ray_id, rays, conv = ctx.saved_tensors
-        min_rough, detach_n = ctx.cfg
+        normals, heads, inv, ray_id, rays, conv, bidx = ctx.saved_tensors
+        min_rough, detach_n, row_inputs = ctx.cfg
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         d_normals, d_heads, d_app = hip.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n,
-                                                        dN, dr1, df0, ddiff, c(dfeat))      # column slices read in place
-        return (None if detach_n else d_normals, d_app, d_heads) + (None,) * 10
+                                                        dN, dr1, df0, ddiff, c(dfeat), bidx=bidx,
+                                                        row_inputs=row_inputs)          # column slices read in place
+        return (None if detach_n else d_normals, d_app, d_heads) + (None,) * 11
 
 
 class RayCompose(torch.autograd.Function):

@@ -95,18 +95,29 @@ class Microfacet(torch.nn.Module):
         return sh_.rgb(), sh_.debug()
 
     def shade_compact(self, samples, app_features, normals, weights, render_reflection, bg_module, is_train, recur,
-                      noise):
-        """samples: samplers.alphagrid.Samples; app_features [M,24]; normals [M,3]; weights [M].
+                      noise, app_fn=None):
+        """samples: samplers.alphagrid.Samples; app_features [M,24] or None; normals [M,3]; weights [M].
         Returns a Shaded record: radiance per BOUNCE ROW (samples that spawned secondary rays; every other sample
-        has zero radiance, models/microfacet.py:596-613) + the inverse map, with the debug maps computed on demand."""
+        has zero radiance, models/microfacet.py:596-613) + the inverse map, with the debug maps computed on demand.
+
+        app_features=None selects the sparse evaluation: the appearance branch of the field (app_fn(xyzt_rows) -> [Mb,24]),
+        its noise and the material heads are evaluated on the bounce rows only -- 5-20 % of the samples -- which is all
+        the radiance depends on; the per-sample outputs of the reference (albedo / roughness maps ...) are then produced
+        on demand by Shaded.debug()."""
         M = samples.M
-        dev = app_features.device
-        feat_noise = noise.normal((M, app_features.shape[1]))                                       # :297
-        if feat_noise is not None:
-            feat_noise = feat_noise.contiguous()
+        dev = normals.device
+        sparse = app_features is None
+        feat_noise, heads, deferred = None, None, None
+        if not sparse:
+            feat_noise = noise.normal((M, app_features.shape[1]))                                   # :297
+            if feat_noise is not None:
+                feat_noise = feat_noise.contiguous()
+        else:
+            deferred = noise.normal_deferred((M, 24))                                               # :297, rows drawn later
         noise.skip("randn", (M, 3))
         noise.skip("randn", (M, 2))
-        heads = self.diffuse_module.heads(app_features)                                              # :299
+        if not sparse:
+            heads = self.diffuse_module.heads(app_features)                                          # :299
         noise.skip("rand", (5000,))                                                                 # :304-315
         noise.skip("rand", (5000,))
         _, conv = bg_module.get_spherical_harmonics(100)
@@ -133,15 +144,21 @@ class Microfacet(torch.nn.Module):
             self.trace[f"counts{recur}"] = counts
         bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)                                    # :333-350
         R, Mb = (int(v) for v in tot.cpu())
-        out = Shaded(self, samples, heads, normals, conv, w_det, inv, M)
+        out = Shaded(self, samples, heads, normals, conv, w_det, inv, M, app_fn)
         if R == 0:
             return out
         bidx, row_off, cnt32 = bidx[:Mb], row_off[:Mb + 1], cnt32[:Mb]
         row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)            # = torch.where(ray_mask)
         off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                              # base.py:18
+        if sparse:      # appearance, its noise and the heads on the bounce rows only
+            app_in = app_fn(torch.index_select(samples.xyzt, 0, bidx.long()))
+            feat_noise = noise.rows(deferred, bidx)
+            heads_in = self.diffuse_module.heads(app_in)                                             # :299
+        else:
+            app_in, heads_in = app_features, heads
         bV, bN, r1, f0, diffuse, feat, xyz = BouncePrep.apply(
-            normals, app_features, heads, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,
-            float(self.anoise), float(self.min_rough) if is_train else -1e30, bool(self.detach_N))   # :352-361
+            normals, app_in, heads_in, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,
+            float(self.anoise), float(self.min_rough) if is_train else -1e30, bool(self.detach_N), sparse)   # :352-361
         L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                             # :367-456
             bV, bN, r1, xyz, off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray, row_off)
         brdf_weight = self.brdf.forward_compact(halfvec, diffvec, feat, r1, row_of_ray, row_off)
@@ -195,21 +212,23 @@ class Shaded:
     Training only reads refl_rows; the on-demand tensors are plain torch expressions of the graph tensors, so a
     caller that puts them into a loss still gets their gradients."""
 
-    def __init__(self, model, samples, heads, normals, conv, w_det, inv, M):
+    def __init__(self, model, samples, heads, normals, conv, w_det, inv, M, app_fn=None):
         self.model, self.samples, self.heads, self.normals, self.conv = model, samples, heads, normals, conv
-        self.w_det, self.inv, self.M = w_det, inv, M
+        self.w_det, self.inv, self.M, self.app_fn = w_det, inv, M, app_fn
         self.refl_rows = None
         self.rows = None
         self._debug = None
 
     def rgb(self):
-        z = torch.zeros((self.M, 3), device=self.heads.device)
+        z = torch.zeros((self.M, 3), device=self.normals.device)
         if self.refl_rows is None:
             return z
         return z.index_put((self.rows[0].long(),), self.refl_rows)
 
     def debug(self):
         if self._debug is None:
+            if self.heads is None:          # sparse evaluation: the per-sample material maps were not needed so far
+                self.heads = self.model.diffuse_module.heads(self.app_fn(self.samples.xyzt))
             S, h, n = self.samples, self.heads, self.normals
             albedo, f0, r1 = h[:, 0:3], h[:, 6:9], h[:, 9:10]
             viewdirs = torch.index_select(S.rays[:, 3:6], 0, S.ray_id.long())

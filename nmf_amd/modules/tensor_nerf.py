@@ -140,7 +140,13 @@ class TensorNeRF(torch.nn.Module):
         offsets = S.offsets[: B + 1]
         ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
 
-        sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=True, want_normal=True)       # :286,386,393
+        # Sparse appearance: the radiance only depends on the appearance features of the samples that spawn secondary
+        # rays, so unless the per-sample debug maps are wanted (eval with draw_debug) the field's appearance branch and the
+        # material heads run on those rows only (Microfacet.shade_compact).
+        dense_app = (not is_train) and draw_debug
+        sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=dense_app, want_normal=True)   # :286,386,393
+        if not dense_app:
+            app = None
         weight = Composite.apply(sigma, S.dist, offsets, B, float(self.rf.distance_scale))          # :366
 
         def render_reflection(brays, mipval, retrace):                                               # :291-317
@@ -158,7 +164,7 @@ class TensorNeRF(torch.nn.Module):
         shaded = None
         if M > 0:
             shaded = self.model.shade_compact(S, app, world_normal, weight, render_reflection, self.bg_module,
-                                              is_train, recur, noise)
+                                              is_train, recur, noise, app_fn=self.rf.compute_appfeature)
 
         images = {}
         stats = dict(recur=recur, whole_valid=wv, n_samples=n_samples)

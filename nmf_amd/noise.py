@@ -29,6 +29,13 @@ class DeviceNoise:
     def normal(self, shape):
         return torch.randn(shape, device=self.device, generator=self.gen)
 
+    def normal_deferred(self, shape):
+        """an i.i.d. normal [M, C] matrix of which only some rows will be used: nothing is drawn until rows() asks"""
+        return tuple(shape)
+
+    def rows(self, deferred, rows):
+        return torch.randn((rows.shape[0],) + deferred[1:], device=self.device, generator=self.gen)
+
     def uniform(self, shape):
         return torch.rand(shape, device=self.device, generator=self.gen)
 
@@ -71,6 +78,12 @@ class ReplayNoise:
 
     def normal(self, shape):
         return self._next("randn", shape).to(self.device)
+
+    def normal_deferred(self, shape):
+        return self._next("randn", shape).to(self.device)          # consumed at the reference's position in the stream
+
+    def rows(self, deferred, rows):
+        return deferred[rows.long()].contiguous()
 
     def uniform(self, shape):
         return self._next("rand", shape).to(self.device)

@@ -637,8 +637,9 @@ def test_bounce_index_empty():
     assert tot.cpu().tolist() == [0, 0] and int(row_off[0]) == 0 and inv.shape[0] == 0
 
 
-@pytest.mark.parametrize("M,detach_n", [(1, False), (4099, False), (4099, True)])
-def test_bounce_prep_vs_torch(M, detach_n):
+@pytest.mark.parametrize("M,detach_n,rows_in", [(1, False, False), (4099, False, False), (4099, True, False),
+                                                 (4099, False, True), (1, False, True)])
+def test_bounce_prep_vs_torch(M, detach_n, rows_in):
     """nmf_bounce_prep_fwd/bwd against the torch expressions of models/microfacet.py:297,304-316,352-361."""
     from nmf_amd.functional import BouncePrep
     hip = _hip()
@@ -659,9 +660,15 @@ def test_bounce_prep_vs_torch(M, detach_n):
     d = lambda t: t.to(DEV)  # noqa: E731
     bidx, row_off, cnt, inv, tot = hip.bounce_index(d(counts))
     Mb = int(tot[1])
-    td = [d(t).requires_grad_(True) for t in (normals, app, heads)]
-    outs = BouncePrep.apply(td[0], td[1], td[2], bidx[:Mb], inv, d(xyzt), d(ray_id), d(rays), d(conv), d(nz), anoise,
-                            min_rough, detach_n)
+    idx0 = torch.nonzero(counts > 0).reshape(-1)
+    if rows_in:      # appearance / heads / noise supplied per bounce row (sparse evaluation)
+        td = [d(normals).requires_grad_(True), d(app[idx0]).requires_grad_(True), d(heads[idx0]).requires_grad_(True)]
+        nz_in = d(nz[idx0].contiguous())
+    else:
+        td = [d(t).requires_grad_(True) for t in (normals, app, heads)]
+        nz_in = d(nz)
+    outs = BouncePrep.apply(td[0], td[1], td[2], bidx[:Mb], inv, d(xyzt), d(ray_id), d(rays), d(conv), nz_in, anoise,
+                            min_rough, detach_n, rows_in)
     tr = [t.clone().requires_grad_(True) for t in (normals, app, heads)]
     idx = torch.nonzero(counts > 0).reshape(-1)
     n, a, h = (t[idx] for t in tr)
@@ -683,6 +690,8 @@ def test_bounce_prep_vs_torch(M, detach_n):
         if b_ is None:
             assert a_ is None or float(a_.abs().max()) == 0.0
             continue
+        if rows_in and nme != "normals":
+            b_ = b_[idx0]
         assert_close(a_.cpu(), b_, rtol=1e-5, atol=1e-6, what="bounce prep d" + nme)
 
 
