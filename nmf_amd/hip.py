@@ -67,6 +67,39 @@ EXPORTS = [
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
         raise NmfHipError(f"libnmf_hip.so does not export {_n}")
+
+
+def _declare_from_header():
+    """argtypes / restype of every entry point, derived from include/nmf_hip.h (pointers and arrays -> void*, so wrappers
+    pass Tensor.data_ptr() integers straight through; scalars are converted by ctypes)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "nmf_hip.h")
+    if not os.path.exists(hdr):
+        return
+    text = re.sub(r"/\*.*?\*/", " ", open(hdr).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    scal = {"int64_t": C.c_int64, "int32_t": C.c_int32, "int": C.c_int32, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32,
+            "float": C.c_float, "double": C.c_double}
+    for ret, name, args in re.findall(r"\b(int64_t|int|const char\s*\*)\s+(nmf_\w+)\s*\(([^;{}]*?)\)\s*;", text):
+        fn = getattr(_lib, name, None)
+        if fn is None:
+            continue
+        fn.restype = C.c_int64 if ret == "int64_t" else (C.c_char_p if "char" in ret else C.c_int)
+        types = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a or "[" in a:
+                types.append(C.c_void_p)
+            else:
+                tok = [t for t in a.replace("const", " ").split() if t in scal]
+                if not tok:
+                    raise NmfHipError(f"cannot derive the ctypes type of '{a}' in {name}")
+                types.append(scal[tok[0]])
+        fn.argtypes = types
+
+
+_declare_from_header()
 _lib.nmf_last_error_string.restype = C.c_char_p
 _lib.nmf_version.restype = C.c_int
 _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
@@ -88,20 +121,20 @@ def _check(code, what):
 def _stream():
     # raw handle of torch's current stream on the current device (what torch.cuda.current_stream().cuda_stream
     # returns, without building the Stream object: this runs ~100 times per training step)
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t, dtype=None):
-    """device pointer of a contiguous tensor (None -> NULL)"""
+    """device pointer (integer) of a contiguous tensor; None -> NULL"""
     if t is None:
-        return C.c_void_p(0)
+        return None
     if dtype is not None and t.dtype != dtype:
         raise NmfHipError(f"expected {dtype}, got {t.dtype}")
     if not t.is_cuda:
         raise NmfHipError("nmf_amd operators need device tensors (no CPU path)")
     if not t.is_contiguous():
         raise NmfHipError("tensor must be contiguous")
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr() or None
 
 
 def _p3(ts, dtype=torch.float32):
@@ -109,7 +142,7 @@ def _p3(ts, dtype=torch.float32):
     if ts is None:
         return None
     for i in range(3):
-        arr[i] = _p(ts[i], dtype).value
+        arr[i] = _p(ts[i], dtype)
     return arr
 
 
