@@ -14,6 +14,15 @@ class GradPass:
 
     def __init__(self):
         self.bufs = None
+        self.token_sent = False
+
+    def token_grad(self, like):
+        """Gradient for the pass token: the node behind the token only has to be scheduled, so exactly one consumer
+        hands it a (zero) gradient and the others return None -- no fill kernel per consumer, no accumulation adds."""
+        if self.token_sent:
+            return None
+        self.token_sent = True
+        return like.new_zeros(())
 
 
 class ParamGrads(torch.autograd.Function):
@@ -135,7 +144,7 @@ class VMQuery(torch.autograd.Function):
         if d_sigma is not None or d_app_c is not None or d_nrm_c is not None:
             hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
                              g_dpk, g_dlk, g_apl, g_ali, g_basis if d_app_c is not None else None)
-        return None, None, None, None, None, xyzt.new_zeros(())
+        return None, None, None, None, None, holder.token_grad(xyzt)
 
 
 class VMAppQuery(torch.autograd.Function):
@@ -158,7 +167,7 @@ class VMAppQuery(torch.autograd.Function):
         g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, p.grid, xyzt.device)
         hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, None, None, None, None, None, d_app.contiguous(),
                          g_dpk, g_dlk, g_apl, g_ali, g_basis)
-        return None, None, None, xyzt.new_zeros(())
+        return None, None, None, holder.token_grad(xyzt)
 
 
 class Composite(torch.autograd.Function):
@@ -251,7 +260,7 @@ class EnvLookup(torch.autograd.Function):
         d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
                                            want_dirs=ctx.needs_input_grad[1], want_mipbias=ctx.needs_input_grad[3])
         return (None, d_dirs, None, d_mip.to(torch.float64).reshape(()) if d_mip is not None else None, None,
-                d_out.new_zeros(()) if want_tab else None)
+                holder.token_grad(d_out) if want_tab else None)
 
 
 class BrdfFeatures(torch.autograd.Function):
@@ -296,7 +305,7 @@ class BrdfMLP(torch.autograd.Function):
         d_xfeat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out, grads)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
         return (None, None, d_feat, None, None, None, None, None,
-                d_out.new_zeros(()) if ctx.holder is not None else None) + (None,) * len(ws)
+                ctx.holder.token_grad(d_out) if ctx.holder is not None else None) + (None,) * len(ws)
 
 
 class MaterialHeads(torch.autograd.Function):
@@ -317,7 +326,7 @@ class MaterialHeads(torch.autograd.Function):
         feat, W, b = ctx.saved_tensors
         gW, gb = grad_views(ctx.holder, [W, b]) if ctx.holder is not None else (torch.zeros_like(W), torch.zeros_like(b))
         d_feat = hip.heads_bwd(feat, W, b, ctx.hp, d_out, gW, gb)
-        return d_feat, None, None, None, None, d_out.new_zeros(()) if ctx.holder is not None else None
+        return d_feat, None, None, None, None, ctx.holder.token_grad(d_out) if ctx.holder is not None else None
 
 
 class StackedHeadGrads(torch.autograd.Function):

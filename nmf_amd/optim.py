@@ -41,7 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] = t = int(st["step"]) + 1
                 if p.dtype not in (torch.float32, torch.float64) or g.dtype != p.dtype:
                     raise hip.NmfHipError(f"FusedAdam: unsupported dtype {p.dtype}/{g.dtype}")
-                if g.stride() != p.stride() or not _dense(p):
+                if not _same_layout(g, p) or not _dense(p):
                     if not _dense(p):
                         raise hip.NmfHipError("FusedAdam: parameter storage must be dense")
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
@@ -62,6 +62,11 @@ class FusedAdam(torch.optim.Optimizer):
             # density tables, SAT, stacked head weights, host mirrors of scalars) that the parameters changed
             torch.autograd.graph.increment_version(touched)
         return None
+
+
+def _same_layout(a, b):
+    """same memory order: strides agree on every dimension of extent > 1 (size-1 dimensions carry arbitrary strides)"""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
 
 
 def _dense(t):
