@@ -24,12 +24,15 @@ sys.path.insert(0, ROOT)
 RAYS_PER_GPU = 4096
 GRID = 128
 BG_RES = 512
-G_S = 4800            # algorithmic bytes per kept sample, forward: 18 taps x (16+2*16+24... ) fp32
-BWD_BYTES = 3 * G_S   # backward = recompute read + read-modify-write of the gradients (fwd+bwd = 4 G_s)
+# Algorithmic bytes per kept sample, forward (SURVEY 8d, fp32 tables, 18 taps): density value 1152 + density gradient
+# 1920 + appearance 1728 = G_s = 4800.  Backward = recompute read + read-modify-write of the gradients = 3 x forward.
+# The density / normal walk runs over all kept samples, the appearance walk only over the bounce rows (sparse appearance).
+G_DENSITY, G_APP = 1152 + 1920, 1728
+BWD_BYTES_DENSITY, BWD_BYTES_APP = 3 * G_DENSITY, 3 * G_APP
 HBM_PEAK_GBS = 8000.0
-# the same kernel seen from the matrix pipe: per 4 samples 3 x (20 + 18) v_mfma_f32_16x16x4_f32 of 2048 FLOP each
-# (dense-equivalent, ~95 % of the products are structural zeros of the scatter matrix); fp32 MFMA peak 157.3 TFLOP/s
-BWD_MFMA_FLOP = 3 * (20 + 18) * 2048 / 4
+# the same kernel seen from the matrix pipe: per 4 samples 3 x 20 (density) / 3 x 18 (appearance) v_mfma_f32_16x16x4_f32 of
+# 2048 FLOP each (dense-equivalent, ~95 % of the products are structural zeros of the scatter matrix)
+MFMA_FLOP_DENSITY, MFMA_FLOP_APP = 3 * 20 * 2048 / 4, 3 * 18 * 2048 / 4
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
@@ -64,7 +67,9 @@ class KernelTimer:
             s.record()
             r = orig(p, xyzt, *a, **k)
             e.record()
-            self.records.append((s, e, int(xyzt.shape[0])))
+            dens = a[7] is not None or a[8] is not None or a[9] is not None      # d_sigma / d_sigma_feat / d_normal
+            app = a[10] is not None                                              # d_app
+            self.records.append((s, e, int(xyzt.shape[0]), dens, app))
             return r
 
         hip.vm_query_bwd = wrapped
@@ -83,9 +88,11 @@ class KernelTimer:
             setattr(hip, name, counted)
 
     def summary(self):
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        samples = sum(m for _, _, m in self.records)
-        return ms, samples, len(self.records)
+        """-> total ms, algorithmic bytes, dense-equivalent MFMA flop, samples, launches"""
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        nbytes = sum(m * (BWD_BYTES_DENSITY * d + BWD_BYTES_APP * a) for _, _, m, d, a in self.records)
+        flop = sum(m * (MFMA_FLOP_DENSITY * d + MFMA_FLOP_APP * a) for _, _, m, d, a in self.records)
+        return ms, nbytes, flop, sum(r[2] for r in self.records), len(self.records)
 
 
 def cpu_baseline(n_rays=512):
@@ -192,8 +199,8 @@ def main():
     if min(timer.rebuilds.values()) < args.steps:
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
     if rank == 0:
-        k_ms, k_samples, k_launches = timer.summary()
-        achieved = (BWD_BYTES * k_samples) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        k_ms, k_bytes, k_flop, k_samples, k_launches = timer.summary()
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_vm_bwd.json")
         if os.path.exists(pmc):
@@ -212,11 +219,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd (k_vm_bwd_brick + binning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": k_launches,
-                         "avg_launch_ms": k_ms / max(k_launches, 1), "bytes_per_sample": BWD_BYTES,
+                         "avg_launch_ms": k_ms / max(k_launches, 1),
+                         "bytes_per_sample": {"density+normals (all samples)": BWD_BYTES_DENSITY,
+                                              "appearance (bounce rows)": BWD_BYTES_APP},
+                         "samples_per_step": k_samples / max(args.steps, 1),
                          "note": "algorithmic bytes assume every tap is read from HBM (SURVEY 8d); the tables are "
                                  "L2/MALL-resident and tiles accumulate in registers, so frac can exceed 1 -- compare "
                                  "`traffic` (PMC) and `mfma_frac` (dense-equivalent fp32 MFMA rate / 157.3 TFLOP/s)",
-                         "mfma_frac": (BWD_MFMA_FLOP * k_samples / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if k_ms > 0 else 0.0},
+                         "mfma_frac": (k_flop / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if k_ms > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
