@@ -344,6 +344,18 @@ typedef struct {
 } nmf_adam_slot;
 int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream);
 
+/* Multi-tensor copy with fp32 <-> fp64 conversion, all slots in one launch (slots: HOST array, passed by value): packs the
+ * per-parameter gradients into the flat fp32 all-reduce buffer and unpacks the reduced sums (ONE collective
+ * per optimizer step).  src / dst are dense runs of `numel` elements. */
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t numel;
+    int32_t src_is_f64;
+    int32_t dst_is_f64;
+} nmf_copy_slot;
+int nmf_multi_copy(const nmf_copy_slot* slots, int32_t n_slots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

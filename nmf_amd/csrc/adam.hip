@@ -56,7 +56,56 @@ __global__ void __launch_bounds__(256) k_adam(Batch b) {
     else adam_slot<float>(s);
 }
 
+// multi-tensor copy with fp32 <-> fp64 conversion: gradient pack / unpack around the all-reduce in ONE launch each
+constexpr int COPY_SLOTS = 96;
+struct CopyBatch {
+    nmf_copy_slot s[COPY_SLOTS];
+};
+
+template <typename S, typename D>
+__device__ __forceinline__ void copy_slot(const nmf_copy_slot& s) {
+    const S* __restrict__ src = static_cast<const S*>(s.src);
+    D* __restrict__ dst = static_cast<D*>(s.dst);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.numel; i += stride) dst[i] = (D)src[i];
+}
+
+__global__ void __launch_bounds__(256) k_multi_copy(CopyBatch b) {
+    const nmf_copy_slot& s = b.s[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;
+    if (s.src_is_f64) {
+        if (s.dst_is_f64) copy_slot<double, double>(s);
+        else copy_slot<double, float>(s);
+    } else {
+        if (s.dst_is_f64) copy_slot<float, double>(s);
+        else copy_slot<float, float>(s);
+    }
+}
+
 }  // namespace
+
+extern "C" int nmf_multi_copy(const nmf_copy_slot* slots, int32_t n_slots, void* stream) {
+    NMF_REQUIRE(n_slots >= 0 && (slots || n_slots == 0), NMF_EINVAL, "nmf_multi_copy: bad slot table");
+    for (int32_t i = 0; i < n_slots; ++i)
+        NMF_REQUIRE(slots[i].numel >= 0 && (slots[i].numel == 0 || (slots[i].src && slots[i].dst)), NMF_EINVAL,
+                    "nmf_multi_copy: null tensor pointer");
+    for (int32_t base = 0; base < n_slots; base += COPY_SLOTS) {
+        const int32_t n = (n_slots - base < COPY_SLOTS) ? n_slots - base : COPY_SLOTS;
+        CopyBatch b;
+        memset(&b, 0, sizeof(b));
+        int64_t biggest = 0;
+        for (int32_t i = 0; i < n; ++i) {
+            b.s[i] = slots[base + i];
+            if (b.s[i].numel > biggest) biggest = b.s[i].numel;
+        }
+        if (biggest == 0) continue;
+        int64_t bx = cdiv(biggest, 256 * 4);
+        bx = bx > 1024 ? 1024 : (bx < 1 ? 1 : bx);
+        hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        NMF_CHECK_LAUNCH("k_multi_copy");
+    }
+    return NMF_OK;
+}
 
 extern "C" int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream) {
     NMF_REQUIRE(slots != nullptr || n_slots == 0, NMF_EINVAL, "nmf_adam_step: null slot table");

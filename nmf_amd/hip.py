@@ -53,6 +53,11 @@ class AdamSlot(C.Structure):
                 ("is_f64", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CopySlot(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("numel", C.c_int64), ("src_is_f64", C.c_int32),
+                ("dst_is_f64", C.c_int32)]
+
+
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
@@ -62,7 +67,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -716,3 +721,8 @@ def argsort_f32(keys):
         _check(_lib.nmf_argsort_f32(_p(keys, torch.float32), C.c_int64(n), _p(order), _p(ws), C.c_int64(nbytes),
                                     _stream()), "nmf_argsort_f32")
     return order
+
+
+def multi_copy(slots, n):
+    """slots: (CopySlot * k) host array; copies the first n (src -> dst, with fp32 <-> fp64 conversion) in one launch"""
+    _check(_lib.nmf_multi_copy(slots, n, _stream()), "nmf_multi_copy")

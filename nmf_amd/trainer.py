@@ -45,6 +45,7 @@ class FlatGradAllReduce:
     def __init__(self, params):
         self.params = [p for p in params]
         self.buf = None
+        self._slots = None
 
     def __call__(self, group=None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -53,7 +54,9 @@ class FlatGradAllReduce:
         n = sum(p.numel() for p in ps)
         if self.buf is None or self.buf.numel() != n or self.buf.device != ps[0].device:
             self.buf = torch.empty(n, dtype=torch.float32, device=ps[0].device)
-        off = 0
+        if self.buf.is_cuda:
+            return self._reduce_device(ps, n, group)
+        off = 0                                   # host tensors (gloo tests of the sharding logic): plain torch copies
         for p in ps:
             self.buf[off:off + p.numel()].copy_(p.grad.reshape(-1).float())
             off += p.numel()
@@ -62,6 +65,29 @@ class FlatGradAllReduce:
         for p in ps:
             p.grad.copy_(self.buf[off:off + p.numel()].reshape(p.grad.shape).to(p.grad.dtype))
             off += p.numel()
+        return n * 4
+
+    def _reduce_device(self, ps, n, group):
+        """pack (one launch: nmf_multi_copy over all gradients, in each tensor's own memory order) -> RCCL all-reduce
+        -> unpack (one launch)"""
+        from . import hip
+        from .optim import _dense
+        if self._slots is None or len(self._slots[0]) < len(ps):
+            self._slots = ((hip.CopySlot * len(ps))(), (hip.CopySlot * len(ps))())
+        pack, unpack = self._slots
+        base, off = self.buf.data_ptr(), 0
+        for i, p in enumerate(ps):
+            g = p.grad
+            if not _dense(g) or g.dtype not in (torch.float32, torch.float64):
+                raise hip.NmfHipError("gradient all-reduce needs dense fp32 / fp64 gradients")
+            f64 = 1 if g.dtype == torch.float64 else 0
+            a, b = pack[i], unpack[i]
+            a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = g.data_ptr(), base + 4 * off, g.numel(), f64, 0
+            b.src, b.dst, b.numel, b.src_is_f64, b.dst_is_f64 = base + 4 * off, g.data_ptr(), g.numel(), 0, f64
+            off += g.numel()
+        hip.multi_copy(pack, len(ps))
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        hip.multi_copy(unpack, len(ps))
         return n * 4
 
 

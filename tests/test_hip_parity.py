@@ -826,3 +826,29 @@ def test_march_coarse_mask_is_exact(G, B):
     words = coarse.cpu().numpy().view(np.uint32)
     got = torch.tensor([(int(words[i >> 5]) >> (i & 31)) & 1 for i in range(cg ** 3)], dtype=torch.bool)
     assert torch.equal(got, ref)
+
+
+def test_multi_copy_pack_unpack():
+    """nmf_multi_copy: gradient pack (fp32 / fp64, any dense layout -> flat fp32) and unpack in one launch each."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(0)
+    ts = [torch.randn(1, 16, 9, 9, generator=gen).to(memory_format=torch.channels_last), torch.randn(70001, generator=gen),
+          torch.tensor(1.2345678901234, dtype=torch.float64), torch.randn(3, 5, generator=gen), torch.randn(0)]
+    td = [t.to(DEV) for t in ts]
+    n = sum(t.numel() for t in ts)
+    flat = torch.full((n,), float("nan"), device=DEV)
+    pack, unpack = (hip.CopySlot * len(ts))(), (hip.CopySlot * len(ts))()
+    out = [torch.full_like(t, float("nan")) for t in td]
+    off = 0
+    for i, (t, o) in enumerate(zip(td, out)):
+        f64 = 1 if t.dtype == torch.float64 else 0
+        pack[i].src, pack[i].dst, pack[i].numel, pack[i].src_is_f64, pack[i].dst_is_f64 = t.data_ptr(), flat.data_ptr() + 4 * off, t.numel(), f64, 0
+        unpack[i].src, unpack[i].dst, unpack[i].numel, unpack[i].src_is_f64, unpack[i].dst_is_f64 = flat.data_ptr() + 4 * off, o.data_ptr(), t.numel(), 0, f64
+        off += t.numel()
+    hip.multi_copy(pack, len(ts))
+    ref = torch.cat([t.permute(0, 2, 3, 1).reshape(-1) if t.dim() == 4 else t.reshape(-1).float() for t in ts])   # memory order
+    assert torch.equal(flat.cpu(), ref)
+    hip.multi_copy(unpack, len(ts))
+    for t, o in zip(ts, out):
+        assert o.stride() == t.stride() or t.numel() <= 1
+        assert torch.equal(o.cpu().float(), t.float())
