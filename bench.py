@@ -146,6 +146,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+        # create the communicator (RCCL ring / tree setup takes seconds) outside every timed or warm-up step
+        dist.all_reduce(torch.zeros(1, device=device))
+        torch.cuda.synchronize()
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "nmf_amd", "lib", "libnmf_hip.so")):
