@@ -16,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, device="cpu"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nmf_amd.trainer import FlatGradAllReduce, rank_slice
@@ -24,20 +24,21 @@ def _worker(rank, world, port, out):
     params = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)),
               torch.nn.Parameter(torch.randn(1, 4, 6, 6).contiguous(memory_format=torch.channels_last)),
               torch.nn.Parameter(torch.tensor(1.0, dtype=torch.float64)), torch.nn.Parameter(torch.randn(2))]
-    rays = torch.arange(10 * 6, dtype=torch.float32).reshape(10, 6)
+    params = [torch.nn.Parameter(p.detach().to(device)) for p in params]
+    rays = torch.arange(10 * 6, dtype=torch.float32, device=device).reshape(10, 6)
     mine = rays[rank_slice(10, world, rank)]
     # a "loss" whose gradient depends on the local shard only; params[4] gets no gradient at all
     loss = (params[0].sum() * mine.sum() + (params[1] ** 2).sum() * (rank + 1) + params[2].mean() * mine[:, 0].sum()
             + params[3] * float(mine.shape[0]))
     loss.backward()
-    local = [p.grad.clone() if p.grad is not None else None for p in params]
+    local = [p.grad.clone().cpu() if p.grad is not None else None for p in params]
     nbytes = FlatGradAllReduce(params)()
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     ok = nbytes == 4 * sum(p.numel() for p in params[:4])
     for i, p in enumerate(params[:4]):
         want = sum(g[i].double() for g in gathered)
-        ok &= bool(torch.allclose(p.grad.double(), want, rtol=1e-6, atol=1e-6))
+        ok &= bool(torch.allclose(p.grad.double().cpu(), want, rtol=1e-6, atol=1e-6))
         ok &= p.grad.shape == p.shape and p.grad.dtype == p.dtype
     ok &= params[4].grad is None
     ok &= params[2].grad.is_contiguous(memory_format=torch.channels_last)
@@ -45,12 +46,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_flat_gradient_allreduce_world2_gloo():
+def _run(device):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
         out = m.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out, device)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -78,3 +79,17 @@ def test_single_process_is_a_noop():
     p = torch.nn.Parameter(torch.ones(3))
     p.grad = torch.ones(3)
     assert FlatGradAllReduce([p])() == 0 and torch.equal(p.grad, torch.ones(3))
+
+
+def test_flat_gradient_allreduce_world2_gloo():
+    _run("cpu")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_flat_gradient_allreduce_world2_device():
+    """same exchange with the gradients on the GPU: nmf_multi_copy pack -> all-reduce -> unpack (two ranks share cuda:0 and
+    reduce through gloo, which is what a 1-GPU box allows; the production backend is RCCL, one rank per GPU)"""
+    _run("cuda:0")
