@@ -209,11 +209,12 @@ def segment_sum(vals, offsets, seg_id, n_seg):
 
 class SatBuild(torch.autograd.Function):
     """Graph node for the cached summed-area table: sat = cumsum_W(cumsum_H(exp(brightness + mul*bg_mat)/1000))
-    (modules/integral_equirect.py:431-433).  Hands out a scalar token; all lookups of the pass accumulate their table
-    adjoints into holder.bufs = (d_sat, d_pole), and the two reverse prefix sums run once here."""
+    (modules/integral_equirect.py:431-433) and for the mip bias.  Hands out a scalar token; all lookups of the pass
+    accumulate their adjoints into holder.bufs = (d_sat [H,W,4], d_pole [2,3], d_mipbias [1]) -- one zero fill for the three --
+    and the two reverse prefix sums run once here."""
 
     @staticmethod
-    def forward(ctx, holder, env, bg_mat, brightness, mul):
+    def forward(ctx, holder, env, bg_mat, brightness, mul, mipbias):
         ctx.env, ctx.holder = env, holder
         return bg_mat.new_zeros(())
 
@@ -221,23 +222,35 @@ class SatBuild(torch.autograd.Function):
     def backward(ctx, _d_token):
         env, holder = ctx.env, ctx.holder
         if holder.bufs is None:
-            return None, None, None, None, None
-        d_sat, d_pole = holder.bufs
+            return None, None, None, None, None, None
+        d_sat, d_pole, d_mip = holder.bufs
         holder.bufs = None
         act, sat, pole = env._tables()
         _, br, mul = env._host_scalars()
         d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, br, mul)    # d_sat is consumed in place
-        d_pre = d_bg / mul                                   # adjoint of (brightness + mul * bg_mat)
-        d_br = d_pre.sum(dtype=torch.float64)
-        d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
-        return None, None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul
+        d_br = d_mul = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            d_pre = d_bg / mul                               # adjoint of (brightness + mul * bg_mat)
+            d_br = d_pre.sum(dtype=torch.float64)
+            d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
+        return None, None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul, d_mip.to(torch.float64).reshape(())
+
+
+def env_grad_buffers(holder, sat):
+    if holder.bufs is None:
+        H, W = sat.shape[-2:]
+        flat = torch.zeros(H * W * 4 + 8, dtype=torch.float32, device=sat.device)
+        holder.bufs = (flat[: H * W * 4].view(H, W, 4), flat[H * W * 4: H * W * 4 + 6].view(2, 3),
+                       flat[H * W * 4 + 6: H * W * 4 + 7])
+    return holder.bufs
 
 
 class EnvLookup(torch.autograd.Function):
-    """IntegralEquirect.forward (modules/integral_equirect.py:409-504) on the cached SAT."""
+    """IntegralEquirect.forward (modules/integral_equirect.py:409-504) on the cached SAT.  The adjoints of the table, of
+    the pole rows and of the mip bias go to the pass's SatBuild node; the direction adjoint is returned here."""
 
     @staticmethod
-    def forward(ctx, env, dirs, sa, mipbias, holder, token):
+    def forward(ctx, env, dirs, sa, holder, token):
         act, sat, pole = env._tables()
         dirs_c = dirs.contiguous()
         sa_c = sa.reshape(-1).contiguous()
@@ -252,15 +265,15 @@ class EnvLookup(torch.autograd.Function):
     def backward(ctx, d_out):
         holder = ctx.holder
         dirs, sa, sat = ctx.saved_tensors
-        want_tab = holder is not None and ctx.needs_input_grad[5]
-        if want_tab and holder.bufs is None:
-            holder.bufs = (torch.zeros(sat.shape[-2:] + (4,), dtype=torch.float32, device=sat.device),   # [H][W][4]
-                           torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
-        d_sat, d_pole = holder.bufs if want_tab else (None, torch.zeros((2, 3), dtype=torch.float32, device=sat.device))
-        d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole,
-                                           want_dirs=ctx.needs_input_grad[1], want_mipbias=ctx.needs_input_grad[3])
-        return (None, d_dirs, None, d_mip.to(torch.float64).reshape(()) if d_mip is not None else None, None,
-                holder.token_grad(d_out) if want_tab else None)
+        want_tab = holder is not None and ctx.needs_input_grad[4]
+        if want_tab:
+            d_sat, d_pole, d_mip = env_grad_buffers(holder, sat)
+        else:
+            d_sat, d_mip = None, None
+            d_pole = torch.zeros((2, 3), dtype=torch.float32, device=sat.device)
+        d_dirs = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole, d_mip,
+                                    want_dirs=ctx.needs_input_grad[1])
+        return None, d_dirs, None, None, holder.token_grad(d_out) if want_tab else None
 
 
 class BrdfFeatures(torch.autograd.Function):

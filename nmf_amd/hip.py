@@ -410,16 +410,20 @@ def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows):
     return out
 
 
-def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, want_dirs=True, want_mipbias=True):
+def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None):
+    """d_sat [H,W,4] / d_pole [2,3] / d_mip [1] are ACCUMULATED into (any may be None except d_pole).  Returns d_dirs; with
+    want_mipbias=True (legacy form) a fresh d_mip accumulator is allocated and (d_dirs, d_mip) is returned."""
     R = dirs.shape[0]
     H, W = sat.shape[-2:]
     d_dirs = torch.empty((R, 3), dtype=torch.float32, device=dirs.device) if want_dirs else None
-    d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device) if want_mipbias else None
+    legacy = want_mipbias is not None
+    if legacy and want_mipbias and d_mip is None:
+        d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
                                    _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias),
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
                                    _stream()), "nmf_sat_lookup_bwd")
-    return d_dirs, d_mip
+    return (d_dirs, d_mip) if legacy else d_dirs
 
 
 # ---- shading helpers -------------------------------------------------------------------------------

@@ -81,7 +81,7 @@ class IntegralEquirect(torch.nn.Module):
             return viewdirs.new_zeros((0, 3))
         sa = saSample.reshape(-1).detach().float()
         holder, token = self._pass_token()
-        return EnvLookup.apply(self, viewdirs.float(), sa, self.mipbias, holder, token)
+        return EnvLookup.apply(self, viewdirs.float(), sa, holder, token)
 
     # ---- gradient pass: every lookup between begin_pass() and end_pass() shares one SatBuild node ---------------
     def begin_pass(self):
@@ -92,12 +92,12 @@ class IntegralEquirect(torch.nn.Module):
 
     def _pass_token(self):
         if not (torch.is_grad_enabled() and (self.bg_mat.requires_grad or self.brightness.requires_grad
-                                             or self.mul.requires_grad)):
+                                             or self.mul.requires_grad or self.mipbias.requires_grad)):
             return None, None
         if self._pass_open and self._pass is not None:
             return self._pass
         holder = GradPass()
-        token = SatBuild.apply(holder, self, self.bg_mat, self.brightness, self.mul)
+        token = SatBuild.apply(holder, self, self.bg_mat, self.brightness, self.mul, self.mipbias)
         if self._pass_open:
             self._pass = (holder, token)
         return holder, token

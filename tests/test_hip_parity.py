@@ -350,7 +350,8 @@ def test_env_lookup_golden_and_gradients():
                                            [sd["bg_module.bg_mat"], sd["bg_module.mipbias"], d_or])
     d_sat = torch.zeros(sat.shape[-2:] + (4,), device=sat.device)        # channel-interleaved adjoint table
     d_pole = torch.zeros(2, 3, device=DEV)
-    d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs.to(DEV).contiguous(), sa.to(DEV).contiguous(), 1.0, c.to(DEV), d_sat, d_pole)
+    d_dirs, d_mip = hip.sat_lookup_bwd(sat, dirs.to(DEV).contiguous(), sa.to(DEV).contiguous(), 1.0, c.to(DEV), d_sat, d_pole,
+                                       want_mipbias=True)
     d_bg = hip.sat_build_bwd(d_sat, bg.to(DEV), act, d_pole)
     assert_close(d_bg.cpu()[None], gb_o, rtol=2e-3, atol=2e-4 * float(gb_o.abs().max()), what="grad bg_mat")
     assert_close(d_dirs.cpu(), gd_o, rtol=5e-3, atol=5e-4 * float(gd_o.abs().max()), what="grad dirs")
