@@ -473,6 +473,68 @@ class RayCompose(torch.autograd.Function):
         return (d_weight, d_refl if ctx.needs_input_grad[1] else None, d_normals, d_bg) + (None,) * 9
 
 
+class BounceRays(torch.autograd.Function):
+    """Sparse training / inference path: everything between "these samples spawn secondary rays" and the secondary rays with
+    their BRDF weights as ONE graph node -- appearance features of the bounce rows (VMAppQuery), material heads
+    (MaterialHeads), row preparation (BouncePrep, row_inputs), GGX rays (GgxRays) and the BRDF MLP (BrdfMLP), i.e. the same
+    seven C-ABI calls forward and backward, minus four nodes of autograd bookkeeping per recursion level.  `c` carries the
+    no-grad inputs; parameter gradients leave through the three pass tokens.
+    Returns L, half_local, diff_local, lpdf, mipval, bounce_rays, brdf_weight, V_rows, f0_rows, diffuse_rows, N_rows."""
+
+    @staticmethod
+    def forward(ctx, normals, c, tok_field, tok_heads, tok_mlp):
+        normals = normals.contiguous()
+        p, dpk, dlk, apl, ali, basis = c.field._tables()
+        app = hip.vm_query_fwd(p, c.xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False,
+                               want_app=True)[4]
+        heads = hip.heads_fwd(app, c.head_W, c.head_b, c.head_hp)
+        V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(c.bidx, normals, app, heads, c.xyzt, c.ray_id, c.rays, c.conv,
+                                                           c.feat_noise, c.anoise, c.min_rough, True)
+        L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, c.off, c.cnt, c.sobol, c.row_of_ray, c.j_of_ray)
+        brdf = hip.brdf_mlp_fwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias)
+        ctx.c = c
+        ctx.save_for_backward(normals, app, heads, V, N, r1, feat, hl, dl)
+        N_out = N.detach().clone()
+        ctx.mark_non_differentiable(hl, dl, lpdf, mip, V, N_out)
+        ctx.set_materialize_grads(False)
+        return L, hl, dl, lpdf, mip, brays, brdf, V, f0, diff, N_out
+
+    @staticmethod
+    def backward(ctx, dL, _hl, _dl, _lp, _mip, d_brays, d_brdf, _dV, d_f0, d_diff, _dN):
+        c = ctx.c
+        normals, app, heads, V, N, r1, feat, hl, dl = ctx.saved_tensors
+        Mb = V.shape[0]
+        cc = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_feat = None
+        if d_brdf is not None:
+            grads = grad_views(c.mlp_holder, c.mlp_ws) if c.mlp_holder is not None else [torch.zeros_like(w) for w in c.mlp_ws]
+            d_xfeat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias, d_brdf, grads)
+            d_feat = hip.segment_sum_wide(d_xfeat, 24, c.row_off, Mb)
+        dN = dr1 = None
+        if dL is not None or d_brays is not None:
+            d_nr = hip.ggx_rays_bwd(V, N, r1, c.off, c.sobol, c.row_of_ray, c.j_of_ray, cc(dL), cc(d_brays))
+            rows4 = hip.segment_sum(d_nr, None, c.row_off, Mb)
+            dN, dr1 = rows4[:, 0:3], rows4[:, 3]
+        d_normals, d_heads, d_app = hip.bounce_prep_bwd(c.inv, normals, heads, c.ray_id, c.rays, c.conv, c.min_rough,
+                                                        c.detach_n, dN, dr1, d_f0, d_diff, d_feat, bidx=c.bidx,
+                                                        row_inputs=True)
+        if c.head_holder is not None:
+            gW, gb = grad_views(c.head_holder, [c.head_W, c.head_b])
+        else:
+            gW, gb = torch.zeros_like(c.head_W), torch.zeros_like(c.head_b)
+        d_app.add_(hip.heads_bwd(app, c.head_W, c.head_b, c.head_hp, d_heads, gW, gb))
+        tf = None
+        if c.field_holder is not None:
+            p, dpk, dlk, apl, ali, basis = c.field._tables()
+            g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(c.field_holder, p.grid, d_app.device)
+            hip.vm_query_bwd(p, c.xyz_rows, dpk, dlk, apl, ali, basis, None, None, None, None, None, d_app,
+                             g_dpk, g_dlk, g_apl, g_ali, g_basis)
+            tf = c.field_holder.token_grad(d_app)
+        th = c.head_holder.token_grad(d_app) if c.head_holder is not None else None
+        tm = c.mlp_holder.token_grad(d_app) if (c.mlp_holder is not None and d_brdf is not None) else None
+        return (None if c.detach_n else d_normals), None, tf, th, tm
+
+
 def brdf_mlp(half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, weights, owner=None):
     """BrdfMLP with its gradient pass: `owner` (a PassMixin module) shares one ParamGrads node per forward/backward pass;
     without an owner the call gets a node of its own."""

@@ -4,11 +4,12 @@ for diffuse_mixing_mode='fresnel', no_emitters=True, russian_roulette=False.
 Works on the compact sample list (weights [M] + ray offsets) instead of the dense [rays x N] matrices, and on
 a compact secondary-ray list (row_of_ray, j_of_ray) instead of the padded [bounce points x m] ray_mask."""
 import math
+import types
 
 import torch
 
 from .. import hip
-from ..functional import BouncePrep, GgxRays, ShadeMix
+from ..functional import BouncePrep, BounceRays, GgxRays, ShadeMix
 from ..modules import sh
 from ..brdf_samplers.ggx import mat3T_vec, normalize
 
@@ -150,18 +151,28 @@ class Microfacet(torch.nn.Module):
         bidx, row_off, cnt32 = bidx[:Mb], row_off[:Mb + 1], cnt32[:Mb]
         row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)            # = torch.where(ray_mask)
         off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2)                                              # base.py:18
-        if sparse:      # appearance, its noise and the heads on the bounce rows only
-            app_in = app_fn(torch.index_select(samples.xyzt, 0, bidx.long()))
-            feat_noise = noise.rows(deferred, bidx)
-            heads_in = self.diffuse_module.heads(app_in)                                             # :299
+        if sparse:      # appearance, its noise, the heads, GGX rays and BRDF weights of the bounce rows: one graph node
+            c = types.SimpleNamespace()
+            c.field = field = app_fn.__self__
+            c.xyz_rows = torch.index_select(samples.xyzt, 0, bidx.long())
+            c.field_holder, tok_field = field._pass_token()
+            c.head_hp, c.head_W, c.head_b, c.head_holder, tok_heads = self.diffuse_module.head_pass()            # :299
+            c.mlp_ws, c.mlp_bias, c.mlp_holder, tok_mlp = self.brdf.mlp_pass()
+            c.bidx, c.inv, c.xyzt, c.ray_id, c.rays, c.conv = bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv
+            c.feat_noise = noise.rows(deferred, bidx)                                                # :297
+            c.anoise, c.min_rough = float(self.anoise), float(self.min_rough) if is_train else -1e30
+            c.detach_n = bool(self.detach_N)
+            c.off, c.cnt, c.sobol = off.contiguous(), cnt32, self.brdf_sampler.angs
+            c.row_of_ray, c.j_of_ray, c.row_off = row_of_ray, j_of_ray, row_off
+            L, halfvec, diffvec, lpdf, mipval, bounce_rays, brdf_weight, bV, f0, diffuse, bN = BounceRays.apply(
+                normals, c, tok_field, tok_heads, tok_mlp)                                            # :352-472
         else:
-            app_in, heads_in = app_features, heads
-        bV, bN, r1, f0, diffuse, feat, xyz = BouncePrep.apply(
-            normals, app_in, heads_in, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,
-            float(self.anoise), float(self.min_rough) if is_train else -1e30, bool(self.detach_N), sparse)   # :352-361
-        L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                             # :367-456
-            bV, bN, r1, xyz, off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray, row_off)
-        brdf_weight = self.brdf.forward_compact(halfvec, diffvec, feat, r1, row_of_ray, row_off)
+            bV, bN, r1, f0, diffuse, feat, xyz = BouncePrep.apply(
+                normals, app_features, heads, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,
+                float(self.anoise), float(self.min_rough) if is_train else -1e30, bool(self.detach_N), False)   # :352-361
+            L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
+                bV, bN, r1, xyz, off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray, row_off)
+            brdf_weight = self.brdf.forward_compact(halfvec, diffvec, feat, r1, row_of_ray, row_off)
         if self.trace is not None:
             self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
                                f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,

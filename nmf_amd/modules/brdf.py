@@ -39,6 +39,15 @@ class MLPBRDF(PassMixin, torch.nn.Module):
         self.init_val = 0.25
         self.fused = kwargs.get("hidden_w", 128) == 64 and kwargs.get("num_layers", 0) == 3
 
+    def mlp_pass(self):
+        """(weights, bias, holder, token) for fused callers (functional.BounceRays)"""
+        if not self.fused:
+            raise NotImplementedError("the fused path implements hidden_w=64, num_layers=3 (microfacet_tensorf2.yaml:86-104)")
+        m = self.mlp
+        ws = (m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+        holder, token = self._param_pass(ws)
+        return [w.detach().contiguous() for w in ws], float(self.bias), holder, token
+
     def forward_compact(self, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
         if self.fused:
             m = self.mlp

@@ -34,6 +34,29 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
         return (self.diffuse_mlp[0].weight, self.diffuse_mlp[0].bias, self.tint_mlp[0].weight, self.tint_mlp[0].bias,
                 self.f0_mlp[0].weight, self.f0_mlp[0].bias, self.roughness_mlp[0].weight, self.roughness_mlp[0].bias)
 
+    def head_pass(self):
+        """(hp, W [11,24], b [11], holder, token) for fused callers (functional.BounceRays): the stacked head weights of the
+        current parameter version and the gradient pass they accumulate into"""
+        from ..functional import GradPass, StackedHeadGrads
+        hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
+              float(self.roughness_bias))
+        ps = self._head_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._stacked is None or self._stacked[0] != key:
+            self._stacked = (key, (torch.cat([p.detach() for p in ps[0::2]], 0).contiguous(),
+                                   torch.cat([p.detach() for p in ps[1::2]], 0).contiguous()))
+        W, b = self._stacked[1]
+        holder, token = None, None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ps):
+            if self._pass_open and self._pass is not None:
+                holder, token = self._pass
+            else:
+                holder = GradPass()
+                token = StackedHeadGrads.apply(holder, *ps)
+                if self._pass_open:
+                    self._pass = (holder, token)
+        return hp, W, b, holder, token
+
     def heads(self, features):
         """[M,11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied (nmf_heads_fwd)."""
         if features.shape[0] == 0:
