@@ -37,12 +37,32 @@ __device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const floa
     return c;
 }
 
+// The four uniforms of one Philox counter belong to four CONSECUTIVE steps, and a wave walks 64 steps per round: instead of
+// every lane running the 10 Philox rounds for its own step (and discarding 3 of the 4 outputs), lane l evaluates counter
+// 64 g + l once per GROUP of four rounds (steps [256 g, 256 g + 256)) and the rounds fetch their uniform with shuffles.
+// Same stream, same values: ~100 of ~190 VALU instructions per step gone (the marcher is VALU-bound).
+struct JitterCache {
+    uint32_t o[4];
+};
+__device__ __forceinline__ void jc_fill(JitterCache& c, const Philox& rng, const nmf_march_params& p, int64_t r, int g) {
+    rng((uint64_t)r * 1024u + (uint64_t)(64 * g + lane_id()), p.offset, c.o);
+}
+// uniform of step 256 g + k_local (all lanes of the wave must call this together)
+__device__ __forceinline__ float jc_get(const JitterCache& c, int k_local) {
+    const int src = (k_local >> 2) & 63, comp = k_local & 3;
+    const uint32_t v0 = __shfl(c.o[0], src, 64), v1 = __shfl(c.o[1], src, 64);
+    const uint32_t v2 = __shfl(c.o[2], src, 64), v3 = __shfl(c.o[3], src, 64);
+    return u32_to_unit(comp == 0 ? v0 : (comp == 1 ? v1 : (comp == 2 ? v2 : v3)));
+}
+
 // step length of candidate k (train) -- alphagrid.py:169-172
 __device__ __forceinline__ float step_len(const nmf_march_params& p, const float* jitter, const Philox& rng,
-                                          int64_t r, int k) {
+                                          int64_t r, int k, const JitterCache* jc = nullptr) {
     float u;
     if (jitter) {
         u = jitter[r * p.n_steps + k];
+    } else if (jc) {
+        u = jc_get(*jc, k & 255);
     } else {
         uint32_t o[4];
         rng((uint64_t)r * 1024u + (uint64_t)(k >> 2), p.offset, o);
@@ -113,12 +133,13 @@ struct StepOut {
 
 __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const RayCtx& c, const float* jitter,
                                              const Philox& rng, const uint32_t* bits, const uint32_t* coarse, int64_t r,
-                                             int k, double& carry, double* cum_out) {
+                                             int k, double& carry, double* cum_out, const JitterCache* jc = nullptr) {
     const bool in_range = k < p.n_steps;
     float step;
     double cum = 0.0;
     if (p.is_train) {
-        float s = in_range ? step_len(p, jitter, rng, r, k) : 0.f;
+        float s = step_len(p, jitter, rng, r, in_range ? k : 0, jc);      // wave-uniform call (shuffles inside)
+        s = in_range ? s : 0.f;
         double incl = wave_incl_scan((double)s);
         cum = carry + incl;
         carry += __shfl(incl, 63, 64);
@@ -161,8 +182,12 @@ __global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const f
         double carry = 0.0;
         int total = 0;
         int j = 0;
+        JitterCache jc;
+        const bool use_jc = p.is_train && !jitter;
         for (; j < W; ++j) {
-            StepOut o = march_one(p, c, jitter, rng, bits, s_coarse, r, j * 64 + lane, carry, nullptr);
+            if (use_jc && (j & 3) == 0) jc_fill(jc, rng, p, r, j >> 2);
+            StepOut o = march_one(p, c, jitter, rng, bits, s_coarse, r, j * 64 + lane, carry, nullptr,
+                                  use_jc ? &jc : nullptr);
             uint64_t m = __ballot(o.keep);
             total += __popcll(m);
             if (lane == 0) valid[r * W + j] = m;

@@ -853,3 +853,50 @@ def test_multi_copy_pack_unpack():
     for t, o in zip(ts, out):
         assert o.stride() == t.stride() or t.numel() <= 1
         assert torch.equal(o.cpu().float(), t.float())
+
+
+def _philox4x32_10(ctr_lo, ctr_hi, seed):
+    """numpy Philox4x32-10 exactly as csrc/common.hpp: counter (lo64, hi64), key = seed (lo32, hi32) -> [n, 4] uint32"""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c = [np.asarray(ctr_lo & 0xffffffff, np.uint64), np.asarray(ctr_lo >> 32, np.uint64),
+         np.full_like(np.asarray(ctr_lo, np.uint64), ctr_hi & 0xffffffff), np.full_like(np.asarray(ctr_lo, np.uint64), ctr_hi >> 32)]
+    a, b = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & np.uint64(0xffffffff), p1 >> np.uint64(32), p1 & np.uint64(0xffffffff)
+        c = [hi1 ^ c[1] ^ a, lo1, hi0 ^ c[3] ^ b, lo0]
+        a, b = (a + np.uint64(0x9E3779B9)) & np.uint64(0xffffffff), (b + np.uint64(0xBB67AE85)) & np.uint64(0xffffffff)
+    return np.stack(c, -1).astype(np.uint32)
+
+
+def test_march_in_kernel_philox_equals_explicit_jitter():
+    """The in-kernel jitter (Philox4x32-10 keyed by seed / offset, counter = ray * 1024 + step / 4, one counter evaluation
+    shared by four steps and fetched with wave shuffles) must reproduce the stream exactly: feeding the same uniforms as an
+    explicit jitter tensor gives bit-identical masks, counts, positions and distances."""
+    hip = _hip()
+    cfg = O.Cfg(grid=40)
+    d = cfg.derived()
+    G, B, N = 40, 777, d["n_samples"]
+    gen = torch.Generator().manual_seed(4)
+    vol = (torch.rand(G, G, G, generator=gen) < 0.05).float()
+    rays = torch.cat([torch.randn(B, 3, generator=gen) * 2.5, torch.randn(B, 3, generator=gen)], -1)
+    rays[:, 3:] /= rays[:, 3:].norm(dim=-1, keepdim=True)
+    seed, offset = 0x9E3779B9, 12345
+    aabb = d["aabb"]
+    p = hip.march_params(aabb, (1.0 / (aabb[1] - aabb[0]) * 2).numpy(), float(d["stepsize"]), 0.2, 7.0, 900.0, N, (G, G, G),
+                         True, seed=seed, offset=offset)
+    r_idx = np.arange(B, dtype=np.uint64)[:, None] * np.uint64(1024) + (np.arange(N, dtype=np.uint64)[None, :] >> np.uint64(2))
+    o = _philox4x32_10(r_idx.reshape(-1), offset, seed).reshape(B, N, 4)
+    u32 = np.take_along_axis(o, (np.arange(N)[None, :, None] & 3).repeat(B, 0), axis=2)[..., 0]
+    U = torch.from_numpy(((u32 >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)))
+    rays_d, bits = rays.to(DEV).contiguous(), hip.alpha_pack(vol.to(DEV).reshape(-1))
+    coarse = hip.alpha_coarse(bits, (G, G, G))
+    outs = []
+    for jit in (None, U.to(DEV).contiguous()):
+        valid, counts = hip.march_count(p, rays_d, jit, bits, coarse)
+        offsets, wv, totals = hip.march_scan(counts, -1)
+        M, b = [int(v) for v in totals.cpu()]
+        outs.append((valid, counts) + tuple(hip.march_fill(p, rays_d, b, M, jit, valid, offsets)))
+    assert int(outs[0][1].sum()) > 1000
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
