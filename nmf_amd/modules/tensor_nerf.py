@@ -113,6 +113,10 @@ class TensorNeRF(torch.nn.Module):
                                   getattr(self.model, "diffuse_module", None)) if hasattr(m, "begin_pass")]
             for m in passes:
                 m.begin_pass()
+            # derived tables of the field (packed density planes) depend only on the parameters: queue their rebuild now, so
+            # that it is issued while the GPU may still be busy with the previous step and before the sampler's read-back
+            if rays.is_cuda:
+                self.rf._tables()
             try:
                 return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
                                     dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples,

@@ -165,6 +165,22 @@ class Trainer:
             self.num_rays = p["starting_batch_size"]
             nerf.model.reset_counter()
         self.iteration += 1
-        loss_sum = float(torch.stack(losses).sum()) if losses else 0.0
-        return dict(rays=used_rays, loss=loss_sum, n_samples=n_samples_last, comm_bytes=comm_bytes,
-                    psnr=(-10.0 * math.log10(max(loss_sum / max(used_rays * 3, 1), 1e-12))))
+        return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes)
+
+
+class StepStats(dict):
+    """What Trainer.step returns: rays / n_samples / comm_bytes are host values; `loss` (sum of squared errors over the
+    step's rays) and `psnr` (train-PSNR proxy, train.py:609-613) live on the device until first read, so a training loop that
+    does not log every step never waits for the GPU at the end of a step."""
+
+    def __init__(self, losses, **kw):
+        super().__init__(**kw)
+        self._losses = losses
+
+    def __missing__(self, key):
+        if key not in ("loss", "psnr"):
+            raise KeyError(key)
+        loss_sum = float(torch.stack(self._losses).sum()) if self._losses else 0.0
+        self["loss"] = loss_sum
+        self["psnr"] = -10.0 * math.log10(max(loss_sum / max(self["rays"] * 3, 1), 1e-12))
+        return self[key]
