@@ -163,26 +163,29 @@ int nmf_segment_sum(const float* vals, const float* scale, const int64_t* offset
  * Environment map: IntegralEquirect (modules/integral_equirect.py:18-173,373-504), activation 'exp'.
  * bg_mat / activated / sat are [3][H][W] fp32.  The summed-area table reproduces torch's CPU
  * rounding (float64 running sums rounded per element, H then W, :433).
+ * scalars_dev (optional, DEVICE float[3] = mipbias, brightness, mul) overrides the by-value scalars so that the
+ * three learnable 0-d parameters never have to be read back to the host.
  * ---------------------------------------------------------------------------------------- */
 /* activated = exp(min(brightness + mul*bg_mat, 20)); sat = cumsum_W(cumsum_H(activated/1000)). */
 int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
-                  float* activated, float* sat, void* stream);
+                  const float* scalars_dev, float* activated, float* sat, void* stream);
 /* d_sat = channel-interleaved adjoint table [H][W][4] (4th lane unused; accumulated by nmf_sat_lookup_bwd;
  * DESTROYED here) -> d_bg [3][H][W] (overwritten).
  * d_pole [2][3]: adjoint of the (top,bottom) pole-row means, may be NULL. */
 int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float* activated, int32_t H, int32_t W,
-                      float brightness, float mul, const float* d_pole, float* d_bg, void* stream);
+                      float brightness, float mul, const float* scalars_dev, const float* d_pole, float* d_bg,
+                      void* stream);
 /* out[r] = prefiltered radiance along dirs[r] for log-solid-angle sa[r] (IntegralEquirect.forward).
  * pole_rows [2][3] = mean of the first / last row of `activated` (:499-502). */
 int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs /*[R][3]*/,
-                       const float* sa /*[R]*/, int64_t R, float mipbias, const float* pole_rows,
-                       float* out /*[R][3]*/, void* stream);
+                       const float* sa /*[R]*/, int64_t R, float mipbias, const float* scalars_dev,
+                       const float* pole_rows, float* out /*[R][3]*/, void* stream);
 /* Adjoints: d_sat [H][W][4] (channel-interleaved so that 8 lanes share one 32-byte atomic run, see csrc/env.hip) and
  * d_pole [2][3] are ACCUMULATED (caller zeroes), d_dirs [R][3] is overwritten, d_mipbias [1] accumulated.
  * d_sat / d_dirs / d_mipbias may be NULL. */
 int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
-                       int64_t R, float mipbias, const float* d_out /*[R][3]*/, float* d_sat,
-                       float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
+                       int64_t R, float mipbias, const float* scalars_dev, const float* d_out /*[R][3]*/,
+                       float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shading helpers.

@@ -241,10 +241,12 @@ struct ListAcc {   // table adjoint, phase 1: park (texel, fractions, sign) of e
 // ---- kernels -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs,
                                                         const float* __restrict__ sa, int64_t R, float mipbias,
+                                                        const float* __restrict__ sc,
                                                         const float* __restrict__ pole_rows /*[2][3] top,bot*/,
                                                         float* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    if (sc) mipbias = sc[0];
     const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
     Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
     SumAcc<float> acc;
@@ -261,6 +263,7 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
 
 __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs,
                                                        const float* __restrict__ sa, int64_t R, float mipbias,
+                                                       const float* __restrict__ sc,
                                                        const float* __restrict__ d_out, float* __restrict__ d_sat4,
                                                        float* __restrict__ d_pole /*[2][3]*/,
                                                        float* __restrict__ d_dirs, float* __restrict__ d_mipbias) {
@@ -269,6 +272,7 @@ __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* 
     __shared__ int s_n[64];
     const int lane = threadIdx.x;
     const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    if (sc) mipbias = sc[0];
     float dm = 0.f;
     int n_corner = 0;
     float gk[3] = {0.f, 0.f, 0.f};
@@ -347,7 +351,9 @@ __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* 
 // (a lane-per-column walk is a 512-deep dependent chain on only 3072 lanes: 0.2-0.5 ms; the map is L2-resident, so
 // the stride-W accesses of this layout are cheap)
 __global__ void __launch_bounds__(256) k_sat_cols(const float* __restrict__ bg, int H, int W, float brightness,
-                                                  float mul, float* __restrict__ act, float* __restrict__ sat) {
+                                                  float mul, const float* __restrict__ sc, float* __restrict__ act,
+                                                  float* __restrict__ sat) {
+    if (sc) { brightness = sc[1]; mul = sc[2]; }
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= 3 * W) return;
     const int c = col / W, x = col % W, lane = lane_id();
@@ -405,10 +411,11 @@ __global__ void __launch_bounds__(256) k_sat_rows_rev(float* __restrict__ dsat4,
 
 __global__ void __launch_bounds__(256) k_sat_cols_rev(const float* __restrict__ dsat, const float* __restrict__ bg,
                                                       const float* __restrict__ act, int H, int W, float brightness,
-                                                      float mul, const float* __restrict__ d_pole,
-                                                      float* __restrict__ d_bg) {
+                                                      float mul, const float* __restrict__ sc,
+                                                      const float* __restrict__ d_pole, float* __restrict__ d_bg) {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= 3 * W) return;
+    if (sc) { brightness = sc[1]; mul = sc[2]; }
     const int c = col / W, x = col % W, lane = lane_id();
     double carry = 0.0;
     for (int y0 = 0; y0 < H; y0 += 64) {
@@ -429,49 +436,51 @@ __global__ void __launch_bounds__(256) k_sat_cols_rev(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul, float* activated,
-                             float* sat, void* stream) {
+extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
+                             const float* scalars_dev, float* activated, float* sat, void* stream) {
     NMF_REQUIRE(bg_mat && activated && sat && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build: null/size");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sat_cols, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
-                       activated, sat);
+                       scalars_dev, activated, sat);
     hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W);
     NMF_CHECK_LAUNCH("nmf_sat_build");
     return NMF_OK;
 }
 
 extern "C" int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float* activated, int32_t H, int32_t W,
-                                 float brightness, float mul, const float* d_pole, float* d_bg, void* stream) {
+                                 float brightness, float mul, const float* scalars_dev, const float* d_pole, float* d_bg,
+                                 void* stream) {
     NMF_REQUIRE(d_sat && bg_mat && activated && d_bg && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build_bwd: null/size");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sat_rows_rev, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, d_sat, H, W);
     hipLaunchKernelGGL(k_sat_cols_rev, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, d_sat, bg_mat, activated, H,
-                       W, brightness, mul, d_pole, d_bg);
+                       W, brightness, mul, scalars_dev, d_pole, d_bg);
     NMF_CHECK_LAUNCH("nmf_sat_build_bwd");
     return NMF_OK;
 }
 
 extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
-                                  int64_t R, float mipbias, const float* pole_rows, float* out, void* stream) {
+                                  int64_t R, float mipbias, const float* scalars_dev, const float* pole_rows, float* out,
+                                  void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_fwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && pole_rows && out, NMF_EINVAL, "nmf_sat_lookup_fwd: null");
     EnvTab tab{sat, H, W};
     hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs, sa,
-                       R, mipbias, pole_rows, out);
+                       R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
     return NMF_OK;
 }
 
 extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
-                                  int64_t R, float mipbias, const float* d_out, float* d_sat, float* d_pole,
-                                  float* d_dirs, float* d_mipbias, void* stream) {
+                                  int64_t R, float mipbias, const float* scalars_dev, const float* d_out, float* d_sat,
+                                  float* d_pole, float* d_dirs, float* d_mipbias, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
     EnvTab tab{sat, H, W};
     hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, tab, dirs, sa,
-                       R, mipbias, d_out, d_sat, d_pole, d_dirs, d_mipbias);
+                       R, mipbias, scalars_dev, d_out, d_sat, d_pole, d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
     return NMF_OK;
 }

@@ -226,11 +226,11 @@ class SatBuild(torch.autograd.Function):
         d_sat, d_pole, d_mip = holder.bufs
         holder.bufs = None
         act, sat, pole = env._tables()
-        _, br, mul = env._host_scalars()
-        d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, br, mul)    # d_sat is consumed in place
+        sc = env._dev_scalars()
+        d_bg = hip.sat_build_bwd(d_sat, env.bg_mat.detach(), act, d_pole, sc=sc)    # d_sat is consumed in place
         d_br = d_mul = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            d_pre = d_bg / mul                               # adjoint of (brightness + mul * bg_mat)
+            d_pre = d_bg / sc[2]                             # adjoint of (brightness + mul * bg_mat)
             d_br = d_pre.sum(dtype=torch.float64)
             d_mul = (d_pre * env.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)
         return None, None, d_bg.reshape(env.bg_mat.shape), d_br, d_mul, d_mip.to(torch.float64).reshape(())
@@ -254,25 +254,24 @@ class EnvLookup(torch.autograd.Function):
         act, sat, pole = env._tables()
         dirs_c = dirs.contiguous()
         sa_c = sa.reshape(-1).contiguous()
-        mip = env._host_scalars()[0]
-        out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, mip, pole)
+        sc = env._dev_scalars()
+        out = hip.sat_lookup_fwd(sat, dirs_c, sa_c, 0.0, pole, sc=sc)
         ctx.env, ctx.holder = env, holder
-        ctx.save_for_backward(dirs_c, sa_c, sat)
-        ctx.mip = mip
+        ctx.save_for_backward(dirs_c, sa_c, sat, sc)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         holder = ctx.holder
-        dirs, sa, sat = ctx.saved_tensors
+        dirs, sa, sat, sc = ctx.saved_tensors
         want_tab = holder is not None and ctx.needs_input_grad[4]
         if want_tab:
             d_sat, d_pole, d_mip = env_grad_buffers(holder, sat)
         else:
             d_sat, d_mip = None, None
             d_pole = torch.zeros((2, 3), dtype=torch.float32, device=sat.device)
-        d_dirs = hip.sat_lookup_bwd(sat, dirs, sa, ctx.mip, d_out.contiguous(), d_sat, d_pole, d_mip,
-                                    want_dirs=ctx.needs_input_grad[1])
+        d_dirs = hip.sat_lookup_bwd(sat, dirs, sa, 0.0, d_out.contiguous(), d_sat, d_pole, d_mip,
+                                    want_dirs=ctx.needs_input_grad[1], sc=sc)
         return None, d_dirs, None, None, holder.token_grad(d_out) if want_tab else None
 
 

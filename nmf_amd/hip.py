@@ -379,38 +379,39 @@ def segment_sum(vals, scale, offsets, n_seg):
 
 
 # ---- environment map ---------------------------------------------------------------------------
-def sat_build(bg_mat, brightness=0.0, mul=1.0):
-    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W]."""
+def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None):
+    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W].  sc: optional device float32 [3] = (mipbias, brightness, mul)
+    read by the kernels instead of the by-value scalars (no host read-back of the parameters)."""
     bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
     H, W = bg.shape[-2:]
     act = torch.empty_like(bg)
     sat = torch.empty_like(bg)
     _check(_lib.nmf_sat_build(_p(bg.contiguous(), torch.float32), C.c_int32(H), C.c_int32(W), C.c_float(brightness),
-                              C.c_float(mul), _p(act), _p(sat), _stream()), "nmf_sat_build")
+                              C.c_float(mul), _p(sc), _p(act), _p(sat), _stream()), "nmf_sat_build")
     return act, sat
 
 
-def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0):
+def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None):
     bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
     H, W = bg.shape[-2:]
     d_bg = torch.empty_like(bg)
     _check(_lib.nmf_sat_build_bwd(_p(d_sat, torch.float32), _p(bg.contiguous(), torch.float32), _p(act), C.c_int32(H),
-                                  C.c_int32(W), C.c_float(brightness), C.c_float(mul), _p(d_pole), _p(d_bg), _stream()),
+                                  C.c_int32(W), C.c_float(brightness), C.c_float(mul), _p(sc), _p(d_pole), _p(d_bg), _stream()),
            "nmf_sat_build_bwd")
     return d_bg
 
 
-def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows):
+def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
     R = dirs.shape[0]
     H, W = sat.shape[-2:]
     out = torch.empty((R, 3), dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_fwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(pole_rows), _p(out),
+                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), _p(pole_rows), _p(out),
                                    _stream()), "nmf_sat_lookup_fwd")
     return out
 
 
-def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None):
+def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
     """d_sat [H,W,4] / d_pole [2,3] / d_mip [1] are ACCUMULATED into (any may be None except d_pole).  Returns d_dirs; with
     want_mipbias=True (legacy form) a fresh d_mip accumulator is allocated and (d_dirs, d_mip) is returned."""
     R = dirs.shape[0]
@@ -420,7 +421,7 @@ def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, wan
     if legacy and want_mipbias and d_mip is None:
         d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias),
+                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc),
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
                                    _stream()), "nmf_sat_lookup_bwd")
     return (d_dirs, d_mip) if legacy else d_dirs

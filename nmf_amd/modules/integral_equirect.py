@@ -53,19 +53,24 @@ class IntegralEquirect(torch.nn.Module):
     def get_device(self):
         return self.bg_mat.device
 
-    def _host_scalars(self):
-        key = (self.mipbias._version, self.brightness._version, self.mul._version)
+    def _dev_scalars(self):
+        """float32 [3] = (mipbias, brightness, mul) on the device, refreshed when a parameter changes: the kernels read the
+        three learnable scalars from here, so an optimizer update never forces a host read-back"""
+        key = (self.mipbias._version, self.brightness._version, self.mul._version, self.mipbias.data_ptr())
         if self._scalars is None or self._scalars[0] != key:
-            # one read-back for the three 0-d parameters
-            vals = torch.stack([self.mipbias.detach(), self.brightness.detach(), self.mul.detach()]).tolist()
-            self._scalars = (key, tuple(float(v) for v in vals))
+            with torch.no_grad():
+                sc = torch.stack([self.mipbias.detach(), self.brightness.detach(), self.mul.detach()]).float().contiguous()
+            self._scalars = (key, sc)
         return self._scalars[1]
 
+    def _host_scalars(self):
+        """(mipbias, brightness, mul) as python floats (one read-back; used by tests / tools, not by the render path)"""
+        return tuple(float(v) for v in self._dev_scalars().tolist())
+
     def _tables(self):
-        key = (self.bg_mat.data_ptr(), self.bg_mat._version) + self._host_scalars()[1:]
+        key = (self.bg_mat.data_ptr(), self.bg_mat._version, self.brightness._version, self.mul._version)
         if self._cache is None or self._cache[0] != key:
-            _, br, mul = self._host_scalars()
-            act, sat = hip.sat_build(self.bg_mat.detach(), br, mul)
+            act, sat = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars())
             pole = torch.stack([act[:, 0, :].mean(-1), act[:, -1, :].mean(-1)]).contiguous()
             self._cache = (key, (act, sat, pole))
         return self._cache[1]
@@ -105,7 +110,8 @@ class IntegralEquirect(torch.nn.Module):
     @torch.no_grad()
     def get_spherical_harmonics(self, G, mipval=-5):
         """modules/integral_equirect.py:324-360; cached per bg_mat version (the reference recomputes it)."""
-        key = (self.bg_mat.data_ptr(), self.bg_mat._version, G, mipval) + self._host_scalars()
+        key = (self.bg_mat.data_ptr(), self.bg_mat._version, G, mipval, self.mipbias._version, self.brightness._version,
+               self.mul._version)
         if self._sh_cache is None or self._sh_cache[0] != key:
             dev = self.get_device()
             ck = (G, float(mipval), str(dev))
@@ -121,7 +127,7 @@ class IntegralEquirect(torch.nn.Module):
                 self._sh_const = (ck, dirs, torch.full((SB,), float(mipval), device=dev), wq.reshape(SB, 9, 1).contiguous())
             _, dirs, mips, wq = self._sh_const
             act, sat, pole = self._tables()
-            bg = hip.sat_lookup_fwd(sat, dirs, mips, self._host_scalars()[0], pole)
+            bg = hip.sat_lookup_fwd(sat, dirs, mips, 0.0, pole, sc=self._dev_scalars())
             coeffs = (wq * bg.reshape(-1, 1, 3)).sum(dim=0)
             conv = self.sh_A.reshape(-1, 1)[: coeffs.shape[0]] * coeffs
             self._sh_cache = (key, (coeffs, (conv / np.pi).contiguous()))

@@ -117,6 +117,10 @@ class TensorNeRF(torch.nn.Module):
             # that it is issued while the GPU may still be busy with the previous step and before the sampler's read-back
             if rays.is_cuda:
                 self.rf._tables()
+                if hasattr(self.bg_module, "_tables"):          # summed-area table + SH projection of the environment
+                    self.bg_module._tables()
+                    if hasattr(self.model, "brdf"):             # the microfacet model's diffuse irradiance (G=100)
+                        self.bg_module.get_spherical_harmonics(100)
             try:
                 return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
                                     dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples,
