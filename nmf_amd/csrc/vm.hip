@@ -372,8 +372,15 @@ __device__ __forceinline__ RunInfo wave_runs(int key, bool active) {
     return r;
 }
 
+// Counter copies: the hot bricks (the visible surface) are few and neighbours share 128-byte lines, and L2 executes the
+// atomics of one line one after the other -- 0.24 M runs of the 0.88 M secondary-ray samples on ~100 hot lines cost 84 us
+// in the histogram and 90 us in the scatter.  Every brick therefore has KC counters (wave w of the launch uses copy
+// w % KC, the same wave in both kernels); the scan runs over the flat [brick][copy] array, so copy k of a brick owns the
+// slice of the brick's segment that follows copies < k.
+__device__ __forceinline__ int bin_copy(int kc) { return (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kc - 1)); }
+
 __global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
-                                                    int nbx, int32_t* __restrict__ counts,
+                                                    int nbx, int kc, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ brick_id) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = m < M;
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float
         brick_id[m] = b;
     }
     const RunInfo r = wave_runs(b, active);
-    if (r.head) atomicAdd(counts + b, r.len);
+    if (r.head) atomicAdd(counts + b * kc + bin_copy(kc), r.len);
 }
 
 // single-workgroup exclusive scan of n int32 counts -> offsets[n+1]; also copies offsets into cursor[n] and builds the
@@ -393,7 +400,7 @@ __global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float
 // [offsets[b] + t*item, +item).  Only non-empty bricks produce items, items are equally sized, and consecutive items
 // (= consecutive workgroups) land on consecutive XCDs, so the hot surface bricks are spread over the whole chip
 // instead of following the brick index -> XCD round-robin of a dense (brick, part) grid.
-__global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ counts, int n,
+__global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ counts, int n, int kc,
                                                     int32_t* __restrict__ offsets, int32_t* __restrict__ cursor,
                                                     int item, int2* __restrict__ items, int32_t* __restrict__ n_items) {
     __shared__ int64_t wsum[16];
@@ -403,7 +410,16 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
-        const int c = i < n ? counts[i] : 0;
+        int c = 0, ck[4] = {0, 0, 0, 0};
+        if (i < n) {
+            if (kc == 4) {
+                const int4 v4 = reinterpret_cast<const int4*>(counts)[i];
+                ck[0] = v4.x; ck[1] = v4.y; ck[2] = v4.z; ck[3] = v4.w;
+                c = v4.x + v4.y + v4.z + v4.w;
+            } else {
+                for (int k = 0; k < kc; ++k) c += counts[i * kc + k];
+            }
+        }
         const int ni = (c + item - 1) / item;
         const int64_t v = (int64_t)c | ((int64_t)ni << 32);          // low word: samples, high word: items
         int64_t incl = v;
@@ -419,7 +435,15 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
         const int so = (int)(excl & 0xffffffffll), io = (int)(excl >> 32);
         if (i < n) {
             offsets[i] = so;
-            cursor[i] = so;
+            if (kc == 4) {
+                reinterpret_cast<int4*>(cursor)[i] = make_int4(so, so + ck[0], so + ck[0] + ck[1], so + ck[0] + ck[1] + ck[2]);
+            } else {
+                int run = so;
+                for (int k = 0; k < kc; ++k) {
+                    cursor[i * kc + k] = run;
+                    run += counts[i * kc + k];
+                }
+            }
             for (int t = 0; t < ni; ++t) items[io + t] = make_int2(i, t);
         }
         __syncthreads();
@@ -437,7 +461,7 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
 // density feature, adjoint of the raw density gradient in normalised-coordinate units).  The softplus / normalize
 // backward is evaluated here, once per sample, fully parallel.
 __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const float4* __restrict__ xyzt,
-                                                       const int32_t* __restrict__ brick_id, int64_t M,
+                                                       const int32_t* __restrict__ brick_id, int64_t M, int kc,
                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
                                                        const float* __restrict__ sigma_feat,
                                                        const float* __restrict__ grad, const float* __restrict__ d_sigma,
@@ -450,7 +474,7 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
     const int b = active ? brick_id[m] : -1;
     const RunInfo r = wave_runs(b, active);
     int base = 0;
-    if (r.head) base = atomicAdd(cursor + b, r.len);
+    if (r.head) base = atomicAdd(cursor + b * kc + bin_copy(kc), r.len);
     base = __shfl(base, lane_id() - r.off, 64);          // the run's head lane broadcasts its base
     if (!active) return;
     const int pos = base + r.off;
@@ -947,12 +971,23 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
     return NMF_OK;
 }
 
+// counter copies per brick (power of two; measured on S1: 1 -> 64 us, 4 -> 45 us, 8 -> 64 us of binning per 0.88 M
+// samples, the scan growing with the copies): 4 while the single-workgroup scan over [brick][copy] stays short
+static int bin_copies(int64_t nb) {
+    if (const char* ev = getenv("NMF_BIN_COPIES")) {   // tuning knob: 1, 2, 4 or 8
+        const int k = atoi(ev);
+        if (k == 1 || k == 2 || k == 4 || k == 8) return k;
+    }
+    return nb <= 32768 ? 4 : 1;
+}
+
 extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nbx = (grid + BR - 1) / BR;
     const int64_t nb = nbx * nbx * nbx;
     const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
-    return (2 * M + 3 * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
-           M * 3 * CA * (int64_t)sizeof(float) + 32;
+    const int64_t kc = bin_copies(nb);
+    return (2 * M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
+           M * 3 * CA * (int64_t)sizeof(float) + 64;
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
@@ -983,27 +1018,29 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
     int32_t* ws = (int32_t*)workspace;
     int32_t* brick_id = ws;            // [M]
     int32_t* perm = ws + M;            // [M]
-    int32_t* counts = ws + 2 * M;      // [nb+1]
-    int32_t* offsets = counts + nb + 1;   // [nb+1]
-    int32_t* cursor = offsets + nb + 1;   // [nb+1]
-    int32_t* n_items = cursor + nb + 1;   // [2] (8-byte aligned start of the item list follows)
+    const int kc = bin_copies(nb);
+    auto align16 = [](int32_t* q) { return (int32_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15); };
+    int32_t* counts = align16(ws + 2 * M);        // [(nb+1)*kc]  copy k of brick b at b*kc + k (int4 per brick at kc = 4)
+    int32_t* offsets = counts + (nb + 1) * kc;    // [nb+1]
+    int32_t* cursor = align16(offsets + nb + 1);  // [(nb+1)*kc]
+    int32_t* n_items = cursor + (nb + 1) * kc;    // [2] (8-byte aligned start of the item list follows)
     int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
     if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
     item_size = (item_size + 3) & ~3;
     const int64_t max_items = M / item_size + nb + 1;
     int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1), st);
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc, st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt, M, nbx,
-                       counts, brick_id);
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor, item_size, items, n_items);
+                       kc, counts, brick_id);
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, kc, offsets, cursor, item_size, items, n_items);
     // 16-byte aligned record arrays behind the integer scratch
     uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
     float4* rec0 = (float4*)rp;
     float4* rec1 = rec0 + M;
     float* dcoef = (float*)(rec1 + M);
     hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt,
-                       brick_id, M, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1,
+                       brick_id, M, kc, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1,
                        want_a ? d_app : nullptr, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
