@@ -352,7 +352,9 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
     hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
     const int64_t tiles = cdiv(R, TR);
-    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    // one workgroup per CU: a second resident workgroup adds weight staging and 8.5 k flush atomics on the same 270 lines
+    // without hiding anything (measured 173 -> 158 us average per launch)
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(256), BWD_LDS, (hipStream_t)stream, w, half_vec, diff_vec,
                        feat_src, rough_src, src_idx, R, out_bias, d_out, d_xfeat, gW0, gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
