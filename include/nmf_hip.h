@@ -327,6 +327,13 @@ int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], int32_t count
  * d_pred = 2 (pred - clip(gt)) d_out inside [0,1], 0 outside (d_out: device scalar). */
 int nmf_sqerr_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);
 int nmf_sqerr_bwd(const float* pred, const float* gt, int64_t n, const float* d_out, float* d_pred, void* stream);
+/* train.py:640-677 loss assembly: out += scale * sum_i w_i * sum(x_i) over up to 8 dense fp32 tensors (scalars or
+ * per-ray vectors such as the orientation terms of tensor_nerf.py:583-587 and acc_map of :598-602); backward fills
+ * g_i[:] = d_out * scale * w_i (d_out: device scalar).  x, numel, w, g: HOST arrays of `count` entries. */
+int nmf_loss_mix_fwd(const float* const x[], const int64_t numel[], const float w[], int32_t count, float scale,
+                     float* out, void* stream);
+int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t count, float scale, const float* d_out,
+                     float* const g[], void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam over the per-module param groups (train.py:443-469), every tensor in one launch.

@@ -51,6 +51,33 @@ __global__ void __launch_bounds__(256) k_l1_bwd(L1Tab tab, const float* __restri
     }
 }
 
+// out += scale * w_i * sum(x_i): blockIdx.y = tensor
+struct MixTab {
+    const float* x[L1_MAX];
+    float* g[L1_MAX];
+    int64_t n[L1_MAX];
+    float w[L1_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_mix_fwd(MixTab tab, float scale, float* __restrict__ out) {
+    __shared__ float ws[4];
+    const int i = blockIdx.y;
+    const int64_t n = tab.n[i];
+    const float* __restrict__ x = tab.x[i];
+    float a = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) a += x[k];
+    const float t = block_sum(a, ws);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t * tab.w[i] * scale);
+}
+
+__global__ void __launch_bounds__(256) k_mix_bwd(MixTab tab, float scale, const float* __restrict__ d_out) {
+    const int i = blockIdx.y;
+    const int64_t n = tab.n[i];
+    float* __restrict__ g = tab.g[i];
+    const float s = d_out[0] * scale * tab.w[i];
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) g[k] = s;
+}
+
 __device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
 // out += sum (clip(pred, 0, 1) - clip(gt, 0, 1))^2  over n floats
@@ -140,5 +167,39 @@ extern "C" int nmf_sqerr_bwd(const float* pred, const float* gt, int64_t n, cons
     hipLaunchKernelGGL(k_sqerr_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
                        d_pred);
     NMF_CHECK_LAUNCH("nmf_sqerr_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_loss_mix_fwd(const float* const x[], const int64_t numel[], const float w[], int32_t count, float scale,
+                                float* out, void* stream) {
+    NMF_REQUIRE(count >= 0 && count <= L1_MAX, NMF_ERANGE, "nmf_loss_mix_fwd: at most 8 tensors");
+    NMF_REQUIRE(out && (count == 0 || (x && numel && w)), NMF_EINVAL, "nmf_loss_mix_fwd: null");
+    if (count == 0) return NMF_OK;
+    MixTab t;
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < count; ++i) {
+        NMF_REQUIRE(numel[i] >= 0 && (numel[i] == 0 || x[i]), NMF_EINVAL, "nmf_loss_mix_fwd: bad tensor");
+        t.x[i] = x[i]; t.n[i] = numel[i]; t.w[i] = w[i];
+    }
+    hipLaunchKernelGGL(k_mix_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+                       scale, out);
+    NMF_CHECK_LAUNCH("nmf_loss_mix_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t count, float scale, const float* d_out,
+                                float* const g[], void* stream) {
+    NMF_REQUIRE(count >= 0 && count <= L1_MAX, NMF_ERANGE, "nmf_loss_mix_bwd: at most 8 tensors");
+    NMF_REQUIRE(d_out && (count == 0 || (numel && w && g)), NMF_EINVAL, "nmf_loss_mix_bwd: null");
+    if (count == 0) return NMF_OK;
+    MixTab t;
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < count; ++i) {
+        NMF_REQUIRE(numel[i] >= 0 && (numel[i] == 0 || g[i]), NMF_EINVAL, "nmf_loss_mix_bwd: bad tensor");
+        t.g[i] = g[i]; t.n[i] = numel[i]; t.w[i] = w[i];
+    }
+    hipLaunchKernelGGL(k_mix_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+                       scale, d_out);
+    NMF_CHECK_LAUNCH("nmf_loss_mix_bwd");
     return NMF_OK;
 }

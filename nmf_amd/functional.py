@@ -22,7 +22,19 @@ class GradPass:
         if self.token_sent:
             return None
         self.token_sent = True
-        return like.new_zeros(())
+        return zero_token(like)
+
+
+_ZERO = {}
+
+
+def zero_token(like):
+    """A 0-d zero for pass tokens and their gradients.  Token VALUES are never read (the nodes behind them only have to be
+    scheduled), so every token aliases one cached per-device scalar instead of paying a fill launch each."""
+    z = _ZERO.get(like.device)
+    if z is None:
+        z = _ZERO[like.device] = torch.zeros((), dtype=torch.float32, device=like.device)
+    return z.detach()
 
 
 class ParamGrads(torch.autograd.Function):
@@ -32,7 +44,7 @@ class ParamGrads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *params):
         ctx.holder, ctx.n = holder, len(params)
-        return params[0].new_zeros(())
+        return zero_token(params[0])
 
     @staticmethod
     def backward(ctx, _d_token):
@@ -95,7 +107,7 @@ class FieldGrads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, field, *params):
         ctx.holder, ctx.field = holder, field
-        return params[0].new_zeros(())
+        return zero_token(params[0])
 
     @staticmethod
     def backward(ctx, _d_token):
@@ -125,8 +137,8 @@ class VMQuery(torch.autograd.Function):
         ctx.mark_non_differentiable(sf)
         ctx.set_materialize_grads(False)
         outs = [sg, sf,
-                ap if want_app else xyzt.new_zeros((xyzt.shape[0], 24)),
-                nr if want_normal else xyzt.new_zeros((xyzt.shape[0], 3))]
+                ap if want_app else xyzt.new_empty((0, 24)),          # branch not evaluated: empty placeholder
+                nr if want_normal else xyzt.new_empty((0, 3))]
         return tuple(outs)
 
     @staticmethod
@@ -216,7 +228,7 @@ class SatBuild(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, env, bg_mat, brightness, mul, mipbias):
         ctx.env, ctx.holder = env, holder
-        return bg_mat.new_zeros(())
+        return zero_token(bg_mat)
 
     @staticmethod
     def backward(ctx, _d_token):
@@ -347,7 +359,7 @@ class StackedHeadGrads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, wd, bd, wt, bt, wf, bf, wr, br):
         ctx.holder = holder
-        return wd.new_zeros(())
+        return zero_token(wd)
 
     @staticmethod
     def backward(ctx, _d_token):
@@ -576,6 +588,21 @@ class L1Mean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         return tuple(hip.l1_mean_bwd(list(ctx.saved_tensors), d_out.contiguous()))
+
+
+class LossMix(torch.autograd.Function):
+    """scale * sum_i w_i * sum(x_i): the loss assembly of train.py:640-677 (photometric term, orientation and prediction
+    regularisers as per-ray vectors, density L1) in one launch per direction instead of ~20 scalar kernels."""
+
+    @staticmethod
+    def forward(ctx, scale, weights, *tensors):
+        ctx.cfg = (float(scale), tuple(float(w) for w in weights), [t.shape for t in tensors])
+        return hip.loss_mix_fwd([t.detach().contiguous() for t in tensors], ctx.cfg[1], ctx.cfg[0])
+
+    @staticmethod
+    def backward(ctx, d_out):
+        scale, weights, shapes = ctx.cfg
+        return (None, None) + tuple(hip.loss_mix_bwd(shapes, weights, scale, d_out.contiguous()))
 
 
 class SquaredError(torch.autograd.Function):

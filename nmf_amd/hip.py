@@ -7,6 +7,7 @@ torch.distributed.  Every wrapper takes torch tensors, checks dtype / contiguity
 passes raw pointers + sizes + the current stream to the C ABI.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -67,6 +68,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -685,6 +687,31 @@ def l1_mean_bwd(tensors, d_out):
     gptrs = (C.c_void_p * n)(*[_dense_f32(g) for g in grads])
     numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
     _check(_lib.nmf_l1_mean_bwd(ptrs, numel, C.c_int32(n), _p(d_out, torch.float32), gptrs, _stream()), "nmf_l1_mean_bwd")
+    return grads
+
+
+def loss_mix_fwd(tensors, weights, scale):
+    """scale * sum_i w_i * sum(x_i) -> 0-d tensor (one launch)"""
+    n = len(tensors)
+    out = torch.zeros((), dtype=torch.float32, device=tensors[0].device)
+    ptrs = (C.c_void_p * n)(*[_dense_f32(t) for t in tensors])
+    numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    w = (C.c_float * n)(*[float(v) for v in weights])
+    _check(_lib.nmf_loss_mix_fwd(ptrs, numel, w, C.c_int32(n), C.c_float(scale), _p(out), _stream()), "nmf_loss_mix_fwd")
+    return out
+
+
+def loss_mix_bwd(shapes, weights, scale, d_out):
+    """constant gradients d_out * scale * w_i shaped like the inputs (one launch, one allocation)"""
+    n = len(shapes)
+    sizes = [int(math.prod(s)) for s in shapes]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=d_out.device)
+    grads = [v.view(s) for v, s in zip(flat.split(sizes), shapes)]
+    numel = (C.c_int64 * n)(*sizes)
+    w = (C.c_float * n)(*[float(v) for v in weights])
+    gptrs = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    _check(_lib.nmf_loss_mix_bwd(numel, w, C.c_int32(n), C.c_float(scale), _p(d_out, torch.float32), gptrs, _stream()),
+           "nmf_loss_mix_bwd")
     return grads
 
 

@@ -206,11 +206,10 @@ class TensorNeRF(torch.nn.Module):
                 for k, v in debug.items():
                     images[k] = segment_sum(v * weight[:, None], offsets, S.ray_id, B) + (1 - acc_d[..., None]) * bg
         elif recur == 0:                                                                             # :567-649
-            zero = torch.zeros((), device=dev)
-            stats["ori_loss"] = ori.sum() if ori is not None else zero
-            # normal_module is None: pred_norms == 0 -> align_world_loss == 2
-            stats["prediction_loss"] = 2.0 * acc_map.sum()
-            stats["distortion_loss"] = zero
+            # per-ray terms; the sums (ori_loss :583-587, prediction_loss :598-602 -- normal_module is None, so
+            # pred_norms == 0 and align_world_loss == 2) are formed on first read, the trainer mixes the
+            # vectors directly (functional.LossMix)
+            stats["ori_terms"], stats["acc_terms"] = ori, acc_map
             stats = LazyStats(stats, self, shaded, weight, M)
             images = LazyImages(shaded)
         images["rgb_map"] = rgb_map
@@ -224,7 +223,7 @@ class LazyStats(dict):
     (train.py:650-654), so the training step never pays for them, while a caller that does read them gets the same
     differentiable tensors as before."""
 
-    _LAZY = ("envmap_reg", "brdf_reg", "diffuse_reg")
+    _LAZY = ("envmap_reg", "brdf_reg", "diffuse_reg", "ori_loss", "prediction_loss", "distortion_loss")
 
     def __init__(self, base, nerf, shaded, weight, M):
         super().__init__(base)
@@ -235,7 +234,14 @@ class LazyStats(dict):
             raise KeyError(key)
         nerf, shaded, weight, M = self._src
         dev = weight.device
-        if key == "envmap_reg":
+        if key == "ori_loss":
+            ori = self["ori_terms"]
+            v = ori.sum() if ori is not None else torch.zeros((), device=dev)
+        elif key == "prediction_loss":
+            v = 2.0 * self["acc_terms"].sum()
+        elif key == "distortion_loss":
+            v = torch.zeros((), device=dev)
+        elif key == "envmap_reg":
             v = (nerf.bg_module.mean_color().mean() - 0.05).clip(min=0)
         elif key == "brdf_reg":
             v = shaded.debug()["tint"].mean().clip(min=0) if M > 0 else torch.tensor(0.0, device=dev)

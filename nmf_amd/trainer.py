@@ -10,8 +10,23 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .functional import SquaredError
+from .functional import LossMix, SquaredError
 from .optim import FusedAdam
+
+_CONST = {}
+
+
+def _ones(shape, device):
+    """cached constant tensors of ones (backward seed, white background): no fill launch per step"""
+    key = (tuple(shape), device)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.ones(shape, dtype=torch.float32, device=device)
+    return t
+
+
+def _one(like):
+    return _ones((), like.device)
 
 
 def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
@@ -130,7 +145,7 @@ class Trainer:
         n_total = rays.shape[0]
         lbatch = n_total * self.world_size          # the loss normaliser is the GLOBAL ray count
         pos, used_rays, losses, n_samples_last = 0, 0, [], None
-        bg = torch.ones(3, device=rays.device)
+        bg = _ones((3,), rays.device)
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
             r = rays[pos:pos + chunk]
@@ -143,10 +158,15 @@ class Trainer:
             wv = st["whole_valid"]
             rgb_map = ims["rgb_map"]                 # valid rays are a prefix of the chunk (alphagrid.py:353-364)
             loss = SquaredError.apply(rgb_map, gt[: rgb_map.shape[0]])                           # train.py:598-601
-            total = loss + p["ori_lambda"] * st["ori_loss"] + p["pred_lambda"] * st["prediction_loss"]
-            total = total + p["L1_weight_initial"] * nerf.rf.density_L1()                        # train.py:670-677
-            total = total / lbatch
-            total.backward()
+            terms, wts = [loss, nerf.rf.density_L1()], [1.0, p["L1_weight_initial"]]            # train.py:640-677
+            if st.get("ori_terms") is not None:
+                terms.append(st["ori_terms"]); wts.append(p["ori_lambda"])
+            if "acc_terms" in st:
+                terms.append(st["acc_terms"]); wts.append(2.0 * p["pred_lambda"])
+            else:
+                terms.append(st["prediction_loss"]); wts.append(p["pred_lambda"])
+            total = LossMix.apply(1.0 / lbatch, wts, *terms)
+            total.backward(_one(total))
             kept = rgb_map.shape[0]                  # = number of valid rays (no device read-back)
             used_rays += kept
             losses.append(loss.detach())             # read back after the optimizer step has been queued

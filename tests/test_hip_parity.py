@@ -900,3 +900,23 @@ def test_march_in_kernel_philox_equals_explicit_jitter():
     assert int(outs[0][1].sum()) > 1000
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.gpu
+def test_loss_mix_matches_torch():
+    """nmf_loss_mix_fwd/bwd (train.py:640-677 loss assembly): scale * sum_i w_i * sum(x_i) and its constant gradients"""
+    from nmf_amd.functional import LossMix
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.rand((), generator=g), torch.rand(4096, generator=g), torch.rand(3000, generator=g) - 0.5, torch.rand((), generator=g)]
+    w = [1.0, 0.1, 6e-4, 8e-5]
+    scale = 1.0 / 4096
+    ref_in = [x.clone().double().requires_grad_(True) for x in xs]
+    ref = scale * sum(wi * x.sum() for wi, x in zip(w, ref_in))
+    ref.backward()
+    dev_in = [x.to(DEV).requires_grad_(True) for x in xs]
+    out = LossMix.apply(scale, w, *dev_in)
+    out.backward()
+    assert_close(out.detach().cpu(), ref.detach().float(), rtol=2e-6, what="loss mix")
+    for a, b in zip(dev_in, ref_in):
+        assert a.grad.shape == a.shape
+        assert_close(a.grad.cpu(), b.grad.float(), rtol=1e-6, what="loss mix grad")
