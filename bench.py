@@ -50,7 +50,7 @@ def build(device):
 
 
 class KernelTimer:
-    """HIP events around every nmf_vm_query_bwd call (issued on torch's current stream, which is the stream the
+    """HIP events around every nmf_vm_query_bwd / nmf_vm_query_bwd_segments call (issued on torch's current stream, which is the stream the
     C ABI launches on) -> per-launch duration of the dominant kernel inside the timed region."""
 
     def __init__(self):
@@ -74,6 +74,22 @@ class KernelTimer:
 
         hip.vm_query_bwd = wrapped
         functional.hip.vm_query_bwd = wrapped
+        orig_segs = hip.vm_query_bwd_segments
+
+        def wrapped_segs(p, segs, *a, **k):      # the training pass walks its sample sets together (functional.py)
+            if not self.enabled:
+                return orig_segs(p, segs, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_segs(p, segs, *a, **k)
+            e.record()
+            m = sum(int(sg[0].shape[0]) for sg in segs)
+            dens = any(sg[3] is not None or sg[4] is not None or sg[5] is not None for sg in segs)
+            app = any(sg[6] is not None for sg in segs)
+            self.records.append((s, e, m, dens, app))
+            return r
+
+        hip.vm_query_bwd_segments = wrapped_segs
         # per-step derived tables must be rebuilt after every optimizer update (packed density planes, SAT): count the
         # rebuilds inside the timed region so a stale cache (= skipped work) shows up in the report
         self.rebuilds = {"vm_pack_density": 0, "sat_build": 0}
@@ -219,7 +235,7 @@ def main():
                        "rays_per_gpu": RAYS_PER_GPU, "grid": GRID, "samples_per_step": last["n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd (k_vm_bwd_brick + binning)",
+            "roofline": {"bound": "hbm", "kernel": "nmf_vm_query_bwd_segments (k_vm_bwd_brick + binning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": k_launches,
                          "avg_launch_ms": k_ms / max(k_launches, 1),

@@ -137,8 +137,31 @@ int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
                      const float* d_app, float* const g_dpk[3], float* const g_dlk[3],
                      float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
                      void* workspace, int64_t workspace_bytes, void* stream);
-/* Scratch the backward needs (brick ids, permutation, bin counters); contents are undefined on return. */
+/* Scratch the backward needs (brick ids, bin counters, records in brick order); contents are undefined on return.
+ * For nmf_vm_query_bwd_segments M is the total over the segments. */
 int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid);
+
+/* The same walk over the concatenation of up to NMF_VM_MAX_SEGMENTS sample sets (no copy): one training pass queries the
+ * field for the primary and for the re-traced rays (tensor_nerf.py:286-393 at recur 0 and 1); their adjoints all land in
+ * the same tables, so walking them together bins once and flushes every brick both sets touch once.  All non-empty
+ * segments must provide the same set of adjoints (d_sigma / d_normal / d_app NULL-ness). */
+#define NMF_VM_MAX_SEGMENTS 4
+typedef struct nmf_vm_bwd_segment {
+    const float* xyzt;          /* [M][4] */
+    int64_t M;
+    const float* sigma_feat;    /* [M]    saved forward outputs */
+    const float* grad;          /* [M][3] */
+    const float* d_sigma;       /* [M]    upstream adjoints, any may be NULL */
+    const float* d_sigma_feat;  /* [M] */
+    const float* d_normal;      /* [M][3] */
+    const float* d_app;         /* [M][24] */
+} nmf_vm_bwd_segment;
+int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs /*HOST array*/, int32_t n_segs,
+                              const float* const dpk[3], const float* const dlk[3],
+                              const float* const app_planes[3], const float* const app_lines[3],
+                              const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                              float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Folds the packed gradient back onto the factors (transpose of nmf_vm_pack_density):
  * g_planes[i] [G][G][16], g_lines[i] [G][16] are OVERWRITTEN. */

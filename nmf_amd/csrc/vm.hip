@@ -379,15 +379,41 @@ __device__ __forceinline__ RunInfo wave_runs(int key, bool active) {
 // slice of the brick's segment that follows copies < k.
 __device__ __forceinline__ int bin_copy(int kc) { return (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kc - 1)); }
 
-__global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
+// The samples of one walk may come from up to four caller arrays ("segments": the sample sets of the primary and of the
+// re-traced rays of one training pass are walked together, so that bricks both touch are flushed once).  Sample m of
+// the concatenation lives in segment sg at row m - start[sg].
+constexpr int MAX_SEG = NMF_VM_MAX_SEGMENTS;
+struct Segs {
+    const float* xyzt[MAX_SEG];
+    const float* sigma_feat[MAX_SEG];
+    const float* grad[MAX_SEG];
+    const float* d_sigma[MAX_SEG];
+    const float* d_sigma_feat[MAX_SEG];
+    const float* d_normal[MAX_SEG];
+    const float* d_app[MAX_SEG];
+    int64_t start[MAX_SEG + 1];
+};
+template <class T>
+__device__ __forceinline__ T pick4(const T (&a)[MAX_SEG], int k) {
+    return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3]));
+}
+__device__ __forceinline__ int seg_of(const Segs& sg, int64_t m, int64_t& local) {
+    const int k = (m >= sg.start[1] ? 1 : 0) + (m >= sg.start[2] ? 1 : 0) + (m >= sg.start[3] ? 1 : 0);
+    local = m - (k == 0 ? sg.start[0] : (k == 1 ? sg.start[1] : (k == 2 ? sg.start[2] : sg.start[3])));
+    return k;
+}
+
+__global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, Segs sg, int64_t M,
                                                     int nbx, int kc, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ brick_id) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = m < M;
     int b = -1;
     if (active) {
+        int64_t l;
+        const int k = seg_of(sg, m, l);
         float xn[3];
-        normalized(p, xyzt[m], xn);
+        normalized(p, reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l], xn);
         b = brick_of(p, xn, nbx);
         brick_id[m] = b;
     }
@@ -460,14 +486,10 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
 // SORTED order so that the brick kernels stream them without an indirection: rec0 = xyzt, rec1 = (adjoint of the raw
 // density feature, adjoint of the raw density gradient in normalised-coordinate units).  The softplus / normalize
 // backward is evaluated here, once per sample, fully parallel.
-__global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const float4* __restrict__ xyzt,
+__global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, Segs sg,
                                                        const int32_t* __restrict__ brick_id, int64_t M, int kc,
-                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ perm,
-                                                       const float* __restrict__ sigma_feat,
-                                                       const float* __restrict__ grad, const float* __restrict__ d_sigma,
-                                                       const float* __restrict__ d_sigma_feat,
-                                                       const float* __restrict__ d_normal, float4* __restrict__ rec0,
-                                                       float4* __restrict__ rec1, const float* __restrict__ d_app,
+                                                       int32_t* __restrict__ cursor, float4* __restrict__ rec0,
+                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted,
                                                        const float* __restrict__ basis, float* __restrict__ dcoef) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = m < M;
@@ -478,20 +500,24 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
     base = __shfl(base, lane_id() - r.off, 64);          // the run's head lane broadcasts its base
     if (!active) return;
     const int pos = base + r.off;
-    perm[pos] = (int32_t)m;
-    rec0[pos] = xyzt[m];
-    float dsf = d_sigma_feat ? d_sigma_feat[m] : 0.f;
-    if (d_sigma) {
-        const float f = sigma_feat[m];
+    int64_t l;
+    const int k = seg_of(sg, m, l);
+    rec0[pos] = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
+    const float* d_sigma_feat = pick4(sg.d_sigma_feat, k);
+    float dsf = d_sigma_feat ? d_sigma_feat[l] : 0.f;
+    if (sg.d_sigma[0]) {
+        const float f = pick4(sg.sigma_feat, k)[l];
         const float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
         float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));          // softplus'
         if (f < -15.f || f > 1e3f) ds = 0.f;                         // clamp'
-        dsf += d_sigma[m] * ds;
+        dsf += pick4(sg.d_sigma, k)[l] * ds;
     }
     float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
-    if (d_normal) {   // through n = -g / sqrt(max(|g|^2, eps))
-        const float g0 = grad[m * 3], g1 = grad[m * 3 + 1], g2 = grad[m * 3 + 2];
-        const float dn0 = d_normal[m * 3], dn1 = d_normal[m * 3 + 1], dn2 = d_normal[m * 3 + 2];
+    if (sg.d_normal[0]) {   // through n = -g / sqrt(max(|g|^2, eps))
+        const float* grad = pick4(sg.grad, k);
+        const float* d_normal = pick4(sg.d_normal, k);
+        const float g0 = grad[l * 3], g1 = grad[l * 3 + 1], g2 = grad[l * 3 + 2];
+        const float dn0 = d_normal[l * 3], dn1 = d_normal[l * 3 + 1], dn2 = d_normal[l * 3 + 2];
         const float n2 = g0 * g0 + g1 * g1 + g2 * g2;
         const float eps = 1.1920929e-07f;
         const float inv = 1.f / sqrtf(fmaxf(n2, eps));
@@ -502,9 +528,12 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, const fl
         dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
     }
     rec1[pos] = make_float4(dsf, dg0, dg1, dg2);
-    if (d_app) {   // adjoint of the 72 plane*line coefficients: dcoef = d_app x basis_mat (weights via scalar loads)
+    if (sg.d_app[0]) {   // adjoint of the 72 plane*line coefficients: dcoef = d_app x basis_mat (weights via scalar loads)
         float da[AD];
-        load_run<AD / 4>(d_app + m * AD, da);
+        load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
+        float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);   // d_app row in brick order
+#pragma unroll
+        for (int q = 0; q < AD / 4; ++q) srt[q] = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
         float4* out = reinterpret_cast<float4*>(dcoef + (int64_t)pos * (3 * CA));
 #pragma unroll
         for (int c4 = 0; c4 < 3 * CA / 4; ++c4) {
@@ -758,7 +787,7 @@ struct AGrp {
 };
 
 __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __restrict__ rec0,
-                                            const int32_t* __restrict__ perm, int brick, int s, int e, int i, int nbx,
+                                            int brick, int s, int e, int i, int nbx,
                                             Ptrs3 apl, Ptrs3 ali, const float* __restrict__ dcoef,
                                             const float* __restrict__ d_app, MPtrs3 g_apl, MPtrs3 g_ali,
                                             float* __restrict__ g_basis, float4* __restrict__ lds) {
@@ -788,9 +817,8 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
             const int idx = min(base + lane, e - 1);
             const bool valid = base + lane < e;
             const float4 x = rec0[idx];
-            const int64_t m = perm[idx];
             const float4* dc = reinterpret_cast<const float4*>(dcoef + (int64_t)idx * (3 * CA) + i * CA);
-            const float4* da = reinterpret_cast<const float4*>(d_app + m * AD);
+            const float4* da = reinterpret_cast<const float4*>(d_app + (int64_t)idx * AD);      // rows in brick order
             float4 c[6], a[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) c[q] = valid ? dc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -881,7 +909,6 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
 template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
-                                                              const int32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ bin_off,
                                                               const int2* __restrict__ items,
                                                               const int32_t* __restrict__ n_items, int item_size, int nbx,
@@ -899,7 +926,7 @@ __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, c
         __shared__ float4 lds[64 * 16];
         if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
         else if (half == z_app)
-            vm_bwd_app2(p, rec0, perm, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
+            vm_bwd_app2(p, rec0, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
     }
 }
 
@@ -986,8 +1013,95 @@ extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nb = nbx * nbx * nbx;
     const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
     const int64_t kc = bin_copies(nb);
-    return (2 * M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
-           M * 3 * CA * (int64_t)sizeof(float) + 64;
+    return (M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
+           M * (3 * CA + AD) * (int64_t)sizeof(float) + 64;
+}
+
+extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
+                                         const float* const dpk[3], const float* const dlk[3],
+                                         const float* const app_planes[3], const float* const app_lines[3],
+                                         const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                         float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
+                "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
+    Segs sg;
+    memset(&sg, 0, sizeof(sg));
+    int64_t M = 0;
+    int n = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const nmf_vm_bwd_segment& q = segs[i];
+        NMF_REQUIRE(q.M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: M < 0");
+        if (q.M == 0) continue;
+        NMF_REQUIRE(q.xyzt, NMF_EINVAL, "nmf_vm_query_bwd: xyzt null");
+        sg.xyzt[n] = q.xyzt; sg.sigma_feat[n] = q.sigma_feat; sg.grad[n] = q.grad; sg.d_sigma[n] = q.d_sigma;
+        sg.d_sigma_feat[n] = q.d_sigma_feat; sg.d_normal[n] = q.d_normal; sg.d_app[n] = q.d_app;
+        sg.start[n] = M;
+        M += q.M;
+        ++n;
+    }
+    if (M == 0) return NMF_OK;
+    for (int i = n; i <= MAX_SEG; ++i) sg.start[i] = M;      // unused segments start past the end
+    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_bwd: M >= 2^31");
+    for (int i = 1; i < n; ++i)                              // the kernels branch on segment 0's adjoint set
+        NMF_REQUIRE(!sg.d_sigma[i] == !sg.d_sigma[0] && !sg.d_normal[i] == !sg.d_normal[0] && !sg.d_app[i] == !sg.d_app[0],
+                    NMF_EINVAL, "nmf_vm_query_bwd: segments must provide the same adjoints");
+    const float *d_sigma = sg.d_sigma[0], *d_normal = sg.d_normal[0], *d_app = sg.d_app[0];
+    bool any_dsf = false;
+    for (int i = 0; i < n; ++i) {
+        any_dsf = any_dsf || sg.d_sigma_feat[i];
+        NMF_REQUIRE(!d_sigma || sg.sigma_feat[i], NMF_EINVAL, "nmf_vm_query_bwd: d_sigma needs saved sigma_feat");
+        NMF_REQUIRE(!d_normal || sg.grad[i], NMF_EINVAL, "nmf_vm_query_bwd: d_normal needs saved grad");
+    }
+    const bool want_d = d_sigma || any_dsf || d_normal;
+    const bool want_a = d_app != nullptr;
+    NMF_REQUIRE(!want_d || (all3(dpk) && all3(dlk) && all3m(g_dpk) && all3m(g_dlk)), NMF_EINVAL,
+                "nmf_vm_query_bwd: density tables missing");
+    NMF_REQUIRE(!want_a || (all3(app_planes) && all3(app_lines) && basis && all3m(g_app_planes) && all3m(g_app_lines)),
+                NMF_EINVAL, "nmf_vm_query_bwd: appearance tables missing");
+    NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
+                "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
+    if (!want_d && !want_a) return NMF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (p->grid + BR - 1) / BR;
+    const int nb = nbx * nbx * nbx;
+    int32_t* ws = (int32_t*)workspace;
+    int32_t* brick_id = ws;            // [M]
+    const int kc = bin_copies(nb);
+    auto align16 = [](int32_t* q) { return (int32_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15); };
+    int32_t* counts = align16(ws + M);            // [(nb+1)*kc]  copy k of brick b at b*kc + k (int4 per brick at kc = 4)
+    int32_t* offsets = counts + (nb + 1) * kc;    // [nb+1]
+    int32_t* cursor = align16(offsets + nb + 1);  // [(nb+1)*kc]
+    int32_t* n_items = cursor + (nb + 1) * kc;    // [2] (8-byte aligned start of the item list follows)
+    int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
+    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
+    item_size = (item_size + 3) & ~3;
+    const int64_t max_items = M / item_size + nb + 1;
+    int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc, st);
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
+    hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, nbx, kc, counts, brick_id);
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, kc, offsets, cursor, item_size, items, n_items);
+    // 16-byte aligned record arrays behind the integer scratch
+    uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
+    float4* rec0 = (float4*)rp;
+    float4* rec1 = rec0 + M;
+    float* dcoef = (float*)(rec1 + M);              // [M][72]
+    float* d_app_sorted = dcoef + M * 3 * CA;       // [M][24]
+    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc, cursor,
+                       rec0, rec1, d_app_sorted, basis, dcoef);
+    const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
+    const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
+    const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
+#define NMF_LAUNCH_BWD(WN)                                                                                            \
+    hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
+                       mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \
+                       mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app)
+    if (d_normal) NMF_LAUNCH_BWD(true);
+    else NMF_LAUNCH_BWD(false);
+#undef NMF_LAUNCH_BWD
+    NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
+    return NMF_OK;
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
@@ -999,59 +1113,9 @@ extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64
                                 float* g_basis, void* workspace, int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: params");
     if (M == 0) return NMF_OK;
-    NMF_REQUIRE(xyzt, NMF_EINVAL, "nmf_vm_query_bwd: xyzt null");
-    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_bwd: M >= 2^31");
-    const bool want_d = d_sigma || d_sigma_feat || d_normal;
-    const bool want_a = d_app != nullptr;
-    NMF_REQUIRE(!want_d || (all3(dpk) && all3(dlk) && all3m(g_dpk) && all3m(g_dlk)), NMF_EINVAL,
-                "nmf_vm_query_bwd: density tables missing");
-    NMF_REQUIRE(!d_sigma || sigma_feat, NMF_EINVAL, "nmf_vm_query_bwd: d_sigma needs saved sigma_feat");
-    NMF_REQUIRE(!d_normal || grad, NMF_EINVAL, "nmf_vm_query_bwd: d_normal needs saved grad");
-    NMF_REQUIRE(!want_a || (all3(app_planes) && all3(app_lines) && basis && all3m(g_app_planes) && all3m(g_app_lines)),
-                NMF_EINVAL, "nmf_vm_query_bwd: appearance tables missing");
-    NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
-                "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
-    if (!want_d && !want_a) return NMF_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const int nbx = (p->grid + BR - 1) / BR;
-    const int nb = nbx * nbx * nbx;
-    int32_t* ws = (int32_t*)workspace;
-    int32_t* brick_id = ws;            // [M]
-    int32_t* perm = ws + M;            // [M]
-    const int kc = bin_copies(nb);
-    auto align16 = [](int32_t* q) { return (int32_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15); };
-    int32_t* counts = align16(ws + 2 * M);        // [(nb+1)*kc]  copy k of brick b at b*kc + k (int4 per brick at kc = 4)
-    int32_t* offsets = counts + (nb + 1) * kc;    // [nb+1]
-    int32_t* cursor = align16(offsets + nb + 1);  // [(nb+1)*kc]
-    int32_t* n_items = cursor + (nb + 1) * kc;    // [2] (8-byte aligned start of the item list follows)
-    int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
-    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
-    item_size = (item_size + 3) & ~3;
-    const int64_t max_items = M / item_size + nb + 1;
-    int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc, st);
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
-    hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt, M, nbx,
-                       kc, counts, brick_id);
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, kc, offsets, cursor, item_size, items, n_items);
-    // 16-byte aligned record arrays behind the integer scratch
-    uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
-    float4* rec0 = (float4*)rp;
-    float4* rec1 = rec0 + M;
-    float* dcoef = (float*)(rec1 + M);
-    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, (const float4*)xyzt,
-                       brick_id, M, kc, cursor, perm, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, rec0, rec1,
-                       want_a ? d_app : nullptr, basis, dcoef);
-    const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
-    const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
-#define NMF_LAUNCH_BWD(WN)                                                                                            \
-    hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, perm, offsets, items, n_items,     \
-                       item_size, nbx, mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app, mkm(g_dpk),        \
-                       mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app)
-    if (d_normal) NMF_LAUNCH_BWD(true);
-    else NMF_LAUNCH_BWD(false);
-#undef NMF_LAUNCH_BWD
-    NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
-    return NMF_OK;
+    nmf_vm_bwd_segment seg;
+    seg.xyzt = xyzt; seg.M = M; seg.sigma_feat = sigma_feat; seg.grad = grad; seg.d_sigma = d_sigma;
+    seg.d_sigma_feat = d_sigma_feat; seg.d_normal = d_normal; seg.d_app = d_app;
+    return nmf_vm_query_bwd_segments(p, &seg, 1, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
+                                     g_app_lines, g_basis, workspace, workspace_bytes, stream);
 }

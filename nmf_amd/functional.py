@@ -15,6 +15,7 @@ class GradPass:
     def __init__(self):
         self.bufs = None
         self.token_sent = False
+        self.pending = []          # deferred field walks: (adjoint-set key, segment tuple), see defer_field_walk
 
     def token_grad(self, like):
         """Gradient for the pass token: the node behind the token only has to be scheduled, so exactly one consumer
@@ -89,6 +90,28 @@ class PassMixin:
         return holder, token
 
 
+def defer_field_walk(holder, field, seg):
+    """Queue one backward walk of the field (seg = (xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app)).  The
+    walks of one pass -- primary and re-traced samples -- accumulate into the same tables, so they are run together when
+    the pass's FieldGrads node fires: one binning, and every brick both sample sets touch is flushed once."""
+    key = tuple(t is not None for t in seg[3:])
+    holder.pending.append((key, seg))
+    if sum(1 for k, _ in holder.pending if k == key) >= hip.VM_MAX_SEGMENTS:
+        flush_field_walks(holder, field)
+
+
+def flush_field_walks(holder, field):
+    if not holder.pending:
+        return
+    pending, holder.pending = holder.pending, []
+    p, dpk, dlk, apl, ali, basis = field._tables()
+    g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, p.grid, pending[0][1][0].device)
+    for key in dict.fromkeys(k for k, _ in pending):
+        segs = [sg for k, sg in pending if k == key]
+        hip.vm_query_bwd_segments(p, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali,
+                                  g_basis if key[3] else None)
+
+
 def field_grad_buffers(holder, G, dev):
     """packed gradient tables of the pass (one zero fill for all 13), created by the first backward that needs them"""
     if holder.bufs is None:
@@ -112,6 +135,7 @@ class FieldGrads(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _d_token):
         holder, field = ctx.holder, ctx.field
+        flush_field_walks(holder, field)
         if holder.bufs is None:
             return (None, None) + (None,) * len(field._param_list())
         g_dpk, g_dlk, g_apl, g_ali, g_basis = holder.bufs
@@ -146,16 +170,11 @@ class VMQuery(torch.autograd.Function):
         field, holder = ctx.field, ctx.holder
         want_app, want_normal = ctx.flags
         xyzt, sf, gr, cf = ctx.saved_tensors
-        p, dpk, dlk, apl, ali, basis = field._tables()
-        G = p.grid
-        dev = xyzt.device
-        g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, G, dev)
         d_sigma = d_sigma.contiguous() if d_sigma is not None else None
         d_app_c = d_app.contiguous() if (want_app and d_app is not None) else None
         d_nrm_c = d_normal.contiguous() if (want_normal and d_normal is not None) else None
         if d_sigma is not None or d_app_c is not None or d_nrm_c is not None:
-            hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, None, d_nrm_c, d_app_c,
-                             g_dpk, g_dlk, g_apl, g_ali, g_basis if d_app_c is not None else None)
+            defer_field_walk(holder, field, (xyzt, sf, gr, d_sigma, None, d_nrm_c, d_app_c))
         return None, None, None, None, None, holder.token_grad(xyzt)
 
 
@@ -175,10 +194,7 @@ class VMAppQuery(torch.autograd.Function):
     def backward(ctx, d_app):
         field, holder = ctx.field, ctx.holder
         (xyzt,) = ctx.saved_tensors
-        p, dpk, dlk, apl, ali, basis = field._tables()
-        g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(holder, p.grid, xyzt.device)
-        hip.vm_query_bwd(p, xyzt, dpk, dlk, apl, ali, basis, None, None, None, None, None, d_app.contiguous(),
-                         g_dpk, g_dlk, g_apl, g_ali, g_basis)
+        defer_field_walk(holder, field, (xyzt, None, None, None, None, None, d_app.contiguous()))
         return None, None, None, holder.token_grad(xyzt)
 
 
@@ -536,10 +552,7 @@ class BounceRays(torch.autograd.Function):
         d_app.add_(hip.heads_bwd(app, c.head_W, c.head_b, c.head_hp, d_heads, gW, gb))
         tf = None
         if c.field_holder is not None:
-            p, dpk, dlk, apl, ali, basis = c.field._tables()
-            g_dpk, g_dlk, g_apl, g_ali, g_basis = field_grad_buffers(c.field_holder, p.grid, d_app.device)
-            hip.vm_query_bwd(p, c.xyz_rows, dpk, dlk, apl, ali, basis, None, None, None, None, None, d_app,
-                             g_dpk, g_dlk, g_apl, g_ali, g_basis)
+            defer_field_walk(c.field_holder, c.field, (c.xyz_rows, None, None, None, None, None, d_app))
             tf = c.field_holder.token_grad(d_app)
         th = c.head_holder.token_grad(d_app) if c.head_holder is not None else None
         tm = c.mlp_holder.token_grad(d_app) if (c.mlp_holder is not None and d_brdf is not None) else None

@@ -68,7 +68,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -334,6 +334,42 @@ def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, gr
                                  _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
                                  _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
                                  _p(g_basis if want_a else None), _p(ws), C.c_int64(nbytes), _stream()), "nmf_vm_query_bwd")
+
+
+class VmBwdSegment(C.Structure):
+    _fields_ = [("xyzt", C.c_void_p), ("M", C.c_int64), ("sigma_feat", C.c_void_p), ("grad", C.c_void_p),
+                ("d_sigma", C.c_void_p), ("d_sigma_feat", C.c_void_p), ("d_normal", C.c_void_p), ("d_app", C.c_void_p)]
+
+
+VM_MAX_SEGMENTS = 4
+
+
+def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
+                          g_basis=None):
+    """One backward walk over several sample sets (no concatenation).  segs: list of tuples
+    (xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app) -- the argument order of vm_query_bwd."""
+    n = len(segs)
+    if n > VM_MAX_SEGMENTS:
+        raise NmfHipError(f"at most {VM_MAX_SEGMENTS} segments per walk")
+    arr = (VmBwdSegment * max(n, 1))()
+    M, want_d, want_a = 0, False, False
+    for i, (xyzt, sf, gr, ds, dsf, dn, da) in enumerate(segs):
+        arr[i] = VmBwdSegment(_p(xyzt, torch.float32), xyzt.shape[0], _p(sf), _p(gr), _p(ds), _p(dsf), _p(dn), _p(da))
+        M += xyzt.shape[0]
+        want_d = want_d or ds is not None or dsf is not None or dn is not None
+        want_a = want_a or da is not None
+    if M == 0:
+        return
+    nbytes = _lib.nmf_vm_bwd_workspace_bytes(C.c_int64(M), C.c_int32(p.grid))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=segs[0][0].device)
+    _check(_lib.nmf_vm_query_bwd_segments(C.byref(p), arr, C.c_int32(n),
+                                          _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
+                                          _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
+                                          _p(basis) if want_a else None,
+                                          _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
+                                          _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
+                                          _p(g_basis if want_a else None), _p(ws), C.c_int64(nbytes), _stream()),
+           "nmf_vm_query_bwd_segments")
 
 
 def vm_unpack_density_grad(p, g_dpk, g_dlk):

@@ -920,3 +920,45 @@ def test_loss_mix_matches_torch():
     for a, b in zip(dev_in, ref_in):
         assert a.grad.shape == a.shape
         assert_close(a.grad.cpu(), b.grad.float(), rtol=1e-6, what="loss mix grad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_app", [False, True])
+def test_vm_backward_segments_equal_concatenation(with_app):
+    """nmf_vm_query_bwd_segments over ragged sample sets (incl. an empty one) accumulates the same table gradients as
+    nmf_vm_query_bwd over their concatenation (tensor_nerf.py:286-393: primary + re-traced samples of one pass)."""
+    from nmf_amd import hip, synthetic
+    G = 32
+    cfg = O.Cfg(grid=G)
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=8, seed=2)
+    tabs = _field_tables(hip, sd, cfg)
+    p, dpk, dlk, apl, ali, basis = tabs
+    g = torch.Generator().manual_seed(11)
+    sizes = [1500, 0, 37, 4096]
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)  # noqa: E731
+    segs = []
+    for n in sizes:
+        xyz = torch.cat([(torch.rand(n, 3, generator=g) * 2 - 1) * 1.45, torch.zeros(n, 1)], 1).to(DEV).contiguous()
+        sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis) if n else (z(0), z(0), z(0, 3), z(0, 3), z(0, 24), None)
+        if with_app:
+            segs.append((xyz, None, None, None, None, None, torch.randn(n, 24, generator=g).to(DEV)))
+        else:
+            segs.append((xyz, sf, gr, torch.randn(n, generator=g).to(DEV), None, torch.randn(n, 3, generator=g).to(DEV), None))
+
+    def bufs():
+        return ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)], [z(G, G, 24) for _ in range(3)],
+                [z(G, 24) for _ in range(3)], z(24, 72))
+
+    a = bufs()
+    hip.vm_query_bwd_segments(p, segs, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], a[4] if with_app else None)
+    cat = [None if segs[0][i] is None else torch.cat([s[i] for s in segs], 0).contiguous() for i in range(7)]
+    b = bufs()
+    hip.vm_query_bwd(p, cat[0], dpk, dlk, apl, ali, basis, cat[1], cat[2], cat[3], cat[4], cat[5], cat[6],
+                     b[0], b[1], b[2], b[3], b[4] if with_app else None)
+    flat = lambda t: torch.cat([x.reshape(-1) for x in (t[0] + t[1] + t[2] + t[3] + [t[4]])]).cpu()  # noqa: E731
+    fa, fb = flat(a), flat(b)
+    assert fb.abs().max() > 0
+    assert_close(fa, fb, rtol=2e-5, atol=2e-5 * float(fb.abs().max()), what="segmented walk vs concatenation")
+    with pytest.raises(hip.NmfHipError):                       # mixed adjoint sets are rejected
+        bad = [segs[0], (segs[3][0], None, None, None, None, None, None)]
+        hip.vm_query_bwd_segments(p, bad, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], None)
