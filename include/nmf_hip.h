@@ -178,9 +178,11 @@ int nmf_composite_fwd(const float* sigma, const float* dist, const int64_t* offs
 int nmf_composite_bwd(const float* sigma, const float* dist, const float* weight,
                       const int64_t* offsets, int64_t b, float distance_scale,
                       const float* d_weight /*[M]*/, float* d_sigma /*[M]*/, void* stream);
-/* out[r][d] = sum_{k in segment r} (scale ? scale[k] : 1) * vals[k][d], added in index order (fp32). */
+/* out[r][d] = sum_{k in segment r} (scale ? scale[k] : 1) * vals[k][d], D = 1..4.  lanes = 1: one lane per segment,
+ * added in index order (fp32, reproduces scatter_add_ on the CPU bit for bit); lanes = 8: eight lanes per segment and a
+ * shuffle tree (different fp32 rounding; for the adjoint reductions over the secondary rays of a bounce point). */
 int nmf_segment_sum(const float* vals, const float* scale, const int64_t* offsets, int64_t n_seg,
-                    int32_t D, float* out, void* stream);
+                    int32_t D, int32_t lanes, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Environment map: IntegralEquirect (modules/integral_equirect.py:18-173,373-504), activation 'exp'.

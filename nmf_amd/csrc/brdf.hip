@@ -65,17 +65,24 @@ __global__ void __launch_bounds__(256) k_brdf_features(const float* __restrict__
     x[63] = dx; x[64] = dy; x[65] = dz;
 }
 
-// out[s][0:D] = sum over rows r in [offsets[s], offsets[s+1]) of vals[r*stride + 0:D]  (one wave per segment)
+// out[s][0:D] = sum over rows r in [offsets[s], offsets[s+1]) of vals[r*stride + 0:D].  One wave per segment; the wave
+// is split into 64/G row slots of G = pow2 >= D lanes (2 slots for D = 24, 8 for D = 6) that take alternating rows and
+// are combined with a shuffle tree.
+template <int G>
 __global__ void __launch_bounds__(256) k_segment_sum_wide(const float* __restrict__ vals, int64_t stride, int D,
                                                           const int64_t* __restrict__ offsets, int64_t n_seg,
                                                           float* __restrict__ out) {
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_seg) return;
     const int lane = lane_id();
+    const int ch = lane & (G - 1), slot = lane / G;
+    constexpr int SLOTS = 64 / G;
     const int64_t b = offsets[s], e = offsets[s + 1];
     float a = 0.f;
-    if (lane < D)
-        for (int64_t r = b; r < e; ++r) a += vals[r * stride + lane];
+    if (ch < D)
+        for (int64_t r = b + slot; r < e; r += SLOTS) a += vals[r * stride + ch];
+#pragma unroll
+    for (int sh = 32; sh >= G; sh >>= 1) a += __shfl_down(a, sh, 64);
     if (lane < D) out[s * D + lane] = a;
 }
 
@@ -97,8 +104,12 @@ extern "C" int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32
     NMF_REQUIRE(n_seg >= 0, NMF_EINVAL, "nmf_segment_sum_wide: n_seg < 0");
     if (n_seg == 0) return NMF_OK;
     NMF_REQUIRE(vals && offsets && out && D > 0 && D <= 64 && row_stride >= D, NMF_EINVAL, "nmf_segment_sum_wide: args");
-    hipLaunchKernelGGL(k_segment_sum_wide, dim3((unsigned)cdiv(n_seg, 4)), dim3(256), 0, (hipStream_t)stream, vals,
-                       row_stride, D, offsets, n_seg, out);
+    const dim3 grid((unsigned)cdiv(n_seg, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 8) hipLaunchKernelGGL(k_segment_sum_wide<8>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else if (D <= 16) hipLaunchKernelGGL(k_segment_sum_wide<16>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else if (D <= 32) hipLaunchKernelGGL(k_segment_sum_wide<32>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else hipLaunchKernelGGL(k_segment_sum_wide<64>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
     NMF_CHECK_LAUNCH("nmf_segment_sum_wide");
     return NMF_OK;
 }

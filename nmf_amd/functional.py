@@ -410,7 +410,7 @@ class GgxRays(torch.autograd.Function):
         d_nr = hip.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray,
                                 dL.contiguous() if dL is not None else None,
                                 d_rays.contiguous() if d_rays is not None else None)
-        rows = hip.segment_sum(d_nr, None, row_off, V.shape[0])
+        rows = hip.segment_sum(d_nr, None, row_off, V.shape[0], lanes=8)
         return None, rows[:, 0:3], rows[:, 3].reshape(ctx.r_shape), None, None, None, None, None, None, None
 
 
@@ -423,7 +423,7 @@ class ShadeMix(torch.autograd.Function):
         L, inc, brdf = L.contiguous(), inc.contiguous(), brdf.contiguous()
         contrib = hip.shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf)
         ctx.save_for_backward(V, f0, diff, cnt, row_of_ray, row_off, L, inc, brdf)
-        return hip.segment_sum(contrib, None, row_off, V.shape[0])
+        return hip.segment_sum(contrib, None, row_off, V.shape[0], lanes=8)
 
     @staticmethod
     def backward(ctx, d_rows):
@@ -540,7 +540,7 @@ class BounceRays(torch.autograd.Function):
         dN = dr1 = None
         if dL is not None or d_brays is not None:
             d_nr = hip.ggx_rays_bwd(V, N, r1, c.off, c.sobol, c.row_of_ray, c.j_of_ray, cc(dL), cc(d_brays))
-            rows4 = hip.segment_sum(d_nr, None, c.row_off, Mb)
+            rows4 = hip.segment_sum(d_nr, None, c.row_off, Mb, lanes=8)
             dN, dr1 = rows4[:, 0:3], rows4[:, 3]
         d_normals, d_heads, d_app = hip.bounce_prep_bwd(c.inv, normals, heads, c.ray_id, c.rays, c.conv, c.min_rough,
                                                         c.detach_n, dN, dr1, d_f0, d_diff, d_feat, bidx=c.bidx,

@@ -406,13 +406,14 @@ def composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight):
     return d_sigma
 
 
-def segment_sum(vals, scale, offsets, n_seg):
+def segment_sum(vals, scale, offsets, n_seg, lanes=1):
+    """lanes=1: index-order sums (bit-reproducible); lanes=8: eight lanes per segment (tree sum)"""
     D = vals.shape[1]
     out = torch.empty((n_seg, D), dtype=torch.float32, device=vals.device)
     if vals.shape[0] == 0:
         return out.zero_()
     _check(_lib.nmf_segment_sum(_p(vals, torch.float32), _p(scale), _p(offsets, torch.int64), C.c_int64(n_seg),
-                                C.c_int32(D), _p(out), _stream()), "nmf_segment_sum")
+                                C.c_int32(D), C.c_int32(lanes), _p(out), _stream()), "nmf_segment_sum")
     return out
 
 

@@ -262,7 +262,8 @@ def test_composite_golden_and_backward():
 
 @pytest.mark.parametrize("b,N,p", [(300, 500, 0.4), (20000, 24, 0.3)])
 def test_composite_empty_and_long_segments(b, N, p):
-    """b = 300: wave-per-ray kernels (few rays, long segments); b = 20000: lane-per-ray kernels (many short rays)."""
+    """b = 300: one wave per ray (few rays, long segments); b = 20000: eight lanes per ray (many short rays, N = 24 spans
+    three passes of the lane group)."""
     hip = _hip()
     gen = torch.Generator().manual_seed(5)
     mask = torch.rand(b, N, generator=gen) < p
@@ -282,6 +283,19 @@ def test_composite_empty_and_long_segments(b, N, p):
     (gs,) = torch.autograd.grad((wo * dw).sum(), sigma)
     ds = hip.composite_bwd(sig_c, dist_c, w, off, b, 25.0, dw[mask].to(DEV).contiguous())
     assert_close(ds.cpu(), gs[mask], rtol=2e-4, atol=2e-6 * float(gs.abs().max()), what="d_sigma")
+    # segmented sums: index order (bit exact vs a sequential fp32 walk) and the eight-lane tree, D = 1..4 and wide rows
+    for D in (1, 3, 4):
+        vals = torch.randn(int(mask.sum()), D, generator=gen)
+        ref = torch.zeros(b, D, dtype=torch.float64).index_add_(0, torch.nonzero(mask)[:, 0], vals.double())
+        seq = hip.segment_sum(vals.to(DEV), None, off, b)
+        tree = hip.segment_sum(vals.to(DEV), None, off, b, lanes=8)
+        assert_close(seq.cpu(), ref.float(), rtol=1e-5, atol=1e-5, what="segment_sum index order")
+        assert_close(tree.cpu(), ref.float(), rtol=1e-5, atol=1e-5, what="segment_sum 8 lanes")
+    for D in (6, 24):
+        vals = torch.randn(int(mask.sum()), D + 2, generator=gen)
+        ref = torch.zeros(b, D, dtype=torch.float64).index_add_(0, torch.nonzero(mask)[:, 0], vals[:, :D].double())
+        wide = hip.segment_sum_wide(vals.to(DEV), D, off, b)
+        assert_close(wide.cpu(), ref.float(), rtol=1e-5, atol=2e-5, what="segment_sum_wide")
 
 
 # ---------------------------------------------------------------------------------------------
