@@ -150,7 +150,7 @@ class TensorVMSplit(torch.nn.Module):
         self.dbasis_mat = torch.nn.Linear(self.density_rf.dim(), 1, bias=False)
         self._cache = None
         self._plist = None
-        self._pass, self._pass_open = None, False
+        self._pass, self._pass_open, self._tables_memo = None, False, None
 
     # ---- geometry bookkeeping (fields/tensor_base.py:55-64,219-232) ---------------------------------
     def set_register(self, name, val):
@@ -188,6 +188,15 @@ class TensorVMSplit(torch.nn.Module):
         return self._plist
 
     def _tables(self):
+        # parameters cannot change inside a pass: one version / pointer comparison per pass, then the memo
+        if self._pass_open and self._tables_memo is not None:
+            return self._tables_memo
+        tab = self._tables_checked()
+        if self._pass_open:
+            self._tables_memo = tab
+        return tab
+
+    def _tables_checked(self):
         ps = self._param_list()
         key = [p._version for p in ps]
         if self._cache is None or self._cache[0] != key or self._cache[2] != [p.data_ptr() for p in ps]:
@@ -229,10 +238,10 @@ class TensorVMSplit(torch.nn.Module):
 
     # ---- gradient pass: all queries between begin_pass() and end_pass() share one FieldGrads node -----------
     def begin_pass(self):
-        self._pass, self._pass_open = None, True
+        self._pass, self._pass_open, self._tables_memo = None, True, None
 
     def end_pass(self):
-        self._pass, self._pass_open = None, False
+        self._pass, self._pass_open, self._tables_memo = None, False, None
 
     def _pass_token(self):
         ps = self._param_list()

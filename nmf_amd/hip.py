@@ -739,12 +739,10 @@ def loss_mix_fwd(tensors, weights, scale):
 
 
 def loss_mix_bwd(shapes, weights, scale, d_out):
-    """constant gradients d_out * scale * w_i shaped like the inputs (one launch, one allocation)"""
+    """constant gradients d_out * scale * w_i shaped like the inputs (one launch)"""
     n = len(shapes)
-    sizes = [int(math.prod(s)) for s in shapes]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=d_out.device)
-    grads = [v.view(s) for v, s in zip(flat.split(sizes), shapes)]
-    numel = (C.c_int64 * n)(*sizes)
+    grads = [torch.empty(s, dtype=torch.float32, device=d_out.device) for s in shapes]
+    numel = (C.c_int64 * n)(*[g.numel() for g in grads])
     w = (C.c_float * n)(*[float(v) for v in weights])
     gptrs = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
     _check(_lib.nmf_loss_mix_bwd(numel, w, C.c_int32(n), C.c_float(scale), _p(d_out, torch.float32), gptrs, _stream()),

@@ -34,6 +34,7 @@ class IntegralEquirect(torch.nn.Module):
         self._sh_cache = None
         self._sh_const = None
         self._scalars = None
+        self._memo = None
         self._pass, self._pass_open = None, False   # (GradPass, token) shared by the lookups of a forward/backward pass
 
     def get_optparam_groups(self, lr_scale=1):
@@ -56,6 +57,15 @@ class IntegralEquirect(torch.nn.Module):
     def _dev_scalars(self):
         """float32 [3] = (mipbias, brightness, mul) on the device, refreshed when a parameter changes: the kernels read the
         three learnable scalars from here, so an optimizer update never forces a host read-back"""
+        memo = self._memo
+        if memo is not None and "sc" in memo:
+            return memo["sc"]
+        sc = self._dev_scalars_checked()
+        if memo is not None:
+            memo["sc"] = sc
+        return sc
+
+    def _dev_scalars_checked(self):
         key = (self.mipbias._version, self.brightness._version, self.mul._version, self.mipbias.data_ptr())
         if self._scalars is None or self._scalars[0] != key:
             with torch.no_grad():
@@ -68,6 +78,15 @@ class IntegralEquirect(torch.nn.Module):
         return tuple(float(v) for v in self._dev_scalars().tolist())
 
     def _tables(self):
+        memo = self._memo
+        if memo is not None and "tab" in memo:
+            return memo["tab"]
+        tab = self._tables_checked()
+        if memo is not None:
+            memo["tab"] = tab
+        return tab
+
+    def _tables_checked(self):
         key = (self.bg_mat.data_ptr(), self.bg_mat._version, self.brightness._version, self.mul._version)
         if self._cache is None or self._cache[0] != key:
             act, sat = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars())
@@ -90,10 +109,12 @@ class IntegralEquirect(torch.nn.Module):
 
     # ---- gradient pass: every lookup between begin_pass() and end_pass() shares one SatBuild node ---------------
     def begin_pass(self):
-        self._pass, self._pass_open = None, True
+        # parameters cannot change inside a pass: the derived tables are looked up once and memoised until end_pass()
+        # (the version / pointer comparison of every cache costs ~15 us of host time per call on the critical path)
+        self._pass, self._pass_open, self._memo = None, True, {}
 
     def end_pass(self):
-        self._pass, self._pass_open = None, False
+        self._pass, self._pass_open, self._memo = None, False, None
 
     def _pass_token(self):
         if not (torch.is_grad_enabled() and (self.bg_mat.requires_grad or self.brightness.requires_grad
@@ -110,6 +131,15 @@ class IntegralEquirect(torch.nn.Module):
     @torch.no_grad()
     def get_spherical_harmonics(self, G, mipval=-5):
         """modules/integral_equirect.py:324-360; cached per bg_mat version (the reference recomputes it)."""
+        memo = self._memo
+        if memo is not None and ("sh", G, mipval) in memo:
+            return memo[("sh", G, mipval)]
+        out = self._spherical_harmonics_checked(G, mipval)
+        if memo is not None:
+            memo[("sh", G, mipval)] = out
+        return out
+
+    def _spherical_harmonics_checked(self, G, mipval):
         key = (self.bg_mat.data_ptr(), self.bg_mat._version, G, mipval, self.mipbias._version, self.brightness._version,
                self.mul._version)
         if self._sh_cache is None or self._sh_cache[0] != key:
