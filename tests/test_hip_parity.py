@@ -181,7 +181,7 @@ def test_vm_field_golden_values_normals_gradients():
         assert_close(gq, ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max()), what="grad " + k)
 
 
-@pytest.mark.parametrize("G,M,seed", [(16, 1, 0), (33, 777, 1), (128, 60000, 2)])
+@pytest.mark.parametrize("G,M,seed", [(16, 1, 0), (33, 777, 1), (128, 60000, 2), (300, 20000, 3)])   # 300: final grid of the schedule
 def test_vm_field_vs_oracle_random(G, M, seed):
     hip = _hip()
     gen = torch.Generator().manual_seed(seed)
@@ -200,7 +200,8 @@ def test_vm_field_vs_oracle_random(G, M, seed):
     nr_o = O.normals(sd, cfg, xyz)
     ca, cb, cc = torch.randn(M, generator=gen), torch.randn(M, 24, generator=gen), torch.randn(M, 3, generator=gen)
     gn = O.density_gradient(sd, cfg, xyz).detach().norm(dim=-1)
-    cc = cc * (gn > 0.05 * float(gn.median()))[:, None]      # d normalize/dg ~ 1/|g|: keep the test well conditioned
+    # d normalize/dg ~ 1/|g|: keep the test well conditioned (the round-off of g itself grows with G, see `ga` below)
+    cc = cc * (gn > (0.05 if G <= 128 else 0.3) * float(gn.median()))[:, None]
     loss = (sg_o * ca).sum() + (ap_o * cb).sum() + (nr_o * cc).sum()
     names = list(sd)
     ref = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
@@ -208,20 +209,22 @@ def test_vm_field_vs_oracle_random(G, M, seed):
     p = tabs[0]
     xyz_d = xyz.to(DEV).contiguous()
     sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyz_d, *tabs[1:], want_coef=True)
-    assert_close(sf.cpu(), sf_o.detach(), rtol=1e-5, atol=2e-5, what="sigma_feat")
-    assert_close(sg.cpu(), sg_o.detach(), rtol=2e-5, atol=1e-6, what="sigma")
-    assert_close(ap.cpu(), ap_o.detach(), rtol=1e-5, atol=1e-5, what="app")   # 72-term fp32 dot, |terms| ~ 0.1
+    # the texel coordinate is x * (G - 1) / 2 in fp32: its round-off, hence that of the interpolation weights, grows with G
+    ga = max(1.0, G / 128)
+    assert_close(sf.cpu(), sf_o.detach(), rtol=1e-5, atol=2e-5 * ga, what="sigma_feat")
+    assert_close(sg.cpu(), sg_o.detach(), rtol=2e-5 * ga, atol=1e-6 * ga, what="sigma")
+    assert_close(ap.cpu(), ap_o.detach(), rtol=1e-5, atol=1e-5 * ga, what="app")   # 72-term fp32 dot, |terms| ~ 0.1
     # a random field has samples with a vanishing gradient, where normalize() amplifies round-off:
     # compare the raw gradient everywhere and the unit normal where |g| is not tiny
     g_o = O.density_gradient(sd, cfg, xyz).detach()
-    assert_close(gr.cpu(), g_o, rtol=1e-4, atol=2e-5 * float(g_o.abs().max()), what="density gradient")
+    assert_close(gr.cpu(), g_o, rtol=1e-4, atol=2e-5 * ga * float(g_o.abs().max()), what="density gradient")
     ok = g_o.norm(dim=-1) > 0.05 * float(g_o.norm(dim=-1).median())
     assert int(ok.sum()) > 0.9 * M
-    assert_close(nr.cpu()[ok], nr_o.detach()[ok], rtol=1e-4, atol=2e-4, what="normals")
+    assert_close(nr.cpu()[ok], nr_o.detach()[ok], rtol=1e-4, atol=2e-4 * ga, what="normals")
     grads = _vm_backward(hip, p, xyz_d, tabs, sf, gr, ca.to(DEV), None, cc.to(DEV).contiguous(), cb.to(DEV).contiguous(), cf)
     for k, gq in grads.items():
         r = ref[k]
-        assert_close(gq, r, rtol=5e-4, atol=5e-5 * float(r.abs().max()), what="grad " + k)
+        assert_close(gq, r, rtol=5e-4 * ga, atol=5e-5 * ga * float(r.abs().max()), what="grad " + k)
 
 
 # ---------------------------------------------------------------------------------------------
