@@ -190,8 +190,9 @@ __global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __res
     // persistent accumulators
     floatx16 accW2 = {0}, accW0 = {0};
     float accW4 = 0.f;                   // thread (j = t>>6, k = t&63)
-    float accb = 0.f;                    // t<64: db0[t]; 64<=t<128: db2[t-64]; 128<=t<132: db4
-    float accW0tail = 0.f;               // t<128: dW0[t&63][64 + (t>>6)]
+    float accb = 0.f;                    // 64<=t<128: db2[t-64]; 128<=t<132: db4
+    float accW0tail = 0.f;               // waves 1, 3: dW0[lane][64 + (wave >> 1)]
+    float accb0 = 0.f;                   // wave 1: db0[lane]
     const int64_t n_tiles = (R + TR - 1) / TR;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t r0 = tile * TR;
@@ -266,30 +267,36 @@ __global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __res
         }
         __syncthreads();
         outer_quadrant(accW0, H1s, Xs, wr, wc, lane);                  // dW0[:, 0:64] += dH1^T X[:, 0:64]
-        if (t < 128) {                                                 // the two trailing input columns 64, 65
-            const int i = t & 63, c = 64 + (t >> 6);
+        if (wc == 0) {
+            // dX[:, 0:24] = dH1 W0[:, 0:24] -> adjoint of the gathered feature row, on the matrix core: waves 0 and 2 own
+            // the ray blocks 0-31 / 32-63 of a 64 x 32 product (feature columns 24..31 are padding), K = 64 units
+            floatx16 dx = {0};
+            const float* arow = H1s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
+            const int col = lane & 31;
+            const float* brow = W0f + (lane >> 5) * 24 + (col < 24 ? col : 0);
+            const float bmask = col < 24 ? 1.f : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < K2; ++kk)
+                dx = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], brow[2 * kk * 24] * bmask, dx, 0, 0, 0);
+            if (col < 24) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = r0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < R) d_xfeat[row * 24 + col] = dx[r];
+                }
+            }
+        } else {
+            // meanwhile waves 1 and 3: the two trailing input columns 64, 65 of dW0, then db0 on wave 1
+            const int i = lane, c = 64 + wr;
             float a = 0.f;
 #pragma unroll 8
             for (int ray = 0; ray < TR; ++ray) a += H1s[ray * LS + i] * Xs[ray * LS + c];
             accW0tail += a;
-        }
-        if (t < 64) {                                                  // db0
-            float b = 0.f;
-            for (int ray = 0; ray < TR; ++ray) b += H1s[ray * LS + t];
-            accb += b;
-        }
-        {   // dX[:, 0:24] = dH1 W0[:, 0:24]  -> adjoint of the gathered feature row
-            const int ray = t >> 2, f0 = (t & 3) * 6;
-            if (r0 + ray < R) {
-                float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const float* h = H1s + ray * LS;
-                for (int i = 0; i < HID; ++i) {
-                    const float hv = h[i];
-#pragma unroll
-                    for (int f = 0; f < 6; ++f) a[f] += hv * W0f[i * 24 + f0 + f];
-                }
-#pragma unroll
-                for (int f = 0; f < 6; ++f) d_xfeat[(r0 + ray) * 24 + f0 + f] = a[f];
+            if (wr == 0) {
+                float b = 0.f;
+#pragma unroll 8
+                for (int ray = 0; ray < TR; ++ray) b += H1s[ray * LS + lane];
+                accb0 += b;
             }
         }
     }
@@ -302,11 +309,11 @@ __global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __res
             atomicAdd(gW2 + row * HID + col, accW2[r]);
             atomicAdd(gW0 + row * IN + col, accW0[r]);
         }
-        if (t < 128) atomicAdd(gW0 + (t & 63) * IN + 64 + (t >> 6), accW0tail);
+        if (wc == 1) atomicAdd(gW0 + lane * IN + 64 + wr, accW0tail);
         atomicAdd(gW4 + (t >> 6) * HID + (t & 63), accW4);
-        if (t < 64) atomicAdd(gb0 + t, accb);
-        else if (t < 128) atomicAdd(gb2 + (t - 64), accb);
-        else if (t < 132) atomicAdd(gb4 + (t - 128), accb);
+        if (wave == 1) atomicAdd(gb0 + lane, accb0);
+        if (t >= 64 && t < 128) atomicAdd(gb2 + (t - 64), accb);
+        else if (t >= 128 && t < 132) atomicAdd(gb4 + (t - 128), accb);
     }
 }
 
