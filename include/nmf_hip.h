@@ -191,9 +191,15 @@ int nmf_segment_sum(const float* vals, const float* scale, const int64_t* offset
  * scalars_dev (optional, DEVICE float[3] = mipbias, brightness, mul) overrides the by-value scalars so that the
  * three learnable 0-d parameters never have to be read back to the host.
  * ---------------------------------------------------------------------------------------- */
-/* activated = exp(min(brightness + mul*bg_mat, 20)); sat = cumsum_W(cumsum_H(activated/1000)). */
+/* activated = exp(min(brightness + mul*bg_mat, 20)); sat = cumsum_W(cumsum_H(activated/1000));
+ * pole_rows [2][3] (optional) = mean of the first / last row of `activated` per channel (:499-502). */
 int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
-                  const float* scalars_dev, float* activated, float* sat, void* stream);
+                  const float* scalars_dev, float* activated, float* sat, float* pole_rows, void* stream);
+/* SH projection of prefiltered lookups (modules/integral_equirect.py:324-360, no gradient): coeffs[k][c] =
+ * sum_i wq[i][k] * vals[i][c] over n lattice directions (vals [n][3] from nmf_sat_lookup_fwd, wq [n][K] = quadrature
+ * weight x SH basis), conv[k][c] = sh_A[k] * coeffs[k][c] / pi (conv / sh_A may be NULL). */
+int nmf_sh_project(const float* vals, const float* wq, int64_t n, int32_t K, const float* sh_A, float* coeffs,
+                   float* conv, void* stream);
 /* d_sat = channel-interleaved adjoint table [H][W][4] (4th lane unused; accumulated by nmf_sat_lookup_bwd;
  * DESTROYED here) -> d_bg [3][H][W] (overwritten).
  * d_pole [2][3]: adjoint of the (top,bottom) pole-row means, may be NULL. */

@@ -436,14 +436,53 @@ __global__ void __launch_bounds__(256) k_sat_cols_rev(const float* __restrict__ 
 
 }  // namespace
 
+// SH irradiance coefficients (modules/integral_equirect.py:324-360): coeffs[k][c] = sum_i wq[i][k] * vals[i][c] over the
+// quadrature lattice, conv[k][c] = A[k] * coeffs[k][c] / pi.  One workgroup per (k, c), float64 partial sums.
+__global__ void __launch_bounds__(256) k_sh_project(const float* __restrict__ vals, const float* __restrict__ wq, int64_t n,
+                                                    int K, const float* __restrict__ A, float* __restrict__ coeffs,
+                                                    float* __restrict__ conv) {
+    __shared__ double ws[4];
+    const int k = blockIdx.x / 3, c = blockIdx.x % 3;
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) a += (double)wq[i * K + k] * (double)vals[i * 3 + c];
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(ws[0] + ws[1] + ws[2] + ws[3]);
+        coeffs[k * 3 + c] = v;
+        if (conv) conv[k * 3 + c] = (A[k] * v) / 3.14159265358979323846f;
+    }
+}
+
+// pole[0][c] = mean of the first row of activated[c], pole[1][c] = mean of its last row (:499-502): one wave per mean
+__global__ void __launch_bounds__(64) k_pole_rows(const float* __restrict__ act, int H, int W, float* __restrict__ pole) {
+    const int which = blockIdx.x / 3, c = blockIdx.x % 3, lane = lane_id();
+    const float* row = act + ((int64_t)c * H + (which ? H - 1 : 0)) * W;
+    double a = 0.0;
+    for (int x = lane; x < W; x += 64) a += (double)row[x];
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
+    if (lane == 0) pole[which * 3 + c] = (float)(a / (double)W);
+}
+
 extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
-                             const float* scalars_dev, float* activated, float* sat, void* stream) {
+                             const float* scalars_dev, float* activated, float* sat, float* pole_rows, void* stream) {
     NMF_REQUIRE(bg_mat && activated && sat && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build: null/size");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sat_cols, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
                        scalars_dev, activated, sat);
     hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W);
+    if (pole_rows) hipLaunchKernelGGL(k_pole_rows, dim3(6), dim3(64), 0, st, activated, H, W, pole_rows);
     NMF_CHECK_LAUNCH("nmf_sat_build");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sh_project(const float* vals, const float* wq, int64_t n, int32_t K, const float* sh_A, float* coeffs,
+                              float* conv, void* stream) {
+    NMF_REQUIRE(vals && wq && coeffs && n > 0 && K > 0 && K <= 64 && (!conv || sh_A), NMF_EINVAL, "nmf_sh_project: args");
+    hipLaunchKernelGGL(k_sh_project, dim3((unsigned)(3 * K)), dim3(256), 0, (hipStream_t)stream, vals, wq, n, (int)K, sh_A,
+                       coeffs, conv);
+    NMF_CHECK_LAUNCH("nmf_sh_project");
     return NMF_OK;
 }
 

@@ -199,15 +199,24 @@ class TensorVMSplit(torch.nn.Module):
     def _tables_checked(self):
         ps = self._param_list()
         key = [p._version for p in ps]
-        if self._cache is None or self._cache[0] != key or self._cache[2] != [p.data_ptr() for p in ps]:
-            G = int(hip.host(self.grid_size)[0])
-            vp = hip.vm_params(self.aabb, self.invaabbSize, self.density_shift, G)
-            dpl, dli = self.density_rf.tables()
-            apl, ali = self.app_rf.tables()
-            dpk, dlk = hip.vm_pack_density(vp, dpl, dli)
-            basis = self.basis_mat.weight.detach().contiguous()
-            # the pack may re-layout a parameter in place (channel-last): take versions / pointers afterwards
-            self._cache = ([p._version for p in ps], (vp, dpk, dlk, apl, ali, basis), [p.data_ptr() for p in ps])
+        ptrs = [p.data_ptr() for p in ps]
+        c = self._cache
+        if c is not None and c[2] == ptrs:
+            if c[0] != key:
+                # same storages, new values (an optimizer step): the views of the factors stay valid, only the packed
+                # density tables (value + derivative planes) are stale -- re-pack them in place
+                vp, dpk, dlk = c[1][0], c[1][1], c[1][2]
+                hip.vm_pack_density(vp, c[3][0], c[3][1], out=(dpk, dlk))
+                self._cache = (key, c[1], ptrs, c[3])
+            return c[1]
+        G = int(hip.host(self.grid_size)[0])
+        vp = hip.vm_params(self.aabb, self.invaabbSize, self.density_shift, G)
+        dpl, dli = self.density_rf.tables()
+        apl, ali = self.app_rf.tables()
+        dpk, dlk = hip.vm_pack_density(vp, dpl, dli)
+        basis = self.basis_mat.weight.detach().contiguous()
+        # the pack may re-layout a parameter in place (channel-last): take versions / pointers afterwards
+        self._cache = ([p._version for p in ps], (vp, dpk, dlk, apl, ali, basis), [p.data_ptr() for p in ps], (dpl, dli))
         return self._cache[1]
 
     def _grads_to_param_layout(self, gp, gl, g_apl, g_ali, g_basis):

@@ -68,7 +68,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -287,12 +287,15 @@ def vm_params(aabb, inv_size, density_shift, grid):
     return p
 
 
-def vm_pack_density(p, planes, lines):
-    """planes[i]: [G,G,16] channel-last storage, lines[i]: [G,16]."""
+def vm_pack_density(p, planes, lines, out=None):
+    """planes[i]: [G,G,16] channel-last storage, lines[i]: [G,16].  out = (dpk, dlk) of an earlier call re-packs in place."""
     G = p.grid
     dev = planes[0].device
-    dpk = [torch.empty((G, G, 48), dtype=torch.float32, device=dev) for _ in range(3)]
-    dlk = [torch.empty((G, 32), dtype=torch.float32, device=dev) for _ in range(3)]
+    if out is not None:
+        dpk, dlk = out
+    else:
+        dpk = [torch.empty((G, G, 48), dtype=torch.float32, device=dev) for _ in range(3)]
+        dlk = [torch.empty((G, 32), dtype=torch.float32, device=dev) for _ in range(3)]
     _check(_lib.nmf_vm_pack_density(C.byref(p), _p3(planes), _p3(lines), _p3(dpk), _p3(dlk), _stream()),
            "nmf_vm_pack_density")
     return dpk, dlk
@@ -418,16 +421,33 @@ def segment_sum(vals, scale, offsets, n_seg, lanes=1):
 
 
 # ---- environment map ---------------------------------------------------------------------------
-def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None):
-    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W].  sc: optional device float32 [3] = (mipbias, brightness, mul)
-    read by the kernels instead of the by-value scalars (no host read-back of the parameters)."""
+def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None, out=None, pole=False):
+    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W] (+ pole-row means [2,3] with pole=True).  sc: optional device
+    float32 [3] = (mipbias, brightness, mul) read by the kernels instead of the by-value scalars (no host read-back of the
+    parameters).  out = the tuple of an earlier call rebuilds the tables in place."""
     bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
     H, W = bg.shape[-2:]
-    act = torch.empty_like(bg)
-    sat = torch.empty_like(bg)
+    if out is not None:
+        act, sat = out[0], out[1]
+        pl = out[2] if pole else None
+    else:
+        act = torch.empty_like(bg)
+        sat = torch.empty_like(bg)
+        pl = torch.empty((2, 3), dtype=torch.float32, device=bg.device) if pole else None
     _check(_lib.nmf_sat_build(_p(bg.contiguous(), torch.float32), C.c_int32(H), C.c_int32(W), C.c_float(brightness),
-                              C.c_float(mul), _p(sc), _p(act), _p(sat), _stream()), "nmf_sat_build")
-    return act, sat
+                              C.c_float(mul), _p(sc), _p(act), _p(sat), _p(pl), _stream()), "nmf_sat_build")
+    return (act, sat, pl) if pole else (act, sat)
+
+
+def sh_project(vals, wq, sh_A, out=None):
+    """-> (coeffs [K,3], conv [K,3]); wq [n,K] contiguous, sh_A [>=K]"""
+    n, K = wq.shape[0], wq.shape[1]
+    if out is None:
+        out = (torch.empty((K, 3), dtype=torch.float32, device=vals.device),
+               torch.empty((K, 3), dtype=torch.float32, device=vals.device))
+    _check(_lib.nmf_sh_project(_p(vals, torch.float32), _p(wq, torch.float32), C.c_int64(n), C.c_int32(K),
+                               _p(sh_A, torch.float32), _p(out[0]), _p(out[1]), _stream()), "nmf_sh_project")
+    return out
 
 
 def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None):

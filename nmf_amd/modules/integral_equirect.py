@@ -66,12 +66,23 @@ class IntegralEquirect(torch.nn.Module):
         return sc
 
     def _dev_scalars_checked(self):
-        key = (self.mipbias._version, self.brightness._version, self.mul._version, self.mipbias.data_ptr())
-        if self._scalars is None or self._scalars[0] != key:
-            with torch.no_grad():
-                sc = torch.stack([self.mipbias.detach(), self.brightness.detach(), self.mul.detach()]).float().contiguous()
-            self._scalars = (key, sc)
-        return self._scalars[1]
+        ps = (self.mipbias, self.brightness, self.mul)
+        key = (ps[0]._version, ps[1]._version, ps[2]._version)
+        ptrs = (ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr())
+        c = self._scalars
+        if c is None or c[2] != ptrs:
+            # persistent float32 [3] + the slot table of the converting copy (0-d float64 parameters, :199-207)
+            sc = torch.empty(3, dtype=torch.float32, device=self.bg_mat.device)
+            slots = (hip.CopySlot * 3)()
+            for i, p in enumerate(ps):
+                if p.dtype not in (torch.float32, torch.float64):
+                    raise hip.NmfHipError("env-map scalars must be float32 or float64")
+                slots[i] = hip.CopySlot(p.data_ptr(), sc.data_ptr() + 4 * i, 1, 1 if p.dtype == torch.float64 else 0, 0)
+            c = self._scalars = (None, sc, ptrs, slots)
+        if c[0] != key:
+            hip.multi_copy(c[3], 3)                      # one launch, no host read-back, no temporaries
+            self._scalars = (key, c[1], c[2], c[3])
+        return c[1]
 
     def _host_scalars(self):
         """(mipbias, brightness, mul) as python floats (one read-back; used by tests / tools, not by the render path)"""
@@ -87,11 +98,15 @@ class IntegralEquirect(torch.nn.Module):
         return tab
 
     def _tables_checked(self):
-        key = (self.bg_mat.data_ptr(), self.bg_mat._version, self.brightness._version, self.mul._version)
-        if self._cache is None or self._cache[0] != key:
-            act, sat = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars())
-            pole = torch.stack([act[:, 0, :].mean(-1), act[:, -1, :].mean(-1)]).contiguous()
-            self._cache = (key, (act, sat, pole))
+        key = (self.bg_mat._version, self.brightness._version, self.mul._version)
+        ptr = self.bg_mat.data_ptr()
+        c = self._cache
+        if c is None or c[2] != ptr:
+            tab = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), pole=True)
+            self._cache = (key, tab, ptr)
+        elif c[0] != key:       # same storage, new values (an optimizer step): rebuild the tables in place
+            hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), out=c[1], pole=True)
+            self._cache = (key, c[1], ptr)
         return self._cache[1]
 
     def activation_fn(self, x):
@@ -154,13 +169,12 @@ class IntegralEquirect(torch.nn.Module):
                                     torch.cos(theta)], dim=-1).reshape(-1, 3).contiguous()
                 SB = dirs.shape[0]
                 wq = (2 * np.pi ** 2 / SB) * sh.eval_sh_bases(9, dirs) * torch.sin(theta.reshape(SB, 1))     # [SB, 9]
-                self._sh_const = (ck, dirs, torch.full((SB,), float(mipval), device=dev), wq.reshape(SB, 9, 1).contiguous())
-            _, dirs, mips, wq = self._sh_const
+                self._sh_const = (ck, dirs, torch.full((SB,), float(mipval), device=dev), wq.float().contiguous(),
+                                  self.sh_A.reshape(-1)[:9].float().contiguous())
+            _, dirs, mips, wq, shA = self._sh_const
             act, sat, pole = self._tables()
             bg = hip.sat_lookup_fwd(sat, dirs, mips, 0.0, pole, sc=self._dev_scalars())
-            coeffs = (wq * bg.reshape(-1, 1, 3)).sum(dim=0)
-            conv = self.sh_A.reshape(-1, 1)[: coeffs.shape[0]] * coeffs
-            self._sh_cache = (key, (coeffs, (conv / np.pi).contiguous()))
+            self._sh_cache = (key, hip.sh_project(bg, wq, shA))            # (coeffs, conv) [9,3] each
         return self._sh_cache[1]
 
     def _load_from_state_dict(self, *a, **k):

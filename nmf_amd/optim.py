@@ -3,8 +3,10 @@ builds), executed as ONE kernel launch for all parameter tensors (nmf_adam_step,
 ~13 foreach launches per param group.  param_groups / state_dict / LambdaLR work as with torch.optim.Adam
 (state keys: step, exp_avg, exp_avg_sq); amsgrad / maximize / capturable are not supported (the reference does not
 use them)."""
+import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import hip
@@ -13,23 +15,78 @@ from . import hip
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
-        super().__init__(params, defaults)
         self._slots = None
+        self._plan = None
+        super().__init__(params, defaults)
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise hip.NmfHipError("FusedAdam.step does not take a closure")
+        if not self._step_planned():
+            self._step_checked()
+
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad without its per-call profiler / hook plumbing (50 us per step for 31 tensors)"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
+    def _step_planned(self):
+        """Steady state: the same tensors carry gradients of the same layout as in the previous step, so the slot table is
+        already filled except for the gradient pointers and the step-dependent factors (the full validation of
+        _step_checked costs ~9 us per tensor, i.e. 270 us of host time per step on a path where the GPU is waiting)."""
+        plan = self._plan
+        if plan is None:
+            return False
+        slots, entries, skipped, hyper0, col_u64, col_f64 = plan
+        hyper = [(g["betas"][0], g["betas"][1], float(g["eps"]), float(g["weight_decay"])) for g in self.param_groups]
+        if hyper != hyper0:
+            return False
+        for p in skipped:
+            if p.grad is not None:
+                return False
+        gptr = []
+        for p, st, gi, pptr, gstride in entries:        # validate everything before touching any state
+            g = p.grad
+            if g is None or g.dtype != p.dtype or g.stride() != gstride or p.data_ptr() != pptr or g.is_sparse:
+                return False
+            gptr.append(g.data_ptr())
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        memo, step_size, bc2 = {}, [], []
+        for p, st, gi, pptr, gstride in entries:
+            st["step"] = t = st["step"] + 1
+            f = memo.get((gi, t))
+            if f is None:
+                beta1, beta2 = hyper[gi][0], hyper[gi][1]
+                f = memo[(gi, t)] = (lrs[gi] / (1 - beta1 ** t), math.sqrt(1 - beta2 ** t))
+            step_size.append(f[0])
+            bc2.append(f[1])
+        n = len(entries)
+        if n:
+            # the slot table is a dense array of 12 eight-byte words per tensor: write the three per-step columns at once
+            col_u64[:n, 1] = gptr
+            col_f64[:n, 9] = step_size
+            col_f64[:n, 10] = bc2
+            hip.adam_step(slots, n)
+            torch.autograd.graph.increment_version([e[0] for e in entries])
+        return True
+
+    def _step_checked(self):
         n_params = sum(len(g["params"]) for g in self.param_groups)
         if self._slots is None or len(self._slots) < n_params:
             self._slots = (hip.AdamSlot * max(n_params, 1))()
         slots, n, keep, touched = self._slots, 0, [], []
-        for group in self.param_groups:
+        entries, skipped, plannable = [], [], True
+        for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
             lr, eps, wd = float(group["lr"]), float(group["eps"]), float(group["weight_decay"])
             for p in group["params"]:
                 g = p.grad
                 if g is None:
+                    skipped.append(p)
                     continue
                 if g.is_sparse:
                     raise hip.NmfHipError("FusedAdam does not support sparse gradients")
@@ -46,6 +103,7 @@ class FusedAdam(torch.optim.Optimizer):
                         raise hip.NmfHipError("FusedAdam: parameter storage must be dense")
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                     keep.append(g)
+                    plannable = False                      # this gradient needs a re-layout copy every step
                 s = slots[n]
                 s.param, s.grad = p.data_ptr(), g.data_ptr()
                 s.exp_avg, s.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
@@ -56,12 +114,29 @@ class FusedAdam(torch.optim.Optimizer):
                 s.is_f64 = 1 if p.dtype == torch.float64 else 0
                 n += 1
                 touched.append(p)
+                entries.append((p, st, gi, p.data_ptr(), p.grad.stride()))
         if n:
             hip.adam_step(slots, n)
             # the kernel writes through raw pointers: tell autograd (and every cache keyed on Tensor._version -- packed
             # density tables, SAT, stacked head weights, host mirrors of scalars) that the parameters changed
             torch.autograd.graph.increment_version(touched)
+        if plannable:
+            hyper = [(g["betas"][0], g["betas"][1], float(g["eps"]), float(g["weight_decay"])) for g in self.param_groups]
+            words = C.sizeof(hip.AdamSlot) // 8
+            assert words == 12
+            self._plan = (slots, entries, skipped, hyper, np.frombuffer(slots, dtype=np.uint64).reshape(-1, words),
+                          np.frombuffer(slots, dtype=np.float64).reshape(-1, words))
+        else:
+            self._plan = None
         return None
+
+    def add_param_group(self, group):
+        self._plan = None
+        return super().add_param_group(group)
+
+    def load_state_dict(self, state_dict):
+        self._plan = None
+        return super().load_state_dict(state_dict)
 
 
 def _same_layout(a, b):

@@ -1,6 +1,8 @@
 """GPU parity: the HIP kernels (through the C ABI, nmf_amd/hip.py) against the CPU oracle and against
 the reference's golden vectors.  Bit-exact for masks / indices / counts / sample positions;
 floats within the stated tolerances.  Run on the MI355X box with `-m gpu`."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -332,6 +334,21 @@ def test_env_sat_build_matches_cpu_rounding(H):
     frac = float((sat.cpu() != sat_ref).float().mean())
     assert frac < 0.05, frac
     assert_close(sat.cpu(), sat_ref, rtol=3e-7, atol=0, what="sat vs cpu")
+    # in-place rebuild with the scalars on the device + pole-row means (:499-502) + SH projection (:324-360)
+    sc = torch.tensor([1.0, 0.1, 0.9], device=DEV)
+    tab = hip.sat_build(bg.to(DEV), sc=sc, pole=True)
+    ptrs = [t.data_ptr() for t in tab]
+    tab2 = hip.sat_build(bg.to(DEV), sc=torch.tensor([1.0, 0.0, 1.0], device=DEV), out=tab, pole=True)
+    assert [t.data_ptr() for t in tab2] == ptrs
+    assert torch.equal(tab2[0], act) and torch.equal(tab2[1], sat)
+    pole_ref = torch.stack([act.cpu()[:, 0, :].double().mean(-1), act.cpu()[:, -1, :].double().mean(-1)]).float()
+    assert_close(tab2[2].cpu(), pole_ref, rtol=2e-7, atol=0, what="pole rows")
+    n, K = 777, 9
+    vals, wq, shA = torch.randn(n, 3, generator=gen), torch.randn(n, K, generator=gen), torch.rand(K, generator=gen)
+    coeffs, conv = hip.sh_project(vals.to(DEV), wq.to(DEV), shA.to(DEV))
+    ref = torch.einsum("ik,ic->kc", wq.double(), vals.double())
+    assert_close(coeffs.cpu(), ref.float(), rtol=1e-6, atol=1e-6, what="sh coeffs")
+    assert_close(conv.cpu(), (shA.double()[:, None] * ref / math.pi).float(), rtol=1e-6, atol=1e-6, what="sh conv")
 
 
 def test_env_lookup_golden_and_gradients():
