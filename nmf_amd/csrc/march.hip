@@ -41,28 +41,31 @@ __device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const floa
 // every lane running the 10 Philox rounds for its own step (and discarding 3 of the 4 outputs), lane l evaluates counter
 // 64 g + l once per GROUP of four rounds (steps [256 g, 256 g + 256)) and the rounds fetch their uniform with shuffles.
 // Same stream, same values: ~100 of ~190 VALU instructions per step gone (the marcher is VALU-bound).
-struct JitterCache {
-    uint32_t o[4];
+struct JitterCache {     // four scalar members, always passed by reference: stays in VGPRs (an o[4] reached through a
+    uint32_t o0, o1, o2, o3;   // conditional pointer was placed in scratch: one 16-byte scratch load per round)
+    bool on;
 };
 __device__ __forceinline__ void jc_fill(JitterCache& c, const Philox& rng, const nmf_march_params& p, int64_t r, int g) {
-    rng((uint64_t)r * 1024u + (uint64_t)(64 * g + lane_id()), p.offset, c.o);
+    uint32_t o[4];
+    rng((uint64_t)r * 1024u + (uint64_t)(64 * g + lane_id()), p.offset, o);
+    c.o0 = o[0]; c.o1 = o[1]; c.o2 = o[2]; c.o3 = o[3];
 }
 // uniform of step 256 g + k_local (all lanes of the wave must call this together)
 __device__ __forceinline__ float jc_get(const JitterCache& c, int k_local) {
     const int src = (k_local >> 2) & 63, comp = k_local & 3;
-    const uint32_t v0 = __shfl(c.o[0], src, 64), v1 = __shfl(c.o[1], src, 64);
-    const uint32_t v2 = __shfl(c.o[2], src, 64), v3 = __shfl(c.o[3], src, 64);
+    const uint32_t v0 = __shfl(c.o0, src, 64), v1 = __shfl(c.o1, src, 64);
+    const uint32_t v2 = __shfl(c.o2, src, 64), v3 = __shfl(c.o3, src, 64);
     return u32_to_unit(comp == 0 ? v0 : (comp == 1 ? v1 : (comp == 2 ? v2 : v3)));
 }
 
 // step length of candidate k (train) -- alphagrid.py:169-172
 __device__ __forceinline__ float step_len(const nmf_march_params& p, const float* jitter, const Philox& rng,
-                                          int64_t r, int k, const JitterCache* jc = nullptr) {
+                                          int64_t r, int k, const JitterCache& jc) {
     float u;
     if (jitter) {
         u = jitter[r * p.n_steps + k];
-    } else if (jc) {
-        u = jc_get(*jc, k & 255);
+    } else if (jc.on) {
+        u = jc_get(jc, k & 255);
     } else {
         uint32_t o[4];
         rng((uint64_t)r * 1024u + (uint64_t)(k >> 2), p.offset, o);
@@ -133,7 +136,7 @@ struct StepOut {
 
 __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const RayCtx& c, const float* jitter,
                                              const Philox& rng, const uint32_t* bits, const uint32_t* coarse, int64_t r,
-                                             int k, double& carry, double* cum_out, const JitterCache* jc = nullptr) {
+                                             int k, double& carry, double* cum_out, const JitterCache& jc) {
     const bool in_range = k < p.n_steps;
     float step;
     double cum = 0.0;
@@ -162,7 +165,7 @@ __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const Ra
 
 // Pass 1: one wave per ray, lane = step within the current group of 64 candidates.  Workgroups are persistent
 // (grid-stride over rays) so the coarse occupancy mask is staged into LDS once per workgroup.
-__global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const float* __restrict__ rays, int64_t B,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) k_march_count(nmf_march_params p, const float* __restrict__ rays, int64_t B,
                                                      const float* __restrict__ jitter,
                                                      const uint32_t* __restrict__ bits,
                                                      const uint32_t* __restrict__ coarse, int coarse_words,
@@ -183,11 +186,13 @@ __global__ void __launch_bounds__(256) k_march_count(nmf_march_params p, const f
         int total = 0;
         int j = 0;
         JitterCache jc;
+        jc.o0 = jc.o1 = jc.o2 = jc.o3 = 0u;
         const bool use_jc = p.is_train && !jitter;
+        jc.on = use_jc;
         for (; j < W; ++j) {
             if (use_jc && (j & 3) == 0) jc_fill(jc, rng, p, r, j >> 2);
             StepOut o = march_one(p, c, jitter, rng, bits, s_coarse, r, j * 64 + lane, carry, nullptr,
-                                  use_jc ? &jc : nullptr);
+                                  jc);
             uint64_t m = __ballot(o.keep);
             total += __popcll(m);
             if (lane == 0) valid[r * W + j] = m;
@@ -239,11 +244,29 @@ __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const fl
     RayCtx c = load_ray(p, rays, r);
     Philox rng(p.seed);
     double carry = 0.0;
+    JitterCache jc, jc_off;
+    jc.o0 = jc.o1 = jc.o2 = jc.o3 = 0u;
+    jc.on = p.is_train && !jitter;
+    jc_off = jc;
+    jc_off.on = false;
     for (int j = 0; j < W; ++j) {
         const int k = j * 64 + lane;
         double cum;
+        if (jc.on && (j & 3) == 0) jc_fill(jc, rng, p, r, j >> 2);
         // positions are recomputed (cheap) instead of being stored by pass 1
-        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, &cum);
+        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, &cum, jc);
+        // step length of the NEXT candidate (the sample's dist, :348-350), fetched while the wave is still converged:
+        // it sits in the jitter cache except for the last step of a 256-step group (next Philox counter group)
+        float s_next = 0.f;
+        if (dist && p.is_train) {
+            const int kn = min(k + 1, p.n_steps - 1);
+            if (jc.on) {
+                s_next = fadd(fmul(jc_get(jc, kn & 255), p.stepsize), p.half_step);
+                if ((k & 255) == 255) s_next = step_len(p, jitter, rng, r, kn, jc_off);
+            } else {
+                s_next = step_len(p, jitter, rng, r, kn, jc_off);
+            }
+        }
         const uint64_t m = valid[r * W + j];
         if ((m >> lane) & 1ull) {
             int64_t idx = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -255,12 +278,8 @@ __global__ void __launch_bounds__(256) k_march_fill(nmf_march_params p, const fl
                 float d = 0.f;                                                              // :348-350
                 if (k + 1 < p.n_steps) {
                     float znext;
-                    if (p.is_train) {
-                        float s = step_len(p, jitter, rng, r, k + 1);
-                        znext = fadd(c.tmin, (float)(cum + (double)s));
-                    } else {
-                        znext = fadd(c.tmin, fmul(p.stepsize, (float)(k + 1)));
-                    }
+                    if (p.is_train) znext = fadd(c.tmin, (float)(cum + (double)s_next));
+                    else znext = fadd(c.tmin, fmul(p.stepsize, (float)(k + 1)));
                     d = fsub(znext, o.z);
                 }
                 dist[idx] = d;
@@ -282,9 +301,12 @@ __global__ void __launch_bounds__(256) k_march_dense(nmf_march_params p, const f
     RayCtx c = load_ray(p, rays, r);
     Philox rng(p.seed);
     double carry = 0.0;
+    JitterCache jc_off;
+    jc_off.o0 = jc_off.o1 = jc_off.o2 = jc_off.o3 = 0u;
+    jc_off.on = false;
     for (int j = 0; j < W; ++j) {
         const int k = j * 64 + lane;
-        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, nullptr);
+        StepOut o = march_one(p, c, jitter, rng, nullptr, nullptr, r, k, carry, nullptr, jc_off);
         if (k < p.n_steps) {
             if (ray_valid) ray_valid[r * p.n_steps + k] = (uint8_t)((valid[r * W + j] >> lane) & 1ull);
             if (z_vals) z_vals[r * p.n_steps + k] = o.z;
