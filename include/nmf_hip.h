@@ -207,14 +207,16 @@ int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float* activated,
                       float brightness, float mul, const float* scalars_dev, const float* d_pole, float* d_bg,
                       void* stream);
 /* out[r] = prefiltered radiance along dirs[r] for log-solid-angle sa[r] (IntegralEquirect.forward).
- * pole_rows [2][3] = mean of the first / last row of `activated` (:499-502). */
-int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs /*[R][3]*/,
+ * pole_rows [2][3] = mean of the first / last row of `activated` (:499-502).
+ * dirs_ld = row pitch of dirs in floats: 3 for [R][3] directions, 6 for [R][6] ray rows (origin | direction) whose
+ * direction is columns 3..5 -- secondary rays are looked up without slicing them (tensor_nerf.py:302-317). */
+int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
                        const float* sa /*[R]*/, int64_t R, float mipbias, const float* scalars_dev,
                        const float* pole_rows, float* out /*[R][3]*/, void* stream);
 /* Adjoints: d_sat [H][W][4] (channel-interleaved so that 8 lanes share one 32-byte atomic run, see csrc/env.hip) and
- * d_pole [2][3] are ACCUMULATED (caller zeroes), d_dirs [R][3] is overwritten, d_mipbias [1] accumulated.
- * d_sat / d_dirs / d_mipbias may be NULL. */
-int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
+ * d_pole [2][3] are ACCUMULATED (caller zeroes), d_dirs [R][dirs_ld] is overwritten (with dirs_ld = 6 the origin
+ * columns are written as zeros), d_mipbias [1] accumulated.  d_sat / d_dirs / d_mipbias may be NULL. */
+int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
                        int64_t R, float mipbias, const float* scalars_dev, const float* d_out /*[R][3]*/,
                        float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
 
@@ -251,7 +253,7 @@ int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_ro
 int nmf_shade_mix_fwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
                       const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
                       const float* incoming, const float* brdf, float* contrib, void* stream);
-/* d_rows [Mb][3] = adjoint of the row sums.  d_incoming, d_brdf [R][3] overwritten; dL [R][3] ADDED TO;
+/* d_rows [Mb][3] = adjoint of the row sums.  d_incoming, d_brdf, dL [R][3] overwritten;
  * d_f0diff [R][6] = per-ray (d f0 | d diffuse), reduce per row. */
 int nmf_shade_mix_bwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
                       const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,

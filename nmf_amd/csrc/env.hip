@@ -239,7 +239,7 @@ struct ListAcc {   // table adjoint, phase 1: park (texel, fractions, sign) of e
 };
 
 // ---- kernels -----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs,
+__global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                         const float* __restrict__ sa, int64_t R, float mipbias,
                                                         const float* __restrict__ sc,
                                                         const float* __restrict__ pole_rows /*[2][3] top,bot*/,
@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     if (sc) mipbias = sc[0];
-    const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
+    const float* q = dirs + r * ld + (ld - 3);            // ld = 6: [origin | direction] ray rows
+    const float a = q[0], b = q[1], c = q[2];
     Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
     SumAcc<float> acc;
     acc.tab = tab;
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
     out[r * 3] = v[0]; out[r * 3 + 1] = v[1]; out[r * 3 + 2] = v[2];
 }
 
-__global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs,
+__global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                        const float* __restrict__ sa, int64_t R, float mipbias,
                                                        const float* __restrict__ sc,
                                                        const float* __restrict__ d_out, float* __restrict__ d_sat4,
@@ -277,7 +278,10 @@ __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* 
     int n_corner = 0;
     float gk[3] = {0.f, 0.f, 0.f};
     if (r < R) {
-        const float a = dirs[r * 3], b = dirs[r * 3 + 1], c = dirs[r * 3 + 2];
+        const float* q = dirs + r * ld + (ld - 3);
+        const float a = q[0], b = q[1], c = q[2];
+        float* dq = d_dirs ? d_dirs + r * ld + (ld - 3) : nullptr;
+        if (dq && ld == 6) { dq[-3] = 0.f; dq[-2] = 0.f; dq[-1] = 0.f; }          // no dependence on the ray origin
         const float go[3] = {d_out[r * 3], d_out[r * 3 + 1], d_out[r * 3 + 2]};
         Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
         const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* 
             // value = mean of a pole row of the activated map: no dependence on dirs / mipbias
             float* q = d_pole + (top ? 0 : 3);
             atomicAdd(q, go[0]); atomicAdd(q + 1, go[1]); atomicAdd(q + 2, go[2]);
-            if (d_dirs) { d_dirs[r * 3] = 0.f; d_dirs[r * 3 + 1] = 0.f; d_dirs[r * 3 + 2] = 0.f; }
+            if (dq) { dq[0] = 0.f; dq[1] = 0.f; dq[2] = 0.f; }
         } else {
             if (d_sat4) {
                 ListAcc lacc;
@@ -311,7 +315,7 @@ __global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     gsum[i] = 1000.f * (go[0] * acc.total[0].d[i] + go[1] * acc.total[1].d[i] + go[2] * acc.total[2].d[i]);
-                if (d_dirs) { d_dirs[r * 3] = gsum[0]; d_dirs[r * 3 + 1] = gsum[1]; d_dirs[r * 3 + 2] = gsum[2]; }
+                if (dq) { dq[0] = gsum[0]; dq[1] = gsum[1]; dq[2] = gsum[2]; }
                 dm = gsum[3];
             }
         }
@@ -498,28 +502,30 @@ extern "C" int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float*
     return NMF_OK;
 }
 
-extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
-                                  int64_t R, float mipbias, const float* scalars_dev, const float* pole_rows, float* out,
-                                  void* stream) {
+extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
+                                  const float* sa, int64_t R, float mipbias, const float* scalars_dev,
+                                  const float* pole_rows, float* out, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_fwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && pole_rows && out, NMF_EINVAL, "nmf_sat_lookup_fwd: null");
+    NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_fwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W};
-    hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs, sa,
-                       R, mipbias, scalars_dev, pole_rows, out);
+    hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
+                       (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
     return NMF_OK;
 }
 
-extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, const float* sa,
-                                  int64_t R, float mipbias, const float* scalars_dev, const float* d_out, float* d_sat,
-                                  float* d_pole, float* d_dirs, float* d_mipbias, void* stream) {
+extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
+                                  const float* sa, int64_t R, float mipbias, const float* scalars_dev, const float* d_out,
+                                  float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
+    NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W};
-    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, tab, dirs, sa,
-                       R, mipbias, scalars_dev, d_out, d_sat, d_pole, d_dirs, d_mipbias);
+    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, tab, dirs,
+                       (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole, d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
     return NMF_OK;
 }

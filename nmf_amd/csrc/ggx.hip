@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) k_shade_mix_fwd(const float* __restrict__
     }
 }
 
-// adjoints per ray: d_inc [R][3], d_brdf [R][3], dL [R][3] (ADDED to dL), d_f0diff [R][6] = (d f0 | d diffuse),
+// adjoints per ray: d_inc [R][3], d_brdf [R][3], dL [R][3], d_f0diff [R][6] = (d f0 | d diffuse), all overwritten,
 // to be reduced per row by the caller
 __global__ void __launch_bounds__(256) k_shade_mix_bwd(const float* __restrict__ Vrow, const float* __restrict__ f0row,
                                                        const float* __restrict__ diffrow,
@@ -244,9 +244,9 @@ __global__ void __launch_bounds__(256) k_shade_mix_bwd(const float* __restrict__
     const float hd = dH.x * H.x + dH.y * H.y + dH.z * H.z;
     const float s = n2 > EPS_F ? 1.f : 0.f;     // clip: below eps H = h / sqrt(eps), no projection term
     const float k2 = 0.5f * inv;
-    dL[i * 3] += k2 * (dH.x - s * hd * H.x);
-    dL[i * 3 + 1] += k2 * (dH.y - s * hd * H.y);
-    dL[i * 3 + 2] += k2 * (dH.z - s * hd * H.z);
+    dL[i * 3] = k2 * (dH.x - s * hd * H.x);
+    dL[i * 3 + 1] = k2 * (dH.y - s * hd * H.y);
+    dL[i * 3 + 2] = k2 * (dH.z - s * hd * H.z);
 }
 
 }  // namespace

@@ -461,11 +461,12 @@ def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None):
 
 
 def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
-    R = dirs.shape[0]
+    """dirs: [R,3] directions, or [R,6] ray rows (origin | direction) looked up along their columns 3..5"""
+    R, ld = dirs.shape[0], dirs.shape[1]
     H, W = sat.shape[-2:]
     out = torch.empty((R, 3), dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_fwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), _p(pole_rows), _p(out),
+                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), _p(pole_rows), _p(out),
                                    _stream()), "nmf_sat_lookup_fwd")
     return out
 
@@ -473,14 +474,14 @@ def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
 def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
     """d_sat [H,W,4] / d_pole [2,3] / d_mip [1] are ACCUMULATED into (any may be None except d_pole).  Returns d_dirs; with
     want_mipbias=True (legacy form) a fresh d_mip accumulator is allocated and (d_dirs, d_mip) is returned."""
-    R = dirs.shape[0]
+    R, ld = dirs.shape[0], dirs.shape[1]
     H, W = sat.shape[-2:]
-    d_dirs = torch.empty((R, 3), dtype=torch.float32, device=dirs.device) if want_dirs else None
+    d_dirs = torch.empty((R, ld), dtype=torch.float32, device=dirs.device) if want_dirs else None   # shaped like dirs
     legacy = want_mipbias is not None
     if legacy and want_mipbias and d_mip is None:
         d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc),
+                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc),
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
                                    _stream()), "nmf_sat_lookup_bwd")
     return (d_dirs, d_mip) if legacy else d_dirs
@@ -604,7 +605,7 @@ def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
     dev = V.device
     d_inc = torch.empty((R, 3), dtype=torch.float32, device=dev)
     d_brdf = torch.empty((R, 3), dtype=torch.float32, device=dev)
-    dL = torch.zeros((R, 3), dtype=torch.float32, device=dev)
+    dL = torch.empty((R, 3), dtype=torch.float32, device=dev)
     d_fd = torch.empty((R, 6), dtype=torch.float32, device=dev)
     _check(_lib.nmf_shade_mix_bwd(_p(V, torch.float32), _p(f0, torch.float32), _p(diff, torch.float32), _p(cnt, torch.int32),
                                   _p(row_of_ray, torch.int32), C.c_int64(R), _p(L, torch.float32), _p(inc, torch.float32),

@@ -154,7 +154,7 @@ class Microfacet(torch.nn.Module):
         if sparse:      # appearance, its noise, the heads, GGX rays and BRDF weights of the bounce rows: one graph node
             c = types.SimpleNamespace()
             c.field = field = app_fn.__self__
-            c.xyz_rows = torch.index_select(samples.xyzt, 0, bidx.long())
+            c.xyz_rows = torch.index_select(samples.xyzt, 0, bidx)
             c.field_holder, tok_field = field._pass_token()
             c.head_hp, c.head_W, c.head_b, c.head_holder, tok_heads = self.diffuse_module.head_pass()            # :299
             c.mlp_ws, c.mlp_bias, c.mlp_holder, tok_mlp = self.brdf.mlp_pass()

@@ -116,6 +116,8 @@ class IntegralEquirect(torch.nn.Module):
         return self.activation_fn(self.bg_mat).reshape(-1, 3).mean(dim=0)
 
     def forward(self, viewdirs, saSample, max_level=None):
+        """viewdirs [R,3]; the build's callers may also hand over [R,6] ray rows (origin | direction): they are looked up
+        along columns 3..5 in place, and the gradient comes back with the rays' own shape (no slice / pad kernels)."""
         if viewdirs.shape[0] == 0:
             return viewdirs.new_zeros((0, 3))
         sa = saSample.reshape(-1).detach().float()

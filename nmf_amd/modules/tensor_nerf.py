@@ -146,7 +146,8 @@ class TensorNeRF(torch.nn.Module):
         n_samples = [M]
         wv = S.whole_valid
         offsets = S.offsets[: B + 1]
-        ray_dirs = rays[:B, 3:6]                       # valid rays are a prefix (alphagrid.py:359)
+        # valid rays are a prefix (alphagrid.py:359); the env-map lookup takes whole ray rows and reads columns 3..5
+        ray_dirs = rays if B == rays.shape[0] else rays[:B]
 
         # Sparse appearance: the radiance only depends on the appearance features of the samples that spawn secondary
         # rays, so unless the per-sample debug maps are wanted (eval with draw_debug) the field's appearance branch and the
@@ -167,7 +168,7 @@ class TensorNeRF(torch.nn.Module):
                 return ims["rgb_map"]
             noise.skip("rand", (brays.shape[0],))
             noise.skip("rand", (brays.shape[0],))
-            return self.render_just_bg(brays[..., 3:6], mipval.reshape(-1))
+            return self.render_just_bg(brays, mipval.reshape(-1))
 
         shaded = None
         if M > 0:
