@@ -71,12 +71,13 @@ class PassMixin:
     (GradPass, token) pair, i.e. one gradient node per parameter set (TensorNeRF.forward opens it at recursion 0)."""
     _pass = None
     _pass_open = False
+    _memo = None        # per-pass memo of derived operands (stacked / detached weights): parameters cannot change inside a pass
 
     def begin_pass(self):
-        self._pass, self._pass_open = None, True
+        self._pass, self._pass_open, self._memo = None, True, {}
 
     def end_pass(self):
-        self._pass, self._pass_open = None, False
+        self._pass, self._pass_open, self._memo = None, False, None
 
     def _param_pass(self, params):
         if not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):

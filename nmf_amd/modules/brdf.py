@@ -43,10 +43,15 @@ class MLPBRDF(PassMixin, torch.nn.Module):
         """(weights, bias, holder, token) for fused callers (functional.BounceRays)"""
         if not self.fused:
             raise NotImplementedError("the fused path implements hidden_w=64, num_layers=3 (microfacet_tensorf2.yaml:86-104)")
+        if self._memo is not None and "mlp_pass" in self._memo:
+            return self._memo["mlp_pass"]
         m = self.mlp
         ws = (m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
         holder, token = self._param_pass(ws)
-        return [w.detach().contiguous() for w in ws], float(self.bias), holder, token
+        out = ([w.detach().contiguous() for w in ws], float(self.bias), holder, token)
+        if self._memo is not None:
+            self._memo["mlp_pass"] = out
+        return out
 
     def forward_compact(self, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
         if self.fused:

@@ -38,6 +38,8 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
         """(hp, W [11,24], b [11], holder, token) for fused callers (functional.BounceRays): the stacked head weights of the
         current parameter version and the gradient pass they accumulate into"""
         from ..functional import GradPass, StackedHeadGrads
+        if self._memo is not None and "head_pass" in self._memo:
+            return self._memo["head_pass"]
         hp = (float(self.diffuse_mul), float(self.diffuse_bias), float(self.tint_bias), float(self.f0_bias),
               float(self.roughness_bias))
         ps = self._head_params()
@@ -55,6 +57,8 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
                 token = StackedHeadGrads.apply(holder, *ps)
                 if self._pass_open:
                     self._pass = (holder, token)
+        if self._memo is not None:
+            self._memo["head_pass"] = (hp, W, b, holder, token)
         return hp, W, b, holder, token
 
     def heads(self, features):

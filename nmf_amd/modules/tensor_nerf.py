@@ -121,6 +121,12 @@ class TensorNeRF(torch.nn.Module):
                     self.bg_module._tables()
                     if hasattr(self.model, "brdf"):             # the microfacet model's diffuse irradiance (G=100)
                         self.bg_module.get_spherical_harmonics(100)
+                if is_train and torch.is_grad_enabled():            # pass tokens / stacked weights of the shading modules
+                    for m, fn in ((getattr(self.model, "diffuse_module", None), "head_pass"),
+                                  (getattr(self.model, "brdf", None), "mlp_pass")):
+                        if m is not None and hasattr(m, fn) and getattr(m, "fused", True):
+                            getattr(m, fn)()
+                    self.rf._pass_token()
             try:
                 return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
                                     dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples,
