@@ -20,3 +20,24 @@ done
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/libnmf_hip.so"
 echo "built $out/libnmf_hip.so"
+
+# Optional host-side fast path (csrc/host_ext.cpp: the forward wrappers of hip.py in C++, same C ABI underneath).  Plain
+# g++ against the torch headers, no device code; hip.py works without it (pure-Python wrappers), so a failure is not fatal.
+ext="$out/_nmf_host.so"
+if [ "${NMF_BUILD_HOST_EXT:-1}" = "1" ]; then
+  if [ ! -f "$ext" ] || [ "$here/host_ext.cpp" -nt "$ext" ] || [ "$here/../../include/nmf_hip.h" -nt "$ext" ]; then
+    tdir="$(python3 -c 'import torch, os; print(os.path.dirname(torch.__file__))' 2>/dev/null || true)"
+    pyinc="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])' 2>/dev/null || true)"
+    if [ -n "$tdir" ] && [ -n "$pyinc" ] && g++ -O2 -fPIC -shared -std=c++17 "$here/host_ext.cpp" \
+         -I"$here/../../include" -I"$tdir/include" -I"$tdir/include/torch/csrc/api/include" -I"$pyinc" \
+         -D_GLIBCXX_USE_CXX11_ABI=1 -DTORCH_EXTENSION_NAME=_nmf_host \
+         -L"$tdir/lib" -ltorch -ltorch_cpu -lc10 -ltorch_python -L"$out" -lnmf_hip \
+         -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$tdir/lib" -o "$ext.tmp" 2> "$out/host_ext.log"; then
+      mv "$ext.tmp" "$ext"
+      echo "built $ext"
+    else
+      rm -f "$ext.tmp"
+      echo "warning: host extension not built (see $out/host_ext.log); hip.py falls back to its Python wrappers"
+    fi
+  fi
+fi

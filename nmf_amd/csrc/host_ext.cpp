@@ -1,0 +1,314 @@
+// Host-side fast path for the forward wrappers of nmf_amd/hip.py (compiled with g++, no device code).
+//
+// The training step is host-bound where the GPU kernels are short (level-0 shading, the forward tail): a ctypes wrapper
+// costs 10-25 us of Python per call -- one torch.empty per output (~2 us each), a checked data_ptr per argument, ctypes
+// marshalling -- against 3-10 us of kernel time.  The functions here do exactly what the Python wrappers of the same
+// name do (same argument order, same outputs, same checks, same C-ABI entry point of include/nmf_hip.h -- with the
+// compiler checking the prototypes), in ~3 us.  hip.py installs them over its own definitions when this module is
+// present (NMF_HOST_EXT=0 keeps the pure-Python wrappers); nothing else in the package knows about it.
+#include <torch/extension.h>
+
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "nmf_hip.h"
+
+namespace py = pybind11;
+using at::Tensor;
+using OT = c10::optional<Tensor>;
+
+namespace {
+
+PyObject* g_error_class = nullptr;   // nmf_amd.hip.NmfHipError
+
+[[noreturn]] void fail(const std::string& msg) {
+    if (g_error_class) {
+        PyErr_SetString(g_error_class, msg.c_str());
+        throw py::error_already_set();
+    }
+    throw std::runtime_error(msg);
+}
+
+void check(int code, const char* what) {
+    if (code != 0) fail(std::string(what) + " failed: " + nmf_last_error_string() + " [" + std::to_string(code) + "]");
+}
+
+// device pointer of a contiguous tensor of the expected dtype (mirrors hip._p); empty tensors give NULL
+template <class T>
+T* ptr(const Tensor& t, at::ScalarType st) {
+    if (t.scalar_type() != st) fail(std::string("expected ") + c10::toString(st) + ", got " + c10::toString(t.scalar_type()));
+    if (!t.is_cuda()) fail("nmf_amd operators need device tensors (no CPU path)");
+    if (!t.is_contiguous()) fail("tensor must be contiguous");
+    return static_cast<T*>(t.data_ptr());
+}
+template <class T>
+T* optr(const OT& t, at::ScalarType st) {
+    return t.has_value() ? ptr<T>(*t, st) : nullptr;
+}
+// any dtype (bit masks, workspaces): only device + contiguity are checked
+void* vptr(const OT& t) {
+    if (!t.has_value()) return nullptr;
+    if (!t->is_cuda()) fail("nmf_amd operators need device tensors (no CPU path)");
+    if (!t->is_contiguous()) fail("tensor must be contiguous");
+    return t->data_ptr();
+}
+const float* f32(const Tensor& t) { return ptr<const float>(t, at::kFloat); }
+const float* of32(const OT& t) { return optr<const float>(t, at::kFloat); }
+const int32_t* i32(const Tensor& t) { return ptr<const int32_t>(t, at::kInt); }
+const int64_t* i64(const Tensor& t) { return ptr<const int64_t>(t, at::kLong); }
+
+Tensor fe(const Tensor& like, at::IntArrayRef shape) { return at::empty(shape, like.options().dtype(at::kFloat)); }
+Tensor ie(const Tensor& like, at::IntArrayRef shape, at::ScalarType st) { return at::empty(shape, like.options().dtype(st)); }
+float* out(Tensor& t) { return static_cast<float*>(t.data_ptr()); }
+void* st(int64_t stream) { return reinterpret_cast<void*>(stream); }
+
+struct P3 {
+    const float* p[3];
+};
+P3 three(const std::vector<Tensor>& ts) {
+    if (ts.size() != 3) fail("expected three tensors");
+    P3 r;
+    for (int i = 0; i < 3; ++i) r.p[i] = f32(ts[i]);
+    return r;
+}
+
+// ---- sampler --------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> march_count(int64_t p_addr, const Tensor& rays, const OT& jitter, const OT& alpha_bits,
+                                       const OT& alpha_coarse, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_march_params*>(p_addr);
+    const int64_t B = rays.size(0), W = (p->n_steps + 63) / 64;
+    Tensor valid = ie(rays, {B, W}, at::kLong), counts = ie(rays, {B}, at::kInt);
+    check(nmf_march_count(p, f32(rays), B, of32(jitter), static_cast<const uint32_t*>(vptr(alpha_bits)),
+                          alpha_bits.has_value() ? static_cast<const uint32_t*>(vptr(alpha_coarse)) : nullptr,
+                          static_cast<uint64_t*>(valid.data_ptr()), static_cast<int32_t*>(counts.data_ptr()), st(stream)),
+          "nmf_march_count");
+    return {valid, counts};
+}
+
+std::tuple<Tensor, Tensor, Tensor> march_scan(const Tensor& counts, int64_t max_samples, int64_t stream) {
+    const int64_t B = counts.size(0);
+    Tensor offsets = ie(counts, {B + 1}, at::kLong), whole = ie(counts, {B}, at::kByte), totals = ie(counts, {2}, at::kLong);
+    const int64_t nbytes = nmf_march_scan_workspace_bytes(B);
+    Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
+    check(nmf_march_scan(i32(counts), B, max_samples, static_cast<int64_t*>(offsets.data_ptr()),
+                         static_cast<uint8_t*>(whole.data_ptr()), static_cast<int64_t*>(totals.data_ptr()), ws.data_ptr(),
+                         nbytes, st(stream)),
+          "nmf_march_scan");
+    return {offsets, whole, totals};
+}
+
+std::tuple<Tensor, Tensor, Tensor, OT, Tensor> march_fill(int64_t p_addr, const Tensor& rays, int64_t b, int64_t M,
+                                                         const OT& jitter, const Tensor& valid, const Tensor& offsets,
+                                                         bool want_z, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_march_params*>(p_addr);
+    Tensor xyzt = fe(rays, {M, 4}), ray_id = ie(rays, {M}, at::kInt), step_id = ie(rays, {M}, at::kInt), dist = fe(rays, {M});
+    OT z;
+    if (want_z) z = fe(rays, {M});
+    check(nmf_march_fill(p, f32(rays), b, of32(jitter), static_cast<const uint64_t*>(vptr(valid)), i64(offsets), out(xyzt),
+                         static_cast<int32_t*>(ray_id.data_ptr()), static_cast<int32_t*>(step_id.data_ptr()),
+                         z.has_value() ? out(*z) : nullptr, out(dist), st(stream)),
+          "nmf_march_fill");
+    return {xyzt, ray_id, step_id, z, dist};
+}
+
+// ---- field ----------------------------------------------------------------------------------------------------------
+std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& dpk,
+                                                const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl,
+                                                const std::vector<Tensor>& ali, const OT& basis, bool want_density,
+                                                bool want_normal, bool want_app, bool want_coef, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    const int64_t M = xyzt.size(0);
+    OT sf, sg, gr, nr, ap, cf;
+    if (want_density) { sf = fe(xyzt, {M}); sg = fe(xyzt, {M}); }
+    if (want_normal) { gr = fe(xyzt, {M, 3}); nr = fe(xyzt, {M, 3}); }
+    if (want_app) ap = fe(xyzt, {M, 24});
+    if (want_coef) cf = fe(xyzt, {M, 72});
+    const bool need_d = want_density || want_normal, need_a = want_app || want_coef;
+    P3 a{}, b{}, c{}, d{};
+    if (need_d) { a = three(dpk); b = three(dlk); }
+    if (need_a) { c = three(apl); d = three(ali); }
+    auto o = [](OT& t) { return t.has_value() ? static_cast<float*>(t->data_ptr()) : nullptr; };
+    check(nmf_vm_query_fwd(p, f32(xyzt), M, need_d ? a.p : nullptr, need_d ? b.p : nullptr, need_a ? c.p : nullptr,
+                           need_a ? d.p : nullptr, need_a ? of32(basis) : nullptr, o(sf), o(sg), o(gr), o(nr), o(ap), o(cf),
+                           st(stream)),
+          "nmf_vm_query_fwd");
+    return {sf, sg, gr, nr, ap, cf};
+}
+
+// ---- compositing ------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> composite_fwd(const Tensor& sigma, const Tensor& dist, const Tensor& offsets, int64_t b,
+                                         double distance_scale, int64_t stream) {
+    const int64_t M = sigma.size(0);
+    Tensor weight = fe(sigma, {M}), acc = fe(sigma, {b});
+    if (M == 0) {
+        acc.zero_();
+        return {weight, acc};
+    }
+    check(nmf_composite_fwd(f32(sigma), f32(dist), i64(offsets), b, (float)distance_scale, out(weight), out(acc), st(stream)),
+          "nmf_composite_fwd");
+    return {weight, acc};
+}
+
+Tensor segment_sum(const Tensor& vals, const OT& scale, const Tensor& offsets, int64_t n_seg, int64_t lanes, int64_t stream) {
+    const int64_t D = vals.size(1);
+    Tensor o = fe(vals, {n_seg, D});
+    if (vals.size(0) == 0) {
+        o.zero_();
+        return o;
+    }
+    check(nmf_segment_sum(f32(vals), static_cast<const float*>(vptr(scale)), i64(offsets), n_seg, (int32_t)D, (int32_t)lanes,
+                          out(o), st(stream)),
+          "nmf_segment_sum");
+    return o;
+}
+
+// ---- environment map --------------------------------------------------------------------------------------------------
+Tensor sat_lookup_fwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const OT& pole_rows,
+                      const OT& sc, int64_t stream) {
+    const int64_t R = dirs.size(0), ld = dirs.size(1);
+    const int64_t H = sat.size(-2), W = sat.size(-1);
+    Tensor o = fe(dirs, {R, 3});
+    check(nmf_sat_lookup_fwd(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
+                             static_cast<const float*>(vptr(sc)), static_cast<const float*>(vptr(pole_rows)), out(o),
+                             st(stream)),
+          "nmf_sat_lookup_fwd");
+    return o;
+}
+
+// ---- shading ------------------------------------------------------------------------------------------------------------
+Tensor select_bounces(const Tensor& weights, const Tensor& u, int64_t mode, double mul, double add, double sum_w,
+                      const OT& sum_w_dev, int64_t stream) {
+    const int64_t M = weights.size(0);
+    Tensor counts = ie(weights, {M}, at::kInt);
+    check(nmf_select_bounces(f32(weights), f32(u), M, (int32_t)mode, (float)mul, (float)add,
+                             sum_w_dev.has_value() ? 1.0f : (float)sum_w, of32(sum_w_dev),
+                             static_cast<int32_t*>(counts.data_ptr()), st(stream)),
+          "nmf_select_bounces");
+    return counts;
+}
+
+std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg, int64_t total, int64_t stream) {
+    Tensor seg = ie(offsets, {total}, at::kInt), loc = ie(offsets, {total}, at::kInt);
+    check(nmf_expand_segments(i64(offsets), n_seg, static_cast<int32_t*>(seg.data_ptr()),
+                              static_cast<int32_t*>(loc.data_ptr()), st(stream)),
+          "nmf_expand_segments");
+    return {seg, loc};
+}
+
+Tensor brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
+                    const Tensor& rough_src, const OT& src_idx, double out_bias, int64_t stream) {
+    if (w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
+    const int64_t R = half_vec.size(0);
+    Tensor o = fe(half_vec, {R, 3});
+    check(nmf_brdf_mlp_fwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
+                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
+                           st(stream)),
+          "nmf_brdf_mlp_fwd");
+    return o;
+}
+
+Tensor heads_fwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, int64_t stream) {
+    if (hp.size() != 5) fail("heads_fwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
+    const int64_t M = feat.size(0);
+    Tensor o = fe(feat, {M, 11});
+    check(nmf_heads_fwd(f32(feat), M, f32(W), f32(b), (float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3], (float)hp[4],
+                        out(o), st(stream)),
+          "nmf_heads_fwd");
+    return o;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> ggx_rays_fwd(const Tensor& V, const Tensor& N, const Tensor& r,
+                                                                        const Tensor& x, const Tensor& off, const Tensor& cnt,
+                                                                        const Tensor& sobol, const Tensor& row_of_ray,
+                                                                        const Tensor& j_of_ray, int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor L = fe(V, {R, 3}), hl = fe(V, {R, 3}), dl = fe(V, {R, 3}), lpdf = fe(V, {R}), mip = fe(V, {R}), rays = fe(V, {R, 6});
+    check(nmf_ggx_rays_fwd(f32(V), f32(N), f32(r), f32(x), f32(off), i32(cnt), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
+                           out(L), out(hl), out(dl), out(lpdf), out(mip), out(rays), st(stream)),
+          "nmf_ggx_rays_fwd");
+    return {L, hl, dl, lpdf, mip, rays};
+}
+
+Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, const Tensor& cnt, const Tensor& row_of_ray,
+                     const Tensor& L, const Tensor& inc, const Tensor& brdf, int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor contrib = fe(V, {R, 3});
+    check(nmf_shade_mix_fwd(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf),
+                            out(contrib), st(stream)),
+          "nmf_shade_mix_fwd");
+    return contrib;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> bounce_index(const Tensor& counts, int64_t stream) {
+    const int64_t M = counts.size(0), M1 = M > 0 ? M : 1;
+    Tensor bidx = ie(counts, {M1}, at::kInt), row_off = ie(counts, {M + 1}, at::kLong), inv = ie(counts, {M1}, at::kInt);
+    Tensor cnt_rows = ie(counts, {M1}, at::kInt), totals = ie(counts, {2}, at::kLong);
+    const int64_t nbytes = nmf_bounce_index_workspace_bytes(M);
+    Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
+    check(nmf_bounce_index(M ? i32(counts) : nullptr, M, static_cast<int32_t*>(bidx.data_ptr()),
+                           static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
+                           static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()), ws.data_ptr(), nbytes,
+                           st(stream)),
+          "nmf_bounce_index");
+    return {bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_fwd(
+    const Tensor& bidx, const Tensor& normals, const Tensor& app, const Tensor& heads, const Tensor& xyzt, const Tensor& ray_id,
+    const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough, bool row_inputs,
+    int64_t stream) {
+    const int64_t Mb = bidx.size(0);
+    Tensor V = fe(normals, {Mb, 3}), N = fe(normals, {Mb, 3}), r1 = fe(normals, {Mb}), f0 = fe(normals, {Mb, 3});
+    Tensor diff = fe(normals, {Mb, 3}), feat = fe(normals, {Mb, 24}), xyz = fe(normals, {Mb, 3});
+    if (Mb)
+        check(nmf_bounce_prep_fwd(i32(bidx), Mb, f32(normals), f32(app), f32(heads), f32(xyzt), i32(ray_id), f32(rays),
+                                  f32(conv), static_cast<const float*>(vptr(feat_noise)), (float)anoise, (float)min_rough,
+                                  row_inputs ? 1 : 0, out(V), out(N), out(r1), out(f0), out(diff), out(feat), out(xyz),
+                                  st(stream)),
+              "nmf_bounce_prep_fwd");
+    return {V, N, r1, f0, diff, feat, xyz};
+}
+
+std::tuple<Tensor, Tensor, Tensor, OT> ray_compose_fwd(const Tensor& weight, const OT& refl_rows, const OT& inv,
+                                                       const OT& normals, const Tensor& rays, const Tensor& offsets, int64_t B,
+                                                       const Tensor& bg, bool bg_per_ray, bool tonemap, bool noclip,
+                                                       bool want_ori, int64_t stream) {
+    Tensor rgb_map = fe(weight, {B, 3}), acc = fe(weight, {B}), rgb_lin = fe(weight, {B, 3});
+    OT ori;
+    if (want_ori) ori = fe(weight, {B});
+    if (B)
+        check(nmf_ray_compose_fwd(f32(weight), static_cast<const float*>(vptr(refl_rows)),
+                                  static_cast<const int32_t*>(vptr(inv)), static_cast<const float*>(vptr(normals)), f32(rays),
+                                  i64(offsets), B, f32(bg), bg_per_ray ? 1 : 0, tonemap ? 1 : 0, noclip ? 1 : 0, out(rgb_map),
+                                  out(acc), out(rgb_lin), ori.has_value() ? out(*ori) : nullptr, st(stream)),
+              "nmf_ray_compose_fwd");
+    return {rgb_map, acc, rgb_lin, ori};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_nmf_host, m) {
+    m.doc() = "host-side fast path of nmf_amd.hip (same C ABI underneath)";
+    m.def("set_error_class", [](py::object cls) {
+        g_error_class = cls.ptr();
+        Py_XINCREF(g_error_class);
+    });
+    m.def("abi_version", []() { return nmf_version(); });
+    m.def("march_count", &march_count);
+    m.def("march_scan", &march_scan);
+    m.def("march_fill", &march_fill);
+    m.def("vm_query_fwd", &vm_query_fwd);
+    m.def("composite_fwd", &composite_fwd);
+    m.def("segment_sum", &segment_sum);
+    m.def("sat_lookup_fwd", &sat_lookup_fwd);
+    m.def("select_bounces", &select_bounces);
+    m.def("expand_segments", &expand_segments);
+    m.def("brdf_mlp_fwd", &brdf_mlp_fwd);
+    m.def("heads_fwd", &heads_fwd);
+    m.def("ggx_rays_fwd", &ggx_rays_fwd);
+    m.def("shade_mix_fwd", &shade_mix_fwd);
+    m.def("bounce_index", &bounce_index);
+    m.def("bounce_prep_fwd", &bounce_prep_fwd);
+    m.def("ray_compose_fwd", &ray_compose_fwd);
+}

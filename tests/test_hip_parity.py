@@ -996,3 +996,49 @@ def test_vm_backward_segments_equal_concatenation(with_app):
     with pytest.raises(hip.NmfHipError):                       # mixed adjoint sets are rejected
         bad = [segs[0], (segs[3][0], None, None, None, None, None, None)]
         hip.vm_query_bwd_segments(p, bad, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], None)
+
+
+@pytest.mark.gpu
+def test_host_extension_matches_python_wrappers():
+    """lib/_nmf_host.so (csrc/host_ext.cpp) replaces the forward wrappers of hip.py with C++ ones over the same C ABI:
+    same outputs bit for bit, same error type."""
+    from nmf_amd import hip, synthetic
+    if hip.HOST_EXT is None:
+        pytest.skip("host extension not built / disabled (NMF_HOST_EXT=0): the Python wrappers are the ones under test")
+    py = hip.PY_WRAPPERS
+    g = torch.Generator().manual_seed(9)
+    G = 32
+    cfg = O.Cfg(grid=G)
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=16, seed=1)
+    tabs = _field_tables(hip, sd, cfg)
+    xyz = torch.cat([(torch.rand(3001, 3, generator=g) * 2 - 1) * 1.4, torch.zeros(3001, 1)], 1).to(DEV).contiguous()
+    a = hip.vm_query_fwd(*tabs[:1], xyz, *tabs[1:], want_coef=True)
+    b = py["vm_query_fwd"](*tabs[:1], xyz, *tabs[1:], want_coef=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    a = hip.vm_query_fwd(*tabs[:1], xyz, *tabs[1:], want_density=False, want_normal=False)
+    assert a[0] is None and a[2] is None and a[4].shape == (3001, 24)
+    # segmented sums, composite, bounce bookkeeping
+    counts = (torch.rand(5000, generator=g) < 0.2).int() * torch.randint(1, 9, (5000,), generator=g).int()
+    a, b = hip.bounce_index(counts.to(DEV)), py["bounce_index"](counts.to(DEV))
+    Mb = int(a[4][1])
+    assert torch.equal(a[4], b[4]) and torch.equal(a[0][:Mb], b[0][:Mb]) and torch.equal(a[1][:Mb + 1], b[1][:Mb + 1])
+    assert torch.equal(a[3], b[3]) and a[3].shape == (5000,)
+    off = a[1][:Mb + 1].contiguous()
+    R = int(a[4][0])
+    sa_, sb_ = hip.expand_segments(off, Mb, R), py["expand_segments"](off, Mb, R)
+    assert torch.equal(sa_[0], sb_[0]) and torch.equal(sa_[1], sb_[1])
+    vals = torch.randn(R, 3, generator=g).to(DEV)
+    for lanes in (1, 8):
+        assert torch.equal(hip.segment_sum(vals, None, off, Mb, lanes=lanes), py["segment_sum"](vals, None, off, Mb, lanes=lanes))
+    sig, dist = torch.rand(R, generator=g).to(DEV), (torch.rand(R, generator=g) * 0.01).to(DEV)
+    wa, wb = hip.composite_fwd(sig, dist, off, Mb, 25.0), py["composite_fwd"](sig, dist, off, Mb, 25.0)
+    assert torch.equal(wa[0], wb[0]) and torch.equal(wa[1], wb[1])
+    u = torch.rand(R, generator=g).to(DEV)
+    assert torch.equal(hip.select_bounces(wa[0], u, 0, 64.0), py["select_bounces"](wa[0], u, 0, 64.0))
+    # misuse raises the package's error type from both paths
+    for fn in (hip.composite_fwd, py["composite_fwd"]):
+        with pytest.raises(hip.NmfHipError):
+            fn(sig.cpu(), dist, off, Mb, 25.0)
+    with pytest.raises(hip.NmfHipError):
+        hip.segment_sum(vals, None, off, Mb, lanes=3)
