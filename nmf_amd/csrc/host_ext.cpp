@@ -286,6 +286,114 @@ std::tuple<Tensor, Tensor, Tensor, OT> ray_compose_fwd(const Tensor& weight, con
     return {rgb_map, acc, rgb_lin, ori};
 }
 
+// ---- backward wrappers (the step is GPU-bound there on a fast host, host-bound on a loaded one) ----------------------
+Tensor composite_bwd(const Tensor& sigma, const Tensor& dist, const Tensor& weight, const Tensor& offsets, int64_t b,
+                     double distance_scale, const Tensor& d_weight, int64_t stream) {
+    Tensor d_sigma = at::empty_like(sigma);
+    if (sigma.size(0) == 0) return d_sigma;
+    Tensor dw = d_weight.contiguous();
+    check(nmf_composite_bwd(f32(sigma), f32(dist), f32(weight), i64(offsets), b, (float)distance_scale, f32(dw),
+                            out(d_sigma), st(stream)),
+          "nmf_composite_bwd");
+    return d_sigma;
+}
+
+Tensor segment_sum_wide(const Tensor& vals, int64_t D, const Tensor& offsets, int64_t n_seg, int64_t stream) {
+    Tensor o = fe(vals, {n_seg, D});
+    if (vals.size(0) == 0) {
+        o.zero_();
+        return o;
+    }
+    check(nmf_segment_sum_wide(f32(vals), vals.size(1), (int32_t)D, i64(offsets), n_seg, out(o), st(stream)),
+          "nmf_segment_sum_wide");
+    return o;
+}
+
+OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const Tensor& d_out, const OT& d_sat,
+                  const OT& d_pole, const OT& d_mip, bool want_dirs, const OT& sc, int64_t stream) {
+    const int64_t R = dirs.size(0), ld = dirs.size(1);
+    const int64_t H = sat.size(-2), W = sat.size(-1);
+    OT d_dirs;
+    if (want_dirs) d_dirs = fe(dirs, {R, ld});
+    Tensor go = d_out.contiguous();
+    check(nmf_sat_lookup_bwd(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
+                             static_cast<const float*>(vptr(sc)), f32(go), static_cast<float*>(vptr(d_sat)),
+                             static_cast<float*>(vptr(d_pole)), d_dirs.has_value() ? out(*d_dirs) : nullptr,
+                             static_cast<float*>(vptr(d_mip)), st(stream)),
+          "nmf_sat_lookup_bwd");
+    return d_dirs;
+}
+
+Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
+                    const Tensor& rough_src, const OT& src_idx, double out_bias, const Tensor& d_out,
+                    const std::vector<Tensor>& grads, int64_t stream) {
+    if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
+    const int64_t R = half_vec.size(0);
+    Tensor d_xfeat = fe(half_vec, {R, 24});
+    Tensor go = d_out.contiguous();
+    float* g[6];
+    for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
+    check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
+                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, f32(go),
+                           out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], st(stream)),
+          "nmf_brdf_mlp_bwd");
+    return d_xfeat;
+}
+
+Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& d_out,
+                 const Tensor& gW, const Tensor& gb, int64_t stream) {
+    if (hp.size() != 5) fail("heads_bwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
+    const int64_t M = feat.size(0);
+    Tensor d_feat = at::empty_like(feat);
+    Tensor go = d_out.contiguous();
+    check(nmf_heads_bwd(f32(feat), M, f32(W), f32(b), (float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3], (float)hp[4],
+                        f32(go), out(d_feat), static_cast<float*>(vptr(gW)), static_cast<float*>(vptr(gb)), st(stream)),
+          "nmf_heads_bwd");
+    return d_feat;
+}
+
+Tensor ggx_rays_bwd(const Tensor& V, const Tensor& N, const Tensor& r, const Tensor& off, const Tensor& sobol,
+                    const Tensor& row_of_ray, const Tensor& j_of_ray, const OT& dL, const OT& d_rays, int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor d_nr = fe(V, {R, 4});
+    check(nmf_ggx_rays_bwd(f32(V), f32(N), f32(r), f32(off), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
+                           static_cast<const float*>(vptr(dL)), static_cast<const float*>(vptr(d_rays)), out(d_nr), st(stream)),
+          "nmf_ggx_rays_bwd");
+    return d_nr;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> shade_mix_bwd(const Tensor& V, const Tensor& f0, const Tensor& diff, const Tensor& cnt,
+                                                         const Tensor& row_of_ray, const Tensor& L, const Tensor& inc,
+                                                         const Tensor& brdf, const Tensor& d_rows, int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor d_inc = fe(V, {R, 3}), d_brdf = fe(V, {R, 3}), dL = fe(V, {R, 3}), d_fd = fe(V, {R, 6});
+    check(nmf_shade_mix_bwd(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf), f32(d_rows),
+                            out(d_inc), out(d_brdf), out(dL), out(d_fd), st(stream)),
+          "nmf_shade_mix_bwd");
+    return {d_inc, d_brdf, dL, d_fd};
+}
+
+std::tuple<Tensor, OT, OT> ray_compose_bwd(const Tensor& weight, const OT& refl_rows, const OT& inv, const OT& normals,
+                                           const Tensor& rays, const Tensor& ray_id, const Tensor& bg, bool bg_per_ray,
+                                           bool tonemap, bool noclip, const OT& rgb_lin, const OT& d_rgb_map, const OT& d_acc,
+                                           const OT& d_ori, bool want_d_normals, int64_t stream) {
+    const int64_t M = weight.size(0);
+    Tensor d_weight = fe(weight, {M});
+    OT d_refl, d_normals;
+    if (refl_rows.has_value()) d_refl = at::empty_like(*refl_rows);
+    if (want_d_normals) d_normals = fe(weight, {M, 3});
+    if (M)
+        check(nmf_ray_compose_bwd(f32(weight), static_cast<const float*>(vptr(refl_rows)), static_cast<const int32_t*>(vptr(inv)),
+                                  static_cast<const float*>(vptr(normals)), f32(rays), i32(ray_id), M, f32(bg),
+                                  bg_per_ray ? 1 : 0, tonemap ? 1 : 0, noclip ? 1 : 0, static_cast<const float*>(vptr(rgb_lin)),
+                                  static_cast<const float*>(vptr(d_rgb_map)), static_cast<const float*>(vptr(d_acc)),
+                                  static_cast<const float*>(vptr(d_ori)), out(d_weight),
+                                  d_refl.has_value() ? out(*d_refl) : nullptr,
+                                  d_normals.has_value() ? out(*d_normals) : nullptr, st(stream)),
+              "nmf_ray_compose_bwd");
+    return {d_weight, d_refl, d_normals};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_nmf_host, m) {
@@ -311,4 +419,12 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("bounce_index", &bounce_index);
     m.def("bounce_prep_fwd", &bounce_prep_fwd);
     m.def("ray_compose_fwd", &ray_compose_fwd);
+    m.def("composite_bwd", &composite_bwd);
+    m.def("segment_sum_wide", &segment_sum_wide);
+    m.def("sat_lookup_bwd", &sat_lookup_bwd);
+    m.def("brdf_mlp_bwd", &brdf_mlp_bwd);
+    m.def("heads_bwd", &heads_bwd);
+    m.def("ggx_rays_bwd", &ggx_rays_bwd);
+    m.def("shade_mix_bwd", &shade_mix_bwd);
+    m.def("ray_compose_bwd", &ray_compose_bwd);
 }

@@ -905,8 +905,39 @@ def _install_host_ext():
         return fx.ray_compose_fwd(weight, refl_rows, inv, normals, rays, offsets, B, bg, bool(bg_per_ray), bool(tonemap),
                                   bool(noclip), bool(want_ori), _stream())
 
+    def composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight):
+        return fx.composite_bwd(sigma, dist, weight, offsets, b, distance_scale, d_weight, _stream())
+
+    def segment_sum_wide(vals, D, offsets, n_seg):
+        return fx.segment_sum_wide(vals, D, offsets, n_seg, _stream())
+
+    py_sat_lookup_bwd = g["sat_lookup_bwd"]
+
+    def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
+        if want_mipbias is not None:      # legacy return form (tests): the Python wrapper
+            return py_sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, want_mipbias, sc)
+        return fx.sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, sc, _stream())
+
+    def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads):
+        return fx.brdf_mlp_bwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, list(grads),
+                               _stream())
+
+    def heads_bwd(feat, W, b, hp, d_out, gW, gb):
+        return fx.heads_bwd(feat, W, b, list(hp), d_out, gW, gb, _stream())
+
+    def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
+        return fx.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays, _stream())
+
+    def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
+        return fx.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows, _stream())
+
+    def ray_compose_bwd(weight, refl_rows, inv, normals, rays, ray_id, bg, bg_per_ray, tonemap, noclip, rgb_lin, d_rgb_map,
+                        d_acc, d_ori, want_d_normals):
+        return fx.ray_compose_bwd(weight, refl_rows, inv, normals, rays, ray_id, bg, bool(bg_per_ray), bool(tonemap),
+                                  bool(noclip), rgb_lin, d_rgb_map, d_acc, d_ori, bool(want_d_normals), _stream())
+
     for name, fn in list(locals().items()):
-        if callable(fn) and name in g and name not in ("fx", "addr", "g"):
+        if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd"):
             PY_WRAPPERS[name] = g[name]
             fn.__doc__ = g[name].__doc__
             g[name] = fn
