@@ -69,6 +69,28 @@ __device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8
 // ---- wave-level helpers (64 lanes) ------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// The same inclusive sum with DPP lane moves instead of ds_bpermute (six dependent LDS-crossbar round trips, ~100 cycles
+// each, were a third of a marcher round): Kogge-Stone inside the rows of 16 lanes (row_shr:1,2,4,8, zeros shifted in),
+// then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into lanes 32-63 (row_bcast:31).  A different
+// association than wave_incl_scan: use it where the partial sums are EXACT in float64 (the marcher's step lengths), so
+// that the result does not depend on the order.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_scan_dpp(double v) {
+    v += dpp_f64<0x111, 0xf, 0xf>(v);      // row_shr:1
+    v += dpp_f64<0x112, 0xf, 0xf>(v);      // row_shr:2
+    v += dpp_f64<0x114, 0xf, 0xf>(v);      // row_shr:4
+    v += dpp_f64<0x118, 0xf, 0xf>(v);      // row_shr:8
+    v += dpp_f64<0x142, 0xa, 0xf>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc, 0xf>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ double wave_incl_scan(double v) {
     const int lane = lane_id();
 #pragma unroll

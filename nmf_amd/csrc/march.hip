@@ -143,7 +143,7 @@ __device__ __forceinline__ StepOut march_one(const nmf_march_params& p, const Ra
     if (p.is_train) {
         float s = step_len(p, jitter, rng, r, in_range ? k : 0, jc);      // wave-uniform call (shuffles inside)
         s = in_range ? s : 0.f;
-        double incl = wave_incl_scan((double)s);
+        double incl = wave_incl_scan_dpp((double)s);      // exact partial sums (header comment): order-free
         cum = carry + incl;
         carry += __shfl(incl, 63, 64);
         step = (float)cum;
