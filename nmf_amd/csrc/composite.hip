@@ -23,22 +23,35 @@ namespace {
 // carried across passes.
 constexpr int WPR_MAX_RAYS = 16384;     // batches up to this size use one wave per ray, larger ones 8 lanes per ray
 
+// value of the lane D below (garbage where that lane is outside the row of 16: callers only use it for lane >= D inside
+// groups that do not straddle rows).  Groups of 8 move lanes with DPP row_shr -- same operands, same association as the
+// ds_bpermute-based __shfl_up, without the LDS-crossbar round trip per step.
+template <int W, int D>
+__device__ __forceinline__ double lane_below(double v) {
+    if constexpr (W <= 16) {
+        return dpp_f64<0x110 + D, 0xf, 0xf>(v);
+    } else {
+        return __shfl_up(v, D, W);
+    }
+}
 template <int W>
 __device__ __forceinline__ double group_incl_prod(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < W; d <<= 1) {
-        const double t = __shfl_up(v, d, W);
-        if (lane >= d) v *= t;
-    }
+    { const double t = lane_below<W, 1>(v); if (lane >= 1) v *= t; }
+    if constexpr (W > 2) { const double t = lane_below<W, 2>(v); if (lane >= 2) v *= t; }
+    if constexpr (W > 4) { const double t = lane_below<W, 4>(v); if (lane >= 4) v *= t; }
+    if constexpr (W > 8) { const double t = lane_below<W, 8>(v); if (lane >= 8) v *= t; }
+    if constexpr (W > 16) { const double t = __shfl_up(v, 16, W); if (lane >= 16) v *= t; }
+    if constexpr (W > 32) { const double t = __shfl_up(v, 32, W); if (lane >= 32) v *= t; }
     return v;
 }
 template <int W>
 __device__ __forceinline__ double group_incl_sum(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < W; d <<= 1) {
-        const double t = __shfl_up(v, d, W);
-        if (lane >= d) v += t;
-    }
+    { const double t = lane_below<W, 1>(v); if (lane >= 1) v += t; }
+    if constexpr (W > 2) { const double t = lane_below<W, 2>(v); if (lane >= 2) v += t; }
+    if constexpr (W > 4) { const double t = lane_below<W, 4>(v); if (lane >= 4) v += t; }
+    if constexpr (W > 8) { const double t = lane_below<W, 8>(v); if (lane >= 8) v += t; }
+    if constexpr (W > 16) { const double t = __shfl_up(v, 16, W); if (lane >= 16) v += t; }
+    if constexpr (W > 32) { const double t = __shfl_up(v, 32, W); if (lane >= 32) v += t; }
     return v;
 }
 
