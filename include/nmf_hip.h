@@ -55,6 +55,10 @@ typedef struct {
     int32_t is_train;     /* 1: cumulative jitter (alphagrid.py:168-173); 0: stepsize*k (:190)    */
     uint64_t seed;        /* Philox seed used when jitter == NULL and is_train                    */
     uint64_t offset;      /* Philox stream offset (advance per call)                              */
+    float occ_min[3], occ_max[3];  /* optional world-space box around every point whose 8-corner footprint can touch a
+                                    * set alpha bit (tight box of the set voxels grown by one voxel + margin): the
+                                    * marcher stops a ray once it has left this box (nothing can be kept beyond it).
+                                    * occ_min > occ_max on any axis = not provided.  Results are unchanged.          */
 } nmf_march_params;
 
 /* float 0/1 volume [gz][gy][gx] -> bitfield, bit i of word i/32 = volume[i] > 0

@@ -22,6 +22,24 @@ struct RayCtx {
     float tfar;   // distance at which the ray leaves the AABB (used only to stop marching early, with a margin)
 };
 
+// [t0, t1] = parameter interval of the ray inside p.occ_min..occ_max (t1 < t0: misses the box).  Conservative: axes the
+// ray is parallel to only decide inside / outside.  Without a box (occ_min > occ_max) the interval is everything.
+__device__ __forceinline__ void occ_interval(const nmf_march_params& p, const RayCtx& c, float& t0, float& t1) {
+    t0 = -3.0e38f; t1 = 3.0e38f;
+    if (p.occ_min[0] > p.occ_max[0] || p.occ_min[1] > p.occ_max[1] || p.occ_min[2] > p.occ_max[2]) return;
+    const float o[3] = {c.ox, c.oy, c.oz}, d[3] = {c.dx, c.dy, c.dz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (fabsf(d[a]) < 1e-12f) {
+            if (o[a] < p.occ_min[a] || o[a] > p.occ_max[a]) { t0 = 1.f; t1 = 0.f; return; }
+        } else {
+            const float ta = (p.occ_min[a] - o[a]) / d[a], tb = (p.occ_max[a] - o[a]) / d[a];
+            t0 = fmaxf(t0, fminf(ta, tb));
+            t1 = fminf(t1, fmaxf(ta, tb));
+        }
+    }
+}
+
 __device__ __forceinline__ RayCtx load_ray(const nmf_march_params& p, const float* rays, int64_t r) {
     RayCtx c;
     const float* q = rays + r * 6;
@@ -185,11 +203,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
         double carry = 0.0;
         int total = 0;
         int j = 0;
+        // with an alpha mask nothing is kept outside the box around its set voxels: rays that miss it need no round at
+        // all, the others stop once they have left it (1e-2 margin as for the AABB exit below)
+        float t_stop = c.tfar;
+        bool hopeless = false;
+        if (bits) {
+            float o0, o1;
+            occ_interval(p, c, o0, o1);
+            hopeless = o1 < o0 || o1 < c.tmin - 1e-2f || o0 > c.tfar + 1e-2f;
+            t_stop = fminf(t_stop, o1);
+        }
         JitterCache jc;
         jc.o0 = jc.o1 = jc.o2 = jc.o3 = 0u;
         const bool use_jc = p.is_train && !jitter;
         jc.on = use_jc;
-        for (; j < W; ++j) {
+        for (; j < W && !hopeless; ++j) {
             if (use_jc && (j & 3) == 0) jc_fill(jc, rng, p, r, j >> 2);
             StepOut o = march_one(p, c, jitter, rng, bits, s_coarse, r, j * 64 + lane, carry, nullptr,
                                   jc);
@@ -199,7 +227,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
             // z grows monotonically along the ray: once the last step of this chunk is clearly beyond the AABB exit
             // every later step fails the in-box test (:195) too.  The 1e-2 margin dwarfs the fp32 error of the positions.
             const float z_last = __shfl(o.z, 63, 64);
-            if (z_last > c.tfar + 1e-2f) { ++j; break; }
+            if (z_last > t_stop + 1e-2f) { ++j; break; }
         }
         for (int jj = j + lane; jj < W; jj += 64) valid[r * W + jj] = 0ull;
         if (lane == 0) counts[r] = total;

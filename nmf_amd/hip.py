@@ -39,7 +39,7 @@ class MarchParams(C.Structure):
     _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("alpha_inv", C.c_float * 3),
                 ("stepsize", C.c_float), ("half_step", C.c_float), ("near_t", C.c_float), ("far_t", C.c_float),
                 ("focal", C.c_float), ("n_steps", C.c_int32), ("grid", C.c_int32 * 3), ("is_train", C.c_int32),
-                ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("seed", C.c_uint64), ("offset", C.c_uint64), ("occ_min", C.c_float * 3), ("occ_max", C.c_float * 3)]
 
 
 class VmParams(C.Structure):
@@ -180,8 +180,15 @@ def host(t):
 
 
 # ---- sampler ----------------------------------------------------------------------------------
-def march_params(aabb, alpha_inv, stepsize, near, far, focal, n_steps, grid, is_train, seed=0, offset=0):
+def march_params(aabb, alpha_inv, stepsize, near, far, focal, n_steps, grid, is_train, seed=0, offset=0, occ_box=None):
+    """occ_box: optional ((x0,y0,z0), (x1,y1,z1)) world box outside of which the alpha mask cannot keep a step"""
     p = MarchParams()
+    if occ_box is not None:
+        p.occ_min[:] = [float(v) for v in occ_box[0]]
+        p.occ_max[:] = [float(v) for v in occ_box[1]]
+    else:
+        p.occ_min[:] = [1.0, 1.0, 1.0]
+        p.occ_max[:] = [-1.0, -1.0, -1.0]
     a = host(aabb).astype(np.float32)
     p.aabb_min[:] = a[0].tolist()
     p.aabb_max[:] = a[1].tolist()

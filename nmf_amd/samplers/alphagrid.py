@@ -5,6 +5,7 @@ CSR ray offsets, never the dense [rays x N] tensors."""
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -49,8 +50,33 @@ class AlphaGridMask(torch.nn.Module):
             bits = hip.alpha_pack(self.alpha_volume.reshape(-1).float())
             gz, gy, gx = self.alpha_volume.shape[-3:]
             self._bits = ((self.alpha_volume.data_ptr(), self.alpha_volume._version), bits,
-                          hip.alpha_coarse(bits, (gx, gy, gz)))
+                          hip.alpha_coarse(bits, (gx, gy, gz)), self._occupied_box())
         return self._bits
+
+    @torch.no_grad()
+    def _occupied_box(self):
+        """World-space box outside of which sample_alpha (:23-45) cannot be positive: a set voxel i reaches points whose
+        texel coordinate lies in (i-1, i+1) (trilinear footprint, align_corners=True), so the box of the set voxels grown
+        by 1.5 voxels.  Evaluated once per mask (one read-back), handed to the marcher as nmf_march_params.occ_min/max."""
+        vol = self.alpha_volume[0, 0] > 0
+        if not bool(vol.any()):
+            return None
+        a = hip.host(self.aabb).astype(np.float64)
+        lo, hi = [], []
+        for axis, dim in ((0, 2), (1, 1), (2, 0)):            # world x, y, z <-> volume dims 2, 1, 0
+            keep = [d for d in range(3) if d != dim]
+            occ = vol.any(dim=keep[1]).any(dim=keep[0]) if keep[1] > keep[0] else vol.any(dim=keep[0]).any(dim=keep[1])
+            idx = torch.nonzero(occ).reshape(-1)
+            g = vol.shape[dim]
+            i0, i1 = float(idx.min()) - 1.5, float(idx.max()) + 1.5
+            size = a[1][axis] - a[0][axis]
+            den = max(g - 1, 1)
+            lo.append(a[0][axis] + size * i0 / den)
+            hi.append(a[0][axis] + size * i1 / den)
+        return lo, hi
+
+    def occupied_box(self):
+        return self._packed()[3]
 
     def bits(self):
         """occupancy bit per voxel (nmf_alpha_pack)"""
@@ -147,7 +173,7 @@ class AlphaGridSampler(torch.nn.Module):
         p = hip.march_params(self.aabb, hip.host(self.alphaMask.invgrid_size) if use_mask else None,
                              float(hip.host(self.stepsize)), near, far, focal, N,
                              [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train,
-                             seed, off)
+                             seed, off, occ_box=self.alphaMask.occupied_box() if use_mask else None)
         rays = rays_chunk.contiguous()
         valid, counts = hip.march_count(p, rays, jitter, self.alphaMask.bits() if use_mask else None,
                                         self.alphaMask.coarse_bits() if use_mask else None)

@@ -854,6 +854,15 @@ def test_march_coarse_mask_is_exact(G, B):
     v0, c0 = hip.march_count(p, rays.to(DEV).contiguous(), None, bits, None)
     v1, c1 = hip.march_count(p, rays.to(DEV).contiguous(), None, bits, coarse)
     assert torch.equal(v0, v1) and torch.equal(c0, c1) and int(c0.sum()) > 0
+    # the occupied-voxel box of AlphaGridMask (nmf_march_params.occ_min/max) only ends rays early: same bits, same counts
+    from nmf_amd.samplers.alphagrid import AlphaGridMask
+    mask = AlphaGridMask(aabb.to(DEV), vol.to(DEV))
+    box = mask.occupied_box()
+    assert box is not None and box[1][2] < float(aabb[1][2]) - 0.5          # upper z half is empty: the box is tight there
+    p_box = hip.march_params(aabb, alpha_inv, float(d["stepsize"]), cfg.near_far[0], cfg.near_far[1], 700.0, d["n_samples"],
+                             (G, G, G), True, seed=3, offset=5, occ_box=box)
+    v2, c2 = hip.march_count(p_box, rays.to(DEV).contiguous(), None, bits, coarse)
+    assert torch.equal(v0, v2) and torch.equal(c0, c2)
     cg = (G + 7) // 8
     pad = torch.zeros(cg * 8 + 1, cg * 8 + 1, cg * 8 + 1)
     pad[:G, :G, :G] = vol
