@@ -234,6 +234,194 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     }
 }
 
+// ---- 16 lanes per ray -----------------------------------------------------------------------------------------------
+// The re-traced secondary rays (0.24 M per step) keep ~4 samples each, all within their first few steps, and leave the
+// occupied box right after: a wave per ray spends a whole 64-step round (Philox, float64 scan, 64 alpha tests) on them.
+// Here a wave carries FOUR rays, one per row of 16 lanes, in rounds of 16 steps: the same arithmetic per step (the
+// partial sums of the step lengths are exact in float64, so neither the round width nor the scan order matters), the
+// float64 scan stays inside a DPP row, the Philox cache covers 64 steps = 4 rounds per fill.  A row that is done idles
+// (masked) until the other three are; the valid words of a ray are assembled from its 16-bit pieces.
+__device__ __forceinline__ double row_incl_scan_dpp(double v) {
+    v += dpp_f64<0x111, 0xf, 0xf>(v);
+    v += dpp_f64<0x112, 0xf, 0xf>(v);
+    v += dpp_f64<0x114, 0xf, 0xf>(v);
+    v += dpp_f64<0x118, 0xf, 0xf>(v);
+    return v;
+}
+// lane l16 of a row evaluates counter 16 g + l16 of the ray (steps [64 g, 64 g + 64))
+__device__ __forceinline__ void jc16_fill(JitterCache& c, const Philox& rng, const nmf_march_params& p, int64_t r, int g) {
+    uint32_t o[4];
+    rng((uint64_t)r * 1024u + (uint64_t)(16 * g + (lane_id() & 15)), p.offset, o);
+    c.o0 = o[0]; c.o1 = o[1]; c.o2 = o[2]; c.o3 = o[3];
+}
+// uniform of step 64 g + k_local (0..63) of this lane's row (all lanes of the wave call this together)
+__device__ __forceinline__ float jc16_get(const JitterCache& c, int k_local) {
+    const int src = (k_local >> 2) & 15, comp = k_local & 3;
+    const uint32_t v0 = __shfl(c.o0, src, 16), v1 = __shfl(c.o1, src, 16);
+    const uint32_t v2 = __shfl(c.o2, src, 16), v3 = __shfl(c.o3, src, 16);
+    return u32_to_unit(comp == 0 ? v0 : (comp == 1 ? v1 : (comp == 2 ? v2 : v3)));
+}
+// one round of 16 steps of this lane's row: step k = 16 s + l16
+__device__ __forceinline__ StepOut march_one16(const nmf_march_params& p, const RayCtx& c, const float* jitter,
+                                               const Philox& rng, const uint32_t* bits, const uint32_t* coarse, int64_t r,
+                                               int k, bool live, double& carry, double* cum_out, float* s_out,
+                                               const JitterCache& jc, const JitterCache& jc_off) {
+    const bool in_range = k < p.n_steps;
+    float step;
+    double cum = 0.0;
+    float s = 0.f;
+    if (p.is_train) {
+        if (jc.on) s = fadd(fmul(jc16_get(jc, k & 63), p.stepsize), p.half_step);
+        else s = step_len(p, jitter, rng, r, in_range ? k : 0, jc_off);
+        s = in_range ? s : 0.f;
+        const double incl = row_incl_scan_dpp((double)s);
+        cum = carry + incl;
+        carry += __shfl(incl, 15, 16);
+        step = (float)cum;
+    } else {
+        step = fmul(p.stepsize, (float)k);   // alphagrid.py:190
+    }
+    if (cum_out) *cum_out = cum;
+    if (s_out) *s_out = s;
+    StepOut o;
+    o.z = fadd(c.tmin, step);                                              // :192
+    o.px = fadd(c.ox, fmul(c.dx, o.z));                                    // :194
+    o.py = fadd(c.oy, fmul(c.dy, o.z));
+    o.pz = fadd(c.oz, fmul(c.dz, o.z));
+    bool outside = (p.aabb_min[0] > o.px) | (o.px > p.aabb_max[0]) | (p.aabb_min[1] > o.py) |
+                   (o.py > p.aabb_max[1]) | (p.aabb_min[2] > o.pz) | (o.pz > p.aabb_max[2]);   // :195
+    o.keep = live && in_range && !outside;
+    if (o.keep && bits) o.keep = alpha_hit(p, bits, coarse, o.px, o.py, o.pz);    // :341-346
+    return o;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_march_count16(nmf_march_params p, const float* __restrict__ rays, int64_t B, const float* __restrict__ jitter,
+                const uint32_t* __restrict__ bits, const uint32_t* __restrict__ coarse, int coarse_words,
+                uint64_t* __restrict__ valid, int32_t* __restrict__ counts) {
+    extern __shared__ uint32_t s_coarse_buf[];
+    const uint32_t* s_coarse = nullptr;
+    if (coarse && bits) {
+        for (int i = threadIdx.x; i < coarse_words; i += blockDim.x) s_coarse_buf[i] = coarse[i];
+        __syncthreads();
+        s_coarse = s_coarse_buf;
+    }
+    const int lane = lane_id(), l16 = lane & 15, row = lane >> 4;
+    const int W = (p.n_steps + 63) >> 6;
+    const int n_rounds = (p.n_steps + 15) >> 4;
+    Philox rng(p.seed);
+    JitterCache jc, jc_off;
+    jc.o0 = jc.o1 = jc.o2 = jc.o3 = 0u;
+    jc.on = p.is_train && !jitter;
+    jc_off = jc;
+    jc_off.on = false;
+    const int64_t n_quads = (B + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_quads; q += (int64_t)gridDim.x * 4) {
+        const int64_t r = q * 4 + row;
+        const bool active = r < B;
+        RayCtx c = load_ray(p, rays, active ? r : B - 1);
+        double carry = 0.0;
+        int total = 0, next_word = 0;
+        uint64_t word = 0;
+        float t_stop = c.tfar;
+        bool live = active;
+        if (bits) {
+            float o0, o1;
+            occ_interval(p, c, o0, o1);
+            if (o1 < o0 || o1 < c.tmin - 1e-2f || o0 > c.tfar + 1e-2f) live = false;
+            t_stop = fminf(t_stop, o1);
+        }
+        for (int s = 0; s < n_rounds; ++s) {
+            if (__ballot(live) == 0ull) break;                               // every row of the wave is done
+            if (jc.on && (s & 3) == 0) jc16_fill(jc, rng, p, active ? r : 0, s >> 2);
+            StepOut o = march_one16(p, c, jitter, rng, bits, s_coarse, active ? r : 0, 16 * s + l16, live, carry, nullptr,
+                                    nullptr, jc, jc_off);
+            const uint64_t m = __ballot(o.keep);
+            const uint64_t piece = (m >> (16 * row)) & 0xffffull;
+            total += __popcll(piece);
+            word |= piece << (16 * (s & 3));
+            const float z_last = __shfl(o.z, 15, 16);
+            const bool finishing = live && (z_last > t_stop + 1e-2f || s == n_rounds - 1);
+            if (live && ((s & 3) == 3 || finishing)) {
+                if (l16 == 0) valid[r * W + (s >> 2)] = word;
+                next_word = (s >> 2) + 1;
+                word = 0;
+            }
+            if (finishing) live = false;
+        }
+        if (active) {
+            for (int jj = next_word + l16; jj < W; jj += 16) valid[r * W + jj] = 0ull;
+            if (l16 == 0) counts[r] = total;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_march_fill16(nmf_march_params p, const float* __restrict__ rays, int64_t b,
+                                                      const float* __restrict__ jitter,
+                                                      const uint64_t* __restrict__ valid,
+                                                      const int64_t* __restrict__ offsets, float4* __restrict__ xyzt,
+                                                      int32_t* __restrict__ ray_id, int32_t* __restrict__ step_id,
+                                                      float* __restrict__ zout, float* __restrict__ dist) {
+    const int lane = lane_id(), l16 = lane & 15, row = lane >> 4;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + row;
+    const bool active = r < b;
+    const int W = (p.n_steps + 63) >> 6;
+    const int n_rounds = (p.n_steps + 15) >> 4;
+    int64_t base = active ? offsets[r] : 0;
+    const int64_t end = active ? offsets[r + 1] : 0;
+    bool live = active && end > base;
+    if (__ballot(live) == 0ull) return;        // wave-uniform: nothing kept on these four rays
+    RayCtx c = load_ray(p, rays, active ? r : b - 1);
+    Philox rng(p.seed);
+    double carry = 0.0;
+    JitterCache jc, jc_off;
+    jc.o0 = jc.o1 = jc.o2 = jc.o3 = 0u;
+    jc.on = p.is_train && !jitter;
+    jc_off = jc;
+    jc_off.on = false;
+    const int64_t rr = active ? r : 0;
+    for (int s = 0; s < n_rounds; ++s) {
+        if (__ballot(live) == 0ull) break;
+        const int k = 16 * s + l16;
+        double cum;
+        if (jc.on && (s & 3) == 0) jc16_fill(jc, rng, p, rr, s >> 2);
+        StepOut o = march_one16(p, c, jitter, rng, nullptr, nullptr, rr, k, live, carry, &cum, nullptr, jc, jc_off);
+        // step length of the NEXT candidate (the sample's dist, :348-350), fetched while the wave is converged: it sits in
+        // the row's jitter cache except for the last step of a 64-step group
+        float s_next = 0.f;
+        if (dist && p.is_train) {
+            const int kn = min(k + 1, p.n_steps - 1);
+            if (jc.on) {
+                s_next = fadd(fmul(jc16_get(jc, kn & 63), p.stepsize), p.half_step);
+                if ((k & 63) == 63) s_next = step_len(p, jitter, rng, rr, kn, jc_off);
+            } else {
+                s_next = step_len(p, jitter, rng, rr, kn, jc_off);
+            }
+        }
+        const uint64_t mw = live ? valid[r * W + (s >> 2)] : 0ull;
+        const uint32_t piece = (uint32_t)((mw >> (16 * (s & 3))) & 0xffffull);
+        if ((piece >> l16) & 1u) {
+            const int64_t idx = base + __popc(piece & ((1u << l16) - 1u));
+            if (xyzt) xyzt[idx] = make_float4(o.px, o.py, o.pz, fdiv(o.z, p.focal));       // :200
+            if (ray_id) ray_id[idx] = (int32_t)r;
+            if (step_id) step_id[idx] = k;
+            if (zout) zout[idx] = o.z;
+            if (dist) {
+                float d = 0.f;                                                              // :348-350
+                if (k + 1 < p.n_steps) {
+                    float znext;
+                    if (p.is_train) znext = fadd(c.tmin, (float)(cum + (double)s_next));
+                    else znext = fadd(c.tmin, fmul(p.stepsize, (float)(k + 1)));
+                    d = fsub(znext, o.z);
+                }
+                dist[idx] = d;
+            }
+        }
+        base += __popc(piece);
+        if (base >= end) live = false;            // every kept sample of this ray has been written
+    }
+}
+
 // coarse[c] = OR of the fine bits of the 9^3 voxels [8c, 8c+8]^3 (clamped): the union of the 8-corner footprints of all
 // points whose floor coordinates fall into coarse cell c
 __global__ void __launch_bounds__(256) k_alpha_coarse(const uint32_t* __restrict__ bits, int gx, int gy, int gz,
@@ -490,6 +678,16 @@ extern "C" int nmf_alpha_coarse(const uint32_t* bits, const int32_t grid[3], uin
     return NMF_OK;
 }
 
+// 64 lanes per ray for primary-ray batches (few rays, every round of 64 steps is needed), 16 for large batches (the
+// re-traced secondary rays finish within their first rounds).  NMF_MARCH_LANES = 16 | 64 forces one (tests compare both).
+static int lanes_per_ray(int64_t n_rays) {
+    if (const char* ev = getenv("NMF_MARCH_LANES")) {
+        const int v = atoi(ev);
+        if (v == 16 || v == 64) return v;
+    }
+    return n_rays > 16384 ? 16 : 64;
+}
+
 extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int64_t B, const float* jitter,
                                const uint32_t* alpha_bits, const uint32_t* alpha_coarse, uint64_t* valid_bits,
                                int32_t* counts, void* stream) {
@@ -498,6 +696,14 @@ extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int
     if (B == 0) return NMF_OK;
     int64_t words = (alpha_bits && alpha_coarse) ? nmf_alpha_coarse_words(p->grid) : 0;
     if (words * 4 > 60 * 1024) { alpha_coarse = nullptr; words = 0; }        // mask larger than the LDS budget: skip it
+    if (lanes_per_ray(B) == 16) {      // many rays (the re-traced secondary rays): four rays per wave, rounds of 16 steps
+        int64_t blocks = cdiv(cdiv(B, 4), 4);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_march_count16, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p,
+                           rays, B, jitter, alpha_bits, alpha_coarse, (int)words, valid_bits, counts);
+        NMF_CHECK_LAUNCH("nmf_march_count");
+        return NMF_OK;
+    }
     int64_t blocks = cdiv(B, 4);
     if (blocks > 256 * 16) blocks = 256 * 16;                                 // persistent: 16 workgroups per CU
     hipLaunchKernelGGL(k_march_count, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p, rays,
@@ -537,8 +743,12 @@ extern "C" int nmf_march_fill(const nmf_march_params* p, const float* rays, int6
     if (int e = check_params(p)) return e;
     NMF_REQUIRE(b >= 0 && (b == 0 || (rays && valid_bits && offsets)), NMF_EINVAL, "nmf_march_fill: null");
     if (b == 0) return NMF_OK;
-    hipLaunchKernelGGL(k_march_fill, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
-                       valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
+    if (lanes_per_ray(b) == 16)
+        hipLaunchKernelGGL(k_march_fill16, dim3((unsigned)cdiv(cdiv(b, 4), 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b,
+                           jitter, valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
+    else
+        hipLaunchKernelGGL(k_march_fill, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
+                           valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
     NMF_CHECK_LAUNCH("nmf_march_fill");
     return NMF_OK;
 }

@@ -1051,3 +1051,40 @@ def test_host_extension_matches_python_wrappers():
             fn(sig.cpu(), dist, off, Mb, 25.0)
     with pytest.raises(hip.NmfHipError):
         hip.segment_sum(vals, None, off, Mb, lanes=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is_train,explicit", [(True, False), (True, True), (False, False)])
+def test_march_16_lanes_per_ray_equals_64(is_train, explicit, monkeypatch):
+    """The marcher has two mappings (one wave per ray / four rays per wave in rounds of 16 steps, chosen by batch size):
+    same valid bits, counts and compacted samples bit for bit, with Philox or explicit jitter, train or eval."""
+    hip = _hip()
+    G, B = 48, 1237
+    cfg = O.Cfg(grid=G)
+    d = cfg.derived()
+    gen = torch.Generator().manual_seed(21)
+    vol = (torch.rand(G, G, G, generator=gen) < 0.03).float()
+    vol[:, :, G // 2:] = 0
+    rays = torch.cat([torch.randn(B, 3, generator=gen) * 1.2, torch.randn(B, 3, generator=gen)], -1)
+    rays[:, 3:] /= rays[:, 3:].norm(dim=-1, keepdim=True)
+    rays[5, :3] = 40.0                                        # a ray that misses everything
+    aabb = d["aabb"]
+    N = 333                                                   # not a multiple of 16 or 64
+    from nmf_amd.samplers.alphagrid import AlphaGridMask
+    box = AlphaGridMask(aabb.to(DEV), vol.to(DEV)).occupied_box()
+    p = hip.march_params(aabb, (1.0 / (aabb[1] - aabb[0]) * 2).numpy(), float(d["stepsize"]), 0.05, 9.0, 800.0, N, (G, G, G),
+                         is_train, seed=11, offset=3, occ_box=box)
+    bits = hip.alpha_pack(vol.to(DEV).reshape(-1))
+    coarse = hip.alpha_coarse(bits, (G, G, G))
+    jit = torch.rand(B, N, generator=gen).to(DEV) if explicit else None
+    rd = rays.to(DEV).contiguous()
+    outs = {}
+    for lanes in ("64", "16"):
+        monkeypatch.setenv("NMF_MARCH_LANES", lanes)
+        valid, counts = hip.march_count(p, rd, jit, bits, coarse)
+        offsets, wv, totals = hip.march_scan(counts, -1)
+        M, b = (int(v) for v in totals.cpu())
+        outs[lanes] = (valid, counts) + tuple(hip.march_fill(p, rd, b, M, jit, valid, offsets))
+    assert int(outs["64"][1].sum()) > 1000 and int(outs["64"][1][5]) == 0
+    for x, y in zip(outs["64"], outs["16"]):
+        assert torch.equal(x, y)
