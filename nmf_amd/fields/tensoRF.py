@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..functional import FieldGrads, GradPass, L1Mean, VMAppQuery, VMQuery
+from ..functional import FieldGrads, GradPass, L1Mean, VMAppQuery, VMQuery, FastPrivateAttrs
 
 
 def N_to_reso(n_voxels, bbox):
@@ -106,7 +106,7 @@ class TensoRF(torch.nn.Module):
         self.grid_size = int(res_target[0])
 
 
-class TensorVMSplit(torch.nn.Module):
+class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, aabb, smoothing=1, interp_mode="bilinear", calibrate=True, dbasis=True, triplanar=False,
                  init_mode="trig", d_init_val=0.1, app_init_val=0.1, numer_grad=True, density_n_comp=16,
                  appearance_n_comp=24, step_ratio=0.5, app_dim=24, density_res_multi=1, N_voxel_init=2097156,

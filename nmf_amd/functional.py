@@ -66,7 +66,20 @@ def grad_views(holder, params):
     return holder.bufs[1]
 
 
-class PassMixin:
+class FastPrivateAttrs:
+    """torch.nn.Module.__setattr__ costs ~3 us (parameter / buffer / submodule bookkeeping); the operator modules rebind a
+    few private caches and pass tokens ~40 times per step.  A private name that already lives in the instance dict is a
+    plain attribute by construction, so it is rebound directly."""
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if name[0] == "_" and name in d:
+            d[name] = value
+        else:
+            super().__setattr__(name, value)
+
+
+class PassMixin(FastPrivateAttrs):
     """begin_pass()/end_pass() bracket one forward/backward pass; every operator call in between shares one
     (GradPass, token) pair, i.e. one gradient node per parameter set (TensorNeRF.forward opens it at recursion 0)."""
     _pass = None

@@ -9,12 +9,12 @@ import types
 import torch
 
 from .. import hip
-from ..functional import BouncePrep, BounceRays, GgxRays, ShadeMix
+from ..functional import BouncePrep, BounceRays, GgxRays, ShadeMix, FastPrivateAttrs
 from ..modules import sh
 from ..brdf_samplers.ggx import mat3T_vec, normalize
 
 
-class Microfacet(torch.nn.Module):
+class Microfacet(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, app_dim, diffuse_module, brdf, brdf_sampler, anoise, max_brdf_rays, target_num_samples,
                  russian_roulette, percent_bright, cold_start_bg_iters, detach_N_iters, min_rough_start=0,
                  min_rough_decay=1, start_std=0, std_decay=1, std_decay_interval=10, conserve_energy=True,

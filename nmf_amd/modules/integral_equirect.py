@@ -8,11 +8,11 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from ..functional import EnvLookup, GradPass, SatBuild
+from ..functional import EnvLookup, GradPass, SatBuild, FastPrivateAttrs
 from . import sh
 
 
-class IntegralEquirect(torch.nn.Module):
+class IntegralEquirect(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, bg_resolution, init_val, activation="identity", mipbias=0, mipnoise=0, lr=0.15, mipbias_lr=1e-3,
                  brightness_lr=0.01, mul_lr=0.01, mul_betas=(0.9, 0.999), betas=(0.9, 0.99)):
         super().__init__()

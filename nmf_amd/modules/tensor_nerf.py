@@ -5,12 +5,12 @@ state_dict layout.  Every stage runs on the compact sample list produced by the 
 import torch
 
 from .. import hip
-from ..functional import Composite, RayCompose, segment_sum
+from ..functional import Composite, RayCompose, segment_sum, FastPrivateAttrs
 from ..noise import DeviceNoise
 from .tonemap import SRGBTonemap
 
 
-class TensorNeRF(torch.nn.Module):
+class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, rf, model, aabb, near_far, sampler, tonemap=None, bg_module=None, normal_module=None,
                  alphaMask=None, infinity_border=False, recur_stepmul=1, recur_alpha_thres=1e-3, detach_inter=False,
                  hdr=False, bg_noise=0, bg_noise_decay=0.999, use_predicted_normals=True, orient_world_normals=False,

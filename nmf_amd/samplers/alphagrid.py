@@ -7,6 +7,7 @@ from typing import Optional
 
 import numpy as np
 import torch
+from ..functional import FastPrivateAttrs
 import torch.nn.functional as F
 
 from .. import hip
@@ -34,7 +35,7 @@ class Samples:
         return hip.march_dense(self.params, self.rays, self.b, self.jitter, self.valid_bits)
 
 
-class AlphaGridMask(torch.nn.Module):
+class AlphaGridMask(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, aabb, alpha_volume):
         super().__init__()
         self.register_buffer("aabb", aabb)
@@ -87,7 +88,7 @@ class AlphaGridMask(torch.nn.Module):
         return self._packed()[2]
 
 
-class AlphaGridSampler(torch.nn.Module):
+class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
     def __init__(self, aabb, enable_alpha_mask=False, threshold=1e-4, multiplier=1, near_far=(2, 6), nEnvSamples=0,
                  alphaMask_thres=0.001, update_list=(), max_samples=-1):
         super().__init__()
