@@ -253,55 +253,20 @@ __device__ __forceinline__ float srgb_grad(float x, int noclip) {
     return g;
 }
 
-__global__ void __launch_bounds__(256) k_ray_compose_fwd(
-    const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
-    const float* __restrict__ normals, const float* __restrict__ rays, const int64_t* __restrict__ offsets, int64_t B,
-    const float* __restrict__ bg, int bg_per_ray, int tonemap, int noclip, float* __restrict__ rgb_map,
-    float* __restrict__ acc_out, float* __restrict__ rgb_lin, float* __restrict__ ori_out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B) return;
-    const int64_t s = offsets[r], e = offsets[r + 1];
-    const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
-    float acc = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, ori = 0.f;
-    for (int64_t k = s; k < e; ++k) {
-        const float w = weight[k];
-        acc += w;
-        if (inv && refl_rows) {
-            const int64_t row = inv[k];
-            if (row >= 0) {
-                c0 += w * refl_rows[row * 3];
-                c1 += w * refl_rows[row * 3 + 1];
-                c2 += w * refl_rows[row * 3 + 2];
-            }
-        }
-        if (ori_out) {
-            const float ndv = fminf(-(dx * normals[k * 3] + dy * normals[k * 3 + 1] + dz * normals[k * 3 + 2]), 0.f);
-            ori += w * (ndv * ndv);
-        }
-    }
-    rgb_lin[r * 3] = c0; rgb_lin[r * 3 + 1] = c1; rgb_lin[r * 3 + 2] = c2;
-    acc_out[r] = acc;
-    if (ori_out) ori_out[r] = ori;
-    const float* b = bg + (bg_per_ray ? r * 3 : 0);
-    const float t = 1.f - acc;
-    rgb_map[r * 3] = (tonemap ? srgb(c0, noclip) : c0) + t * b[0];
-    rgb_map[r * 3 + 1] = (tonemap ? srgb(c1, noclip) : c1) + t * b[1];
-    rgb_map[r * 3 + 2] = (tonemap ? srgb(c2, noclip) : c2) + t * b[2];
-}
-
-// wave-per-ray variant for small batches of long segments (primary rays): lanes stride the ray's samples, wave reduction
+template <int W>      // lanes per ray: 64 for primary-ray batches, 8 for the re-traced rays (short segments, many rays)
 __global__ void __launch_bounds__(256) k_ray_compose_fwd_wave(
     const float* __restrict__ weight, const float* __restrict__ refl_rows, const int32_t* __restrict__ inv,
     const float* __restrict__ normals, const float* __restrict__ rays, const int64_t* __restrict__ offsets, int64_t B,
     const float* __restrict__ bg, int bg_per_ray, int tonemap, int noclip, float* __restrict__ rgb_map,
     float* __restrict__ acc_out, float* __restrict__ rgb_lin, float* __restrict__ ori_out) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= B) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t s = offsets[r], e = offsets[r + 1];
-    const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / W;
+    const int lane = threadIdx.x & (W - 1);
+    const bool ok = r < B;                       // whole lane groups are in or out; the shuffles below stay inside a group
+    const int64_t s = ok ? offsets[r] : 0, e = ok ? offsets[r + 1] : 0;
+    const int64_t rq = ok ? r : 0;
+    const float dx = rays[rq * 6 + 3], dy = rays[rq * 6 + 4], dz = rays[rq * 6 + 5];
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // acc, c0, c1, c2, ori
-    for (int64_t k = s + lane; k < e; k += 64) {
+    for (int64_t k = s + lane; k < e; k += W) {
         const float w = weight[k];
         v[0] += w;
         if (inv && refl_rows) {
@@ -319,8 +284,8 @@ __global__ void __launch_bounds__(256) k_ray_compose_fwd_wave(
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q)
-        for (int d = 32; d > 0; d >>= 1) v[q] += __shfl_down(v[q], d, 64);
-    if (lane != 0) return;
+        for (int d = W / 2; d > 0; d >>= 1) v[q] += __shfl_down(v[q], d, W);
+    if (lane != 0 || !ok) return;
     rgb_lin[r * 3] = v[1]; rgb_lin[r * 3 + 1] = v[2]; rgb_lin[r * 3 + 2] = v[3];
     acc_out[r] = v[0];
     if (ori_out) ori_out[r] = v[4];
@@ -456,11 +421,11 @@ extern "C" int nmf_ray_compose_fwd(const float* weight, const float* refl_rows, 
     NMF_REQUIRE(rays && offsets && bg && rgb_map && acc && rgb_lin, NMF_EINVAL, "nmf_ray_compose_fwd: null");
     NMF_REQUIRE(!ori || normals, NMF_EINVAL, "nmf_ray_compose_fwd: ori needs normals");
     if (B <= 16384)      // few rays with long segments (primary rays): one wave per ray
-        hipLaunchKernelGGL(k_ray_compose_fwd_wave, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, weight,
+        hipLaunchKernelGGL(k_ray_compose_fwd_wave<64>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, weight,
                            refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
                            rgb_map, acc, rgb_lin, ori);
-    else
-        hipLaunchKernelGGL(k_ray_compose_fwd, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+    else                 // many rays with short segments (re-traced rays): eight lanes per ray
+        hipLaunchKernelGGL(k_ray_compose_fwd_wave<8>, dim3((unsigned)cdiv(B, 32)), dim3(256), 0, (hipStream_t)stream, weight,
                            refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
                            rgb_map, acc, rgb_lin, ori);
     NMF_CHECK_LAUNCH("nmf_ray_compose_fwd");

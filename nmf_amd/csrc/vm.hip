@@ -486,6 +486,8 @@ __global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ 
 // SORTED order so that the brick kernels stream them without an indirection: rec0 = xyzt, rec1 = (adjoint of the raw
 // density feature, adjoint of the raw density gradient in normalised-coordinate units).  The softplus / normalize
 // backward is evaluated here, once per sample, fully parallel.
+// APP = false: the density walk (no coefficient adjoints): a third of the registers, twice the waves to hide the cursor atomics
+template <bool APP>
 __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, Segs sg,
                                                        const int32_t* __restrict__ brick_id, int64_t M, int kc,
                                                        int32_t* __restrict__ cursor, float4* __restrict__ rec0,
@@ -528,24 +530,33 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, Segs sg,
         dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
     }
     rec1[pos] = make_float4(dsf, dg0, dg1, dg2);
-    if (sg.d_app[0]) {   // adjoint of the 72 plane*line coefficients: dcoef = d_app x basis_mat (weights via scalar loads)
+    if constexpr (APP) {   // d_app row in brick order; its 72 coefficient adjoints follow in k_dcoef
         float da[AD];
         load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
-        float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);   // d_app row in brick order
+        float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);
 #pragma unroll
         for (int q = 0; q < AD / 4; ++q) srt[q] = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-        float4* out = reinterpret_cast<float4*>(dcoef + (int64_t)pos * (3 * CA));
-#pragma unroll
-        for (int c4 = 0; c4 < 3 * CA / 4; ++c4) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < AD; ++q) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] += basis[q * (3 * CA) + 4 * c4 + u] * da[q];
-            }
-            out[c4] = make_float4(v[0], v[1], v[2], v[3]);
-        }
     }
+}
+
+// adjoint of the 72 plane*line coefficients: dcoef[pos] = d_app[pos] x basis_mat, one thread per (row, 4 coefficients) --
+// the appearance walk has few rows (the bounce points), a thread per row left the chip idle for 30 us
+__global__ void __launch_bounds__(256) k_dcoef(const float* __restrict__ d_app_sorted, const float* __restrict__ basis,
+                                               int64_t M, float* __restrict__ dcoef) {
+    constexpr int Q = 3 * CA / 4;            // 18 float4 groups per row
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * Q) return;
+    const int64_t pos = t / Q;
+    const int c4 = (int)(t - pos * Q);
+    const float* da = d_app_sorted + pos * AD;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < AD; ++q) {
+        const float a = da[q];
+        const float4 b = *reinterpret_cast<const float4*>(basis + q * (3 * CA) + 4 * c4);
+        v[0] += b.x * a; v[1] += b.y * a; v[2] += b.z * a; v[3] += b.w * a;
+    }
+    reinterpret_cast<float4*>(dcoef + pos * (3 * CA))[c4] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -1088,8 +1099,14 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
     float4* rec1 = rec0 + M;
     float* dcoef = (float*)(rec1 + M);              // [M][72]
     float* d_app_sorted = dcoef + M * 3 * CA;       // [M][24]
-    hipLaunchKernelGGL(k_brick_scatter, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc, cursor,
-                       rec0, rec1, d_app_sorted, basis, dcoef);
+    if (want_a) {
+        hipLaunchKernelGGL(k_brick_scatter<true>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc,
+                           cursor, rec0, rec1, d_app_sorted, basis, dcoef);
+        hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, d_app_sorted, basis, M,
+                           dcoef);
+    } else
+        hipLaunchKernelGGL(k_brick_scatter<false>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc,
+                           cursor, rec0, rec1, d_app_sorted, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
