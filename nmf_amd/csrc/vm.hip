@@ -326,6 +326,7 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 // plane tiles (density: 48 ch, appearance: 24 ch) and three 9-entry line segments -- ON THE MATRIX
 // CORES (see k_vm_bwd_brick), flushing the non-zero entries once (~80x fewer global atomics).
 // ------------------------------------------------------------------------------------------------
+constexpr int BASIS_COPIES = 16;   // scratch copies of the basis_mat gradient (power of two), see vm_bwd_app2
 constexpr int BR = 8;             // brick edge in texels
 constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
 
@@ -557,6 +558,15 @@ __global__ void __launch_bounds__(256) k_dcoef(const float* __restrict__ d_app_s
         v[0] += b.x * a; v[1] += b.y * a; v[2] += b.z * a; v[3] += b.w * a;
     }
     reinterpret_cast<float4*>(dcoef + pos * (3 * CA))[c4] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void __launch_bounds__(256) k_basis_reduce(const float* __restrict__ copies, float* __restrict__ g_basis) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= AD * 3 * CA) return;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < BASIS_COPIES; ++c) a += copies[c * (AD * 3 * CA) + t];
+    if (a != 0.f) g_basis[t] += a;          // the caller's accumulator: this launch is the only writer in stream order
 }
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -890,11 +900,15 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
         __syncthreads();
     }
     if (g_basis) {
+        // every work item adds into the same 24 x 72 matrix (54 cache lines): 1 200 items x 3 planes serialised in the L2
+        // atomic units for ~45 us of a 50 us walk.  The adds go to one of BASIS_COPIES scratch copies (by work item);
+        // k_basis_reduce folds them into the caller's matrix.
+        float* gb = g_basis + (int64_t)(blockIdx.x & (BASIS_COPIES - 1)) * (AD * 3 * CA);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = 4 * (lane >> 4) + r;                 // row of the 16x16 tile, column = j
-            float* w0 = g_basis + (int64_t)q * (3 * CA) + i * CA;
-            float* w1 = g_basis + (int64_t)(16 + q) * (3 * CA) + i * CA;
+            float* w0 = gb + (int64_t)q * (3 * CA) + i * CA;
+            float* w1 = gb + (int64_t)(16 + q) * (3 * CA) + i * CA;
             if (accW00[r] != 0.f) atomicAdd(w0 + j, accW00[r]);
             if (hi_ok && accW01[r] != 0.f) atomicAdd(w0 + 16 + j, accW01[r]);
             if (q < AD - 16) {
@@ -1025,7 +1039,7 @@ extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
     const int64_t kc = bin_copies(nb);
     return (M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
-           M * (3 * CA + AD) * (int64_t)sizeof(float) + 64;
+           M * (3 * CA + AD) * (int64_t)sizeof(float) + BASIS_COPIES * AD * 3 * CA * (int64_t)sizeof(float) + 64;
 }
 
 extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
@@ -1081,7 +1095,8 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
     const int kc = bin_copies(nb);
     auto align16 = [](int32_t* q) { return (int32_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15); };
     int32_t* counts = align16(ws + M);            // [(nb+1)*kc]  copy k of brick b at b*kc + k (int4 per brick at kc = 4)
-    int32_t* offsets = counts + (nb + 1) * kc;    // [nb+1]
+    float* basis_copies = (float*)(counts + (nb + 1) * kc);      // [BASIS_COPIES][24][72], zeroed with the counters
+    int32_t* offsets = (int32_t*)(basis_copies + BASIS_COPIES * AD * 3 * CA);   // [nb+1]
     int32_t* cursor = align16(offsets + nb + 1);  // [(nb+1)*kc]
     int32_t* n_items = cursor + (nb + 1) * kc;    // [2] (8-byte aligned start of the item list follows)
     int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
@@ -1089,7 +1104,9 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
     item_size = (item_size + 3) & ~3;
     const int64_t max_items = M / item_size + nb + 1;
     int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc, st);
+    const bool use_copies = want_a && g_basis;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc +
+                                  (use_copies ? sizeof(float) * BASIS_COPIES * AD * 3 * CA : 0), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, nbx, kc, counts, brick_id);
     hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, kc, offsets, cursor, item_size, items, n_items);
@@ -1113,10 +1130,12 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
 #define NMF_LAUNCH_BWD(WN)                                                                                            \
     hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
                        mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \
-                       mkm(g_app_planes), mkm(g_app_lines), g_basis, z_density, z_app)
+                       mkm(g_app_planes), mkm(g_app_lines), use_copies ? basis_copies : nullptr, z_density, z_app)
     if (d_normal) NMF_LAUNCH_BWD(true);
     else NMF_LAUNCH_BWD(false);
 #undef NMF_LAUNCH_BWD
+    if (use_copies)
+        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, basis_copies, g_basis);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }
