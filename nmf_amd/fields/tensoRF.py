@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..functional import FieldGrads, GradPass, L1Mean, VMAppQuery, VMQuery, FastPrivateAttrs
+from ..functional import FieldGrads, GradPass, L1Mean, VMAppQuery, VMQuery, VMQueryWeights, FastPrivateAttrs
 
 
 def N_to_reso(n_voxels, bbox):
@@ -244,6 +244,13 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
             xyz = torch.cat([xyz, torch.zeros_like(xyz[:, :1])], -1)
         holder, token = self._pass_token()
         return VMQuery.apply(self, xyz.contiguous(), want_app, want_normal, holder, token)
+
+    def query_weights(self, xyzt, dist, offsets, b, want_app=True, want_normal=True):
+        """-> weights [M] (raw2alpha over the ray segments `offsets`, tensor_nerf.py:19-35,366), sigma_feat [M], app [M,24],
+        normals [M,3]: query() and the compositing as one graph node.  xyzt [M,4] with M > 0."""
+        holder, token = self._pass_token()
+        return VMQueryWeights.apply(self, xyzt.detach().contiguous(), want_app, want_normal, holder, token, dist, offsets, b,
+                                    float(self.distance_scale))
 
     # ---- gradient pass: all queries between begin_pass() and end_pass() share one FieldGrads node -----------
     def begin_pass(self):

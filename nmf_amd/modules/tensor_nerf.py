@@ -159,10 +159,14 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         # rays, so unless the per-sample debug maps are wanted (eval with draw_debug) the field's appearance branch and the
         # material heads run on those rows only (Microfacet.shade_compact).
         dense_app = (not is_train) and draw_debug
-        sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=dense_app, want_normal=True)   # :286,386,393
+        if M > 0 and hasattr(self.rf, "query_weights"):      # field query + raw2alpha as one graph node (:286,366,386,393)
+            weight, _sf, app, world_normal = self.rf.query_weights(S.xyzt, S.dist, offsets, B, want_app=dense_app,
+                                                                   want_normal=True)
+        else:
+            sigma, _sf, app, world_normal = self.rf.query(S.xyzt, want_app=dense_app, want_normal=True)
+            weight = Composite.apply(sigma, S.dist, offsets, B, float(self.rf.distance_scale))
         if not dense_app:
             app = None
-        weight = Composite.apply(sigma, S.dist, offsets, B, float(self.rf.distance_scale))          # :366
 
         def render_reflection(brays, mipval, retrace):                                               # :291-317
             if retrace:
