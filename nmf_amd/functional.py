@@ -543,6 +543,52 @@ class RayCompose(torch.autograd.Function):
         return (d_weight, d_refl if ctx.needs_input_grad[1] else None, d_normals, d_bg) + (None,) * 9
 
 
+class ShadeCompose(torch.autograd.Function):
+    """ShadeMix followed by RayCompose as ONE graph node: the row radiance (microfacet.py:595-613) only feeds the per-ray
+    sums of tensor_nerf.py:448-452, so the pair costs one autograd node per level and direction instead of two.
+    Returns (rgb_map [B,3], acc [B], ori [B] or None, refl_rows [Mb,3] detached for the debug maps)."""
+
+    @staticmethod
+    def forward(ctx, weight, normals, bg, inv, offsets, ray_id, rays, B, bg_per_ray, tonemap, noclip, want_ori,
+                V, f0, diff, cnt, row_of_ray, row_off, L, inc, brdf):
+        V, f0, diff = V.contiguous(), f0.contiguous(), diff.contiguous()
+        L, inc, brdf = L.contiguous(), inc.contiguous(), brdf.contiguous()
+        contrib = hip.shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf)
+        refl = hip.segment_sum(contrib, None, row_off, V.shape[0], lanes=8)
+        weight = weight.contiguous()
+        normals = normals.contiguous() if normals is not None else None
+        bg = bg.contiguous()
+        rgb_map, acc, rgb_lin, ori = hip.ray_compose_fwd(weight, refl, inv, normals if want_ori else None, rays, offsets, B,
+                                                         bg, bg_per_ray, tonemap, noclip, want_ori)
+        ctx.save_for_backward(weight, refl, normals, bg, inv, ray_id, rays, rgb_lin, acc, V, f0, diff, cnt, row_of_ray,
+                              row_off, L, inc, brdf)
+        ctx.cfg = (bg_per_ray, tonemap, noclip, want_ori)
+        ctx.mark_non_differentiable(refl)
+        ctx.set_materialize_grads(False)
+        return rgb_map, acc, ori, refl
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, d_ori, _d_refl):
+        (weight, refl, normals, bg, inv, ray_id, rays, rgb_lin, acc, V, f0, diff, cnt, row_of_ray, row_off, L, inc,
+         brdf) = ctx.saved_tensors
+        bg_per_ray, tonemap, noclip, want_ori = ctx.cfg
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_rgb, d_acc, d_ori = c(d_rgb), c(d_acc), c(d_ori) if want_ori else None
+        want_dn = d_ori is not None and ctx.needs_input_grad[1]
+        d_weight, d_refl, d_normals = hip.ray_compose_bwd(weight, refl, inv, normals if d_ori is not None else None, rays,
+                                                          ray_id, bg, bg_per_ray, tonemap, noclip, rgb_lin, d_rgb, d_acc, d_ori,
+                                                          want_dn)
+        d_bg = None
+        if ctx.needs_input_grad[2] and d_rgb is not None:
+            d_bg = (1 - acc)[:, None] * d_rgb
+            if not bg_per_ray:
+                d_bg = d_bg.sum(0).reshape(bg.shape)
+        d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_refl)
+        rows = hip.segment_sum_wide(d_fd, 6, row_off, V.shape[0])
+        return (d_weight, d_normals, d_bg) + (None,) * 9 + (None, rows[:, 0:3], rows[:, 3:6], None, None, None, dL, d_inc,
+                                                               d_brdf)
+
+
 class BounceRays(torch.autograd.Function):
     """Sparse training / inference path: everything between "these samples spawn secondary rays" and the secondary rays with
     their BRDF weights as ONE graph node -- appearance features of the bounce rows (VMAppQuery), material heads

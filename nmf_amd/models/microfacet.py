@@ -211,7 +211,8 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
             incoming = render_reflection(bounce_rays, mipval, False)
         if self.trace is not None:
             self.trace[f"incoming{recur}"] = incoming
-        out.refl_rows = ShadeMix.apply(bV, f0, diffuse, cnt32, row_of_ray, row_off, L, incoming, brdf_weight)  # :596-613
+        # :596-613 -- evaluated together with the per-ray sums (functional.ShadeCompose) by TensorNeRF, or on first read
+        out.mix_args = (bV, f0, diffuse, cnt32, row_of_ray, row_off, L, incoming, brdf_weight)
         out.rows = (bidx, row_off, cnt32, row_of_ray, incoming.detach(), brdf_weight.detach())
         return out
 
@@ -226,9 +227,20 @@ class Shaded:
     def __init__(self, model, samples, heads, normals, conv, w_det, inv, M, app_fn=None):
         self.model, self.samples, self.heads, self.normals, self.conv = model, samples, heads, normals, conv
         self.w_det, self.inv, self.M, self.app_fn = w_det, inv, M, app_fn
-        self.refl_rows = None
+        self._refl_rows = None
+        self.mix_args = None          # inputs of the Fresnel mix when the row radiance has not been formed yet
         self.rows = None
         self._debug = None
+
+    @property
+    def refl_rows(self):
+        if self._refl_rows is None and self.mix_args is not None:
+            self._refl_rows = ShadeMix.apply(*self.mix_args)
+        return self._refl_rows
+
+    @refl_rows.setter
+    def refl_rows(self, value):
+        self._refl_rows = value
 
     def rgb(self):
         z = torch.zeros((self.M, 3), device=self.normals.device)

@@ -5,7 +5,7 @@ state_dict layout.  Every stage runs on the compact sample list produced by the 
 import torch
 
 from .. import hip
-from ..functional import Composite, RayCompose, segment_sum, FastPrivateAttrs
+from ..functional import Composite, RayCompose, ShadeCompose, segment_sum, FastPrivateAttrs
 from ..noise import DeviceNoise
 from .tonemap import SRGBTonemap
 
@@ -200,10 +200,17 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
 
         want_stats = recur == 0 and (is_train or not draw_debug)
         # one pass per ray: acc (:448), rgb (:452), orientation term (:583-587), tonemap (:658), background (:659)
-        rgb_map, acc_map, ori = RayCompose.apply(
-            weight, shaded.refl_rows if shaded is not None else None, world_normal if M > 0 else None, bg,
-            shaded.inv if shaded is not None else None, offsets, S.ray_id, S.rays, B, per_ray_bg, bool(tonemap),
-            bool(self.hdr), bool(want_stats and M > 0))
+        if shaded is not None and shaded.mix_args is not None and shaded._refl_rows is None:
+            # Fresnel mix of the bounce rows + the per-ray sums as one graph node
+            rgb_map, acc_map, ori, refl = ShadeCompose.apply(
+                weight, world_normal, bg, shaded.inv, offsets, S.ray_id, S.rays, B, per_ray_bg, bool(tonemap), bool(self.hdr),
+                bool(want_stats and M > 0), *shaded.mix_args)
+            shaded.refl_rows = refl              # detached: the debug maps of this pass read values only
+        else:
+            rgb_map, acc_map, ori = RayCompose.apply(
+                weight, shaded.refl_rows if shaded is not None else None, world_normal if M > 0 else None, bg,
+                shaded.inv if shaded is not None else None, offsets, S.ray_id, S.rays, B, per_ray_bg, bool(tonemap),
+                bool(self.hdr), bool(want_stats and M > 0))
 
         if not is_train and draw_debug:                                                              # :480-566
             with torch.no_grad():
