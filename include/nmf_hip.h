@@ -356,10 +356,12 @@ int64_t nmf_argsort_workspace_bytes(int64_t n);
  * Loss terms (csrc/loss.hip).  `out` scalars are ACCUMULATED into (caller zeroes).
  * ---------------------------------------------------------------------------------------- */
 /* fields/tensoRF.py:332-340 density_L1: out += sum_i mean(|x_i|) over up to 8 dense fp32 tensors (x, numel: HOST arrays
- * of `count` entries); backward g_i = d_out * sgn(x_i) / numel_i, written in x_i's own memory order. */
+ * of `count` entries); backward g_i = d_out * sgn(x_i) / numel_i, written in x_i's own memory order -- or, with
+ * accumulate != 0, ADDED to g_i (which then already holds the rendering gradient of the same factor: one launch instead
+ * of one accumulation kernel per tensor). */
 int nmf_l1_mean_fwd(const float* const x[], const int64_t numel[], int32_t count, float* out, void* stream);
 int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], int32_t count, const float* d_out,
-                    float* const g[], void* stream);
+                    float* const g[], int32_t accumulate, void* stream);
 /* train.py:598-601 photometric term: out += sum (clip(pred,0,1) - clip(gt,0,1))^2 over n floats; backward
  * d_pred = 2 (pred - clip(gt)) d_out inside [0,1], 0 outside (d_out: device scalar). */
 int nmf_sqerr_fwd(const float* pred, const float* gt, int64_t n, float* out, void* stream);

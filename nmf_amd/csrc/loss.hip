@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(256) k_l1_fwd(L1Tab tab, float* __restrict__ o
     if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t / (float)n);
 }
 
-// g_i = d_out * sgn(x_i) / n_i
-__global__ void __launch_bounds__(256) k_l1_bwd(L1Tab tab, const float* __restrict__ d_out) {
+// g_i = d_out * sgn(x_i) / n_i  (accumulate: added to g_i, which then already holds the other gradient of x_i)
+__global__ void __launch_bounds__(256) k_l1_bwd(L1Tab tab, const float* __restrict__ d_out, int accumulate) {
     const int i = blockIdx.y;
     const int64_t n = tab.n[i];
     const float* __restrict__ x = tab.x[i];
@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) k_l1_bwd(L1Tab tab, const float* __restri
     const float s = d_out[0] / (float)n;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const float v = x[k];
-        g[k] = v > 0.f ? s : (v < 0.f ? -s : 0.f);
+        const float gv = v > 0.f ? s : (v < 0.f ? -s : 0.f);
+        g[k] = accumulate ? g[k] + gv : gv;
     }
 }
 
@@ -135,7 +136,7 @@ extern "C" int nmf_l1_mean_fwd(const float* const x[], const int64_t numel[], in
 }
 
 extern "C" int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], int32_t count, const float* d_out,
-                               float* const g[], void* stream) {
+                               float* const g[], int32_t accumulate, void* stream) {
     NMF_REQUIRE(count >= 0 && count <= L1_MAX, NMF_ERANGE, "nmf_l1_mean_bwd: at most 8 tensors");
     NMF_REQUIRE(d_out && (count == 0 || (x && numel && g)), NMF_EINVAL, "nmf_l1_mean_bwd: null");
     if (count == 0) return NMF_OK;
@@ -143,7 +144,7 @@ extern "C" int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], in
     memset(&t, 0, sizeof(t));
     NMF_REQUIRE(fill_tab(t, x, g, numel, count, true) == 0, NMF_EINVAL, "nmf_l1_mean_bwd: bad tensor");
     hipLaunchKernelGGL(k_l1_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
-                       d_out);
+                       d_out, (int)accumulate);
     NMF_CHECK_LAUNCH("nmf_l1_mean_bwd");
     return NMF_OK;
 }

@@ -151,6 +151,7 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         self._cache = None
         self._plist = None
         self._pass, self._pass_open, self._tables_memo = None, False, None
+        self._last_holder = None
 
     # ---- geometry bookkeeping (fields/tensor_base.py:55-64,219-232) ---------------------------------
     def set_register(self, name, val):
@@ -269,6 +270,7 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         token = FieldGrads.apply(holder, self, *ps)
         if self._pass_open:
             self._pass = (holder, token)
+            self._last_holder = holder
         return holder, token
 
     def compute_densityfeature(self, xyz_sampled, activate=True):
@@ -298,9 +300,24 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
                 {"params": self.dbasis_mat.parameters(), "lr": lr_scale * self.lr_net, "betas": [0.9, 0.99]},
                 *self.density_rf.get_optparam_groups(lr_scale), *self.app_rf.get_optparam_groups(lr_scale)]
 
-    def density_L1(self):
-        # fields/tensoRF.py:332-340
-        return L1Mean.apply(*self.density_rf.app_plane, *self.density_rf.app_line)
+    def density_L1(self, with_pass=False):
+        """fields/tensoRF.py:332-340.  with_pass: the caller adds this term to the loss of the rendering pass that has just
+        been evaluated (the trainer does), so its gradient can ride on that pass's table-gradient node."""
+        holder = self._last_holder if with_pass else None
+        return L1Mean.apply(holder, *self.density_rf.app_plane, *self.density_rf.app_line)
+
+    @torch.no_grad()
+    def flush_pending_l1(self):
+        """Safety net for density_L1(with_pass=True): if the pass's gradient node did not run in the backward that consumed
+        the term (no field query was connected to that loss), the term's gradient is applied here."""
+        h = self._last_holder
+        if h is None or h.l1 is None:
+            return
+        tensors, d_out = h.l1
+        h.l1 = None
+        grads = hip.l1_mean_bwd(tensors, d_out)
+        for prm, g in zip(list(self.density_rf.app_plane) + list(self.density_rf.app_line), grads):
+            prm.grad = g if prm.grad is None else prm.grad + g
 
     def vector_comp_diffs(self):
         total = 0

@@ -16,6 +16,9 @@ class GradPass:
         self.bufs = None
         self.token_sent = False
         self.pending = []          # deferred field walks: (adjoint-set key, segment tuple), see defer_field_walk
+        self.l1 = None             # (density factors, d_out) of a density_L1 term that joins the table gradients of this pass
+        self.used = False          # a field query of the pass holds the token: FieldGrads.backward will run
+        self.done = False
 
     def token_grad(self, like):
         """Gradient for the pass token: the node behind the token only has to be scheduled, so exactly one consumer
@@ -150,12 +153,21 @@ class FieldGrads(torch.autograd.Function):
     def backward(ctx, _d_token):
         holder, field = ctx.holder, ctx.field
         flush_field_walks(holder, field)
+        holder.done = True
+        l1, holder.l1 = holder.l1, None
         if holder.bufs is None:
-            return (None, None) + (None,) * len(field._param_list())
+            out = [None] * len(field._param_list())
+            if l1 is not None:                       # no walk happened: the regulariser's own gradients
+                out[:len(l1[0])] = hip.l1_mean_bwd(l1[0], l1[1])
+            return (None, None) + tuple(out)
         g_dpk, g_dlk, g_apl, g_ali, g_basis = holder.bufs
         holder.bufs = None
         p = field._tables()[0]
         gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+        if l1 is not None:
+            # density_L1 of the same step (train.py:670-677): its sign(x)/n term is added to the unpacked gradients in one
+            # launch ([G,G,16] / [G,16] are the factors' own storage order) instead of six autograd accumulation kernels
+            hip.l1_mean_bwd(l1[0], l1[1], out=gp + gl)
         return (None, None) + tuple(field._grads_to_param_layout(gp, gl, g_apl, g_ali, g_basis))
 
 
@@ -170,6 +182,8 @@ class VMQuery(torch.autograd.Function):
         sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
                                                   want_normal=want_normal, want_app=want_app, want_coef=False)
         ctx.field, ctx.holder = field, holder
+        if holder is not None:
+            holder.used = True
         ctx.flags = (want_app, want_normal)
         ctx.save_for_backward(xyzt, sf, gr, cf)
         ctx.mark_non_differentiable(sf)
@@ -204,6 +218,8 @@ class VMQueryWeights(torch.autograd.Function):
                                                   want_normal=want_normal, want_app=want_app, want_coef=False)
         w, _acc = hip.composite_fwd(sg, dist, offsets, b, scale)
         ctx.meta = (field, holder, want_app, want_normal, b, scale)
+        if holder is not None:
+            holder.used = True
         ctx.save_for_backward(xyzt, sf, gr, sg, dist, w, offsets)
         ctx.mark_non_differentiable(sf)
         ctx.set_materialize_grads(False)
@@ -680,16 +696,23 @@ def material_heads(feat, hp, params, owner=None, stacked=None):
 
 
 class L1Mean(torch.autograd.Function):
-    """sum_i mean(|x_i|) over a list of dense tensors in one launch (fields/tensoRF.py:332-340)."""
+    """sum_i mean(|x_i|) over a list of dense tensors in one launch (fields/tensoRF.py:332-340).  `holder`: the GradPass
+    of a field pass whose FieldGrads node is part of the same backward (the trainer's total loss); the gradient is then
+    handed to that node, which adds it to the table gradients it emits (see FieldGrads.backward)."""
 
     @staticmethod
-    def forward(ctx, *tensors):
+    def forward(ctx, holder, *tensors):
+        ctx.holder = holder
         ctx.save_for_backward(*tensors)
         return hip.l1_mean_fwd([t.detach() for t in tensors])
 
     @staticmethod
     def backward(ctx, d_out):
-        return tuple(hip.l1_mean_bwd(list(ctx.saved_tensors), d_out.contiguous()))
+        h = ctx.holder
+        if h is not None and h.used and not h.done and h.l1 is None:
+            h.l1 = ([t.detach() for t in ctx.saved_tensors], d_out.contiguous())
+            return (None,) * (1 + len(ctx.saved_tensors))
+        return (None,) + tuple(hip.l1_mean_bwd(list(ctx.saved_tensors), d_out.contiguous()))
 
 
 class LossMix(torch.autograd.Function):

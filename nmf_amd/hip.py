@@ -745,13 +745,18 @@ def l1_mean_fwd(tensors):
     return out
 
 
-def l1_mean_bwd(tensors, d_out):
+def l1_mean_bwd(tensors, d_out, out=None):
+    """-> gradients in the tensors' own memory order; out = existing gradient tensors of the same storage order to ADD into"""
     n = len(tensors)
-    grads = [torch.empty_like(t, memory_format=torch.preserve_format) for t in tensors]
+    grads = out if out is not None else [torch.empty_like(t, memory_format=torch.preserve_format) for t in tensors]
     ptrs = (C.c_void_p * n)(*[_dense_f32(t) for t in tensors])
     gptrs = (C.c_void_p * n)(*[_dense_f32(g) for g in grads])
     numel = (C.c_int64 * n)(*[t.numel() for t in tensors])
-    _check(_lib.nmf_l1_mean_bwd(ptrs, numel, C.c_int32(n), _p(d_out, torch.float32), gptrs, _stream()), "nmf_l1_mean_bwd")
+    for t, g in zip(tensors, grads):
+        if g.numel() != t.numel():
+            raise NmfHipError("l1_mean_bwd: gradient / tensor size mismatch")
+    _check(_lib.nmf_l1_mean_bwd(ptrs, numel, C.c_int32(n), _p(d_out, torch.float32), gptrs, C.c_int32(0 if out is None else 1),
+                                _stream()), "nmf_l1_mean_bwd")
     return grads
 
 

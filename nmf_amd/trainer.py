@@ -188,7 +188,8 @@ class Trainer:
             wv = st["whole_valid"]
             rgb_map = ims["rgb_map"]                 # valid rays are a prefix of the chunk (alphagrid.py:353-364)
             loss = SquaredError.apply(rgb_map, gt[: rgb_map.shape[0]])                           # train.py:598-601
-            terms, wts = [loss, nerf.rf.density_L1()], [1.0, p["L1_weight_initial"]]            # train.py:640-677
+            l1 = nerf.rf.density_L1(with_pass=True) if hasattr(nerf.rf, "flush_pending_l1") else nerf.rf.density_L1()
+            terms, wts = [loss, l1], [1.0, p["L1_weight_initial"]]                              # train.py:640-677
             if st.get("ori_terms") is not None:
                 terms.append(st["ori_terms"]); wts.append(p["ori_lambda"])
             if "acc_terms" in st:
@@ -197,6 +198,8 @@ class Trainer:
                 terms.append(st["prediction_loss"]); wts.append(p["pred_lambda"])
             total = LossMix.apply(1.0 / lbatch, wts, *terms)
             total.backward(_one(total))
+            if hasattr(nerf.rf, "flush_pending_l1"):
+                nerf.rf.flush_pending_l1()
             kept = rgb_map.shape[0]                  # = number of valid rays (no device read-back)
             used_rays += kept
             losses.append(loss.detach())             # read back after the optimizer step has been queued

@@ -433,3 +433,48 @@ def test_render_cli_with_relighting(tmp_path, capsys):
     a = np.asarray(Image.open(tmp_path / "imgs" / "000.png")).astype(np.float32)
     b = np.asarray(Image.open(tmp_path / "relit" / "000.png")).astype(np.float32)
     assert a.shape == (48, 48, 3) and np.isfinite(b).all() and np.abs(a - b).mean() > 0.5       # lighting changed
+
+
+@pytest.mark.gpu
+def test_density_l1_rides_on_the_pass_gradient_node():
+    """density_L1(with_pass=True) hands its gradient to the rendering pass's table-gradient node (one accumulating launch
+    instead of six autograd adds): parameter gradients equal the plain formulation, also when no field query is connected
+    to the loss (flush_pending_l1)."""
+    import torch
+    from nmf_amd import synthetic
+    import bench
+    dev = torch.device("cuda", 0)
+    grid_saved = bench.GRID
+    try:
+        bench.GRID = 32
+        nerf, _params = bench.build(dev)
+    finally:
+        bench.GRID = grid_saved
+    rays, focal = synthetic.camera_rays(512, seed=3)
+    rays = rays.to(dev)
+    from nmf_amd.noise import DeviceNoise
+    dens = list(nerf.rf.density_rf.app_plane) + list(nerf.rf.density_rf.app_line)
+
+    def grads(with_pass, seed):
+        for p in nerf.parameters():
+            p.grad = None
+        ims, st = nerf(rays, focal, bg_col=torch.ones(3, device=dev), is_train=True, ndc_ray=False, noise=DeviceNoise(dev, seed))
+        l1 = nerf.rf.density_L1(with_pass=with_pass)
+        (ims["rgb_map"].sum() + 3.0 * l1).backward()
+        nerf.rf.flush_pending_l1()
+        return [p.grad.clone() for p in dens]
+
+    a, b = grads(False, 5), grads(True, 5)
+    for x, y in zip(a, b):
+        assert x.abs().max() > 0
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(x.abs().max()))
+    # the term alone (its pass node is not part of this backward): applied by the safety flush
+    for p in nerf.parameters():
+        p.grad = None
+    nerf(rays, focal, bg_col=torch.ones(3, device=dev), is_train=True, ndc_ray=False, noise=DeviceNoise(dev, 6))
+    nerf.rf.density_L1(with_pass=True).backward()
+    assert all(p.grad is None for p in dens)
+    nerf.rf.flush_pending_l1()
+    ref = [torch.sign(p.detach()) / p.numel() for p in dens]
+    for p, r in zip(dens, ref):
+        assert torch.allclose(p.grad, r, rtol=1e-6, atol=0)

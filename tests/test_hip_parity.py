@@ -785,7 +785,7 @@ def test_loss_kernels_vs_torch():
     ts[0][0, 0, 0, 0] = 0.0
     td = [t.to(DEV).requires_grad_(True) for t in ts]
     tr = [t.clone().requires_grad_(True) for t in ts]
-    out = L1Mean.apply(*td)
+    out = L1Mean.apply(None, *td)
     ref = sum(t.abs().mean() for t in tr)
     assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-7, what="l1 mean")
     g_h = torch.autograd.grad(out * 3.0, td)
