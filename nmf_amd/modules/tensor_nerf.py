@@ -113,6 +113,9 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
                                   getattr(self.model, "diffuse_module", None)) if hasattr(m, "begin_pass")]
             for m in passes:
                 m.begin_pass()
+            nz = noise if noise is not None else self._noise
+            if nz is not None and hasattr(nz, "begin_pass"):
+                nz.begin_pass()                         # the pass's uniform / normal pools, one generator launch each
             # derived tables of the field (packed density planes) depend only on the parameters: queue their rebuild now, so
             # that it is issued while the GPU may still be busy with the previous step and before the sampler's read-back
             if rays.is_cuda:
