@@ -394,6 +394,69 @@ std::tuple<Tensor, OT, OT> ray_compose_bwd(const Tensor& weight, const OT& refl_
     return {d_weight, d_refl, d_normals};
 }
 
+// ---- field backward (FieldGrads.backward: two walks + the unpack, ~180 us of Python per step) -------------------------
+using Seg = std::tuple<Tensor, OT, OT, OT, OT, OT, OT>;     // xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app
+
+void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
+                           const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
+                           const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
+                           const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
+                           int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    if (segs.size() > NMF_VM_MAX_SEGMENTS) fail("at most " + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments per walk");
+    nmf_vm_bwd_segment arr[NMF_VM_MAX_SEGMENTS];
+    int64_t M = 0;
+    bool want_d = false, want_a = false;
+    for (size_t i = 0; i < segs.size(); ++i) {
+        const Tensor& x = std::get<0>(segs[i]);
+        arr[i].xyzt = f32(x);
+        arr[i].M = x.size(0);
+        arr[i].sigma_feat = static_cast<const float*>(vptr(std::get<1>(segs[i])));
+        arr[i].grad = static_cast<const float*>(vptr(std::get<2>(segs[i])));
+        arr[i].d_sigma = static_cast<const float*>(vptr(std::get<3>(segs[i])));
+        arr[i].d_sigma_feat = static_cast<const float*>(vptr(std::get<4>(segs[i])));
+        arr[i].d_normal = static_cast<const float*>(vptr(std::get<5>(segs[i])));
+        arr[i].d_app = static_cast<const float*>(vptr(std::get<6>(segs[i])));
+        M += arr[i].M;
+        want_d = want_d || std::get<3>(segs[i]).has_value() || std::get<4>(segs[i]).has_value() || std::get<5>(segs[i]).has_value();
+        want_a = want_a || std::get<6>(segs[i]).has_value();
+    }
+    if (M == 0) return;
+    const int64_t nbytes = nmf_vm_bwd_workspace_bytes(M, p->grid);
+    Tensor ws = ie(std::get<0>(segs[0]), {(nbytes + 3) / 4}, at::kInt);
+    P3 a{}, b{}, c{}, d{};
+    float *ga[3] = {nullptr, nullptr, nullptr}, *gb[3] = {nullptr, nullptr, nullptr}, *gc[3] = {nullptr, nullptr, nullptr},
+          *gd[3] = {nullptr, nullptr, nullptr};
+    auto three_out = [](const std::vector<Tensor>& ts, float* (&o)[3]) {
+        if (ts.size() != 3) fail("expected three tensors");
+        for (int i = 0; i < 3; ++i) o[i] = const_cast<float*>(f32(ts[i]));
+    };
+    if (want_d) { a = three(dpk); b = three(dlk); three_out(g_dpk, ga); three_out(g_dlk, gb); }
+    if (want_a) { c = three(apl); d = three(ali); three_out(g_apl, gc); three_out(g_ali, gd); }
+    check(nmf_vm_query_bwd_segments(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
+                                    want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
+                                    want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
+                                    want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, ws.data_ptr(), nbytes, st(stream)),
+          "nmf_vm_query_bwd_segments");
+}
+
+std::tuple<std::vector<Tensor>, std::vector<Tensor>> vm_unpack_density_grad(int64_t p_addr, const std::vector<Tensor>& g_dpk,
+                                                                            const std::vector<Tensor>& g_dlk, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    const int64_t G = p->grid;
+    P3 a = three(g_dpk), b = three(g_dlk);
+    std::vector<Tensor> gp, gl;
+    float *op[3], *ol[3];
+    for (int i = 0; i < 3; ++i) {
+        gp.push_back(fe(g_dpk[0], {G, G, 16}));
+        gl.push_back(fe(g_dpk[0], {G, 16}));
+        op[i] = out(gp[i]);
+        ol[i] = out(gl[i]);
+    }
+    check(nmf_vm_unpack_density_grad(p, a.p, b.p, op, ol, st(stream)), "nmf_vm_unpack_density_grad");
+    return {gp, gl};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_nmf_host, m) {
@@ -427,4 +490,6 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("ggx_rays_bwd", &ggx_rays_bwd);
     m.def("shade_mix_bwd", &shade_mix_bwd);
     m.def("ray_compose_bwd", &ray_compose_bwd);
+    m.def("vm_query_bwd_segments", &vm_query_bwd_segments);
+    m.def("vm_unpack_density_grad", &vm_unpack_density_grad);
 }

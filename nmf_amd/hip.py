@@ -948,6 +948,14 @@ def _install_host_ext():
         return fx.ray_compose_bwd(weight, refl_rows, inv, normals, rays, ray_id, bg, bool(bg_per_ray), bool(tonemap),
                                   bool(noclip), rgb_lin, d_rgb_map, d_acc, d_ori, bool(want_d_normals), _stream())
 
+    def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
+                              g_basis=None):
+        return fx.vm_query_bwd_segments(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
+                                        g_app_lines, g_basis, _stream())
+
+    def vm_unpack_density_grad(p, g_dpk, g_dlk):
+        return fx.vm_unpack_density_grad(addr(p), g_dpk, g_dlk, _stream())
+
     for name, fn in list(locals().items()):
         if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd"):
             PY_WRAPPERS[name] = g[name]

@@ -21,7 +21,7 @@ for n in ['march_params','march_count','march_scan','march_fill','vm_query_fwd',
           'vm_query_bwd','vm_query_bwd_segments','loss_mix_fwd','loss_mix_bwd','composite_bwd','heads_bwd','bounce_prep_bwd','ggx_rays_bwd','brdf_mlp_bwd','sat_lookup_bwd','shade_mix_bwd','ray_compose_bwd','segment_sum_wide','sat_build_bwd','vm_unpack_density_grad','adam_step','l1_mean_fwd','l1_mean_bwd','sqerr_fwd','sqerr_bwd','sat_build','vm_pack_density']:
     wrap(hip,n,'hip.'+n)
 import nmf_amd.functional as F_
-for cls in ['VMQuery','Composite','BouncePrep','GgxRays','BrdfMLP','MaterialHeads','ShadeMix','RayCompose','BounceRays','VMAppQuery','LossMix','EnvLookup','FieldGrads','SatBuild','ParamGrads','StackedHeadGrads','L1Mean','SquaredError']:
+for cls in ['VMQuery','Composite','BouncePrep','GgxRays','BrdfMLP','MaterialHeads','ShadeMix','RayCompose','BounceRays','VMAppQuery','LossMix','ShadeCompose','VMQueryWeights','EnvLookup','FieldGrads','SatBuild','ParamGrads','StackedHeadGrads','L1Mean','SquaredError']:
     c=getattr(F_,cls)
     for m in ('forward','backward'):
         f=getattr(c,m)
