@@ -448,8 +448,10 @@ std::tuple<std::vector<Tensor>, std::vector<Tensor>> vm_unpack_density_grad(int6
     std::vector<Tensor> gp, gl;
     float *op[3], *ol[3];
     for (int i = 0; i < 3; ++i) {
-        gp.push_back(fe(g_dpk[0], {G, G, 16}));
-        gl.push_back(fe(g_dpk[0], {G, 16}));
+        // parameter-shaped ([1,16,G,G] / [1,16,G,1]) with channel-last strides: the storage is the [G][G][16] / [G][16] the
+        // kernel writes, and autograd gets the gradient without a chain of permute / unsqueeze views
+        gp.push_back(at::empty({1, 16, G, G}, g_dpk[0].options().dtype(at::kFloat).memory_format(at::MemoryFormat::ChannelsLast)));
+        gl.push_back(at::empty({1, 16, G, 1}, g_dpk[0].options().dtype(at::kFloat).memory_format(at::MemoryFormat::ChannelsLast)));
         op[i] = out(gp[i]);
         ol[i] = out(gl[i]);
     }

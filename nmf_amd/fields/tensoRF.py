@@ -224,9 +224,9 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         """kernel layouts ([G,G,C] / [G,C]) -> views shaped like the parameters (no copies)"""
         out = []
         for t in gp:
-            out.append(t.permute(2, 0, 1)[None])
+            out.append(t if t.dim() == 4 else t.permute(2, 0, 1)[None])     # vm_unpack_density_grad returns parameter shapes
         for t in gl:
-            out.append(t.t()[None, :, :, None])
+            out.append(t if t.dim() == 4 else t.t()[None, :, :, None])
         for t in g_apl:
             out.append(t.permute(2, 0, 1)[None])
         for t in g_ali:

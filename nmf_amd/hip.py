@@ -385,9 +385,13 @@ def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk
 def vm_unpack_density_grad(p, g_dpk, g_dlk):
     G = p.grid
     dev = g_dpk[0].device
-    gp = [torch.empty((G, G, 16), dtype=torch.float32, device=dev) for _ in range(3)]
-    gl = [torch.empty((G, 16), dtype=torch.float32, device=dev) for _ in range(3)]
-    _check(_lib.nmf_vm_unpack_density_grad(C.byref(p), _p3(g_dpk), _p3(g_dlk), _p3(gp), _p3(gl), _stream()),
+    # parameter-shaped outputs with channel-last strides: the storage is the [G][G][16] / [G][16] the kernel writes
+    gp = [torch.empty((1, 16, G, G), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+          for _ in range(3)]
+    gl = [torch.empty((1, 16, G, 1), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+          for _ in range(3)]
+    arr_p, arr_l = (C.c_void_p * 3)(*[t.data_ptr() for t in gp]), (C.c_void_p * 3)(*[t.data_ptr() for t in gl])
+    _check(_lib.nmf_vm_unpack_density_grad(C.byref(p), _p3(g_dpk), _p3(g_dlk), arr_p, arr_l, _stream()),
            "nmf_vm_unpack_density_grad")
     return gp, gl
 

@@ -155,8 +155,9 @@ def _vm_backward(hip, p, xyz_d, tabs, sf, gr, d_sigma, d_sf, d_normal, d_app, co
     assert float((g_basis - ref_basis).abs().max()) <= 2e-4 * float(ref_basis.abs().max()) + 1e-6
     out = {}
     for i in range(3):
-        out[f"rf.density_rf.app_plane.{i}"] = gp[i].permute(2, 0, 1)[None].cpu()
-        out[f"rf.density_rf.app_line.{i}"] = gl[i].t().reshape(1, 16, G, 1).cpu()
+        assert gp[i].shape == (1, 16, G, G) and gl[i].shape == (1, 16, G, 1)      # parameter-shaped, channel-last storage
+        out[f"rf.density_rf.app_plane.{i}"] = gp[i].cpu()
+        out[f"rf.density_rf.app_line.{i}"] = gl[i].cpu()
         out[f"rf.app_rf.app_plane.{i}"] = g_apl[i].permute(2, 0, 1)[None].cpu()
         out[f"rf.app_rf.app_line.{i}"] = g_ali[i].t().reshape(1, 24, G, 1).cpu()
     out["rf.basis_mat.weight"] = g_basis.cpu()
