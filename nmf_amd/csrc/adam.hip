@@ -10,7 +10,8 @@
 //   m   = m + (g - m) * (1 - beta1)                          (lerp_)
 //   v   = v * beta2 + (1 - beta2) * g * g                    (mul_, addcmul_)
 //   p   = p - step_size * m / (sqrt(v) / bc2_sqrt + eps)     (sqrt, div_, add_, addcdiv_)
-// in the parameter's own dtype (fp32 tables, fp64 for the three env-map scalars).
+// in the parameter's own dtype (fp32 tables, fp64 for the three env-map scalars).  Elements with a non-finite gradient
+// are skipped (see adam_slot).
 #include "common.hpp"
 
 namespace {
@@ -43,8 +44,12 @@ __device__ void adam_slot(const nmf_adam_slot& s) {
     const int64_t n = s.numel;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T gg = g[i];
+        // NaN guard (train.py:704-705 drops a chunk whose loss is NaN, after a host read-back): an element whose gradient
+        // is not finite keeps its parameter and its moments, so one bad chunk cannot poison the optimizer state
+        if (!(fabs(gg) <= (T)3.0e38)) continue;
         T pp = p[i], mm = m[i], vv = v[i];
-        adam_one<T>(pp, g[i], mm, vv, wd, omb1, b2, omb2, step, bc2s, eps);
+        adam_one<T>(pp, gg, mm, vv, wd, omb1, b2, omb2, step, bc2s, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }

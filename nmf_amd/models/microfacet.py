@@ -46,6 +46,9 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
         self.ratio_list = None
         self.trace = None            # tests: dict that receives intermediate tensors
         self.forced = None           # tests: {'retrace_order<r>': LongTensor, 'counts<r>': IntTensor} pin bookkeeping decisions
+        # True: sort the re-trace scores even when every secondary ray is re-traced, as models/microfacet.py:506-509 does
+        # (the order then pairs rays with jitter rows exactly like the reference); False: identity order in that case
+        self.exact_retrace_order = False
 
     # ---- controllers / bookkeeping (models/microfacet.py:79-121,236-269) --------------------------------
     def calibrate(self, args, xyz, feat, bg_brightness, save_config=True):
@@ -180,7 +183,7 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
         if len(self.max_retrace_rays) > recur:                                                      # :475-559
             num_retrace = min(R, self.max_retrace_rays[recur])
             pinned = self.forced is not None and f"retrace_order{recur}" in self.forced
-            if num_retrace >= R and not pinned and self.trace is None:
+            if num_retrace >= R and not pinned and self.trace is None and not self.exact_retrace_order:
                 # steady state: every secondary ray is re-traced.  The reference still argsorts the
                 # scores, which only permutes the rays before they meet their i.i.d. jitter rows; the draw is
                 # consumed for stream parity and the identity order is used (same distribution, no 250 k-key sort).
@@ -196,10 +199,11 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
                     order = hip.argsort_f32(cc.contiguous()).long()                                  # :522
                     if pinned:
                         order = self.forced[f"retrace_order{recur}"].to(dev)
-                    if self.trace is not None:
-                        self.trace[f"retrace_score{recur}"] = cc
                     cut = max(R - num_retrace, 0)
                     idx_re, idx_no = order[cut:], order[:cut]
+                    if self.trace is not None:
+                        self.trace.update({f"retrace_score{recur}": cc, f"retrace_order{recur}": order,
+                                           f"retrace_idx{recur}": idx_re})
                 incoming = torch.zeros((R, 3), device=dev)
                 if idx_re.shape[0] > 0:
                     inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)

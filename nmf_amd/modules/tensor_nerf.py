@@ -189,7 +189,7 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
                                               is_train, recur, noise, app_fn=self.rf.compute_appfeature)
 
         images = {}
-        stats = dict(recur=recur, whole_valid=wv, n_samples=n_samples)
+        stats = dict(recur=recur, whole_valid=wv, n_samples=n_samples, rays_kept=B)
         per_ray_bg = self.bg_module is not None and bg_col is None
         if per_ray_bg:                                                                               # :460-468
             rough = -100 * torch.ones(B, device=dev) if start_mipval is None else start_mipval[:B]

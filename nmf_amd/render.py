@@ -19,7 +19,7 @@ from . import synthetic
 from .modules.integral_equirect import IntegralEquirect
 from .modules.tensor_nerf import TensorNeRF
 from .noise import DeviceNoise
-from .trainer import psnr_8bit
+from .renderer import psnr_8bit, render_images
 
 
 def load_fixed_bg(path, device):
@@ -40,12 +40,7 @@ def render_frames(nerf, rays, focal, chunk, noise):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in range(rays.shape[0]):
-        img = []
-        for i in range(0, rays.shape[1], chunk):
-            ims, _ = nerf(rays[f, i:i + chunk], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=noise,
-                          draw_debug=False)
-            img.append(ims["rgb_map"])
-        out.append(torch.cat(img, 0))
+        out.append(render_images(nerf, rays[f], focal, chunk, noise))
     torch.cuda.synchronize()
     return torch.stack(out), time.perf_counter() - t0
 

@@ -23,17 +23,13 @@ import torch
 from . import synthetic
 from .config import build_model, resolved_config
 from .noise import DeviceNoise
-from .trainer import Trainer, psnr_8bit, rank_slice
+from .renderer import psnr_8bit, render_images as _render_images
+from .trainer import Trainer, agree, rank_slice
 
 
-@torch.no_grad()
 def render_images(nerf, rays, focal, chunk, noise):
     """chunk_renderer with render2completion (renderer.py:56-106) in eval mode -> rgb [n,3]"""
-    out = []
-    for i in range(0, rays.shape[0], chunk):
-        ims, _ = nerf(rays[i:i + chunk], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False, noise=noise)
-        out.append(ims["rgb_map"])
-    return torch.cat(out, 0)
+    return _render_images(nerf, rays, focal, chunk, noise, draw_debug=True)
 
 
 def main(argv=None):
@@ -50,6 +46,9 @@ def main(argv=None):
     ap.add_argument("--near-far", type=float, nargs=2, default=None)
     ap.add_argument("--downsample", type=float, default=1.0)
     ap.add_argument("--save", type=str, default=None, help="write a checkpoint (TensorNeRF.save) at the end")
+    ap.add_argument("--rays-per-gpu", type=int, default=None,
+                    help="weak scaling: every rank takes this many rays per optimizer step (BASELINE configs[3]: 32768), "
+                         "processed in num_rays chunks; default: the reference's lbatch_size split over the ranks")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -107,18 +106,21 @@ def main(argv=None):
     perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
     t0, rays_seen = time.time(), 0
     for it in range(args.iters):
-        nb = trainer.lbatch_size()
+        # The global batch must be the same number on every rank (it sizes the shards, advances the shared permutation and
+        # normalises the loss, train.py:504-507,703) while each rank's ray controller follows its own chunks: agree on it.
+        nb = world * args.rays_per_gpu if args.rays_per_gpu else agree(trainer.lbatch_size(), "min", device=dev)
         if cur + nb > n_total:
             perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
         ids = perm[cur:cur + nb][rank_slice(nb, world, rank)]      # SimpleSampler (train.py:36-51), sharded over ranks
         cur += nb
-        out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise)
+        out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
         rays_seen += out["rays"] * world
         if (it + 1) % args.eval_every == 0 or it + 1 == args.iters:
             nerf.eval()
             pred = render_images(nerf, rays_te, focal, 4096, noise)
             nerf.train()
-            psnr = float(psnr_8bit(pred.reshape(args.test_views, -1, 3), rgb_te.reshape(args.test_views, -1, 3)))
+            pv, gv = pred.reshape(args.test_views, -1, 3), rgb_te.reshape(args.test_views, -1, 3)
+            psnr = float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(args.test_views)]).mean())   # renderer.py:511-513
             if rank == 0:
                 print(json.dumps(dict(iteration=it + 1, train_psnr=round(out["psnr"], 3), test_psnr=round(psnr, 3),
                                       rays_per_s=round(rays_seen / (time.time() - t0), 1), num_rays=trainer.num_rays,

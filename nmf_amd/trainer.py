@@ -69,10 +69,7 @@ class DecayLR:
         self._apply()
 
 
-def psnr_8bit(pred, gt):
-    # renderer.py:399-401
-    q = torch.floor(pred.clip(0, 1) * 255) / 255
-    return -10.0 * torch.log10(((q - gt.clip(0, 1)) ** 2).mean())
+from .renderer import psnr_8bit  # noqa: E402,F401  (re-exported: renderer.py:399-401)
 
 
 def rank_slice(n_total, world_size, rank):
@@ -85,20 +82,32 @@ def rank_slice(n_total, world_size, rank):
 class FlatGradAllReduce:
     """One collective per optimizer step: gradients are packed into a flat fp32 buffer (14 MB at 128^3, 50 MB at
     300^3), summed over ranks (RCCL over xGMI when backend='nccl', gloo on CPU) and unpacked.  A single bucket:
-    at 7 x ~153 GB/s per GPU the ring time (<1 ms) is far below the step time, so overlap buys nothing here."""
+    at 7 x ~153 GB/s per GPU the ring time (<1 ms) is far below the step time, so overlap buys nothing here.
+
+    The buffer layout is FIXED: every parameter of the list owns its slot whether or not this rank produced a gradient
+    for it in this step (a rank whose chunk spawned no bounce rows, or whose chunks were all empty, still has to enter
+    the collective with the same element count as its peers).  Missing gradients travel as zeros and are materialised
+    on unpack, so every replica hands the same set of gradients to its optimizer."""
 
     def __init__(self, params):
         self.params = [p for p in params]
+        self.numel = sum(p.numel() for p in self.params)
         self.buf = None
         self._slots = None
+        self.last_comm_ms = None          # (start, end) device events of the last collective, or host seconds on CPU
 
     def __call__(self, group=None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return 0
-        ps = [p for p in self.params if p.grad is not None]
-        n = sum(p.numel() for p in ps)
-        if self.buf is None or self.buf.numel() != n or self.buf.device != ps[0].device:
-            self.buf = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+        ps, n = self.params, self.numel
+        if n == 0:
+            return 0
+        dev = ps[0].device
+        if self.buf is None or self.buf.device != dev:
+            self.buf = torch.empty(n, dtype=torch.float32, device=dev)
+        for p in ps:                              # zero gradient for what this rank did not touch (same memory order as p)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
         if self.buf.is_cuda:
             return self._reduce_device(ps, n, group)
         off = 0                                   # host tensors (gloo tests of the sharding logic): plain torch copies
@@ -131,9 +140,33 @@ class FlatGradAllReduce:
             b.src, b.dst, b.numel, b.src_is_f64, b.dst_is_f64 = base + 4 * off, g.data_ptr(), g.numel(), 0, f64
             off += g.numel()
         hip.multi_copy(pack, len(ps))
+        ev = self._events = getattr(self, "_events", None) or (torch.cuda.Event(enable_timing=True),
+                                                               torch.cuda.Event(enable_timing=True))
+        ev[0].record()
         dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        ev[1].record()
+        self.last_comm_ms = ev
         hip.multi_copy(unpack, len(ps))
         return n * 4
+
+    def comm_ms(self):
+        """duration of the last device collective (blocks until it has finished); None if there was none"""
+        ev = self.last_comm_ms
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+
+def agree(value, op="min", group=None, device=None):
+    """One scalar agreed over the ranks (min / max / sum of a python number): controller inputs that must be identical on
+    every replica (global batch size, the decision to re-permute).  Identity without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op], group=group)
+    v = float(t[0])
+    return int(round(v)) if isinstance(value, int) else v
 
 
 class Trainer:
@@ -145,6 +178,12 @@ class Trainer:
         self.prev_ratio = None
         self.iteration = 0
         self.reduce = None
+        # train.py:470-481,748-749: exponential decay of the two regulariser weights towards their final values
+        self.ori_lambda, self.pred_lambda = float(params["ori_lambda"]), float(params["pred_lambda"])
+        n_it = params["n_iters"]
+        fo, fp = params.get("final_ori_lambda"), params.get("final_pred_lambda")
+        self.ori_decay = math.exp(math.log(fo / self.ori_lambda) / n_it) if self.ori_lambda > 0 and fo is not None else 1.0
+        self.pred_decay = math.exp(math.log(fp / self.pred_lambda) / n_it) if self.pred_lambda > 0 and fp is not None else 1.0
         self._make_optimizer()
         # The step allocates a few hundred short-lived Python containers; a full (generation-2) collection walks every
         # tracked object of the process (~270 k after importing torch: 70 ms measured, i.e. 13 steps).  Park what exists now
@@ -166,37 +205,42 @@ class Trainer:
         p = self.p
         return min(p["min_batch_size"] if self.num_rays < p["min_batch_size"] else self.num_rays, p["max_batch_size"])
 
-    def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None):
+    def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None, global_rays=None):
         """One optimizer step over this rank's rays (train.py:497-747).  rays [n,6], rgb_gt [n,3] (already blended
-        onto the background colour, train.py:525-530).  Returns a stats dict (python scalars)."""
+        onto the background colour, train.py:525-530).  `global_rays`: the loss normaliser `lbatch_size` of train.py:703,
+        i.e. the number of rays ALL ranks process in this step (default: n * world_size, equal shards).
+        Returns a stats dict (python scalars)."""
         p = self.p
         nerf = self.nerf
         self.optimizer.zero_grad(set_to_none=True)
         n_total = rays.shape[0]
-        lbatch = n_total * self.world_size          # the loss normaliser is the GLOBAL ray count
-        pos, used_rays, losses, n_samples_last = 0, 0, [], None
+        lbatch = global_rays if global_rays is not None else n_total * self.world_size
+        pos, used_rays, losses, n_samples_last, n_chunks = 0, 0, [], None, 0
         bg = _ones((3,), rays.device)
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
             r = rays[pos:pos + chunk]
             gt = rgb_gt[pos:pos + chunk]
             pos += r.shape[0]
+            n_chunks += 1
             ims, st = nerf(r, focal, bg_col=bg, is_train=True, ndc_ray=False, noise=noise)
             n_samples = st["n_samples"]
             if n_samples[0] == 0:
                 continue
-            wv = st["whole_valid"]
             rgb_map = ims["rgb_map"]                 # valid rays are a prefix of the chunk (alphagrid.py:353-364)
             loss = SquaredError.apply(rgb_map, gt[: rgb_map.shape[0]])                           # train.py:598-601
             l1 = nerf.rf.density_L1(with_pass=True) if hasattr(nerf.rf, "flush_pending_l1") else nerf.rf.density_L1()
             terms, wts = [loss, l1], [1.0, p["L1_weight_initial"]]                              # train.py:640-677
             if st.get("ori_terms") is not None:
-                terms.append(st["ori_terms"]); wts.append(p["ori_lambda"])
+                terms.append(st["ori_terms"]); wts.append(self.ori_lambda)
             if "acc_terms" in st:
-                terms.append(st["acc_terms"]); wts.append(2.0 * p["pred_lambda"])
+                terms.append(st["acc_terms"]); wts.append(2.0 * self.pred_lambda)
             else:
-                terms.append(st["prediction_loss"]); wts.append(p["pred_lambda"])
+                terms.append(st["prediction_loss"]); wts.append(self.pred_lambda)
             total = LossMix.apply(1.0 / lbatch, wts, *terms)
+            # train.py:704-705 skips a chunk whose loss is NaN (a host read-back per chunk); here the chunk is
+            # back-propagated regardless and nmf_adam_step leaves every element with a non-finite gradient untouched, so a
+            # NaN never reaches the moments or the parameters and no synchronisation is needed
             total.backward(_one(total))
             if hasattr(nerf.rf, "flush_pending_l1"):
                 nerf.rf.flush_pending_l1()
@@ -211,14 +255,20 @@ class Trainer:
                 self.num_rays = int(mean_ratio * p["target_num_samples"] + 1)
                 nerf.model.update_n_samples(n_samples[1:])
         comm_bytes = self.reduce()
+        if p.get("clip_grad") is not None:                                                       # train.py:744-745
+            torch.nn.utils.clip_grad_norm_([q for q in nerf.parameters() if q.grad is not None], p["clip_grad"])
         self.optimizer.step()
         self.scheduler.step()
+        self.ori_lambda *= self.ori_decay                                                        # train.py:748-749
+        self.pred_lambda *= self.pred_decay
         if nerf.check_schedule(self.iteration, 1):                                               # train.py:806-813
             self._make_optimizer()
             self.num_rays = p["starting_batch_size"]
+            self.prev_ratio = None
             nerf.model.reset_counter()
         self.iteration += 1
-        return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes)
+        return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes, chunks=n_chunks,
+                         reduce=self.reduce)
 
 
 class StepStats(dict):
@@ -231,6 +281,9 @@ class StepStats(dict):
         self._losses = losses
 
     def __missing__(self, key):
+        if key == "comm_ms":             # duration of this step's gradient all-reduce (device events; waits for it)
+            self[key] = self["reduce"].comm_ms() if self.get("reduce") is not None and self["comm_bytes"] else None
+            return self[key]
         if key not in ("loss", "psnr"):
             raise KeyError(key)
         loss_sum = float(torch.stack(self._losses).sum()) if self._losses else 0.0

@@ -133,10 +133,14 @@ def alpha_query(alpha_volume, aabb, xyz):
     return F.grid_sample(alpha_volume, coords.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
 
 
-def sample(rays, focal, cfg: Cfg, alpha_volume, noise: Noise, is_train, override_near=None,
+@torch.no_grad()                                                                     # :278 -- sample positions, z and dists
+def sample(rays, focal, cfg: Cfg, alpha_volume, noise: Noise, is_train, override_near=None,   # carry NO gradient to the rays
            dynamic_batch_size=True):
-    """AlphaGridSampler.sample, samplers/alphagrid.py:279-370 (N_samples is forced to nSamples,
-    SURVEY F7).  Returns xyzs [M,4], ray_valid [b,N], N, z_vals, dists, whole_valid [B]."""
+    """AlphaGridSampler.sample, samplers/alphagrid.py:278-370 (N_samples is forced to nSamples,
+    SURVEY F7).  Returns xyzs [M,4], ray_valid [b,N], N, z_vals, dists, whole_valid [B].
+    The reference decorates it with @torch.no_grad() (:278): the secondary rays' direction L depends on the normals and
+    the roughness, but their sample positions / step lengths do not back-propagate into them (only the environment lookup
+    and the BRDF inputs do).  Matters in the steady state, where every secondary ray is marched (e2e_full_steady)."""
     d = cfg.derived()
     near, far = cfg.near_far
     if override_near is not None:
@@ -384,7 +388,9 @@ def material_heads(sd, cfg: Cfg, feat):
     p = "model.diffuse_module."
 
     def lin(name):
-        return feat @ sd[p + name + "_mlp.0.weight"].T + sd[p + name + "_mlp.0.bias"]
+        # nn.Linear = F.linear (one addmm with the bias as the accumulator's start value: rounds differently from
+        # `x @ W.T + b`, and the re-trace ORDER of the steady state is sensitive to the last bit of every score input)
+        return F.linear(feat, sd[p + name + "_mlp.0.weight"], sd[p + name + "_mlp.0.bias"])
 
     albedo = torch.sigmoid(cfg.diffuse_mul * lin("diffuse") + cfg.diffuse_bias).clip(min=0, max=1)
     r = (torch.sigmoid(lin("roughness") + cfg.roughness_bias) / 2).clip(min=1e-2, max=1)
@@ -720,16 +726,21 @@ def brdf_mlp(sd, cfg: Cfg, half_vec, diff_vec, feat, rough):
     x = torch.cat([feat, ish_basis(cfg.ish_degs, half_vec, kappa), half_vec,
                    ish_basis(cfg.ish_degs, diff_vec, kappa), diff_vec], dim=-1)
     p = "model.brdf.mlp."
-    h = torch.relu(x @ sd[p + "0.weight"].T + sd[p + "0.bias"])
-    h = torch.relu(h @ sd[p + "2.weight"].T + sd[p + "2.bias"])
-    o = h @ sd[p + "4.weight"].T + sd[p + "4.bias"]
+    h = torch.relu(F.linear(x, sd[p + "0.weight"], sd[p + "0.bias"]))       # nn.Sequential(Linear, ReLU, ...) = F.linear
+    h = torch.relu(F.linear(h, sd[p + "2.weight"], sd[p + "2.bias"]))
+    o = F.linear(h, sd[p + "4.weight"], sd[p + "4.bias"])
     return torch.sigmoid(o[..., :3] + cfg.brdf_bias)
 
 
 # ----------------------------------------------------------------------------------------------
 # a20: retrace selection (models/microfacet.py:475-537)
 # ----------------------------------------------------------------------------------------------
-def retrace_select(brdf_weight, eV, eN, samp_prob, w_bounce, ray_count, ray_mask, num_retrace, noise: Noise):
+def retrace_select(brdf_weight, eV, eN, samp_prob, w_bounce, ray_count, ray_mask, num_retrace, noise: Noise,
+                   forced_order=None):
+    """forced_order: the argsort result recorded from the reference (tests/golden BookkeepingTap).  The scores are
+    contribution + U(0,1) in fp32; their inputs (normals -> GGX directions -> BRDF weights) agree with the reference to
+    ~1 ulp, not bit for bit, so ~0.1 % of neighbouring rays swap places in the sort -- harmless when a few rays are selected,
+    but in the steady state (every ray re-traced) the order pairs each ray with a jitter row of the recursive render."""
     with torch.no_grad():
         ri, rj = torch.where(ray_mask)
         per_sample = w_bounce.reshape(-1, 1) / ray_count
@@ -739,15 +750,21 @@ def retrace_select(brdf_weight, eV, eN, samp_prob, w_bounce, ray_count, ray_mask
         cc = cc / cc.sum() * num_retrace
         cc = cc + noise.draw("rand", cc.shape)
         order = cc.argsort()
+        if forced_order is not None:
+            assert forced_order.shape == order.shape
+            own, order = order, forced_order.long()
+            cc = (cc, own)
         M = max(order.shape[0] - num_retrace, 0)
-        return order[M:], order[:M], (cc, order)
+        if isinstance(cc, tuple):
+            return order[M:], order[:M], (cc[0], order, cc[1])
+        return order[M:], order[:M], (cc, order, order)
 
 
 # ----------------------------------------------------------------------------------------------
 # a21: shading (models/microfacet.py:271-673, diffuse_mixing_mode='fresnel')
 # ----------------------------------------------------------------------------------------------
 def shade(sd, cfg: Cfg, xyzs, app_features, viewdirs, nrm, weights, app_mask, render_reflection,
-          noise: Noise, is_train, recur, trace=None):
+          noise: Noise, is_train, recur, trace=None, forced=None):
     M = xyzs.shape[0]
     noise_feat = app_features + noise.draw("randn", app_features.shape) * cfg.anoise       # :297
     noise.draw("randn", (M, 3), unused=True)
@@ -796,10 +813,11 @@ def shade(sd, cfg: Cfg, xyzs, app_features, viewdirs, nrm, weights, app_mask, re
             num_retrace = min(brdf_weight.shape[0], cfg.max_retrace_rays[recur])
             idx_re, idx_no, cc = retrace_select(brdf_weight, eV, eN, samp_prob,
                                                 weights[app_mask][bounce_mask], ray_count, ray_mask,
-                                                num_retrace, noise)
+                                                num_retrace, noise,
+                                                None if forced is None else forced.get(f"retrace_order{recur}"))
             if trace is not None:
                 trace.update({f"retrace_idx{recur}": idx_re, f"retrace_score{recur}": cc[0],
-                              f"retrace_order{recur}": cc[1]})
+                              f"retrace_order{recur}": cc[1], f"retrace_order_own{recur}": cc[2]})
             incoming = torch.zeros((bounce_rays.shape[0], 3))
             if len(idx_re) > 0:
                 inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
@@ -833,8 +851,8 @@ def shade(sd, cfg: Cfg, xyzs, app_features, viewdirs, nrm, weights, app_mask, re
 # ----------------------------------------------------------------------------------------------
 def render(sd, cfg: Cfg, rays, focal, alpha_volume, noise: Noise, is_train=True, recur=0,
            bg_col=None, start_mipval=None, override_near=None, dynamic_batch_size=True, tonemap=True,
-           trace=None):
-    """Returns (images, stats) with the reference's key names."""
+           trace=None, forced=None):
+    """Returns (images, stats) with the reference's key names.  forced: {"retrace_order0": ...} see retrace_select."""
     d = cfg.derived()
     xyz, ray_valid, N, z_vals, dists, whole_valid = sample(
         rays, focal, cfg, alpha_volume, noise, is_train, override_near, dynamic_batch_size)
@@ -856,7 +874,7 @@ def render(sd, cfg: Cfg, rays, focal, alpha_volume, noise: Noise, is_train=True,
             ims, st = render(sd, cfg, brays, focal, alpha_volume, noise, is_train=is_train,
                              recur=recur + 1, bg_col=None, start_mipval=mipval.reshape(-1),
                              override_near=3 * d["stepsize"], dynamic_batch_size=False,
-                             tonemap=False, trace=trace)
+                             tonemap=False, trace=trace, forced=forced)
             n_samples.extend(st["n_samples"])
             return ims["rgb_map"]
         noise.draw("rand", (brays.shape[0],), unused=True)
@@ -867,7 +885,7 @@ def render(sd, cfg: Cfg, rays, focal, alpha_volume, noise: Noise, is_train=True,
         app = app_feature(sd, cfg, xyz)                                                     # :386
         world_normal = normals(sd, cfg, xyz)                                                # :393
         rgb, debug = shade(sd, cfg, xyz, app, viewdirs[ray_valid], world_normal, weight, ray_valid,
-                           render_reflection, noise, is_train, recur, trace)
+                           render_reflection, noise, is_train, recur, trace, forced)
     else:
         rgb = torch.empty((0, 3))
         debug = {}

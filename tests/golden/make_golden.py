@@ -310,31 +310,105 @@ def case_e2e_small():
         save("e2e_small_" + tag, out)
 
 
-def case_e2e_full():
-    """Full BASELINE size (4096 rays, 128^3, 512x1024 env): noise is replayed BY SEED (the global
-    torch CPU generator), only per-ray outputs and gradient norms are stored."""
-    G, BG, B = 128, 512, 4096
-    nerf, sd = small_reference(G, BG)
+class BookkeepingTap:
+    """Records the reference's own bookkeeping decisions while it runs: the per-sample secondary-ray counts of
+    select_bounces (per recursion level, in call order) and every argsort the shading model takes (the re-trace order,
+    models/microfacet.py:506-509).  Outputs of reference functions, no reference code."""
+
+    def __init__(self):
+        self.counts, self.orders = [], []
+
+    def __enter__(self):
+        import models.microfacet as mm
+        self._mm, self._sel, self._argsort = mm, mm.select_bounces, torch.Tensor.argsort
+        tap = self
+
+        def sel(weights, app_mask, *a, **k):
+            bm, rm = tap._sel(weights, app_mask, *a, **k)
+            c = torch.zeros(bm.shape[0], dtype=torch.int32)
+            c[bm] = rm.sum(1).int()
+            tap.counts.append(c)
+            return bm, rm
+
+        def argsort(t, *a, **k):
+            o = tap._argsort(t, *a, **k)
+            if t.dim() == 1 and t.is_floating_point():
+                tap.orders.append(o.clone())
+            return o
+
+        mm.select_bounces = sel
+        torch.Tensor.argsort = argsort
+        return self
+
+    def __exit__(self, *exc):
+        self._mm.select_bounces = self._sel
+        torch.Tensor.argsort = self._argsort
+        return False
+
+
+def _store_grads(out, nerf, full_bytes=1 << 20):
+    """norm of every parameter gradient; the full gradient of every tensor <= 1 MiB; strided slices of the larger ones"""
+    for n, p in nerf.named_parameters():
+        if p.grad is None:
+            continue
+        out["gradnorm/" + n] = p.grad.norm()
+        if p.grad.numel() * p.grad.element_size() <= full_bytes:
+            out["grad/" + n] = p.grad
+        elif p.grad.dim() == 4:
+            out["grad_slice4/" + n] = p.grad[0, :, ::4, ::4]
+
+
+def _full_size_case(name, max_retrace, G=128, BG=512, B=4096, ray_seed=0, noise_seed=1234):
+    """Full BASELINE size (4096 rays, 128^3, 512x1024 env): noise is replayed BY SEED (the global torch CPU generator);
+    per-ray outputs, losses, parameter gradients and the reference's bookkeeping decisions are stored."""
+    nerf, sd = small_reference(G, BG, max_retrace_rays=(max_retrace,))
     nerf.sampler.update(nerf.rf, init=False)
     nerf.sampler.update(nerf.rf, init=True)
     nerf.model.detach_N = False
-    rays, focal = synthetic.camera_rays(B, seed=0)
-    torch.manual_seed(1234)
-    ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
+    rays, focal = synthetic.camera_rays(B, seed=ray_seed)
+    torch.manual_seed(noise_seed)
+    with BookkeepingTap() as tap:
+        ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
     g = torch.Generator().manual_seed(9)
     gt = torch.rand(B, 3, generator=g)
     wv = stats["whole_valid"]
     loss = ((ims["rgb_map"].clip(max=1).clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
     total = (loss + 0.1 * stats["ori_loss"] + 3e-4 * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 4096
     total.backward()
-    out = dict(grid=G, bg_res=BG, n_rays=B, noise_seed=1234, rgb_map=ims["rgb_map"], acc_map=ims["acc_map"],
+    out = dict(grid=G, bg_res=BG, n_rays=B, ray_seed=ray_seed, noise_seed=noise_seed, max_retrace=max_retrace,
+               rgb_map=ims["rgb_map"], acc_map=ims["acc_map"],
                whole_valid=wv, n_samples=np.asarray(stats["n_samples"]), loss=loss, total=total,
                ori_loss=stats["ori_loss"], prediction_loss=stats["prediction_loss"],
                n_alpha=int(nerf.sampler.alphaMask.alpha_volume.sum()))
-    for n, p in nerf.named_parameters():
-        if p.grad is not None:
-            out["gradnorm/" + n] = p.grad.norm()
-    save("e2e_full_seeded", out)
+    for lvl, c in enumerate(tap.counts):
+        assert int(c.max()) < 32768
+        out[f"counts{lvl}"] = c.to(torch.int16)
+    assert len(tap.orders) == 1
+    order = tap.orders[0]
+    R = order.shape[0]
+    out["n_secondary"] = R
+    if max_retrace >= R:
+        out["retrace_order0"] = order.int()                 # every ray re-traced: the order pairs rays with jitter rows
+    else:
+        out["retrace_idx0"] = order[R - max_retrace:].int()  # the re-traced rays, in the order they are traced
+    _store_grads(out, nerf)
+    save(name, out)
+
+
+def case_e2e_full():
+    """early phase (first 19 chunks after any (re)start): 1000 of ~246 k secondary rays are re-traced"""
+    _full_size_case("e2e_full_seeded", 1000)
+
+
+def case_e2e_full_steady():
+    """steady state (models/microfacet.py:241-268): max_retrace_rays has ramped to max_brdf_rays[0], every
+    secondary ray is re-traced -- the regime bench.py times"""
+    _full_size_case("e2e_full_steady", 650000)
+
+
+def case_e2e_g300():
+    """final grid of the schedule (300^3, 1036 steps per ray, 41 MB of factor tables), steady state, small ray batch"""
+    _full_size_case("e2e_g300_steady", 650000, G=300, B=192, ray_seed=4, noise_seed=77)
 
 
 def case_upsample():
@@ -400,7 +474,8 @@ def case_blender_rays():
 
 
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
-             shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full)
+             shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
+             e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -27,21 +27,37 @@ def _worker(rank, world, port, out, device="cpu"):
     params = [torch.nn.Parameter(p.detach().to(device)) for p in params]
     rays = torch.arange(10 * 6, dtype=torch.float32, device=device).reshape(10, 6)
     mine = rays[rank_slice(10, world, rank)]
-    # a "loss" whose gradient depends on the local shard only; params[4] gets no gradient at all
-    loss = (params[0].sum() * mine.sum() + (params[1] ** 2).sum() * (rank + 1) + params[2].mean() * mine[:, 0].sum()
-            + params[3] * float(mine.shape[0]))
+    # a "loss" whose gradient depends on the local shard only.  params[1] gets a gradient on rank 0 ONLY (a rank whose chunk
+    # spawned no bounce rows has no BRDF-MLP gradient), params[4] on no rank (tint head in fresnel mode): the buffer layout
+    # must not depend on which gradients exist locally
+    loss = (params[0].sum() * mine.sum() + params[2].mean() * mine[:, 0].sum() + params[3] * float(mine.shape[0]))
+    if rank == 0:
+        loss = loss + (params[1] ** 2).sum() * 3.0
     loss.backward()
-    local = [p.grad.clone().cpu() if p.grad is not None else None for p in params]
-    nbytes = FlatGradAllReduce(params)()
+    assert (params[1].grad is None) == (rank != 0) and params[4].grad is None
+    local = [p.grad.clone().cpu() if p.grad is not None else torch.zeros_like(p).cpu() for p in params]
+    red = FlatGradAllReduce(params)
+    nbytes = red()
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
-    ok = nbytes == 4 * sum(p.numel() for p in params[:4])
-    for i, p in enumerate(params[:4]):
+    ok = nbytes == 4 * sum(p.numel() for p in params)
+    for i, p in enumerate(params):
         want = sum(g[i].double() for g in gathered)
-        ok &= bool(torch.allclose(p.grad.double().cpu(), want, rtol=1e-6, atol=1e-6))
+        ok &= p.grad is not None and bool(torch.allclose(p.grad.double().cpu(), want, rtol=1e-6, atol=1e-6))
         ok &= p.grad.shape == p.shape and p.grad.dtype == p.dtype
-    ok &= params[4].grad is None
+    ok &= float(params[4].grad.abs().max()) == 0.0 and float(params[1].grad.abs().max()) > 0
     ok &= params[2].grad.is_contiguous(memory_format=torch.channels_last)
+    # a rank with NO local gradient at all (every chunk of its shard was empty, trainer.py `continue`) still enters the
+    # collective with the same element count
+    for p in params:
+        p.grad = None
+    if rank == 0:
+        params[0].grad = torch.ones_like(params[0])
+    ok &= red() == nbytes and bool(torch.equal(params[0].grad.cpu(), torch.ones(3, 5)))
+    ok &= all(p.grad is not None for p in params)
+    # agree(): one scalar, identical on every rank afterwards
+    from nmf_amd.trainer import agree
+    ok &= agree(4096 + 100 * rank, "min", device=device) == 4096 and agree(1, "sum", device=device) == world
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -393,6 +393,31 @@ def test_env_lookup_golden_and_gradients():
     assert abs(float(d_mip) - float(gm_o)) <= 5e-3 * abs(float(gm_o)) + 1e-5, (float(d_mip), float(gm_o))
 
 
+def test_env_spherical_harmonics_golden():
+    """a13: IntegralEquirect.get_spherical_harmonics (modules/integral_equirect.py:324-360) THROUGH THE MODULE -- 5000
+    prefiltered lookups at mipval -5 on the direction lattice, projected on 9 SH terms and convolved with the clamped-cosine
+    kernel (sh_A) -- against the reference's coefficients for the fixture's map."""
+    from nmf_amd.modules.integral_equirect import IntegralEquirect
+    g = Golden("env")
+    H = g["H"]
+    env = IntegralEquirect(bg_resolution=H, mipbias=1, activation="exp", lr=0.02, init_val=-0.6, mul_lr=0, brightness_lr=0,
+                           mipbias_lr=1e-4, mipnoise=0.0).to(DEV)
+    with torch.no_grad():
+        env.bg_mat.copy_(g["bg_mat"].to(DEV))
+    coeffs, conv = env.get_spherical_harmonics(100)
+    ref_c, ref_v = g["sh_coeffs"].reshape(9, 3), g["sh_conv"].reshape(9, 3)
+    # the DC term is ~3.5; every lookup inherits the SAT cancellation noise of the 32x64 fixture map (see
+    # test_env_lookup_golden_and_gradients), which averages down over the 5000 directions
+    assert_close(coeffs.cpu().reshape(9, 3), ref_c, rtol=1e-3, atol=1e-3 * float(ref_c.abs().max()), what="sh coeffs")
+    assert_close(conv.cpu().reshape(9, 3), ref_v, rtol=1e-3, atol=1e-3 * float(ref_v.abs().max()), what="sh conv")
+    assert_close(env.mean_color().detach().cpu(), g["mean_color"], rtol=1e-5, atol=1e-6, what="mean_color")
+    # cached per parameter version: a changed map gives new coefficients
+    with torch.no_grad():
+        env.bg_mat.mul_(0.5)
+    c2, _ = env.get_spherical_harmonics(100)
+    assert float((c2 - coeffs).abs().max()) > 1e-3
+
+
 def test_env_lookup_full_size_properties():
     """512x1024 map: constant map integrates to the constant for every direction / footprint, and
     the lookup is linear in the table (size-independent properties at BASELINE size)."""
