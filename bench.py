@@ -142,7 +142,7 @@ def physical_cores():
     return max(len(cores), 1)
 
 
-def cpu_baseline(budget_s=75.0):
+def cpu_baseline(budget_s=150.0):
     """The CPU oracle (validated against the reference, tests/test_oracle_golden.py) timed on the host cores with the
     SURVEY 8(d) protocol: the SAME workload as the GPU step (S1, 128^3, B = 4096 rays, forward + backward of the training
     loss), one thread per physical core, one warm-up step and up to three timed steps in each phase -- early (1000 rays
@@ -225,28 +225,42 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
                      global_rays=global_rays)
     sync()
     t0 = time.perf_counter()
-    rays_done, last, comm = 0, None, []
+    rays_done, last, comm, first = 0, None, [], None
     for i in range(warmup, warmup + steps):
         last = trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
                             global_rays=global_rays)
+        first = first if first is not None else last
         rays_done += last["rays"]
         if last["comm_bytes"]:
             comm.append(last)
     sync()
     dt = time.perf_counter() - t0
     comm_ms = [c["comm_ms"] for c in comm[-50:]] if comm else []
+    last["first_n_samples"] = first["n_samples"]
     return dt, rays_done, last, (sum(comm_ms) / len(comm_ms) if comm_ms else None)
 
 
-def make_batches(n, rays_per_gpu, rank, device, distinct=48):
-    """disjoint random pixels per rank and step, resident in HBM (at most `distinct` different batches, then reused)"""
+def make_batches(nerf, n, rays_per_gpu, rank, device, distinct=48):
+    """Disjoint random pixels per rank and step, resident in HBM (at most `distinct` different batches, then reused).
+    The target colours are the scene's own render of those rays (training-mode forward, other noise): the loss is then the
+    Monte-Carlo noise of the estimator, the parameters stay where they are and the workload (samples per step) is
+    stationary over hundreds of optimizer steps -- random targets would reshape the scene within ~100 steps."""
     import torch
     from nmf_amd import synthetic
-    g = torch.Generator().manual_seed(77 + rank)
+    from nmf_amd.noise import DeviceNoise
     out, focal = [], None
+    gt_noise = DeviceNoise(device, seed=4242 + rank)
+    white = torch.ones(3, device=device)
     for i in range(min(n, distinct)):
         rays, focal = synthetic.camera_rays(rays_per_gpu, seed=10007 * (rank + 1) + i)
-        out.append((rays.to(device), torch.rand(rays_per_gpu, 3, generator=g).to(device)))
+        rays = rays.to(device)
+        gt = torch.ones(rays_per_gpu, 3, device=device)
+        with torch.no_grad():
+            for s in range(0, rays_per_gpu, CHUNK):
+                ims, _ = nerf(rays[s:s + CHUNK], focal, bg_col=white, is_train=True, ndc_ray=False, noise=gt_noise)
+                k = ims["rgb_map"].shape[0]
+                gt[s:s + k] = ims["rgb_map"].clip(0, 1)
+        out.append((rays, gt))
     return out, focal
 
 
@@ -286,9 +300,10 @@ def extras(device, params, focal):
 
     def train_ms(nerf, rays_per_gpu, steps, warmup):
         tr = Trainer(nerf, params)
-        batches, f = make_batches(steps + warmup, rays_per_gpu, 0, device, distinct=12)
+        batches, f = make_batches(nerf, steps + warmup, rays_per_gpu, 0, device, distinct=12)
         dt, rays_done, last, _ = time_train(tr, batches, f, DeviceNoise(device, seed=5), warmup, steps, CHUNK, sync)
-        return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_step=last["n_samples"],
+        return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=last["n_samples"],
+                    samples_per_chunk_first_step=last["first_n_samples"],
                     steps=steps, rays_per_step=rays_per_gpu)
 
     nerf, _ = build(device)
@@ -403,7 +418,7 @@ def main():
 
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
     noise = DeviceNoise(device, seed=1000 + rank)
-    batches, focal = make_batches(args.warmup + args.steps, args.rays_per_gpu, rank, device)
+    batches, focal = make_batches(nerf, args.warmup + args.steps, args.rays_per_gpu, rank, device)
     timer.enabled = False
     for i in range(args.warmup):
         trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
@@ -447,7 +462,7 @@ def main():
                                    f"BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not available "
                                    "offline)",
                        "rays_per_gpu": args.rays_per_gpu, "chunks_per_step": chunks_per_step, "grid": args.grid,
-                       "samples_per_chunk": last["n_samples"],
+                       "samples_per_chunk": last["n_samples"], "samples_per_chunk_first_step": last["first_n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"]},

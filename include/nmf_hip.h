@@ -247,6 +247,10 @@ int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const float* r_ro
                      const float* off_rows, const int32_t* cnt_rows, const float* sobol,
                      const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R, float* L,
                      float* half_local, float* diff_local, float* lpdf, float* mipval, float* rays, void* stream);
+/* GGXSampler.compute_prob (brdf_samplers/ggx.py:228-268, isotropic r2 = r1): pdf of a sampled direction from the
+ * local-frame incoming / outgoing / half vectors [R][3] and the roughness [R]; 0 below the horizon (dir_in.z <= 0). */
+int nmf_ggx_prob(const float* dir_in_local, const float* dir_out_local, const float* half_local, const float* rough,
+                 int64_t R, float* prob, void* stream);
 /* d_nr [R][4] = (dL/dN)^T g | (dL/dr)^T g per ray (dual-number evaluation of the same sampler); reduce per row.
  * g = dL + d_rays[:,3:6] + 5e-3 d_rays[:,0:3]  (adjoints of L [R][3] and of the bounce rays [R][6]; either may be NULL). */
 int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,

@@ -1,13 +1,14 @@
-"""GGX visible-normal importance sampling -- host-side mirror of the reference's brdf_samplers/ggx.py
-(GGXSampler :60-268) and brdf_samplers/base.py (PseudoRandomSampler :3-23).
+"""GGX visible-normal importance sampling -- the reference's operator interface (brdf_samplers/ggx.py GGXSampler :60-268,
+brdf_samplers/base.py PseudoRandomSampler :3-23) on top of the HIP kernels.
 
-Round-1 status: this operator is differentiable wrt the normal and the roughness (second-order effects of
-the reference flow through it), so it is expressed with torch tensor ops ON THE DEVICE and torch autograd
-provides its backward; it works on the compact ray list (row_of_ray) instead of the reference's padded
-[bounce points x m] mask.  A fused HIP forward/backward is the next step for this row."""
-import math
-
+The hot path (models/microfacet.py `Microfacet.shade_compact`) calls nmf_ggx_rays_fwd / _bwd directly on the compact ray
+list; the methods below keep the reference's dense signatures -- `draw(B, m)`, `sample(u1, u2, V, N, r1, r2, ray_mask)`,
+`compute_prob(dir_in, dir_out, halfvec, r1, r2)` -- for callers written against the reference: they convert the padded
+[bounce points x m] mask to the compact list and run the same kernels (differentiable wrt the normal and the roughness)."""
 import torch
+
+from .. import hip
+from ..functional import GgxRays
 
 EPS = torch.finfo(torch.float32).eps
 
@@ -26,8 +27,25 @@ def mat3T_vec(m, v):
     return (m * v.unsqueeze(-1)).sum(-2)
 
 
-def _safe_trig(x, fn):
-    return fn(x % (100 * math.pi))
+def compact_from_mask(ray_mask):
+    """[Mb, m] bool -> (cnt [Mb] i32, row_of_ray [R] i32, j_of_ray [R] i32, row_off [Mb+1] i64): the rays of
+    `torch.where(ray_mask)` in its (row-major) order"""
+    ri, rj = torch.where(ray_mask)
+    cnt = ray_mask.sum(dim=1)
+    row_off = torch.zeros(ray_mask.shape[0] + 1, dtype=torch.int64, device=ray_mask.device)
+    row_off[1:] = torch.cumsum(cnt, 0)
+    return cnt.int().contiguous(), ri.int().contiguous(), rj.int().contiguous(), row_off
+
+
+def world_basis(N):
+    """row_world_basis of ggx.py:83-91 transposed: columns (tangent, bitangent, normal) per row [Mb,3,3]"""
+    Mb = N.shape[0]
+    z_up = torch.tensor([0.0, 0.0, 1.0], device=N.device).expand(Mb, 3)
+    x_up = torch.tensor([-1.0, 0.0, 0.0], device=N.device).expand(Mb, 3)
+    up = torch.where(N[:, 2:3].abs() < 0.999, z_up, x_up)
+    tangent = normalize(torch.linalg.cross(up, N))
+    bitangent = normalize(torch.linalg.cross(N, tangent))
+    return torch.stack([tangent, bitangent, N], dim=1).permute(0, 2, 1)
 
 
 class PseudoRandomSampler(torch.nn.Module):
@@ -36,60 +54,43 @@ class PseudoRandomSampler(torch.nn.Module):
         self.max_samples = max_samples
         self.register_buffer("angs", torch.quasirandom.SobolEngine(dimension=2, scramble=True).draw(max_samples))
 
-    def draw_compact(self, n_rows, row_of_ray, j_of_ray, noise):
-        """(Sobol[j] + 0.25*U[row]) mod 1 for every ray (base.py:11-20)"""
-        offset = noise.uniform((n_rows, 1, 2)).reshape(n_rows, 2) * 0.25
-        return (self.angs[j_of_ray.long()] + offset[row_of_ray.long()]) % 1.0
+    def draw(self, B, num_samples, noise=None):
+        """base.py:11-20: (Sobol[:m] + 0.25 * U[B,1,2]) mod 1 -> [B, m, 2].  (The hot path never materialises this
+        matrix: nmf_ggx_rays_fwd forms the same numbers per ray from the table and the row offsets.)"""
+        if noise is not None:
+            offset = noise.uniform((B, 1, 2)).reshape(B, 1, 2)
+        else:
+            offset = torch.rand(B, 1, 2, device=self.angs.device)
+        angs = self.angs.reshape(1, self.max_samples, 2)[:, :num_samples, :].expand(B, num_samples, 2)
+        return (angs + offset * 0.25) % 1.0
 
     def update(self, *args, **kwargs):
         pass
 
 
 class GGXSampler(PseudoRandomSampler):
-    def sample_compact(self, u1, u2, V, N, r, row_of_ray):
-        """V, N [Mb,3], r [Mb,1], u1/u2/row_of_ray [R] -> L [R,3], basisT [R,3,3], logpdf [R] (ggx.py:61-226)."""
-        Mb = V.shape[0]
-        dev = V.device
-        rows = row_of_ray.long()
-        z_up = torch.tensor([0.0, 0.0, 1.0], device=dev).expand(Mb, 3)
-        x_up = torch.tensor([-1.0, 0.0, 0.0], device=dev).expand(Mb, 3)
-        up = torch.where(N[:, 2:3].abs() < 0.999, z_up, x_up)
-        tangent = normalize(torch.linalg.cross(up, N))
-        bitangent = normalize(torch.linalg.cross(N, tangent))
-        basis = torch.stack([tangent, bitangent, N], dim=1)
-        V_l = mat3_vec(basis, V)
-        rc = r.reshape(-1)
-        Vs = normalize(torch.stack([rc * V_l[..., 0], rc * V_l[..., 1], V_l[..., 2]], dim=-1))
-        T1 = torch.where(Vs[..., 2:3] < 0.999, normalize(torch.linalg.cross(Vs, z_up, dim=-1)), x_up)
-        T2 = normalize(torch.linalg.cross(T1, Vs, dim=-1))
-        z = Vs[..., 2]
-        a = (1 / (1 + z.detach()).clip(min=1e-8)).clip(max=1e4)
-        a_m, r_m, z_m = a[rows], rc[rows], z[rows]
-        T1_m, T2_m, Vs_m = T1[rows], T2[rows], Vs[rows]
-        basisT = basis.permute(0, 2, 1)[rows]
-        rr = torch.sqrt(u1)
-        phi = torch.where(u2 < a_m, u2 / a_m * math.pi, (u2 - a_m) / (1 - a_m) * math.pi + math.pi)
-        P1 = (rr * _safe_trig(phi, torch.cos)).unsqueeze(-1)
-        P2 = (rr * _safe_trig(phi, torch.sin) * torch.where(u2 < a_m, torch.ones_like(z_m), z_m)).unsqueeze(-1)
-        Ns = P1 * T1_m + P2 * T2_m + (1 - P1 * P1 - P2 * P2).clip(min=EPS).sqrt() * Vs_m
-        H_l = normalize(torch.stack([Ns[..., 0] * r_m, Ns[..., 1] * r_m, Ns[..., 2]], dim=-1))
-        H = mat3_vec(basisT, H_l)
-        w_o, eN = V[rows], N[rows]
-        w_i = normalize(2.0 * (w_o * H).sum(dim=-1, keepdim=True) * H - w_o)
-        w_i = w_i * torch.where((w_i * eN).sum(dim=-1, keepdim=True) > 0, 1.0, -1.0)
-        with torch.no_grad():
-            lw_i = mat3T_vec(basisT, w_i)
-            lw_o = mat3T_vec(basisT, w_o)
-            logp = self.compute_prob(lw_i, lw_o, H_l, r_m, r_m).clip(min=EPS).log().reshape(-1)
-        return w_i, basisT, logp
+    def sample(self, u1, u2, dir_out, normal, r1, r2, ray_mask, eps=EPS, **kwargs):
+        """ggx.py:61-226.  u1, u2 [B,m] uniforms, dir_out V [B,3], normal [B,3], r1 [B,1] (r2 is overwritten by r1, :75),
+        ray_mask [B,m] bool -> (L [R,3], row_world_basis [R,3,3], logpdf [R]) for the R rays of torch.where(ray_mask).
+        One launch of nmf_ggx_rays_fwd: the kernel's per-ray Sobol lookup is pointed at the caller's (u1,u2) matrix."""
+        B, m = ray_mask.shape
+        cnt, row_of_ray, rj, row_off = compact_from_mask(ray_mask)
+        R = int(row_of_ray.shape[0])
+        dev = normal.device
+        if R == 0:
+            return normal.new_zeros((0, 3)), normal.new_zeros((0, 3, 3)), normal.new_zeros((0,))
+        table = torch.stack([u1, u2], dim=-1).reshape(B * m, 2).float().contiguous()       # "sobol" table = the given draws
+        j_of_ray = (row_of_ray * m + rj).contiguous()
+        zero_off = torch.zeros(B, 2, device=dev)
+        L, _hl, _dl, lpdf, _mip, _rays = GgxRays.apply(dir_out.float(), normal.float(), r1.float().reshape(B, 1),
+                                                        torch.zeros(B, 3, device=dev), zero_off, cnt, table, row_of_ray,
+                                                        j_of_ray, row_off)
+        basisT = torch.index_select(world_basis(normal.float()), 0, row_of_ray.long())
+        return L, basisT, lpdf
 
+    @torch.no_grad()
     def compute_prob(self, dir_in, dir_out, halfvec, r1, r2, **kwargs):
-        # ggx.py:228-268 (isotropic: r2 = r1)
-        r2 = r1.reshape(-1).clip(min=EPS)
-        r1 = (r1.reshape(-1) + r2).clip(min=EPS) / 2
-        lam = (-1 + (1 + ((dir_in[:, 0] * r1) ** 2 + (dir_in[:, 1] * r2) ** 2)
-                     / (dir_in[:, 2] ** 2).clip(min=1e-6)).clip(min=EPS).sqrt()) / 2
-        invD = math.pi * r1 * r2 * (halfvec[:, 0] ** 2 / r1 ** 2 + halfvec[:, 1] ** 2 / r2 ** 2 + halfvec[:, 2] ** 2) ** 2
-        logD = -((1 + lam) * invD).clip(min=EPS).log() - (4 * dir_out[..., 2]).clip(min=EPS).log()
-        prob = logD.exp().reshape(-1, 1)
-        return torch.where(dir_in[:, 2:3] > 0, prob, torch.zeros_like(prob))
+        """ggx.py:228-268 (isotropic: r2 = r1): pdf of the sampled direction, [R,1]; zero below the horizon.  Local-frame
+        inputs.  Evaluated by the kernel behind nmf_retrace_scores' sibling entry nmf_ggx_prob."""
+        return hip.ggx_prob(dir_in.float().contiguous(), dir_out.float().contiguous(), halfvec.float().contiguous(),
+                            r1.float().reshape(-1).contiguous()).reshape(-1, 1)

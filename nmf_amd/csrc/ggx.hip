@@ -274,6 +274,27 @@ extern "C" int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const 
     return NMF_OK;
 }
 
+// GGXSampler.compute_prob as an operator of its own (the reference exposes it: brdf_samplers/ggx.py:228-268)
+__global__ void __launch_bounds__(256) k_ggx_prob(const float* __restrict__ li, const float* __restrict__ lo,
+                                                  const float* __restrict__ h, const float* __restrict__ r, int64_t R,
+                                                  float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    out[i] = ggx_prob(V3<float>{li[i * 3], li[i * 3 + 1], li[i * 3 + 2]}, V3<float>{lo[i * 3], lo[i * 3 + 1], lo[i * 3 + 2]},
+                      V3<float>{h[i * 3], h[i * 3 + 1], h[i * 3 + 2]}, r[i]);
+}
+
+extern "C" int nmf_ggx_prob(const float* dir_in_local, const float* dir_out_local, const float* half_local,
+                            const float* rough, int64_t R, float* prob, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_ggx_prob: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(dir_in_local && dir_out_local && half_local && rough && prob, NMF_EINVAL, "nmf_ggx_prob: null");
+    hipLaunchKernelGGL(k_ggx_prob, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, dir_in_local,
+                       dir_out_local, half_local, rough, R, prob);
+    NMF_CHECK_LAUNCH("nmf_ggx_prob");
+    return NMF_OK;
+}
+
 extern "C" int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
                                 const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
                                 const float* dL, const float* d_rays, float* d_nr, void* stream) {

@@ -65,7 +65,7 @@ EXPORTS = [
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
-    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments", "nmf_sh_project",
@@ -82,7 +82,9 @@ def _declare_from_header():
     import re
     hdr = os.path.join(os.path.dirname(_HERE), "include", "nmf_hip.h")
     if not os.path.exists(hdr):
-        return
+        # without prototypes ctypes would pass Tensor.data_ptr() integers as 32-bit C ints (truncated device pointers)
+        raise NmfHipError(f"{hdr} is missing: the C-ABI prototypes of libnmf_hip.so are read from it (keep include/ next "
+                          "to the nmf_amd package)")
     text = re.sub(r"/\*.*?\*/", " ", open(hdr).read(), flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     scal = {"int64_t": C.c_int64, "int32_t": C.c_int32, "int": C.c_int32, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32,
@@ -591,6 +593,14 @@ def ggx_rays_fwd(V, N, r, x, off, cnt, sobol, row_of_ray, j_of_ray):
                                  _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32), C.c_int64(R), _p(L), _p(hl),
                                  _p(dl), _p(lpdf), _p(mip), _p(rays), _stream()), "nmf_ggx_rays_fwd")
     return L, hl, dl, lpdf, mip, rays
+
+
+def ggx_prob(dir_in, dir_out, half, rough):
+    R = dir_in.shape[0]
+    out = torch.empty((R,), dtype=torch.float32, device=dir_in.device)
+    _check(_lib.nmf_ggx_prob(_p(dir_in, torch.float32), _p(dir_out, torch.float32), _p(half, torch.float32),
+                             _p(rough, torch.float32), C.c_int64(R), _p(out), _stream()), "nmf_ggx_prob")
+    return out
 
 
 def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):

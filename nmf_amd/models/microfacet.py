@@ -90,12 +90,37 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
                                      self.max_retrace_rays)]
 
     # ---- shading ----------------------------------------------------------------------------------------
-    def forward(self, samples, app_features, viewdirs, normals, weights, render_reflection, bg_module, is_train,
-                recur, noise):
-        """Reference interface (models/microfacet.py:271-673): rgb [M,3] and the debug dict.  The hot path
-        (TensorNeRF.forward) uses shade_compact() directly and never materialises the [M,3] radiance."""
-        sh_ = self.shade_compact(samples, app_features, normals, weights, render_reflection, bg_module, is_train,
-                                 recur, noise)
+    def forward(self, xyzs, xyzs_normed, app_features, viewdirs, normals, weights, app_mask, B, render_reflection,
+                bg_module=None, is_train=False, recur=0, eps=torch.finfo(torch.float32).eps, noise=None):
+        """Reference interface (models/microfacet.py:271-673): xyzs [M,4], app_features [M,C], viewdirs [M,3], normals
+        [M,3] of the kept samples, the dense weights [b,N] and mask app_mask [b,N] they were taken from, and
+        render_reflection(rays [R,6], mipval [R], retrace=bool) -> (radiance [R,3], visibility).  Returns rgb [M,3] and the
+        debug dict {diffuse, tint, roughness, spec, albedo}.  The dense inputs are converted to the compact sample list and
+        run through shade_compact(), i.e. the same HIP kernels as the hot path (TensorNeRF.forward calls shade_compact
+        directly and never forms the [M,3] radiance or the padded ray mask)."""
+        from ..noise import DeviceNoise
+        from ..samplers.alphagrid import Samples
+        dev = xyzs.device
+        b, N = app_mask.shape
+        ri, rj = torch.where(app_mask)
+        M = int(ri.shape[0])
+        offsets = torch.zeros(b + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(app_mask.sum(dim=1), 0)
+        w = (weights[app_mask] if weights.dim() == 2 else weights.reshape(-1)).contiguous()
+        rays = torch.zeros(b, 6, device=dev)                    # shade_compact reads a sample's view direction per RAY
+        rays[ri, 3:6] = viewdirs.detach().float()
+        S = Samples(xyzs.float().contiguous(), ri.int().contiguous(), rj.int().contiguous(), None, None, offsets, None, M, b, N,
+                    rays=rays)
+        if noise is None:
+            noise = self.__dict__.get("_own_noise")
+            if noise is None:
+                noise = self.__dict__["_own_noise"] = DeviceNoise(dev, seed=20211200)
+
+        def rr(brays, mipval, retrace):
+            out = render_reflection(brays, mipval, retrace=retrace)
+            return out[0] if isinstance(out, tuple) else out
+
+        sh_ = self.shade_compact(S, app_features.float().contiguous(), normals, w, rr, bg_module, is_train, recur, noise)
         return sh_.rgb(), sh_.debug()
 
     def shade_compact(self, samples, app_features, normals, weights, render_reflection, bg_module, is_train, recur,

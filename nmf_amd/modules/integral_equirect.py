@@ -115,6 +115,37 @@ class IntegralEquirect(FastPrivateAttrs, torch.nn.Module):
     def mean_color(self):
         return self.activation_fn(self.bg_mat).reshape(-1, 3).mean(dim=0)
 
+    def save(self, path, prefix="", tonemap=None):
+        """modules/integral_equirect.py:363-371: the activated map as `<prefix>pano.exr` (float RGB, equirectangular)"""
+        import os
+        from .. import exr
+        im = self.activation_fn(self.bg_mat.detach())
+        if tonemap is not None:
+            im = tonemap(im)
+        exr.imwrite(os.path.join(str(path), f"{prefix}pano.exr"), im.permute(0, 2, 3, 1).squeeze(0).cpu().numpy())
+
+    @torch.no_grad()
+    def calc_envmap_psnr(self, gt_im, fH=500):
+        """modules/integral_equirect.py:289-322: PSNR of the learned map against a ground-truth panorama [H,W,3] (numpy)
+        after flipping / rolling it into this module's parameterisation, resampling both to fH x 2fH (nearest) and fitting
+        an affine colour transform pred -> gt by least squares (the reference uses sklearn's LinearRegression: 3x3 matrix +
+        intercept), squared error clipped to [0,1]."""
+        import numpy as np
+        import torch.nn.functional as F
+        fW = 2 * fH
+        gW = gt_im.shape[1]
+        gt_im = gt_im[:, ::-1]
+        gt_im = np.concatenate([gt_im[:, gW // 2:], gt_im[:, : gW // 2]], axis=1)
+        gt = torch.as_tensor(np.ascontiguousarray(gt_im), dtype=torch.float32)
+        gt = F.interpolate(gt.permute(2, 0, 1).unsqueeze(0), (fH, fW)).squeeze(0).permute(1, 2, 0)
+        pred = self.activation_fn(self.bg_mat[0]).permute(1, 2, 0).detach().float().cpu()
+        pred = F.interpolate(pred.permute(2, 0, 1).unsqueeze(0), (fH, fW)).squeeze(0).permute(1, 2, 0)
+        Y = gt.reshape(-1, 3).double()
+        X = torch.cat([pred.reshape(-1, 3).double(), torch.ones(fH * fW, 1, dtype=torch.float64)], dim=1)
+        coef = torch.linalg.lstsq(X, Y).solution
+        err = ((X @ coef - Y) ** 2).clip(min=0, max=1)
+        return float(-10.0 * torch.log10(err.mean()))
+
     def forward(self, viewdirs, saSample, max_level=None):
         """viewdirs [R,3]; the build's callers may also hand over [R,6] ray rows (origin | direction): they are looked up
         along columns 3..5 in place, and the gradient comes back with the rays' own shape (no slice / pad kernels)."""
