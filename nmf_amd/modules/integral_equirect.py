@@ -119,9 +119,10 @@ class IntegralEquirect(FastPrivateAttrs, torch.nn.Module):
         """modules/integral_equirect.py:363-371: the activated map as `<prefix>pano.exr` (float RGB, equirectangular)"""
         import os
         from .. import exr
-        im = self.activation_fn(self.bg_mat.detach())
-        if tonemap is not None:
-            im = tonemap(im)
+        with torch.no_grad():
+            im = self.activation_fn(self.bg_mat.detach())
+            if tonemap is not None:
+                im = tonemap(im)
         exr.imwrite(os.path.join(str(path), f"{prefix}pano.exr"), im.permute(0, 2, 3, 1).squeeze(0).cpu().numpy())
 
     @torch.no_grad()

@@ -57,10 +57,14 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         """modules/tensor_nerf.py:136-175: rebuild the scene module from a checkpoint written by save() -- {"config":
         arch config (the `model.arch` node, `_target_` strings of the reference), "state_dict": ...} -- with the grid size
         and AABB stored in the state_dict, the calibrated biases taken from the checkpoint's config, then load the weights.
-        Checkpoints written by the reference itself pickle an OmegaConf object and need `omegaconf` to be importable."""
+        Checkpoints written by the reference itself (config = an OmegaConf DictConfig) are read by
+        nmf_amd.checkpoint.load_checkpoint without omegaconf and without executing pickled code."""
+        from ..checkpoint import load_checkpoint, to_plain
         from ..yaml_config import instantiate
         if not isinstance(ckpt, dict):
-            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+            ckpt = load_checkpoint(ckpt)
+        else:
+            ckpt = dict(ckpt, config=to_plain(ckpt["config"]))
         saved = ckpt["config"]
         if config is not None:
             config = dict(config)

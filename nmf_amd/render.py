@@ -24,7 +24,8 @@ from .renderer import psnr_8bit, render_images
 
 def load_fixed_bg(path, device):
     """train.py:96-138: an IntegralEquirect with mipbias 0 / activation exp, its learning rates zeroed"""
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    from .checkpoint import load_checkpoint
+    sd = load_checkpoint(path)
     sd = sd.get("state_dict", sd) if isinstance(sd, dict) and "bg_mat" not in sd else sd
     res = int(sd["bg_mat"].shape[-2])
     bg = IntegralEquirect(bg_resolution=res, mipbias=0, activation="exp", lr=0.0, init_val=-1.897, mul_lr=0.0,

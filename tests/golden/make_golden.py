@@ -316,12 +316,21 @@ class BookkeepingTap:
     models/microfacet.py:506-509).  Outputs of reference functions, no reference code."""
 
     def __init__(self):
-        self.counts, self.orders = [], []
+        self.counts, self.orders, self.valid = [], [], []
 
     def __enter__(self):
         import models.microfacet as mm
+        from samplers.alphagrid import AlphaGridSampler
         self._mm, self._sel, self._argsort = mm, mm.select_bounces, torch.Tensor.argsort
+        self._smp_cls, self._smp = AlphaGridSampler, AlphaGridSampler.sample
         tap = self
+
+        def sample(smp, *a, **k):
+            out = tap._smp(smp, *a, **k)
+            tap.valid.append(out[1].clone())                # ray_valid [b, N] of this recursion level
+            return out
+
+        AlphaGridSampler.sample = sample
 
         def sel(weights, app_mask, *a, **k):
             bm, rm = tap._sel(weights, app_mask, *a, **k)
@@ -343,6 +352,7 @@ class BookkeepingTap:
     def __exit__(self, *exc):
         self._mm.select_bounces = self._sel
         torch.Tensor.argsort = self._argsort
+        self._smp_cls.sample = self._smp
         return False
 
 
@@ -383,6 +393,12 @@ def _full_size_case(name, max_retrace, G=128, BG=512, B=4096, ray_seed=0, noise_
     for lvl, c in enumerate(tap.counts):
         assert int(c.max()) < 32768
         out[f"counts{lvl}"] = c.to(torch.int16)
+    # which candidate steps of the SECONDARY rays survive the occupancy test (samplers/alphagrid.py:341-346): their
+    # origins / directions come out of a float chain (normals -> GGX), so an implementation that differs in the last bit of a
+    # direction flips a sample that sits on a voxel boundary -- recorded so that a replay can pin them
+    assert len(tap.valid) == 2
+    out["valid1"] = np.packbits(tap.valid[1].numpy().reshape(-1))
+    out["valid1_shape"] = np.asarray(tap.valid[1].shape)
     assert len(tap.orders) == 1
     order = tap.orders[0]
     R = order.shape[0]

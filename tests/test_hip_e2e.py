@@ -196,30 +196,36 @@ def _check_loss_and_gradients(nerf, g, ims, st, full_tol=5e-3, loss_tol=1e-4):
     assert_close(total.detach().cpu(), g["total"], rtol=loss_tol, what="total")
     total.backward()
     params = dict(nerf.named_parameters())
+    bad, rows = [], []
     for k in g.keys("gradnorm/"):
         name = k[len("gradnorm/"):]
         ref, got = float(g[k]), float(params[name].grad.norm())
         tol = max(2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3, full_tol)
-        assert abs(got - ref) <= tol * ref + 1e-12, (name, got, ref)
+        rows.append(f"  |grad| {name:48s} {got:.6e} vs {ref:.6e}  ({got / max(ref, 1e-30) - 1:+.2e})")
+        if abs(got - ref) > tol * ref + 1e-12:
+            bad.append(rows[-1])
     checked = 0
     for k in g.keys("grad/") + g.keys("grad_slice4/"):
         name = k.split("/", 1)[1]
         gr = params[name].grad
-        got = gr if k.startswith("grad/") else gr[0, :, ::4, ::4]
+        got = (gr if k.startswith("grad/") else gr[0, :, ::4, ::4]).detach().cpu()
         ref = torch.as_tensor(g[k]).reshape(got.shape)
         scale = float(ref.abs().max())
         tol = max(2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3, full_tol)
-        got = got.detach().cpu()
         # the whole tensor: relative L2 error (catches sign / layout / scale errors of any element group) ...
         rel = float((got.double() - ref.double()).norm() / ref.double().norm().clip(min=1e-30))
-        assert rel <= tol, (k, rel)
         # ... and no single element further off than a few per cent of the largest entry
-        assert_close(got, ref, rtol=4 * tol, atol=4 * tol * scale + 1e-12, what=k)
+        worst = float((got.double() - ref.double()).abs().max()) / max(scale, 1e-30)
+        rows.append(f"  full   {k:48s} rel L2 {rel:.2e}, worst element {worst:.2e} of max")
+        if rel > tol or worst > 8 * tol:
+            bad.append(rows[-1])
         checked += 1
+    print("\n".join(rows))
+    assert not bad, "\n" + "\n".join(bad)
     assert checked >= 25, checked
 
 
-def _pin_reference_bookkeeping(nerf, g, order=True):
+def _pin_reference_bookkeeping(nerf, g, order=True, valid=True):
     """The reference's own bookkeeping decisions (recorded while it ran, tests/golden/make_golden.py BookkeepingTap):
     per-sample secondary-ray counts floor(w*128 + U - 0.5) -- w differs from the CPU in the last bits (expf), so a handful
     of the 170 k floors flip, which shifts every later ray index and with it every later noise row of a replay BY SEED --
@@ -230,6 +236,11 @@ def _pin_reference_bookkeeping(nerf, g, order=True):
         forced["retrace_order0"] = g["retrace_order0"].long()
     nerf.model.forced = forced
     nerf.model.trace = {}
+    if valid and "valid1" in g:
+        # occupancy decisions of the secondary rays' candidate steps: a ray direction that differs from the CPU's in its last
+        # bit flips a step that sits on a voxel boundary (a couple of the ~10^8 candidates); pinned like the counts, and the
+        # marcher's own decisions are compared with them (sampler.valid_flips)
+        nerf.sampler.forced_valid = {1: g.bits("valid1", tuple(int(v) for v in g.np("valid1_shape")))}
 
 
 def test_e2e_full_size_seeded_vs_reference():
@@ -240,7 +251,7 @@ def test_e2e_full_size_seeded_vs_reference():
     full parameter gradients."""
     g = Golden("e2e_full_seeded")
     nerf = _full_size_model(g)
-    _pin_reference_bookkeeping(nerf, g, order=False)
+    _pin_reference_bookkeeping(nerf, g, order=False, valid=False)
     ims, st = _seeded_render(nerf, g)
     ns, ns_ref = list(st["n_samples"]), [int(v) for v in g.np("n_samples")]
     assert ns[0] == ns_ref[0] and torch.equal(st["whole_valid"].cpu(), g["whole_valid"])
@@ -295,14 +306,22 @@ def test_e2e_steady_state_vs_reference(name):
     ims, st = _seeded_render(nerf, g)
     assert list(st["n_samples"]) == list(g.np("n_samples"))
     assert torch.equal(st["whole_valid"].cpu(), g["whole_valid"])
+    n_cand = int(np.prod(g.np("valid1_shape")))
+    print(f"{name}: marcher's own occupancy decisions differ from the reference's on {nerf.sampler.valid_flips} 64-step words "
+          f"of {n_cand} candidate steps")
+    assert nerf.sampler.valid_flips <= max(4, n_cand // 10_000_000), nerf.sampler.valid_flips
     for lvl in (0, 1):
         own, pinned = nerf.model.trace[f"counts_own{lvl}"].cpu(), nerf.model.forced[f"counts{lvl}"]
         flips = int((own != pinned).sum())
         assert flips <= max(8, own.shape[0] // 20000) and int((own - pinned).abs().max()) <= 1, (lvl, flips)
     assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     frac, worst = _frac_close(ims["rgb_map"].detach().cpu(), g["rgb_map"], 1e-4, 1e-4)
+    print(f"{name}: rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
     assert frac >= 0.999, (frac, worst)
-    _check_loss_and_gradients(nerf, g, ims, st)
+    # The reference's own gradients move by 1-2 % (density factors) when ONE input is perturbed in its last bit at the 192-ray
+    # batch of the 300^3 fixture (measured: scratch of tests/golden, roughness bias * (1 + 3e-7)); at 4096 rays the
+    # ill-conditioned GGX samples average out
+    _check_loss_and_gradients(nerf, g, ims, st, full_tol=3e-2 if "g300" in name else 5e-3)
 
 
 def test_retrace_order_steady_state_own_vs_reference():
@@ -313,7 +332,7 @@ def test_retrace_order_steady_state_own_vs_reference():
     swaps allow (a swapped ray meets another jitter row)."""
     g = Golden("e2e_full_steady")
     nerf = _full_size_model(g)
-    _pin_reference_bookkeeping(nerf, g, order=False)
+    _pin_reference_bookkeeping(nerf, g, order=False, valid=False)
     nerf.model.exact_retrace_order = True
     with torch.no_grad():
         ims, st = _seeded_render(nerf, g)

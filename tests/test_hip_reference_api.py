@@ -151,7 +151,7 @@ def test_microfacet_forward_reference_signature():
     rgb_map = O.srgb_tonemap(rgb_map, noclip=False) + (1 - acc[:, None]) * torch.ones(1, 3)
     assert_close(rgb_map, g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map through Microfacet.forward")
     for k in ("roughness", "albedo", "tint"):
-        img = O.row_mask_sum(w * debug[k].cpu(), ray_valid) + (1 - acc[:, None])
+        img = O.row_mask_sum(w * debug[k].cpu(), ray_valid) + (1 - acc[:, None]) * torch.ones(1, 3)
         assert_close(img, g["debug/" + k], rtol=1e-4, atol=1e-5, what=k)
 
 
@@ -165,7 +165,8 @@ def test_integral_equirect_save_and_envmap_psnr(tmp_path):
         env.bg_mat.copy_((-0.6 + 0.5 * torch.randn(1, 3, 16, 32, generator=gen)).to(DEV))
     env.save(tmp_path, prefix="t_")                                      # modules/integral_equirect.py:363-371
     im = exr.imread(str(tmp_path / "t_pano.exr"))
-    want = env.activation_fn(env.bg_mat.detach())[0].permute(1, 2, 0).cpu().numpy()
+    with torch.no_grad():
+        want = env.activation_fn(env.bg_mat.detach())[0].permute(1, 2, 0).cpu().numpy()
     assert im.shape == (16, 32, 3) and np.array_equal(im, want)
     # calc_envmap_psnr: a ground truth that is an affine colour transform of the map (in the file's own parameterisation:
     # flipped and rolled by half a turn) is matched exactly by the regression -> very high PSNR; noise lowers it
@@ -174,3 +175,28 @@ def test_integral_equirect_save_and_envmap_psnr(tmp_path):
     hi = env.calc_envmap_psnr(gt_aff, fH=16)
     lo = env.calc_envmap_psnr(gt_aff + 0.3 * np.random.default_rng(0).standard_normal(gt.shape).astype(np.float32), fH=16)
     assert hi > 60 and 5 < lo < 25, (hi, lo)
+
+
+def test_pano2env_fits_an_exr_panorama(tmp_path):
+    """scripts/pano2cube.py counterpart: EXR panorama -> IntegralEquirect state_dict usable as fixed_bg."""
+    from nmf_amd import exr, pano2env
+    from nmf_amd.render import load_fixed_bg
+    H, W = 32, 64
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    pano = np.stack([0.6 + 0.4 * np.sin(xx / W * 2 * np.pi), 0.5 + 0.3 * np.cos(yy / H * np.pi), 0.3 + 0.2 * np.sin(xx / W * 4 * np.pi)],
+                    -1).astype(np.float32)
+    src = str(tmp_path / "pano.exr")
+    exr.imwrite(src, pano, "ZIP")
+    out = str(tmp_path / "env" / "pano.th")
+    rec = pano2env.main([src, "--output", out, "--res", "32", "--epochs", "300", "--batch", "2048"])
+    assert rec["resolution"] == 32 and rec["panorama"] == [H, W, 3]
+    bg = load_fixed_bg(out, DEV)
+    assert bg.bg_mat.shape == (1, 3, 32, 64)
+    rows, cols = torch.meshgrid(torch.arange(2, H - 2, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    dirs = pano2env.pixel_directions(rows.reshape(-1), cols.reshape(-1), H, W).to(DEV)
+    with torch.no_grad():
+        got = bg(dirs, torch.full((dirs.shape[0],), float(np.log(1e-5)), device=DEV)).cpu().reshape(H - 4, W, 3)
+    err = (got - torch.from_numpy(pano[2:H - 2])).abs().mean()
+    assert float(err) < 0.05, float(err)
+    fitted = exr.imread(str(tmp_path / "env" / "pano_pano.exr"))
+    assert fitted.shape == (32, 64, 3) and np.isfinite(fitted).all()
