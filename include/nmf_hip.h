@@ -256,6 +256,12 @@ int nmf_ggx_prob(const float* dir_in_local, const float* dir_out_local, const fl
 int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
                      const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
                      const float* dL, const float* d_rays, float* d_nr, void* stream);
+/* Same with the view direction as a third differentiable input: d_nrv [R][7] = (dN | dr | dV).  The rays of recursion
+ * level >= 1 look along the direction the level above sampled (viewdirs = rays[:, 3:6], modules/tensor_nerf.py:262, is part
+ * of the graph: bV = -viewdirs, models/microfacet.py:354), so their radiance back-propagates into that direction. */
+int nmf_ggx_rays_bwd_view(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
+                          const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
+                          const float* dL, const float* d_rays, float* d_nrv, void* stream);
 /* Fresnel-Schlick mix (models/microfacet.py:595-613): contrib [R][3] = (F Li brdf + (1-F) diffuse) / cnt with
  * F = f0 + (1-f0)(1-|V.H|)^5, H = normalize((V+L)/2); sum contrib per row for reflect_rgb. */
 int nmf_shade_mix_fwd(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
@@ -267,6 +273,11 @@ int nmf_shade_mix_bwd(const float* V_rows, const float* f0_rows, const float* di
                       const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
                       const float* incoming, const float* brdf, const float* d_rows, float* d_incoming,
                       float* d_brdf, float* dL, float* d_f0diff, void* stream);
+/* Same, plus dV [R][3] (nullable): the adjoint of the view direction per ray (F depends on V.H, H = normalize((V+L)/2)). */
+int nmf_shade_mix_bwd_view(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
+                           const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
+                           const float* incoming, const float* brdf, const float* d_rows, float* d_incoming,
+                           float* d_brdf, float* dL, float* d_f0diff, float* dV, void* stream);
 /* RandHydraMLPDiffuse heads (modules/render_modules.py:519-574; pospe=-1, feape=0, one Linear each, std=0):
  * out [M][11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied; W [11][24] / b [11] are
  * the four Linear layers stacked in that order. */

@@ -49,11 +49,11 @@ struct GgxOut {
     V3<T> Hl;                   // sampled half vector in the local frame
 };
 
-// GGXSampler.sample for ONE ray (ggx.py:61-226); V fixed, N and r carry tangents when T is a dual number
+// GGXSampler.sample for ONE ray (ggx.py:61-226); V, N and r carry tangents when T is a dual number (V only for the
+// rays of recursion level >= 1, whose view direction is the sampled direction of the level above)
 template <class T>
-__device__ __forceinline__ GgxOut<T> ggx_sample(const V3<float>& Vf, const V3<T>& N, const T& r, float u1, float u2) {
+__device__ __forceinline__ GgxOut<T> ggx_sample(const V3<T>& V, const V3<T>& N, const T& r, float u1, float u2) {
     GgxOut<T> o;
-    const V3<T> V = lift(Vf, r);
     const V3<float> z_up = {0.f, 0.f, 1.f}, x_up = {-1.f, 0.f, 0.f};
     const V3<T> up = lift(fabsf(val(N.z)) < 0.999f ? z_up : x_up, r);
     o.tangent = nrm(cross(up, N));
@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(256) k_ggx_rays_fwd(RowIn in, const float* __r
     q[3] = L.x; q[4] = L.y; q[5] = L.z;
 }
 
-// adjoint: dL [R][3] -> per-ray (dN, dr) [R][4]; the caller reduces them per row with nmf_segment_sum
+// adjoint: dL [R][3] -> per-ray (dN, dr) [R][4] (NT = 4) or (dN, dr, dV) [R][7] (NT = 7); the caller reduces them per row
+// with nmf_segment_sum
+template <int NT>
 __global__ void __launch_bounds__(256) k_ggx_rays_bwd(RowIn in, const float* __restrict__ sobol,
                                                       const int32_t* __restrict__ row_of_ray,
                                                       const int32_t* __restrict__ j_of_ray, int64_t R,
@@ -157,11 +159,13 @@ __global__ void __launch_bounds__(256) k_ggx_rays_bwd(RowIn in, const float* __r
     V3<float> V, Nf;
     float rf, u1, u2;
     load_ray(in, sobol, row, j_of_ray[i], V, Nf, rf, u1, u2);
-    typedef Dual<4> D;
-    V3<D> N = {mk_const<4>(Nf.x), mk_const<4>(Nf.y), mk_const<4>(Nf.z)};
-    D r = mk_const<4>(rf);
+    typedef Dual<NT> D;
+    V3<D> N = {mk_const<NT>(Nf.x), mk_const<NT>(Nf.y), mk_const<NT>(Nf.z)};
+    V3<D> Vd = {mk_const<NT>(V.x), mk_const<NT>(V.y), mk_const<NT>(V.z)};
+    D r = mk_const<NT>(rf);
     N.x.d[0] = 1.f; N.y.d[1] = 1.f; N.z.d[2] = 1.f; r.d[3] = 1.f;
-    const GgxOut<D> o = ggx_sample<D>(V, N, r, u1, u2);
+    if (NT == 7) { Vd.x.d[NT - 3] = 1.f; Vd.y.d[NT - 2] = 1.f; Vd.z.d[NT - 1] = 1.f; }
+    const GgxOut<D> o = ggx_sample<D>(Vd, N, r, u1, u2);
     // adjoint of L itself plus of the bounce ray (origin x + 5e-3 L | direction L), either may be absent
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (dL) { g0 = dL[i * 3]; g1 = dL[i * 3 + 1]; g2 = dL[i * 3 + 2]; }
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) k_ggx_rays_bwd(RowIn in, const float* __r
         g0 += q[3] + 5e-3f * q[0]; g1 += q[4] + 5e-3f * q[1]; g2 += q[5] + 5e-3f * q[2];
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) d_nr[i * 4 + t] = g0 * o.L.x.d[t] + g1 * o.L.y.d[t] + g2 * o.L.z.d[t];
+    for (int t = 0; t < NT; ++t) d_nr[i * NT + t] = g0 * o.L.x.d[t] + g1 * o.L.y.d[t] + g2 * o.L.z.d[t];
 }
 
 // ---- Fresnel mix ------------------------------------------------------------------------------------
@@ -208,7 +212,8 @@ __global__ void __launch_bounds__(256) k_shade_mix_bwd(const float* __restrict__
                                                        const float* __restrict__ brdf,
                                                        const float* __restrict__ d_rows /*[Mb][3]*/,
                                                        float* __restrict__ d_inc, float* __restrict__ d_brdf,
-                                                       float* __restrict__ dL, float* __restrict__ d_f0diff) {
+                                                       float* __restrict__ dL, float* __restrict__ d_f0diff,
+                                                       float* __restrict__ dV /*[R][3] or null*/) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const int32_t row = row_of_ray[i];
@@ -244,9 +249,11 @@ __global__ void __launch_bounds__(256) k_shade_mix_bwd(const float* __restrict__
     const float hd = dH.x * H.x + dH.y * H.y + dH.z * H.z;
     const float s = n2 > EPS_F ? 1.f : 0.f;     // clip: below eps H = h / sqrt(eps), no projection term
     const float k2 = 0.5f * inv;
-    dL[i * 3] = k2 * (dH.x - s * hd * H.x);
-    dL[i * 3 + 1] = k2 * (dH.y - s * hd * H.y);
-    dL[i * 3 + 2] = k2 * (dH.z - s * hd * H.z);
+    const V3<float> gl = {k2 * (dH.x - s * hd * H.x), k2 * (dH.y - s * hd * H.y), k2 * (dH.z - s * hd * H.z)};
+    dL[i * 3] = gl.x; dL[i * 3 + 1] = gl.y; dL[i * 3 + 2] = gl.z;
+    if (dV) {      // V enters d = -V.H directly and through h = (V+L)/2 like L does
+        dV[i * 3] = gl.x - dd * H.x; dV[i * 3 + 1] = gl.y - dd * H.y; dV[i * 3 + 2] = gl.z - dd * H.z;
+    }
 }
 
 }  // namespace
@@ -302,10 +309,24 @@ extern "C" int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const 
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && d_nr, NMF_EINVAL,
                 "nmf_ggx_rays_bwd: null");
-    hipLaunchKernelGGL(k_ggx_rays_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_ggx_rays_bwd<4>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
                        mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL, d_rays,
                        d_nr);
     NMF_CHECK_LAUNCH("nmf_ggx_rays_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_ggx_rays_bwd_view(const float* V_rows, const float* N_rows, const float* r_rows, const float* off_rows,
+                                     const float* sobol, const int32_t* row_of_ray, const int32_t* j_of_ray, int64_t R,
+                                     const float* dL, const float* d_rays, float* d_nrv, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_ggx_rays_bwd_view: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && d_nrv, NMF_EINVAL,
+                "nmf_ggx_rays_bwd_view: null");
+    hipLaunchKernelGGL(k_ggx_rays_bwd<7>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+                       mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL, d_rays,
+                       d_nrv);
+    NMF_CHECK_LAUNCH("nmf_ggx_rays_bwd_view");
     return NMF_OK;
 }
 
@@ -326,13 +347,21 @@ extern "C" int nmf_shade_mix_bwd(const float* V_rows, const float* f0_rows, cons
                                  const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
                                  const float* incoming, const float* brdf, const float* d_rows, float* d_incoming,
                                  float* d_brdf, float* dL, float* d_f0diff, void* stream) {
+    return nmf_shade_mix_bwd_view(V_rows, f0_rows, diffuse_rows, cnt_rows, row_of_ray, R, L, incoming, brdf, d_rows,
+                                  d_incoming, d_brdf, dL, d_f0diff, nullptr, stream);
+}
+
+extern "C" int nmf_shade_mix_bwd_view(const float* V_rows, const float* f0_rows, const float* diffuse_rows,
+                                      const int32_t* cnt_rows, const int32_t* row_of_ray, int64_t R, const float* L,
+                                      const float* incoming, const float* brdf, const float* d_rows, float* d_incoming,
+                                      float* d_brdf, float* dL, float* d_f0diff, float* dV, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_shade_mix_bwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(V_rows && f0_rows && diffuse_rows && cnt_rows && row_of_ray && L && incoming && brdf && d_rows &&
                     d_incoming && d_brdf && dL && d_f0diff,
                 NMF_EINVAL, "nmf_shade_mix_bwd: null");
     hipLaunchKernelGGL(k_shade_mix_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, V_rows, f0_rows,
-                       diffuse_rows, cnt_rows, row_of_ray, R, L, incoming, brdf, d_rows, d_incoming, d_brdf, dL, d_f0diff);
+                       diffuse_rows, cnt_rows, row_of_ray, R, L, incoming, brdf, d_rows, d_incoming, d_brdf, dL, d_f0diff, dV);
     NMF_CHECK_LAUNCH("nmf_shade_mix_bwd");
     return NMF_OK;
 }

@@ -599,9 +599,16 @@ class ShadeCompose(torch.autograd.Function):
             d_bg = (1 - acc)[:, None] * d_rgb
             if not bg_per_ray:
                 d_bg = d_bg.sum(0).reshape(bg.shape)
-        d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_refl)
+        dV_rows = None
+        if ctx.needs_input_grad[12]:
+            # recursion level >= 1: the view direction of these rows is the direction the level above sampled
+            # (bV = -viewdirs, models/microfacet.py:354) and the Fresnel term depends on it
+            d_inc, d_brdf, dL, d_fd, dV = hip.shade_mix_bwd_view(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_refl)
+            dV_rows = hip.segment_sum(dV, None, row_off, V.shape[0], lanes=8)
+        else:
+            d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_refl)
         rows = hip.segment_sum_wide(d_fd, 6, row_off, V.shape[0])
-        return (d_weight, d_normals, d_bg) + (None,) * 9 + (None, rows[:, 0:3], rows[:, 3:6], None, None, None, dL, d_inc,
+        return (d_weight, d_normals, d_bg) + (None,) * 9 + (dV_rows, rows[:, 0:3], rows[:, 3:6], None, None, None, dL, d_inc,
                                                                d_brdf)
 
 
@@ -614,8 +621,12 @@ class BounceRays(torch.autograd.Function):
     Returns L, half_local, diff_local, lpdf, mipval, bounce_rays, brdf_weight, V_rows, f0_rows, diffuse_rows, N_rows."""
 
     @staticmethod
-    def forward(ctx, normals, c, tok_field, tok_heads, tok_mlp):
+    def forward(ctx, normals, c, tok_field, tok_heads, tok_mlp, rays=None):
+        """rays: the [b,6] ray rows when they are part of the graph (recursion level >= 1: origin | direction sampled by the
+        level above).  The rows' view vector V = -direction then carries a gradient (models/microfacet.py:354 does not
+        detach it): through the GGX sample L(V, N, r) here and through the Fresnel term in ShadeCompose."""
         normals = normals.contiguous()
+        ctx.view_grad = rays is not None and rays.requires_grad
         p, dpk, dlk, apl, ali, basis = c.field._tables()
         app = hip.vm_query_fwd(p, c.xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False,
                                want_app=True)[4]
@@ -627,12 +638,15 @@ class BounceRays(torch.autograd.Function):
         ctx.c = c
         ctx.save_for_backward(normals, app, heads, V, N, r1, feat, hl, dl)
         N_out = N.detach().clone()
-        ctx.mark_non_differentiable(hl, dl, lpdf, mip, V, N_out)
+        if ctx.view_grad:
+            ctx.mark_non_differentiable(hl, dl, lpdf, mip, N_out)
+        else:
+            ctx.mark_non_differentiable(hl, dl, lpdf, mip, V, N_out)
         ctx.set_materialize_grads(False)
         return L, hl, dl, lpdf, mip, brays, brdf, V, f0, diff, N_out
 
     @staticmethod
-    def backward(ctx, dL, _hl, _dl, _lp, _mip, d_brays, d_brdf, _dV, d_f0, d_diff, _dN):
+    def backward(ctx, dL, _hl, _dl, _lp, _mip, d_brays, d_brdf, dV_in, d_f0, d_diff, _dN):
         c = ctx.c
         normals, app, heads, V, N, r1, feat, hl, dl = ctx.saved_tensors
         Mb = V.shape[0]
@@ -642,11 +656,24 @@ class BounceRays(torch.autograd.Function):
             grads = grad_views(c.mlp_holder, c.mlp_ws) if c.mlp_holder is not None else [torch.zeros_like(w) for w in c.mlp_ws]
             d_xfeat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias, d_brdf, grads)
             d_feat = hip.segment_sum_wide(d_xfeat, 24, c.row_off, Mb)
-        dN = dr1 = None
+        dN = dr1 = dV_rows = None
         if dL is not None or d_brays is not None:
-            d_nr = hip.ggx_rays_bwd(V, N, r1, c.off, c.sobol, c.row_of_ray, c.j_of_ray, cc(dL), cc(d_brays))
-            rows4 = hip.segment_sum(d_nr, None, c.row_off, Mb, lanes=8)
-            dN, dr1 = rows4[:, 0:3], rows4[:, 3]
+            if ctx.view_grad:
+                d_nrv = hip.ggx_rays_bwd_view(V, N, r1, c.off, c.sobol, c.row_of_ray, c.j_of_ray, cc(dL), cc(d_brays))
+                rows7 = hip.segment_sum_wide(d_nrv, 7, c.row_off, Mb)
+                dN, dr1, dV_rows = rows7[:, 0:3], rows7[:, 3], rows7[:, 4:7]
+            else:
+                d_nr = hip.ggx_rays_bwd(V, N, r1, c.off, c.sobol, c.row_of_ray, c.j_of_ray, cc(dL), cc(d_brays))
+                rows4 = hip.segment_sum(d_nr, None, c.row_off, Mb, lanes=8)
+                dN, dr1 = rows4[:, 0:3], rows4[:, 3]
+        d_rays = None
+        if ctx.view_grad:
+            if dV_in is not None:
+                dV_rows = dV_in if dV_rows is None else dV_rows + dV_in
+            if dV_rows is not None:           # V_row = -direction of the row's ray: scatter the rows back onto their rays
+                ray_of_row = torch.index_select(c.ray_id, 0, c.bidx.long()).long()
+                d_rays = torch.zeros_like(c.rays)
+                d_rays[:, 3:6].index_add_(0, ray_of_row, -dV_rows)
         d_normals, d_heads, d_app = hip.bounce_prep_bwd(c.inv, normals, heads, c.ray_id, c.rays, c.conv, c.min_rough,
                                                         c.detach_n, dN, dr1, d_f0, d_diff, d_feat, bidx=c.bidx,
                                                         row_inputs=True)
@@ -661,7 +688,7 @@ class BounceRays(torch.autograd.Function):
             tf = c.field_holder.token_grad(d_app)
         th = c.head_holder.token_grad(d_app) if c.head_holder is not None else None
         tm = c.mlp_holder.token_grad(d_app) if (c.mlp_holder is not None and d_brdf is not None) else None
-        return (None if c.detach_n else d_normals), None, tf, th, tm
+        return (None if c.detach_n else d_normals), None, tf, th, tm, d_rays
 
 
 def brdf_mlp(half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets, out_bias, weights, owner=None):

@@ -65,7 +65,7 @@ EXPORTS = [
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
-    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments", "nmf_sh_project",
@@ -610,6 +610,29 @@ def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
                                  _p(sobol, torch.float32), _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32),
                                  C.c_int64(R), _p(dL), _p(d_rays), _p(d_nr), _stream()), "nmf_ggx_rays_bwd")
     return d_nr
+
+
+def ggx_rays_bwd_view(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
+    """-> d_nrv [R,7] = per-ray adjoints of (normal | roughness | view direction)"""
+    R = row_of_ray.shape[0]
+    d = torch.empty((R, 7), dtype=torch.float32, device=V.device)
+    _check(_lib.nmf_ggx_rays_bwd_view(_p(V, torch.float32), _p(N, torch.float32), _p(r, torch.float32), _p(off, torch.float32),
+                                      _p(sobol, torch.float32), _p(row_of_ray, torch.int32), _p(j_of_ray, torch.int32),
+                                      C.c_int64(R), _p(dL), _p(d_rays), _p(d), _stream()), "nmf_ggx_rays_bwd_view")
+    return d
+
+
+def shade_mix_bwd_view(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
+    """shade_mix_bwd plus dV [R,3]"""
+    R = row_of_ray.shape[0]
+    dev = V.device
+    f = lambda *s_: torch.empty(s_, dtype=torch.float32, device=dev)  # noqa: E731
+    d_inc, d_brdf, dL, d_fd, dV = f(R, 3), f(R, 3), f(R, 3), f(R, 6), f(R, 3)
+    _check(_lib.nmf_shade_mix_bwd_view(_p(V, torch.float32), _p(f0, torch.float32), _p(diff, torch.float32),
+                                       _p(cnt, torch.int32), _p(row_of_ray, torch.int32), C.c_int64(R), _p(L, torch.float32),
+                                       _p(inc, torch.float32), _p(brdf, torch.float32), _p(d_rows, torch.float32), _p(d_inc),
+                                       _p(d_brdf), _p(dL), _p(d_fd), _p(dV), _stream()), "nmf_shade_mix_bwd_view")
+    return d_inc, d_brdf, dL, d_fd, dV
 
 
 def shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf):

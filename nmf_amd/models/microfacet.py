@@ -11,7 +11,8 @@ import torch
 from .. import hip
 from ..functional import BouncePrep, BounceRays, GgxRays, ShadeMix, FastPrivateAttrs
 from ..modules import sh
-from ..brdf_samplers.ggx import mat3T_vec, normalize
+from ..brdf_samplers.ggx import mat3T_vec, normalize  # noqa: F401
+from ..controllers import RetraceController
 
 
 class Microfacet(FastPrivateAttrs, torch.nn.Module):
@@ -37,13 +38,12 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
         self.target_num_samples = list(target_num_samples)
         self.max_brdf_rays = list(max_brdf_rays)
         self.start_max_retrace_rays = list(max_retrace_rays)
-        self.max_retrace_rays = list(max_retrace_rays)
+        # models/microfacet.py:236-269 (reset_counter / update_n_samples): host-side feedback loop, nmf_amd/controllers.py
+        self._retrace = RetraceController(max_retrace_rays, self.target_num_samples, self.max_brdf_rays)
         self.detach_N_iters = detach_N_iters
         self.detach_N = True
         self.rays_per_ray, self.test_rays_per_ray = rays_per_ray, test_rays_per_ray
         self.outputs = {"diffuse": 3, "roughness": 1, "tint": 3, "spec": 3, "albedo": 3}
-        self.mean_ratios = None
-        self.ratio_list = None
         self.trace = None            # tests: dict that receives intermediate tensors
         self.forced = None           # tests: {'retrace_order<r>': LongTensor, 'counts<r>': IntTensor} pin bookkeeping decisions
         # True: sort the re-trace scores even when every secondary ray is re-traced, as models/microfacet.py:506-509 does
@@ -72,22 +72,26 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
         return False
 
     def reset_counter(self):
-        self.max_retrace_rays = list(self.start_max_retrace_rays)
-        self.mean_ratios = None
-        self.ratio_list = None
+        self._retrace.reset()
 
     def update_n_samples(self, n_samples):
-        if len(n_samples) != len(self.max_retrace_rays):
-            return
-        ratios = [(n_rays / n) if n > 0 else 1e-3 for n_rays, n in zip(self.max_retrace_rays, n_samples)]
-        if self.ratio_list is None:
-            self.ratio_list = [[r, 1e-3] for r in ratios]
-        else:
-            self.ratio_list = [([ratio] + rl)[:20] for ratio, rl in zip(ratios, self.ratio_list)]
-        self.mean_ratios = [min(rl) if len(rl) > 0 else None for rl in self.ratio_list]
-        self.max_retrace_rays = [min(int(t * r + 1), mx) if r is not None else prev for t, r, mx, prev in
-                                 zip(self.target_num_samples, self.mean_ratios, self.max_brdf_rays[:-1],
-                                     self.max_retrace_rays)]
+        self._retrace.update(n_samples)
+
+    @property
+    def max_retrace_rays(self):
+        return self._retrace.max_retrace_rays
+
+    @max_retrace_rays.setter
+    def max_retrace_rays(self, v):
+        self._retrace.max_retrace_rays = list(v)
+
+    @property
+    def mean_ratios(self):
+        return self._retrace.mean_ratios
+
+    @property
+    def ratio_list(self):
+        return self._retrace.ratio_list
 
     # ---- shading ----------------------------------------------------------------------------------------
     def forward(self, xyzs, xyzs_normed, app_features, viewdirs, normals, weights, app_mask, B, render_reflection,
@@ -192,8 +196,11 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
             c.detach_n = bool(self.detach_N)
             c.off, c.cnt, c.sobol = off.contiguous(), cnt32, self.brdf_sampler.angs
             c.row_of_ray, c.j_of_ray, c.row_off = row_of_ray, j_of_ray, row_off
+            # recursion level >= 1: the ray rows are outputs of the level above (origin x + 5e-3 L | direction L) and their
+            # direction enters the shading as the view vector bV = -viewdirs (:354, not detached)
+            graph_rays = samples.rays if (recur > 0 and torch.is_grad_enabled() and samples.rays.requires_grad) else None
             L, halfvec, diffvec, lpdf, mipval, bounce_rays, brdf_weight, bV, f0, diffuse, bN = BounceRays.apply(
-                normals, c, tok_field, tok_heads, tok_mlp)                                            # :352-472
+                normals, c, tok_field, tok_heads, tok_mlp, graph_rays)                                # :352-472
         else:
             bV, bN, r1, f0, diffuse, feat, xyz = BouncePrep.apply(
                 normals, app_features, heads, bidx, inv, samples.xyzt, samples.ray_id, samples.rays, conv, feat_noise,

@@ -29,14 +29,7 @@ def _one(like):
     return _ones((), like.device)
 
 
-def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
-    # utils.py:327-359 (float64 arithmetic like the reference's numpy scalars, without numpy's per-call overhead)
-    if lr_delay_steps > 0:
-        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
-    else:
-        delay_rate = 1.0
-    t = min(max(step / max_steps, 0.0), 1.0)
-    return delay_rate * math.exp(t * (math.log(lr_final) - math.log(lr_init)) + math.log(lr_init))
+from .controllers import RayBatchController, learning_rate_decay  # noqa: E402,F401
 
 
 class DecayLR:
@@ -174,8 +167,7 @@ class Trainer:
         self.nerf = nerf
         self.p = params
         self.world_size, self.rank = world_size, rank
-        self.num_rays = params["starting_batch_size"]
-        self.prev_ratio = None
+        self.batch = RayBatchController(params)          # train.py:504-507,618-626 (num_rays / lbatch_size)
         self.iteration = 0
         self.reduce = None
         # train.py:470-481,748-749: exponential decay of the two regulariser weights towards their final values
@@ -201,30 +193,51 @@ class Trainer:
         self.scheduler = DecayLR(self.optimizer, lam)
         self.reduce = FlatGradAllReduce([q for g in self.optimizer.param_groups for q in g["params"]])
 
-    def lbatch_size(self):
-        p = self.p
-        return min(p["min_batch_size"] if self.num_rays < p["min_batch_size"] else self.num_rays, p["max_batch_size"])
+    @property
+    def num_rays(self):
+        return self.batch.num_rays
 
-    def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None, global_rays=None):
+    @num_rays.setter
+    def num_rays(self, v):
+        self.batch.num_rays = v
+
+    def lbatch_size(self):
+        return self.batch.lbatch_size()
+
+    def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None, global_rays=None,
+             fetch=None, trace=None):
         """One optimizer step over this rank's rays (train.py:497-747).  rays [n,6], rgb_gt [n,3] (already blended
         onto the background colour, train.py:525-530).  `global_rays`: the loss normaliser `lbatch_size` of train.py:703,
         i.e. the number of rays ALL ranks process in this step (default: n * world_size, equal shards).
+        `fetch(n) -> (rays [n,6], rgb [n,3])` instead of rays / rgb_gt: the step pulls its chunks one by one exactly like
+        train.py:509-512 (`trainingSampler.nextids(lnum_rays)` per chunk, so a re-permutation can fall inside a step);
+        `n` = this rank's share of the step (rays.shape[0] when rays is given, else lbatch_size()).
+        `trace`: list that receives one record per chunk (num_rays, rays in / kept, n_samples, loss, max_retrace_rays).
         Returns a stats dict (python scalars)."""
         p = self.p
         nerf = self.nerf
         self.optimizer.zero_grad(set_to_none=True)
-        n_total = rays.shape[0]
+        n_total = rays.shape[0] if rays is not None else self.lbatch_size()
         lbatch = global_rays if global_rays is not None else n_total * self.world_size
         pos, used_rays, losses, n_samples_last, n_chunks = 0, 0, [], None, 0
-        bg = _ones((3,), rays.device)
+        bg = None
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
-            r = rays[pos:pos + chunk]
-            gt = rgb_gt[pos:pos + chunk]
+            if fetch is not None:
+                r, gt = fetch(min(chunk, n_total - pos))
+            else:
+                r = rays[pos:pos + chunk]
+                gt = rgb_gt[pos:pos + chunk]
+            if bg is None:
+                bg = _ones((3,), r.device)
             pos += r.shape[0]
             n_chunks += 1
+            if trace is not None:
+                trace.append(dict(num_rays=chunk, rays_in=int(r.shape[0]), max_retrace=list(nerf.model.max_retrace_rays)))
             ims, st = nerf(r, focal, bg_col=bg, is_train=True, ndc_ray=False, noise=noise)
             n_samples = st["n_samples"]
+            if trace is not None:
+                trace[-1].update(n_samples=list(n_samples), kept=int(ims["rgb_map"].shape[0]))
             if n_samples[0] == 0:
                 continue
             rgb_map = ims["rgb_map"]                 # valid rays are a prefix of the chunk (alphagrid.py:353-364)
@@ -242,6 +255,8 @@ class Trainer:
             # back-propagated regardless and nmf_adam_step leaves every element with a non-finite gradient untouched, so a
             # NaN never reaches the moments or the parameters and no synchronisation is needed
             total.backward(_one(total))
+            if trace is not None:
+                trace[-1]["total"] = total.detach()
             if hasattr(nerf.rf, "flush_pending_l1"):
                 nerf.rf.flush_pending_l1()
             kept = rgb_map.shape[0]                  # = number of valid rays (no device read-back)
@@ -249,10 +264,7 @@ class Trainer:
             losses.append(loss.detach())             # read back after the optimizer step has been queued
             n_samples_last = n_samples
             if update_controllers:                                                               # train.py:618-627
-                ratio = kept / n_samples[0]
-                mean_ratio = ratio if self.prev_ratio is None else min(0.1 * ratio + 0.9 * self.prev_ratio, ratio)
-                self.prev_ratio = mean_ratio
-                self.num_rays = int(mean_ratio * p["target_num_samples"] + 1)
+                self.batch.update(kept, n_samples[0])
                 nerf.model.update_n_samples(n_samples[1:])
         comm_bytes = self.reduce()
         if p.get("clip_grad") is not None:                                                       # train.py:744-745
@@ -263,8 +275,7 @@ class Trainer:
         self.pred_lambda *= self.pred_decay
         if nerf.check_schedule(self.iteration, 1):                                               # train.py:806-813
             self._make_optimizer()
-            self.num_rays = p["starting_batch_size"]
-            self.prev_ratio = None
+            self.batch.reset()
             nerf.model.reset_counter()
         self.iteration += 1
         return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes, chunks=n_chunks,

@@ -44,7 +44,12 @@ def _stub(name, **attrs):
     m = types.ModuleType(name)
     m.__spec__ = importlib.machinery.ModuleSpec(name, None)
     m.__path__ = []
-    m.__getattr__ = lambda attr: _Anything()
+    def _attr(attr):
+        if attr.startswith("__"):             # inspect / importlib probe __file__, __wrapped__, ...: behave like a plain module
+            raise AttributeError(attr)
+        return _Anything()
+
+    m.__getattr__ = _attr
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m

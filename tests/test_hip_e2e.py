@@ -670,3 +670,120 @@ def test_density_l1_rides_on_the_pass_gradient_node():
     ref = [torch.sign(p.detach()) / p.numel() for p in dens]
     for p, r in zip(dens, ref):
         assert torch.allclose(p.grad, r, rtol=1e-6, atol=0)
+
+
+def test_training_run_follows_the_reference_trace():
+    """SURVEY 8(f1) / north_star "PSNR after equal iterations": the HIP Trainer against a run of the REFERENCE's own
+    `reconstruction()` loop (tests/golden/make_train_trace.py: 40 iterations, small scene, forced upsample + optimizer
+    restart at iteration 15, dynamic ray batch and re-trace controllers live).  Same data, same initial parameters and
+    calibrated biases, the same random stream (the CPU generator state recorded at the first iteration; ray permutation,
+    jitter, feature noise, bounce counts, Sobol offsets, re-trace tie-breaks drawn in the reference's order).
+
+    The first iterations must agree closely (identical noise); afterwards last-bit differences (a bounce count that floors
+    the other way, a neighbour swap in the re-trace order) shift the random stream, so the runs become two realisations of the
+    same stochastic optimisation: compared through their controllers, loss level, parameter norms and test PSNR."""
+    from nmf_amd.config import build_model, resolved_config
+    from nmf_amd.noise import ReplayNoise
+    from nmf_amd.renderer import psnr_8bit, render_images
+    from nmf_amd.trainer import Trainer
+    g = Golden("train_trace")
+    G0, G1, BG, up, n_iters = g["grid0"], g["grid1"], g["bg_res"], g["upsample_at"], g["n_iters"]
+    over = {"sampler.update_list": [up], "sampler.max_samples": 20000, "model.max_brdf_rays": [40000, 20000],
+            "model.target_num_samples": [40000], "model.max_retrace_rays": [200], "model.rays_per_ray": 32,
+            "rf.upsamp_list": [up], "rf.N_voxel_init": G0 ** 3, "rf.N_voxel_final": G1 ** 3}
+    nerf, _ = build_model(grid=G0, bg_resolution=BG, device=DEV, overrides=over)
+    sd = {k[len("init/"):]: g[k] for k in g.keys("init/")}
+    missing = nerf.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = \
+        (float(v) for v in g.np("biases"))
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=True)
+    mn, mx, start, target = (int(v) for v in g.np("params_params"))
+    params = dict(resolved_config()["params"], n_iters=n_iters, batch_size=512, min_batch_size=mn, max_batch_size=mx,
+                  starting_batch_size=start, target_num_samples=target)
+    tr = Trainer(nerf, params)
+    rays_tr, rgb_tr = g["rays_train"].to(DEV), g["rgb_train"].to(DEV)
+    rays_te, rgb_te = g["rays_test"].to(DEV), g["rgb_test"]
+    focal = g["focal"]
+    n_views = rays_te.shape[0] // (g["res"] ** 2)
+
+    class SimpleSampler:                                   # train.py:36-51
+        def __init__(self, total):
+            self.total, self.curr, self.ids = total, total, None
+
+        def nextids(self, batch):
+            self.curr += batch
+            if self.curr + batch > self.total:
+                self.ids = torch.randperm(self.total)
+                self.curr = 0
+            return self.ids[self.curr:self.curr + batch]
+
+    smp = SimpleSampler(rays_tr.shape[0])
+
+    def fetch(n):
+        ids = smp.nextids(n).to(DEV)
+        return rays_tr[ids], rgb_tr[ids]
+
+    def test_psnr():
+        with torch.random.fork_rng():
+            torch.manual_seed(11)
+            nerf.eval()
+            pred = render_images(nerf, rays_te, focal, 800, ReplayNoise(DEV, None), draw_debug=True).cpu()
+            nerf.train()
+        return [float(psnr_8bit(pred.reshape(n_views, -1, 3)[i], rgb_te.reshape(n_views, -1, 3)[i])) for i in range(n_views)]
+
+    torch.set_rng_state(g["rng_state_at_loop"])
+    chunks, lrs, pnorm, psnrs, grids, opts = [], [], [], [], [], []
+    pnames = str(g.np("param_names")).split("\n")
+    for it in range(n_iters):
+        lrs.append([float(gr["lr"]) for gr in tr.optimizer.param_groups])
+        rec = []
+        tr.step(None, None, focal, noise=ReplayNoise(DEV, None), fetch=fetch, trace=rec)
+        for r_ in rec:
+            r_["iter"] = it
+        chunks += rec
+        named = dict(nerf.named_parameters())
+        pnorm.append([float(named[n].detach().double().norm()) for n in pnames])
+        grids.append(int(nerf.rf.density_rf.app_plane[0].shape[-1]))
+        opts.append(id(tr.optimizer))
+        if it + 1 in [int(v) for v in g.np("psnr_at")]:
+            psnrs.append(test_psnr())
+    # ---- schedule: exact
+    ref_lr = g.np("iter_lr")
+    assert np.allclose(np.asarray(lrs), ref_lr, rtol=1e-9, atol=0), "per-group learning rates"
+    assert grids[up - 1] == G0 and grids[up] == G1 and grids[-1] == G1, grids          # upsampled at the end of iteration `up`
+    assert len(set(opts[:up + 1])) == 1 and len(set(opts[up + 1:])) == 1 and opts[up] != opts[up + 1]
+    # ---- controllers / bookkeeping per chunk
+    ref_iter, ref_nr, ref_in = g.np("chunk_iter"), g.np("chunk_num_rays"), g.np("chunk_rays_in")
+    ref_kept, ref_ns, ref_mr, ref_loss = g.np("chunk_kept"), g.np("chunk_n_samples"), g.np("chunk_max_retrace"), g.np("chunk_loss")
+    print(f"chunks: {len(chunks)} vs {len(ref_iter)}")
+    n_cmp = min(len(chunks), len(ref_iter))
+    rows = []
+    for c in range(n_cmp):
+        ch = chunks[c]
+        ns = list(ch.get("n_samples", [0, 0])) + [0, 0]
+        rows.append(f"  it {ch['iter']:2d}/{int(ref_iter[c]):2d} num_rays {ch['num_rays']:4d}/{int(ref_nr[c]):4d} kept {ch.get('kept', 0):4d}/"
+                    f"{int(ref_kept[c]):4d} n_samples {ns[0]:6d},{ns[1]:6d}/{int(ref_ns[c][0]):6d},{int(ref_ns[c][1]):6d} retrace "
+                    f"{ch['max_retrace'][0]:5d}/{int(ref_mr[c]):5d} loss {float(ch.get('total', float('nan'))):.5f}/{float(ref_loss[c]):.5f}")
+    print("\n".join(rows))
+    ref_pn = g.np("iter_param_norm")
+    drift = np.abs(np.asarray(pnorm) / np.maximum(ref_pn, 1e-30) - 1)
+    print("max relative parameter-norm difference per iteration:", np.round(drift.max(axis=1), 4).tolist())
+    ref_ps = g.np("test_psnr")
+    print("test PSNR per view:", np.round(np.asarray(psnrs), 3).tolist(), "reference:", np.round(ref_ps, 3).tolist())
+    # identical noise: the first iteration (before any shape of the stream can differ)
+    first = [c for c in range(n_cmp) if chunks[c]["iter"] == 0]
+    for c in first:
+        assert chunks[c]["num_rays"] == int(ref_nr[c]) and chunks[c]["rays_in"] == int(ref_in[c])
+        assert chunks[c]["n_samples"][0] == int(ref_ns[c][0]) and chunks[c]["kept"] == int(ref_kept[c])
+        assert abs(float(chunks[c]["total"]) - float(ref_loss[c])) <= 2e-3 * abs(float(ref_loss[c])), (c, float(chunks[c]["total"]))
+    # the whole run: same number of chunks per iteration, controllers within a few per cent, loss level, parameters, PSNR
+    assert len(chunks) == len(ref_iter) and [c["iter"] for c in chunks] == [int(v) for v in ref_iter]
+    nr = np.asarray([c["num_rays"] for c in chunks], dtype=np.float64)
+    assert np.all(np.abs(nr / ref_nr - 1) <= 0.05), "num_rays controller"
+    tot = np.asarray([float(c["total"]) for c in chunks])
+    assert abs(tot.mean() / ref_loss.mean() - 1) <= 0.03 and np.all(np.abs(tot - ref_loss) <= 0.15 * ref_loss + 5e-3)
+    assert drift.max() <= 0.02, drift.max()
+    assert np.all(np.abs(np.asarray(psnrs) - ref_ps) <= 0.25), (psnrs, ref_ps.tolist())
+    assert abs(float(np.mean(psnrs[-1])) - float(ref_ps[-1].mean())) <= 0.1          # "PSNR after equal iterations"

@@ -624,6 +624,59 @@ def test_ggx_rays_and_mix_vs_oracle():
         assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), what="mix d" + n)
 
 
+def test_view_direction_adjoints_vs_oracle():
+    """Rays of recursion level >= 1 look along a direction the level above sampled, and the reference keeps it in the graph
+    (viewdirs = rays[:, 3:6], modules/tensor_nerf.py:262; bV = -viewdirs, models/microfacet.py:354): the GGX sample L(V, N, r)
+    and the Fresnel term back-propagate into V.  nmf_ggx_rays_bwd_view / nmf_shade_mix_bwd_view vs autograd of the oracle."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(17)
+    Mb, m = 200, 24
+    V = torch.nn.functional.normalize(torch.randn(Mb, 3, generator=gen), dim=-1)
+    N = torch.nn.functional.normalize(V + 0.8 * torch.randn(Mb, 3, generator=gen), dim=-1)
+    N = N * (V * N).sum(-1, keepdim=True).sign()
+    r = torch.rand(Mb, 1, generator=gen) * 0.4 + 0.05
+    counts = torch.randint(1, m + 1, (Mb,), generator=gen)
+    row_off, rows, js = _ray_lists(counts)
+    ray_mask = torch.arange(m)[None] < counts[:, None]
+    sobol = torch.quasirandom.SobolEngine(2, scramble=True, seed=5).draw(1024)
+    sobol = sobol.clip(max=0.98)                   # keep away from u1 -> 1 (ill-conditioned, see the test above)
+    off = torch.zeros(Mb, 1, 2)
+    Vo, No, ro = V.clone().requires_grad_(True), N.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    angs = O.sobol_draw(sobol, Mb, m, O.Noise([("rand", off)]))
+    L_o, _, _ = O.ggx_sample(angs[..., 0], angs[..., 1], Vo, No, ro, ray_mask)
+    c = torch.randn(L_o.shape, generator=gen)
+    gV_o, gN_o, gr_o = torch.autograd.grad((L_o * c).sum(), [Vo, No, ro])
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    d_nrv = hip.ggx_rays_bwd_view(d(V), d(N), d(r.reshape(-1)), d(off.reshape(Mb, 2)), d(sobol), d(rows.int()), d(js.int()),
+                                  d(c), None)
+    rows7 = hip.segment_sum_wide(d_nrv, 7, d(row_off), Mb).cpu()
+    for got, ref, what in ((rows7[:, 0:3], gN_o, "dN"), (rows7[:, 3:4], gr_o, "dr"), (rows7[:, 4:7], gV_o, "dV")):
+        sc = float(ref.abs().max())
+        err = (got - ref).abs().max(1).values
+        assert float((err < 1e-3 * sc).float().mean()) > 0.99 and float(err.max()) < 0.05 * sc, (what, float(err.max()), sc)
+    # the 4-tangent kernel is the same computation without the view tangents
+    d_nr = hip.ggx_rays_bwd(d(V), d(N), d(r.reshape(-1)), d(off.reshape(Mb, 2)), d(sobol), d(rows.int()), d(js.int()), d(c))
+    assert torch.allclose(d_nr, d_nrv[:, :4], rtol=1e-4, atol=1e-5 * float(d_nr.abs().max()))
+    # ---- Fresnel mix: d/dV per ray
+    Vm = V.clone().requires_grad_(True)
+    f0, diff = torch.rand(Mb, 3, generator=gen), torch.rand(Mb, 3, generator=gen)
+    Lin = L_o.detach().clone().requires_grad_(True)
+    inc, bw = torch.rand(L_o.shape, generator=gen), torch.rand(L_o.shape, generator=gen)
+    eV = Vm[rows]
+    Hh = O.normalize((eV + Lin) / 2)
+    cos_t = (-eV * Hh).sum(-1, keepdim=True).abs()
+    Fr = f0[rows] + (1 - f0[rows]) * (1 - cos_t).clip(0, 1) ** 5
+    comb = (Fr * inc * bw + (1 - Fr) * diff[rows]) / counts.float()[rows][:, None].clip(min=1)
+    ref = O.row_mask_sum(comb, ray_mask)
+    cc = torch.randn(Mb, 3, generator=gen)
+    gV_m, gL_m = torch.autograd.grad((ref * cc).sum(), [Vm, Lin])
+    d_inc, d_brdf, dL, d_fd, dV = hip.shade_mix_bwd_view(d(V), d(f0), d(diff), d(counts.int()), d(rows.int()), d(L_o.detach()),
+                                                         d(inc), d(bw), d(cc))
+    assert_close(dL.cpu(), gL_m, rtol=2e-4, atol=2e-5 * float(gL_m.abs().max()), what="mix dL")
+    dV_rows = hip.segment_sum(dV, None, d(row_off), Mb, lanes=8).cpu()
+    assert_close(dV_rows, gV_m, rtol=2e-4, atol=2e-5 * float(gV_m.abs().max()), what="mix dV")
+
+
 @pytest.mark.gpu
 def test_fused_adam_matches_torch_adam():
     """nmf_adam_step (one launch for every tensor) against torch.optim.Adam (train.py:443-469): per-group lr / betas,
