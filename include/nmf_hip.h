@@ -126,6 +126,14 @@ int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64_t M,
                      const float* const app_planes[3], const float* const app_lines[3],
                      const float* basis, float* sigma_feat, float* sigma, float* grad, float* normal,
                      float* app, float* coef, void* stream);
+/* bf16-table variant (BASELINE configs[1], train.py:540 `fp16` autocast is the reference's only precision hook): the same
+ * query with every factor table stored as bfloat16 (the upper 16 bits of the fp32 pattern) -- half the bytes per tap --
+ * and fp32 arithmetic.  The caller keeps fp32 master tables (Adam, backward walk) and refreshes the bf16 copies after each
+ * optimizer step (nmf_multi_copy with dst_is_f64 = 2). */
+int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, const uint16_t* const dpk[3],
+                          const uint16_t* const dlk[3], const uint16_t* const app_planes[3],
+                          const uint16_t* const app_lines[3], const float* basis, float* sigma_feat, float* sigma,
+                          float* grad, float* normal, float* app, float* coef, void* stream);
 
 /* Backward.  Upstream adjoints (any may be NULL): d_sigma [M] (wrt activated sigma), d_sigma_feat [M]
  * (wrt the raw feature, added to the former's contribution), d_normal [M][3], d_app [M][24].
@@ -415,8 +423,8 @@ typedef struct {
     const void* src;
     void* dst;
     int64_t numel;
-    int32_t src_is_f64;
-    int32_t dst_is_f64;
+    int32_t src_is_f64;      /* 0: fp32 source, 1: fp64 source */
+    int32_t dst_is_f64;      /* 0: fp32, 1: fp64, 2: bfloat16 (fp32 source only, round to nearest even) */
 } nmf_copy_slot;
 int nmf_multi_copy(const nmf_copy_slot* slots, int32_t n_slots, void* stream);
 

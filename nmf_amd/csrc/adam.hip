@@ -75,9 +75,27 @@ __device__ __forceinline__ void copy_slot(const nmf_copy_slot& s) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.numel; i += stride) dst[i] = (D)src[i];
 }
 
+// fp32 -> bf16, round to nearest even (NaN stays NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ void copy_slot_bf16(const nmf_copy_slot& s) {
+    const float* __restrict__ src = static_cast<const float*>(s.src);
+    uint16_t* __restrict__ dst = static_cast<uint16_t*>(s.dst);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.numel; i += stride) dst[i] = f32_to_bf16(src[i]);
+}
+
 __global__ void __launch_bounds__(256) k_multi_copy(CopyBatch b) {
     const nmf_copy_slot& s = b.s[blockIdx.y];
     if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;
+    if (s.dst_is_f64 == 2) {             // bf16 destination (fp32 source): the bf16 table copies of configs[1]
+        copy_slot_bf16(s);
+        return;
+    }
     if (s.src_is_f64) {
         if (s.dst_is_f64) copy_slot<double, double>(s);
         else copy_slot<double, float>(s);

@@ -194,9 +194,23 @@ __device__ __forceinline__ void load_run(const float* base, float (&dst)[N4 * 4]
         dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
     }
 }
+// bf16 tables (BASELINE configs[1]): the same runs at half the bytes; a bf16 is the upper half of the fp32 bit pattern,
+// all arithmetic stays fp32.  Runs are 16-byte aligned for every table (16 / 24 / 32 / 48 channels).
+template <int N4>
+__device__ __forceinline__ void load_run(const uint16_t* base, float (&dst)[N4 * 4]) {
+    const uint2* q = reinterpret_cast<const uint2*>(base);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const uint2 v = q[i];
+        dst[4 * i] = __uint_as_float(v.x << 16); dst[4 * i + 1] = __uint_as_float(v.x & 0xffff0000u);
+        dst[4 * i + 2] = __uint_as_float(v.y << 16); dst[4 * i + 3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+}
+template <class TT> struct PtrsT3 { const TT* p[3]; };
 
+template <class TT>
 __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
-                                                Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
+                                                PtrsT3<TT> dpk, PtrsT3<TT> dlk, PtrsT3<TT> apl, PtrsT3<TT> ali,
                                                 const float* __restrict__ basis, float* __restrict__ sigma_feat,
                                                 float* __restrict__ sigma, float* __restrict__ grad,
                                                 float* __restrict__ normal, float* __restrict__ app,
@@ -1003,24 +1017,49 @@ extern "C" int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* c
     return NMF_OK;
 }
 
-extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
-                                const float* const dlk[3], const float* const app_planes[3],
-                                const float* const app_lines[3], const float* basis, float* sigma_feat, float* sigma,
-                                float* grad, float* normal, float* app, float* coef, void* stream) {
+template <class TT>
+static PtrsT3<TT> mkT(const TT* const a[3], bool on) {
+    PtrsT3<TT> r;
+    for (int i = 0; i < 3; ++i) r.p[i] = (on && a) ? a[i] : nullptr;
+    return r;
+}
+
+template <class TT>
+static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const float* xyzt, int64_t M, const TT* const dpk[3],
+                             const TT* const dlk[3], const TT* const app_planes[3], const TT* const app_lines[3],
+                             const float* basis, float* sigma_feat, float* sigma, float* grad, float* normal, float* app,
+                             float* coef, void* stream) {
     NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_fwd: params");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(xyzt, NMF_EINVAL, "nmf_vm_query_fwd: xyzt null");
     const bool want_d = sigma_feat || sigma || grad || normal;
     const bool want_a = app || coef;
-    NMF_REQUIRE(!want_d || (all3(dpk) && all3(dlk)), NMF_EINVAL, "nmf_vm_query_fwd: density tables missing");
-    NMF_REQUIRE(!want_a || (all3(app_planes) && all3(app_lines) && (!app || basis)), NMF_EINVAL,
-                "nmf_vm_query_fwd: appearance tables missing");
-    hipLaunchKernelGGL(k_vm_fwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                       (const float4*)xyzt, M, want_d ? mk(dpk) : mk(nullptr), want_d ? mk(dlk) : mk(nullptr),
-                       want_a ? mk(app_planes) : mk(nullptr), want_a ? mk(app_lines) : mk(nullptr), basis, sigma_feat,
-                       sigma, grad, normal, app, coef);
-    NMF_CHECK_LAUNCH("nmf_vm_query_fwd");
+    NMF_REQUIRE(!want_d || (dpk && dlk && dpk[0] && dpk[1] && dpk[2] && dlk[0] && dlk[1] && dlk[2]), NMF_EINVAL,
+                "nmf_vm_query_fwd: density tables missing");
+    NMF_REQUIRE(!want_a || (app_planes && app_lines && app_planes[0] && app_planes[1] && app_planes[2] && app_lines[0] &&
+                            app_lines[1] && app_lines[2] && (!app || basis)),
+                NMF_EINVAL, "nmf_vm_query_fwd: appearance tables missing");
+    hipLaunchKernelGGL(k_vm_fwd<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                       (const float4*)xyzt, M, mkT<TT>(dpk, want_d), mkT<TT>(dlk, want_d), mkT<TT>(app_planes, want_a),
+                       mkT<TT>(app_lines, want_a), basis, sigma_feat, sigma, grad, normal, app, coef);
+    NMF_CHECK_LAUNCH(what);
     return NMF_OK;
+}
+
+extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],
+                                const float* const dlk[3], const float* const app_planes[3],
+                                const float* const app_lines[3], const float* basis, float* sigma_feat, float* sigma,
+                                float* grad, float* normal, float* app, float* coef, void* stream) {
+    return vm_query_fwd_impl<float>("nmf_vm_query_fwd", p, xyzt, M, dpk, dlk, app_planes, app_lines, basis, sigma_feat, sigma,
+                                    grad, normal, app, coef, stream);
+}
+
+extern "C" int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, const uint16_t* const dpk[3],
+                                     const uint16_t* const dlk[3], const uint16_t* const app_planes[3],
+                                     const uint16_t* const app_lines[3], const float* basis, float* sigma_feat,
+                                     float* sigma, float* grad, float* normal, float* app, float* coef, void* stream) {
+    return vm_query_fwd_impl<uint16_t>("nmf_vm_query_fwd_bf16", p, xyzt, M, dpk, dlk, app_planes, app_lines, basis,
+                                       sigma_feat, sigma, grad, normal, app, coef, stream);
 }
 
 // counter copies per brick (power of two; measured on S1: 1 -> 64 us, 4 -> 45 us, 8 -> 64 us of binning per 0.88 M

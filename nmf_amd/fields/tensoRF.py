@@ -152,6 +152,9 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         self._plist = None
         self._pass, self._pass_open, self._tables_memo = None, False, None
         self._last_holder = None
+        self.table_dtype = "f32"
+        self._bf16 = None
+        self._fwd_memo = None
 
     # ---- geometry bookkeeping (fields/tensor_base.py:55-64,219-232) ---------------------------------
     def set_register(self, name, val):
@@ -220,6 +223,39 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         self._cache = ([p._version for p in ps], (vp, dpk, dlk, apl, ali, basis), [p.data_ptr() for p in ps], (dpl, dli))
         return self._cache[1]
 
+    # ---- bf16-table variant (BASELINE configs[1]) -----------------------------------------------------------------
+    def set_table_dtype(self, dtype):
+        """'f32' (default) or 'bf16': the FORWARD queries read bfloat16 copies of the factor tables (packed density planes /
+        lines, appearance planes / lines) -- half the bytes per tap, fp32 arithmetic.  The parameters, the optimizer and the
+        backward walk keep the fp32 tables (the copies are refreshed once per parameter update, one launch), i.e. the usual
+        mixed-precision arrangement: low-precision operands in the forward pass, fp32 master weights."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(dtype)
+        self.table_dtype = dtype
+        self._bf16 = None
+        self._fwd_memo = None
+
+    def _fwd_tables(self):
+        """(p, dpk, dlk, apl, ali, basis) as the forward kernel should read them"""
+        if self.table_dtype == "f32":
+            return self._tables()
+        if self._pass_open and self._fwd_memo is not None:
+            return self._fwd_memo
+        tab = self._tables()
+        p, dpk, dlk, apl, ali, basis = tab
+        key = (self._cache[0], self._cache[2])
+        if self._bf16 is None or self._bf16[0][1] != key[1]:
+            copies = hip.to_bf16_tables(list(dpk) + list(dlk) + list(apl) + list(ali))
+            self._bf16 = (key, copies)
+        elif self._bf16[0][0] != key[0]:
+            hip.to_bf16_tables(list(dpk) + list(dlk) + list(apl) + list(ali), self._bf16[1])
+            self._bf16 = (key, self._bf16[1])
+        c = self._bf16[1]
+        out = (p, c[0:3], c[3:6], c[6:9], c[9:12], basis)
+        if self._pass_open:
+            self._fwd_memo = out
+        return out
+
     def _grads_to_param_layout(self, gp, gl, g_apl, g_ali, g_basis):
         """kernel layouts ([G,G,C] / [G,C]) -> views shaped like the parameters (no copies)"""
         out = []
@@ -255,10 +291,10 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
 
     # ---- gradient pass: all queries between begin_pass() and end_pass() share one FieldGrads node -----------
     def begin_pass(self):
-        self._pass, self._pass_open, self._tables_memo = None, True, None
+        self._pass, self._pass_open, self._tables_memo, self._fwd_memo = None, True, None, None
 
     def end_pass(self):
-        self._pass, self._pass_open, self._tables_memo = None, False, None
+        self._pass, self._pass_open, self._tables_memo, self._fwd_memo = None, False, None, None
 
     def _pass_token(self):
         ps = self._param_list()
@@ -342,6 +378,7 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         self.update_stepSize(res_target)
         self._cache = None
         self._plist = None
+        self._bf16 = None
 
     def check_schedule(self, iter, batch_mul):
         # fields/tensor_base.py:234-243
@@ -361,6 +398,7 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
             self.update_stepSize(state_dict[k])
         self._cache = None
         self._plist = None
+        self._bf16 = None
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 

