@@ -1,0 +1,363 @@
+"""The training pass of `TensorNeRF.forward` + `backward()` without the autograd engine.
+
+`modules/tensor_nerf.py` / `models/microfacet.py` / `functional.py` express the hot path as ~12 autograd nodes per direction
+around the C-ABI kernels; that keeps the reference's operator API differentiable for any caller, but in the training loop
+the graph is the same every step and the engine's bookkeeping (node construction, the backward dispatch through Python,
+pass tokens) is host time on a path where host time and kernel time are the same ~3 ms.  TrainPass runs the SAME kernel
+sequence as straight-line code: forward for recursion level 0 and 1 keeping the intermediates on a tape, then the adjoint
+calls in reverse order, with the table / MLP / head / env-map gradients accumulated in persistent buffers over all chunks of
+an optimizer step and converted to parameter gradients once (`end_step`).
+
+Scope: is_train=True, the sparse-appearance path (no debug maps), recursion depth len(max_retrace_rays) <= 1, no test
+hooks (model.forced / model.trace / sampler.forced_valid).  Anything else raises Unsupported BEFORE touching an accumulator
+and the Trainer runs that chunk through the autograd path instead (tests/test_hip_e2e.py compares the two paths).
+Reference spans are the ones cited in functional.py for each call."""
+import types
+
+import torch
+
+from . import hip
+
+
+class Unsupported(Exception):
+    pass
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+class TrainPass:
+    def __init__(self, nerf):
+        self.nerf = nerf
+        self.acc = None
+        self.n_loss_chunks = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    def supported(self):
+        n = self.nerf
+        m = n.model
+        return (m.forced is None and m.trace is None and n.sampler.forced_valid is None and len(m.max_retrace_rays) <= 1
+                and n.bg_module is not None and not n.hdr and getattr(m.brdf, "fused", False))
+
+    # ---- accumulators of one optimizer step ------------------------------------------------------------------------
+    def begin_step(self):
+        self.acc = None
+        self.n_loss_chunks = 0
+        self.l1_scale = 0.0
+
+    def _accumulators(self, dev):
+        if self.acc is None:
+            n = self.nerf
+            G = int(n.rf.density_rf.grid_size)
+            H, W = n.bg_module.hw()
+            shapes = ([(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]      # field (packed)
+                      + [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)]                                    # BRDF MLP
+                      + [(11, 24), (11,)]                                                                     # stacked heads
+                      + [(H, W, 4), (2, 3), (1,)])                                                            # d_sat, d_pole, d_mip
+            sizes = [int(torch.Size(s).numel()) for s in shapes]
+            pad = [(s + 3) & ~3 for s in sizes]                      # every view 16-byte aligned
+            flat = torch.zeros(sum(pad), dtype=torch.float32, device=dev)
+            v, o = [], 0
+            for s, sh, p_ in zip(sizes, shapes, pad):
+                v.append(flat[o:o + s].view(sh))
+                o += p_
+            self.acc = _ns(flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], g_apl=v[6:9], g_ali=v[9:12], g_basis=v[12], g_mlp=v[13:19],
+                           g_hW=v[19], g_hb=v[20], d_sat=v[21], d_pole=v[22], d_mip=v[23], used_env=False)
+        return self.acc
+
+    # ---- forward of one recursion level ------------------------------------------------------------------------------
+    def _env_fwd(self, rows, sa):
+        bgm = self.nerf.bg_module
+        act, sat, pole = bgm._tables()
+        return hip.sat_lookup_fwd(sat, rows, sa, 0.0, pole, sc=bgm._dev_scalars())
+
+    def _env_bwd(self, rows, sa, d_out):
+        bgm = self.nerf.bg_module
+        act, sat, pole = bgm._tables()
+        a = self.acc
+        a.used_env = True
+        return hip.sat_lookup_bwd(sat, rows, sa, 0.0, d_out, a.d_sat, a.d_pole, a.d_mip, want_dirs=True, sc=bgm._dev_scalars())
+
+    def _fwd(self, lvl, rays, focal, start_mip, noise):
+        nerf = self.nerf
+        rf, model, smp = nerf.rf, nerf.model, nerf.sampler
+        S = smp.sample_compact(rays, focal, rf=rf, override_near=None if lvl == 0 else self.near1, is_train=True,
+                               dynamic_batch_size=(lvl == 0), noise=noise)
+        B, M = S.b, S.M
+        t = _ns(lvl=lvl, S=S, B=B, M=M, n_samples=[M])
+        if M == 0:
+            return t
+        offsets = S.offsets[: B + 1]
+        p, dpk, dlk, apl, ali, basis = rf._fwd_tables()
+        sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, S.xyzt, dpk, dlk, apl, ali, basis, want_density=True, want_normal=True,
+                                                want_app=False, want_coef=False)
+        w, _acc = hip.composite_fwd(sg, S.dist, offsets, B, self.scale)
+        # ---- Microfacet.shade_compact, sparse appearance (same draw order as the autograd path)
+        deferred = noise.normal_deferred((M, 24))
+        noise.skip("randn", (M, 3))
+        noise.skip("randn", (M, 2))
+        noise.skip("rand", (5000,))
+        noise.skip("rand", (5000,))
+        conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)
+        if lvl == 0:
+            counts = hip.select_bounces(w, noise.uniform((M,)).contiguous(), 0, float(model.rays_per_ray))
+        else:
+            u, u_total = noise.select_dense(S.b, S.N, S.ray_id, S.step_id)
+            total = (w.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
+            nb = model.max_brdf_rays[lvl] - M
+            if nb > 0:
+                counts = hip.select_bounces(w, u.contiguous(), 1, float(nb), 1.0, total)
+            else:
+                counts = hip.select_bounces(w, u.contiguous(), 1, float(model.max_brdf_rays[lvl]), 0.5, total)
+        bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)
+        R, Mb = (int(v) for v in tot.cpu())
+        if R == 0:
+            raise Unsupported("no bounce rows")
+        bidx, row_off, cnt32 = bidx[:Mb], row_off[: Mb + 1], cnt32[:Mb]
+        row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)
+        off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2).contiguous()
+        xyz_rows = torch.index_select(S.xyzt, 0, bidx)
+        feat_noise = noise.rows(deferred, bidx)
+        app = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
+        hp, hW, hb = self.heads
+        heads = hip.heads_fwd(app, hW, hb, hp)
+        V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(bidx, nr, app, heads, S.xyzt, S.ray_id, S.rays, conv, feat_noise,
+                                                           self.anoise, self.min_rough, True)
+        sobol = model.brdf_sampler.angs
+        L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
+        brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
+        t.__dict__.update(offsets=offsets, sf=sf, sg=sg, gr=gr, nr=nr, w=w, conv=conv, bidx=bidx, row_off=row_off, cnt32=cnt32,
+                          inv=inv, R=R, Mb=Mb, row_of_ray=row_of_ray, j_of_ray=j_of_ray, off=off, xyz_rows=xyz_rows, app=app,
+                          heads=heads, V=V, N=N, r1=r1, f0=f0, diff=diff, feat=feat, L=L, hl=hl, dl=dl, mip=mip, brays=brays,
+                          brdf=brdf, child=None, idx_re=None, idx_no=None)
+        # ---- incoming radiance of the secondary rays (models/microfacet.py:475-563)
+        if lvl < len(model.max_retrace_rays):
+            num_retrace = min(R, model.max_retrace_rays[lvl])
+            if num_retrace >= R and not model.exact_retrace_order:
+                noise.skip("rand", (R,))
+                t.child = self._fwd(lvl + 1, brays, focal, mip, noise)
+                if t.child.M == 0:
+                    raise Unsupported("no secondary sample")
+                t.n_samples += t.child.n_samples
+                incoming = t.child.rgb_map
+            else:
+                w_rows = torch.index_select(w, 0, bidx.long())
+                cc = hip.retrace_scores(brdf, V, N, lpdf, w_rows, cnt32, row_of_ray)
+                cc = cc / cc.sum() * num_retrace
+                cc = cc + noise.uniform((R,))
+                order = hip.argsort_f32(cc.contiguous()).long()
+                cut = max(R - num_retrace, 0)
+                t.idx_re, t.idx_no = order[cut:], order[:cut]
+                incoming = torch.zeros((R, 3), device=rays.device)
+                if t.idx_re.shape[0] > 0:
+                    t.brays_re, t.mip_re = brays[t.idx_re], mip[t.idx_re]
+                    t.child = self._fwd(lvl + 1, t.brays_re, focal, t.mip_re, noise)
+                    if t.child.M == 0:
+                        raise Unsupported("no secondary sample")
+                    t.n_samples += t.child.n_samples
+                    incoming.index_copy_(0, t.idx_re, t.child.rgb_map)
+                if t.idx_no.shape[0] > 0:
+                    t.brays_no, t.mip_no = brays[t.idx_no], mip[t.idx_no]
+                    noise.skip("rand", (t.idx_no.shape[0],))
+                    noise.skip("rand", (t.idx_no.shape[0],))
+                    incoming.index_copy_(0, t.idx_no, self._env_fwd(t.brays_no, t.mip_no))
+        else:
+            noise.skip("rand", (R,))
+            noise.skip("rand", (R,))
+            incoming = self._env_fwd(brays, mip)
+        # ---- Fresnel mix + per-ray sums, tonemap, background (ShadeCompose)
+        per_ray_bg = lvl > 0
+        if per_ray_bg:
+            t.rough = start_mip[:B].contiguous()
+            noise.skip("rand", (B,))
+            noise.skip("rand", (B,))
+            bg = self._env_fwd(S.rays if B == S.rays.shape[0] else S.rays[:B], t.rough)
+        else:
+            bg = self.white
+        contrib = hip.shade_mix_fwd(V, f0, diff, cnt32, row_of_ray, L, incoming, brdf)
+        refl = hip.segment_sum(contrib, None, row_off, Mb, lanes=8)
+        rgb_map, acc, rgb_lin, ori = hip.ray_compose_fwd(w, refl, inv, nr if lvl == 0 else None, S.rays, offsets, B, bg,
+                                                         per_ray_bg, lvl == 0, False, lvl == 0)
+        t.__dict__.update(incoming=incoming, bg=bg, refl=refl, rgb_map=rgb_map, acc=acc, rgb_lin=rgb_lin, ori=ori,
+                          per_ray_bg=per_ray_bg)
+        return t
+
+    # ---- backward of one recursion level -----------------------------------------------------------------------------
+    def _bwd(self, t, d_rgb, d_acc, d_ori):
+        a = self.acc
+        S, lvl = t.S, t.lvl
+        view = lvl > 0                  # the rows' view vector is the direction the level above sampled: keep its adjoint
+        d_w, d_refl, d_nrm = hip.ray_compose_bwd(t.w, t.refl, t.inv, t.nr if d_ori is not None else None, S.rays, S.ray_id,
+                                                 t.bg, t.per_ray_bg, lvl == 0, False, t.rgb_lin, d_rgb, d_acc, d_ori,
+                                                 d_ori is not None)
+        d_rays = None
+        if t.per_ray_bg:
+            d_bg = (1 - t.acc)[:, None] * d_rgb
+            d_rays = self._env_bwd(S.rays if t.B == S.rays.shape[0] else S.rays[:t.B], t.rough, d_bg)
+        dV_rows = None
+        if view:
+            d_inc, d_brdf, dL, d_fd, dV = hip.shade_mix_bwd_view(t.V, t.f0, t.diff, t.cnt32, t.row_of_ray, t.L, t.incoming,
+                                                                 t.brdf, d_refl)
+            dV_rows = hip.segment_sum(dV, None, t.row_off, t.Mb, lanes=8)
+        else:
+            d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(t.V, t.f0, t.diff, t.cnt32, t.row_of_ray, t.L, t.incoming, t.brdf,
+                                                        d_refl)
+        rows6 = hip.segment_sum_wide(d_fd, 6, t.row_off, t.Mb)
+        # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
+        if t.idx_re is None and t.child is not None:
+            d_brays = self._bwd(t.child, d_inc, None, None)
+        elif t.idx_re is None:
+            d_brays = self._env_bwd(t.brays, t.mip, d_inc)
+        else:
+            d_brays = torch.zeros_like(t.brays)
+            if t.idx_re.shape[0] > 0:
+                d_brays.index_copy_(0, t.idx_re, self._bwd(t.child, d_inc[t.idx_re], None, None))
+            if t.idx_no.shape[0] > 0:
+                d_brays.index_copy_(0, t.idx_no, self._env_bwd(t.brays_no, t.mip_no, d_inc[t.idx_no]))
+        # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
+        d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp)
+        d_feat = hip.segment_sum_wide(d_xfeat, 24, t.row_off, t.Mb)
+        sobol = self.nerf.model.brdf_sampler.angs
+        if view:
+            d_nrv = hip.ggx_rays_bwd_view(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)
+            rows7 = hip.segment_sum_wide(d_nrv, 7, t.row_off, t.Mb)
+            dN, dr1 = rows7[:, 0:3], rows7[:, 3]
+            dV_rows = dV_rows + rows7[:, 4:7]
+        else:
+            d_nr = hip.ggx_rays_bwd(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)
+            rows4 = hip.segment_sum(d_nr, None, t.row_off, t.Mb, lanes=8)
+            dN, dr1 = rows4[:, 0:3], rows4[:, 3]
+        d_normals, d_heads, d_app = hip.bounce_prep_bwd(t.inv, t.nr, t.heads, S.ray_id, S.rays, t.conv, self.min_rough,
+                                                        self.detach_n, dN, dr1, rows6[:, 0:3], rows6[:, 3:6], d_feat,
+                                                        bidx=t.bidx, row_inputs=True)
+        hp, hW, hb = self.heads
+        d_app.add_(hip.heads_bwd(t.app, hW, hb, hp, d_heads, a.g_hW, a.g_hb))
+        self.app_segs.append((t.xyz_rows, None, None, None, None, None, d_app))
+        if self.detach_n:
+            d_normal = d_nrm
+        elif d_nrm is not None:
+            d_normal = d_normals.add_(d_nrm)
+        else:
+            d_normal = d_normals
+        d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
+        self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
+        if view:
+            ray_of_row = torch.index_select(S.ray_id, 0, t.bidx.long()).long()
+            if d_rays is None:
+                d_rays = torch.zeros_like(S.rays)
+            d_rays[:, 3:6].index_add_(0, ray_of_row, -dV_rows)
+        return d_rays
+
+    def _flush_walks(self):
+        rf, a = self.nerf.rf, self.acc
+        p, dpk, dlk, apl, ali, basis = rf._tables()
+        for segs, g_basis in ((self.dens_segs, None), (self.app_segs, a.g_basis)):
+            for i in range(0, len(segs), hip.VM_MAX_SEGMENTS):
+                hip.vm_query_bwd_segments(p, segs[i:i + hip.VM_MAX_SEGMENTS], dpk, dlk, apl, ali, basis, a.g_dpk, a.g_dlk,
+                                          a.g_apl, a.g_ali, g_basis)
+        self.dens_segs, self.app_segs = [], []
+
+    # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False):
+        """wts = (w_photo, w_l1, w_ori, w_acc).  Returns dict(loss 0-d tensor, kept, n_samples) -- loss None when the chunk
+        had no sample (train.py:567-568 skips it).  want_total: also evaluate the chunk's total loss value (the gradients do
+        not need it: every term enters linearly with a constant weight)."""
+        nerf = self.nerf
+        if not self.supported():
+            raise Unsupported("configuration")
+        rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
+        dev = rays.device
+        mods = [m for m in (rf, bgm, model.brdf, model.diffuse_module) if hasattr(m, "begin_pass")]
+        for m in mods:
+            m.begin_pass()
+        try:
+            if hasattr(noise, "begin_pass"):
+                noise.begin_pass()
+            rf._fwd_tables()
+            bgm._tables()
+            bgm.get_spherical_harmonics(100)
+            hp, hW, hb, _, _ = model.diffuse_module.head_pass()
+            self.heads = (hp, hW, hb)
+            self.mlp_ws, self.mlp_bias, _, _ = model.brdf.mlp_pass()
+            self.scale = float(rf.distance_scale)
+            self.anoise, self.min_rough, self.detach_n = float(model.anoise), float(model.min_rough), bool(model.detach_N)
+            self.near1 = 3 * float(hip.host(nerf.sampler.stepsize))
+            self.white = _white(dev)
+            self.dens_segs, self.app_segs = [], []
+            t = self._fwd(0, rays, focal, None, noise)
+            if t.M == 0:
+                return dict(loss=None, kept=t.B, n_samples=[0])
+            a = self._accumulators(dev)
+            b = t.rgb_map.shape[0]
+            gt_b = gt[:b].contiguous()
+            loss = hip.sqerr_fwd(t.rgb_map, gt_b)
+            total = None
+            if want_total:
+                dens = list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)
+                l1 = hip.l1_mean_fwd([x.detach() for x in dens])
+                total = hip.loss_mix_fwd([loss, l1, t.ori, t.acc], wts, inv_lbatch)
+            d_loss, _d_l1, d_ori, d_acc = hip.loss_mix_bwd([loss.shape, loss.shape, t.ori.shape, t.acc.shape], wts, inv_lbatch,
+                                                           _one(dev))
+            d_rgb = hip.sqerr_bwd(t.rgb_map, gt_b, d_loss)
+            self._bwd(t, d_rgb, d_acc, d_ori)
+            self._flush_walks()
+            self.n_loss_chunks += 1
+            self.l1_scale += float(wts[1]) * float(inv_lbatch)
+            return dict(loss=loss, total=total, kept=b, n_samples=t.n_samples)
+        finally:
+            for m in mods:
+                m.end_pass()
+
+    # ---- accumulators -> parameter gradients ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def end_step(self):
+        a = self.acc
+        if a is None:
+            return
+        nerf = self.nerf
+        rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
+        p = rf._tables()[0]
+        gp, gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk)
+        if self.l1_scale != 0.0:
+            dens = [x.detach() for x in list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)]
+            hip.l1_mean_bwd(dens, torch.full((), self.l1_scale, dtype=torch.float32, device=a.flat.device), out=gp + gl)
+        grads = list(zip(rf._param_list(), rf._grads_to_param_layout(gp, gl, a.g_apl, a.g_ali, a.g_basis)))
+        m = model.brdf.mlp
+        grads += list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
+        hps = model.diffuse_module._head_params()
+        for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
+            grads += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
+        if a.used_env:
+            act, sat, pole = bgm._tables()
+            sc = bgm._dev_scalars()
+            d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc)
+            grads.append((bgm.bg_mat, d_bg.reshape(bgm.bg_mat.shape)))
+            if bgm.brightness_lr != 0 or bgm.mul_lr != 0:           # lr 0 (microfacet_tensorf2.yaml:150-151): no update anyway
+                d_pre = d_bg / sc[2]
+                grads.append((bgm.brightness, d_pre.sum(dtype=torch.float64)))
+                grads.append((bgm.mul, (d_pre * bgm.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)))
+            grads.append((bgm.mipbias, a.d_mip.to(torch.float64).reshape(())))
+        for prm, g in grads:
+            if not prm.requires_grad:
+                continue
+            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+        self.acc = None
+
+
+_CONST = {}
+
+
+def _white(dev):
+    k = ("white", dev)
+    if k not in _CONST:
+        _CONST[k] = torch.ones((1, 3), dtype=torch.float32, device=dev)
+    return _CONST[k]
+
+
+def _one(dev):
+    k = ("one", dev)
+    if k not in _CONST:
+        _CONST[k] = torch.ones((), dtype=torch.float32, device=dev)
+    return _CONST[k]

@@ -5,11 +5,13 @@ batch and ONE RCCL all-reduce (sum) of the flat fp32 gradient precedes optimizer
 """
 import gc
 import math
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from .fast_step import Unsupported
 from .functional import LossMix, SquaredError
 from .optim import FusedAdam
 
@@ -177,6 +179,11 @@ class Trainer:
         self.ori_decay = math.exp(math.log(fo / self.ori_lambda) / n_it) if self.ori_lambda > 0 and fo is not None else 1.0
         self.pred_decay = math.exp(math.log(fp / self.pred_lambda) / n_it) if self.pred_lambda > 0 and fp is not None else 1.0
         self._make_optimizer()
+        # tape-free training pass (nmf_amd/fast_step.py): same kernels, no autograd engine; NMF_FAST_STEP=0 keeps autograd
+        self.fast = None
+        if os.environ.get("NMF_FAST_STEP", "1") != "0":
+            from .fast_step import TrainPass
+            self.fast = TrainPass(nerf)
         # The step allocates a few hundred short-lived Python containers; a full (generation-2) collection walks every
         # tracked object of the process (~270 k after importing torch: 70 ms measured, i.e. 13 steps).  Park what exists now
         # in the permanent generation so collections only look at what the steps create.
@@ -221,6 +228,9 @@ class Trainer:
         lbatch = global_rays if global_rays is not None else n_total * self.world_size
         pos, used_rays, losses, n_samples_last, n_chunks = 0, 0, [], None, 0
         bg = None
+        fast = self.fast if (self.fast is not None and self.fast.supported()) else None
+        if fast is not None:
+            fast.begin_step()
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
             if fetch is not None:
@@ -234,6 +244,28 @@ class Trainer:
             n_chunks += 1
             if trace is not None:
                 trace.append(dict(num_rays=chunk, rays_in=int(r.shape[0]), max_retrace=list(nerf.model.max_retrace_rays)))
+            if fast is not None:
+                try:
+                    out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
+                                     (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
+                                     want_total=trace is not None)
+                except Unsupported:
+                    out = None                      # this chunk goes through the autograd path below
+                if out is not None:
+                    n_samples = out["n_samples"]
+                    if trace is not None:
+                        trace[-1].update(n_samples=list(n_samples), kept=int(out["kept"]))
+                    if out["loss"] is None:
+                        continue
+                    if trace is not None:
+                        trace[-1]["total"] = out["total"]
+                    used_rays += out["kept"]
+                    losses.append(out["loss"])
+                    n_samples_last = n_samples
+                    if update_controllers:
+                        self.batch.update(out["kept"], n_samples[0])
+                        nerf.model.update_n_samples(n_samples[1:])
+                    continue
             ims, st = nerf(r, focal, bg_col=bg, is_train=True, ndc_ray=False, noise=noise)
             n_samples = st["n_samples"]
             if trace is not None:
@@ -266,6 +298,8 @@ class Trainer:
             if update_controllers:                                                               # train.py:618-627
                 self.batch.update(kept, n_samples[0])
                 nerf.model.update_n_samples(n_samples[1:])
+        if fast is not None:
+            fast.end_step()
         comm_bytes = self.reduce()
         if p.get("clip_grad") is not None:                                                       # train.py:744-745
             torch.nn.utils.clip_grad_norm_([q for q in nerf.parameters() if q.grad is not None], p["clip_grad"])

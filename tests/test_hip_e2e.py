@@ -749,11 +749,6 @@ def test_training_run_follows_the_reference_trace():
         opts.append(id(tr.optimizer))
         if it + 1 in [int(v) for v in g.np("psnr_at")]:
             psnrs.append(test_psnr())
-    # ---- schedule: exact
-    ref_lr = g.np("iter_lr")
-    assert np.allclose(np.asarray(lrs), ref_lr, rtol=1e-9, atol=0), "per-group learning rates"
-    assert grids[up - 1] == G0 and grids[up] == G1 and grids[-1] == G1, grids          # upsampled at the end of iteration `up`
-    assert len(set(opts[:up + 1])) == 1 and len(set(opts[up + 1:])) == 1 and opts[up] != opts[up + 1]
     # ---- controllers / bookkeeping per chunk
     ref_iter, ref_nr, ref_in = g.np("chunk_iter"), g.np("chunk_num_rays"), g.np("chunk_rays_in")
     ref_kept, ref_ns, ref_mr, ref_loss = g.np("chunk_kept"), g.np("chunk_n_samples"), g.np("chunk_max_retrace"), g.np("chunk_loss")
@@ -772,6 +767,12 @@ def test_training_run_follows_the_reference_trace():
     print("max relative parameter-norm difference per iteration:", np.round(drift.max(axis=1), 4).tolist())
     ref_ps = g.np("test_psnr")
     print("test PSNR per view:", np.round(np.asarray(psnrs), 3).tolist(), "reference:", np.round(ref_ps, 3).tolist())
+    # ---- schedule: exact
+    ref_lr = g.np("iter_lr")
+    assert np.allclose(np.asarray(lrs), ref_lr, rtol=1e-9, atol=0), "per-group learning rates"
+    # grid / optimizer are read AFTER each step here (the reference trace reads them inside Adam.step, before the restart)
+    assert grids[up - 1] == G0 and grids[up] == G1 and grids[-1] == G1, grids          # upsampled at the end of iteration `up`
+    assert len(set(opts[:up])) == 1 and len(set(opts[up:])) == 1 and opts[up - 1] != opts[up]
     # identical noise: the first iteration (before any shape of the stream can differ)
     first = [c for c in range(n_cmp) if chunks[c]["iter"] == 0]
     for c in first:
@@ -787,3 +788,53 @@ def test_training_run_follows_the_reference_trace():
     assert drift.max() <= 0.02, drift.max()
     assert np.all(np.abs(np.asarray(psnrs) - ref_ps) <= 0.25), (psnrs, ref_ps.tolist())
     assert abs(float(np.mean(psnrs[-1])) - float(ref_ps[-1].mean())) <= 0.1          # "PSNR after equal iterations"
+
+
+@pytest.mark.parametrize("phase", ["steady", "early", "steady_detachN", "two_chunks"])
+def test_tape_free_training_pass_equals_autograd_path(phase):
+    """nmf_amd/fast_step.py (the training pass as straight-line C-ABI calls, no autograd engine) against the autograd
+    operator graph it replaces: same model, same rays, same noise stream -> the same parameter gradients (atomics reorder
+    float sums, nothing else may differ), in the steady state (every secondary ray re-traced), in the early phase (argsort +
+    partial re-trace), with detached normals, and accumulated over two chunks of one optimizer step."""
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    grid_saved = bench.GRID
+    grads = {}
+    for mode in ("autograd", "tape_free"):
+        try:
+            bench.GRID = 64
+            torch.manual_seed(3)
+            nerf, params = bench.build(dev)
+        finally:
+            bench.GRID = grid_saved
+        if phase == "early":
+            nerf.model.max_retrace_rays = [1500]
+        nerf.model.detach_N = phase == "steady_detachN"
+        tr = Trainer(nerf, params)
+        if mode == "autograd":
+            tr.fast = None
+        else:
+            assert tr.fast is not None and tr.fast.supported()
+        tr.optimizer.step = lambda: None                      # keep the gradients, leave the parameters alone
+        n = 2048 if phase == "two_chunks" else 1024
+        rays, focal = synthetic.camera_rays(n, seed=21)
+        gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+        out = tr.step(rays.to(dev), gt, focal, noise=DeviceNoise(dev, seed=77, pooled=False), update_controllers=False,
+                      fixed_chunk=1024)
+        assert out["chunks"] == (2 if phase == "two_chunks" else 1)
+        grads[mode] = ({k: p.grad.detach().clone() for k, p in nerf.named_parameters() if p.grad is not None},
+                       out["n_samples"], out["loss"], out["rays"])
+    ga, gf = grads["autograd"], grads["tape_free"]
+    assert ga[1] == gf[1] and ga[3] == gf[3], (ga[1], gf[1])
+    assert abs(ga[2] - gf[2]) <= 1e-5 * abs(ga[2]), (ga[2], gf[2])
+    for k in ga[0]:
+        a, f = ga[0][k], gf[0].get(k)
+        if f is None:                                         # lr-0 scalars are not produced by the tape-free pass
+            assert k in ("bg_module.brightness", "bg_module.mul"), k
+            continue
+        assert a.shape == f.shape and a.stride() == f.stride(), (k, a.stride(), f.stride())
+        rel = float((a.double() - f.double()).norm() / a.double().norm().clip(min=1e-30))
+        assert rel <= 2e-5, (k, rel)
+    assert set(gf[0]) <= set(ga[0])

@@ -651,7 +651,10 @@ def test_vm_query_bf16_tables():
         assert torch.equal(a, b), what
     for a, b, what in zip(got, ref32, ("sigma_feat", "sigma", "grad", "normal", "app")):
         scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-2 * scale, (what, float((a - b).abs().max()), scale)
+        # bf16 keeps 8 significant bits (relative 2^-9 per table entry); unit normals divide by |grad|, which amplifies it
+        tol = 6e-2 if what == "normal" else 2e-2
+        assert float((a - b).abs().max()) <= tol * scale, (what, float((a - b).abs().max()), scale)
+        assert float((a - b).abs().mean()) <= 4e-3 * scale, (what, float((a - b).abs().mean()), scale)
     # through the module: forward on bf16, gradients from the fp32 walk
     sg, _, app, nrm = rf.query(xyz)
     (sg.sum() + app.sum() + nrm.sum()).backward()

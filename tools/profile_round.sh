@@ -38,9 +38,9 @@ print(open(sys.argv[2]).read()[:6000])
 PY
 # ---- counters, one group per run (rocprofv3 --pmc with --kernel-trace only; 8 SQ slots / 4 TCC slots per pass,
 #      FETCH_SIZE costs 3 TCC slots and WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots")
-GROUPS="FETCH_SIZE WRITE_SIZE SQ_WAVES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY,SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_INST_CYCLES_VMEM,SQ_ACTIVE_INST_LDS,SQ_INSTS_VMEM_WR TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum TCC_EA0_RDREQ_sum,TCC_EA0_WRREQ_sum,TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE,GRBM_COUNT"
+PMC_SETS="FETCH_SIZE WRITE_SIZE SQ_WAVES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_INSTS_VALU,SQ_INSTS_MFMA,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY,SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_INST_CYCLES_VMEM,SQ_ACTIVE_INST_LDS,SQ_INSTS_VMEM_WR TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum TCC_EA0_RDREQ_sum,TCC_EA0_WRREQ_sum,TCC_EA0_ATOMIC_sum GRBM_GUI_ACTIVE,GRBM_COUNT"
 i=0
-for G in $GROUPS; do
+for G in $PMC_SETS; do
   i=$((i+1))
   rm -rf /tmp/prof_pmc_$i
   rocprofv3 --pmc $(echo $G | tr ',' ' ') --kernel-trace --output-format csv -d /tmp/prof_pmc_$i -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/${TAG}_pmc_$i.log" 2>&1 || echo "counter group $G failed (see ${TAG}_pmc_$i.log)"
