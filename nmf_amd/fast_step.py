@@ -252,10 +252,14 @@ class TrainPass:
     def _flush_walks(self):
         rf, a = self.nerf.rf, self.acc
         p, dpk, dlk, apl, ali, basis = rf._tables()
-        for segs, g_basis in ((self.dens_segs, None), (self.app_segs, a.g_basis)):
-            for i in range(0, len(segs), hip.VM_MAX_SEGMENTS):
-                hip.vm_query_bwd_segments(p, segs[i:i + hip.VM_MAX_SEGMENTS], dpk, dlk, apl, ali, basis, a.g_dpk, a.g_dlk,
-                                          a.g_apl, a.g_ali, g_basis)
+        for all_segs, g_basis in ((self.dens_segs, None), (self.app_segs, a.g_basis)):
+            # one walk takes sample sets that carry the same adjoints (with detached normals the re-traced samples have no
+            # normal adjoint while the primary ones still have the orientation-loss term)
+            for key in dict.fromkeys(tuple(x is not None for x in sg[3:]) for sg in all_segs):
+                segs = [sg for sg in all_segs if tuple(x is not None for x in sg[3:]) == key]
+                for i in range(0, len(segs), hip.VM_MAX_SEGMENTS):
+                    hip.vm_query_bwd_segments(p, segs[i:i + hip.VM_MAX_SEGMENTS], dpk, dlk, apl, ali, basis, a.g_dpk,
+                                              a.g_dlk, a.g_apl, a.g_ali, g_basis)
         self.dens_segs, self.app_segs = [], []
 
     # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------
