@@ -192,8 +192,10 @@ def cpu_baseline(budget_s=150.0):
 
 
 def counters_summary():
-    """Counter-backed per-kernel figures written by tools/profile_round.sh at the profiled commit (rocprofv3 --pmc passes,
-    one counter group per run): profiles/<tag>_roofline.json.  bench.py combines them with the LIVE duration it measures."""
+    """Counter-backed per-kernel figures written by tools/profile_round.sh + tools/roofline_metrics.py at the profiled commit
+    (rocprofv3 --pmc passes, one counter group per run): profiles/<tag>_roofline.json.  The `roofline` object of the bench line
+    is computed from LIVE timings; these counters are reported beside it (`per_kernel`, `traffic`) with the tag / commit they
+    were taken at, so a reader can see that the live MFMA rate and the profiled SQ_VALU_MFMA_BUSY_CYCLES agree."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline.json")))
     if not files:
@@ -447,9 +449,11 @@ def main():
         ctr = counters_summary()
         traffic, per_kernel, ctr_meta = None, None, None
         if ctr is not None:
-            dom = ctr.get("kernels", {}).get("nmf_vm_query_bwd_segments", {})
-            traffic = dom.get("hbm_bytes_per_launch")
-            per_kernel = ctr.get("kernels")
+            ks = ctr.get("kernels", {})
+            traffic = ks.get("k_vm_bwd_brick<density>", {}).get("hbm_bytes_per_launch")
+            # counter-derived figures of every kernel of the step (bound = the largest of mfma_busy / valu_busy / l2 / hbm)
+            per_kernel = {k: dict(v.get("derived", {}), avg_launch_us=v.get("avg_launch_us")) for k, v in ks.items()
+                          if "derived" in v}
             ctr_meta = {k: ctr.get(k) for k in ("tag", "commit", "command")}
         out = {
             "metric": "train rays/sec (microfacet_tensorf2, 4096-ray chunks, steady state)",

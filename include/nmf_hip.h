@@ -295,10 +295,6 @@ int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const float* b, 
 int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
                   float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, const float* d_out,
                   float* d_feat, float* gW, float* gb, void* stream);
-/* MLPBRDF input rows X [R][66] = [feat_src[src_idx[r]] | ISH(half) | half | ISH(diff) | diff]
- * (modules/brdf.py:177-261 with feape=0, dotpe=-1, ListISH degs [0,1,2,4]; kappa = 1/(rough+1e-3)). */
-int nmf_brdf_features(const float* half_vec, const float* diff_vec, const float* feat_src,
-                      const float* rough_src, const int32_t* src_idx, int64_t R, float* X, void* stream);
 /* Fused MLPBRDF (modules/brdf.py:177-261): out[r] = sigmoid(MLP(X[r])[0:3] + out_bias) with X as above and
  * MLP = Linear(66,64) ReLU Linear(64,64) ReLU Linear(64,4) (weights row-major [out][in], torch layout).
  * Dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).  Nothing but out [R][3] is written. */

@@ -362,25 +362,6 @@ class EnvLookup(torch.autograd.Function):
         return None, d_dirs, None, None, holder.token_grad(d_out) if want_tab else None
 
 
-class BrdfFeatures(torch.autograd.Function):
-    """X[R,66] for the BRDF MLP; differentiable wrt the per-bounce-point feature rows only (the reference
-    detaches half/diff vectors and roughness, models/microfacet.py:461-472)."""
-
-    @staticmethod
-    def forward(ctx, half_vec, diff_vec, feat_rows, rough_rows, row_of_ray, row_offsets):
-        X = hip.brdf_features(half_vec.contiguous(), diff_vec.contiguous(), feat_rows.contiguous(),
-                              rough_rows.contiguous(), row_of_ray)
-        ctx.save_for_backward(row_offsets)
-        ctx.n_rows = feat_rows.shape[0]
-        return X
-
-    @staticmethod
-    def backward(ctx, dX):
-        (row_offsets,) = ctx.saved_tensors
-        d_feat = hip.segment_sum_wide(dX.contiguous(), 24, row_offsets, ctx.n_rows)
-        return None, None, d_feat, None, None, None
-
-
 class BrdfMLP(torch.autograd.Function):
     """sigmoid(MLP([feat | ISH(half) | half | ISH(diff) | diff])[:3] + bias) in one fused MFMA kernel
     (modules/brdf.py:177-261).  Differentiable wrt the per-bounce-point feature rows and, through the pass's ParamGrads

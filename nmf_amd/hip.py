@@ -64,7 +64,7 @@ EXPORTS = [
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
-    "nmf_select_bounces", "nmf_expand_segments", "nmf_brdf_features", "nmf_segment_sum_wide",
+    "nmf_select_bounces", "nmf_expand_segments", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
@@ -539,15 +539,6 @@ def expand_segments(offsets, n_seg, total):
     _check(_lib.nmf_expand_segments(_p(offsets, torch.int64), C.c_int64(n_seg), _p(seg), _p(loc), _stream()),
            "nmf_expand_segments")
     return seg, loc
-
-
-def brdf_features(half_vec, diff_vec, feat_src, rough_src, src_idx):
-    R = half_vec.shape[0]
-    X = torch.empty((R, 66), dtype=torch.float32, device=half_vec.device)
-    _check(_lib.nmf_brdf_features(_p(half_vec, torch.float32), _p(diff_vec, torch.float32), _p(feat_src, torch.float32),
-                                  _p(rough_src, torch.float32), _p(src_idx, torch.int32), C.c_int64(R), _p(X), _stream()),
-           "nmf_brdf_features")
-    return X
 
 
 def segment_sum_wide(vals, D, offsets, n_seg):

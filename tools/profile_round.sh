@@ -128,3 +128,4 @@ res["kernels"]["nmf_vm_query_bwd_segments"] = {
 json.dump(res, open(f"{out}/{tag}_roofline.json", "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_per_launch"} for k, v in kernels.items()}, indent=1)[:6000])
 PY
+python "$ROOT/tools/roofline_metrics.py" "$OUT/${TAG}_roofline.json"
