@@ -242,6 +242,16 @@ int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs
  * The dense ray_mask of the reference is the per-row prefix [0, counts[i]). */
 int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t mode, float mul,
                        float add, float sum_w, const float* sum_w_dev, int32_t* counts, void* stream);
+/* Normaliser of the level >= 1 selection above (pt_selectors.py:24-31), on the device in one launch:
+ * total = clip(float(sum(weights) + 1e-3 * (sum(u) + extra)), 1e-3), float64 sums.  `extra` = the caller's value for the sum
+ * of the uniforms at the culled entries of the dense matrix.  workspace3: 24 bytes the caller zeroes ONCE (the kernel leaves
+ * it zeroed).  The result is what nmf_select_bounces takes as sum_w_dev. */
+int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace3, float* total,
+                     void* stream);
+/* Adjoint of the bounce rows' view vector (V = -ray direction: bV = -viewdirs, models/microfacet.py:354) scattered to the
+ * rays: d_rays[ray_id[bidx[row]]][3..5] -= dv_a[row] (+ dv_b[row]); dv_* rows of pitch lda / ldb floats, dv_b nullable. */
+int nmf_view_adjoint_to_rays(const int32_t* ray_id, const int32_t* bidx, const float* dv_a, int32_t lda, const float* dv_b,
+                             int32_t ldb, int64_t Mb, float* d_rays, void* stream);
 /* seg_id[r] / local[r] for r in [offsets[i], offsets[i+1]) = i / r - offsets[i]  (= torch.where(ray_mask)). */
 int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_t* seg_id, int32_t* local,
                         void* stream);

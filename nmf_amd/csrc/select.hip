@@ -42,7 +42,75 @@ __global__ void __launch_bounds__(256) k_expand_segments(const int64_t* __restri
     }
 }
 
+// total = clip(float(sum(w) + 1e-3 * (sum(u) + extra)), 1e-3) with float64 sums: the normaliser of the level >= 1 bounce
+// selection (modules/pt_selectors.py:24-31: the dense weight matrix perturbed by 1e-3 U, then divided by its sum).  One
+// launch: every workgroup adds its partial sums to two float64 accumulators, the last one to arrive (ticket counter)
+// writes the result and resets the workspace {sum_w, sum_u, ticket} for the next call.
+__global__ void __launch_bounds__(256) k_select_total(const float* __restrict__ w, const float* __restrict__ u, int64_t M,
+                                                      double extra, double* __restrict__ ws, float* __restrict__ total) {
+    double a = 0.0, b = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) { a += (double)w[i]; b += (double)u[i]; }
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
+    __shared__ double sa[4], sb[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    atomicAdd(&ws[0], sa[0] + sa[1] + sa[2] + sa[3]);
+    atomicAdd(&ws[1], sb[0] + sb[1] + sb[2] + sb[3]);
+    __threadfence();
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws + 2);
+    if (atomicAdd(ticket, 1ull) + 1ull == (unsigned long long)gridDim.x) {
+        __threadfence();
+        const double sw = atomicAdd(&ws[0], 0.0), su = atomicAdd(&ws[1], 0.0);      // coherent reads of the final sums
+        *total = fmaxf((float)(sw + 1e-3 * (su + extra)), 1e-3f);
+        ws[0] = 0.0; ws[1] = 0.0; *ticket = 0ull;
+    }
+}
+
+// d_rays[ray_of(row)][3 + k] -= dv_a[row][k] + dv_b[row][k]: the adjoint of the rows' view vector V = -direction scattered
+// back onto the rays the rows belong to (ray_id[bidx[row]]); rows of one ray are few, plain atomics
+__global__ void __launch_bounds__(256) k_view_adjoint_to_rays(const int32_t* __restrict__ ray_id,
+                                                              const int32_t* __restrict__ bidx,
+                                                              const float* __restrict__ dv_a, int lda,
+                                                              const float* __restrict__ dv_b, int ldb, int64_t Mb,
+                                                              float* __restrict__ d_rays) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Mb) return;
+    const int64_t ray = ray_id[bidx[r]];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = dv_a[r * lda + k];
+        if (dv_b) v += dv_b[r * ldb + k];
+        if (v != 0.f) atomicAdd(&d_rays[ray * 6 + 3 + k], -v);
+    }
+}
+
 }  // namespace
+
+extern "C" int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace3,
+                                float* total, void* stream) {
+    NMF_REQUIRE(M > 0 && weights && u && workspace3 && total, NMF_EINVAL, "nmf_select_total: null / empty");
+    int64_t blocks = cdiv(M, 256 * 8);
+    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(k_select_total, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weights, u, M, extra,
+                       workspace3, total);
+    NMF_CHECK_LAUNCH("nmf_select_total");
+    return NMF_OK;
+}
+
+extern "C" int nmf_view_adjoint_to_rays(const int32_t* ray_id, const int32_t* bidx, const float* dv_a, int32_t lda,
+                                        const float* dv_b, int32_t ldb, int64_t Mb, float* d_rays, void* stream) {
+    NMF_REQUIRE(Mb >= 0, NMF_EINVAL, "nmf_view_adjoint_to_rays: Mb < 0");
+    if (Mb == 0) return NMF_OK;
+    NMF_REQUIRE(ray_id && bidx && dv_a && d_rays && lda >= 3 && (!dv_b || ldb >= 3), NMF_EINVAL,
+                "nmf_view_adjoint_to_rays: null");
+    hipLaunchKernelGGL(k_view_adjoint_to_rays, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, ray_id, bidx,
+                       dv_a, (int)lda, dv_b, (int)ldb, Mb, d_rays);
+    NMF_CHECK_LAUNCH("nmf_view_adjoint_to_rays");
+    return NMF_OK;
+}
 
 extern "C" int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t mode, float mul, float add,
                                   float sum_w, const float* sum_w_dev, int32_t* counts, void* stream) {

@@ -97,8 +97,8 @@ __device__ __forceinline__ float* pick3(const MPtrs3& a, int i) { return i == 0 
 //   DX[y][x] = sum_{i=0..4, j=0..4} kx[i][j] P[y+i-2][x+j-2];  kx rows 0 and 4 are zero, column 2 is zero
 //   ky = kx^T
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_plane(nmf_vm_params p, const float* __restrict__ P,
-                                                    float* __restrict__ out) {
+__device__ __forceinline__ void pack_plane(const nmf_vm_params& p, const float* __restrict__ P,
+                                           float* __restrict__ out) {
     const int G = p.grid;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over G*G*CD
     if (t >= (int64_t)G * G * CD) return;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_pack_plane(nmf_vm_params p, const float
     o[2 * CD + c] = dy;
 }
 
-__global__ void k_pack_line(nmf_vm_params p, const float* __restrict__ L, float* __restrict__ out) {
+__device__ __forceinline__ void pack_line(const nmf_vm_params& p, const float* __restrict__ L, float* __restrict__ out) {
     const int G = p.grid;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * CD) return;
@@ -141,9 +141,22 @@ __global__ void k_pack_line(nmf_vm_params p, const float* __restrict__ L, float*
     out[k * DL + CD + c] = d;
 }
 
+// all six tables of the field in ONE launch: blockIdx.y = 0..2 plane i, 3..5 line i (the line blocks beyond G*CD/256 exit)
+struct Pack6 {
+    const float* src[6];
+    float* dst[6];
+};
+__global__ void __launch_bounds__(256) k_pack_tables(nmf_vm_params p, Pack6 a) {
+    const int y = blockIdx.y;
+    const float* src = y == 0 ? a.src[0] : y == 1 ? a.src[1] : y == 2 ? a.src[2] : y == 3 ? a.src[3] : y == 4 ? a.src[4] : a.src[5];
+    float* dst = y == 0 ? a.dst[0] : y == 1 ? a.dst[1] : y == 2 ? a.dst[2] : y == 3 ? a.dst[3] : y == 4 ? a.dst[4] : a.dst[5];
+    if (y < 3) pack_plane(p, src, dst);
+    else pack_line(p, src, dst);
+}
+
 // transpose of the pack: gP = gdpk.P + corr^T(gdpk.DX) + corr^T(gdpk.DY)
-__global__ void __launch_bounds__(256) k_unpack_plane(nmf_vm_params p, const float* __restrict__ g,
-                                                      float* __restrict__ gP) {
+__device__ __forceinline__ void unpack_plane(const nmf_vm_params& p, const float* __restrict__ g,
+                                             float* __restrict__ gP) {
     const int G = p.grid;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)G * G * CD) return;
@@ -168,7 +181,7 @@ __global__ void __launch_bounds__(256) k_unpack_plane(nmf_vm_params p, const flo
     gP[((int64_t)y * G + x) * CD + c] = acc;
 }
 
-__global__ void k_unpack_line(nmf_vm_params p, const float* __restrict__ g, float* __restrict__ gL) {
+__device__ __forceinline__ void unpack_line(const nmf_vm_params& p, const float* __restrict__ g, float* __restrict__ gL) {
     const int G = p.grid;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * CD) return;
@@ -180,6 +193,14 @@ __global__ void k_unpack_line(nmf_vm_params p, const float* __restrict__ g, floa
         if (i != 2 && kk >= 0 && kk < G) acc += p.stencil[i] * g[kk * DL + CD + c];
     }
     gL[k * CD + c] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_tables(nmf_vm_params p, Pack6 a) {
+    const int y = blockIdx.y;
+    const float* src = y == 0 ? a.src[0] : y == 1 ? a.src[1] : y == 2 ? a.src[2] : y == 3 ? a.src[3] : y == 4 ? a.src[4] : a.src[5];
+    float* dst = y == 0 ? a.dst[0] : y == 1 ? a.dst[1] : y == 2 ? a.dst[2] : y == 3 ? a.dst[3] : y == 4 ? a.dst[4] : a.dst[5];
+    if (y < 3) unpack_plane(p, src, dst);
+    else unpack_line(p, src, dst);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,12 +1011,12 @@ extern "C" int nmf_vm_pack_density(const nmf_vm_params* p, const float* const pl
     NMF_REQUIRE(p->grid >= 2 && p->grid <= 4096, NMF_ERANGE, "nmf_vm_pack_density: grid");
     const int G = p->grid;
     const int64_t n = (int64_t)G * G * CD;
+    Pack6 a;
     for (int i = 0; i < 3; ++i) {
-        hipLaunchKernelGGL(k_pack_plane, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *p, planes[i],
-                           dpk[i]);
-        hipLaunchKernelGGL(k_pack_line, dim3((unsigned)cdiv(G * CD, 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                           lines[i], dlk[i]);
+        a.src[i] = planes[i]; a.dst[i] = dpk[i];
+        a.src[3 + i] = lines[i]; a.dst[3 + i] = dlk[i];
     }
+    hipLaunchKernelGGL(k_pack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a);
     NMF_CHECK_LAUNCH("nmf_vm_pack_density");
     return NMF_OK;
 }
@@ -1007,12 +1028,12 @@ extern "C" int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* c
                 "nmf_vm_unpack_density_grad: null");
     const int G = p->grid;
     const int64_t n = (int64_t)G * G * CD;
+    Pack6 a;
     for (int i = 0; i < 3; ++i) {
-        hipLaunchKernelGGL(k_unpack_plane, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *p, g_dpk[i],
-                           g_planes[i]);
-        hipLaunchKernelGGL(k_unpack_line, dim3((unsigned)cdiv(G * CD, 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                           g_dlk[i], g_lines[i]);
+        a.src[i] = g_dpk[i]; a.dst[i] = g_planes[i];
+        a.src[3 + i] = g_dlk[i]; a.dst[3 + i] = g_lines[i];
     }
+    hipLaunchKernelGGL(k_unpack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a);
     NMF_CHECK_LAUNCH("nmf_vm_unpack_density_grad");
     return NMF_OK;
 }

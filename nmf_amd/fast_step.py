@@ -103,8 +103,12 @@ class TrainPass:
         if lvl == 0:
             counts = hip.select_bounces(w, noise.uniform((M,)).contiguous(), 0, float(model.rays_per_ray))
         else:
-            u, u_total = noise.select_dense(S.b, S.N, S.ray_id, S.step_id)
-            total = (w.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
+            if hasattr(noise, "select_dense_parts"):        # device noise: the normaliser in one launch (nmf_select_total)
+                u, extra = noise.select_dense_parts(S.b, S.N, M)
+                total = hip.select_total(w, u.contiguous(), extra)
+            else:
+                u, u_total = noise.select_dense(S.b, S.N, S.ray_id, S.step_id)
+                total = (w.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
             nb = model.max_brdf_rays[lvl] - M
             if nb > 0:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(nb), 1.0, total)
@@ -222,8 +226,7 @@ class TrainPass:
         if view:
             d_nrv = hip.ggx_rays_bwd_view(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)
             rows7 = hip.segment_sum_wide(d_nrv, 7, t.row_off, t.Mb)
-            dN, dr1 = rows7[:, 0:3], rows7[:, 3]
-            dV_rows = dV_rows + rows7[:, 4:7]
+            dN, dr1, dV_ggx = rows7[:, 0:3], rows7[:, 3], rows7[:, 4:7]
         else:
             d_nr = hip.ggx_rays_bwd(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)
             rows4 = hip.segment_sum(d_nr, None, t.row_off, t.Mb, lanes=8)
@@ -242,11 +245,10 @@ class TrainPass:
             d_normal = d_normals
         d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
         self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
-        if view:
-            ray_of_row = torch.index_select(S.ray_id, 0, t.bidx.long()).long()
+        if view:        # V_row = -direction of the row's ray: both view adjoints back onto the rays, one launch
             if d_rays is None:
                 d_rays = torch.zeros_like(S.rays)
-            d_rays[:, 3:6].index_add_(0, ray_of_row, -dV_rows)
+            hip.view_adjoint_to_rays(S.ray_id, t.bidx, dV_rows, dV_ggx, d_rays)
         return d_rays
 
     def _flush_walks(self):

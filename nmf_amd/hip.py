@@ -64,7 +64,7 @@ EXPORTS = [
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
-    "nmf_select_bounces", "nmf_expand_segments", "nmf_segment_sum_wide",
+    "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
@@ -531,6 +531,30 @@ def select_bounces(weights, u, mode, mul, add=0.0, sum_w=1.0):
                                    _p(dev_sum, torch.float32), _p(counts), _stream()),
            "nmf_select_bounces")
     return counts
+
+
+_select_ws = {}
+
+
+def select_total(weights, u, extra):
+    """-> 0-d fp32 device tensor clip(float(sum(w) + 1e-3 * (sum(u) + extra)), 1e-3) (one launch, float64 sums)"""
+    dev = weights.device
+    ws = _select_ws.get(dev)
+    if ws is None:
+        ws = _select_ws[dev] = torch.zeros(3, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+    total = torch.empty((), dtype=torch.float32, device=dev)
+    _check(_lib.nmf_select_total(_p(weights, torch.float32), _p(u, torch.float32), C.c_int64(weights.shape[0]),
+                                 C.c_double(float(extra)), _p(ws), _p(total), _stream()), "nmf_select_total")
+    return total
+
+
+def view_adjoint_to_rays(ray_id, bidx, dv_a, dv_b, d_rays):
+    """d_rays [B,6] (columns 3..5) -= per-row view adjoints dv_a [Mb,>=3] (+ dv_b), rows may be column slices"""
+    Mb = bidx.shape[0]
+    (pa, la) = _rows(dv_a, 3)
+    (pb, lb) = _rows(dv_b, 3) if dv_b is not None else (None, 3)
+    _check(_lib.nmf_view_adjoint_to_rays(_p(ray_id, torch.int32), _p(bidx, torch.int32), pa, C.c_int32(la), pb, C.c_int32(lb),
+                                         C.c_int64(Mb), _p(d_rays, torch.float32), _stream()), "nmf_view_adjoint_to_rays")
 
 
 def expand_segments(offsets, n_seg, total):

@@ -162,8 +162,12 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
             rpr = self.rays_per_ray if is_train else self.test_rays_per_ray
             counts = hip.select_bounces(w_det, noise.uniform((M,)).contiguous(), 0, float(rpr))
         else:
-            u, u_total = noise.select_dense(samples.b, samples.N, samples.ray_id, samples.step_id)
-            total = (w_det.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
+            if hasattr(noise, "select_dense_parts"):        # device noise: the normaliser in one launch (nmf_select_total)
+                u, extra = noise.select_dense_parts(samples.b, samples.N, M)
+                total = hip.select_total(w_det, u.contiguous(), extra)
+            else:
+                u, u_total = noise.select_dense(samples.b, samples.N, samples.ray_id, samples.step_id)
+                total = (w_det.sum(dtype=torch.float64) + 1e-3 * u_total).float().clip(min=1e-3)
             Nbudget = self.max_brdf_rays[recur] - M
             if Nbudget > 0:
                 counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, total)

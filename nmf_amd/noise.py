@@ -72,15 +72,19 @@ class DeviceNoise:
     def skip(self, kind, shape):
         return None
 
-    def select_dense(self, b, N, ray_id, step_id):
-        """U at the kept entries of the dense [b,N] matrix + sum of U over ALL b*N entries
-        (modules/pt_selectors.py:24 perturbs the dense weight matrix).  The dropped entries only enter
-        through their sum, which is drawn from its exact large-n normal limit."""
-        M = ray_id.shape[0]
+    def select_dense_parts(self, b, N, M):
+        """U at the M kept entries of the dense [b,N] matrix + the SUM of U over the b*N - M dropped entries as a host
+        float (modules/pt_selectors.py:24 perturbs the dense weight matrix).  The dropped entries only enter through their
+        sum, which is drawn from its exact large-n normal limit."""
         u = self.uniform((M,))
         n_drop = b * N - M
         extra = 0.5 * n_drop + math.sqrt(max(n_drop, 0) / 12.0) * random.Random(self.calls * 1000003 + self.seed).gauss(0.0, 1.0)
         self.calls += 1
+        return u, extra
+
+    def select_dense(self, b, N, ray_id, step_id):
+        """-> (u [M], sum of U over ALL b*N entries as a float64 device scalar)"""
+        u, extra = self.select_dense_parts(b, N, ray_id.shape[0])
         return u, u.sum(dtype=torch.float64) + extra
 
 

@@ -763,8 +763,12 @@ def test_training_run_follows_the_reference_trace():
                     f"{ch['max_retrace'][0]:5d}/{int(ref_mr[c]):5d} loss {float(ch.get('total', float('nan'))):.5f}/{float(ref_loss[c]):.5f}")
     print("\n".join(rows))
     ref_pn = g.np("iter_param_norm")
-    drift = np.abs(np.asarray(pnorm) - ref_pn) / np.maximum(ref_pn, 1e-3)
-    print("max relative parameter-norm difference per iteration:", np.round(drift.max(axis=1), 4).tolist())
+    # parameter norms: 2 % of the norm + 3e-3 absolute (bias vectors start at zero and random-walk to ~1e-2 in 40 steps)
+    drift = np.abs(np.asarray(pnorm) - ref_pn) / (ref_pn + 0.15)
+    print("max parameter-norm difference per iteration (|a-b| / (|b| + 0.15)):", np.round(drift.max(axis=1), 4).tolist())
+    worst = np.argsort(-drift[-1])[:5]
+    print("largest at the last iteration:", [(pnames[i], round(float(np.asarray(pnorm)[-1][i]), 5), round(float(ref_pn[-1][i]), 5))
+                                            for i in worst])
     ref_ps = g.np("test_psnr")
     print("test PSNR per view:", np.round(np.asarray(psnrs), 3).tolist(), "reference:", np.round(ref_ps, 3).tolist())
     # ---- schedule: exact

@@ -1209,3 +1209,35 @@ def test_march_16_lanes_per_ray_equals_64(is_train, explicit, monkeypatch):
     assert int(outs["64"][1].sum()) > 1000 and int(outs["64"][1][5]) == 0
     for x, y in zip(outs["64"], outs["16"]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_select_total_and_view_adjoint_scatter():
+    """the two glue kernels of the level >= 1 pass: nmf_select_total (normaliser of pt_selectors.py:24-31, float64 sums, one
+    launch, self-resetting workspace) and nmf_view_adjoint_to_rays (row view adjoints back onto their rays)"""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(9)
+    for M in (1, 777, 300001):
+        w = torch.rand(M, generator=gen) ** 4
+        u = torch.rand(M, generator=gen)
+        extra = 12345.678
+        for _ in range(2):                                    # twice: the workspace must come back zeroed
+            got = hip.select_total(w.to(DEV), u.to(DEV), extra)
+            ref = (w.double().sum() + 1e-3 * (u.double().sum() + extra)).float().clip(min=1e-3)
+            assert got.shape == () and abs(float(got) - float(ref)) <= 1.2e-7 * abs(float(ref)), (M, float(got), float(ref))
+    assert float(hip.select_total(torch.zeros(5, device=DEV), torch.zeros(5, device=DEV), 0.0)) == pytest.approx(1e-3)
+    B, Msmp, Mb = 50, 400, 120
+    ray_id = torch.sort(torch.randint(0, B, (Msmp,), generator=gen)).values.int()
+    bidx = torch.sort(torch.randperm(Msmp, generator=gen)[:Mb]).values.int()
+    a, b7 = torch.randn(Mb, 3, generator=gen), torch.randn(Mb, 7, generator=gen)
+    d_rays = torch.randn(B, 6, generator=gen)
+    ref = d_rays.clone()
+    ref[:, 3:6].index_add_(0, ray_id[bidx.long()].long(), -(a + b7[:, 4:7]))
+    out = d_rays.clone().to(DEV)
+    hip.view_adjoint_to_rays(ray_id.to(DEV), bidx.to(DEV), a.to(DEV), b7.to(DEV)[:, 4:7], out)
+    assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5, what="view adjoint scatter")
+    out2 = d_rays.clone().to(DEV)
+    hip.view_adjoint_to_rays(ray_id.to(DEV), bidx.to(DEV), a.to(DEV), None, out2)
+    ref2 = d_rays.clone()
+    ref2[:, 3:6].index_add_(0, ray_id[bidx.long()].long(), -a)
+    assert_close(out2.cpu(), ref2, rtol=1e-5, atol=1e-5, what="view adjoint scatter, one operand")
