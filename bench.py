@@ -39,10 +39,15 @@ FRAME = 800
 G_DENSITY, G_APP = 1152 + 1920, 1728
 BWD_BYTES_DENSITY, BWD_BYTES_APP = 3 * G_DENSITY, 3 * G_APP
 HBM_PEAK_GBS = 8000.0
-# The dominant kernel (k_vm_bwd_brick) performs the scatter-add of the table gradients on the matrix cores: per 4 samples
-# 3 planes x 20 (density: value + 2 derivative taps, + the 2 line tiles) / 3 x 18 (appearance) v_mfma_f32_16x16x4_f32 of
-# 16*16*4*2 = 2048 FLOP each, issued at 32 cycles/SIMD (MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense).
-MFMA_FLOP_DENSITY, MFMA_FLOP_APP = 3 * 20 * 2048 / 4, 3 * 18 * 2048 / 4
+# The dominant kernel (k_vm_bwd_brick) performs the scatter-add of the table gradients on the matrix cores.  Per group of 4
+# samples and per plane/line pair it issues NRB row blocks x (value + 2 derivative taps) + 2 line tiles (density), or
+# NRB x 2 channel halves + 2 line tiles (appearance; + 4 for the basis matrix once per group) v_mfma_f32_16x16x4_f32 of
+# 16*16*4*2 = 2048 FLOP each.  NRB = ceil((BR+1)^2 / 16) = 2 for the 4^3 bricks of vm.hip (it was 6 with the 8^3 bricks
+# of the r02_b profile: a third of the matrix instructions per sample now, so `achieved` counts ISSUED FLOP and fell with
+# them while the launch got 1.5x faster).  f32-input MFMA peak = 157.3 TFLOP/s dense (MI355X_MICROARCH.md).
+VM_BWD_NRB = 2
+MFMA_FLOP_DENSITY = 3 * (3 * VM_BWD_NRB + 2) * 2048 / 4
+MFMA_FLOP_APP = (3 * (2 * VM_BWD_NRB + 2) + 4) * 2048 / 4
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 

@@ -356,13 +356,15 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 // A per-sample scatter with global atomics (768 density + 432 appearance adds per sample) runs at
 // ~14 G atomics/s on MI355X -- device-scope float atomics execute at the memory side -- i.e. ~90 ms
 // for the 1.1 M samples of a steady-state step.  Instead the samples are counting-sorted by the
-// 8x8x8-voxel brick of their lower corner (k_brick_hist / k_scan_bins / k_brick_scatter); one
-// workgroup then owns one brick and accumulates every gradient that brick can touch -- three 9x9
-// plane tiles (density: 48 ch, appearance: 24 ch) and three 9-entry line segments -- ON THE MATRIX
-// CORES (see k_vm_bwd_brick), flushing the non-zero entries once (~80x fewer global atomics).
+// BR^3-voxel brick of their lower corner (k_brick_hist / k_bins_partial+k_bins_final / k_brick_scatter);
+// a wave then owns a slice of one brick and accumulates every gradient that brick can touch -- three
+// TLxTL plane tiles (density: 48 ch, appearance: 24 ch) and three TL-entry line segments -- ON THE
+// MATRIX CORES (see k_vm_bwd_brick), flushing the non-zero entries once.  BR = 4 (TL = 5): a 25-cell
+// tile is 2 MFMA row blocks of 16, against 6 for the 81 cells of an 8^3 brick, so the walk issues a
+// third of the matrix instructions per sample for ~2x the flush atomics (measured 498 -> 318 us).
 // ------------------------------------------------------------------------------------------------
 constexpr int BASIS_COPIES = 16;   // scratch copies of the basis_mat gradient (power of two), see vm_bwd_app2
-constexpr int BR = 8;             // brick edge in texels
+constexpr int BR = 4;             // brick edge in texels (R2: 4 -> 5x5 = 25 tile cells = 2 MFMA row blocks instead of 6)
 constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
 
 __device__ __forceinline__ int axis_floor(const nmf_vm_params& p, float xn_a) {
@@ -457,64 +459,101 @@ __global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, Segs sg, in
     if (r.head) atomicAdd(counts + b * kc + bin_copy(kc), r.len);
 }
 
-// single-workgroup exclusive scan of n int32 counts -> offsets[n+1]; also copies offsets into cursor[n] and builds the
-// work-item list of the backward walk: brick b with c samples becomes ceil(c / item) items (b, t) covering samples
-// [offsets[b] + t*item, +item).  Only non-empty bricks produce items, items are equally sized, and consecutive items
-// (= consecutive workgroups) land on consecutive XCDs, so the hot surface bricks are spread over the whole chip
-// instead of following the brick index -> XCD round-robin of a dense (brick, part) grid.
-__global__ void __launch_bounds__(1024) k_scan_bins(const int32_t* __restrict__ counts, int n, int kc,
-                                                    int32_t* __restrict__ offsets, int32_t* __restrict__ cursor,
-                                                    int item, int2* __restrict__ items, int32_t* __restrict__ n_items) {
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        int c = 0, ck[4] = {0, 0, 0, 0};
-        if (i < n) {
-            if (kc == 4) {
-                const int4 v4 = reinterpret_cast<const int4*>(counts)[i];
-                ck[0] = v4.x; ck[1] = v4.y; ck[2] = v4.z; ck[3] = v4.w;
-                c = v4.x + v4.y + v4.z + v4.w;
-            } else {
-                for (int k = 0; k < kc; ++k) c += counts[i * kc + k];
-            }
-        }
-        const int ni = (c + item - 1) / item;
-        const int64_t v = (int64_t)c | ((int64_t)ni << 32);          // low word: samples, high word: items
-        int64_t incl = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            int64_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        int64_t woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wsum[w];
-        const int64_t excl = carry_s + woff + incl - v;
-        const int so = (int)(excl & 0xffffffffll), io = (int)(excl >> 32);
-        if (i < n) {
-            offsets[i] = so;
-            if (kc == 4) {
-                reinterpret_cast<int4*>(cursor)[i] = make_int4(so, so + ck[0], so + ck[0] + ck[1], so + ck[0] + ck[1] + ck[2]);
-            } else {
-                int run = so;
-                for (int k = 0; k < kc; ++k) {
-                    cursor[i * kc + k] = run;
-                    run += counts[i * kc + k];
-                }
-            }
-            for (int t = 0; t < ni; ++t) items[io + t] = make_int2(i, t);
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
+// Exclusive scan of the n brick counts -> offsets[n+1], the scatter cursors, and the work-item list of the backward walk:
+// brick b with c samples becomes ceil(c / item) items (b, t) covering samples [offsets[b] + t*item, +item).  Only
+// non-empty bricks produce items, items are equally sized, and consecutive items land on consecutive XCDs, so the hot
+// surface bricks are spread over the whole chip instead of following the brick index -> XCD round-robin.
+// Two launches over chunks of 4096 bricks (R2: with 4^3 bricks there are 32 k bricks at 128^3 and 422 k at 300^3; the
+// single-workgroup scan of round 1 took 57 us / 372 us there): k_bins_partial sums each chunk (samples | items packed in
+// one int64), k_bins_final lets every chunk add up the totals before it and scan itself.
+constexpr int SB_THREADS = 1024, SB_PER = 4, SB_CHUNK = SB_THREADS * SB_PER;
+
+__device__ __forceinline__ int brick_count(const int32_t* __restrict__ counts, int i, int kc, int (&ck)[8]) {
+    int c = 0;
+    if (kc == 4) {
+        const int4 v4 = reinterpret_cast<const int4*>(counts)[i];
+        ck[0] = v4.x; ck[1] = v4.y; ck[2] = v4.z; ck[3] = v4.w;
+        c = v4.x + v4.y + v4.z + v4.w;
+    } else {
+        for (int k = 0; k < kc; ++k) { ck[k] = counts[i * kc + k]; c += ck[k]; }
     }
-    if (tid == 0) {
-        offsets[n] = (int)(carry_s & 0xffffffffll);
-        *n_items = (int)(carry_s >> 32);
+    return c;
+}
+
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t* ws) {       // all threads get the block total
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if (lane == 0) ws[wid] = v;
+    __syncthreads();
+    int64_t t = 0;
+    for (int w = 0; w < SB_THREADS / 64; ++w) t += ws[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(SB_THREADS) k_bins_partial(const int32_t* __restrict__ counts, int n, int kc, int item,
+                                                             int64_t* __restrict__ chunk_tot) {
+    __shared__ int64_t ws[SB_THREADS / 64];
+    const int i0 = blockIdx.x * SB_CHUNK + threadIdx.x * SB_PER;
+    int64_t v = 0;
+    int ck[8];
+#pragma unroll
+    for (int q = 0; q < SB_PER; ++q) {
+        if (i0 + q < n) {
+            const int c = brick_count(counts, i0 + q, kc, ck);
+            v += (int64_t)c | ((int64_t)((c + item - 1) / item) << 32);
+        }
+    }
+    const int64_t t = block_sum_i64(v, ws);
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __restrict__ counts, int n, int kc,
+                                                           const int64_t* __restrict__ chunk_tot,
+                                                           int32_t* __restrict__ offsets, int32_t* __restrict__ cursor,
+                                                           int item, int2* __restrict__ items,
+                                                           int32_t* __restrict__ n_items) {
+    __shared__ int64_t ws[SB_THREADS / 64];
+    __shared__ int64_t wsum[SB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // totals of the chunks before this one (at most a few hundred values)
+    int64_t before = 0;
+    for (int c = tid; c < (int)blockIdx.x; c += SB_THREADS) before += chunk_tot[c];
+    const int64_t carry = block_sum_i64(before, ws);
+    const int i0 = blockIdx.x * SB_CHUNK + tid * SB_PER;
+    int c[SB_PER], ni[SB_PER], ck[SB_PER][8];
+    int64_t v = 0;
+#pragma unroll
+    for (int q = 0; q < SB_PER; ++q) {
+        c[q] = 0;
+        if (i0 + q < n) c[q] = brick_count(counts, i0 + q, kc, ck[q]);
+        ni[q] = (c[q] + item - 1) / item;
+        v += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    int64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    int64_t run = carry + woff + incl - v;
+#pragma unroll
+    for (int q = 0; q < SB_PER; ++q) {
+        if (i0 + q < n) {
+            const int so = (int)(run & 0xffffffffll), io = (int)(run >> 32);
+            offsets[i0 + q] = so;
+            int pos = so;
+            for (int k = 0; k < kc; ++k) { cursor[(i0 + q) * kc + k] = pos; pos += ck[q][k]; }
+            for (int t = 0; t < ni[q]; ++t) items[io + t] = make_int2(i0 + q, t);
+        }
+        run += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == SB_THREADS - 1) {       // the last thread of the last chunk holds the grand total
+        offsets[n] = (int)(run & 0xffffffffll);
+        *n_items = (int)(run >> 32);
     }
 }
 
@@ -607,18 +646,18 @@ __global__ void __launch_bounds__(256) k_basis_reduce(const float* __restrict__ 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BWD_THREADS = 64;               // one single-wave workgroup per (brick, part, plane/line pair)
-constexpr int NRB = 6;                       // 81 tile cells -> 6 row blocks of 16
+constexpr int NRB = (TL * TL + 15) / 16;     // tile cells -> row blocks of 16 (BR 8: 81 -> 6, BR 4: 25 -> 2)
 constexpr int BWD_ITEM = 256;                // samples per work item (brick slice); 128 below 400 k samples
 constexpr int BWD_ITEM_MIN = 64;             // smallest item size the workspace is sized for (tuning knob)
 
 // Scatter-add on the matrix cores.
 //
-// Inside one 8^3 brick every gradient tile is small and dense (a 9x9 plane tile x 48 / 24 channels, a 9-entry line
+// Inside one BR^3 brick every gradient tile is small and dense (a TLxTL plane tile x 48 / 24 channels, a TL-entry line
 // segment x 32 / 24 channels), and the update   G[cell][ch] += w(sample, cell) * adj(sample, ch)   is the product of a
 // sparse [cells x samples] weight matrix (4 non-zeros per column) with a dense [samples x channels] adjoint matrix.
 // LDS float atomics run at ~0.2 lane-ops/clk/CU on gfx950 (measured: 17 ms per 1 M samples, 36 ds_add_f32 per sample),
 // so the accumulation is done with v_mfma_f32_16x16x4_f32 instead: exact fp32, K = 4 samples per instruction, the
-// 18 (+2) accumulator tiles of a plane live in AGPRs for the whole work item, no atomics until the final flush.
+// NRB x 3 (+2) accumulator tiles of a plane live in AGPRs for the whole work item, no atomics until the final flush.
 // The 95 % zero products are free: the matrix pipe is otherwise idle here.
 //
 // Lane mapping of a wave: k = lane >> 4 is the sample of the current group of 4, j = lane & 15 is a channel (B operand)
@@ -964,8 +1003,10 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
     }
 }
 
-// one launch for both halves: blockIdx.x = work item (brick, 512-sample slice), blockIdx.y = density planes 0-2 /
-// appearance planes 3-5, so all six latency-bound walks of an item overlap; single-wave workgroups
+// one launch for both halves: blockIdx.x strides over the work items (brick, BWD_ITEM-sample slice) -- a persistent
+// loop, the grid is capped at 16 k workgroups so that 300^3 (where most of the 422 k bricks hold a handful of samples)
+// does not pay one workgroup launch per item --, blockIdx.y = density planes 0-2 / appearance planes 3-5, so all six
+// latency-bound walks of an item overlap; single-wave workgroups
 template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
@@ -977,16 +1018,20 @@ __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, c
                                                               const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
                                                               MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
                                                               int z_density, int z_app) {
-    if ((int)blockIdx.x >= *n_items) return;
-    const int2 it = items[blockIdx.x];
-    const int brick = it.x;
-    const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
+    // The item count lives on the device; the grid is a fixed number of single-wave workgroups that stride over the list
+    // (a grid sized by the host-side upper bound -- non-empty bricks <= all bricks -- would be 100 k-1 M mostly idle
+    // workgroups with 4^3 bricks)
+    __shared__ float4 lds[64 * 16];
+    const int n = *n_items;
     const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
-    {
-        __shared__ float4 lds[64 * 16];
+    for (int item = (int)blockIdx.x; item < n; item += (int)gridDim.x) {
+        const int2 it = items[item];
+        const int brick = it.x;
+        const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
         if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
         else if (half == z_app)
             vm_bwd_app2(p, rec0, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
+        __syncthreads();
     }
 }
 
@@ -1098,7 +1143,8 @@ extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
     const int64_t nb = nbx * nbx * nbx;
     const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
     const int64_t kc = bin_copies(nb);
-    return (M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) + 2 * M * (int64_t)sizeof(float4) +
+    return (M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) +
+           ((nb + SB_CHUNK - 1) / SB_CHUNK + 1) * (int64_t)sizeof(int64_t) + 2 * M * (int64_t)sizeof(float4) +
            M * (3 * CA + AD) * (int64_t)sizeof(float) + BASIS_COPIES * AD * 3 * CA * (int64_t)sizeof(float) + 64;
 }
 
@@ -1163,13 +1209,18 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
     if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
     item_size = (item_size + 3) & ~3;
     const int64_t max_items = M / item_size + nb + 1;
-    int2* items = (int2*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [max_items]
+    const int n_chunks_ws = (nb + SB_CHUNK - 1) / SB_CHUNK;
+    int64_t* chunk_tot = (int64_t*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [n_chunks] (samples | items) per 4096 bricks
+    int2* items = (int2*)(chunk_tot + n_chunks_ws);                            // [max_items]
     const bool use_copies = want_a && g_basis;
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc +
                                   (use_copies ? sizeof(float) * BASIS_COPIES * AD * 3 * CA : 0), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, nbx, kc, counts, brick_id);
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, kc, offsets, cursor, item_size, items, n_items);
+    const int n_chunks = (nb + SB_CHUNK - 1) / SB_CHUNK;
+    hipLaunchKernelGGL(k_bins_partial, dim3(n_chunks), dim3(SB_THREADS), 0, st, counts, nb, kc, item_size, chunk_tot);
+    hipLaunchKernelGGL(k_bins_final, dim3(n_chunks), dim3(SB_THREADS), 0, st, counts, nb, kc, chunk_tot, offsets, cursor,
+                       item_size, items, n_items);
     // 16-byte aligned record arrays behind the integer scratch
     uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
     float4* rec0 = (float4*)rp;
@@ -1186,7 +1237,8 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
                            cursor, rec0, rec1, d_app_sorted, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    const dim3 grid((unsigned)max_items, (unsigned)(3 * nz)), block(BWD_THREADS);
+    const int64_t grid_x = max_items < 16384 ? max_items : 16384;       // 64 single-wave workgroups per CU and plane
+    const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);
 #define NMF_LAUNCH_BWD(WN)                                                                                            \
     hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
                        mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \

@@ -787,9 +787,20 @@ def test_training_run_follows_the_reference_trace():
     # the whole run: same number of chunks per iteration, controllers within a few per cent, loss level, parameters, PSNR
     assert len(chunks) == len(ref_iter) and [c["iter"] for c in chunks] == [int(v) for v in ref_iter]
     nr = np.asarray([c["num_rays"] for c in chunks], dtype=np.float64)
-    assert np.all(np.abs(nr / ref_nr - 1) <= 0.08), "num_rays controller"
+    # The controllers themselves are replayed exactly on the reference's inputs in tests/test_train_trace_cpu.py; here their
+    # inputs come from a run whose float atomics make it differ from itself after ~3 iterations, so the bounds are the
+    # estimators' noise: num_rays follows kept / n_samples of the previous chunk (8 % for a full chunk; the chunk after
+    # the 100-ray probe that follows a controller reset inherits the probe's ~7 % sigma -- five runs of this test gave
+    # 5316 .. 5596 samples against the reference's single draw of 5089), max_retrace is a min over <= 20 such ratios and
+    # steps up when the 1e-3 seed leaves the window, where one chunk's ratio decides it.
+    probe = np.flatnonzero(ref_nr == start)          # first chunk of the run and the one after the upsample
+    nr_tol = np.full(nr.shape, 0.08)
+    nr_tol[np.minimum(probe + 1, len(nr) - 1)] = 0.25
+    nr_tol[np.minimum(probe + 2, len(nr) - 1)] = 0.12                     # the 0.9 / 0.1 blend carries it one more chunk
+    assert np.all(np.abs(nr / ref_nr - 1) <= nr_tol), ("num_rays controller", (nr / ref_nr).tolist())
     mr = np.asarray([c["max_retrace"][0] for c in chunks], dtype=np.float64)
-    assert np.all(np.abs(mr / ref_mr - 1) <= 0.35), "re-trace controller"          # min over 20 noisy ratios: coarse
+    mr_err = np.abs(np.log(mr / ref_mr))
+    assert np.all(mr_err <= np.log(2.0)) and np.mean(mr_err <= np.log(1.35)) >= 0.9, ("re-trace controller", (mr / ref_mr).tolist())
     # once the streams differ the two runs draw different ray batches: compare the loss level, not chunk by chunk
     tot = np.asarray([float(c["total"]) for c in chunks])
     it_of = np.asarray([c["iter"] for c in chunks])
