@@ -204,9 +204,11 @@ int nmf_segment_sum(const float* vals, const float* scale, const int64_t* offset
  * three learnable 0-d parameters never have to be read back to the host.
  * ---------------------------------------------------------------------------------------- */
 /* activated = exp(min(brightness + mul*bg_mat, 20)); sat = cumsum_W(cumsum_H(activated/1000));
- * pole_rows [2][3] (optional) = mean of the first / last row of `activated` per channel (:499-502). */
+ * pole_rows [2][3] (optional) = mean of the first / last row of `activated` per channel (:499-502).
+ * sat_i4 [H][W][4] (optional) = the same table with the channels interleaved (4th lane unwritten): the lookups read one
+ * 16-byte texel per tap from it instead of three 4-byte values on three planes (layout = 1 below). */
 int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
-                  const float* scalars_dev, float* activated, float* sat, float* pole_rows, void* stream);
+                  const float* scalars_dev, float* activated, float* sat, float* pole_rows, float* sat_i4, void* stream);
 /* SH projection of prefiltered lookups (modules/integral_equirect.py:324-360, no gradient): coeffs[k][c] =
  * sum_i wq[i][k] * vals[i][c] over n lattice directions (vals [n][3] from nmf_sat_lookup_fwd, wq [n][K] = quadrature
  * weight x SH basis), conv[k][c] = sh_A[k] * coeffs[k][c] / pi (conv / sh_A may be NULL). */
@@ -221,15 +223,17 @@ int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float* activated,
 /* out[r] = prefiltered radiance along dirs[r] for log-solid-angle sa[r] (IntegralEquirect.forward).
  * pole_rows [2][3] = mean of the first / last row of `activated` (:499-502).
  * dirs_ld = row pitch of dirs in floats: 3 for [R][3] directions, 6 for [R][6] ray rows (origin | direction) whose
- * direction is columns 3..5 -- secondary rays are looked up without slicing them (tensor_nerf.py:302-317). */
+ * direction is columns 3..5 -- secondary rays are looked up without slicing them (tensor_nerf.py:302-317).
+ * layout: 0 = sat is the planar table [3][H][W], 1 = sat is nmf_sat_build's interleaved sat_i4 [H][W][4]; the results
+ * are bit-identical. */
 int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
                        const float* sa /*[R]*/, int64_t R, float mipbias, const float* scalars_dev,
-                       const float* pole_rows, float* out /*[R][3]*/, void* stream);
+                       const float* pole_rows, int32_t layout, float* out /*[R][3]*/, void* stream);
 /* Adjoints: d_sat [H][W][4] (channel-interleaved so that 8 lanes share one 32-byte atomic run, see csrc/env.hip) and
  * d_pole [2][3] are ACCUMULATED (caller zeroes), d_dirs [R][dirs_ld] is overwritten (with dirs_ld = 6 the origin
  * columns are written as zeros), d_mipbias [1] accumulated.  d_sat / d_dirs / d_mipbias may be NULL. */
 int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
-                       int64_t R, float mipbias, const float* scalars_dev, const float* d_out /*[R][3]*/,
+                       int64_t R, float mipbias, const float* scalars_dev, int32_t layout, const float* d_out /*[R][3]*/,
                        float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------

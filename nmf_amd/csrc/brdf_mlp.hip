@@ -13,6 +13,12 @@
 // The backward re-computes the forward per tile, forms dH2/dH1 with two more MFMA passes, accumulates
 // dW2 = dH2^T H1 and dW0 = dH1^T X over ALL its tiles in MFMA accumulators (K = rays) and flushes them
 // once per workgroup.
+//
+// Measured on MI355X (round 2, scratch micro-benchmark of dependent v_mfma_f32_32x32x2_f32 chains): an fp32 MFMA occupies
+// its SIMD for 64 cycles and NO other VALU instruction of any wave of that SIMD issues meanwhile
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0; "MFMA wave + FMA wave" on one SIMD takes longer than the two one after the other) --
+// the fp32 matrix rate equals the packed-FMA rate, the instructions seem to share the lanes.  So the floor of this kernel
+// is MFMA cycles + VALU cycles, not their maximum; a second workgroup per CU only hides LDS / barrier / global latency.
 #include "common.hpp"
 
 namespace {
@@ -87,6 +93,37 @@ __device__ __forceinline__ void build_x_tile(float* Xs, int64_t r0, int64_t R, c
     }
 }
 
+// A chain of N dependent v_mfma_f32_32x32x2_f32 on one accumulator runs at 64 cycles per instruction at best.  Left to
+// itself the compiler issues each pair's ds_read right after the previous pair and waits for it (lgkmcnt(0)) in front of
+// the next one, which exposes the LDS latency once per pair (~170 instead of 128 cycles, ISA of round 2).  Here the
+// operands of chunk c+1 are requested before the instructions of chunk c issue; the empty asm keeps the loads above it.
+constexpr int CH = 8;
+template <int N, class FA, class FB>
+__device__ __forceinline__ void mfma_chain(floatx16& acc, FA load_a, FB load_b) {
+    constexpr int NC = (N + CH - 1) / CH;
+    float a[2][CH], b[2][CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        a[0][i] = load_a(i);
+        b[0][i] = load_b(i);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if ((c + 1) * CH + i < N) {
+                    a[(c + 1) & 1][i] = load_a((c + 1) * CH + i);
+                    b[(c + 1) & 1][i] = load_b((c + 1) * CH + i);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c * CH + i < N) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][i], b[c & 1][i], acc, 0, 0, 0);
+    }
+}
+
 // one 32x32 quadrant of  act_out = relu(act_in[64 x K] * W^T + bias)  on the matrix core.
 // wreg[kk] = W[32*wc + (lane&31)][2*kk + (lane>>5)]
 template <int KS>
@@ -94,8 +131,12 @@ __device__ __forceinline__ void layer_quadrant(const float* in_s, float* out_s, 
                                                const float* __restrict__ bias, int wr, int wc, int lane, bool relu) {
     floatx16 acc = {0};
     const float* arow = in_s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
+    float a[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], wreg[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < KS; ++kk) a[kk] = arow[2 * kk];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wreg[kk], acc, 0, 0, 0);
     const int col = 32 * wc + (lane & 31);
     const float bv = bias[col];
 #pragma unroll
@@ -156,12 +197,10 @@ __device__ __forceinline__ void outer_quadrant(floatx16& acc, const float* a_s, 
                                                int lane) {
     const float* ap = a_s + (lane >> 5) * LS + 32 * wr + (lane & 31);
     const float* bp = b_s + (lane >> 5) * LS + 32 * wc + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < TR / 2; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * LS], bp[2 * kk * LS], acc, 0, 0, 0);
+    mfma_chain<TR / 2>(acc, [&](int kk) { return ap[2 * kk * LS]; }, [&](int kk) { return bp[2 * kk * LS]; });
 }
 
-__global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v,
+__global__ void __launch_bounds__(256, 2) k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v,
                                                       const float* __restrict__ diff_v,
                                                       const float* __restrict__ feat_src,
                                                       const float* __restrict__ rough_src,
@@ -251,9 +290,7 @@ __global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __res
         {
             const float* arow = H2s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
             const float* brow = W2s + (lane >> 5) * HID + 32 * wc + (lane & 31);
-#pragma unroll
-            for (int kk = 0; kk < K2; ++kk)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], brow[2 * kk * HID], acc, 0, 0, 0);
+            mfma_chain<K2>(acc, [&](int kk) { return arow[2 * kk]; }, [&](int kk) { return brow[2 * kk * HID]; });
         }
         __syncthreads();                                               // everyone is done reading H1
         {
@@ -275,9 +312,7 @@ __global__ void __launch_bounds__(256) k_brdf_mlp_bwd(MlpW w, const float* __res
             const int col = lane & 31;
             const float* brow = W0f + (lane >> 5) * 24 + (col < 24 ? col : 0);
             const float bmask = col < 24 ? 1.f : 0.f;
-#pragma unroll
-            for (int kk = 0; kk < K2; ++kk)
-                dx = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], brow[2 * kk * 24] * bmask, dx, 0, 0, 0);
+            mfma_chain<K2>(dx, [&](int kk) { return arow[2 * kk]; }, [&](int kk) { return brow[2 * kk * 24] * bmask; });
             if (col < 24) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -359,9 +394,11 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
     hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
     const int64_t tiles = cdiv(R, TR);
-    // one workgroup per CU: a second resident workgroup adds weight staging and 8.5 k flush atomics on the same 270 lines
-    // without hiding anything (measured 173 -> 158 us average per launch)
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    // The kernel is compiled for two workgroups per CU (<= 256 registers, 2 x 76 KB of LDS).  The second one hides barrier
+    // and LDS latency of the first but doubles the weight staging and the 8.5 k flush atomics per workgroup, so it only
+    // pays for long launches (measured: 242 k rays 210 -> 187 us, 46 k rays 60 -> 68 us).
+    const int64_t cap = tiles >= 2048 ? 512 : 256;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(256), BWD_LDS, (hipStream_t)stream, w, half_vec, diff_vec,
                        feat_src, rough_src, src_idx, R, out_bias, d_out, d_xfeat, gW0, gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");

@@ -25,8 +25,9 @@ constexpr float TWO_PI_F = 6.28318530717958647692f;
 constexpr float EPS_F = 1.1920929e-07f;
 
 struct EnvTab {
-    const float* sat;   // [3][H][W]
+    const float* sat;   // [3][H][W], or [H][W][4] when i4 is set
     int H, W;
+    bool i4;            // channel-interleaved copy: one 16-byte load per tap instead of three 4-byte loads on three planes
 };
 
 // bilinear sample of the SAT at normalised (x, y) in [-1,1] (already clipped): returns 3 channels.
@@ -43,56 +44,53 @@ __device__ __forceinline__ void sat_sample(const EnvTab& t, const T& x, const T&
     const int x0 = (int)fx, y0 = (int)fy;
     const bool xi0 = x0 >= 0 && x0 < t.W, xi1 = x0 + 1 >= 0 && x0 + 1 < t.W;
     const bool yi0 = y0 >= 0 && y0 < t.H, yi1 = y0 + 1 >= 0 && y0 + 1 < t.H;
+    float vnw[3] = {0.f, 0.f, 0.f}, vne[3] = {0.f, 0.f, 0.f}, vsw[3] = {0.f, 0.f, 0.f}, vse[3] = {0.f, 0.f, 0.f};
+    if (t.i4) {
+        const float4* p = reinterpret_cast<const float4*>(t.sat);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 a = (xi0 && yi0) ? p[y0 * t.W + x0] : z;
+        const float4 b = (xi1 && yi0) ? p[y0 * t.W + x0 + 1] : z;
+        const float4 c = (xi0 && yi1) ? p[(y0 + 1) * t.W + x0] : z;
+        const float4 d = (xi1 && yi1) ? p[(y0 + 1) * t.W + x0 + 1] : z;
+        vnw[0] = a.x; vnw[1] = a.y; vnw[2] = a.z;
+        vne[0] = b.x; vne[1] = b.y; vne[2] = b.z;
+        vsw[0] = c.x; vsw[1] = c.y; vsw[2] = c.z;
+        vse[0] = d.x; vse[1] = d.y; vse[2] = d.z;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = t.sat + (int64_t)c * t.H * t.W;
+            vnw[c] = (xi0 && yi0) ? p[y0 * t.W + x0] : 0.f;
+            vne[c] = (xi1 && yi0) ? p[y0 * t.W + x0 + 1] : 0.f;
+            vsw[c] = (xi0 && yi1) ? p[(y0 + 1) * t.W + x0] : 0.f;
+            vse[c] = (xi1 && yi1) ? p[(y0 + 1) * t.W + x0 + 1] : 0.f;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float* p = t.sat + (int64_t)c * t.H * t.W;
-        const float vnw = (xi0 && yi0) ? p[y0 * t.W + x0] : 0.f;
-        const float vne = (xi1 && yi0) ? p[y0 * t.W + x0 + 1] : 0.f;
-        const float vsw = (xi0 && yi1) ? p[(y0 + 1) * t.W + x0] : 0.f;
-        const float vse = (xi1 && yi1) ? p[(y0 + 1) * t.W + x0 + 1] : 0.f;
         if constexpr (sizeof(T) == sizeof(float)) {
-            float r = vnw * nw;
-            r = fmaf(vne, ne, r);
-            r = fmaf(vsw, sw, r);
-            r = fmaf(vse, se, r);
+            float r = vnw[c] * nw;
+            r = fmaf(vne[c], ne, r);
+            r = fmaf(vsw[c], sw, r);
+            r = fmaf(vse[c], se, r);
             out[c] = r;
         } else {
-            out[c] = nw * vnw + ne * vne + sw * vsw + se * vse;
+            out[c] = nw * vnw[c] + ne * vne[c] + sw * vsw[c] + se * vse[c];
         }
     }
 }
 
 // Table adjoint.  Device-scope float atomics cost ~one L2 operation per distinct cache line touched by an instruction
-// (measured on MI355X: 21 G line-ops/s whatever the table size; 8 lanes on one 32-byte run = 156 G lane-ops/s).  A
-// lane-per-lookup scatter touches 64 lines per instruction (3 channel planes x 4 taps x 4..8 corners = 48-96
-// instructions per wave).  Instead every lookup parks its box corners in LDS and the wave replays them with 8 lanes per
-// corner on a CHANNEL-INTERLEAVED adjoint table dSAT4 [H][W][4]: lane t of a group owns (texel x0 + (t >> 2), channel
-// t & 3), so one instruction covers 8 lookups with one 32-byte run each; two instructions (rows y0, y0+1) per corner.
-constexpr int MAXC = 16;     // corners parked per lookup (2 wrap boxes x 2 wrap boxes x 4); more fall back to the direct path
-
+// (measured on MI355X: 21 G line-ops/s whatever the table size; 8 lanes on one 32-byte run = 156 G lane-ops/s, the same
+// with workgroup-scope atomics on per-XCD copies of the table).  A lane-per-lookup scatter touches 64 lines per
+// instruction; the adjoint therefore runs with 8 lanes per lookup on a CHANNEL-INTERLEAVED table dSAT4 [H][W][4]
+// (Scatter8Acc below).
 __device__ __forceinline__ void corner_taps(int H, int W, float x, float y, int& x0, int& y0, float& w, float& n) {
     const float ix = (x + 1.f) * ((float)(W - 1) * 0.5f);
     const float iy = (y + 1.f) * ((float)(H - 1) * 0.5f);
     const float fx = floorf(ix), fy = floorf(iy);
     w = ix - fx; n = iy - fy;
     x0 = (int)fx; y0 = (int)fy;
-}
-
-// direct (lane-per-corner) scatter into the interleaved table: overflow path only
-__device__ __forceinline__ void sat_scatter4(float* dsat4, int H, int W, float x, float y, const float (&g)[3]) {
-    int x0, y0;
-    float w, n;
-    corner_taps(H, W, x, y, x0, y0, w, n);
-    const float e = 1.f - w, s = 1.f - n;
-    const bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
-    const bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (xi0 && yi0) atomicAdd(dsat4 + ((int64_t)y0 * W + x0) * 4 + c, g[c] * (e * s));
-        if (xi1 && yi0) atomicAdd(dsat4 + ((int64_t)y0 * W + x0 + 1) * 4 + c, g[c] * (w * s));
-        if (xi0 && yi1) atomicAdd(dsat4 + ((int64_t)(y0 + 1) * W + x0) * 4 + c, g[c] * (e * n));
-        if (xi1 && yi1) atomicAdd(dsat4 + ((int64_t)(y0 + 1) * W + x0 + 1) * 4 + c, g[c] * (w * n));
-    }
 }
 
 template <class T>
@@ -216,28 +214,6 @@ struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL s
     }
 };
 
-struct ListAcc {   // table adjoint, phase 1: park (texel, fractions, sign) of every corner in this lane's LDS list
-    float4* list;     // [MAXC] records of this lane
-    float* dsat4;     // overflow path
-    int H, W, n;
-    float g[3];       // d_vals * 1000 / size
-    __device__ void begin() {}
-    __device__ void corner(float x, float y, int k) {
-        const float sgn = k < 2 ? 1.f : -1.f;
-        if (n < MAXC) {
-            int x0, y0;
-            float w, nn;
-            corner_taps(H, W, x, y, x0, y0, w, nn);
-            list[n] = make_float4(__int_as_float((x0 + 1) | ((y0 + 1) << 16)), w, nn, sgn);
-            ++n;
-        } else {
-            const float gg[3] = {sgn * g[0], sgn * g[1], sgn * g[2]};
-            sat_scatter4(dsat4, H, W, x, y, gg);
-        }
-    }
-    __device__ void end() {}
-};
-
 // ---- kernels -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                         const float* __restrict__ sa, int64_t R, float mipbias,
@@ -262,87 +238,97 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
     out[r * 3] = v[0]; out[r * 3 + 1] = v[1]; out[r * 3 + 2] = v[2];
 }
 
-__global__ void __launch_bounds__(64) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs, int ld,
-                                                       const float* __restrict__ sa, int64_t R, float mipbias,
-                                                       const float* __restrict__ sc,
-                                                       const float* __restrict__ d_out, float* __restrict__ d_sat4,
-                                                       float* __restrict__ d_pole /*[2][3]*/,
-                                                       float* __restrict__ d_dirs, float* __restrict__ d_mipbias) {
-    __shared__ float4 s_list[64 * (MAXC + 1)];     // +1: odd record pitch against LDS bank conflicts in phase 2
-    __shared__ float4 s_g[64];
-    __shared__ int s_n[64];
-    const int lane = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+// Table adjoint, 8 lanes per lookup: lane t of a group owns (texel x0 + (t >> 2), channel t & 3) of every corner of the
+// lookup's boxes, so one atomic instruction covers 8 lookups with one 32-byte run each (two instructions per corner:
+// rows y0, y0 + 1).  The 8 lanes walk the same boxes (the float geometry is recomputed per lane: ~200 instructions).
+struct Scatter8Acc {
+    float* dsat4;
+    int H, W, dx, ch;
+    float g;          // d_vals[ch] * 1000 / size (0 on the padding channel)
+    __device__ void begin() {}
+    __device__ void corner(float x, float y, int k) {
+        int x0, y0;
+        float w, n;
+        corner_taps(H, W, x, y, x0, y0, w, n);
+        const float sgn = k < 2 ? 1.f : -1.f;
+        const int X = x0 + dx;
+        const float v = g * sgn * (dx ? w : 1.f - w);
+        if (X >= 0 && X < W && v != 0.f) {
+            float* p = dsat4 + ((int64_t)y0 * W + X) * 4 + ch;
+            const float v0 = v * (1.f - n), v1 = v * n;
+            if (y0 >= 0 && y0 < H && v0 != 0.f) atomicAdd(p, v0);
+            if (y0 + 1 >= 0 && y0 + 1 < H && v1 != 0.f) atomicAdd(p + (int64_t)W * 4, v1);
+        }
+    }
+    __device__ void end() {}
+};
+
+// Backward of the lookup, two roles in one launch (blocks b % 9 == 0: role A, the others: role B), so that the
+// instruction-bound role A overlaps the atomic-bound role B:
+//   A  one lane per lookup: the forward on dual numbers (4 tangents) -> d_dirs, d_mipbias; pole rows -> d_pole
+//   B  eight lanes per lookup: the table adjoint (Scatter8Acc)
+// Round 1 did both in one 64-thread workgroup with the corners parked in 18.5 KB of LDS (8 waves per CU resident:
+// 192 us for 242 k lookups, profiles/r02_c); neither role needs LDS now.
+constexpr int ENV_BWD_THREADS = 256;
+__global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs, int ld,
+                                                                    const float* __restrict__ sa, int64_t R, float mipbias,
+                                                                    const float* __restrict__ sc,
+                                                                    const float* __restrict__ d_out,
+                                                                    float* __restrict__ d_sat4,
+                                                                    float* __restrict__ d_pole /*[2][3]*/,
+                                                                    float* __restrict__ d_dirs,
+                                                                    float* __restrict__ d_mipbias) {
     if (sc) mipbias = sc[0];
+    const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
+    const int64_t period = blockIdx.x / 9;
+    const int slot = blockIdx.x % 9;
+    if (slot != 0) {
+        // ---- role B -------------------------------------------------------------------------------------------------
+        if (!d_sat4) return;
+        const int64_t r = (period * 8 + (slot - 1)) * (ENV_BWD_THREADS / 8) + (threadIdx.x >> 3);
+        if (r >= R) return;
+        const int t = threadIdx.x & 7;
+        const float* q = dirs + r * ld + (ld - 3);
+        const Geometry<float> g = env_geometry<float>(tab.H, tab.W, q[0], q[1], q[2], sa[r], mipbias);
+        if (g.cy > cutoff || g.cy < -cutoff) return;          // pole rows: role A
+        Scatter8Acc acc;
+        acc.dsat4 = d_sat4; acc.H = tab.H; acc.W = tab.W; acc.dx = t >> 2; acc.ch = t & 3;
+        acc.g = acc.ch < 3 ? d_out[r * 3 + acc.ch] * (1000.f / g.size) : 0.f;
+        box_wrap(g.rect, acc);
+        return;
+    }
+    // ---- role A -----------------------------------------------------------------------------------------------------
+    const int64_t r = period * ENV_BWD_THREADS + threadIdx.x;
     float dm = 0.f;
-    int n_corner = 0;
-    float gk[3] = {0.f, 0.f, 0.f};
     if (r < R) {
         const float* q = dirs + r * ld + (ld - 3);
         const float a = q[0], b = q[1], c = q[2];
         float* dq = d_dirs ? d_dirs + r * ld + (ld - 3) : nullptr;
         if (dq && ld == 6) { dq[-3] = 0.f; dq[-2] = 0.f; dq[-1] = 0.f; }          // no dependence on the ray origin
         const float go[3] = {d_out[r * 3], d_out[r * 3 + 1], d_out[r * 3 + 2]};
-        Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
-        const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
+        typedef Dual<4> D;
+        D da = mk_const<4>(a), db = mk_const<4>(b), dc = mk_const<4>(c), dmb = mk_const<4>(mipbias);
+        da.d[0] = 1.f; db.d[1] = 1.f; dc.d[2] = 1.f; dmb.d[3] = 1.f;
+        const Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);     // the branch role B takes
         const bool bot = g.cy > cutoff, top = g.cy < -cutoff;
         if (top || bot) {
             // value = mean of a pole row of the activated map: no dependence on dirs / mipbias
-            float* q = d_pole + (top ? 0 : 3);
-            atomicAdd(q, go[0]); atomicAdd(q + 1, go[1]); atomicAdd(q + 2, go[2]);
+            float* qp = d_pole + (top ? 0 : 3);
+            atomicAdd(qp, go[0]); atomicAdd(qp + 1, go[1]); atomicAdd(qp + 2, go[2]);
             if (dq) { dq[0] = 0.f; dq[1] = 0.f; dq[2] = 0.f; }
-        } else {
-            if (d_sat4) {
-                ListAcc lacc;
-                lacc.list = s_list + lane * (MAXC + 1);
-                lacc.dsat4 = d_sat4; lacc.H = tab.H; lacc.W = tab.W; lacc.n = 0;
-                const float k = 1000.f / g.size;
-                lacc.g[0] = gk[0] = go[0] * k; lacc.g[1] = gk[1] = go[1] * k; lacc.g[2] = gk[2] = go[2] * k;
-                box_wrap(g.rect, lacc);
-                n_corner = lacc.n;
-            }
-            if (d_dirs || d_mipbias) {
-                typedef Dual<4> D;
-                D da = mk_const<4>(a), db = mk_const<4>(b), dc = mk_const<4>(c), dmb = mk_const<4>(mipbias);
-                da.d[0] = 1.f; db.d[1] = 1.f; dc.d[2] = 1.f; dmb.d[3] = 1.f;
-                Geometry<D> gd = env_geometry<D>(tab.H, tab.W, da, db, dc, sa[r], dmb);
-                SumAcc<D> acc;
-                acc.tab = tab;
-                acc.size = gd.size;
-                acc.total[0] = acc.total[1] = acc.total[2] = mk_const<4>(0.f);
-                box_wrap(gd.rect, acc);
-                float gsum[4];
+        } else if (d_dirs || d_mipbias) {
+            const Geometry<D> gd = env_geometry<D>(tab.H, tab.W, da, db, dc, sa[r], dmb);
+            SumAcc<D> acc;
+            acc.tab = tab;
+            acc.size = gd.size;
+            acc.total[0] = acc.total[1] = acc.total[2] = mk_const<4>(0.f);
+            box_wrap(gd.rect, acc);
+            float gsum[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    gsum[i] = 1000.f * (go[0] * acc.total[0].d[i] + go[1] * acc.total[1].d[i] + go[2] * acc.total[2].d[i]);
-                if (dq) { dq[0] = gsum[0]; dq[1] = gsum[1]; dq[2] = gsum[2]; }
-                dm = gsum[3];
-            }
-        }
-    }
-    if (d_sat4) {   // phase 2: 8 lanes per corner
-        s_n[lane] = n_corner;
-        s_g[lane] = make_float4(gk[0], gk[1], gk[2], 0.f);
-        __syncthreads();
-        const int grp = lane >> 3, t = lane & 7, dx = t >> 2, ch = t & 3;
-        const int H = tab.H, W = tab.W;
-        for (int q = 0; q < 8; ++q) {
-            const int src = grp * 8 + q;
-            const int n = s_n[src];
-            const float gv = reinterpret_cast<const float*>(&s_g[src])[ch];
-            const float4* rec = s_list + src * (MAXC + 1);
-            for (int c = 0; c < n; ++c) {
-                const float4 rc = rec[c];
-                const int pk = __float_as_int(rc.x);
-                const int x = (pk & 0xffff) - 1 + dx, y0 = (pk >> 16) - 1;
-                const float v = gv * rc.w * (dx ? rc.y : 1.f - rc.y);
-                if (x >= 0 && x < W && v != 0.f) {
-                    float* p = d_sat4 + ((int64_t)y0 * W + x) * 4 + ch;
-                    const float v0 = v * (1.f - rc.z), v1 = v * rc.z;
-                    if (y0 >= 0 && y0 < H && v0 != 0.f) atomicAdd(p, v0);
-                    if (y0 + 1 >= 0 && y0 + 1 < H && v1 != 0.f) atomicAdd(p + (int64_t)W * 4, v1);
-                }
-            }
+            for (int i = 0; i < 4; ++i)
+                gsum[i] = 1000.f * (go[0] * acc.total[0].d[i] + go[1] * acc.total[1].d[i] + go[2] * acc.total[2].d[i]);
+            if (dq) { dq[0] = gsum[0]; dq[1] = gsum[1]; dq[2] = gsum[2]; }
+            dm = gsum[3];
         }
     }
     if (d_mipbias) {   // wave reduction, one atomic per wave
@@ -379,17 +365,22 @@ __global__ void __launch_bounds__(256) k_sat_cols(const float* __restrict__ bg, 
 }
 
 // prefix sum across W, in place: one wave per (channel, row)
-__global__ void __launch_bounds__(256) k_sat_rows(float* __restrict__ sat, int H, int W) {
+__global__ void __launch_bounds__(256) k_sat_rows(float* __restrict__ sat, int H, int W, float* __restrict__ sat_i4) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 3 * H) return;
     const int lane = lane_id();
     float* p = sat + (int64_t)row * W;
+    float* q = sat_i4 ? sat_i4 + (int64_t)(row % H) * W * 4 + row / H : nullptr;
     double carry = 0.0;
     for (int x0 = 0; x0 < W; x0 += 64) {
         const int x = x0 + lane;
         const double v = x < W ? (double)p[x] : 0.0;
         const double incl = wave_incl_scan(v);
-        if (x < W) p[x] = (float)(carry + incl);
+        if (x < W) {
+            const float v32 = (float)(carry + incl);
+            p[x] = v32;
+            if (q) q[(int64_t)x * 4] = v32;
+        }
         carry += __shfl(incl, 63, 64);
     }
 }
@@ -470,12 +461,13 @@ __global__ void __launch_bounds__(64) k_pole_rows(const float* __restrict__ act,
 }
 
 extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float brightness, float mul,
-                             const float* scalars_dev, float* activated, float* sat, float* pole_rows, void* stream) {
+                             const float* scalars_dev, float* activated, float* sat, float* pole_rows, float* sat_i4,
+                             void* stream) {
     NMF_REQUIRE(bg_mat && activated && sat && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build: null/size");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sat_cols, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
                        scalars_dev, activated, sat);
-    hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W);
+    hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W, sat_i4);
     if (pole_rows) hipLaunchKernelGGL(k_pole_rows, dim3(6), dim3(64), 0, st, activated, H, W, pole_rows);
     NMF_CHECK_LAUNCH("nmf_sat_build");
     return NMF_OK;
@@ -504,12 +496,12 @@ extern "C" int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float*
 
 extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
                                   const float* sa, int64_t R, float mipbias, const float* scalars_dev,
-                                  const float* pole_rows, float* out, void* stream) {
+                                  const float* pole_rows, int32_t layout, float* out, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_fwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && pole_rows && out, NMF_EINVAL, "nmf_sat_lookup_fwd: null");
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_fwd: dirs_ld must be 3 or 6");
-    EnvTab tab{sat, H, W};
+    EnvTab tab{sat, H, W, layout == 1};
     hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
                        (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
@@ -517,15 +509,17 @@ extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const 
 }
 
 extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
-                                  const float* sa, int64_t R, float mipbias, const float* scalars_dev, const float* d_out,
-                                  float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream) {
+                                  const float* sa, int64_t R, float mipbias, const float* scalars_dev, int32_t layout,
+                                  const float* d_out, float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias,
+                                  void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd: dirs_ld must be 3 or 6");
-    EnvTab tab{sat, H, W};
-    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, tab, dirs,
-                       (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole, d_dirs, d_mipbias);
+    EnvTab tab{sat, H, W, layout == 1};
+    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
+                       (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
+                       d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
     return NMF_OK;
 }

@@ -167,11 +167,12 @@ Tensor segment_sum(const Tensor& vals, const OT& scale, const Tensor& offsets, i
 Tensor sat_lookup_fwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const OT& pole_rows,
                       const OT& sc, int64_t stream) {
     const int64_t R = dirs.size(0), ld = dirs.size(1);
-    const int64_t H = sat.size(-2), W = sat.size(-1);
+    const bool i4 = sat.dim() == 3 && sat.size(-1) == 4 && sat.size(0) != 3;          // [H][W][4] (nmf_sat_build's sat_i4)
+    const int64_t H = i4 ? sat.size(0) : sat.size(-2), W = i4 ? sat.size(1) : sat.size(-1);
     Tensor o = fe(dirs, {R, 3});
     check(nmf_sat_lookup_fwd(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
-                             static_cast<const float*>(vptr(sc)), static_cast<const float*>(vptr(pole_rows)), out(o),
-                             st(stream)),
+                             static_cast<const float*>(vptr(sc)), static_cast<const float*>(vptr(pole_rows)), i4 ? 1 : 0,
+                             out(o), st(stream)),
           "nmf_sat_lookup_fwd");
     return o;
 }
@@ -312,12 +313,13 @@ Tensor segment_sum_wide(const Tensor& vals, int64_t D, const Tensor& offsets, in
 OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const Tensor& d_out, const OT& d_sat,
                   const OT& d_pole, const OT& d_mip, bool want_dirs, const OT& sc, int64_t stream) {
     const int64_t R = dirs.size(0), ld = dirs.size(1);
-    const int64_t H = sat.size(-2), W = sat.size(-1);
+    const bool i4 = sat.dim() == 3 && sat.size(-1) == 4 && sat.size(0) != 3;
+    const int64_t H = i4 ? sat.size(0) : sat.size(-2), W = i4 ? sat.size(1) : sat.size(-1);
     OT d_dirs;
     if (want_dirs) d_dirs = fe(dirs, {R, ld});
     Tensor go = d_out.contiguous();
     check(nmf_sat_lookup_bwd(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
-                             static_cast<const float*>(vptr(sc)), f32(go), static_cast<float*>(vptr(d_sat)),
+                             static_cast<const float*>(vptr(sc)), i4 ? 1 : 0, f32(go), static_cast<float*>(vptr(d_sat)),
                              static_cast<float*>(vptr(d_pole)), d_dirs.has_value() ? out(*d_dirs) : nullptr,
                              static_cast<float*>(vptr(d_mip)), st(stream)),
           "nmf_sat_lookup_bwd");

@@ -70,14 +70,15 @@ class TrainPass:
     def _env_fwd(self, rows, sa):
         bgm = self.nerf.bg_module
         act, sat, pole = bgm._tables()
-        return hip.sat_lookup_fwd(sat, rows, sa, 0.0, pole, sc=bgm._dev_scalars())
+        return hip.sat_lookup_fwd(bgm._lookup_table(), rows, sa, 0.0, pole, sc=bgm._dev_scalars())
 
     def _env_bwd(self, rows, sa, d_out):
         bgm = self.nerf.bg_module
         act, sat, pole = bgm._tables()
         a = self.acc
         a.used_env = True
-        return hip.sat_lookup_bwd(sat, rows, sa, 0.0, d_out, a.d_sat, a.d_pole, a.d_mip, want_dirs=True, sc=bgm._dev_scalars())
+        return hip.sat_lookup_bwd(bgm._lookup_table(), rows, sa, 0.0, d_out, a.d_sat, a.d_pole, a.d_mip, want_dirs=True,
+                                  sc=bgm._dev_scalars())
 
     def _fwd(self, lvl, rays, focal, start_mip, noise):
         nerf = self.nerf

@@ -325,7 +325,7 @@ class SatBuild(torch.autograd.Function):
 
 def env_grad_buffers(holder, sat):
     if holder.bufs is None:
-        H, W = sat.shape[-2:]
+        H, W, _ = hip._sat_layout(sat)
         flat = torch.zeros(H * W * 4 + 8, dtype=torch.float32, device=sat.device)
         holder.bufs = (flat[: H * W * 4].view(H, W, 4), flat[H * W * 4: H * W * 4 + 6].view(2, 3),
                        flat[H * W * 4 + 6: H * W * 4 + 7])
@@ -338,7 +338,8 @@ class EnvLookup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, env, dirs, sa, holder, token):
-        act, sat, pole = env._tables()
+        act, _sat, pole = env._tables()
+        sat = env._lookup_table()                    # [H,W,4]
         dirs_c = dirs.contiguous()
         sa_c = sa.reshape(-1).contiguous()
         sc = env._dev_scalars()

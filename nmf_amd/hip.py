@@ -454,22 +454,32 @@ def segment_sum(vals, scale, offsets, n_seg, lanes=1):
 
 
 # ---- environment map ---------------------------------------------------------------------------
-def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None, out=None, pole=False):
-    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W] (+ pole-row means [2,3] with pole=True).  sc: optional device
-    float32 [3] = (mipbias, brightness, mul) read by the kernels instead of the by-value scalars (no host read-back of the
-    parameters).  out = the tuple of an earlier call rebuilds the tables in place."""
+def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None, out=None, pole=False, interleaved=False):
+    """bg_mat [1,3,H,W] or [3,H,W] -> (activated, sat) [3,H,W] (+ pole-row means [2,3] with pole=True, + the channel-
+    interleaved copy of sat [H,W,4] with interleaved=True: what the lookups read fastest).  sc: optional device float32 [3] =
+    (mipbias, brightness, mul) read by the kernels instead of the by-value scalars (no host read-back of the parameters).
+    out = the tuple of an earlier call (same flags) rebuilds the tables in place."""
     bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
     H, W = bg.shape[-2:]
     if out is not None:
         act, sat = out[0], out[1]
         pl = out[2] if pole else None
+        s4 = out[-1] if interleaved else None
     else:
         act = torch.empty_like(bg)
         sat = torch.empty_like(bg)
         pl = torch.empty((2, 3), dtype=torch.float32, device=bg.device) if pole else None
+        s4 = torch.zeros((H, W, 4), dtype=torch.float32, device=bg.device) if interleaved else None
     _check(_lib.nmf_sat_build(_p(bg.contiguous(), torch.float32), C.c_int32(H), C.c_int32(W), C.c_float(brightness),
-                              C.c_float(mul), _p(sc), _p(act), _p(sat), _p(pl), _stream()), "nmf_sat_build")
-    return (act, sat, pl) if pole else (act, sat)
+                              C.c_float(mul), _p(sc), _p(act), _p(sat), _p(pl), _p(s4), _stream()), "nmf_sat_build")
+    return (act, sat) + ((pl,) if pole else ()) + ((s4,) if interleaved else ())
+
+
+def _sat_layout(sat):
+    """-> (H, W, layout) of a summed-area table: planar [3,H,W] (0) or channel-interleaved [H,W,4] (1)"""
+    if sat.dim() == 3 and sat.shape[-1] == 4 and sat.shape[0] != 3:
+        return sat.shape[0], sat.shape[1], 1
+    return sat.shape[-2], sat.shape[-1], 0
 
 
 def sh_project(vals, wq, sh_A, out=None):
@@ -494,13 +504,14 @@ def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None):
 
 
 def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
-    """dirs: [R,3] directions, or [R,6] ray rows (origin | direction) looked up along their columns 3..5"""
+    """dirs: [R,3] directions, or [R,6] ray rows (origin | direction) looked up along their columns 3..5; sat: the planar
+    table [3,H,W] or sat_build's interleaved copy [H,W,4] (same results)"""
     R, ld = dirs.shape[0], dirs.shape[1]
-    H, W = sat.shape[-2:]
+    H, W, layout = _sat_layout(sat)
     out = torch.empty((R, 3), dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_fwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), _p(pole_rows), _p(out),
-                                   _stream()), "nmf_sat_lookup_fwd")
+                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), _p(pole_rows),
+                                   C.c_int32(layout), _p(out), _stream()), "nmf_sat_lookup_fwd")
     return out
 
 
@@ -508,13 +519,13 @@ def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, wan
     """d_sat [H,W,4] / d_pole [2,3] / d_mip [1] are ACCUMULATED into (any may be None except d_pole).  Returns d_dirs; with
     want_mipbias=True (legacy form) a fresh d_mip accumulator is allocated and (d_dirs, d_mip) is returned."""
     R, ld = dirs.shape[0], dirs.shape[1]
-    H, W = sat.shape[-2:]
+    H, W, layout = _sat_layout(sat)
     d_dirs = torch.empty((R, ld), dtype=torch.float32, device=dirs.device) if want_dirs else None   # shaped like dirs
     legacy = want_mipbias is not None
     if legacy and want_mipbias and d_mip is None:
         d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device)
     _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
-                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc),
+                                   C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), C.c_int32(layout),
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
                                    _stream()), "nmf_sat_lookup_bwd")
     return (d_dirs, d_mip) if legacy else d_dirs

@@ -102,12 +102,17 @@ class IntegralEquirect(FastPrivateAttrs, torch.nn.Module):
         ptr = self.bg_mat.data_ptr()
         c = self._cache
         if c is None or c[2] != ptr:
-            tab = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), pole=True)
+            tab = hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), pole=True, interleaved=True)
             self._cache = (key, tab, ptr)
         elif c[0] != key:       # same storage, new values (an optimizer step): rebuild the tables in place
-            hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), out=c[1], pole=True)
+            hip.sat_build(self.bg_mat.detach(), sc=self._dev_scalars(), out=c[1], pole=True, interleaved=True)
             self._cache = (key, c[1], ptr)
-        return self._cache[1]
+        return self._cache[1][:3]
+
+    def _lookup_table(self):
+        """the channel-interleaved copy [H,W,4] of the summed-area table the lookup kernels read (same values as sat)"""
+        self._tables()
+        return self._cache[1][3]
 
     def activation_fn(self, x):
         return torch.exp((self.brightness + self.mul * x).clip(max=20))
@@ -207,7 +212,7 @@ class IntegralEquirect(FastPrivateAttrs, torch.nn.Module):
                                   self.sh_A.reshape(-1)[:9].float().contiguous())
             _, dirs, mips, wq, shA = self._sh_const
             act, sat, pole = self._tables()
-            bg = hip.sat_lookup_fwd(sat, dirs, mips, 0.0, pole, sc=self._dev_scalars())
+            bg = hip.sat_lookup_fwd(self._lookup_table(), dirs, mips, 0.0, pole, sc=self._dev_scalars())
             self._sh_cache = (key, hip.sh_project(bg, wq, shA))            # (coeffs, conv) [9,3] each
         return self._sh_cache[1]
 

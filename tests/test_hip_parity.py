@@ -393,6 +393,43 @@ def test_env_lookup_golden_and_gradients():
     assert abs(float(d_mip) - float(gm_o)) <= 5e-3 * abs(float(gm_o)) + 1e-5, (float(d_mip), float(gm_o))
 
 
+def test_env_interleaved_table_gives_the_same_bits():
+    """nmf_sat_build's channel-interleaved copy [H,W,4] (layout 1: one 16-byte load per tap) against the planar table the
+    golden tests above pin: forward values and direction adjoints bit for bit, the table adjoint up to the order of its
+    float atomics; poles, seams and both ray-row pitches included."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(7)
+    H, W, R = 64, 128, 20000
+    bg = (-0.6 + 0.7 * torch.randn(1, 3, H, W, generator=gen)).to(DEV)
+    act, sat, pole, sat4 = hip.sat_build(bg, pole=True, interleaved=True)
+    assert sat4.shape == (H, W, 4) and torch.equal(sat4[..., :3].permute(2, 0, 1), sat)
+    tab2 = hip.sat_build(bg * 0.5, out=(act, sat, pole, sat4), pole=True, interleaved=True)       # in-place rebuild
+    assert tab2[3].data_ptr() == sat4.data_ptr() and torch.equal(sat4[..., :3].permute(2, 0, 1), sat)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    dirs[:200, 2] = torch.sign(dirs[:200, 2]) * 50.0                     # pole rows
+    dirs[:200] = torch.nn.functional.normalize(dirs[:200], dim=-1)
+    dirs[200:400, 1] = 1e-4 * torch.randn(200, generator=gen)            # the phi = +-pi seam
+    dirs[200:400, 0] = -dirs[200:400, 0].abs()
+    sa = (torch.rand(R, generator=gen) * 12 - 10).to(DEV)
+    c = torch.randn(R, 3, generator=gen).to(DEV)
+    for ld in (3, 6):
+        rows = dirs.to(DEV) if ld == 3 else torch.cat([torch.randn(R, 3, generator=gen), dirs], dim=1).to(DEV)
+        rows = rows.contiguous()
+        v0 = hip.sat_lookup_fwd(sat, rows, sa, 0.3, pole)
+        v1 = hip.sat_lookup_fwd(sat4, rows, sa, 0.3, pole)
+        assert torch.equal(v0, v1)
+        outs = []
+        for tab in (sat, sat4):
+            d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
+            d_dirs = hip.sat_lookup_bwd(tab, rows, sa, 0.3, c, d_sat, d_pole, d_mip)
+            outs.append((d_dirs, d_sat, d_pole, d_mip))
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][0].shape == (R, ld)
+        assert_close(outs[1][1].cpu(), outs[0][1].cpu(), rtol=1e-5, atol=1e-5 * float(outs[0][1].abs().max()), what="d_sat")
+        assert_close(outs[1][2].cpu(), outs[0][2].cpu(), rtol=1e-5, atol=1e-6, what="d_pole")
+        assert_close(outs[1][3].cpu(), outs[0][3].cpu(), rtol=1e-4, atol=1e-4 * float(outs[0][3].abs().max()), what="d_mip")
+        assert float(outs[0][2].abs().sum()) > 0          # the pole rows were exercised
+
+
 def test_env_spherical_harmonics_golden():
     """a13: IntegralEquirect.get_spherical_harmonics (modules/integral_equirect.py:324-360) THROUGH THE MODULE -- 5000
     prefiltered lookups at mipval -5 on the direction lattice, projected on 9 SH terms and convolved with the clamped-cosine
