@@ -1007,32 +1007,47 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
 // loop, the grid is capped at 16 k workgroups so that 300^3 (where most of the 422 k bricks hold a handful of samples)
 // does not pay one workgroup launch per item --, blockIdx.y = density planes 0-2 / appearance planes 3-5, so all six
 // latency-bound walks of an item overlap; single-wave workgroups
-template <bool WITH_NORMAL>
-__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(nmf_vm_params p, const float4* __restrict__ rec0,
-                                                              const float4* __restrict__ rec1,
-                                                              const int32_t* __restrict__ bin_off,
-                                                              const int2* __restrict__ items,
-                                                              const int32_t* __restrict__ n_items, int item_size, int nbx,
-                                                              Ptrs3 dpk, Ptrs3 dlk, Ptrs3 apl, Ptrs3 ali,
-                                                              const float* __restrict__ dcoef,
-                                                              const float* __restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk,
-                                                              MPtrs3 g_apl, MPtrs3 g_ali, float* __restrict__ g_basis,
-                                                              int z_density, int z_app) {
+// HALVES: 0 = density planes only, 1 = appearance planes only, 2 = both (blockIdx.y / 3 picks).  The single-half
+// instantiations keep the other walk's registers out of the allocation: both walks in one kernel need 172 registers = 2
+// waves per SIMD; the density walk alone runs 3 (136 registers; forcing 4 spills and gains nothing).  The 1 M-sample
+// density walk of a training step is latency bound (profiles r02_c: 1.68 waves per SIMD resident, ALU 41 % busy):
+// 318 -> 290 us at 128^3, field backward 0.306 -> 0.256 ms per launch at 300^3.
+#define NMF_BWD_ARGS                                                                                                   \
+    nmf_vm_params p, const float4 *__restrict__ rec0, const float4 *__restrict__ rec1, const int32_t *__restrict__ bin_off, \
+        const int2 *__restrict__ items, const int32_t *__restrict__ n_items, int item_size, int nbx, Ptrs3 dpk, Ptrs3 dlk,  \
+        Ptrs3 apl, Ptrs3 ali, const float *__restrict__ dcoef, const float *__restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk, \
+        MPtrs3 g_apl, MPtrs3 g_ali, float *__restrict__ g_basis, int z_density, int z_app
+template <bool WITH_NORMAL, int HALVES>
+__device__ __forceinline__ void walk_items(NMF_BWD_ARGS) {
     // The item count lives on the device; the grid is a fixed number of single-wave workgroups that stride over the list
     // (a grid sized by the host-side upper bound -- non-empty bricks <= all bricks -- would be 100 k-1 M mostly idle
     // workgroups with 4^3 bricks)
-    __shared__ float4 lds[64 * 16];
+    // 16 KB when the appearance halves run (records + coefficient / adjoint rows of 64 samples), 4 KB for a density-only
+    // launch
+    extern __shared__ float4 lds[];
     const int n = *n_items;
     const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
     for (int item = (int)blockIdx.x; item < n; item += (int)gridDim.x) {
         const int2 it = items[item];
         const int brick = it.x;
         const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
-        if (half == z_density) vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
-        else if (half == z_app)
+        if (HALVES == 0 || (HALVES == 2 && half == z_density))
+            vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
+        else if (HALVES == 1 || (HALVES == 2 && half == z_app))
             vm_bwd_app2(p, rec0, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
         __syncthreads();
     }
+}
+#define NMF_BWD_PASS                                                                                                  \
+    p, rec0, rec1, bin_off, items, n_items, item_size, nbx, dpk, dlk, apl, ali, dcoef, d_app, g_dpk, g_dlk, g_apl, g_ali, \
+        g_basis, z_density, z_app
+template <bool WITH_NORMAL, int HALVES>
+__global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(NMF_BWD_ARGS) {
+    walk_items<WITH_NORMAL, HALVES>(NMF_BWD_PASS);
+}
+template <bool WITH_NORMAL>
+__global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(3))) k_vm_bwd_density(NMF_BWD_ARGS) {
+    walk_items<WITH_NORMAL, 0>(NMF_BWD_PASS);
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -1237,15 +1252,24 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
                            cursor, rec0, rec1, d_app_sorted, basis, dcoef);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
-    const int64_t grid_x = max_items < 16384 ? max_items : 16384;       // 64 single-wave workgroups per CU and plane
+    int64_t gcap = 16384;
+    if (const char* ev = getenv("NMF_BWD_GRID")) gcap = atoi(ev) > 0 ? atoi(ev) : gcap;   // tuning knob
+    const int64_t grid_x = max_items < gcap ? max_items : gcap;       // single-wave workgroups per plane
     const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);
-#define NMF_LAUNCH_BWD(WN)                                                                                            \
-    hipLaunchKernelGGL((k_vm_bwd_brick<WN>), grid, block, 0, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
+    const size_t lds_bytes = sizeof(float4) * 64 * (want_a ? 16 : 4);
+#define NMF_LAUNCH_BWD_KERNEL(KERNEL)                                                                                            \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds_bytes, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
                        mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \
                        mkm(g_app_planes), mkm(g_app_lines), use_copies ? basis_copies : nullptr, z_density, z_app)
-    if (d_normal) NMF_LAUNCH_BWD(true);
-    else NMF_LAUNCH_BWD(false);
-#undef NMF_LAUNCH_BWD
+    if (want_d && want_a) {
+        if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<true, 2>));
+        else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 2>));
+    } else if (want_d) {
+        if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<true>));
+        else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<false>));
+    } else
+        NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 1>));
+#undef NMF_LAUNCH_BWD_KERNEL
     if (use_copies)
         hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, basis_copies, g_basis);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
