@@ -475,12 +475,15 @@ def main():
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"]},
-            # Dominant kernel: the backward walk of the VM field (table-gradient scatter-add on the matrix cores).  The two
-            # rooflines the task names, both from the LIVE per-launch duration (HIP events on the launch stream):
-            #   mfma: issued v_mfma_f32_16x16x4_f32 FLOP / time against the 157.3 TFLOP/s f32 MFMA peak  -> `frac`
-            #   hbm : SURVEY 8(d) algorithmic bytes / time against 8 TB/s -> `algorithmic_over_hbm` (can exceed 1: the
-            #         7.5 MB of factor tables live in L2/MALL and tiles accumulate in registers; `traffic` is what the PMC
-            #         counters say actually crossed the fabric per launch)
+            # Dominant kernel: the backward walk of the VM field (table-gradient scatter-add on the matrix cores).  Its
+            # ceiling is the SIMD's ALU pipe: on gfx950 an fp32 MFMA and the other VALU instructions do not overlap
+            # (tools/ub/coexec.hip), so MFMA cycles and VALU cycles add up.
+            #   `achieved` / `frac`: ISSUED v_mfma_f32_16x16x4_f32 FLOP of the launches of the timed region / their HIP-event
+            #         time (events on the launch stream), against the 157.3 TFLOP/s fp32 MFMA peak = live MFMA-busy share
+            #   `alu_busy_counters`: MFMA-busy + VALU-issue share of the density walk from the committed counter run
+            #         (tools/roofline_metrics.py) -- the fraction of the kernel's real ceiling
+            #   `algorithmic_over_hbm`: SURVEY 8(d) bytes / time against 8 TB/s (can exceed 1: the 7.5 MB of factor tables
+            #         live in L2/MALL and tiles accumulate in registers); `traffic` = fabric bytes per launch from PMC
             "roofline": {"bound": "mfma", "kernel": "nmf_vm_query_bwd_segments (k_vm_bwd_brick + binning)",
                          "achieved": mfma_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": mfma_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
@@ -490,6 +493,7 @@ def main():
                                                           "appearance (bounce rows)": BWD_BYTES_APP},
                          "algorithmic_GBps": alg_gbs, "algorithmic_over_hbm": alg_gbs / HBM_PEAK_GBS,
                          "hbm_frac_counters": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
+                         "alu_busy_counters": (per_kernel or {}).get("k_vm_bwd_brick<density>", {}).get("alu_busy"),
                          "counters": ctr_meta, "per_kernel": per_kernel},
         }
         if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID \

@@ -43,13 +43,14 @@ i=0
 for G in $PMC_SETS; do
   i=$((i+1))
   rm -rf /tmp/prof_pmc_$i
-  rocprofv3 --pmc $(echo $G | tr ',' ' ') --kernel-trace --output-format csv -d /tmp/prof_pmc_$i -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/${TAG}_pmc_$i.log" 2>&1 || echo "counter group $G failed (see ${TAG}_pmc_$i.log)"
+  timeout 300 rocprofv3 --pmc $(echo $G | tr ',' ' ') --kernel-trace --output-format csv -d /tmp/prof_pmc_$i -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/${TAG}_pmc_$i.log" 2>&1 || echo "counter group $G failed (see ${TAG}_pmc_$i.log)"
 done
 python - "$TAG" "$OUT" "$ROOT" <<'PY'
 import csv, glob, json, subprocess, sys, collections, re
 tag, out, root = sys.argv[1], sys.argv[2], sys.argv[3]
 # kernels of the steady-state step, by substring of the demangled name -> report key
-KEYS = {"k_vm_bwd_brick<true": "k_vm_bwd_brick<density>", "k_vm_bwd_brick<false": "k_vm_bwd_brick<appearance>",
+KEYS = {"k_vm_bwd_density": "k_vm_bwd_brick<density>", "k_vm_bwd_brick<true": "k_vm_bwd_brick<density>",
+        "k_vm_bwd_brick<false": "k_vm_bwd_brick<appearance>",
         "k_brdf_mlp_bwd": "k_brdf_mlp_bwd", "k_brdf_mlp_fwd": "k_brdf_mlp_fwd", "k_env_lookup_bwd": "k_env_lookup_bwd",
         "k_env_lookup_fwd": "k_env_lookup_fwd", "k_vm_fwd": "k_vm_fwd", "k_march_count16": "k_march_count16",
         "k_march_fill16": "k_march_fill16", "k_brick_scatter": "k_brick_scatter", "k_ggx_rays_bwd": "k_ggx_rays_bwd",
