@@ -351,6 +351,76 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, appearance only: EIGHT lanes per sample.  The sparse-appearance path queries the appearance features of the
+// bounce rows alone (8 k - 20 k rows per level): with a lane per sample that is 30 - 70 workgroups on 256 CUs, each lane
+// running 108 loads, 430 tap FMAs and the 72 -> 24 basis product one after the other (27 us per launch whatever the row
+// count, profiles/r02_c).  Here lane q of a row owns the channels 3q .. 3q+2 of every tap (a 96-byte run per tap and
+// row), parks its 9 coefficients in LDS, and then computes the outputs 3q .. 3q+2 from the row's 72 coefficients with the
+// basis matrix staged in LDS.  Tap order and the c-order of the basis product are those of k_vm_fwd: identical bits.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+
+constexpr int APP_ROWS = 32;              // rows per 256-thread workgroup
+constexpr int APP_PITCH = 3 * CA + 4;     // LDS pitch of a coefficient row (76: rows of a wave start on different banks)
+template <class TT>
+__global__ void __launch_bounds__(256) k_vm_app_rows(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
+                                                     PtrsT3<TT> apl, PtrsT3<TT> ali, const float* __restrict__ basis,
+                                                     float* __restrict__ app) {
+    __shared__ float s_basis[AD * 3 * CA];
+    __shared__ float s_coef[APP_ROWS * APP_PITCH];
+    for (int i = threadIdx.x; i < AD * 3 * CA; i += 256) s_basis[i] = basis[i];
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int64_t m = (int64_t)blockIdx.x * APP_ROWS + r;
+    const int G = p.grid;
+    if (m < M) {
+        float xn[3];
+        normalized(p, xyzt[m], xn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const Tap1 tl = make_tap1(xn[VEC[i]], G);
+            float La[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (tl.idx[t] < 0) continue;
+                const TT* run = ali.p[i] + (int64_t)tl.idx[t] * CA + 3 * q;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) La[k] += tl.w[t] * ld1(run + k);
+            }
+            const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
+            float Pa[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (tp.idx[t] < 0) continue;
+                const TT* run = apl.p[i] + (int64_t)tp.idx[t] * CA + 3 * q;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Pa[k] += tp.w[t] * ld1(run + k);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_coef[r * APP_PITCH + i * CA + 3 * q + k] = Pa[k] * La[k];     // tensoRF.py:204
+        }
+    }
+    __syncthreads();
+    if (m >= M) return;
+    float out[3] = {0.f, 0.f, 0.f};
+    const float* cf = s_coef + r * APP_PITCH;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CA; ++c) {
+            const float v = cf[i * CA + c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] += s_basis[(3 * q + k) * (3 * CA) + i * CA + c] * v;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] += a[k];
+    }
+    float* o = app + m * AD + 3 * q;
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: brick-binned LDS accumulation.
 //
 // A per-sample scatter with global atomics (768 density + 432 appearance adds per sample) runs at
@@ -1120,6 +1190,12 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
     NMF_REQUIRE(!want_a || (app_planes && app_lines && app_planes[0] && app_planes[1] && app_planes[2] && app_lines[0] &&
                             app_lines[1] && app_lines[2] && (!app || basis)),
                 NMF_EINVAL, "nmf_vm_query_fwd: appearance tables missing");
+    if (!want_d && app && !coef) {      // appearance of the bounce rows: 8 lanes per row
+        hipLaunchKernelGGL(k_vm_app_rows<TT>, dim3((unsigned)cdiv(M, APP_ROWS)), dim3(256), 0, (hipStream_t)stream, *p,
+                           (const float4*)xyzt, M, mkT<TT>(app_planes, true), mkT<TT>(app_lines, true), basis, app);
+        NMF_CHECK_LAUNCH(what);
+        return NMF_OK;
+    }
     hipLaunchKernelGGL(k_vm_fwd<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        (const float4*)xyzt, M, mkT<TT>(dpk, want_d), mkT<TT>(dlk, want_d), mkT<TT>(app_planes, want_a),
                        mkT<TT>(app_lines, want_a), basis, sigma_feat, sigma, grad, normal, app, coef);

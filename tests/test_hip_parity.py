@@ -661,6 +661,32 @@ def test_ggx_rays_and_mix_vs_oracle():
         assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), what="mix d" + n)
 
 
+@pytest.mark.parametrize("M", [1, 31, 33, 5000])
+def test_vm_appearance_rows_kernel_equals_the_full_query(M):
+    """The appearance-only query of the bounce rows runs on its own kernel (8 lanes per row, k_vm_app_rows); the full query
+    (k_vm_fwd, a lane per sample) computes the same features next to the density: same tap order, same c-order in the
+    72 -> 24 basis product, hence the same bits -- fp32 and bf16 tables, samples outside the box included."""
+    hip = _hip()
+    from nmf_amd.config import build_model
+    nerf, _ = build_model(grid=33, bg_resolution=16, device=DEV)
+    rf = nerf.rf
+    gen = torch.Generator().manual_seed(M)
+    with torch.no_grad():
+        for prm in rf._param_list()[:13]:
+            prm.copy_((0.3 * torch.randn(prm.shape, generator=gen)).to(DEV))
+    xyz = ((torch.rand(M, 4, generator=gen) * 2 - 1) * 1.7).to(DEV)
+    p, dpk, dlk, apl, ali, basis = rf._tables()
+    full = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis)[4]
+    rows = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
+    assert rows.shape == (M, 24) and torch.equal(rows, full)
+    assert float(full.abs().max()) > 0
+    rf.set_table_dtype("bf16")
+    pb, dpk_b, dlk_b, apl_b, ali_b, _ = rf._fwd_tables()
+    full_b = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis)[4]
+    rows_b = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_density=False, want_normal=False, want_app=True)[4]
+    assert torch.equal(rows_b, full_b)
+
+
 def test_vm_query_bf16_tables():
     """BASELINE configs[1]: nmf_vm_query_fwd_bf16 reads bfloat16 factor tables (half the bytes per tap) with fp32 arithmetic.
     (1) exactly the fp32 kernel's result on tables rounded to bf16; (2) within bf16 resolution of the fp32-table result;
