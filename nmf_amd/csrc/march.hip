@@ -646,6 +646,111 @@ __global__ void k_scan_clamp(int64_t* __restrict__ offsets, int64_t B, const int
     if (i == B || offsets[i] < 0) offsets[i] = totals[0];
 }
 
+// ---- the same scan in two launches (one for B <= 4096) ---------------------------------------------------------------
+// k_scan_top / k_scan_final / k_scan_clamp above are three dependent launches of a few microseconds each around ~10 KB of
+// data -- a fifth of the level-0 sampler's time.  With at most 4096 chunks every workgroup of the final pass can scan the
+// chunk sums itself (4 per thread): its own base, the grand total, whether the budget binds and in which chunk c* the
+// cumulative count crosses it.  Rays past the crossing take offsets = M directly (workgroups behind c* rescan chunk c*
+// to learn M), so no clamp pass is needed.  With at most 4 chunks the chunk sums are computed here as well (no
+// k_scan_partial).  Same outputs as the three-launch form (tests compare them).
+__device__ __forceinline__ int64_t block_scan_incl(int64_t v, int64_t* ws, int tid, int64_t& block_total) {
+    const int lane = tid & 63, wid = tid >> 6;
+    int64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();                 // ws may still be read by the previous use
+    if (lane == 63) ws[wid] = incl;
+    __syncthreads();
+    int64_t woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int64_t x = ws[w];
+        if (w < wid) woff += x;
+        tot += x;
+    }
+    block_total = tot;
+    return woff + incl;
+}
+
+__global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __restrict__ counts, int64_t B, int64_t max_samples,
+                                                           const int64_t* __restrict__ chunk_sum, int n_chunks,
+                                                           int64_t* __restrict__ offsets, uint8_t* __restrict__ whole_valid,
+                                                           int64_t* __restrict__ totals) {
+    __shared__ int64_t ws[16];
+    __shared__ int64_t s_base, s_cbase, s_direct[4];
+    __shared__ int s_cstar;
+    const int tid = threadIdx.x;
+    const int my = (int)blockIdx.x;
+    // ---- phase A: the chunk sums, 4 per thread (chunk 4 tid + k)
+    int64_t v4[4] = {0, 0, 0, 0};
+    if (chunk_sum) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int c = 4 * tid + k; v4[k] = c < n_chunks ? chunk_sum[c] : 0; }
+    } else {                                         // n_chunks <= 4: sum the chunks here
+        for (int c = 0; c < n_chunks; ++c) {
+            const int64_t i = (int64_t)c * SCAN_CHUNK + tid;
+            int64_t tot;
+            block_scan_incl(i < B ? counts[i] : 0, ws, tid, tot);
+            if (tid == 0) s_direct[c] = tot;
+        }
+        __syncthreads();
+        if (tid == 0) for (int c = 0; c < n_chunks; ++c) v4[c] = s_direct[c];
+    }
+    const int64_t tsum = v4[0] + v4[1] + v4[2] + v4[3];
+    int64_t total;
+    const int64_t excl_t = block_scan_incl(tsum, ws, tid, total) - tsum;
+    const bool budget = max_samples > 0 && total > max_samples;
+    {
+        int64_t run = excl_t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * tid + k;
+            if (c == my) s_base = run;
+            if (budget && c < n_chunks && run < max_samples && run + v4[k] >= max_samples) { s_cstar = c; s_cbase = run; }
+            run += v4[k];
+        }
+    }
+    __syncthreads();
+    const int cstar = budget ? s_cstar : n_chunks;
+    // ---- phase B: this chunk
+    const int64_t i = (int64_t)my * SCAN_CHUNK + tid;
+    const int64_t v = i < B ? counts[i] : 0;
+    int64_t dummy;
+    const int64_t cum = s_base + block_scan_incl(v, ws, tid, dummy);       // inclusive cumsum(counts)[i]
+    const bool ok = !budget || cum < max_samples;                          // strict '<' (alphagrid.py:359)
+    // ---- M (kept samples) for the chunks that hold dropped rays: the largest cumulative count below the budget
+    int64_t M = 0;
+    if (budget && my >= cstar) {
+        int64_t cum_c = cum;
+        bool in_c = i < B;
+        if (my > cstar) {
+            const int64_t ic = (int64_t)cstar * SCAN_CHUNK + tid;
+            in_c = ic < B;
+            cum_c = s_cbase + block_scan_incl(in_c ? counts[ic] : 0, ws, tid, dummy);
+        }
+        const bool ok_c = in_c && cum_c < max_samples;
+        int64_t n_ok;
+        block_scan_incl(ok_c ? 1 : 0, ws, tid, n_ok);                      // valid rays are a prefix: count them
+        __syncthreads();
+        if (tid == 0) s_direct[0] = s_cbase;                               // no valid ray in c*: M = its base
+        __syncthreads();
+        if (ok_c && tid + 1 == n_ok) s_direct[0] = cum_c;                  // the last valid ray
+        __syncthreads();
+        M = s_direct[0];
+        if (my == cstar && tid == 0) {
+            totals[0] = M;
+            totals[1] = (int64_t)cstar * SCAN_CHUNK + n_ok;
+            offsets[B] = M;
+        }
+    }
+    if (!budget && my == 0 && tid == 0) { totals[0] = total; totals[1] = B; offsets[B] = total; }
+    if (i < B) {
+        whole_valid[i] = ok ? 1 : 0;
+        offsets[i] = ok ? cum - v : M;
+    }
+}
+
 }  // namespace
 
 extern "C" int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* bits, void* stream) {
@@ -727,6 +832,14 @@ extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samp
     hipStream_t st = (hipStream_t)stream;
     int64_t* chunk = (int64_t*)workspace;
     int64_t* meta = chunk + n_chunks;
+    const bool three_pass = getenv("NMF_SCAN_3PASS") != nullptr;             // the round-1 form (tests compare the two)
+    if (n_chunks <= 4096 && !three_pass) {
+        if (n_chunks > 4) hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
+        hipLaunchKernelGGL(k_scan_fused, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples,
+                           n_chunks > 4 ? chunk : nullptr, (int)n_chunks, offsets, whole_valid, totals);
+        NMF_CHECK_LAUNCH("nmf_march_scan");
+        return NMF_OK;
+    }
     hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk, (int)n_chunks, B, max_samples, offsets, totals,
                        meta);

@@ -92,8 +92,10 @@ __global__ void __launch_bounds__(256) k_view_adjoint_to_rays(const int32_t* __r
 extern "C" int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace3,
                                 float* total, void* stream) {
     NMF_REQUIRE(M > 0 && weights && u && workspace3 && total, NMF_EINVAL, "nmf_select_total: null / empty");
+    // every workgroup ends in two float64 atomics on the same words, a fence and the ticket: 128 workgroups (0.9 M
+    // samples: 14.5 us) beat 512 (24 us) and 64 (20.7 us)
     int64_t blocks = cdiv(M, 256 * 8);
-    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+    blocks = blocks > 128 ? 128 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(k_select_total, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weights, u, M, extra,
                        workspace3, total);
     NMF_CHECK_LAUNCH("nmf_select_total");

@@ -2,6 +2,7 @@
 the reference's golden vectors.  Bit-exact for masks / indices / counts / sample positions;
 floats within the stated tolerances.  Run on the MI355X box with `-m gpu`."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -51,6 +52,43 @@ def _check_march(out, xyz, rv, z, dists, wv):
     ri, si = torch.where(rv)
     assert torch.equal(out["ray_id"].long(), ri) and torch.equal(out["step_id"].long(), si)
     assert torch.equal(out["counts"][: rv.shape[0]].long(), rv.sum(1))
+
+
+@pytest.mark.parametrize("B", [1, 1000, 1024, 4096, 4097, 5000, 300001])
+def test_march_scan_budget_against_numpy_and_the_three_pass_form(B):
+    """nmf_march_scan (alphagrid.py:353-364): exclusive offsets, whole_valid = cumsum(counts) < max_samples when the
+    budget binds, (M, b) and the clamped offsets of the dropped rays -- the two-launch scan against numpy and against the
+    round-1 three-pass kernels (NMF_SCAN_3PASS=1), budgets below / inside / above the total, crossing at chunk borders."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(B)
+    counts = torch.randint(0, 9, (B,), generator=gen, dtype=torch.int32)
+    counts[torch.rand(B, generator=gen) < 0.3] = 0
+    cum = counts.long().cumsum(0)
+    total = int(cum[-1])
+    budgets = {-1, 0, 1, max(total // 3, 1), max(total - 1, 1), total, total + 1}
+    for k in (1024, 2048, 4096):          # budgets that make the crossing ray the first / last ray of a chunk
+        if B > k:
+            budgets |= {int(cum[k - 1]), int(cum[k - 1]) + 1, int(cum[k]), max(int(cum[k - 2]), 1)}
+    for mx in sorted(budgets):
+        off, wv, tot = hip.march_scan(counts.to(DEV), mx)
+        os.environ["NMF_SCAN_3PASS"] = "1"
+        try:
+            off3, wv3, tot3 = hip.march_scan(counts.to(DEV), mx)
+        finally:
+            del os.environ["NMF_SCAN_3PASS"]
+        assert torch.equal(off, off3) and torch.equal(wv, wv3) and torch.equal(tot, tot3), (B, mx)
+        if mx > 0 and total > mx:
+            ok = cum < mx
+            b = int(ok.sum())
+            M = int(cum[b - 1]) if b > 0 else 0
+            ref_off = torch.where(ok, cum - counts.long(), torch.full_like(cum, M))
+        else:
+            ok = torch.ones(B, dtype=torch.bool)
+            b, M = B, total
+            ref_off = cum - counts.long()
+        assert [int(v) for v in tot.cpu()] == [M, b], (B, mx, tot.cpu().tolist(), M, b)
+        assert torch.equal(wv.cpu().bool(), ok)
+        assert torch.equal(off.cpu()[:B], ref_off) and int(off[B]) == M
 
 
 def test_march_golden_eval_train_budget_secondary():
