@@ -807,8 +807,11 @@ struct DGrp {
     float l0, l1;
     float t[12];   // P, X, Y at the nw, ne, sw, se texels
     float u[4];    // L (2 taps), DL (2 taps)
+    // T / TLn: the plane / line table of this walk (uniform), j4 = 4 * channel lane.  Taps are addressed as a uniform base +
+    // a 32-bit byte offset (global_load ... s[base] with a VGPR offset): 64-bit per-lane pointers cost ~17 VALU per group
+    // in a loop whose ceiling is MFMA + VALU cycles
     __device__ __forceinline__ void load(const float4* lds, int k, int g, const float* __restrict__ T,
-                                         const float* __restrict__ TLn, int G) {
+                                         const float* __restrict__ TLn, int G, uint32_t j4) {
         const float4* r = lds + (4 * g + k) * 4;
         W = r[0];
         const float4 Q = r[1], L = r[2];
@@ -816,17 +819,23 @@ struct DGrp {
         c00 = __float_as_int(Q.x);
         lcell = __float_as_int(Q.w);
         l0 = L.x; l1 = L.y;
-        const int fl = __float_as_int(Q.z);
-        const int sxo = (fl & 1) ? DP : 0, syo = (fl & 2) ? G * DP : 0;
-        const float* q = T + (int64_t)__float_as_int(Q.y) * DP;
-        t[0] = q[0]; t[1] = q[sxo]; t[2] = q[syo]; t[3] = q[syo + sxo];
+        const uint32_t fl = (uint32_t)__float_as_int(Q.z);
+        const uint32_t sxo = (fl & 1u) ? (uint32_t)(DP * 4) : 0u, syo = (fl & 2u) ? (uint32_t)G * (DP * 4) : 0u;
+        const char* tb = reinterpret_cast<const char*>(T);
+        const uint32_t o0 = __umul24((uint32_t)__float_as_int(Q.y), (uint32_t)(DP * 4)) + j4;     // texel index < 2^24
+        const uint32_t o1 = o0 + sxo, o2 = o0 + syo, o3 = o2 + sxo;
+        // the channel-block offsets are added AFTER the zero extension so that they fold into the instruction's immediate
+        auto ld = [](const char* b, uint32_t off, int imm) { return *reinterpret_cast<const float*>(b + (size_t)off + imm); };
+        t[0] = ld(tb, o0, 0); t[1] = ld(tb, o1, 0); t[2] = ld(tb, o2, 0); t[3] = ld(tb, o3, 0);
         if (WITH_NORMAL) {
-            t[4] = q[CD]; t[5] = q[sxo + CD]; t[6] = q[syo + CD]; t[7] = q[syo + sxo + CD];
-            t[8] = q[2 * CD]; t[9] = q[sxo + 2 * CD]; t[10] = q[syo + 2 * CD]; t[11] = q[syo + sxo + 2 * CD];
+            t[4] = ld(tb, o0, CD * 4); t[5] = ld(tb, o1, CD * 4); t[6] = ld(tb, o2, CD * 4); t[7] = ld(tb, o3, CD * 4);
+            t[8] = ld(tb, o0, 2 * CD * 4); t[9] = ld(tb, o1, 2 * CD * 4); t[10] = ld(tb, o2, 2 * CD * 4);
+            t[11] = ld(tb, o3, 2 * CD * 4);
         }
-        const float* a0 = TLn + (int64_t)__float_as_int(L.z) * DL;
-        const float* a1 = TLn + (int64_t)__float_as_int(L.w) * DL;
-        u[0] = a0[0]; u[1] = a1[0]; u[2] = a0[CD]; u[3] = a1[CD];
+        const char* lb = reinterpret_cast<const char*>(TLn);
+        const uint32_t a0 = __umul24((uint32_t)__float_as_int(L.z), (uint32_t)(DL * 4)) + j4;
+        const uint32_t a1 = __umul24((uint32_t)__float_as_int(L.w), (uint32_t)(DL * 4)) + j4;
+        u[0] = ld(lb, a0, 0); u[1] = ld(lb, a1, 0); u[2] = ld(lb, a0, CD * 4); u[3] = ld(lb, a1, CD * 4);
     }
 };
 
@@ -839,8 +848,9 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
     const int lane = threadIdx.x & 63;
     const int k = lane >> 4, j = lane & 15;
     const int ox = i == 2 ? by : bx, oy = i == 0 ? by : bz, oz = i == 0 ? bz : (i == 1 ? by : bx);
-    const float* __restrict__ T = pick3(dpk, i) + j;
-    const float* __restrict__ TLn = pick3(dlk, i) + j;
+    const float* __restrict__ T = pick3(dpk, i);
+    const float* __restrict__ TLn = pick3(dlk, i);
+    const uint32_t j4 = 4u * (uint32_t)j;
     floatx4 accP[NRB], accX[NRB], accY[NRB];
     floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
 #pragma unroll
@@ -868,7 +878,7 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
         // are in flight while group g feeds the matrix pipe
         DGrp<WITH_NORMAL> st0, st1;
         auto step = [&](DGrp<WITH_NORMAL>& cur, DGrp<WITH_NORMAL>& nxt, int g) {
-            nxt.load(lds, k, min(g + 1, 15), T, TLn, G);      // branch-free: slots past the end hold zero adjoints
+            nxt.load(lds, k, min(g + 1, 15), T, TLn, G, j4);  // branch-free: slots past the end hold zero adjoints
             __builtin_amdgcn_sched_barrier(0);
             const float4 W = cur.W, A = cur.A;
             const float Pq = W.x * cur.t[0] + W.y * cur.t[1] + W.z * cur.t[2] + W.w * cur.t[3];
@@ -898,7 +908,7 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
             if (WITH_NORMAL) accDL = __builtin_amdgcn_mfma_f32_16x16x4f32(al, bDL, accDL, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
-        st0.load(lds, k, 0, T, TLn, G);
+        st0.load(lds, k, 0, T, TLn, G, j4);
         for (int g = 0; g < ng; g += 2) {       // an odd tail stage runs on a slot whose adjoints are zero
             step(st0, st1, g);
             step(st1, st0, g + 1);
