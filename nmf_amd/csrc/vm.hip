@@ -950,14 +950,20 @@ struct AGrp {
         dc0 = ldc[sl * CA + j]; dc1 = ldc[sl * CA + jh];            // zero for slots past the end
         aq0 = 0.f; aq1 = 0.f;
         if (want_basis) { aq0 = lda[sl * AD + j]; aq1 = lda[sl * AD + jh]; }
-        const int fl = __float_as_int(Q.z);
-        const int sxo = (fl & 1) ? CA : 0, syo = (fl & 2) ? G * CA : 0;
-        const float* q = T + (int64_t)__float_as_int(Q.y) * CA;
-        t[0] = q[j]; t[1] = q[sxo + j]; t[2] = q[syo + j]; t[3] = q[syo + sxo + j];
-        t[4] = q[jh]; t[5] = q[sxo + jh]; t[6] = q[syo + jh]; t[7] = q[syo + sxo + jh];
-        const float* a0 = TLn + (int64_t)__float_as_int(L.z) * CA;
-        const float* a1 = TLn + (int64_t)__float_as_int(L.w) * CA;
-        u[0] = a0[j]; u[1] = a1[j]; u[2] = a0[jh]; u[3] = a1[jh];
+        // uniform base + 32-bit byte offsets, as in DGrp::load
+        const uint32_t fl = (uint32_t)__float_as_int(Q.z);
+        const uint32_t sxo = (fl & 1u) ? (uint32_t)(CA * 4) : 0u, syo = (fl & 2u) ? (uint32_t)G * (CA * 4) : 0u;
+        const char* tb = reinterpret_cast<const char*>(T);
+        const uint32_t o = __umul24((uint32_t)__float_as_int(Q.y), (uint32_t)(CA * 4));
+        const uint32_t oj = o + 4u * (uint32_t)j, oh = o + 4u * (uint32_t)jh;
+        auto ld = [](const char* b, uint32_t off) { return *reinterpret_cast<const float*>(b + (size_t)off); };
+        t[0] = ld(tb, oj); t[1] = ld(tb, oj + sxo); t[2] = ld(tb, oj + syo); t[3] = ld(tb, oj + syo + sxo);
+        t[4] = ld(tb, oh); t[5] = ld(tb, oh + sxo); t[6] = ld(tb, oh + syo); t[7] = ld(tb, oh + syo + sxo);
+        const char* lb = reinterpret_cast<const char*>(TLn);
+        const uint32_t a0 = __umul24((uint32_t)__float_as_int(L.z), (uint32_t)(CA * 4));
+        const uint32_t a1 = __umul24((uint32_t)__float_as_int(L.w), (uint32_t)(CA * 4));
+        u[0] = ld(lb, a0 + 4u * (uint32_t)j); u[1] = ld(lb, a1 + 4u * (uint32_t)j);
+        u[2] = ld(lb, a0 + 4u * (uint32_t)jh); u[3] = ld(lb, a1 + 4u * (uint32_t)jh);
     }
 };
 
@@ -1089,7 +1095,7 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
 // latency-bound walks of an item overlap; single-wave workgroups
 // HALVES: 0 = density planes only, 1 = appearance planes only, 2 = both (blockIdx.y / 3 picks).  The single-half
 // instantiations keep the other walk's registers out of the allocation: both walks in one kernel need 172 registers = 2
-// waves per SIMD; the density walk alone runs 3 (136 registers; forcing 4 spills and gains nothing).  The 1 M-sample
+// waves per SIMD; the density walk alone ran 3 (136 registers) and runs 4 since its tap addresses are 32-bit offsets (128).  The 1 M-sample
 // density walk of a training step is latency bound (profiles r02_c: 1.68 waves per SIMD resident, ALU 41 % busy):
 // 318 -> 290 us at 128^3, field backward 0.306 -> 0.256 ms per launch at 300^3.
 #define NMF_BWD_ARGS                                                                                                   \
