@@ -73,7 +73,10 @@ __global__ void __launch_bounds__(256) k_composite_fwd_wave(const float* __restr
         if (in) alpha = 1.0f - expf(-fmul(sigma[k], fmul(dist[k], scale)));
         const float f = in ? fadd(fsub(1.0f, alpha), 1e-10f) : 1.0f;
         const double incl = group_incl_prod<W>((double)f, lane);
-        const double T = carry * (incl / (double)f);          // exclusive product (f >= 1e-10 > 0)
+        // exclusive product = the inclusive product of the lane below (a float64 division by f costs ~30 instructions and
+        // two more roundings)
+        const double below = lane_below<W, 1>(incl);
+        const double T = carry * (lane >= 1 ? below : 1.0);
         const float w = fmul(alpha, (float)T);
         if (in) weight[k] = w;
         a_sum += in ? w : 0.f;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd_wave(const float* __restr
             const float d = fmul(dist[k], scale);
             const float ex = expf(-fmul(sigma[k], d));
             const float f = fadd(fsub(1.0f, 1.0f - ex), 1e-10f);
-            d_sigma[k] = (float)(-((carry + incl - v) / (double)f)) * (d * ex);
+            d_sigma[k] = (-(float)(carry + incl - v) / f) * (d * ex);      // float64 suffix sum, fp32 quotient
         }
         carry += __shfl(incl, W - 1, W);
     }
@@ -121,7 +124,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd_wave(const float* __restr
         if (in) { d = fmul(dist[k], scale); ex = expf(-fmul(sigma[k], d)); }
         const float f = in ? fadd(fsub(1.0f, 1.0f - ex), 1e-10f) : 1.0f;
         const double incl = group_incl_prod<W>((double)f, lane);
-        const double T = cp * (incl / (double)f);
+        const double below = lane_below<W, 1>(incl);
+        const double T = cp * (lane >= 1 ? below : 1.0);
         if (in) d_sigma[k] += d_weight[k] * (float)T * (d * ex);
         cp *= __shfl(incl, W - 1, W);
     }
