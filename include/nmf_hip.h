@@ -315,15 +315,18 @@ int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, 
 int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                      const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                      const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
-                     void* stream);
+                     int32_t max_workgroups /* 0 = default; see nmf_brdf_mlp_bwd */, void* stream);
 /* Backward (recomputes the forward per 64-ray tile).  d_xfeat [R][24] = adjoint of the gathered feature
  * columns (overwritten; reduce it per bounce point with nmf_segment_sum_wide); gW* / gb* are ACCUMULATED
- * (caller zeroes): gW0 [64][66], gb0 [64], gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4]. */
+ * (caller zeroes): gW0 [64][66], gb0 [64], gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4].
+ * max_workgroups: 0 = the kernel's own choice (one or two persistent workgroups per CU); > 0 caps the persistent
+ * workgroups, for callers that run this launch on a second stream NEXT TO other kernels and want it to leave
+ * registers / LDS on every CU free for them (the training pass: csrc/brdf_mlp.hip, nmf_amd/fast_step.py). */
 int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                      const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                      const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias,
                      const float* d_out, float* d_xfeat, float* gW0, float* gb0, float* gW2, float* gb2,
-                     float* gW4, float* gb4, void* stream);
+                     float* gW4, float* gb4, int32_t max_workgroups, void* stream);
 /* out[s][0:D] = sum_{r in segment s} vals[r*row_stride + 0:D], D <= 64 (adjoint of the feature gather). */
 int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
                          int64_t n_seg, float* out, void* stream);

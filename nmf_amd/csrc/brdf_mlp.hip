@@ -365,14 +365,16 @@ static int check_w(const float* const* p) {
 extern "C" int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                                 const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
-                                void* stream) {
+                                int32_t max_workgroups, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_fwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
     NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && out, NMF_EINVAL, "nmf_brdf_mlp_fwd: null");
     MlpW w{W0, b0, W2, b2, W4, b4};
     const int64_t tiles = cdiv(R, TR);
-    const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
+    int64_t cap = 1024;
+    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, half_vec, diff_vec, feat_src,
                        rough_src, src_idx, R, out_bias, out);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_fwd");
@@ -383,7 +385,7 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                                 const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias,
                                 const float* d_out, float* d_xfeat, float* gW0, float* gb0, float* gW2, float* gb2,
-                                float* gW4, float* gb4, void* stream) {
+                                float* gW4, float* gb4, int32_t max_workgroups, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
@@ -397,7 +399,8 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
     // The kernel is compiled for two workgroups per CU (<= 256 registers, 2 x 76 KB of LDS).  The second one hides barrier
     // and LDS latency of the first but doubles the weight staging and the 8.5 k flush atomics per workgroup, so it only
     // pays for long launches (measured: 242 k rays 210 -> 187 us, 46 k rays 60 -> 68 us).
-    const int64_t cap = tiles >= 2048 ? 512 : 256;
+    int64_t cap = tiles >= 2048 ? 512 : 256;
+    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(256), BWD_LDS, (hipStream_t)stream, w, half_vec, diff_vec,
                        feat_src, rough_src, src_idx, R, out_bias, d_out, d_xfeat, gW0, gb0, gW2, gb2, gW4, gb4);

@@ -198,13 +198,13 @@ std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg,
 }
 
 Tensor brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
-                    const Tensor& rough_src, const OT& src_idx, double out_bias, int64_t stream) {
+                    const Tensor& rough_src, const OT& src_idx, double out_bias, int64_t max_workgroups, int64_t stream) {
     if (w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor o = fe(half_vec, {R, 3});
     check(nmf_brdf_mlp_fwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
                            f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
-                           st(stream)),
+                           (int32_t)max_workgroups, st(stream)),
           "nmf_brdf_mlp_fwd");
     return o;
 }
@@ -328,7 +328,7 @@ OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, doubl
 
 Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
                     const Tensor& rough_src, const OT& src_idx, double out_bias, const Tensor& d_out,
-                    const std::vector<Tensor>& grads, int64_t stream) {
+                    const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream) {
     if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor d_xfeat = fe(half_vec, {R, 24});
@@ -337,7 +337,7 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
     check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
                            f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, f32(go),
-                           out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], st(stream)),
+                           out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, st(stream)),
           "nmf_brdf_mlp_bwd");
     return d_xfeat;
 }

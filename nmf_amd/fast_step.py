@@ -12,6 +12,7 @@ Scope: is_train=True, the sparse-appearance path (no debug maps), recursion dept
 hooks (model.forced / model.trace / sampler.forced_valid).  Anything else raises Unsupported BEFORE touching an accumulator
 and the Trainer runs that chunk through the autograd path instead (tests/test_hip_e2e.py compares the two paths).
 Reference spans are the ones cited in functional.py for each call."""
+import os
 import types
 
 import torch
@@ -23,6 +24,10 @@ class Unsupported(Exception):
     pass
 
 
+MLP_SIDE_WGS = 128      # persistent workgroups of a BRDF-MLP backward that shares the chip (measured: 128 - 192 alike, 64 and
+                        # 256+ slower; csrc/brdf_mlp.hip)
+
+
 def _ns(**kw):
     return types.SimpleNamespace(**kw)
 
@@ -32,6 +37,14 @@ class TrainPass:
         self.nerf = nerf
         self.acc = None
         self.n_loss_chunks = 0
+        # The BRDF-MLP backward of a level needs only d_brdf; it runs on a side stream next to the adjoint of that level's
+        # bounce rays (level 0: the whole backward of level 1), capped to MLP_SIDE_WGS persistent workgroups so that it
+        # leaves registers and LDS on every CU to the main stream -- uncapped it holds both and nothing overlaps.  The
+        # kernels it runs next to are latency- or atomic-bound: 2.19 - 2.25 -> 2.12 - 2.18 ms per step.
+        # Measured and dropped: the appearance walk next to the density walk (no gain), the MLP forward next to the level-1
+        # sampler (slower: 2.36 ms).  NMF_OVERLAP=0 keeps everything on one stream.
+        self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
+        self._side = {}
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -209,6 +222,12 @@ class TrainPass:
             d_inc, d_brdf, dL, d_fd = hip.shade_mix_bwd(t.V, t.f0, t.diff, t.cnt32, t.row_of_ray, t.L, t.incoming, t.brdf,
                                                         d_refl)
         rows6 = hip.segment_sum_wide(d_fd, 6, t.row_off, t.Mb)
+        # ---- BRDF MLP backward: on a side stream, next to the adjoint of the bounce rays below
+        fork = self._fork(("mlp", lvl))
+        if fork is not None:
+            with torch.cuda.stream(fork[1]):
+                d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp,
+                                           max_workgroups=MLP_SIDE_WGS)
         # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
         if t.idx_re is None and t.child is not None:
             d_brays = self._bwd(t.child, d_inc, None, None)
@@ -221,7 +240,10 @@ class TrainPass:
             if t.idx_no.shape[0] > 0:
                 d_brays.index_copy_(0, t.idx_no, self._env_bwd(t.brays_no, t.mip_no, d_inc[t.idx_no]))
         # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
-        d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp)
+        if fork is not None:
+            self._join(fork, d_xfeat)
+        else:
+            d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, t.row_off, t.Mb)
         sobol = self.nerf.model.brdf_sampler.angs
         if view:
@@ -252,10 +274,31 @@ class TrainPass:
             hip.view_adjoint_to_rays(S.ray_id, t.bidx, dV_rows, dV_ggx, d_rays)
         return d_rays
 
+    # ---- side streams ---------------------------------------------------------------------------------------------------
+    def _fork(self, key):
+        """-> (main, side) with the side stream waiting for everything queued on the current one, or None"""
+        if not self.overlap:
+            return None
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream()
+        main, side = torch.cuda.current_stream(), self._side[key]
+        side.wait_stream(main)
+        return main, side
+
+    @staticmethod
+    def _join(fork, *made_on_side):
+        """the current stream waits for the side stream; tensors allocated under the side stream and consumed (and released)
+        on this one are registered with the allocator"""
+        main, side = fork
+        main.wait_stream(side)
+        for x in made_on_side:
+            x.record_stream(main)
+
     def _flush_walks(self):
         rf, a = self.nerf.rf, self.acc
         p, dpk, dlk, apl, ali, basis = rf._tables()
-        for all_segs, g_basis in ((self.dens_segs, None), (self.app_segs, a.g_basis)):
+
+        def walk(all_segs, g_basis):
             # one walk takes sample sets that carry the same adjoints (with detached normals the re-traced samples have no
             # normal adjoint while the primary ones still have the orientation-loss term)
             for key in dict.fromkeys(tuple(x is not None for x in sg[3:]) for sg in all_segs):
@@ -263,6 +306,9 @@ class TrainPass:
                 for i in range(0, len(segs), hip.VM_MAX_SEGMENTS):
                     hip.vm_query_bwd_segments(p, segs[i:i + hip.VM_MAX_SEGMENTS], dpk, dlk, apl, ali, basis, a.g_dpk,
                                               a.g_dlk, a.g_apl, a.g_ali, g_basis)
+
+        walk(self.dens_segs, None)       # (the appearance walk next to the density walk on a second stream: no gain)
+        walk(self.app_segs, a.g_basis)
         self.dens_segs, self.app_segs = [], []
 
     # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------

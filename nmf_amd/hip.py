@@ -586,26 +586,29 @@ def segment_sum_wide(vals, D, offsets, n_seg):
     return out
 
 
-def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias):
-    """weights = (W0 [64,66], b0, W2 [64,64], b2, W4 [4,64], b4)"""
+def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0):
+    """weights = (W0 [64,66], b0, W2 [64,64], b2, W4 [4,64], b4); max_workgroups: see brdf_mlp_bwd"""
     R = half_vec.shape[0]
     out = torch.empty((R, 3), dtype=torch.float32, device=half_vec.device)
     _check(_lib.nmf_brdf_mlp_fwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
                                  _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
-                                 _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias), _p(out), _stream()),
+                                 _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias), _p(out),
+                                 C.c_int32(max_workgroups), _stream()),
            "nmf_brdf_mlp_fwd")
     return out
 
 
-def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads):
-    """grads: six fp32 tensors shaped like `weights`, ACCUMULATED into (caller zeroes them once per pass)."""
+def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads, max_workgroups=0):
+    """grads: six fp32 tensors shaped like `weights`, ACCUMULATED into (caller zeroes them once per pass).  max_workgroups > 0
+    caps the persistent workgroups (a launch that shares the chip with kernels of another stream)."""
     R = half_vec.shape[0]
     dev = half_vec.device
     d_xfeat = torch.empty((R, 24), dtype=torch.float32, device=dev)
     _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
                                  _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
                                  _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias),
-                                 _p(d_out.contiguous(), torch.float32), _p(d_xfeat), *[_p(g) for g in grads], _stream()),
+                                 _p(d_out.contiguous(), torch.float32), _p(d_xfeat), *[_p(g) for g in grads],
+                                 C.c_int32(max_workgroups), _stream()),
            "nmf_brdf_mlp_bwd")
     return d_xfeat
 
@@ -982,8 +985,9 @@ def _install_host_ext():
     def expand_segments(offsets, n_seg, total):
         return fx.expand_segments(offsets, n_seg, total, _stream())
 
-    def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias):
-        return fx.brdf_mlp_fwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, _stream())
+    def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0):
+        return fx.brdf_mlp_fwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, int(max_workgroups),
+                               _stream())
 
     def heads_fwd(feat, W, b, hp):
         return fx.heads_fwd(feat, W, b, list(hp), _stream())
@@ -1018,9 +1022,9 @@ def _install_host_ext():
             return py_sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, want_mipbias, sc)
         return fx.sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, sc, _stream())
 
-    def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads):
+    def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads, max_workgroups=0):
         return fx.brdf_mlp_bwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, list(grads),
-                               _stream())
+                               int(max_workgroups), _stream())
 
     def heads_bwd(feat, W, b, hp, d_out, gW, gb):
         return fx.heads_bwd(feat, W, b, list(hp), d_out, gW, gb, _stream())
