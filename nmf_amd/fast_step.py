@@ -41,8 +41,10 @@ class TrainPass:
         # bounce rays (level 0: the whole backward of level 1), capped to MLP_SIDE_WGS persistent workgroups so that it
         # leaves registers and LDS on every CU to the main stream -- uncapped it holds both and nothing overlaps.  The
         # kernels it runs next to are latency- or atomic-bound: 2.19 - 2.25 -> 2.12 - 2.18 ms per step.
-        # Measured and dropped: the appearance walk next to the density walk (no gain), the MLP forward next to the level-1
-        # sampler (slower: 2.36 ms).  NMF_OVERLAP=0 keeps everything on one stream.
+        # The environment adjoint of a level's own rays (atomic-bound scatter, result first used when the level returns) runs
+        # on another side stream next to the rest of that level's backward: 2.12 - 2.18 -> 2.07 - 2.11 ms.
+        # Measured and dropped: the appearance walk next to the density walk and the level-1 density walk started early (no
+        # gain), the composite backward on a side stream (2.25 ms), the MLP forward next to the level-1 sampler (2.36 ms).  NMF_OVERLAP=0 keeps everything on one stream.
         self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
         self._side = {}
 
@@ -209,10 +211,16 @@ class TrainPass:
         d_w, d_refl, d_nrm = hip.ray_compose_bwd(t.w, t.refl, t.inv, t.nr if d_ori is not None else None, S.rays, S.ray_id,
                                                  t.bg, t.per_ray_bg, lvl == 0, False, t.rgb_lin, d_rgb, d_acc, d_ori,
                                                  d_ori is not None)
-        d_rays = None
+        d_rays, env_fork = None, None
         if t.per_ray_bg:
             d_bg = (1 - t.acc)[:, None] * d_rgb
-            d_rays = self._env_bwd(S.rays if t.B == S.rays.shape[0] else S.rays[:t.B], t.rough, d_bg)
+            env_rows = S.rays if t.B == S.rays.shape[0] else S.rays[:t.B]
+            env_fork = self._fork(("env", lvl))      # atomic-bound scatter: next to the rest of this level's backward
+            if env_fork is not None:
+                with torch.cuda.stream(env_fork[1]):
+                    d_rays = self._env_bwd(env_rows, t.rough, d_bg)
+            else:
+                d_rays = self._env_bwd(env_rows, t.rough, d_bg)
         dV_rows = None
         if view:
             d_inc, d_brdf, dL, d_fd, dV = hip.shade_mix_bwd_view(t.V, t.f0, t.diff, t.cnt32, t.row_of_ray, t.L, t.incoming,
@@ -268,6 +276,8 @@ class TrainPass:
             d_normal = d_normals
         d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
         self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
+        if env_fork is not None:
+            self._join(env_fork, d_rays)
         if view:        # V_row = -direction of the row's ray: both view adjoints back onto the rays, one launch
             if d_rays is None:
                 d_rays = torch.zeros_like(S.rays)
