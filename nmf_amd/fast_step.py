@@ -44,8 +44,10 @@ class TrainPass:
         # The environment adjoint of a level's own rays (atomic-bound scatter, result first used when the level returns) runs
         # on another side stream next to the rest of that level's backward: 2.12 - 2.18 -> 2.07 - 2.11 ms.
         # Measured and dropped: the appearance walk next to the density walk and the level-1 density walk started early (no
-        # gain), the composite backward on a side stream (2.25 ms), the MLP forward next to the level-1 sampler (2.36 ms).  NMF_OVERLAP=0 keeps everything on one stream.
+        # gain), the composite backward on a side stream (2.25 ms); anything of the FORWARD on a side stream (the MLP next to the
+        # level-1 sampler: 2.36 ms, the background lookup of the secondary rays next to it: 2.28 ms).  NMF_OVERLAP=0 keeps everything on one stream.
         self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
+        self._early_env = None
         self._side = {}
 
     # ------------------------------------------------------------------------------------------------------------
@@ -58,6 +60,7 @@ class TrainPass:
     # ---- accumulators of one optimizer step ------------------------------------------------------------------------
     def begin_step(self):
         self.acc = None
+        self._early_env = None
         self.n_loss_chunks = 0
         self.l1_scale = 0.0
 
@@ -323,7 +326,7 @@ class TrainPass:
 
     # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------
     @torch.no_grad()
-    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False):
+    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False):
         """wts = (w_photo, w_l1, w_ori, w_acc).  Returns dict(loss 0-d tensor, kept, n_samples) -- loss None when the chunk
         had no sample (train.py:567-568 skips it).  want_total: also evaluate the chunk's total loss value (the gradients do
         not need it: every term enters linearly with a constant weight)."""
@@ -365,6 +368,16 @@ class TrainPass:
                                                            _one(dev))
             d_rgb = hip.sqerr_bwd(t.rgb_map, gt_b, d_loss)
             self._bwd(t, d_rgb, d_acc, d_ori)
+            if last and a.used_env:
+                # last chunk of the optimizer step: the env-map adjoint table is complete, its two reverse prefix sums run on
+                # a side stream next to the field walks instead of after them (end_step picks the result up)
+                fork = self._fork("sat_bwd")
+                if fork is not None:
+                    bgm = nerf.bg_module
+                    act, _sat, _pole = bgm._tables()
+                    with torch.cuda.stream(fork[1]):
+                        d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars())
+                    self._early_env = (fork, d_bg)
             self._flush_walks()
             self.n_loss_chunks += 1
             self.l1_scale += float(wts[1]) * float(inv_lbatch)
@@ -395,7 +408,12 @@ class TrainPass:
         if a.used_env:
             act, sat, pole = bgm._tables()
             sc = bgm._dev_scalars()
-            d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc)
+            if self._early_env is not None:
+                fork, d_bg = self._early_env
+                self._join(fork, d_bg)
+                self._early_env = None
+            else:
+                d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc)
             grads.append((bgm.bg_mat, d_bg.reshape(bgm.bg_mat.shape)))
             if bgm.brightness_lr != 0 or bgm.mul_lr != 0:           # lr 0 (microfacet_tensorf2.yaml:150-151): no update anyway
                 d_pre = d_bg / sc[2]

@@ -248,7 +248,7 @@ class Trainer:
                 try:
                     out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
                                      (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
-                                     want_total=trace is not None)
+                                     want_total=trace is not None, last=pos >= n_total)
                 except Unsupported:
                     out = None                      # this chunk goes through the autograd path below
                 if out is not None:
