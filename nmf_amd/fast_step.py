@@ -214,6 +214,9 @@ class TrainPass:
         d_w, d_refl, d_nrm = hip.ray_compose_bwd(t.w, t.refl, t.inv, t.nr if d_ori is not None else None, S.rays, S.ray_id,
                                                  t.bg, t.per_ray_bg, lvl == 0, False, t.rgb_lin, d_rgb, d_acc, d_ori,
                                                  d_ori is not None)
+        # needs only d_w and is first used by the field walk: issued here it fills time in which this stream would wait for the
+        # side streams below, at the end of the level it would sit on the critical path (45 us for the re-traced rays)
+        d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
         d_rays, env_fork = None, None
         if t.per_ray_bg:
             d_bg = (1 - t.acc)[:, None] * d_rgb
@@ -277,7 +280,6 @@ class TrainPass:
             d_normal = d_normals.add_(d_nrm)
         else:
             d_normal = d_normals
-        d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
         self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
         if env_fork is not None:
             self._join(env_fork, d_rays)
