@@ -195,7 +195,7 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
         offsets, wv, totals = hip.march_scan(counts, budget)
         M, b = (int(v) for v in totals.cpu())            # the one host sync of the sampler
         xyzt, ray_id, step_id, z, dist = hip.march_fill(p, rays, b, M, jitter, valid, offsets)
-        return Samples(xyzt, ray_id, step_id, z, dist, offsets, wv.bool(), M, b, N, p, rays, jitter, valid)
+        return Samples(xyzt, ray_id, step_id, z, dist, offsets, wv.view(torch.bool), M, b, N, p, rays, jitter, valid)   # 0 / 1 bytes: no conversion launch
 
     @torch.no_grad()
     def sample(self, rays_chunk, focal, rf=None, override_near=None, is_train=False, dynamic_batch_size=True,
