@@ -24,6 +24,10 @@ class Unsupported(Exception):
     pass
 
 
+MLP_SIDE_MIN_RAYS = 100000   # the capped launch runs at about half speed: it pays only next to enough other work, i.e. when the
+                             # level below re-traces this many rays (steady state: all 0.24 M).  With 20 k re-traced rays
+                             # under 0.1 M+ MLP rows the main stream ran dry and waited for it (-4 %), and at the deepest level
+                             # the 46 k-row launch next to the env adjoint was no faster than the two one after the other
 MLP_SIDE_WGS = 128      # persistent workgroups of a BRDF-MLP backward that shares the chip (measured: 128 - 192 alike, 64 and
                         # 256+ slower; csrc/brdf_mlp.hip)
 
@@ -221,7 +225,8 @@ class TrainPass:
         if t.per_ray_bg:
             d_bg = (1 - t.acc)[:, None] * d_rgb
             env_rows = S.rays if t.B == S.rays.shape[0] else S.rays[:t.B]
-            env_fork = self._fork(("env", lvl))      # atomic-bound scatter: next to the rest of this level's backward
+            # atomic-bound scatter: next to the rest of this level's backward (when it is long enough to be worth a fork)
+            env_fork = self._fork(("env", lvl)) if t.B >= MLP_SIDE_MIN_RAYS else None
             if env_fork is not None:
                 with torch.cuda.stream(env_fork[1]):
                     d_rays = self._env_bwd(env_rows, t.rough, d_bg)
@@ -237,7 +242,7 @@ class TrainPass:
                                                         d_refl)
         rows6 = hip.segment_sum_wide(d_fd, 6, t.row_off, t.Mb)
         # ---- BRDF MLP backward: on a side stream, next to the adjoint of the bounce rays below
-        fork = self._fork(("mlp", lvl))
+        fork = self._fork(("mlp", lvl)) if (t.child is not None and t.child.B >= MLP_SIDE_MIN_RAYS) else None
         if fork is not None:
             with torch.cuda.stream(fork[1]):
                 d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp,
