@@ -102,10 +102,10 @@ class TrainPass:
         return hip.sat_lookup_bwd(bgm._lookup_table(), rows, sa, 0.0, d_out, a.d_sat, a.d_pole, a.d_mip, want_dirs=True,
                                   sc=bgm._dev_scalars())
 
-    def _fwd(self, lvl, rays, focal, start_mip, noise):
+    def _fwd(self, lvl, rays, focal, start_mip, noise, is_train=True):
         nerf = self.nerf
         rf, model, smp = nerf.rf, nerf.model, nerf.sampler
-        S = smp.sample_compact(rays, focal, rf=rf, override_near=None if lvl == 0 else self.near1, is_train=True,
+        S = smp.sample_compact(rays, focal, rf=rf, override_near=None if lvl == 0 else self.near1, is_train=is_train,
                                dynamic_batch_size=(lvl == 0), noise=noise)
         B, M = S.b, S.M
         t = _ns(lvl=lvl, S=S, B=B, M=M, n_samples=[M])
@@ -124,7 +124,8 @@ class TrainPass:
         noise.skip("rand", (5000,))
         conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)
         if lvl == 0:
-            counts = hip.select_bounces(w, noise.uniform((M,)).contiguous(), 0, float(model.rays_per_ray))
+            counts = hip.select_bounces(w, noise.uniform((M,)).contiguous(), 0,
+                                        float(model.rays_per_ray if is_train else model.test_rays_per_ray))
         else:
             if hasattr(noise, "select_dense_parts"):        # device noise: the normaliser in one launch (nmf_select_total)
                 u, extra = noise.select_dense_parts(S.b, S.N, M)
@@ -150,7 +151,7 @@ class TrainPass:
         hp, hW, hb = self.heads
         heads = hip.heads_fwd(app, hW, hb, hp)
         V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(bidx, nr, app, heads, S.xyzt, S.ray_id, S.rays, conv, feat_noise,
-                                                           self.anoise, self.min_rough, True)
+                                                           self.anoise, self.min_rough if is_train else -1e30, True)
         sobol = model.brdf_sampler.angs
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
         brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
@@ -163,7 +164,7 @@ class TrainPass:
             num_retrace = min(R, model.max_retrace_rays[lvl])
             if num_retrace >= R and not model.exact_retrace_order:
                 noise.skip("rand", (R,))
-                t.child = self._fwd(lvl + 1, brays, focal, mip, noise)
+                t.child = self._fwd(lvl + 1, brays, focal, mip, noise, is_train)
                 if t.child.M == 0:
                     raise Unsupported("no secondary sample")
                 t.n_samples += t.child.n_samples
@@ -179,7 +180,7 @@ class TrainPass:
                 incoming = torch.zeros((R, 3), device=rays.device)
                 if t.idx_re.shape[0] > 0:
                     t.brays_re, t.mip_re = brays[t.idx_re], mip[t.idx_re]
-                    t.child = self._fwd(lvl + 1, t.brays_re, focal, t.mip_re, noise)
+                    t.child = self._fwd(lvl + 1, t.brays_re, focal, t.mip_re, noise, is_train)
                     if t.child.M == 0:
                         raise Unsupported("no secondary sample")
                     t.n_samples += t.child.n_samples
@@ -331,6 +332,44 @@ class TrainPass:
         walk(self.app_segs, a.g_basis)
         self.dens_segs, self.app_segs = [], []
 
+    # ---- evaluation: forward only ---------------------------------------------------------------------------------------
+    def _begin(self, dev, noise):
+        nerf = self.nerf
+        rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
+        if hasattr(noise, "begin_pass"):
+            noise.begin_pass()
+        rf._fwd_tables()
+        bgm._tables()
+        bgm.get_spherical_harmonics(100)
+        hp, hW, hb, _, _ = model.diffuse_module.head_pass()
+        self.heads = (hp, hW, hb)
+        self.mlp_ws, self.mlp_bias, _, _ = model.brdf.mlp_pass()
+        self.scale = float(rf.distance_scale)
+        self.anoise, self.min_rough, self.detach_n = float(model.anoise), float(model.min_rough), bool(model.detach_N)
+        self.near1 = 3 * float(hip.host(nerf.sampler.stepsize))
+        self.white = _white(dev)
+
+    @torch.no_grad()
+    def render_chunk(self, rays, focal, noise):
+        """`TensorNeRF.forward(rays, focal, bg_col=white, is_train=False, draw_debug=False)` as the same straight-line kernel
+        sequence as the training forward: -> (rgb_map [b,3], acc_map [b], b = rays the sampler kept, n_samples).  Raises
+        Unsupported (configuration, no sample, no bounce row): the caller renders that chunk through the module."""
+        nerf = self.nerf
+        if not self.supported():
+            raise Unsupported("configuration")
+        mods = [m for m in (nerf.rf, nerf.bg_module, nerf.model.brdf, nerf.model.diffuse_module) if hasattr(m, "begin_pass")]
+        for m in mods:
+            m.begin_pass()
+        try:
+            self._begin(rays.device, noise)
+            t = self._fwd(0, rays, focal, None, noise, is_train=False)
+            if t.M == 0:
+                raise Unsupported("no sample")
+            return t.rgb_map, t.acc, t.B, t.n_samples
+        finally:
+            for m in mods:
+                m.end_pass()
+
     # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------
     @torch.no_grad()
     def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False):
@@ -346,18 +385,7 @@ class TrainPass:
         for m in mods:
             m.begin_pass()
         try:
-            if hasattr(noise, "begin_pass"):
-                noise.begin_pass()
-            rf._fwd_tables()
-            bgm._tables()
-            bgm.get_spherical_harmonics(100)
-            hp, hW, hb, _, _ = model.diffuse_module.head_pass()
-            self.heads = (hp, hW, hb)
-            self.mlp_ws, self.mlp_bias, _, _ = model.brdf.mlp_pass()
-            self.scale = float(rf.distance_scale)
-            self.anoise, self.min_rough, self.detach_n = float(model.anoise), float(model.min_rough), bool(model.detach_N)
-            self.near1 = 3 * float(hip.host(nerf.sampler.stepsize))
-            self.white = _white(dev)
+            self._begin(dev, noise)
             self.dens_segs, self.app_segs = [], []
             t = self._fwd(0, rays, focal, None, noise)
             if t.M == 0:

@@ -60,6 +60,37 @@ def render_images(nerf, rays, focal, chunk=None, noise=None, keys=("rgb_map",), 
     to completion, is_train=False"""
     chunk = chunk or nerf.eval_batch_size
     kw.setdefault("draw_debug", False)
-    ims, _ = chunk_renderer(rays, nerf, focal, keys=keys, chunk=chunk, render2completion=True,
-                            bg_col=torch.ones(3, device=rays.device), is_train=False, ndc_ray=False, noise=noise, **kw)
+    module_kw = dict(bg_col=torch.ones(3, device=rays.device), is_train=False, ndc_ray=False, noise=noise, **kw)
+    tensorf = nerf
+    fast = _eval_pass(nerf) if (rays.is_cuda and not kw["draw_debug"] and set(keys) <= {"rgb_map", "acc_map"}
+                                and len(kw) == 1) else None
+    if fast is not None:
+        from .fast_step import Unsupported
+
+        def tensorf(pending, focal_, **_kw):          # noqa: F811 -- the straight-line forward, the module as its fallback
+            try:
+                nz = noise
+                if nz is None:                        # the module's own generator (tensor_nerf.py: _render)
+                    if nerf._noise is None:
+                        from .noise import DeviceNoise
+                        nerf._noise = DeviceNoise(pending.device, seed=20211200)
+                    nz = nerf._noise
+                rgb, acc, kept, n_samples = fast.render_chunk(pending, focal_, nz)
+            except Unsupported:
+                return nerf(pending, focal_, **module_kw)
+            return dict(rgb_map=rgb, acc_map=acc), dict(rays_kept=kept, n_samples=n_samples)
+    ims, _ = chunk_renderer(rays, tensorf, focal, keys=keys, chunk=chunk, render2completion=True, **module_kw)
     return ims["rgb_map"] if tuple(keys) == ("rgb_map",) else ims
+
+
+def _eval_pass(nerf):
+    """the tape-free pass of nmf_amd/fast_step.py, forward only (NMF_FAST_STEP=0: always the module path)"""
+    import os
+    if os.environ.get("NMF_FAST_STEP", "1") == "0":
+        return None
+    fp = getattr(nerf, "_eval_fast_pass", None)
+    if fp is None:
+        from .fast_step import TrainPass
+        fp = TrainPass(nerf)
+        object.__setattr__(nerf, "_eval_fast_pass", fp)
+    return fp if fp.supported() else None

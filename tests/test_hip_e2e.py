@@ -813,6 +813,38 @@ def test_training_run_follows_the_reference_trace():
     assert abs(float(np.mean(psnrs[-1])) - float(ref_ps[-1].mean())) <= 0.1          # "PSNR after equal iterations"
 
 
+def test_tape_free_evaluation_forward_equals_the_module(monkeypatch):
+    """renderer.render_images: the straight-line forward of fast_step.TrainPass.render_chunk (is_train=False) against
+    TensorNeRF.forward -- the same kernels in the same order on the same noise stream, so the frames are equal bit for bit
+    (the forward has no atomics); early phase (partial re-trace) and steady state, a ragged last chunk included."""
+    import bench
+    from nmf_amd import synthetic
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.renderer import render_images
+    dev = torch.device(DEV)
+    nerf, _ = bench.build(dev)
+    nerf.eval()
+    rays, focal = synthetic.camera_rays(3 * 2048 + 77, seed=3)
+    rays = rays.to(dev)
+    for retrace in (1000, int(nerf.model.max_brdf_rays[0])):
+        nerf.model.max_retrace_rays = [retrace]
+        monkeypatch.setenv("NMF_FAST_STEP", "0")
+        ref = render_images(nerf, rays, focal, 2048, DeviceNoise(dev, seed=5), keys=("rgb_map", "acc_map"))
+        monkeypatch.setenv("NMF_FAST_STEP", "1")
+        calls = []
+        fp = __import__("nmf_amd.renderer", fromlist=["_eval_pass"])._eval_pass(nerf)
+        orig = fp.render_chunk
+        fp.render_chunk = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            got = render_images(nerf, rays, focal, 2048, DeviceNoise(dev, seed=5), keys=("rgb_map", "acc_map"))
+        finally:
+            fp.render_chunk = orig
+        assert len(calls) == 4, calls
+        assert got["rgb_map"].shape == (rays.shape[0], 3)
+        assert torch.equal(got["rgb_map"], ref["rgb_map"]) and torch.equal(got["acc_map"], ref["acc_map"])
+        assert float(ref["rgb_map"].std()) > 0.05
+
+
 @pytest.mark.parametrize("phase", ["steady", "early", "steady_detachN", "two_chunks"])
 def test_tape_free_training_pass_equals_autograd_path(phase):
     """nmf_amd/fast_step.py (the training pass as straight-line C-ABI calls, no autograd engine) against the autograd
