@@ -47,6 +47,10 @@ HBM_PEAK_GBS = 8000.0
 # them while the launch got 1.5x faster).  f32-input MFMA peak = 157.3 TFLOP/s dense (MI355X_MICROARCH.md).
 VM_BWD_NRB = 2
 MFMA_FLOP_DENSITY = 3 * (3 * VM_BWD_NRB + 2) * 2048 / 4
+# value-only walk (the re-traced samples: sparse normals, nmf_amd/fast_step.py): NRB value blocks + 1 line tile, and a third
+# of the density-table bytes of SURVEY 8(d) (16 of the 48 packed floats per tap, 16 of 32 per line tap)
+MFMA_FLOP_VALUE = 3 * (VM_BWD_NRB + 1) * 2048 / 4
+BWD_BYTES_VALUE = 3 * (1152 + 1920) // 3
 MFMA_FLOP_APP = (3 * (2 * VM_BWD_NRB + 2) + 4) * 2048 / 4
 MFMA_F32_PEAK_TFLOPS = 157.3
 
@@ -89,7 +93,7 @@ class KernelTimer:
             e.record()
             dens = a[7] is not None or a[8] is not None or a[9] is not None      # d_sigma / d_sigma_feat / d_normal
             app = a[10] is not None                                              # d_app
-            self.records.append((s, e, int(xyzt.shape[0]), dens, app))
+            self.records.append((s, e, int(xyzt.shape[0]), (2 if a[9] is not None else 1) if dens else 0, app))
             return r
 
         hip.vm_query_bwd = wrapped
@@ -105,6 +109,7 @@ class KernelTimer:
             e.record()
             m = sum(int(sg[0].shape[0]) for sg in segs)
             dens = any(sg[3] is not None or sg[4] is not None or sg[5] is not None for sg in segs)
+            dens = (2 if any(sg[5] is not None for sg in segs) else 1) if dens else 0      # 2: with the normal adjoint
             app = any(sg[6] is not None for sg in segs)
             self.records.append((s, e, m, dens, app))
             return r
@@ -126,8 +131,10 @@ class KernelTimer:
     def summary(self):
         """-> total ms, algorithmic bytes, dense-equivalent MFMA flop, samples, launches"""
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        nbytes = sum(m * (BWD_BYTES_DENSITY * d + BWD_BYTES_APP * a) for _, _, m, d, a in self.records)
-        flop = sum(m * (MFMA_FLOP_DENSITY * d + MFMA_FLOP_APP * a) for _, _, m, d, a in self.records)
+        nbytes = sum(m * ((BWD_BYTES_DENSITY if d == 2 else BWD_BYTES_VALUE if d == 1 else 0) + BWD_BYTES_APP * a)
+                     for _, _, m, d, a in self.records)
+        flop = sum(m * ((MFMA_FLOP_DENSITY if d == 2 else MFMA_FLOP_VALUE if d == 1 else 0) + MFMA_FLOP_APP * a)
+                   for _, _, m, d, a in self.records)
         return ms, nbytes, flop, sum(r[2] for r in self.records), len(self.records)
 
 

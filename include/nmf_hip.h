@@ -346,14 +346,16 @@ int64_t nmf_bounce_index_workspace_bytes(int64_t M);
  * (conv [9][3] DEVICE pointer, modules/sh.py:97-142), feat = app + anoise * feat_noise (feat_noise may be NULL),
  * xyz.  heads is nmf_heads_fwd's output, rays [b][6], ray_id [M].  app / heads / feat_noise are indexed by SAMPLE
  * ([M][24], [M][11], [M][24]) or, with row_inputs != 0, by BOUNCE ROW ([Mb][.]: appearance evaluated only where it is
- * used -- in training that is ~5-20 % of the samples). */
+ * used -- in training that is ~5-20 % of the samples).  row_inputs == 2: `normals` is indexed by bounce row as well
+ * ([Mb][3]: below the first recursion level normals are only needed where secondary rays start). */
 int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* app, const float* heads,
                         const float* xyzt, const int32_t* ray_id, const float* rays, const float* conv,
                         const float* feat_noise, float anoise, float min_rough, int32_t row_inputs, float* V, float* N,
                         float* r1, float* f0, float* diffuse, float* feat, float* xyz, void* stream);
 /* Adjoint: d_normals [M][3] written for ALL samples (zeros where inv < 0 or detach_normals); d_heads / d_app written for
  * all M samples ([M][11], [M][24], zeros where inv < 0) or, with row_inputs, per bounce row ([Mb][11], [Mb][24]; bidx
- * required).  Row gradients may be NULL (= zero).  row_strides = row pitch in floats of (dN, dr1, df0, ddiffuse), so
+ * required); row_inputs == 2: normals AND d_normals are per bounce row ([Mb][3]), inv is not read.  Row gradients may be
+ * NULL (= zero).  row_strides = row pitch in floats of (dN, dr1, df0, ddiffuse), so
  * column slices of wider row tensors are read in place (NULL = dense 3,1,3,3). */
 int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t* bidx, int64_t Mb, const float* normals,
                         const float* heads, const int32_t* ray_id, const float* rays, const float* conv,

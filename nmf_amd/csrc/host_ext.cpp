@@ -257,7 +257,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> bounce_index(const Tensor& co
 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_fwd(
     const Tensor& bidx, const Tensor& normals, const Tensor& app, const Tensor& heads, const Tensor& xyzt, const Tensor& ray_id,
-    const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough, bool row_inputs,
+    const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough, int64_t row_inputs,
     int64_t stream) {
     const int64_t Mb = bidx.size(0);
     Tensor V = fe(normals, {Mb, 3}), N = fe(normals, {Mb, 3}), r1 = fe(normals, {Mb}), f0 = fe(normals, {Mb, 3});
@@ -265,7 +265,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_f
     if (Mb)
         check(nmf_bounce_prep_fwd(i32(bidx), Mb, f32(normals), f32(app), f32(heads), f32(xyzt), i32(ray_id), f32(rays),
                                   f32(conv), static_cast<const float*>(vptr(feat_noise)), (float)anoise, (float)min_rough,
-                                  row_inputs ? 1 : 0, out(V), out(N), out(r1), out(f0), out(diff), out(feat), out(xyz),
+                                  (int32_t)row_inputs, out(V), out(N), out(r1), out(f0), out(diff), out(feat), out(xyz),
                                   st(stream)),
               "nmf_bounce_prep_fwd");
     return {V, N, r1, f0, diff, feat, xyz};

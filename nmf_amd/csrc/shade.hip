@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     const int64_t ia = row_inputs ? row : m;       // app / heads / noise given per bounce row or per sample
     const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
     const float vx = -d[0], vy = -d[1], vz = -d[2];
-    const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
+    const int64_t in = row_inputs == 2 ? row : m;  // normals per bounce row as well (row_inputs 2)
+    const float nx = normals[in * 3], ny = normals[in * 3 + 1], nz = normals[in * 3 + 2];
     const float s = sgn(vx * nx + vy * ny + vz * nz);                       // models/microfacet.py:356
     V[row * 3] = vx; V[row * 3 + 1] = vy; V[row * 3 + 2] = vz;
     N[row * 3] = nx * s; N[row * 3 + 1] = ny * s; N[row * 3 + 2] = nz * s;
@@ -185,7 +186,18 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     const float* __restrict__ ddiff, int sN, int sr, int sf, int sd, const float* __restrict__ dfeat,
     float* __restrict__ d_normals, float* __restrict__ d_heads, float* __restrict__ d_app) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M) {          // normal adjoint of sample t
+    if (row_inputs == 2) {          // normals and their adjoint per bounce row: [Mb][3], nothing sample-sized is touched
+        if (t < Mb) {
+            float gn[3] = {0.f, 0.f, 0.f};
+            if (!detach_n && dN) {
+                const float nx = normals[t * 3], ny = normals[t * 3 + 1], nz = normals[t * 3 + 2];
+                const float* d = rays + (int64_t)ray_id[bidx[t]] * 6 + 3;
+                const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
+                gn[0] = dN[t * sN] * s; gn[1] = dN[t * sN + 1] * s; gn[2] = dN[t * sN + 2] * s;
+            }
+            d_normals[t * 3] = gn[0]; d_normals[t * 3 + 1] = gn[1]; d_normals[t * 3 + 2] = gn[2];
+        }
+    } else if (t < M) {          // normal adjoint of sample t
         const int64_t row = inv[t];
         float gn[3] = {0.f, 0.f, 0.f};
         if (row >= 0 && !detach_n && dN) {
@@ -206,7 +218,8 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
     float4* o4 = reinterpret_cast<float4*>(d_app + t * FEAT);
     if (row >= 0) {
-        const float nx = normals[m * 3], ny = normals[m * 3 + 1], nz = normals[m * 3 + 2];
+        const int64_t in = row_inputs == 2 ? t : m;
+        const float nx = normals[in * 3], ny = normals[in * 3 + 1], nz = normals[in * 3 + 2];
         const float* h = heads + t * HEADS;
         float Y[9];
         sh9(nx, ny, nz, Y);
@@ -400,11 +413,13 @@ extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t*
     const int sf = row_strides ? row_strides[2] : 3, sd = row_strides ? row_strides[3] : 3;
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_prep_bwd: M < 0");
     if (M == 0) return NMF_OK;
-    NMF_REQUIRE(inv && normals && ray_id && rays && conv && d_normals, NMF_EINVAL, "nmf_bounce_prep_bwd: null");
+    NMF_REQUIRE((inv || row_inputs == 2) && normals && ray_id && rays && conv && d_normals, NMF_EINVAL,
+                "nmf_bounce_prep_bwd: null");
     NMF_REQUIRE(Mb >= 0 && Mb <= M, NMF_EINVAL, "nmf_bounce_prep_bwd: Mb outside [0, M]");
     NMF_REQUIRE((row_inputs ? Mb == 0 : false) || (heads && d_heads && d_app), NMF_EINVAL, "nmf_bounce_prep_bwd: null");
     NMF_REQUIRE(!row_inputs || Mb == 0 || bidx, NMF_EINVAL, "nmf_bounce_prep_bwd: row_inputs needs bidx");
-    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, inv, M, bidx,
+    const int64_t n_threads = row_inputs == 2 ? (Mb > 0 ? Mb : 1) : M;
+    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(n_threads, 256)), dim3(256), 0, (hipStream_t)stream, inv, M, bidx,
                        Mb, normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, (int)row_inputs,
                        dN, dr1, df0, ddiffuse, sN, sr, sf, sd, dfeat, d_normals, d_heads, d_app);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_bwd");

@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
                 float run[DL];
                 load_run<DL / 4>(dlk.p[i] + (int64_t)tl.idx[t] * DL, run);
 #pragma unroll
-                for (int c = 0; c < CD; ++c) { Lc[c] += tl.w[t] * run[c]; DLc[c] += tl.w[t] * run[CD + c]; }
+                for (int c = 0; c < CD; ++c) { Lc[c] = fmaf(tl.w[t], run[c], Lc[c]); DLc[c] += tl.w[t] * run[CD + c]; }   // value path: explicit fma, as in k_vm_sigma
             }
             const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
             float s_pl = 0.f, s_dx = 0.f, s_dy = 0.f, s_pdl = 0.f;
@@ -268,12 +268,12 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
                 float a = 0.f, b = 0.f, cdy = 0.f, d = 0.f;
 #pragma unroll
                 for (int c = 0; c < CD; ++c) {
-                    a += run[c] * Lc[c];
+                    a = fmaf(run[c], Lc[c], a);
                     d += run[c] * DLc[c];
                     b += run[CD + c] * Lc[c];
                     cdy += run[2 * CD + c] * Lc[c];
                 }
-                s_pl += tp.w[t] * a; s_pdl += tp.w[t] * d; s_dx += tp.w[t] * b; s_dy += tp.w[t] * cdy;
+                s_pl = fmaf(tp.w[t], a, s_pl); s_pdl += tp.w[t] * d; s_dx += tp.w[t] * b; s_dy += tp.w[t] * cdy;
             }
             sf += s_pl;
             g[MAT0[i]] += s_dx;
@@ -347,6 +347,57 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 #pragma unroll
             for (int j = 0; j < AD / 4; ++j) q[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, density value only (no gradient / normal): the samples of the re-traced rays need normals on their bounce rows
+// alone (nmf_amd/fast_step.py, "sparse normals"), so the 0.9 M-sample query of a training level reads the value third of
+// every texel (16 of 48 floats) and of every line entry (16 of 32).  Same taps, same order of the sums as k_vm_fwd, the
+// value path of both written with explicit fma: sigma_feat and sigma are identical bits.
+// ------------------------------------------------------------------------------------------------
+template <class TT>
+__global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
+                                                  PtrsT3<TT> dpk, PtrsT3<TT> dlk, float* __restrict__ sigma_feat,
+                                                  float* __restrict__ sigma) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int G = p.grid;
+    float xn[3];
+    normalized(p, xyzt[m], xn);
+    float sf = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const Tap1 tl = make_tap1(xn[VEC[i]], G);
+        float Lc[CD];
+#pragma unroll
+        for (int c = 0; c < CD; ++c) Lc[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (tl.idx[t] < 0) continue;
+            float run[CD];
+            load_run<CD / 4>(dlk.p[i] + (int64_t)tl.idx[t] * DL, run);
+#pragma unroll
+            for (int c = 0; c < CD; ++c) Lc[c] = fmaf(tl.w[t], run[c], Lc[c]);
+        }
+        const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
+        float s_pl = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (tp.idx[t] < 0) continue;
+            float run[CD];
+            load_run<CD / 4>(dpk.p[i] + (int64_t)tp.idx[t] * DP, run);
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) a = fmaf(run[c], Lc[c], a);
+            s_pl = fmaf(tp.w[t], a, s_pl);
+        }
+        sf += s_pl;
+    }
+    if (sigma_feat) sigma_feat[m] = sf;
+    if (sigma) {
+        float x = fminf(fmaxf(sf, -15.f), 1e3f) + p.density_shift;       // tensor_base.py:85
+        sigma[m] = x > 20.f ? x : log1pf(expf(x));                       // F.softplus (threshold 20)
     }
 }
 
@@ -1206,6 +1257,12 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
     NMF_REQUIRE(!want_a || (app_planes && app_lines && app_planes[0] && app_planes[1] && app_planes[2] && app_lines[0] &&
                             app_lines[1] && app_lines[2] && (!app || basis)),
                 NMF_EINVAL, "nmf_vm_query_fwd: appearance tables missing");
+    if (want_d && !want_a && !grad && !normal) {      // density value only
+        hipLaunchKernelGGL(k_vm_sigma<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                           (const float4*)xyzt, M, mkT<TT>(dpk, true), mkT<TT>(dlk, true), sigma_feat, sigma);
+        NMF_CHECK_LAUNCH(what);
+        return NMF_OK;
+    }
     if (!want_d && app && !coef) {      // appearance of the bounce rows: 8 lanes per row
         hipLaunchKernelGGL(k_vm_app_rows<TT>, dim3((unsigned)cdiv(M, APP_ROWS)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<TT>(app_planes, true), mkT<TT>(app_lines, true), basis, app);

@@ -51,6 +51,7 @@ class TrainPass:
         # gain), the composite backward on a side stream (2.25 ms); anything of the FORWARD on a side stream (the MLP next to the
         # level-1 sampler: 2.36 ms, the background lookup of the secondary rays next to it: 2.28 ms).  NMF_OVERLAP=0 keeps everything on one stream.
         self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
+        self.sparse_normals = os.environ.get("NMF_SPARSE_NORMALS", "1") != "0"
         self._early_env = None
         self._side = {}
 
@@ -113,8 +114,13 @@ class TrainPass:
             return t
         offsets = S.offsets[: B + 1]
         p, dpk, dlk, apl, ali, basis = rf._fwd_tables()
-        sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, S.xyzt, dpk, dlk, apl, ali, basis, want_density=True, want_normal=True,
-                                                want_app=False, want_coef=False)
+        # Sparse normals: below the first level a normal is only needed where secondary rays start (the orientation term is a
+        # level-0 statistic, tensor_nerf.py:583-587), so the re-traced samples get the density VALUE alone (a third of the
+        # table bytes and of the products) and the bounce rows are queried for value + gradient + appearance afterwards;
+        # the backward mirrors it: a value-only walk over all samples, the normal adjoint walked with the rows.
+        sparse_n = lvl > 0 and self.sparse_normals
+        sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, S.xyzt, dpk, dlk, apl, ali, basis, want_density=True,
+                                                want_normal=not sparse_n, want_app=False, want_coef=False)
         w, _acc = hip.composite_fwd(sg, S.dist, offsets, B, self.scale)
         # ---- Microfacet.shade_compact, sparse appearance (same draw order as the autograd path)
         deferred = noise.normal_deferred((M, 24))
@@ -147,18 +153,25 @@ class TrainPass:
         off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2).contiguous()
         xyz_rows = torch.index_select(S.xyzt, 0, bidx)
         feat_noise = noise.rows(deferred, bidx)
-        app = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
+        sf_rows = gr_rows = None
+        if sparse_n:
+            sf_rows, _sg, gr_rows, nr, app, _ = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=True,
+                                                                want_normal=True, want_app=True)
+        else:
+            app = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False,
+                                   want_app=True)[4]
         hp, hW, hb = self.heads
         heads = hip.heads_fwd(app, hW, hb, hp)
         V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(bidx, nr, app, heads, S.xyzt, S.ray_id, S.rays, conv, feat_noise,
-                                                           self.anoise, self.min_rough if is_train else -1e30, True)
+                                                           self.anoise, self.min_rough if is_train else -1e30,
+                                                           2 if sparse_n else 1)
         sobol = model.brdf_sampler.angs
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
         brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
         t.__dict__.update(offsets=offsets, sf=sf, sg=sg, gr=gr, nr=nr, w=w, conv=conv, bidx=bidx, row_off=row_off, cnt32=cnt32,
                           inv=inv, R=R, Mb=Mb, row_of_ray=row_of_ray, j_of_ray=j_of_ray, off=off, xyz_rows=xyz_rows, app=app,
                           heads=heads, V=V, N=N, r1=r1, f0=f0, diff=diff, feat=feat, L=L, hl=hl, dl=dl, mip=mip, brays=brays,
-                          brdf=brdf, child=None, idx_re=None, idx_no=None)
+                          brdf=brdf, child=None, idx_re=None, idx_no=None, sparse_n=sparse_n, sf_rows=sf_rows, gr_rows=gr_rows)
         # ---- incoming radiance of the secondary rays (models/microfacet.py:475-563)
         if lvl < len(model.max_retrace_rays):
             num_retrace = min(R, model.max_retrace_rays[lvl])
@@ -274,9 +287,9 @@ class TrainPass:
             d_nr = hip.ggx_rays_bwd(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)
             rows4 = hip.segment_sum(d_nr, None, t.row_off, t.Mb, lanes=8)
             dN, dr1 = rows4[:, 0:3], rows4[:, 3]
-        d_normals, d_heads, d_app = hip.bounce_prep_bwd(t.inv, t.nr, t.heads, S.ray_id, S.rays, t.conv, self.min_rough,
-                                                        self.detach_n, dN, dr1, rows6[:, 0:3], rows6[:, 3:6], d_feat,
-                                                        bidx=t.bidx, row_inputs=True)
+        d_normals, d_heads, d_app = hip.bounce_prep_bwd(None if t.sparse_n else t.inv, t.nr, t.heads, S.ray_id, S.rays, t.conv,
+                                                        self.min_rough, self.detach_n, dN, dr1, rows6[:, 0:3], rows6[:, 3:6],
+                                                        d_feat, bidx=t.bidx, row_inputs=2 if t.sparse_n else 1)
         hp, hW, hb = self.heads
         d_app.add_(hip.heads_bwd(t.app, hW, hb, hp, d_heads, a.g_hW, a.g_hb))
         self.app_segs.append((t.xyz_rows, None, None, None, None, None, d_app))
@@ -286,7 +299,13 @@ class TrainPass:
             d_normal = d_normals.add_(d_nrm)
         else:
             d_normal = d_normals
-        self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
+        if t.sparse_n:      # value-only walk over the level's samples; the rows carry the normal adjoint (with a zero d_sigma so
+            # that they share a walk with the level-0 samples)
+            self.dens_segs.append((S.xyzt, t.sf, None, d_sigma, None, None, None))
+            if d_normal is not None:
+                self.dens_segs.append((t.xyz_rows, t.sf_rows, t.gr_rows, torch.zeros_like(t.sf_rows), None, d_normal, None))
+        else:
+            self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
         if env_fork is not None:
             self._join(env_fork, d_rays)
         if view:        # V_row = -direction of the row's ray: both view adjoints back onto the rays, one launch

@@ -740,7 +740,7 @@ def bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_no
         _check(_lib.nmf_bounce_prep_fwd(_p(bidx, torch.int32), C.c_int64(Mb), _p(normals, torch.float32),
                                         _p(app, torch.float32), _p(heads, torch.float32), _p(xyzt, torch.float32),
                                         _p(ray_id, torch.int32), _p(rays, torch.float32), _p(conv, torch.float32),
-                                        _p(feat_noise), C.c_float(anoise), C.c_float(min_rough), C.c_int32(1 if row_inputs else 0),
+                                        _p(feat_noise), C.c_float(anoise), C.c_float(min_rough), C.c_int32(int(row_inputs)),
                                         _p(V), _p(N), _p(r1),
                                         _p(f0), _p(diff), _p(feat), _p(xyz), _stream()), "nmf_bounce_prep_fwd")
     return V, N, r1, f0, diff, feat, xyz
@@ -761,22 +761,23 @@ def _rows(t, width):
 
 def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat,
                     bidx=None, row_inputs=False):
-    """row_inputs: heads is [Mb,11] and d_heads / d_app come back per bounce row ([Mb,11], [Mb,24])"""
-    M = inv.shape[0]
+    """row_inputs: heads is [Mb,11] and d_heads / d_app come back per bounce row ([Mb,11], [Mb,24]); row_inputs == 2: normals
+    [Mb,3] and d_normals [Mb,3] are per bounce row too (inv may be None, M is taken from ray_id)"""
+    M = inv.shape[0] if inv is not None else ray_id.shape[0]
     Mb = bidx.shape[0] if bidx is not None else 0
     n_out = Mb if row_inputs else M
     dev = normals.device
-    d_normals = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    d_normals = torch.empty((Mb if int(row_inputs) == 2 else M, 3), dtype=torch.float32, device=dev)
     d_heads = torch.empty((n_out, 11), dtype=torch.float32, device=dev)
     d_app = torch.empty((n_out, 24), dtype=torch.float32, device=dev)
     if M:
         (pN, sN), (pr, sr), (pf, sf), (pd, sd) = _rows(dN, 3), _rows(dr1, 1), _rows(df0, 3), _rows(ddiff, 3)
         strides = (C.c_int32 * 4)(sN, sr, sf, sd)
-        _check(_lib.nmf_bounce_prep_bwd(_p(inv, torch.int32), C.c_int64(M), _p(bidx), C.c_int64(Mb),
+        _check(_lib.nmf_bounce_prep_bwd(_p(inv, torch.int32) if inv is not None else None, C.c_int64(M), _p(bidx), C.c_int64(Mb),
                                         _p(normals, torch.float32), _p(heads if heads.shape[0] else None),
                                         _p(ray_id, torch.int32), _p(rays, torch.float32), _p(conv, torch.float32),
                                         C.c_float(min_rough), C.c_int32(1 if detach_n else 0),
-                                        C.c_int32(1 if row_inputs else 0), pN, pr, pf, pd, strides, _p(dfeat), _p(d_normals), _p(d_heads), _p(d_app),
+                                        C.c_int32(int(row_inputs)), pN, pr, pf, pd, strides, _p(dfeat), _p(d_normals), _p(d_heads), _p(d_app),
                                         _stream()), "nmf_bounce_prep_bwd")
     return d_normals, d_heads, d_app
 
@@ -1003,7 +1004,7 @@ def _install_host_ext():
 
     def bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, row_inputs=False):
         return fx.bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough,
-                                  bool(row_inputs), _stream())
+                                  int(row_inputs), _stream())
 
     def ray_compose_fwd(weight, refl_rows, inv, normals, rays, offsets, B, bg, bg_per_ray, tonemap, noclip, want_ori):
         return fx.ray_compose_fwd(weight, refl_rows, inv, normals, rays, offsets, B, bg, bool(bg_per_ray), bool(tonemap),

@@ -699,6 +699,57 @@ def test_ggx_rays_and_mix_vs_oracle():
         assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), what="mix d" + n)
 
 
+def test_vm_value_only_query_and_row_normals():
+    """Sparse normals: (1) the density-value-only query (k_vm_sigma, no gradient / normal requested) gives the bits of the
+    full query; (2) nmf_bounce_prep_* with row_inputs = 2 (normals and their adjoint per bounce row) against row_inputs = 1
+    (normals per sample) on the same rows."""
+    hip = _hip()
+    from nmf_amd.config import build_model
+    nerf, _ = build_model(grid=33, bg_resolution=16, device=DEV)
+    rf = nerf.rf
+    gen = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for prm in rf._param_list()[:13]:
+            prm.copy_((0.3 * torch.randn(prm.shape, generator=gen)).to(DEV))
+    M = 7001
+    xyz = ((torch.rand(M, 4, generator=gen) * 2 - 1) * 1.6).to(DEV)
+    p, dpk, dlk, apl, ali, basis = rf._tables()
+    sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis, want_app=False)
+    sf1, sg1, gr1, nr1, _, _ = hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis, want_normal=False, want_app=False)
+    assert gr1 is None and nr1 is None and torch.equal(sf1, sf) and torch.equal(sg1, sg)
+    rf.set_table_dtype("bf16")
+    pb, dpk_b, dlk_b, apl_b, ali_b, _ = rf._fwd_tables()
+    a = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_app=False)
+    b = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_normal=False, want_app=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # bounce rows: every 5th sample, 300 rays
+    B = 300
+    ray_id = torch.sort(torch.randint(0, B, (M,), generator=gen))[0].int().to(DEV)
+    rays = torch.cat([torch.randn(B, 3, generator=gen), torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1)], 1).to(DEV)
+    bidx = torch.arange(0, M, 5, dtype=torch.int32, device=DEV)
+    Mb = bidx.shape[0]
+    inv = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    inv[bidx.long()] = torch.arange(Mb, dtype=torch.int32, device=DEV)
+    app = torch.randn(Mb, 24, generator=gen).to(DEV)
+    heads = torch.rand(Mb, 11, generator=gen).to(DEV)
+    conv = torch.randn(9, 3, generator=gen).to(DEV)
+    noise = torch.randn(Mb, 24, generator=gen).to(DEV)
+    nr_rows = nr[bidx.long()].contiguous()
+    o1 = hip.bounce_prep_fwd(bidx, nr, app, heads, xyz, ray_id, rays, conv, noise, 0.1, 0.02, 1)
+    o2 = hip.bounce_prep_fwd(bidx, nr_rows, app, heads, xyz, ray_id, rays, conv, noise, 0.1, 0.02, 2)
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
+    dN, dr1 = torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, generator=gen).to(DEV)
+    df0, dd, dfeat = torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, 24, generator=gen).to(DEV)
+    g1 = hip.bounce_prep_bwd(inv, nr, heads, ray_id, rays, conv, 0.02, False, dN, dr1, df0, dd, dfeat, bidx=bidx, row_inputs=1)
+    g2 = hip.bounce_prep_bwd(None, nr_rows, heads, ray_id, rays, conv, 0.02, False, dN, dr1, df0, dd, dfeat, bidx=bidx, row_inputs=2)
+    assert g2[0].shape == (Mb, 3) and torch.equal(g2[0], g1[0][bidx.long()])
+    outside = torch.ones(M, dtype=torch.bool, device=DEV)
+    outside[bidx.long()] = False
+    assert float(g1[0][outside].abs().max()) == 0.0 and float(g2[0].abs().max()) > 0          # nothing outside the rows
+    assert torch.equal(g1[1], g2[1]) and torch.equal(g1[2], g2[2])
+
+
 @pytest.mark.parametrize("M", [1, 31, 33, 5000])
 def test_vm_appearance_rows_kernel_equals_the_full_query(M):
     """The appearance-only query of the bounce rows runs on its own kernel (8 lanes per row, k_vm_app_rows); the full query
