@@ -134,6 +134,13 @@ int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, 
                           const uint16_t* const dlk[3], const uint16_t* const app_planes[3],
                           const uint16_t* const app_lines[3], const float* basis, float* sigma_feat, float* sigma,
                           float* grad, float* normal, float* app, float* coef, void* stream);
+/* The density part of the query (value, sigma, gradient, normal; any output may be NULL) for a FEW rows -- the bounce rows
+ * of a re-traced level, where the training pass needs normals (fields/tensor_base.py:66-129 on xyz[bounce_mask]) -- with
+ * 16 lanes per row (one per plane tap); the sums are combined in nmf_vm_query_fwd's order: identical bits.
+ * dpk / dlk: the packed tables of nmf_vm_pack_density, fp32 or (tables_bf16 != 0) bfloat16. */
+int nmf_vm_query_rows(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const dpk[3],
+                      const void* const dlk[3], int32_t tables_bf16, float* sigma_feat, float* sigma, float* grad,
+                      float* normal, void* stream);
 
 /* Backward.  Upstream adjoints (any may be NULL): d_sigma [M] (wrt activated sigma), d_sigma_feat [M]
  * (wrt the raw feature, added to the former's contribution), d_normal [M][3], d_app [M][24].

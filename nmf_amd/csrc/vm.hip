@@ -46,7 +46,11 @@ struct Tap1 {
 
 // F.grid_sample(..., mode=bilinear, padding_mode=zeros, align_corners=True): unnormalise with
 // ((c+1)/2)*(size-1); weights e=1-w, s=1-n (ATen GridSamplerKernel.cpp, ApplyGridSample bilinear).
+// contract(off): `ix - floor(ix)` must see the ROUNDED product in every kernel that inlines this -- left to the optimiser
+// it is fused into an fma in some kernels and not in others (identical at G - 1 = 2^k, one ulp apart otherwise), and
+// k_vm_sigma / k_vm_rows_dn / k_vm_app_rows promise the bits of k_vm_fwd
 __device__ __forceinline__ Tap2 make_tap2(float u, float v, int G) {
+#pragma clang fp contract(off)
     float ix = ((u + 1.f) * 0.5f) * (float)(G - 1);
     float iy = ((v + 1.f) * 0.5f) * (float)(G - 1);
     float fx = floorf(ix), fy = floorf(iy);
@@ -64,6 +68,7 @@ __device__ __forceinline__ Tap2 make_tap2(float u, float v, int G) {
 
 // line [1,C,G,1] sampled at grid (0, w): x index is exactly 0 (width 1), the x+1 tap is outside.
 __device__ __forceinline__ Tap1 make_tap1(float v, int G) {
+#pragma clang fp contract(off)
     float iy = ((v + 1.f) * 0.5f) * (float)(G - 1);
     float fy = floorf(iy);
     float n = iy - fy, s = 1.f - n;
@@ -75,6 +80,7 @@ __device__ __forceinline__ Tap1 make_tap1(float v, int G) {
 }
 
 __device__ __forceinline__ void normalized(const nmf_vm_params& p, const float4 x, float (&xn)[3]) {
+#pragma clang fp contract(off)
     // fields/tensor_base.py:67
     xn[0] = (x.x - p.aabb_min[0]) * p.inv_size[0] - 1.f;
     xn[1] = (x.y - p.aabb_min[1]) * p.inv_size[1] - 1.f;
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
                 float run[DL];
                 load_run<DL / 4>(dlk.p[i] + (int64_t)tl.idx[t] * DL, run);
 #pragma unroll
-                for (int c = 0; c < CD; ++c) { Lc[c] = fmaf(tl.w[t], run[c], Lc[c]); DLc[c] += tl.w[t] * run[CD + c]; }   // value path: explicit fma, as in k_vm_sigma
+                for (int c = 0; c < CD; ++c) { Lc[c] = fmaf(tl.w[t], run[c], Lc[c]); DLc[c] = fmaf(tl.w[t], run[CD + c], DLc[c]); }   // explicit fma throughout: k_vm_sigma / k_vm_rows_dn repeat these sums bit for bit
             }
             const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
             float s_pl = 0.f, s_dx = 0.f, s_dy = 0.f, s_pdl = 0.f;
@@ -269,11 +275,12 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 #pragma unroll
                 for (int c = 0; c < CD; ++c) {
                     a = fmaf(run[c], Lc[c], a);
-                    d += run[c] * DLc[c];
-                    b += run[CD + c] * Lc[c];
-                    cdy += run[2 * CD + c] * Lc[c];
+                    d = fmaf(run[c], DLc[c], d);
+                    b = fmaf(run[CD + c], Lc[c], b);
+                    cdy = fmaf(run[2 * CD + c], Lc[c], cdy);
                 }
-                s_pl = fmaf(tp.w[t], a, s_pl); s_pdl += tp.w[t] * d; s_dx += tp.w[t] * b; s_dy += tp.w[t] * cdy;
+                s_pl = fmaf(tp.w[t], a, s_pl); s_pdl = fmaf(tp.w[t], d, s_pdl); s_dx = fmaf(tp.w[t], b, s_dx);
+                s_dy = fmaf(tp.w[t], cdy, s_dy);
             }
             sf += s_pl;
             g[MAT0[i]] += s_dx;
@@ -401,6 +408,100 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
     }
 }
 
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+
+// ------------------------------------------------------------------------------------------------
+// forward, value + gradient + normal of a FEW rows (the bounce rows of a re-traced level: ~20 k): SIXTEEN lanes per row,
+// lane 4 i + t owns tap t of plane i (lanes 12..15 idle): it forms the plane's line factors and its tap's four channel
+// sums exactly as k_vm_fwd does, the four taps of a plane and then the three planes are combined IN k_vm_fwd's ORDER
+// through shuffles -- identical bits, three dependent load batches per lane instead of eighteen.  A lane per row
+// (k_vm_fwd) leaves these launches at 70 workgroups and 39 us.
+// ------------------------------------------------------------------------------------------------
+template <class TT>
+__global__ void __launch_bounds__(256) k_vm_rows_dn(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
+                                                    PtrsT3<TT> dpk, PtrsT3<TT> dlk, float* __restrict__ sigma_feat,
+                                                    float* __restrict__ sigma, float* __restrict__ grad,
+                                                    float* __restrict__ normal) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15, i = sub >> 2, t = sub & 3;
+    const bool ok = row < M && i < 3;
+    const int G = p.grid;
+    float xn[3] = {0.f, 0.f, 0.f};
+    if (row < M) normalized(p, xyzt[row], xn);
+    float a = 0.f, b = 0.f, cdy = 0.f, d = 0.f, w = 0.f;
+    bool valid = false;
+    if (ok) {
+        const int vec = i == 0 ? 2 : (i == 1 ? 1 : 0), m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2;      // VEC / MAT0 / MAT1
+        const TT* lines = i == 0 ? dlk.p[0] : (i == 1 ? dlk.p[1] : dlk.p[2]);
+        const TT* planes = i == 0 ? dpk.p[0] : (i == 1 ? dpk.p[1] : dpk.p[2]);
+        const Tap1 tl = make_tap1(xn[vec], G);
+        float Lc[CD], DLc[CD];
+#pragma unroll
+        for (int c = 0; c < CD; ++c) { Lc[c] = 0.f; DLc[c] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (tl.idx[q] < 0) continue;
+            float run[DL];
+            load_run<DL / 4>(lines + (int64_t)tl.idx[q] * DL, run);
+#pragma unroll
+            for (int c = 0; c < CD; ++c) { Lc[c] = fmaf(tl.w[q], run[c], Lc[c]); DLc[c] = fmaf(tl.w[q], run[CD + c], DLc[c]); }
+        }
+        const Tap2 tp = make_tap2(xn[m0], xn[m1], G);
+        const int idx = t == 0 ? tp.idx[0] : (t == 1 ? tp.idx[1] : (t == 2 ? tp.idx[2] : tp.idx[3]));
+        w = t == 0 ? tp.w[0] : (t == 1 ? tp.w[1] : (t == 2 ? tp.w[2] : tp.w[3]));
+        valid = idx >= 0;
+        if (valid) {
+            float run[DP];
+            load_run<DP / 4>(planes + (int64_t)idx * DP, run);
+#pragma unroll
+            for (int c = 0; c < CD; ++c) {
+                a = fmaf(run[c], Lc[c], a);
+                d = fmaf(run[c], DLc[c], d);
+                b = fmaf(run[CD + c], Lc[c], b);
+                cdy = fmaf(run[2 * CD + c], Lc[c], cdy);
+            }
+        }
+    }
+    // the four taps of this lane's plane, in tap order
+    const int base = (threadIdx.x & 63) & ~3;
+    float s_pl = 0.f, s_dx = 0.f, s_dy = 0.f, s_pdl = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float wq = __shfl(w, base + q, 64), aq = __shfl(a, base + q, 64), dq = __shfl(d, base + q, 64);
+        const float bq = __shfl(b, base + q, 64), cq = __shfl(cdy, base + q, 64);
+        const bool vq = __shfl((int)valid, base + q, 64) != 0;
+        if (vq) {
+            s_pl = fmaf(wq, aq, s_pl); s_pdl = fmaf(wq, dq, s_pdl); s_dx = fmaf(wq, bq, s_dx); s_dy = fmaf(wq, cq, s_dy);
+        }
+    }
+    // the three planes, in plane order, on lane 0 of the row
+    const int r0 = (threadIdx.x & 63) & ~15;
+    float sf = 0.f, g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const float spl = __shfl(s_pl, r0 + 4 * pl, 64), sdx = __shfl(s_dx, r0 + 4 * pl, 64);
+        const float sdy = __shfl(s_dy, r0 + 4 * pl, 64), spd = __shfl(s_pdl, r0 + 4 * pl, 64);
+        sf += spl;
+        g[MAT0[pl]] += sdx;
+        g[MAT1[pl]] += sdy;
+        g[VEC[pl]] += spd;
+    }
+    if (row >= M || sub != 0) return;
+    if (sigma_feat) sigma_feat[row] = sf;
+    if (sigma) {
+        float x = fminf(fmaxf(sf, -15.f), 1e3f) + p.density_shift;       // tensor_base.py:85
+        sigma[row] = x > 20.f ? x : log1pf(expf(x));                     // F.softplus (threshold 20)
+    }
+    g[0] *= p.inv_size[0]; g[1] *= p.inv_size[1]; g[2] *= p.inv_size[2];
+    if (grad) { grad[row * 3] = g[0]; grad[row * 3 + 1] = g[1]; grad[row * 3 + 2] = g[2]; }
+    if (normal) {                                                        // tensor_base.py:128, mutils.py:8-12
+        float n2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+        float inv = 1.f / sqrtf(fmaxf(n2, 1.1920929e-07f));
+        normal[row * 3] = -g[0] * inv; normal[row * 3 + 1] = -g[1] * inv; normal[row * 3 + 2] = -g[2] * inv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, appearance only: EIGHT lanes per sample.  The sparse-appearance path queries the appearance features of the
 // bounce rows alone (8 k - 20 k rows per level): with a lane per sample that is 30 - 70 workgroups on 256 CUs, each lane
@@ -409,8 +510,6 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
 // row), parks its 9 coefficients in LDS, and then computes the outputs 3q .. 3q+2 from the row's 72 coefficients with the
 // basis matrix staged in LDS.  Tap order and the c-order of the basis product are those of k_vm_fwd: identical bits.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ld1(const float* p) { return *p; }
-__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
 
 constexpr int APP_ROWS = 32;              // rows per 256-thread workgroup
 constexpr int APP_PITCH = 3 * CA + 4;     // LDS pitch of a coefficient row (76: rows of a wave start on different banks)
@@ -1282,6 +1381,29 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
                                 float* grad, float* normal, float* app, float* coef, void* stream) {
     return vm_query_fwd_impl<float>("nmf_vm_query_fwd", p, xyzt, M, dpk, dlk, app_planes, app_lines, basis, sigma_feat, sigma,
                                     grad, normal, app, coef, stream);
+}
+
+extern "C" int nmf_vm_query_rows(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const dpk[3],
+                                 const void* const dlk[3], int32_t tables_bf16, float* sigma_feat, float* sigma, float* grad,
+                                 float* normal, void* stream) {
+    NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_rows: params");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(xyzt && dpk && dlk && dpk[0] && dpk[1] && dpk[2] && dlk[0] && dlk[1] && dlk[2], NMF_EINVAL,
+                "nmf_vm_query_rows: null");
+    const dim3 grid((unsigned)cdiv(M * 16, 256)), block(256);
+    if (tables_bf16) {
+        PtrsT3<uint16_t> a, b;
+        for (int i = 0; i < 3; ++i) { a.p[i] = (const uint16_t*)dpk[i]; b.p[i] = (const uint16_t*)dlk[i]; }
+        hipLaunchKernelGGL(k_vm_rows_dn<uint16_t>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
+                           sigma_feat, sigma, grad, normal);
+    } else {
+        PtrsT3<float> a, b;
+        for (int i = 0; i < 3; ++i) { a.p[i] = (const float*)dpk[i]; b.p[i] = (const float*)dlk[i]; }
+        hipLaunchKernelGGL(k_vm_rows_dn<float>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
+                           sigma_feat, sigma, grad, normal);
+    }
+    NMF_CHECK_LAUNCH("nmf_vm_query_rows");
+    return NMF_OK;
 }
 
 extern "C" int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, const uint16_t* const dpk[3],

@@ -155,11 +155,8 @@ class TrainPass:
         feat_noise = noise.rows(deferred, bidx)
         sf_rows = gr_rows = None
         if sparse_n:
-            sf_rows, _sg, gr_rows, nr, app, _ = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=True,
-                                                                want_normal=True, want_app=True)
-        else:
-            app = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False,
-                                   want_app=True)[4]
+            sf_rows, gr_rows, nr = hip.vm_query_rows(p, xyz_rows, dpk, dlk)
+        app = hip.vm_query_fwd(p, xyz_rows, dpk, dlk, apl, ali, basis, want_density=False, want_normal=False, want_app=True)[4]
         hp, hW, hb = self.heads
         heads = hip.heads_fwd(app, hW, hb, hp)
         V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(bidx, nr, app, heads, S.xyzt, S.ray_id, S.rays, conv, feat_noise,

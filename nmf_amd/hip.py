@@ -61,7 +61,7 @@ class CopySlot(C.Structure):
 
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
-    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_bwd",
+    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
     "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
@@ -333,6 +333,20 @@ def vm_query_fwd(p, xyzt, dpk, dlk, app_planes, app_lines, basis, want_density=T
               _p3(app_planes, td) if need_a else None, _p3(app_lines, td) if need_a else None,
               _p(basis) if need_a else None, _p(sf), _p(sg), _p(gr), _p(nr), _p(ap), _p(cf), _stream()), name)
     return sf, sg, gr, nr, ap, cf
+
+
+def vm_query_rows(p, xyzt, dpk, dlk):
+    """value + gradient + normal of a few rows (16 lanes per row): -> (sigma_feat [M], grad [M,3], normal [M,3])"""
+    M = xyzt.shape[0]
+    dev = xyzt.device
+    sf = torch.empty(M, dtype=torch.float32, device=dev)
+    gr = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    nr = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    td = dpk[0].dtype
+    _check(_lib.nmf_vm_query_rows(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M), _p3(dpk, td), _p3(dlk, td),
+                                  C.c_int32(1 if td == torch.bfloat16 else 0), _p(sf), None, _p(gr), _p(nr), _stream()),
+           "nmf_vm_query_rows")
+    return sf, gr, nr
 
 
 def to_bf16_tables(srcs, dsts=None):

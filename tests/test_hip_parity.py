@@ -705,7 +705,7 @@ def test_vm_value_only_query_and_row_normals():
     (normals per sample) on the same rows."""
     hip = _hip()
     from nmf_amd.config import build_model
-    nerf, _ = build_model(grid=33, bg_resolution=16, device=DEV)
+    nerf, _ = build_model(grid=36, bg_resolution=16, device=DEV)      # G - 1 not a power of two: see make_tap2 in csrc/vm.hip
     rf = nerf.rf
     gen = torch.Generator().manual_seed(11)
     with torch.no_grad():
@@ -722,6 +722,11 @@ def test_vm_value_only_query_and_row_normals():
     a = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_app=False)
     b = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_normal=False, want_app=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # the 16-lanes-per-row query of a few rows (a lane per plane tap, combined in the full query's order): the same bits
+    for tabs in ((pb, dpk_b, dlk_b, a), (p, dpk, dlk, (sf, sg, gr, nr))):
+        for n in (1, 5, 999):
+            sf_r, gr_r, nr_r = hip.vm_query_rows(tabs[0], xyz[:n].contiguous(), tabs[1], tabs[2])
+            assert torch.equal(sf_r, tabs[3][0][:n]) and torch.equal(gr_r, tabs[3][2][:n]) and torch.equal(nr_r, tabs[3][3][:n])
     # bounce rows: every 5th sample, 300 rays
     B = 300
     ray_id = torch.sort(torch.randint(0, B, (M,), generator=gen))[0].int().to(DEV)
@@ -757,7 +762,7 @@ def test_vm_appearance_rows_kernel_equals_the_full_query(M):
     72 -> 24 basis product, hence the same bits -- fp32 and bf16 tables, samples outside the box included."""
     hip = _hip()
     from nmf_amd.config import build_model
-    nerf, _ = build_model(grid=33, bg_resolution=16, device=DEV)
+    nerf, _ = build_model(grid=36, bg_resolution=16, device=DEV)      # G - 1 not a power of two: see make_tap2 in csrc/vm.hip
     rf = nerf.rf
     gen = torch.Generator().manual_seed(M)
     with torch.no_grad():
