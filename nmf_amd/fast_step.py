@@ -28,6 +28,7 @@ MLP_SIDE_MIN_RAYS = 100000   # the capped launch runs at about half speed: it pa
                              # level below re-traces this many rays (steady state: all 0.24 M).  With 20 k re-traced rays
                              # under 0.1 M+ MLP rows the main stream ran dry and waited for it (-4 %), and at the deepest level
                              # the 46 k-row launch next to the env adjoint was no faster than the two one after the other
+WALK_SIDE_MIN_SAMPLES = 200000
 MLP_SIDE_WGS = 128      # persistent workgroups of a BRDF-MLP backward that shares the chip (measured: 128 - 192 alike, 64 and
                         # 256+ slower; csrc/brdf_mlp.hip)
 
@@ -232,6 +233,18 @@ class TrainPass:
         # needs only d_w and is first used by the field walk: issued here it fills time in which this stream would wait for the
         # side streams below, at the end of the level it would sit on the critical path (45 us for the re-traced rays)
         d_sigma = hip.composite_bwd(t.sg, S.dist, t.w, t.offsets, t.B, self.scale, d_w)
+        early_walk = False
+        if t.sparse_n and t.M >= WALK_SIDE_MIN_SAMPLES:
+            # the value-only walk of a re-traced level needs nothing but d_sigma: on a side stream from here on, next to the
+            # whole shading backward, instead of at the end of the pass in front of the other walks
+            wfork = self._fork(("walk", lvl))
+            if wfork is not None:
+                p_, dpk, dlk, apl, ali, basis = self.nerf.rf._tables()
+                with torch.cuda.stream(wfork[1]):
+                    hip.vm_query_bwd_segments(p_, [(S.xyzt, t.sf, None, d_sigma, None, None, None)], dpk, dlk, apl, ali, basis,
+                                              a.g_dpk, a.g_dlk, a.g_apl, a.g_ali, None)
+                self._walk_forks.append((wfork, d_sigma))
+                early_walk = True
         d_rays, env_fork = None, None
         if t.per_ray_bg:
             d_bg = (1 - t.acc)[:, None] * d_rgb
@@ -298,7 +311,8 @@ class TrainPass:
             d_normal = d_normals
         if t.sparse_n:      # value-only walk over the level's samples; the rows carry the normal adjoint (with a zero d_sigma so
             # that they share a walk with the level-0 samples)
-            self.dens_segs.append((S.xyzt, t.sf, None, d_sigma, None, None, None))
+            if not early_walk:
+                self.dens_segs.append((S.xyzt, t.sf, None, d_sigma, None, None, None))
             if d_normal is not None:
                 self.dens_segs.append((t.xyz_rows, t.sf_rows, t.gr_rows, torch.zeros_like(t.sf_rows), None, d_normal, None))
         else:
@@ -346,6 +360,9 @@ class TrainPass:
 
         walk(self.dens_segs, None)       # (the appearance walk next to the density walk on a second stream: no gain)
         walk(self.app_segs, a.g_basis)
+        for wfork, _keep in self._walk_forks:
+            self._join(wfork)
+        self._walk_forks = []
         self.dens_segs, self.app_segs = [], []
 
     # ---- evaluation: forward only ---------------------------------------------------------------------------------------
@@ -402,7 +419,7 @@ class TrainPass:
             m.begin_pass()
         try:
             self._begin(dev, noise)
-            self.dens_segs, self.app_segs = [], []
+            self.dens_segs, self.app_segs, self._walk_forks = [], [], []
             t = self._fwd(0, rays, focal, None, noise)
             if t.M == 0:
                 return dict(loss=None, kept=t.B, n_samples=[0])
