@@ -128,8 +128,18 @@ class KernelTimer:
 
             setattr(hip, name, counted)
 
-    def summary(self):
-        """-> total ms, algorithmic bytes, dense-equivalent MFMA flop, samples, launches"""
+    def summary(self, kind=None):
+        """-> total ms, algorithmic bytes, issued MFMA flop, samples, launches of the walks of one kind (1: value-only density
+        walk, 2: density walk with the normal adjoint, None: all calls incl. appearance)"""
+        all_records = self.records
+        if kind is not None:
+            self.records = [r for r in all_records if r[3] == kind and not r[4]]
+        try:
+            return self._summary()
+        finally:
+            self.records = all_records
+
+    def _summary(self):
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
         nbytes = sum(m * ((BWD_BYTES_DENSITY if d == 2 else BWD_BYTES_VALUE if d == 1 else 0) + BWD_BYTES_APP * a)
                      for _, _, m, d, a in self.records)
@@ -454,7 +464,10 @@ def main():
     if min(timer.rebuilds.values()) < args.steps:
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
     if rank == 0:
-        k_ms, k_bytes, k_flop, k_samples, k_launches = timer.summary()
+        # the largest field walk of the step: the value-only walk of the re-traced samples (sparse normals), else the full one
+        walk_kind = 1 if any(r[3] == 1 and not r[4] for r in timer.records) else 2
+        walk_key = "k_vm_bwd_density<value>" if walk_kind == 1 else "k_vm_bwd_density<normal>"
+        k_ms, k_bytes, k_flop, k_samples, k_launches = timer.summary(walk_kind)
         avg_ms = k_ms / max(k_launches, 1)
         alg_gbs = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         mfma_tflops = k_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -462,7 +475,7 @@ def main():
         traffic, per_kernel, ctr_meta = None, None, None
         if ctr is not None:
             ks = ctr.get("kernels", {})
-            traffic = ks.get("k_vm_bwd_brick<density>", {}).get("hbm_bytes_per_launch")
+            traffic = ks.get(walk_key, ks.get("k_vm_bwd_brick<density>", {})).get("hbm_bytes_per_launch")
             # counter-derived figures of every kernel of the step (bound = the largest of mfma_busy / valu_busy / l2 / hbm)
             per_kernel = {k: dict(v.get("derived", {}), avg_launch_us=v.get("avg_launch_us")) for k, v in ks.items()
                           if "derived" in v}
@@ -491,16 +504,20 @@ def main():
             #         (tools/roofline_metrics.py) -- the fraction of the kernel's real ceiling
             #   `algorithmic_over_hbm`: SURVEY 8(d) bytes / time against 8 TB/s (can exceed 1: the 7.5 MB of factor tables
             #         live in L2/MALL and tiles accumulate in registers); `traffic` = fabric bytes per launch from PMC
-            "roofline": {"bound": "mfma", "kernel": "nmf_vm_query_bwd_segments (k_vm_bwd_brick + binning)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "nmf_vm_query_bwd_segments, " + ("value-only walk of the re-traced samples" if walk_kind == 1
+                                                                    else "density walk with normals") +
+                                   " (binning + " + walk_key + "; runs next to the shading backward on a side stream)",
                          "achieved": mfma_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": mfma_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "launches": k_launches, "avg_launch_ms": avg_ms,
                          "samples_per_launch": k_samples / max(k_launches, 1),
-                         "algorithmic_bytes_per_sample": {"density+normals (all samples)": BWD_BYTES_DENSITY,
+                         "algorithmic_bytes_per_sample": {"density value (re-traced samples)": BWD_BYTES_VALUE,
+                                                          "density+normals (primary samples, bounce rows)": BWD_BYTES_DENSITY,
                                                           "appearance (bounce rows)": BWD_BYTES_APP},
                          "algorithmic_GBps": alg_gbs, "algorithmic_over_hbm": alg_gbs / HBM_PEAK_GBS,
                          "hbm_frac_counters": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
-                         "alu_busy_counters": (per_kernel or {}).get("k_vm_bwd_brick<density>", {}).get("alu_busy"),
+                         "alu_busy_counters": (per_kernel or {}).get(walk_key, (per_kernel or {}).get("k_vm_bwd_brick<density>", {})).get("alu_busy"),
                          "counters": ctr_meta, "per_kernel": per_kernel},
         }
         if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID \

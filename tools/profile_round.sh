@@ -49,7 +49,9 @@ python - "$TAG" "$OUT" "$ROOT" <<'PY'
 import csv, glob, json, subprocess, sys, collections, re
 tag, out, root = sys.argv[1], sys.argv[2], sys.argv[3]
 # kernels of the steady-state step, by substring of the demangled name -> report key
-KEYS = {"k_vm_bwd_density": "k_vm_bwd_brick<density>", "k_vm_bwd_brick<true": "k_vm_bwd_brick<density>",
+KEYS = {"k_vm_bwd_density<false": "k_vm_bwd_density<value>", "k_vm_bwd_density<true": "k_vm_bwd_density<normal>",
+        "k_vm_bwd_brick<true": "k_vm_bwd_brick<density>", "k_vm_sigma": "k_vm_sigma", "k_vm_rows_dn": "k_vm_rows_dn",
+        "k_vm_app_rows": "k_vm_app_rows",
         "k_vm_bwd_brick<false": "k_vm_bwd_brick<appearance>",
         "k_brdf_mlp_bwd": "k_brdf_mlp_bwd", "k_brdf_mlp_fwd": "k_brdf_mlp_fwd", "k_env_lookup_bwd": "k_env_lookup_bwd",
         "k_env_lookup_fwd": "k_env_lookup_fwd", "k_vm_fwd": "k_vm_fwd", "k_march_count16": "k_march_count16",
@@ -112,7 +114,7 @@ for k in sums:
             rec["mfma_tflops"] = round(flop / t / 1e12, 2)
             rec["mfma_frac_of_157.3"] = round(flop / t / 157.3e12, 4)
     kernels[k] = rec
-walk = kernels.get("k_vm_bwd_brick<density>", {})
+walk = kernels.get("k_vm_bwd_density<value>", kernels.get("k_vm_bwd_density<normal>", kernels.get("k_vm_bwd_brick<density>", {})))
 try:
     commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
