@@ -52,6 +52,7 @@ class TrainPass:
         # gain), the composite backward on a side stream (2.25 ms); anything of the FORWARD on a side stream (the MLP next to the
         # level-1 sampler: 2.36 ms, the background lookup of the secondary rays next to it: 2.28 ms).  NMF_OVERLAP=0 keeps everything on one stream.
         self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
+        self._last_chunk = False
         self.sparse_normals = os.environ.get("NMF_SPARSE_NORMALS", "1") != "0"
         self._early_env = None
         self._side = {}
@@ -282,6 +283,17 @@ class TrainPass:
                 d_brays.index_copy_(0, t.idx_re, self._bwd(t.child, d_inc[t.idx_re], None, None))
             if t.idx_no.shape[0] > 0:
                 d_brays.index_copy_(0, t.idx_no, self._env_bwd(t.brays_no, t.mip_no, d_inc[t.idx_no]))
+        if lvl == 0 and self._last_chunk and a.used_env:
+            # every environment adjoint of the optimizer step has been queued (level 0 has no background lookup of its own):
+            # the two reverse prefix sums of the env-map table run on a side stream from here, next to the rest of the pass,
+            # instead of after the field walks (end_step picks the result up)
+            sfork = self._fork("sat_bwd")
+            if sfork is not None:
+                bgm = self.nerf.bg_module
+                act, _sat, _pole = bgm._tables()
+                with torch.cuda.stream(sfork[1]):
+                    d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars())
+                self._early_env = (sfork, d_bg)
         # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
         if fork is not None:
             self._join(fork, d_xfeat)
@@ -435,17 +447,8 @@ class TrainPass:
             d_loss, _d_l1, d_ori, d_acc = hip.loss_mix_bwd([loss.shape, loss.shape, t.ori.shape, t.acc.shape], wts, inv_lbatch,
                                                            _one(dev))
             d_rgb = hip.sqerr_bwd(t.rgb_map, gt_b, d_loss)
+            self._last_chunk = bool(last)
             self._bwd(t, d_rgb, d_acc, d_ori)
-            if last and a.used_env:
-                # last chunk of the optimizer step: the env-map adjoint table is complete, its two reverse prefix sums run on
-                # a side stream next to the field walks instead of after them (end_step picks the result up)
-                fork = self._fork("sat_bwd")
-                if fork is not None:
-                    bgm = nerf.bg_module
-                    act, _sat, _pole = bgm._tables()
-                    with torch.cuda.stream(fork[1]):
-                        d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars())
-                    self._early_env = (fork, d_bg)
             self._flush_walks()
             self.n_loss_chunks += 1
             self.l1_scale += float(wts[1]) * float(inv_lbatch)
