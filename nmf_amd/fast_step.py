@@ -53,6 +53,7 @@ class TrainPass:
         # level-1 sampler: 2.36 ms, the background lookup of the secondary rays next to it: 2.28 ms).  NMF_OVERLAP=0 keeps everything on one stream.
         self.overlap = os.environ.get("NMF_OVERLAP", "1") != "0"
         self._last_chunk = False
+        self._acc_cache = None
         self.sparse_normals = os.environ.get("NMF_SPARSE_NORMALS", "1") != "0"
         self._early_env = None
         self._side = {}
@@ -72,23 +73,37 @@ class TrainPass:
         self.l1_scale = 0.0
 
     def _accumulators(self, dev):
+        """The gradient state of an optimizer step.  Allocated ONCE per (grid, env size): the flat accumulator buffer, its
+        views, the parameter-shaped gradient tensors and the (parameter, gradient) pairs end_step hands over -- per step only
+        one zero fill remains (the host side of a step is on the critical path behind the last size read-back)."""
         if self.acc is None:
             n = self.nerf
             G = int(n.rf.density_rf.grid_size)
             H, W = n.bg_module.hw()
-            shapes = ([(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]      # field (packed)
-                      + [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)]                                    # BRDF MLP
-                      + [(11, 24), (11,)]                                                                     # stacked heads
-                      + [(H, W, 4), (2, 3), (1,)])                                                            # d_sat, d_pole, d_mip
-            sizes = [int(torch.Size(s).numel()) for s in shapes]
-            pad = [(s + 3) & ~3 for s in sizes]                      # every view 16-byte aligned
-            flat = torch.zeros(sum(pad), dtype=torch.float32, device=dev)
-            v, o = [], 0
-            for s, sh, p_ in zip(sizes, shapes, pad):
-                v.append(flat[o:o + s].view(sh))
-                o += p_
-            self.acc = _ns(flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], g_apl=v[6:9], g_ali=v[9:12], g_basis=v[12], g_mlp=v[13:19],
-                           g_hW=v[19], g_hb=v[20], d_sat=v[21], d_pole=v[22], d_mip=v[23], used_env=False)
+            m = n.model.brdf.mlp
+            owners = (n.rf._param_list() + [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
+                      + list(n.model.diffuse_module._head_params()) + [n.bg_module.bg_mat, n.bg_module.mipbias])
+            key = (str(dev), G, H, W) + tuple(id(q) for q in owners)      # new Parameter objects (upsample, load): new state
+            c = self._acc_cache
+            if c is None or c.key != key:
+                shapes = ([(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]      # field (packed)
+                          + [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)]                                    # BRDF MLP
+                          + [(11, 24), (11,)]                                                                     # stacked heads
+                          + [(H, W, 4), (2, 3), (1,)])                                                            # d_sat, d_pole, d_mip
+                sizes = [int(torch.Size(s).numel()) for s in shapes]
+                pad = [(s + 3) & ~3 for s in sizes]                      # every view 16-byte aligned
+                flat = torch.empty(sum(pad), dtype=torch.float32, device=dev)
+                v, o = [], 0
+                for s, sh, p_ in zip(sizes, shapes, pad):
+                    v.append(flat[o:o + s].view(sh))
+                    o += p_
+                c = _ns(key=key, flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], g_apl=v[6:9], g_ali=v[9:12], g_basis=v[12],
+                        g_mlp=v[13:19], g_hW=v[19], g_hb=v[20], d_sat=v[21], d_pole=v[22], d_mip=v[23], used_env=False,
+                        pairs=None, gp=None, gl=None, d_bg=None, l1=None)
+                self._acc_cache = c
+            c.flat.zero_()
+            c.used_env = False
+            self.acc = c
         return self.acc
 
     # ---- forward of one recursion level ------------------------------------------------------------------------------
@@ -291,8 +306,10 @@ class TrainPass:
             if sfork is not None:
                 bgm = self.nerf.bg_module
                 act, _sat, _pole = bgm._tables()
+                if a.d_bg is None:
+                    a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
                 with torch.cuda.stream(sfork[1]):
-                    d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars())
+                    d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars(), out=a.d_bg)
                 self._early_env = (sfork, d_bg)
         # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
         if fork is not None:
@@ -466,31 +483,42 @@ class TrainPass:
         nerf = self.nerf
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
         p = rf._tables()[0]
-        gp, gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk)
+        if a.gp is None:
+            a.gp, a.gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk)
+        else:
+            hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, out=(a.gp, a.gl))
+        gp, gl = a.gp, a.gl
         if self.l1_scale != 0.0:
+            if a.l1 is None or a.l1[0] != self.l1_scale:
+                a.l1 = (self.l1_scale, torch.full((), self.l1_scale, dtype=torch.float32, device=a.flat.device))
             dens = [x.detach() for x in list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)]
-            hip.l1_mean_bwd(dens, torch.full((), self.l1_scale, dtype=torch.float32, device=a.flat.device), out=gp + gl)
-        grads = list(zip(rf._param_list(), rf._grads_to_param_layout(gp, gl, a.g_apl, a.g_ali, a.g_basis)))
-        m = model.brdf.mlp
-        grads += list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
-        hps = model.diffuse_module._head_params()
-        for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
-            grads += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
+            hip.l1_mean_bwd(dens, a.l1[1], out=gp + gl)
+        if a.pairs is None:       # (parameter, gradient tensor) of everything that lives in the persistent buffers
+            pairs = list(zip(rf._param_list(), rf._grads_to_param_layout(gp, gl, a.g_apl, a.g_ali, a.g_basis)))
+            m = model.brdf.mlp
+            pairs += list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
+            hps = model.diffuse_module._head_params()
+            for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
+                pairs += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
+            a.pairs = [(prm, g) for prm, g in pairs if prm.requires_grad]
+        grads = list(a.pairs)
         if a.used_env:
             act, sat, pole = bgm._tables()
             sc = bgm._dev_scalars()
             if self._early_env is not None:
                 fork, d_bg = self._early_env
-                self._join(fork, d_bg)
+                self._join(fork)
                 self._early_env = None
             else:
-                d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc)
-            grads.append((bgm.bg_mat, d_bg.reshape(bgm.bg_mat.shape)))
+                d_bg = a.d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc, out=a.d_bg)
+            if bgm.bg_mat.requires_grad:
+                grads.append((bgm.bg_mat, d_bg.reshape(bgm.bg_mat.shape)))
             if bgm.brightness_lr != 0 or bgm.mul_lr != 0:           # lr 0 (microfacet_tensorf2.yaml:150-151): no update anyway
                 d_pre = d_bg / sc[2]
                 grads.append((bgm.brightness, d_pre.sum(dtype=torch.float64)))
                 grads.append((bgm.mul, (d_pre * bgm.bg_mat.detach().reshape(d_pre.shape)).sum(dtype=torch.float64)))
-            grads.append((bgm.mipbias, a.d_mip.to(torch.float64).reshape(())))
+            if bgm.mipbias.requires_grad:
+                grads.append((bgm.mipbias, a.d_mip.to(torch.float64).reshape(())))
         for prm, g in grads:
             if not prm.requires_grad:
                 continue

@@ -418,14 +418,18 @@ def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk
            "nmf_vm_query_bwd_segments")
 
 
-def vm_unpack_density_grad(p, g_dpk, g_dlk):
+def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
+    """out = (gp, gl) of an earlier call: the same tensors are overwritten (a training pass keeps its gradient tensors)"""
     G = p.grid
     dev = g_dpk[0].device
-    # parameter-shaped outputs with channel-last strides: the storage is the [G][G][16] / [G][16] the kernel writes
-    gp = [torch.empty((1, 16, G, G), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
-          for _ in range(3)]
-    gl = [torch.empty((1, 16, G, 1), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
-          for _ in range(3)]
+    if out is not None:
+        gp, gl = out
+    else:
+        # parameter-shaped outputs with channel-last strides: the storage is the [G][G][16] / [G][16] the kernel writes
+        gp = [torch.empty((1, 16, G, G), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+              for _ in range(3)]
+        gl = [torch.empty((1, 16, G, 1), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+              for _ in range(3)]
     arr_p, arr_l = (C.c_void_p * 3)(*[t.data_ptr() for t in gp]), (C.c_void_p * 3)(*[t.data_ptr() for t in gl])
     _check(_lib.nmf_vm_unpack_density_grad(C.byref(p), _p3(g_dpk), _p3(g_dlk), arr_p, arr_l, _stream()),
            "nmf_vm_unpack_density_grad")
@@ -507,10 +511,10 @@ def sh_project(vals, wq, sh_A, out=None):
     return out
 
 
-def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None):
+def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None, out=None):
     bg = bg_mat.reshape(3, bg_mat.shape[-2], bg_mat.shape[-1])
     H, W = bg.shape[-2:]
-    d_bg = torch.empty_like(bg)
+    d_bg = out if out is not None else torch.empty_like(bg)
     _check(_lib.nmf_sat_build_bwd(_p(d_sat, torch.float32), _p(bg.contiguous(), torch.float32), _p(act), C.c_int32(H),
                                   C.c_int32(W), C.c_float(brightness), C.c_float(mul), _p(sc), _p(d_pole), _p(d_bg), _stream()),
            "nmf_sat_build_bwd")
@@ -1060,11 +1064,15 @@ def _install_host_ext():
         return fx.vm_query_bwd_segments(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
                                         g_app_lines, g_basis, _stream())
 
-    def vm_unpack_density_grad(p, g_dpk, g_dlk):
+    py_unpack = g["vm_unpack_density_grad"]
+
+    def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
+        if out is not None:
+            return py_unpack(p, g_dpk, g_dlk, out)
         return fx.vm_unpack_density_grad(addr(p), g_dpk, g_dlk, _stream())
 
     for name, fn in list(locals().items()):
-        if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd"):
+        if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd", "py_unpack"):
             PY_WRAPPERS[name] = g[name]
             fn.__doc__ = g[name].__doc__
             g[name] = fn

@@ -17,6 +17,9 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         self._slots = None
         self._plan = None
+        self._last_grads = None
+        self._gidx = None
+        self._touched = None
         super().__init__(params, defaults)
 
     @torch.no_grad()
@@ -48,33 +51,67 @@ class FusedAdam(torch.optim.Optimizer):
         for p in skipped:
             if p.grad is not None:
                 return False
-        gptr = []
-        for p, st, gi, pptr, gstride in entries:        # validate everything before touching any state
-            g = p.grad
-            if g is None or g.dtype != p.dtype or g.stride() != gstride or p.data_ptr() != pptr or g.is_sparse:
-                return False
-            gptr.append(g.data_ptr())
+        last = self._last_grads
+        same = last is not None and len(last) == len(entries)
+        if same:                                        # the training pass hands over the SAME gradient tensors every step
+            for e, g0 in zip(entries, last):
+                if e[0].grad is not g0 or e[0].data_ptr() != e[3]:
+                    same = False
+                    break
+        if same:
+            gptr = None                                 # validated in the previous step: pointers and layouts stand
+        else:
+            gptr, grads = [], []
+            for p, st, gi, pptr, gstride in entries:    # validate everything before touching any state
+                g = p.grad
+                if g is None or g.dtype != p.dtype or g.stride() != gstride or p.data_ptr() != pptr or g.is_sparse:
+                    self._last_grads = None
+                    return False
+                gptr.append(g.data_ptr())
+                grads.append(g)
+            self._last_grads = grads
         lrs = [float(g["lr"]) for g in self.param_groups]
-        memo, step_size, bc2 = {}, [], []
-        for p, st, gi, pptr, gstride in entries:
-            st["step"] = t = st["step"] + 1
-            f = memo.get((gi, t))
-            if f is None:
-                beta1, beta2 = hyper[gi][0], hyper[gi][1]
-                f = memo[(gi, t)] = (lrs[gi] / (1 - beta1 ** t), math.sqrt(1 - beta2 ** t))
-            step_size.append(f[0])
-            bc2.append(f[1])
         n = len(entries)
+        steps = [e[1]["step"] for e in entries]
+        if n and steps.count(steps[0]) == n:
+            # all tensors have taken the same number of steps (always, unless a tensor joined later): one pair of factors per
+            # param group, spread over the tensors with the plan's group-index array
+            t = steps[0] + 1
+            fs = np.empty(len(lrs), dtype=np.float64)
+            fb = np.empty(len(lrs), dtype=np.float64)
+            for gi, lr in enumerate(lrs):
+                beta1, beta2 = hyper[gi][0], hyper[gi][1]
+                fs[gi] = lr / (1 - beta1 ** t)
+                fb[gi] = math.sqrt(1 - beta2 ** t)
+            gidx = self._gidx
+            if gidx is None or gidx.shape[0] != n:
+                gidx = self._gidx = np.asarray([e[2] for e in entries], dtype=np.int64)
+            step_size, bc2 = fs[gidx], fb[gidx]
+            for e in entries:
+                e[1]["step"] = t
+        else:
+            memo, step_size, bc2 = {}, [], []
+            for p, st, gi, pptr, gstride in entries:
+                st["step"] = t = st["step"] + 1
+                f = memo.get((gi, t))
+                if f is None:
+                    beta1, beta2 = hyper[gi][0], hyper[gi][1]
+                    f = memo[(gi, t)] = (lrs[gi] / (1 - beta1 ** t), math.sqrt(1 - beta2 ** t))
+                step_size.append(f[0])
+                bc2.append(f[1])
         if n:
             # the slot table is a dense array of 12 eight-byte words per tensor: write the three per-step columns at once
-            col_u64[:n, 1] = gptr
+            if gptr is not None:
+                col_u64[:n, 1] = gptr
             col_f64[:n, 9] = step_size
             col_f64[:n, 10] = bc2
             hip.adam_step(slots, n)
-            torch.autograd.graph.increment_version([e[0] for e in entries])
+            torch.autograd.graph.increment_version(self._touched if self._touched is not None and len(self._touched) == n
+                                                   else [e[0] for e in entries])
         return True
 
     def _step_checked(self):
+        self._last_grads = None
         n_params = sum(len(g["params"]) for g in self.param_groups)
         if self._slots is None or len(self._slots) < n_params:
             self._slots = (hip.AdamSlot * max(n_params, 1))()
@@ -126,16 +163,19 @@ class FusedAdam(torch.optim.Optimizer):
             assert words == 12
             self._plan = (slots, entries, skipped, hyper, np.frombuffer(slots, dtype=np.uint64).reshape(-1, words),
                           np.frombuffer(slots, dtype=np.float64).reshape(-1, words))
+            self._gidx, self._touched = None, list(touched)
         else:
             self._plan = None
         return None
 
     def add_param_group(self, group):
         self._plan = None
+        self._last_grads = None
         return super().add_param_group(group)
 
     def load_state_dict(self, state_dict):
         self._plan = None
+        self._last_grads = None
         return super().load_state_dict(state_dict)
 
 
