@@ -45,8 +45,7 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
         ps = self._head_params()
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if self._stacked is None or self._stacked[0] != key:
-            self._stacked = (key, (torch.cat([p.detach() for p in ps[0::2]], 0).contiguous(),
-                                   torch.cat([p.detach() for p in ps[1::2]], 0).contiguous()))
+            self._stacked = (key, self._restack(ps))
         W, b = self._stacked[1]
         holder, token = None, None
         if torch.is_grad_enabled() and any(p.requires_grad for p in ps):
@@ -61,6 +60,29 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
             self._memo["head_pass"] = (hp, W, b, holder, token)
         return hp, W, b, holder, token
 
+    def _restack(self, ps):
+        """the four Linear layers stacked as W [11,24], b [11]: persistent buffers refreshed with ONE copy launch
+        (nmf_multi_copy) per parameter update instead of two torch.cat"""
+        from .. import hip
+        st = getattr(self, "_stack_state", None)
+        ptrs = tuple(p.data_ptr() for p in ps)
+        if ps[0].is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+            if st is None or st[0] != ptrs:
+                W = torch.empty((sum(p.shape[0] for p in ps[0::2]), ps[0].shape[1]), dtype=torch.float32, device=ps[0].device)
+                b = torch.empty((W.shape[0],), dtype=torch.float32, device=ps[0].device)
+                slots = (hip.CopySlot * len(ps))()
+                ow = ob = 0
+                for i in range(0, len(ps), 2):
+                    w_, b_ = ps[i], ps[i + 1]
+                    slots[i] = hip.CopySlot(w_.data_ptr(), W.data_ptr() + 4 * ow, w_.numel(), 0, 0)
+                    slots[i + 1] = hip.CopySlot(b_.data_ptr(), b.data_ptr() + 4 * ob, b_.numel(), 0, 0)
+                    ow += w_.numel()
+                    ob += b_.numel()
+                st = self._stack_state = (ptrs, W, b, slots)
+            hip.multi_copy(st[3], len(ps))
+            return st[1], st[2]
+        return (torch.cat([p.detach() for p in ps[0::2]], 0).contiguous(), torch.cat([p.detach() for p in ps[1::2]], 0).contiguous())
+
     def heads(self, features):
         """[M,11] = (albedo 3 | tint 3 | f0 3 | roughness 2) with the activations applied (nmf_heads_fwd)."""
         if features.shape[0] == 0:
@@ -70,8 +92,7 @@ class RandHydraMLPDiffuse(PassMixin, torch.nn.Module):
         ps = self._head_params()
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if self._stacked is None or self._stacked[0] != key:      # the four Linear layers stacked, once per update
-            self._stacked = (key, (torch.cat([p.detach() for p in ps[0::2]], 0).contiguous(),
-                                   torch.cat([p.detach() for p in ps[1::2]], 0).contiguous()))
+            self._stacked = (key, self._restack(ps))
         return material_heads(features, hp, ps, owner=self, stacked=self._stacked[1])
 
     def forward(self, pts, viewdirs, features, std=0, **kwargs):

@@ -29,6 +29,14 @@ class FusedAdam(torch.optim.Optimizer):
         if not self._step_planned():
             self._step_checked()
 
+    def step_unhooked(self):
+        """The same update without torch.optim.Optimizer's per-call wrapper around `step` (profiler record + the pre / post
+        hook dispatch: ~50 us on a path where the host is the critical resource).  For callers that registered no optimizer
+        hooks -- the Trainer; the kernels touch raw pointers, so no grad mode is involved."""
+        if not self._step_planned():
+            with torch.no_grad():
+                self._step_checked()
+
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad without its per-call profiler / hook plumbing (50 us per step for 31 tensors)"""
         if not set_to_none:

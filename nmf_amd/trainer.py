@@ -303,7 +303,7 @@ class Trainer:
         comm_bytes = self.reduce()
         if p.get("clip_grad") is not None:                                                       # train.py:744-745
             torch.nn.utils.clip_grad_norm_([q for q in nerf.parameters() if q.grad is not None], p["clip_grad"])
-        self.optimizer.step()
+        (getattr(self.optimizer, "step_unhooked", None) or self.optimizer.step)()
         self.scheduler.step()
         self.ori_lambda *= self.ori_decay                                                        # train.py:748-749
         self.pred_lambda *= self.pred_decay
