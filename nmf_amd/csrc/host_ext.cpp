@@ -461,6 +461,115 @@ std::tuple<std::vector<Tensor>, std::vector<Tensor>> vm_unpack_density_grad(int6
     return {gp, gl};
 }
 
+// ---- round 2: the remaining per-step wrappers of the training pass (the host side of a step is on the critical path) ----
+// (pointer, row pitch in floats) of a [n,width] / [n] fp32 tensor whose rows are dense but may be a column slice (hip._rows)
+std::pair<const float*, int> rows_of(const OT& t, int width, std::vector<Tensor>& keep) {
+    if (!t.has_value()) return {nullptr, width};
+    Tensor x = *t;
+    if (x.scalar_type() != at::kFloat || !x.is_cuda()) fail("expected a float32 device tensor");
+    const bool ok = (x.dim() == 2 && x.size(1) == width && x.stride(1) == 1) || (x.dim() == 1 && width == 1);
+    if (!ok || x.stride(0) < width) {
+        x = x.contiguous();
+        keep.push_back(x);
+    }
+    return {static_cast<const float*>(x.data_ptr()), (int)(x.size(0) > 1 ? x.stride(0) : width)};
+}
+
+std::tuple<Tensor, Tensor, Tensor> vm_query_rows(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& dpk,
+                                                 const std::vector<Tensor>& dlk, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    const int64_t M = xyzt.size(0);
+    if (dpk.size() != 3 || dlk.size() != 3) fail("vm_query_rows: three planes / lines expected");
+    const bool bf16 = dpk[0].scalar_type() == at::kBFloat16;
+    const void *a[3], *b[3];
+    for (int i = 0; i < 3; ++i) {
+        if (dpk[i].scalar_type() != dpk[0].scalar_type() || dlk[i].scalar_type() != dpk[0].scalar_type())
+            fail("vm_query_rows: mixed table dtypes");
+        a[i] = vptr(dpk[i]);
+        b[i] = vptr(dlk[i]);
+    }
+    Tensor sf = fe(xyzt, {M}), gr = fe(xyzt, {M, 3}), nr = fe(xyzt, {M, 3});
+    check(nmf_vm_query_rows(p, f32(xyzt), M, a, b, bf16 ? 1 : 0, out(sf), nullptr, out(gr), out(nr), st(stream)),
+          "nmf_vm_query_rows");
+    return {sf, gr, nr};
+}
+
+Tensor sqerr_fwd(const Tensor& pred, const Tensor& gt, int64_t stream) {
+    Tensor o = at::zeros({}, pred.options().dtype(at::kFloat));
+    if (pred.numel()) check(nmf_sqerr_fwd(f32(pred), f32(gt), pred.numel(), out(o), st(stream)), "nmf_sqerr_fwd");
+    return o;
+}
+
+Tensor sqerr_bwd(const Tensor& pred, const Tensor& gt, const Tensor& d_out, int64_t stream) {
+    Tensor d = at::empty_like(pred);
+    if (pred.numel()) check(nmf_sqerr_bwd(f32(pred), f32(gt), pred.numel(), f32(d_out), out(d), st(stream)), "nmf_sqerr_bwd");
+    return d;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> shade_mix_bwd_view(const Tensor& V, const Tensor& f0, const Tensor& diff,
+                                                                      const Tensor& cnt, const Tensor& row_of_ray,
+                                                                      const Tensor& L, const Tensor& inc, const Tensor& brdf,
+                                                                      const Tensor& d_rows, int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor d_inc = fe(V, {R, 3}), d_brdf = fe(V, {R, 3}), dL = fe(V, {R, 3}), d_fd = fe(V, {R, 6}), dV = fe(V, {R, 3});
+    check(nmf_shade_mix_bwd_view(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf),
+                                 f32(d_rows), out(d_inc), out(d_brdf), out(dL), out(d_fd), out(dV), st(stream)),
+          "nmf_shade_mix_bwd_view");
+    return {d_inc, d_brdf, dL, d_fd, dV};
+}
+
+Tensor ggx_rays_bwd_view(const Tensor& V, const Tensor& N, const Tensor& r, const Tensor& off, const Tensor& sobol,
+                         const Tensor& row_of_ray, const Tensor& j_of_ray, const Tensor& dL, const OT& d_rays,
+                         int64_t stream) {
+    const int64_t R = row_of_ray.size(0);
+    Tensor d = fe(V, {R, 7});
+    check(nmf_ggx_rays_bwd_view(f32(V), f32(N), f32(r), f32(off), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
+                                static_cast<const float*>(vptr(dL)), static_cast<const float*>(vptr(d_rays)), out(d),
+                                st(stream)),
+          "nmf_ggx_rays_bwd_view");
+    return d;
+}
+
+void view_adjoint_to_rays(const Tensor& ray_id, const Tensor& bidx, const Tensor& dv_a, const OT& dv_b, Tensor d_rays,
+                          int64_t stream) {
+    std::vector<Tensor> keep;
+    const auto a = rows_of(dv_a, 3, keep), b = rows_of(dv_b, 3, keep);
+    check(nmf_view_adjoint_to_rays(i32(ray_id), i32(bidx), a.first, a.second, b.first, b.second, bidx.size(0),
+                                   ptr<float>(d_rays, at::kFloat), st(stream)),
+          "nmf_view_adjoint_to_rays");
+}
+
+Tensor select_total(const Tensor& weights, const Tensor& u, double extra, Tensor ws, int64_t stream) {
+    Tensor total = at::empty({}, weights.options().dtype(at::kFloat));
+    check(nmf_select_total(f32(weights), f32(u), weights.size(0), extra, ptr<double>(ws, at::kDouble), out(total),
+                           st(stream)),
+          "nmf_select_total");
+    return total;
+}
+
+std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& normals, const Tensor& heads, const Tensor& ray_id,
+                                                   const Tensor& rays, const Tensor& conv, double min_rough, bool detach_n,
+                                                   const OT& dN, const OT& dr1, const OT& df0, const OT& ddiff, const OT& dfeat,
+                                                   const OT& bidx, int64_t row_inputs, int64_t stream) {
+    const int64_t M = inv.has_value() ? inv->size(0) : ray_id.size(0);
+    const int64_t Mb = bidx.has_value() ? bidx->size(0) : 0;
+    const int64_t n_out = row_inputs ? Mb : M;
+    Tensor d_normals = fe(normals, {row_inputs == 2 ? Mb : M, 3}), d_heads = fe(normals, {n_out, 11});
+    Tensor d_app = fe(normals, {n_out, 24});
+    if (M) {
+        std::vector<Tensor> keep;
+        const auto a = rows_of(dN, 3, keep), b = rows_of(dr1, 1, keep), c = rows_of(df0, 3, keep), d = rows_of(ddiff, 3, keep);
+        const int32_t strides[4] = {a.second, b.second, c.second, d.second};
+        check(nmf_bounce_prep_bwd(static_cast<const int32_t*>(vptr(inv)), M, static_cast<const int32_t*>(vptr(bidx)), Mb,
+                                  f32(normals), heads.size(0) ? f32(heads) : nullptr, i32(ray_id), f32(rays), f32(conv),
+                                  (float)min_rough, detach_n ? 1 : 0, (int32_t)row_inputs, a.first, b.first, c.first, d.first,
+                                  strides, static_cast<const float*>(vptr(dfeat)), out(d_normals), out(d_heads), out(d_app),
+                                  st(stream)),
+              "nmf_bounce_prep_bwd");
+    }
+    return {d_normals, d_heads, d_app};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_nmf_host, m) {
@@ -496,4 +605,12 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("ray_compose_bwd", &ray_compose_bwd);
     m.def("vm_query_bwd_segments", &vm_query_bwd_segments);
     m.def("vm_unpack_density_grad", &vm_unpack_density_grad);
+    m.def("vm_query_rows", &vm_query_rows);
+    m.def("sqerr_fwd", &sqerr_fwd);
+    m.def("sqerr_bwd", &sqerr_bwd);
+    m.def("shade_mix_bwd_view", &shade_mix_bwd_view);
+    m.def("ggx_rays_bwd_view", &ggx_rays_bwd_view);
+    m.def("view_adjoint_to_rays", &view_adjoint_to_rays);
+    m.def("select_total", &select_total);
+    m.def("bounce_prep_bwd", &bounce_prep_bwd);
 }

@@ -1064,6 +1064,36 @@ def _install_host_ext():
         return fx.vm_query_bwd_segments(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
                                         g_app_lines, g_basis, _stream())
 
+    def vm_query_rows(p, xyzt, dpk, dlk):
+        return fx.vm_query_rows(addr(p), xyzt, list(dpk), list(dlk), _stream())
+
+    def sqerr_fwd(pred, gt):
+        return fx.sqerr_fwd(pred, gt, _stream())
+
+    def sqerr_bwd(pred, gt, d_out):
+        return fx.sqerr_bwd(pred, gt, d_out, _stream())
+
+    def shade_mix_bwd_view(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
+        return fx.shade_mix_bwd_view(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows, _stream())
+
+    def ggx_rays_bwd_view(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
+        return fx.ggx_rays_bwd_view(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays, _stream())
+
+    def view_adjoint_to_rays(ray_id, bidx, dv_a, dv_b, d_rays):
+        return fx.view_adjoint_to_rays(ray_id, bidx, dv_a, dv_b, d_rays, _stream())
+
+    def select_total(weights, u, extra):
+        dev = weights.device
+        ws = _select_ws.get(dev)
+        if ws is None:
+            ws = _select_ws[dev] = torch.zeros(3, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+        return fx.select_total(weights, u, float(extra), ws, _stream())
+
+    def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat,
+                        bidx=None, row_inputs=False):
+        return fx.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, float(min_rough), bool(detach_n), dN, dr1, df0, ddiff,
+                                  dfeat, bidx, int(row_inputs), _stream())
+
     py_unpack = g["vm_unpack_density_grad"]
 
     def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
