@@ -570,6 +570,86 @@ std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& 
     return {d_normals, d_heads, d_app};
 }
 
+// slot tables are ctypes arrays owned by the Python side: passed by address
+void adam_step(int64_t slots_addr, int64_t n, int64_t stream) {
+    check(nmf_adam_step(reinterpret_cast<const nmf_adam_slot*>(slots_addr), (int32_t)n, st(stream)), "nmf_adam_step");
+}
+void multi_copy(int64_t slots_addr, int64_t n, int64_t stream) {
+    check(nmf_multi_copy(reinterpret_cast<const nmf_copy_slot*>(slots_addr), (int32_t)n, st(stream)), "nmf_multi_copy");
+}
+
+const float* dense_f32(const Tensor& t) {       // hip._dense_f32: contiguous or channels-last storage
+    if (t.scalar_type() != at::kFloat || !t.is_cuda()) fail("expected a float32 device tensor");
+    if (!(t.is_contiguous() || t.is_contiguous(at::MemoryFormat::ChannelsLast))) fail("tensor storage must be dense");
+    return static_cast<const float*>(t.data_ptr());
+}
+
+std::vector<Tensor> loss_mix_bwd(const std::vector<std::vector<int64_t>>& shapes, const std::vector<double>& weights,
+                                 double scale, const Tensor& d_out, int64_t stream) {
+    const size_t n = shapes.size();
+    if (weights.size() != n || n > 16) fail("loss_mix_bwd: shapes / weights");
+    std::vector<Tensor> grads;
+    int64_t numel[16];
+    float w[16];
+    float* g[16];
+    for (size_t i = 0; i < n; ++i) {
+        grads.push_back(at::empty(shapes[i], d_out.options().dtype(at::kFloat)));
+        numel[i] = grads[i].numel();
+        w[i] = (float)weights[i];
+        g[i] = out(grads[i]);
+    }
+    check(nmf_loss_mix_bwd(numel, w, (int32_t)n, (float)scale, f32(d_out), g, st(stream)), "nmf_loss_mix_bwd");
+    return grads;
+}
+
+void l1_mean_bwd_into(const std::vector<Tensor>& tensors, const Tensor& d_out, std::vector<Tensor> grads, int64_t stream) {
+    const size_t n = tensors.size();
+    if (grads.size() != n || n > 32) fail("l1_mean_bwd: tensors / gradients");
+    const float* x[32];
+    float* g[32];
+    int64_t numel[32];
+    for (size_t i = 0; i < n; ++i) {
+        if (grads[i].numel() != tensors[i].numel()) fail("l1_mean_bwd: gradient / tensor size mismatch");
+        x[i] = dense_f32(tensors[i]);
+        g[i] = const_cast<float*>(dense_f32(grads[i]));
+        numel[i] = tensors[i].numel();
+    }
+    check(nmf_l1_mean_bwd(x, numel, (int32_t)n, f32(d_out), g, 1, st(stream)), "nmf_l1_mean_bwd");
+}
+
+void sat_build_bwd_into(Tensor d_sat, const Tensor& bg, const Tensor& act, const OT& d_pole, double brightness, double mul,
+                        const OT& sc, Tensor d_bg, int64_t stream) {
+    const int64_t H = bg.size(-2), W = bg.size(-1);
+    check(nmf_sat_build_bwd(ptr<float>(d_sat, at::kFloat), f32(bg), f32(act), (int32_t)H, (int32_t)W, (float)brightness,
+                            (float)mul, static_cast<const float*>(vptr(sc)), static_cast<const float*>(vptr(d_pole)),
+                            ptr<float>(d_bg, at::kFloat), st(stream)),
+          "nmf_sat_build_bwd");
+}
+
+void sat_build_into(const Tensor& bg, double brightness, double mul, const OT& sc, Tensor act, Tensor sat, const OT& pole,
+                    const OT& sat_i4, int64_t stream) {
+    const int64_t H = bg.size(-2), W = bg.size(-1);
+    check(nmf_sat_build(f32(bg), (int32_t)H, (int32_t)W, (float)brightness, (float)mul, static_cast<const float*>(vptr(sc)),
+                        ptr<float>(act, at::kFloat), ptr<float>(sat, at::kFloat), static_cast<float*>(vptr(pole)),
+                        static_cast<float*>(vptr(sat_i4)), st(stream)),
+          "nmf_sat_build");
+}
+
+void sh_project_into(const Tensor& vals, const Tensor& wq, const Tensor& sh_A, Tensor coeffs, Tensor conv, int64_t stream) {
+    check(nmf_sh_project(f32(vals), f32(wq), wq.size(0), (int32_t)wq.size(1), f32(sh_A), ptr<float>(coeffs, at::kFloat),
+                         ptr<float>(conv, at::kFloat), st(stream)),
+          "nmf_sh_project");
+}
+
+void vm_pack_density_into(int64_t p_addr, const std::vector<Tensor>& planes, const std::vector<Tensor>& lines,
+                          const std::vector<Tensor>& dpk, const std::vector<Tensor>& dlk, int64_t stream) {
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    P3 a = three(planes), b = three(lines), c = three(dpk), d = three(dlk);
+    float *oc[3], *od[3];
+    for (int i = 0; i < 3; ++i) { oc[i] = const_cast<float*>(c.p[i]); od[i] = const_cast<float*>(d.p[i]); }
+    check(nmf_vm_pack_density(p, a.p, b.p, oc, od, st(stream)), "nmf_vm_pack_density");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_nmf_host, m) {
@@ -605,6 +685,14 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("ray_compose_bwd", &ray_compose_bwd);
     m.def("vm_query_bwd_segments", &vm_query_bwd_segments);
     m.def("vm_unpack_density_grad", &vm_unpack_density_grad);
+    m.def("adam_step", &adam_step);
+    m.def("multi_copy", &multi_copy);
+    m.def("loss_mix_bwd", &loss_mix_bwd);
+    m.def("l1_mean_bwd_into", &l1_mean_bwd_into);
+    m.def("sat_build_bwd_into", &sat_build_bwd_into);
+    m.def("sat_build_into", &sat_build_into);
+    m.def("sh_project_into", &sh_project_into);
+    m.def("vm_pack_density_into", &vm_pack_density_into);
     m.def("vm_query_rows", &vm_query_rows);
     m.def("sqerr_fwd", &sqerr_fwd);
     m.def("sqerr_bwd", &sqerr_bwd);

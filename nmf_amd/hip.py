@@ -1094,6 +1094,49 @@ def _install_host_ext():
         return fx.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, float(min_rough), bool(detach_n), dN, dr1, df0, ddiff,
                                   dfeat, bidx, int(row_inputs), _stream())
 
+    def adam_step(slots, n):
+        return fx.adam_step(C.addressof(slots), int(n), _stream())
+
+    def multi_copy(slots, n):
+        return fx.multi_copy(C.addressof(slots), int(n), _stream())
+
+    def loss_mix_bwd(shapes, weights, scale, d_out):
+        return fx.loss_mix_bwd([list(s_) for s_ in shapes], [float(v) for v in weights], float(scale), d_out, _stream())
+
+    py_l1_bwd, py_sat_bwd, py_sat_build, py_sh, py_pack = (g["l1_mean_bwd"], g["sat_build_bwd"], g["sat_build"], g["sh_project"],
+                                                          g["vm_pack_density"])
+
+    def l1_mean_bwd(tensors, d_out, out=None):
+        if out is None:
+            return py_l1_bwd(tensors, d_out, out)
+        fx.l1_mean_bwd_into(list(tensors), d_out, list(out), _stream())
+        return out
+
+    def sat_build_bwd(d_sat, bg_mat, act, d_pole, brightness=0.0, mul=1.0, sc=None, out=None):
+        if out is None or not bg_mat.is_contiguous():
+            return py_sat_bwd(d_sat, bg_mat, act, d_pole, brightness, mul, sc, out)
+        fx.sat_build_bwd_into(d_sat, bg_mat, act, d_pole, float(brightness), float(mul), sc, out, _stream())
+        return out
+
+    def sat_build(bg_mat, brightness=0.0, mul=1.0, sc=None, out=None, pole=False, interleaved=False):
+        if out is None or not bg_mat.is_contiguous():
+            return py_sat_build(bg_mat, brightness, mul, sc, out, pole, interleaved)
+        fx.sat_build_into(bg_mat, float(brightness), float(mul), sc, out[0], out[1], out[2] if pole else None,
+                          out[-1] if interleaved else None, _stream())
+        return (out[0], out[1]) + ((out[2],) if pole else ()) + ((out[-1],) if interleaved else ())
+
+    def sh_project(vals, wq, sh_A, out=None):
+        if out is None:
+            return py_sh(vals, wq, sh_A, out)
+        fx.sh_project_into(vals, wq, sh_A, out[0], out[1], _stream())
+        return out
+
+    def vm_pack_density(p, planes, lines, out=None):
+        if out is None:
+            return py_pack(p, planes, lines, out)
+        fx.vm_pack_density_into(addr(p), list(planes), list(lines), list(out[0]), list(out[1]), _stream())
+        return out
+
     py_unpack = g["vm_unpack_density_grad"]
 
     def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
@@ -1102,7 +1145,8 @@ def _install_host_ext():
         return fx.vm_unpack_density_grad(addr(p), g_dpk, g_dlk, _stream())
 
     for name, fn in list(locals().items()):
-        if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd", "py_unpack"):
+        if callable(fn) and name in g and name not in ("fx", "addr", "g", "py_sat_lookup_bwd", "py_unpack", "py_l1_bwd", "py_sat_bwd", "py_sat_build", "py_sh",
+                                                             "py_pack"):
             PY_WRAPPERS[name] = g[name]
             fn.__doc__ = g[name].__doc__
             g[name] = fn
