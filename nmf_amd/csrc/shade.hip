@@ -105,6 +105,45 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final(const int32_t* __restri
     if (i == 0) row_off[totals[1]] = totals[0];
 }
 
+// k_idx_top folded into the last pass for up to IDX_CHUNK chunks (1 M samples): every block scans the chunk sums itself
+// (one load per thread), which removes a one-block kernel from the forward's dependent chain.
+__global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __restrict__ counts, int64_t M,
+                                                              const int64_t* __restrict__ chunk_sum, int n_chunks,
+                                                              int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
+                                                              int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
+                                                              int32_t* __restrict__ inv) {
+    __shared__ int64_t ws[17];
+    __shared__ int64_t base_s;
+    const int tid = threadIdx.x;
+    const int64_t cs = tid < n_chunks ? chunk_sum[tid] : 0;
+    int64_t all;
+    const int64_t cincl = block_scan_i64(cs, ws, &all);
+    if (tid == (int)blockIdx.x) base_s = cincl - cs;
+    __syncthreads();
+    const int64_t R = all & (((int64_t)1 << FLAG_SHIFT) - 1), Mb = all >> FLAG_SHIFT;
+    const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + tid;
+    const int32_t c = i < M ? counts[i] : 0;
+    const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
+    int64_t total;
+    const int64_t excl = base_s + block_scan_i64(v, ws, &total) - v;
+    if (i < M) {
+        if (c > 0) {
+            const int64_t row = excl >> FLAG_SHIFT;
+            bidx[row] = (int32_t)i;
+            cnt_rows[row] = c;
+            row_off[row] = excl & (((int64_t)1 << FLAG_SHIFT) - 1);
+            inv[i] = (int32_t)row;
+        } else {
+            inv[i] = -1;
+        }
+    }
+    if (i == 0) {
+        row_off[Mb] = R;
+        totals[0] = R;
+        totals[1] = Mb;
+    }
+}
+
 // ---- bounce prep -------------------------------------------------------------------------------------------------
 constexpr int HEADS = 11;       // albedo 3 | tint 3 | f0 3 | roughness 2 (nmf_heads_fwd)
 constexpr int FEAT = NMF_APP_DIM;
@@ -374,9 +413,14 @@ extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx,
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
     int64_t* chunk = static_cast<int64_t*>(workspace);
     hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk);
-    hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
-    hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
-                       row_off, cnt_rows, inv);
+    if (n_chunks <= IDX_CHUNK) {
+        hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
+                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv);
+    } else {
+        hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
+        hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
+                           row_off, cnt_rows, inv);
+    }
     NMF_CHECK_LAUNCH("nmf_bounce_index");
     return NMF_OK;
 }

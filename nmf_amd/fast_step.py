@@ -343,7 +343,7 @@ class TrainPass:
             if not early_walk:
                 self.dens_segs.append((S.xyzt, t.sf, None, d_sigma, None, None, None))
             if d_normal is not None:
-                self.dens_segs.append((t.xyz_rows, t.sf_rows, t.gr_rows, torch.zeros_like(t.sf_rows), None, d_normal, None))
+                self.dens_segs.append((t.xyz_rows, t.sf_rows, t.gr_rows, _zeros(t.sf_rows), None, d_normal, None))
         else:
             self.dens_segs.append((S.xyzt, t.sf, t.gr, d_sigma, None, d_normal, None))
         if env_fork is not None:
@@ -534,6 +534,15 @@ def _white(dev):
     if k not in _CONST:
         _CONST[k] = torch.ones((1, 3), dtype=torch.float32, device=dev)
     return _CONST[k]
+
+
+def _zeros(like):
+    """a read-only zero tensor of `like`'s shape (a view of one buffer that only grows: no fill per step)"""
+    k = ("zeros", like.device)
+    n = like.numel()
+    if k not in _CONST or _CONST[k].numel() < n:
+        _CONST[k] = torch.zeros(max(n, 1 << 16) * 5 // 4, dtype=torch.float32, device=like.device)
+    return _CONST[k][:n].view(like.shape)
 
 
 def _one(dev):

@@ -920,7 +920,8 @@ def test_fused_adam_matches_torch_adam():
     ob2.load_state_dict(ob.state_dict())             # state_dict is interchangeable with torch.optim.Adam
 
 
-@pytest.mark.parametrize("M,p", [(1, 1.0), (5, 0.0), (1023, 0.3), (1025, 0.5), (300001, 0.07)])
+@pytest.mark.parametrize("M,p", [(1, 1.0), (5, 0.0), (1023, 0.3), (1025, 0.5), (300001, 0.07), (1024 * 1024, 0.2),
+                                 (1024 * 1024 + 1, 0.02)])     # the last: more than 1024 chunks, the three-launch form
 def test_bounce_index_bit_exact(M, p):
     """nmf_bounce_index against the torch bookkeeping of models/microfacet.py:333-350 (nonzero / cumsum)."""
     hip = _hip()
