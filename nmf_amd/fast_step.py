@@ -120,11 +120,18 @@ class TrainPass:
         return hip.sat_lookup_bwd(bgm._lookup_table(), rows, sa, 0.0, d_out, a.d_sat, a.d_pole, a.d_mip, want_dirs=True,
                                   sc=bgm._dev_scalars())
 
-    def _fwd(self, lvl, rays, focal, start_mip, noise, is_train=True):
+    def _fwd(self, lvl, rays, focal, start_mip, noise, is_train=True, filler=None):
+        """filler: work that does not depend on this level's samples; it is queued between the sampler's counting pass and
+        its size read-back so that the device runs it while the host waits for the two numbers (level 0: the per-step table
+        rebuilds, level 1: the BRDF MLP of the level above).  The second read-back of a level (bounce rows) is covered the
+        same way by the env-map rebuild + SH projection (level 0) and the background lookup of the level's rays (level 1)."""
         nerf = self.nerf
         rf, model, smp = nerf.rf, nerf.model, nerf.sampler
-        S = smp.sample_compact(rays, focal, rf=rf, override_near=None if lvl == 0 else self.near1, is_train=is_train,
-                               dynamic_batch_size=(lvl == 0), noise=noise)
+        pending = smp.sample_begin(rays, focal, override_near=None if lvl == 0 else self.near1, is_train=is_train,
+                                   dynamic_batch_size=(lvl == 0), noise=noise)
+        if filler is not None:
+            filler()
+        S = smp.sample_finish(pending)
         B, M = S.b, S.M
         t = _ns(lvl=lvl, S=S, B=B, M=M, n_samples=[M])
         if M == 0:
@@ -145,7 +152,6 @@ class TrainPass:
         noise.skip("randn", (M, 2))
         noise.skip("rand", (5000,))
         noise.skip("rand", (5000,))
-        conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)
         if lvl == 0:
             counts = hip.select_bounces(w, noise.uniform((M,)).contiguous(), 0,
                                         float(model.rays_per_ray if is_train else model.test_rays_per_ray))
@@ -162,7 +168,15 @@ class TrainPass:
             else:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(model.max_brdf_rays[lvl]), 0.5, total)
         bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)
-        R, Mb = (int(v) for v in tot.cpu())
+        rb = hip.Readback.of(tot.device).start(tot)
+        conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)      # first call of a pass: SAT + SH rebuild
+        per_ray_bg = lvl > 0
+        if per_ray_bg:
+            t.rough = start_mip[:B].contiguous()
+            bg = self._env_fwd(S.rays if B == S.rays.shape[0] else S.rays[:B], t.rough)
+        else:
+            bg = self.white
+        R, Mb = rb.get()
         if R == 0:
             raise Unsupported("no bounce rows")
         bidx, row_off, cnt32 = bidx[:Mb], row_off[: Mb + 1], cnt32[:Mb]
@@ -181,7 +195,9 @@ class TrainPass:
                                                            2 if sparse_n else 1)
         sobol = model.brdf_sampler.angs
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
-        brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
+        full_retrace = (lvl < len(model.max_retrace_rays) and min(R, model.max_retrace_rays[lvl]) >= R
+                        and not model.exact_retrace_order)
+        brdf = None if full_retrace else hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
         t.__dict__.update(offsets=offsets, sf=sf, sg=sg, gr=gr, nr=nr, w=w, conv=conv, bidx=bidx, row_off=row_off, cnt32=cnt32,
                           inv=inv, R=R, Mb=Mb, row_of_ray=row_of_ray, j_of_ray=j_of_ray, off=off, xyz_rows=xyz_rows, app=app,
                           heads=heads, V=V, N=N, r1=r1, f0=f0, diff=diff, feat=feat, L=L, hl=hl, dl=dl, mip=mip, brays=brays,
@@ -191,7 +207,11 @@ class TrainPass:
             num_retrace = min(R, model.max_retrace_rays[lvl])
             if num_retrace >= R and not model.exact_retrace_order:
                 noise.skip("rand", (R,))
-                t.child = self._fwd(lvl + 1, brays, focal, mip, noise, is_train)
+
+                def mlp():          # needs nothing of the level below: runs under its sampler's read-back
+                    t.brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
+                t.child = self._fwd(lvl + 1, brays, focal, mip, noise, is_train, filler=mlp)
+                brdf = t.brdf
                 if t.child.M == 0:
                     raise Unsupported("no secondary sample")
                 t.n_samples += t.child.n_samples
@@ -222,14 +242,9 @@ class TrainPass:
             noise.skip("rand", (R,))
             incoming = self._env_fwd(brays, mip)
         # ---- Fresnel mix + per-ray sums, tonemap, background (ShadeCompose)
-        per_ray_bg = lvl > 0
         if per_ray_bg:
-            t.rough = start_mip[:B].contiguous()
             noise.skip("rand", (B,))
             noise.skip("rand", (B,))
-            bg = self._env_fwd(S.rays if B == S.rays.shape[0] else S.rays[:B], t.rough)
-        else:
-            bg = self.white
         contrib = hip.shade_mix_fwd(V, f0, diff, cnt32, row_of_ray, L, incoming, brdf)
         refl = hip.segment_sum(contrib, None, row_off, Mb, lanes=8)
         rgb_map, acc, rgb_lin, ori = hip.ray_compose_fwd(w, refl, inv, nr if lvl == 0 else None, S.rays, offsets, B, bg,
@@ -400,16 +415,19 @@ class TrainPass:
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
         if hasattr(noise, "begin_pass"):
             noise.begin_pass()
-        rf._fwd_tables()
-        bgm._tables()
-        bgm.get_spherical_harmonics(100)
-        hp, hW, hb, _, _ = model.diffuse_module.head_pass()
-        self.heads = (hp, hW, hb)
-        self.mlp_ws, self.mlp_bias, _, _ = model.brdf.mlp_pass()
         self.scale = float(rf.distance_scale)
         self.anoise, self.min_rough, self.detach_n = float(model.anoise), float(model.min_rough), bool(model.detach_N)
         self.near1 = 3 * float(hip.host(nerf.sampler.stepsize))
         self.white = _white(dev)
+
+    def _begin_tables(self):
+        """the per-step rebuilds of the field side (packed tables, stacked heads, MLP weights); the env-map side follows at
+        its first use (_fwd).  Passed to the level-0 _fwd as its filler."""
+        nerf = self.nerf
+        nerf.rf._fwd_tables()
+        hp, hW, hb, _, _ = nerf.model.diffuse_module.head_pass()
+        self.heads = (hp, hW, hb)
+        self.mlp_ws, self.mlp_bias, _, _ = nerf.model.brdf.mlp_pass()
 
     @torch.no_grad()
     def render_chunk(self, rays, focal, noise):
@@ -424,7 +442,7 @@ class TrainPass:
             m.begin_pass()
         try:
             self._begin(rays.device, noise)
-            t = self._fwd(0, rays, focal, None, noise, is_train=False)
+            t = self._fwd(0, rays, focal, None, noise, is_train=False, filler=self._begin_tables)
             if t.M == 0:
                 raise Unsupported("no sample")
             return t.rgb_map, t.acc, t.B, t.n_samples
@@ -449,7 +467,7 @@ class TrainPass:
         try:
             self._begin(dev, noise)
             self.dens_segs, self.app_segs, self._walk_forks = [], [], []
-            t = self._fwd(0, rays, focal, None, noise)
+            t = self._fwd(0, rays, focal, None, noise, filler=self._begin_tables)
             if t.M == 0:
                 return dict(loss=None, kept=t.B, n_samples=[0])
             a = self._accumulators(dev)

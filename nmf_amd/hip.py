@@ -181,6 +181,33 @@ def host(t):
     return v[1]
 
 
+class Readback:
+    """A few int64 sizes from the device to the host, split into start() and get() so that work queued in between runs
+    while the numbers travel.  Pinned staging buffers from a small ring per device (at most two are ever in flight)."""
+    _ring = {}
+
+    def __init__(self):
+        self.pin = torch.empty(4, dtype=torch.int64).pin_memory()
+        self.ev = torch.cuda.Event()
+        self.n = 0
+
+    @classmethod
+    def of(cls, dev):
+        r = cls._ring.setdefault(str(dev), [[cls() for _ in range(4)], 0])
+        r[1] = (r[1] + 1) & 3
+        return r[0][r[1]]
+
+    def start(self, t):
+        self.n = t.numel()
+        self.pin[: self.n].copy_(t, non_blocking=True)
+        self.ev.record()
+        return self
+
+    def get(self):
+        self.ev.synchronize()
+        return self.pin[: self.n].tolist()
+
+
 # ---- sampler ----------------------------------------------------------------------------------
 def march_params(aabb, alpha_inv, stepsize, near, far, focal, n_steps, grid, is_train, seed=0, offset=0, occ_box=None):
     """occ_box: optional ((x0,y0,z0), (x1,y1,z1)) world box outside of which the alpha mask cannot keep a step"""

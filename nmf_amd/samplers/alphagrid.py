@@ -161,6 +161,13 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
     @torch.no_grad()
     def sample_compact(self, rays_chunk, focal, rf=None, override_near=None, is_train=False, dynamic_batch_size=True,
                        noise=None, **_):
+        return self.sample_finish(self.sample_begin(rays_chunk, focal, override_near, is_train, dynamic_batch_size, noise))
+
+    def sample_begin(self, rays_chunk, focal, override_near=None, is_train=False, dynamic_batch_size=True, noise=None):
+        """First half of sample_compact: the counting pass, the budget scan and the START of the size read-back (into pinned
+        memory, behind an event).  Whatever the caller queues between this and sample_finish() runs while the two sizes
+        travel to the host -- the sampler needs nothing of the field, so the per-step table rebuilds (level 0) or the BRDF
+        MLP of the level above (level 1) go there instead of the device idling through the round trip."""
         dev = rays_chunk.device
         B = rays_chunk.shape[0]
         N = int(self.nSamples)
@@ -193,7 +200,13 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
             valid, counts = words.contiguous(), fv.sum(dim=1).int().contiguous()
         budget = self.max_samples if (self.max_samples > 0 and is_train and dynamic_batch_size) else -1
         offsets, wv, totals = hip.march_scan(counts, budget)
-        M, b = (int(v) for v in totals.cpu())            # the one host sync of the sampler
+        rb = hip.Readback.of(dev)
+        rb.start(totals)
+        return (rb, p, rays, jitter, valid, offsets, wv, N)
+
+    def sample_finish(self, pending):
+        rb, p, rays, jitter, valid, offsets, wv, N = pending
+        M, b = rb.get()                                  # the one host sync of the sampler
         xyzt, ray_id, step_id, z, dist = hip.march_fill(p, rays, b, M, jitter, valid, offsets)
         return Samples(xyzt, ray_id, step_id, z, dist, offsets, wv.view(torch.bool), M, b, N, p, rays, jitter, valid)   # 0 / 1 bytes: no conversion launch
 

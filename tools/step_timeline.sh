@@ -25,7 +25,7 @@ for r in rows[lo:hi]:
     g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
     w = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)))
     print(f"{(s - t0) / 1e3:9.1f} {gap:7.1f} {(e - s) / 1e3:8.1f} {g:9d} {w:5d} {r.get('LDS_Block_Size', ''):>6s} {r.get('VGPR_Count', ''):>5s} "
-          f"{r.get('Accum_VGPR_Count', ''):>5s} {r.get('SGPR_Count', ''):>5s} {r.get('Scratch_Size', ''):>3s}  {n}")
+          f"{r.get('Accum_VGPR_Count', ''):>5s} {r.get('SGPR_Count', ''):>5s} {r.get('Scratch_Size', ''):>3s} q{r.get('Queue_Id', '')} {n}")
 print(f"# span {(prev_end - t0) / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, {hi - lo} launches")
 PY
 tail -n 3 "$ROOT/gpurun_out/step_timeline.txt"
