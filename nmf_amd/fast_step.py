@@ -37,6 +37,22 @@ def _ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
+class _on:
+    """`with _on((main, side)):` -- the side stream is torch's current stream inside the block.  set_stream on entry and exit
+    (0.4 us each) instead of torch.cuda.stream()'s context manager (6 us): four of these sit on the host-critical backward."""
+    __slots__ = ("fork",)
+
+    def __init__(self, fork):
+        self.fork = fork
+
+    def __enter__(self):
+        torch.cuda.set_stream(self.fork[1])
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.fork[0])
+        return False
+
+
 class TrainPass:
     def __init__(self, nerf):
         self.nerf = nerf
@@ -57,6 +73,7 @@ class TrainPass:
         self.sparse_normals = os.environ.get("NMF_SPARSE_NORMALS", "1") != "0"
         self._early_env = None
         self._side = {}
+        self._main = None
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -271,7 +288,7 @@ class TrainPass:
             wfork = self._fork(("walk", lvl))
             if wfork is not None:
                 p_, dpk, dlk, apl, ali, basis = self.nerf.rf._tables()
-                with torch.cuda.stream(wfork[1]):
+                with _on(wfork):
                     hip.vm_query_bwd_segments(p_, [(S.xyzt, t.sf, None, d_sigma, None, None, None)], dpk, dlk, apl, ali, basis,
                                               a.g_dpk, a.g_dlk, a.g_apl, a.g_ali, None)
                 self._walk_forks.append((wfork, d_sigma))
@@ -283,7 +300,7 @@ class TrainPass:
             # atomic-bound scatter: next to the rest of this level's backward (when it is long enough to be worth a fork)
             env_fork = self._fork(("env", lvl)) if t.B >= MLP_SIDE_MIN_RAYS else None
             if env_fork is not None:
-                with torch.cuda.stream(env_fork[1]):
+                with _on(env_fork):
                     d_rays = self._env_bwd(env_rows, t.rough, d_bg)
             else:
                 d_rays = self._env_bwd(env_rows, t.rough, d_bg)
@@ -299,7 +316,7 @@ class TrainPass:
         # ---- BRDF MLP backward: on a side stream, next to the adjoint of the bounce rays below
         fork = self._fork(("mlp", lvl)) if (t.child is not None and t.child.B >= MLP_SIDE_MIN_RAYS) else None
         if fork is not None:
-            with torch.cuda.stream(fork[1]):
+            with _on(fork):
                 d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp,
                                            max_workgroups=MLP_SIDE_WGS)
         # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
@@ -323,7 +340,7 @@ class TrainPass:
                 act, _sat, _pole = bgm._tables()
                 if a.d_bg is None:
                     a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
-                with torch.cuda.stream(sfork[1]):
+                with _on(sfork):
                     d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars(), out=a.d_bg)
                 self._early_env = (sfork, d_bg)
         # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
@@ -376,7 +393,7 @@ class TrainPass:
             return None
         if key not in self._side:
             self._side[key] = torch.cuda.Stream()
-        main, side = torch.cuda.current_stream(), self._side[key]
+        main, side = self._main, self._side[key]
         side.wait_stream(main)
         return main, side
 
@@ -466,6 +483,7 @@ class TrainPass:
             m.begin_pass()
         try:
             self._begin(dev, noise)
+            self._main = torch.cuda.current_stream() if self.overlap else None
             self.dens_segs, self.app_segs, self._walk_forks = [], [], []
             t = self._fwd(0, rays, focal, None, noise, filler=self._begin_tables)
             if t.M == 0:
