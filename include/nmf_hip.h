@@ -344,9 +344,12 @@ int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const
 /* models/microfacet.py:333-350.  counts [M] = secondary rays per sample (nmf_select_bounces).  Outputs:
  * bidx [>=Mb] samples with counts > 0 in order ("rows"), row_off [>=Mb+1] exclusive scan of their counts
  * (row_off[Mb] = R), cnt_rows [>=Mb] their counts, inv [M] row of each sample or -1, totals = {R, Mb}.
- * bidx / row_off / cnt_rows are sized by the caller for the worst case (M, M+1, M). */
+ * bidx / row_off / cnt_rows are sized by the caller for the worst case (M, M+1, M).
+ * xyzt_rows (optional, [>=Mb][4], needs xyzt [M][4]): xyzt_rows[row] = xyzt[bidx[row]], the sample positions of the rows
+ * (microfacet.py:352: `xyzs[bounce_mask]`), written by the same pass instead of a gather launch behind the size read-back. */
 int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off, int32_t* cnt_rows,
-                     int32_t* inv, int64_t* totals, void* workspace, int64_t workspace_bytes, void* stream);
+                     int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 int64_t nmf_bounce_index_workspace_bytes(int64_t M);
 /* Per bounce row (models/microfacet.py:297,304-316,352-361): V = -ray direction, N = normal facing V
  * (n * sign(V.n)), r1 = max(roughness, min_rough), f0, diffuse = albedo * E(n) with E the 9-term SH irradiance

@@ -241,18 +241,22 @@ Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, cons
     return contrib;
 }
 
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> bounce_index(const Tensor& counts, int64_t stream) {
+py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream) {
     const int64_t M = counts.size(0), M1 = M > 0 ? M : 1;
     Tensor bidx = ie(counts, {M1}, at::kInt), row_off = ie(counts, {M + 1}, at::kLong), inv = ie(counts, {M1}, at::kInt);
     Tensor cnt_rows = ie(counts, {M1}, at::kInt), totals = ie(counts, {2}, at::kLong);
     const int64_t nbytes = nmf_bounce_index_workspace_bytes(M);
     Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
+    Tensor rows;
+    if (xyzt.has_value()) rows = at::empty({M1, 4}, counts.options().dtype(at::kFloat));
     check(nmf_bounce_index(M ? i32(counts) : nullptr, M, static_cast<int32_t*>(bidx.data_ptr()),
                            static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
-                           static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()), ws.data_ptr(), nbytes,
-                           st(stream)),
+                           static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()),
+                           (xyzt.has_value() && M) ? f32(*xyzt) : nullptr, xyzt.has_value() ? out(rows) : nullptr, ws.data_ptr(),
+                           nbytes, st(stream)),
           "nmf_bounce_index");
-    return {bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals};
+    if (xyzt.has_value()) return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals, rows);
+    return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals);
 }
 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_fwd(

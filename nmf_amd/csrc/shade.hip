@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final(const int32_t* __restri
                                                         const int64_t* __restrict__ chunk_base,
                                                         const int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
                                                         int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
-                                                        int32_t* __restrict__ inv) {
+                                                        int32_t* __restrict__ inv, const float4* __restrict__ xyzt,
+                                                        float4* __restrict__ xyzt_rows) {
     __shared__ int64_t ws[17];
     const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + threadIdx.x;
     const int32_t c = i < M ? counts[i] : 0;
@@ -98,6 +99,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final(const int32_t* __restri
             cnt_rows[row] = c;
             row_off[row] = excl & (((int64_t)1 << FLAG_SHIFT) - 1);
             inv[i] = (int32_t)row;
+            if (xyzt_rows) xyzt_rows[row] = xyzt[i];
         } else {
             inv[i] = -1;
         }
@@ -111,7 +113,8 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
                                                               const int64_t* __restrict__ chunk_sum, int n_chunks,
                                                               int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
                                                               int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
-                                                              int32_t* __restrict__ inv) {
+                                                              int32_t* __restrict__ inv, const float4* __restrict__ xyzt,
+                                                              float4* __restrict__ xyzt_rows) {
     __shared__ int64_t ws[17];
     __shared__ int64_t base_s;
     const int tid = threadIdx.x;
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
             cnt_rows[row] = c;
             row_off[row] = excl & (((int64_t)1 << FLAG_SHIFT) - 1);
             inv[i] = (int32_t)row;
+            if (xyzt_rows) xyzt_rows[row] = xyzt[i];
         } else {
             inv[i] = -1;
         }
@@ -398,7 +402,8 @@ __global__ void __launch_bounds__(256) k_ray_compose_bwd(
 extern "C" int64_t nmf_bounce_index_workspace_bytes(int64_t M) { return (cdiv(M > 0 ? M : 1, IDX_CHUNK) + 1) * 8; }
 
 extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
-                                int32_t* cnt_rows, int32_t* inv, int64_t* totals, void* workspace, int64_t workspace_bytes, void* stream) {
+                                int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_index: M < 0");
     NMF_REQUIRE(totals && row_off, NMF_EINVAL, "nmf_bounce_index: null");
     hipStream_t st = (hipStream_t)stream;
@@ -408,6 +413,9 @@ extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx,
         return e == hipSuccess ? NMF_OK : nmf_fail((int)e, "nmf_bounce_index: memset");
     }
     NMF_REQUIRE(counts && bidx && cnt_rows && inv && workspace, NMF_EINVAL, "nmf_bounce_index: null");
+    NMF_REQUIRE(!xyzt_rows || xyzt, NMF_EINVAL, "nmf_bounce_index: xyzt_rows needs xyzt");
+    const float4* x4 = reinterpret_cast<const float4*>(xyzt);
+    float4* r4 = reinterpret_cast<float4*>(xyzt_rows);
     const int64_t n_chunks = cdiv(M, IDX_CHUNK);
     NMF_REQUIRE(workspace_bytes >= nmf_bounce_index_workspace_bytes(M), NMF_EINVAL, "nmf_bounce_index: workspace too small");
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
@@ -415,11 +423,11 @@ extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx,
     hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk);
     if (n_chunks <= IDX_CHUNK) {
         hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
-                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv);
+                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4);
     } else {
         hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
         hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
-                           row_off, cnt_rows, inv);
+                           row_off, cnt_rows, inv, x4, r4);
     }
     NMF_CHECK_LAUNCH("nmf_bounce_index");
     return NMF_OK;

@@ -191,7 +191,7 @@ class TrainPass:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(nb), 1.0, total)
             else:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(model.max_brdf_rays[lvl]), 0.5, total)
-        bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)
+        bidx, row_off, cnt32, inv, tot, xyz_rows = hip.bounce_index(counts, S.xyzt)
         rb = hip.Readback.of(tot.device).start(tot)
         conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)      # first call of a pass: SAT + SH rebuild
         per_ray_bg = lvl > 0
@@ -206,7 +206,7 @@ class TrainPass:
         bidx, row_off, cnt32 = bidx[:Mb], row_off[: Mb + 1], cnt32[:Mb]
         row_of_ray, j_of_ray = hip.expand_segments(row_off, Mb, R)
         off = noise.uniform((Mb, 1, 2)).reshape(Mb, 2).contiguous()
-        xyz_rows = torch.index_select(S.xyzt, 0, bidx)
+        xyz_rows = xyz_rows[:Mb]
         feat_noise = noise.rows(deferred, bidx)
         sf_rows = gr_rows = None
         if sparse_n:

@@ -759,11 +759,13 @@ def adam_step(slots, n):
 
 
 # ---- shading glue --------------------------------------------------------------------------------
-def bounce_index(counts):
+def bounce_index(counts, xyzt=None):
     """counts [M] int32 -> (bidx [M] int32, row_off [M+1] int64, cnt_rows [M] int32, inv [M] int32,
-    totals [2] int64 = (R, Mb)); the caller slices bidx[:Mb] / row_off[:Mb+1] / cnt_rows[:Mb] once it has read totals."""
+    totals [2] int64 = (R, Mb)); the caller slices bidx[:Mb] / row_off[:Mb+1] / cnt_rows[:Mb] once it has read totals.
+    With xyzt [M,4]: a sixth output xyzt_rows [M,4] whose first Mb rows are xyzt[bidx]."""
     M = counts.shape[0]
     dev = counts.device
+    rows = torch.empty((max(M, 1), 4), dtype=torch.float32, device=dev) if xyzt is not None else None
     bidx = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     row_off = torch.empty(M + 1, dtype=torch.int64, device=dev)
     inv = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
@@ -772,7 +774,10 @@ def bounce_index(counts):
     nbytes = _lib.nmf_bounce_index_workspace_bytes(C.c_int64(M))
     ws = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     _check(_lib.nmf_bounce_index(_p(counts, torch.int32) if M else C.c_void_p(0), C.c_int64(M), _p(bidx), _p(row_off),
-                                 _p(cnt_rows), _p(inv), _p(totals), _p(ws), C.c_int64(nbytes), _stream()), "nmf_bounce_index")
+                                 _p(cnt_rows), _p(inv), _p(totals), _p(xyzt, torch.float32) if (xyzt is not None and M) else None,
+                                 _p(rows), _p(ws), C.c_int64(nbytes), _stream()), "nmf_bounce_index")
+    if xyzt is not None:
+        return bidx, row_off, cnt_rows, inv[:M], totals, rows
     return bidx, row_off, cnt_rows, inv[:M], totals
 
 
@@ -1044,8 +1049,8 @@ def _install_host_ext():
     def shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf):
         return fx.shade_mix_fwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, _stream())
 
-    def bounce_index(counts):
-        return fx.bounce_index(counts, _stream())
+    def bounce_index(counts, xyzt=None):
+        return fx.bounce_index(counts, xyzt, _stream())
 
     def bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, row_inputs=False):
         return fx.bounce_prep_fwd(bidx, normals, app, heads, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough,

@@ -927,10 +927,13 @@ def test_bounce_index_bit_exact(M, p):
     hip = _hip()
     gen = torch.Generator().manual_seed(M)
     counts = (torch.randint(1, 200, (M,), generator=gen) * (torch.rand(M, generator=gen) < p)).int()
-    bidx, row_off, cnt, inv, tot = hip.bounce_index(counts.to(DEV))
+    xyzt = torch.randn(M, 4, generator=gen)
+    bidx, row_off, cnt, inv, tot, rows = hip.bounce_index(counts.to(DEV), xyzt.to(DEV))
     R, Mb = [int(v) for v in tot.cpu()]
     ref_idx = torch.nonzero(counts > 0).reshape(-1)
     assert Mb == ref_idx.shape[0] and R == int(counts.sum())
+    assert torch.equal(rows[:Mb].cpu(), xyzt[ref_idx])              # the optional gather of the rows' positions
+    assert len(hip.bounce_index(counts.to(DEV))) == 5
     assert torch.equal(bidx[:Mb].cpu().long(), ref_idx)
     assert torch.equal(cnt[:Mb].cpu(), counts[ref_idx])
     ro = torch.zeros(Mb + 1, dtype=torch.int64)
