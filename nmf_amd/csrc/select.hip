@@ -50,7 +50,23 @@ __global__ void __launch_bounds__(256) k_select_total(const float* __restrict__ 
                                                       double extra, double* __restrict__ ws, float* __restrict__ total) {
     double a = 0.0, b = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) { a += (double)w[i]; b += (double)u[i]; }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(u)) & 15) == 0) {
+        // 16-byte runs, two independent partial sums per array: the scalar loop was a 27-deep chain of dependent loads + adds
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* u4 = reinterpret_cast<const float4*>(u);
+        const int64_t n4 = M >> 2;
+        double a1 = 0.0, b1 = 0.0;
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 x = w4[i], y = u4[i];
+            a += (double)x.x + (double)x.y; a1 += (double)x.z + (double)x.w;
+            b += (double)y.x + (double)y.y; b1 += (double)y.z + (double)y.w;
+        }
+        a += a1; b += b1;
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < M; i += stride) { a += (double)w[i]; b += (double)u[i]; }
     for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
     __shared__ double sa[4], sb[4];
     const int wave = threadIdx.x >> 6;

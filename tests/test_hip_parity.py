@@ -1386,6 +1386,9 @@ def test_select_total_and_view_adjoint_scatter():
             got = hip.select_total(w.to(DEV), u.to(DEV), extra)
             ref = (w.double().sum() + 1e-3 * (u.double().sum() + extra)).float().clip(min=1e-3)
             assert got.shape == () and abs(float(got) - float(ref)) <= 1.2e-7 * abs(float(ref)), (M, float(got), float(ref))
+    wd, ud = w.to(DEV)[1:M - 2], u.to(DEV)[3:]                # 4-byte aligned views: the scalar path of the kernel
+    ref = (w[1:M - 2].double().sum() + 1e-3 * (u[3:].double().sum() + extra)).float().clip(min=1e-3)
+    assert abs(float(hip.select_total(wd, ud, extra)) - float(ref)) <= 1.2e-7 * abs(float(ref))
     assert float(hip.select_total(torch.zeros(5, device=DEV), torch.zeros(5, device=DEV), 0.0)) == pytest.approx(1e-3)
     B, Msmp, Mb = 50, 400, 120
     ray_id = torch.sort(torch.randint(0, B, (Msmp,), generator=gen)).values.int()
