@@ -187,17 +187,18 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
         # and copied (filling the ctypes struct field by field costs 10 us per call)
         packed = self.alphaMask._packed() if use_mask else None
         stepsize = float(hip.host(self.stepsize))
-        ck = (near, far, float(focal), N, bool(is_train), stepsize, id(self.aabb), self.aabb._version,
-              id(self.alphaMask) if use_mask else None, packed[0] if use_mask else None)
-        tpl = self._params_cache.get(ck)
-        if tpl is None:
+        ck = (near, far, float(focal), N, bool(is_train), stepsize, use_mask)
+        owner = (self.aabb, self.aabb._version, self.alphaMask if use_mask else None, packed[0] if use_mask else None)
+        hit = self._params_cache.get(ck)
+        ho = hit[0] if hit is not None else None         # the entry holds its tensors: identities cannot be reused
+        if ho is None or ho[0] is not owner[0] or ho[1] != owner[1] or ho[2] is not owner[2] or ho[3] != owner[3]:
             if len(self._params_cache) > 8:
                 self._params_cache.clear()
-            tpl = self._params_cache[ck] = hip.march_params(
+            hit = self._params_cache[ck] = (owner, hip.march_params(
                 self.aabb, hip.host(self.alphaMask.invgrid_size) if use_mask else None, stepsize, near, far, focal, N,
                 [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train, 0, 0,
-                occ_box=packed[3] if use_mask else None)
-        p = hip.MarchParams.from_buffer_copy(tpl)
+                occ_box=packed[3] if use_mask else None))
+        p = hip.MarchParams.from_buffer_copy(hit[1])
         p.seed, p.offset = int(seed), int(off)
         rays = rays_chunk.contiguous()
         valid, counts = hip.march_count(p, rays, jitter, packed[1] if use_mask else None, packed[2] if use_mask else None)
