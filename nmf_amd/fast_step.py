@@ -28,6 +28,9 @@ MLP_SIDE_MIN_RAYS = 100000   # the capped launch runs at about half speed: it pa
                              # level below re-traces this many rays (steady state: all 0.24 M).  With 20 k re-traced rays
                              # under 0.1 M+ MLP rows the main stream ran dry and waited for it (-4 %), and at the deepest level
                              # the 46 k-row launch next to the env adjoint was no faster than the two one after the other
+MLP_SIDE_MIN_ENV_RAYS = 200000   # ... or when this many of the level's own bounce rays go to the env map (partial re-trace)
+MLP_SIDE_WGS_ENV = 256           # workgroups next to that env-map adjoint alone (atomic-bound, needs little of a CU): 128 made
+                                 # the MLP the long pole (0.5 M rays at half the re-trace count: 3.78 ms against 3.39 / 3.51 without fork)
 WALK_SIDE_MIN_SAMPLES = 200000
 MLP_SIDE_WGS = 128      # persistent workgroups of a BRDF-MLP backward that shares the chip (measured: 128 - 192 alike, 64 and
                         # 256+ slower; csrc/brdf_mlp.hip)
@@ -321,11 +324,15 @@ class TrainPass:
                                                         d_refl)
         rows6 = hip.segment_sum_wide(d_fd, 6, t.row_off, t.Mb)
         # ---- BRDF MLP backward: on a side stream, next to the adjoint of the bounce rays below
-        fork = self._fork(("mlp", lvl)) if (t.child is not None and t.child.B >= MLP_SIDE_MIN_RAYS) else None
+        # (or next to the env-map adjoint of this level's own bounce rays when there are many of them: with a partial re-trace
+        # the level below gets the rest of the ray budget, microfacet.py:318-331 -- 0.5 M rays at half the re-trace count)
+        n_env = t.R - (t.idx_re.shape[0] if t.idx_re is not None else (t.R if t.child is not None else 0))
+        below = t.child is not None and t.child.B >= MLP_SIDE_MIN_RAYS
+        fork = self._fork(("mlp", lvl)) if (below or n_env >= MLP_SIDE_MIN_ENV_RAYS) else None
         if fork is not None:
             with _on(fork):
                 d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp,
-                                           max_workgroups=MLP_SIDE_WGS)
+                                           max_workgroups=MLP_SIDE_WGS if below else MLP_SIDE_WGS_ENV)
         # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
         if t.idx_re is None and t.child is not None:
             d_brays = self._bwd(t.child, d_inc, None, None)

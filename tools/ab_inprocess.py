@@ -1,7 +1,7 @@
 """In-process A/B of the training step: ONE trainer, the variant switched every BLOCK steps for ROUNDS rounds, so clock /
 thermal drift and box-to-box differences (4 % between `python bench.py` runs on different boxes) cancel; resolves ~0.5 %.
 
-    python tools/ab_inprocess.py <what> <v0,v1,...> [rounds]
+    python tools/ab_inprocess.py <what> <v0,v1,...> [rounds [max_retrace_rays]]
 
 <what>:
     NAME                 os.environ[NAME] = value            (knobs that are read at call time)
@@ -31,9 +31,12 @@ BLOCK = 40
 def main():
     var, vals = sys.argv[1], sys.argv[2].split(",")
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    retrace = int(sys.argv[4]) if len(sys.argv) > 4 else None      # partial re-trace instead of bench.py's steady state
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     nerf, params = bench.build(dev)
+    if retrace is not None:
+        nerf.model.max_retrace_rays = [retrace]
     tr = Trainer(nerf, params)
     noise = DeviceNoise(dev, seed=1)
     batches, focal = bench.make_batches(nerf, 16, bench.CHUNK, 0, dev, distinct=16)
