@@ -32,8 +32,8 @@ MLP_SIDE_MIN_ENV_RAYS = 200000   # ... or when this many of the level's own boun
 MLP_SIDE_WGS_ENV = 256           # workgroups next to that env-map adjoint alone (atomic-bound, needs little of a CU): 128 made
                                  # the MLP the long pole (0.5 M rays at half the re-trace count: 3.78 ms against 3.39 / 3.51 without fork)
 WALK_SIDE_MIN_SAMPLES = 200000
-MLP_SIDE_WGS = 128      # persistent workgroups of a BRDF-MLP backward that shares the chip (measured: 128 - 192 alike, 64 and
-                        # 256+ slower; csrc/brdf_mlp.hip)
+MLP_SIDE_WGS = 256      # persistent workgroups of a BRDF-MLP backward that shares the chip (in-process A/B at the end of round
+                        # 2: 64 +15 %, 96 +1.5 %, 128 +0.6 %, 192 / 256 best, 384 +4 %, uncapped (512) +8 %; csrc/brdf_mlp.hip)
 
 
 def _ns(**kw):
