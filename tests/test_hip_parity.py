@@ -954,6 +954,32 @@ def test_bounce_index_empty():
     assert tot.cpu().tolist() == [0, 0] and int(row_off[0]) == 0 and inv.shape[0] == 0
 
 
+def test_size_readback_and_split_sampler():
+    """hip.Readback (sizes to the host in two halves, so that work can be queued in between) and the sampler's
+    sample_begin / sample_finish around it: several in flight, and the split sampler == sample_compact."""
+    hip = _hip()
+    rbs = [hip.Readback.of(DEV).start(torch.tensor([i, 10 * i], dtype=torch.int64, device=DEV)) for i in range(3)]
+    filler = torch.ones(1 << 20, device=DEV).cumsum(0)                   # something queued between start and get
+    assert [rb.get() for rb in rbs] == [[0, 0], [1, 10], [2, 20]] and float(filler[-1]) == float(1 << 20)
+    from nmf_amd.samplers.alphagrid import AlphaGridSampler
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]], device=DEV)
+    smp = AlphaGridSampler(aabb, near_far=(2.0, 6.0), max_samples=-1).to(DEV)
+    smp.stepsize, smp.nSamples = torch.tensor(0.02, device=DEV), 200
+    gen = torch.Generator().manual_seed(5)
+    o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(300, 3, generator=gen)
+    d = torch.nn.functional.normalize(-o + 0.3 * torch.randn(300, 3, generator=gen), dim=-1)
+    rays = torch.cat([o, d], dim=-1).to(DEV)
+    a = smp.sample_compact(rays, 1000.0, is_train=False)
+    pend = smp.sample_begin(rays, 1000.0, is_train=False)
+    _ = torch.zeros(1 << 18, device=DEV).sum()                            # the caller's filler
+    b = smp.sample_finish(pend)
+    assert a.M == b.M > 0 and a.b == b.b and torch.equal(a.xyzt, b.xyzt) and torch.equal(a.offsets, b.offsets)
+    p1 = smp.sample_begin(rays, 1000.0, is_train=False)[1]                 # the parameter block comes out of the cache ...
+    smp.stepsize = torch.tensor(0.04, device=DEV)                         # ... until the geometry changes
+    p2 = smp.sample_begin(rays, 1000.0, is_train=False)[1]
+    assert abs(p1.stepsize - 0.02) < 1e-7 and abs(p2.stepsize - 0.04) < 1e-7
+
+
 @pytest.mark.parametrize("M,detach_n,rows_in", [(1, False, False), (4099, False, False), (4099, True, False),
                                                  (4099, False, True), (1, False, True)])
 def test_bounce_prep_vs_torch(M, detach_n, rows_in):
