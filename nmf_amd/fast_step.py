@@ -244,23 +244,25 @@ class TrainPass:
                 t.n_samples += t.child.n_samples
                 incoming = t.child.rgb_map
             else:
-                w_rows = torch.index_select(w, 0, bidx.long())
+                w_rows = torch.index_select(w, 0, bidx)
                 cc = hip.retrace_scores(brdf, V, N, lpdf, w_rows, cnt32, row_of_ray)
                 cc = cc / cc.sum() * num_retrace
                 cc = cc + noise.uniform((R,))
                 order = hip.argsort_f32(cc.contiguous()).long()
                 cut = max(R - num_retrace, 0)
                 t.idx_re, t.idx_no = order[cut:], order[:cut]
-                incoming = torch.zeros((R, 3), device=rays.device)
+                # idx_re and idx_no partition the rays: both index_copy_ together write every row
+                incoming = torch.empty((R, 3), dtype=torch.float32, device=rays.device)
+                sel = torch.index_select
                 if t.idx_re.shape[0] > 0:
-                    t.brays_re, t.mip_re = brays[t.idx_re], mip[t.idx_re]
+                    t.brays_re, t.mip_re = sel(brays, 0, t.idx_re), sel(mip, 0, t.idx_re)
                     t.child = self._fwd(lvl + 1, t.brays_re, focal, t.mip_re, noise, is_train)
                     if t.child.M == 0:
                         raise Unsupported("no secondary sample")
                     t.n_samples += t.child.n_samples
                     incoming.index_copy_(0, t.idx_re, t.child.rgb_map)
                 if t.idx_no.shape[0] > 0:
-                    t.brays_no, t.mip_no = brays[t.idx_no], mip[t.idx_no]
+                    t.brays_no, t.mip_no = sel(brays, 0, t.idx_no), sel(mip, 0, t.idx_no)
                     noise.skip("rand", (t.idx_no.shape[0],))
                     noise.skip("rand", (t.idx_no.shape[0],))
                     incoming.index_copy_(0, t.idx_no, self._env_fwd(t.brays_no, t.mip_no))
@@ -339,11 +341,12 @@ class TrainPass:
         elif t.idx_re is None:
             d_brays = self._env_bwd(t.brays, t.mip, d_inc)
         else:
-            d_brays = torch.zeros_like(t.brays)
+            d_brays = torch.empty_like(t.brays)      # the two index sets partition the rays: every row is written below
+            sel = torch.index_select
             if t.idx_re.shape[0] > 0:
-                d_brays.index_copy_(0, t.idx_re, self._bwd(t.child, d_inc[t.idx_re], None, None))
+                d_brays.index_copy_(0, t.idx_re, self._bwd(t.child, sel(d_inc, 0, t.idx_re), None, None))
             if t.idx_no.shape[0] > 0:
-                d_brays.index_copy_(0, t.idx_no, self._env_bwd(t.brays_no, t.mip_no, d_inc[t.idx_no]))
+                d_brays.index_copy_(0, t.idx_no, self._env_bwd(t.brays_no, t.mip_no, sel(d_inc, 0, t.idx_no)))
         if lvl == 0 and self._last_chunk and a.used_env:
             # every environment adjoint of the optimizer step has been queued (level 0 has no background lookup of its own):
             # the two reverse prefix sums of the env-map table run on a side stream from here, next to the rest of the pass,
