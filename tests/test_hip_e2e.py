@@ -856,12 +856,29 @@ def test_tape_free_evaluation_forward_equals_the_module(monkeypatch):
         assert float(ref["rgb_map"].std()) > 0.05
 
 
-@pytest.mark.parametrize("phase", ["steady", "early", "steady_detachN", "two_chunks"])
+@pytest.mark.parametrize("phase", ["steady", "early", "steady_detachN", "two_chunks", "steady_forks", "early_forks"])
 def test_tape_free_training_pass_equals_autograd_path(phase):
     """nmf_amd/fast_step.py (the training pass as straight-line C-ABI calls, no autograd engine) against the autograd
     operator graph it replaces: same model, same rays, same noise stream -> the same parameter gradients (atomics reorder
     float sums, nothing else may differ), in the steady state (every secondary ray re-traced), in the early phase (argsort +
-    partial re-trace), with detached normals, and accumulated over two chunks of one optimizer step."""
+    partial re-trace), with detached normals, and accumulated over two chunks of one optimizer step.  `*_forks`: the
+    thresholds of the side streams lowered to 1, so that every fork of the backward (BRDF-MLP backward next to the level
+    below / next to the env-map adjoint, env-map adjoint of a level's own rays, value-only walk, env-map table backward) is
+    taken at this size too -- their ordering against the main stream must not change a gradient."""
+    from nmf_amd import fast_step
+    knobs = ("MLP_SIDE_MIN_RAYS", "MLP_SIDE_MIN_ENV_RAYS", "WALK_SIDE_MIN_SAMPLES")
+    saved = {name: getattr(fast_step, name) for name in knobs}
+    try:
+        if phase.endswith("_forks"):
+            for name in knobs:
+                setattr(fast_step, name, 1)
+        _tape_free_vs_autograd(phase)
+    finally:
+        for name, v in saved.items():
+            setattr(fast_step, name, v)
+
+
+def _tape_free_vs_autograd(phase):
     import bench
     from nmf_amd.noise import DeviceNoise
     from nmf_amd.trainer import Trainer
@@ -875,7 +892,7 @@ def test_tape_free_training_pass_equals_autograd_path(phase):
             nerf, params = bench.build(dev)
         finally:
             bench.GRID = grid_saved
-        if phase == "early":
+        if phase.startswith("early"):
             nerf.model.max_retrace_rays = [1500]
         nerf.model.detach_N = phase == "steady_detachN"
         tr = Trainer(nerf, params)
