@@ -103,3 +103,41 @@ def test_own_checkpoints_take_the_weights_only_path_and_code_is_refused(tmp_path
     torch.save({"config": Evil(), "state_dict": {}}, bad)
     with pytest.raises(pickle.UnpicklingError, match="refused"):
         load_checkpoint(bad)
+
+
+_GADGET_RAN = []
+
+
+def _gadget_payload(*a):
+    _GADGET_RAN.append(a)
+    return {}
+
+
+class _InnerEvil:
+    def __reduce__(self):
+        return (_gadget_payload, ("inner",))
+
+
+def test_load_from_bytes_gadget_is_refused(tmp_path):
+    """`torch.storage._load_from_bytes(b)` is `torch.load(BytesIO(b), weights_only=False)` -- a checkpoint that
+    names it smuggles a second, unrestricted pickle through the restricted reader.  It is not on the allowlist any more;
+    nor is anything matched by prefix / suffix (`_rebuild*`, `*Storage`)."""
+    import io
+    from nmf_amd.checkpoint import load_checkpoint
+    inner = io.BytesIO()
+    torch.save(_InnerEvil(), inner)
+
+    class Outer:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    class Wide:                       # a `_rebuild*` name that is not one of the four tensor constructors
+        def __reduce__(self):
+            return (torch._utils._rebuild_wrapper_subclass, ())
+
+    for i, obj in enumerate((Outer(), Wide())):
+        bad = str(tmp_path / f"gadget{i}.th")
+        torch.save({"config": obj, "state_dict": {"a": torch.arange(3)}}, bad, pickle_protocol=4)
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            load_checkpoint(bad)
+    assert not _GADGET_RAN
