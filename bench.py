@@ -392,9 +392,20 @@ def main():
     backend = os.environ.get("NMF_BENCH_BACKEND", "gloo" if share else "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # NMF_BENCH_BACKEND=nccl at --gpus 1: a process group of ONE rank over RCCL, and the gradient all-reduce entered anyway
+    # (the sum over one rank is the identity).  What a 1-GPU box can show of the multi-GPU path: the library loads, the
+    # collective is ordered correctly against the training pass's streams, and what pack + all-reduce + unpack cost per step.
+    single_rank_comm = world == 1 and os.environ.get("NMF_BENCH_BACKEND") == "nccl"
+    if single_rank_comm:
+        os.environ["NMF_ALLREDUCE_SINGLE_RANK"] = "1"
+        if "MASTER_ADDR" not in os.environ:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
+            s_.close()
+    if world > 1 or single_rank_comm:
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend)
         # create the communicator (RCCL ring / tree setup takes seconds) outside every timed or warm-up step
@@ -493,7 +504,8 @@ def main():
                        "rays_per_gpu": args.rays_per_gpu, "chunks_per_step": chunks_per_step, "grid": args.grid,
                        "samples_per_chunk": last["n_samples"], "samples_per_chunk_first_step": last["first_n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
-                       "parallelism": f"dp{world}", "ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
+                       "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                       "backend": backend if (world > 1 or single_rank_comm) else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"]},
             # Dominant kernel: the backward walk of the VM field (table-gradient scatter-add on the matrix cores).  Its
             # ceiling is the SIMD's ALU pipe: on gfx950 an fp32 MFMA and the other VALU instructions do not overlap
@@ -527,7 +539,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or single_rank_comm:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -8,9 +8,11 @@ sequence as straight-line code: forward for recursion level 0 and 1 keeping the 
 calls in reverse order, with the table / MLP / head / env-map gradients accumulated in persistent buffers over all chunks of
 an optimizer step and converted to parameter gradients once (`end_step`).
 
-Scope: is_train=True, the sparse-appearance path (no debug maps), recursion depth len(max_retrace_rays) <= 1, no test
-hooks (model.forced / model.trace / sampler.forced_valid).  Anything else raises Unsupported BEFORE touching an accumulator
-and the Trainer runs that chunk through the autograd path instead (tests/test_hip_e2e.py compares the two paths).
+Scope: is_train=True, the sparse-appearance path (no debug maps), recursion depth len(max_retrace_rays) <= 1.  Anything
+else raises Unsupported BEFORE touching an accumulator and the Trainer runs that chunk through the autograd path instead
+(tests/test_hip_e2e.py compares the two paths).  Replayed bookkeeping of a reference run (noise.Pins on a ReplayNoise: bounce
+counts, re-trace order, occupancy decisions) is honoured here exactly as in the modules, so the reference's full-size fixtures
+are checked on THIS path (tests/test_hip_timed_path.py).
 Reference spans are the ones cited in functional.py for each call."""
 import os
 import types
@@ -83,8 +85,7 @@ class TrainPass:
     def supported(self):
         n = self.nerf
         m = n.model
-        return (m.forced is None and m.trace is None and n.sampler.forced_valid is None and len(m.max_retrace_rays) <= 1
-                and n.bg_module is not None and not n.hdr and getattr(m.brdf, "fused", False))
+        return (len(m.max_retrace_rays) <= 1 and n.bg_module is not None and not n.hdr and getattr(m.brdf, "fused", False))
 
     # ---- accumulators of one optimizer step ------------------------------------------------------------------------
     def begin_step(self):
@@ -194,6 +195,10 @@ class TrainPass:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(nb), 1.0, total)
             else:
                 counts = hip.select_bounces(w, u.contiguous(), 1, float(model.max_brdf_rays[lvl]), 0.5, total)
+        pins = getattr(noise, "pins", None)          # tests: replayed bookkeeping of a reference run (noise.Pins)
+        trace = pins.trace if pins is not None else None
+        if pins is not None:
+            counts = pins.counts_for(lvl, counts)
         bidx, row_off, cnt32, inv, tot, xyz_rows = hip.bounce_index(counts, S.xyzt)
         rb = hip.Readback.of(tot.device).start(tot)
         conv = nerf.bg_module.get_spherical_harmonics(100)[1].reshape(9, 3)      # first call of a pass: SAT + SH rebuild
@@ -222,8 +227,8 @@ class TrainPass:
                                                            2 if sparse_n else 1)
         sobol = model.brdf_sampler.angs
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
-        full_retrace = (lvl < len(model.max_retrace_rays) and min(R, model.max_retrace_rays[lvl]) >= R
-                        and not model.exact_retrace_order)
+        sorts = pins is not None and pins.sorts(lvl)
+        full_retrace = lvl < len(model.max_retrace_rays) and min(R, model.max_retrace_rays[lvl]) >= R and not sorts
         brdf = None if full_retrace else hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
         t.__dict__.update(offsets=offsets, sf=sf, sg=sg, gr=gr, nr=nr, w=w, conv=conv, bidx=bidx, row_off=row_off, cnt32=cnt32,
                           inv=inv, R=R, Mb=Mb, row_of_ray=row_of_ray, j_of_ray=j_of_ray, off=off, xyz_rows=xyz_rows, app=app,
@@ -232,7 +237,7 @@ class TrainPass:
         # ---- incoming radiance of the secondary rays (models/microfacet.py:475-563)
         if lvl < len(model.max_retrace_rays):
             num_retrace = min(R, model.max_retrace_rays[lvl])
-            if num_retrace >= R and not model.exact_retrace_order:
+            if num_retrace >= R and not sorts:
                 noise.skip("rand", (R,))
 
                 def mlp():          # needs nothing of the level below: runs under its sampler's read-back
@@ -249,8 +254,14 @@ class TrainPass:
                 cc = cc / cc.sum() * num_retrace
                 cc = cc + noise.uniform((R,))
                 order = hip.argsort_f32(cc.contiguous()).long()
+                if trace is not None:
+                    trace[f"retrace_order_own{lvl}"] = order
+                if pins is not None and lvl in pins.retrace_order:
+                    order = pins.retrace_order[lvl].to(order.device)
                 cut = max(R - num_retrace, 0)
                 t.idx_re, t.idx_no = order[cut:], order[:cut]
+                if trace is not None:
+                    trace.update({f"retrace_score{lvl}": cc, f"retrace_order{lvl}": order, f"retrace_idx{lvl}": t.idx_re})
                 # idx_re and idx_no partition the rays: both index_copy_ together write every row
                 incoming = torch.empty((R, 3), dtype=torch.float32, device=rays.device)
                 sel = torch.index_select
@@ -280,6 +291,9 @@ class TrainPass:
                                                          per_ray_bg, lvl == 0, False, lvl == 0)
         t.__dict__.update(incoming=incoming, bg=bg, refl=refl, rgb_map=rgb_map, acc=acc, rgb_lin=rgb_lin, ori=ori,
                           per_ray_bg=per_ray_bg)
+        if trace is not None:
+            trace.update({f"rgb_map{lvl}": rgb_map, f"acc_map{lvl}": acc, f"whole_valid{lvl}": S.whole_valid,
+                          f"incoming{lvl}": incoming, f"ori{lvl}": ori})
         return t
 
     # ---- backward of one recursion level -----------------------------------------------------------------------------

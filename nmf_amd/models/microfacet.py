@@ -44,11 +44,6 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
         self.detach_N = True
         self.rays_per_ray, self.test_rays_per_ray = rays_per_ray, test_rays_per_ray
         self.outputs = {"diffuse": 3, "roughness": 1, "tint": 3, "spec": 3, "albedo": 3}
-        self.trace = None            # tests: dict that receives intermediate tensors
-        self.forced = None           # tests: {'retrace_order<r>': LongTensor, 'counts<r>': IntTensor} pin bookkeeping decisions
-        # True: sort the re-trace scores even when every secondary ray is re-traced, as models/microfacet.py:506-509 does
-        # (the order then pairs rays with jitter rows exactly like the reference); False: identity order in that case
-        self.exact_retrace_order = False
 
     # ---- controllers / bookkeeping (models/microfacet.py:79-121,236-269) --------------------------------
     def calibrate(self, args, xyz, feat, bg_brightness, save_config=True):
@@ -173,12 +168,10 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
                 counts = hip.select_bounces(w_det, u.contiguous(), 1, float(Nbudget), 1.0, total)
             else:
                 counts = hip.select_bounces(w_det, u.contiguous(), 1, float(self.max_brdf_rays[recur]), 0.5, total)
-        if self.trace is not None:
-            self.trace[f"counts_own{recur}"] = counts
-        if self.forced is not None and f"counts{recur}" in self.forced and self.forced[f"counts{recur}"].shape[0] == M:
-            counts = self.forced[f"counts{recur}"].to(dev).int().contiguous()
-        if self.trace is not None:
-            self.trace[f"counts{recur}"] = counts
+        pins = getattr(noise, "pins", None)          # tests: replayed bookkeeping of a reference run (noise.Pins)
+        trace = pins.trace if pins is not None else None
+        if pins is not None:
+            counts = pins.counts_for(recur, counts)
         bidx, row_off, cnt32, inv, tot = hip.bounce_index(counts)                                    # :333-350
         R, Mb = (int(v) for v in tot.cpu())
         out = Shaded(self, samples, heads, normals, conv, w_det, inv, M, app_fn)
@@ -212,14 +205,13 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
             L, halfvec, diffvec, lpdf, mipval, bounce_rays = GgxRays.apply(                         # :367-456
                 bV, bN, r1, xyz, off, cnt32, self.brdf_sampler.angs, row_of_ray, j_of_ray, row_off)
             brdf_weight = self.brdf.forward_compact(halfvec, diffvec, feat, r1, row_of_ray, row_off)
-        if self.trace is not None:
-            self.trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
-                               f"counts{recur}": counts, f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec,
-                               f"lpdf{recur}": lpdf})
+        if trace is not None:
+            trace.update({f"L{recur}": L, f"mipval{recur}": mipval, f"brdf_weight{recur}": brdf_weight,
+                          f"halfvec{recur}": halfvec, f"diffvec{recur}": diffvec, f"lpdf{recur}": lpdf})
         if len(self.max_retrace_rays) > recur:                                                      # :475-559
             num_retrace = min(R, self.max_retrace_rays[recur])
-            pinned = self.forced is not None and f"retrace_order{recur}" in self.forced
-            if num_retrace >= R and not pinned and self.trace is None and not self.exact_retrace_order:
+            pinned = pins is not None and recur in pins.retrace_order
+            if num_retrace >= R and not (pins is not None and pins.sorts(recur)):
                 # steady state: every secondary ray is re-traced.  The reference still argsorts the
                 # scores, which only permutes the rays before they meet their i.i.d. jitter rows; the draw is
                 # consumed for stream parity and the identity order is used (same distribution, no 250 k-key sort).
@@ -233,13 +225,15 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
                     cc = cc / cc.sum() * num_retrace
                     cc = cc + noise.uniform((R,))
                     order = hip.argsort_f32(cc.contiguous()).long()                                  # :522
+                    if trace is not None:
+                        trace[f"retrace_order_own{recur}"] = order
                     if pinned:
-                        order = self.forced[f"retrace_order{recur}"].to(dev)
+                        order = pins.retrace_order[recur].to(dev)
                     cut = max(R - num_retrace, 0)
                     idx_re, idx_no = order[cut:], order[:cut]
-                    if self.trace is not None:
-                        self.trace.update({f"retrace_score{recur}": cc, f"retrace_order{recur}": order,
-                                           f"retrace_idx{recur}": idx_re})
+                    if trace is not None:
+                        trace.update({f"retrace_score{recur}": cc, f"retrace_order{recur}": order,
+                                      f"retrace_idx{recur}": idx_re})
                 incoming = torch.zeros((R, 3), device=dev)
                 if idx_re.shape[0] > 0:
                     inc = render_reflection(bounce_rays[idx_re], mipval[idx_re], True)
@@ -249,8 +243,8 @@ class Microfacet(FastPrivateAttrs, torch.nn.Module):
                     incoming = incoming.index_put((idx_no,), inc)
         else:
             incoming = render_reflection(bounce_rays, mipval, False)
-        if self.trace is not None:
-            self.trace[f"incoming{recur}"] = incoming
+        if trace is not None:
+            trace[f"incoming{recur}"] = incoming
         # :596-613 -- evaluated together with the per-ray sums (functional.ShadeCompose) by TensorNeRF, or on first read
         out.mix_args = (bV, f0, diffuse, cnt32, row_of_ray, row_off, L, incoming, brdf_weight)
         out.rows = (bidx, row_off, cnt32, row_of_ray, incoming.detach(), brdf_weight.detach())

@@ -13,12 +13,52 @@ import random
 import torch
 
 
+class Pins:
+    """TESTS ONLY: replayed bookkeeping decisions of a reference run, carried by a ReplayNoise next to the replayed random
+    draws (both are "what the reference decided / drew at this call site").  The product modules keep no test state: the
+    sampler, the shading model and the tape-free training pass read `noise.pins` (None on DeviceNoise).
+
+      counts[level]         int32 [M]   secondary rays per kept sample (output of select_bounces, pt_selectors.py:5-60)
+      retrace_order[level]  int64 [R]   the reference's argsort of the re-trace scores (models/microfacet.py:522)
+      valid[level]          bool [R,N]  occupancy decisions of the candidate steps of that level's rays (alphagrid.py:341-346)
+      exact_retrace_order   sort the scores even when every secondary ray is re-traced, as models/microfacet.py:506-509 does
+      trace                 dict that receives intermediate tensors (own counts, scores, order, rgb_map ...), or None
+      trace_scores          with a trace: take the argsort branch at every level so that scores / order are recorded
+      valid_flips           out: 64-step words the marcher itself decided differently from `valid`"""
+
+    def __init__(self, counts=None, retrace_order=None, valid=None, exact_retrace_order=False, trace=True, trace_scores=True):
+        self.counts = dict(counts or {})
+        self.retrace_order = dict(retrace_order or {})
+        self.valid = dict(valid or {})
+        self.exact_retrace_order = bool(exact_retrace_order)
+        self.trace = {} if trace else None
+        self.trace_scores = bool(trace_scores)
+        self.valid_flips = None
+
+    def counts_for(self, level, own):
+        """own = what the kernel decided; -> the pinned counts when they exist for this level and size"""
+        if self.trace is not None:
+            self.trace[f"counts_own{level}"] = own
+        c = self.counts.get(level)
+        if c is not None and c.shape[0] == own.shape[0]:
+            own = c.to(own.device).int().contiguous()
+        if self.trace is not None:
+            self.trace[f"counts{level}"] = own
+        return own
+
+    def sorts(self, level):
+        """does this level take the argsort branch even when every ray is re-traced?"""
+        return level in self.retrace_order or self.exact_retrace_order or (self.trace is not None and self.trace_scores)
+
+
 class DeviceNoise:
     """Draws of one pass come out of two pools (uniform / normal) filled with ONE torch.rand / torch.randn each at the
     start of the pass (begin_pass, sized by the previous pass's consumption + 25 %): six small generator launches per
     training step become two that are issued while the GPU still works on the previous step.  A draw that does not fit
     (first pass, growing scene) falls back to its own launch.  The numbers are i.i.d. either way; only the assignment of
     generator outputs to call sites differs from draw-per-call."""
+
+    pins = None
 
     def __init__(self, device, seed=0, pooled=True):
         self.device = torch.device(device)
@@ -92,10 +132,11 @@ class ReplayNoise:
     """tape: list of (kind, tensor) in the reference's call order, or None to draw from torch's global CPU RNG
     (seed it with torch.manual_seed(s) first) in that same order."""
 
-    def __init__(self, device, tape=None):
+    def __init__(self, device, tape=None, pins=None):
         self.device = torch.device(device)
         self.tape = list(tape) if tape is not None else None
         self.pos = 0
+        self.pins = pins
 
     def _next(self, kind, shape):
         shape = tuple(int(s) for s in shape)

@@ -103,10 +103,6 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
         self.alphaMask_thres = alphaMask_thres
         self.max_samples = max_samples
         self._calls = 0
-        # tests: {1: bool [R, N]} pins which candidate steps of the SECONDARY rays (override_near given) are kept, i.e. the
-        # reference's recorded occupancy decisions; `valid_flips` then counts the bits the marcher itself decided otherwise
-        self.forced_valid = None
-        self.valid_flips = None
 
     def check_schedule(self, iteration, batch_mul, rf):
         if iteration in self.update_list:
@@ -202,14 +198,16 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
         p.seed, p.offset = int(seed), int(off)
         rays = rays_chunk.contiguous()
         valid, counts = hip.march_count(p, rays, jitter, packed[1] if use_mask else None, packed[2] if use_mask else None)
-        if self.forced_valid is not None and override_near is not None and 1 in self.forced_valid \
-                and tuple(self.forced_valid[1].shape) == (B, N):
-            fv = self.forced_valid[1].to(dev)
+        pins = getattr(noise, "pins", None)
+        if pins is not None and override_near is not None and 1 in pins.valid and tuple(pins.valid[1].shape) == (B, N):
+            # tests (noise.Pins): the reference's recorded occupancy decisions of the SECONDARY rays' candidate steps replace
+            # the marcher's own; `valid_flips` counts the 64-step words the marcher itself decided otherwise
+            fv = pins.valid[1].to(dev)
             W = valid.shape[1]
             bits = torch.zeros((B, W * 64), dtype=torch.int64, device=dev)
             bits[:, :N] = fv
             words = (bits.view(B, W, 64) << torch.arange(64, device=dev)).sum(-1)          # bit k of word j = step 64 j + k
-            self.valid_flips = int(((words ^ valid) != 0).sum())
+            pins.valid_flips = int(((words ^ valid) != 0).sum())
             valid, counts = words.contiguous(), fv.sum(dim=1).int().contiguous()
         budget = self.max_samples if (self.max_samples > 0 and is_train and dynamic_batch_size) else -1
         offsets, wv, totals = hip.march_scan(counts, budget)

@@ -90,9 +90,15 @@ class FlatGradAllReduce:
         self.buf = None
         self._slots = None
         self.last_comm_ms = None          # (start, end) device events of the last collective, or host seconds on CPU
+        # NMF_ALLREDUCE_SINGLE_RANK=1: enter the collective even when the group has ONE rank (a sum over one rank is the
+        # identity): exercises RCCL, the pack / unpack launches and their ordering against the training pass's side streams
+        # on a 1-GPU box, and gives a first comm_ms_per_step (bench.py with NMF_BENCH_BACKEND=nccl)
+        self.single_rank = os.environ.get("NMF_ALLREDUCE_SINGLE_RANK") == "1"
 
     def __call__(self, group=None):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        if dist.get_world_size(group) == 1 and not self.single_rank:
             return 0
         ps, n = self.params, self.numel
         if n == 0:

@@ -32,10 +32,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh  # noqa: E402
 from nmf_amd import synthetic, yaml_config  # noqa: E402
 
-GRID0, GRID1, BG, UPSAMPLE_AT, N_ITERS = 32, 40, 32, 15, 40
-PSNR_AT = (10, 20, 30, 40)
-RES, N_TRAIN_VIEWS, N_TEST_VIEWS = 20, 10, 2
-SEED = 20211200
+# the 40-iteration trace (train_trace.npz); make_psnr_trace.py calls run() with a longer, larger configuration
+KNOBS = dict(grid0=32, grid1=40, teacher_grid=32, bg=32, upsample_at=(15,), n_iters=40, psnr_at=(10, 20, 30, 40), res=20,
+             train_views=10, test_views=2, seed=20211200, batch=512, max_batch=1000, max_samples=20000,
+             max_brdf_rays=(40000, 20000), target_num_samples=40000, max_retrace=200, rays_per_ray=32, light=False,
+             threads=8)
 
 
 class Cfg(dict):
@@ -73,8 +74,16 @@ def instantiate(node, *a, **kw):
     return node
 
 
-def main():
-    torch.set_num_threads(8)
+_DATA = {}
+
+
+def run(**knobs):
+    """-> dict of arrays (what main() writes).  light=True keeps the data set, the initial state and the test PSNR only."""
+    K = dict(KNOBS, **knobs)
+    GRID0, GRID1, BG, N_ITERS = K["grid0"], K["grid1"], K["bg"], K["n_iters"]
+    UPSAMPLE_AT, PSNR_AT, RES, SEED = list(K["upsample_at"]), tuple(K["psnr_at"]), K["res"], K["seed"]
+    N_TRAIN_VIEWS, N_TEST_VIEWS = K["train_views"], K["test_views"]
+    torch.set_num_threads(K["threads"])
     rh.install_stubs()
     sys.modules["hydra"].utils = sys.modules["hydra.utils"]
     sys.modules["hydra.utils"].instantiate = instantiate
@@ -88,21 +97,26 @@ def main():
     from dataLoader import dataset_dict
 
     # ---- ground truth: the reference model itself renders the S1 scene from the orbit cameras (eval mode)
-    teacher = rh.build_reference(grid=GRID0, bg_resolution=BG, seed=0, max_samples=20000, max_brdf_rays=(40000, 20000),
-                                 max_retrace_rays=(40000,), target_num_samples=(40000,))
-    teacher.load_state_dict(synthetic.state_dict_s1(grid=GRID0, bg_resolution=BG, seed=0), strict=False)
-    teacher.sampler.update(teacher.rf, init=False)
-    teacher.sampler.update(teacher.rf, init=True)
-    teacher.eval()
-    rays_tr, focal = synthetic.orbit_rays(N_TRAIN_VIEWS, RES, seed=1)
-    rays_te, _ = synthetic.orbit_rays(N_TEST_VIEWS, RES, seed=2)
-    torch.manual_seed(7)
-    with torch.no_grad():
-        rgb_tr = torch.cat([teacher(rays_tr[i:i + 800], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False)[0]["rgb_map"]
-                            for i in range(0, rays_tr.shape[0], 800)])
-        rgb_te = torch.cat([teacher(rays_te[i:i + 800], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False)[0]["rgb_map"]
-                            for i in range(0, rays_te.shape[0], 800)])
-    del teacher
+    dkey = (K["teacher_grid"], BG, RES, N_TRAIN_VIEWS, N_TEST_VIEWS)
+    if dkey not in _DATA:                                            # several seeds train on one data set
+        TG = K["teacher_grid"]
+        teacher = rh.build_reference(grid=TG, bg_resolution=BG, seed=0, max_samples=20000, max_brdf_rays=(40000, 20000),
+                                     max_retrace_rays=(40000,), target_num_samples=(40000,))
+        teacher.load_state_dict(synthetic.state_dict_s1(grid=TG, bg_resolution=BG, seed=0), strict=False)
+        teacher.sampler.update(teacher.rf, init=False)
+        teacher.sampler.update(teacher.rf, init=True)
+        teacher.eval()
+        rays_tr, focal = synthetic.orbit_rays(N_TRAIN_VIEWS, RES, seed=1)
+        rays_te, _ = synthetic.orbit_rays(N_TEST_VIEWS, RES, seed=2)
+        torch.manual_seed(7)
+        with torch.no_grad():
+            rgb_tr = torch.cat([teacher(rays_tr[i:i + 800], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False)[0]["rgb_map"]
+                                for i in range(0, rays_tr.shape[0], 800)])
+            rgb_te = torch.cat([teacher(rays_te[i:i + 800], focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False)[0]["rgb_map"]
+                                for i in range(0, rays_te.shape[0], 800)])
+        del teacher
+        _DATA[dkey] = (rays_tr, rgb_tr, rays_te, rgb_te, focal)
+    rays_tr, rgb_tr, rays_te, rgb_te, focal = _DATA[dkey]
 
     class SyntheticDataset:
         def __init__(self, datadir, split="train", downsample=1.0, is_stack=False, stack_norms=False, white_bg=True,
@@ -122,13 +136,15 @@ def main():
         "vis_every=1000000000", "progress_refresh_rate=1000000000", f"seed={SEED}",
         "dataset.dataset_name=synthetic", "dataset.scenedir=synthetic/s2", "dataset.gt_bg=null",
         f"field.grid_size=[{GRID0},{GRID0},{GRID0}]", f"field.N_voxel_init={GRID0 ** 3}", f"field.N_voxel_final={GRID1 ** 3}",
-        f"field.upsamp_list=[{UPSAMPLE_AT}]",
-        f"model.arch.sampler.update_list=[{UPSAMPLE_AT}]", "model.arch.sampler.max_samples=20000",
-        "model.arch.model.max_brdf_rays=[40000,20000]", "model.arch.model.target_num_samples=[40000]",
-        "model.arch.model.max_retrace_rays=[200]", "model.arch.model.rays_per_ray=32",
+        f"field.upsamp_list={UPSAMPLE_AT}".replace(" ", ""),
+        f"model.arch.sampler.update_list={UPSAMPLE_AT}".replace(" ", ""), f"model.arch.sampler.max_samples={K['max_samples']}",
+        f"model.arch.model.max_brdf_rays={list(K['max_brdf_rays'])}".replace(" ", ""),
+        f"model.arch.model.target_num_samples=[{K['target_num_samples']}]",
+        f"model.arch.model.max_retrace_rays=[{K['max_retrace']}]", f"model.arch.model.rays_per_ray={K['rays_per_ray']}",
         f"model.arch.bg_module.bg_resolution={BG}",
-        f"model.params.n_iters={N_ITERS}", "model.params.batch_size=512", "model.params.min_batch_size=512",
-        "model.params.max_batch_size=1000", "model.params.starting_batch_size=100", "model.params.target_num_samples=20000",
+        f"model.params.n_iters={N_ITERS}", f"model.params.batch_size={K['batch']}", f"model.params.min_batch_size={K['batch']}",
+        f"model.params.max_batch_size={K['max_batch']}", "model.params.starting_batch_size=100",
+        f"model.params.target_num_samples={K['max_samples']}",
     ]
     cfg = yaml_config.compose(os.path.join(rh.REF, "configs"), small)
     args = wrap(cfg)
@@ -254,12 +270,18 @@ def main():
     assert state["it"] == N_ITERS, state["it"]
     per_img = T["test_psnr"][-1]
 
-    out = dict(grid0=GRID0, grid1=GRID1, bg_res=BG, upsample_at=UPSAMPLE_AT, n_iters=N_ITERS, res=RES, focal=focal, seed=SEED,
+    out = dict(grid0=GRID0, grid1=GRID1, bg_res=BG, upsample_at=UPSAMPLE_AT[0] if len(UPSAMPLE_AT) == 1 else np.asarray(UPSAMPLE_AT),
+               n_iters=N_ITERS, res=RES, focal=focal, seed=SEED,
                rays_train=rays_tr, rgb_train=rgb_tr, rays_test=rays_te, rgb_test=rgb_te,
                rng_state_at_loop=state["rng_at_loop"], biases=np.asarray(state["biases"]),
                test_psnr=np.asarray(T["test_psnr"]), psnr_at=np.asarray(PSNR_AT), overrides="\n".join(small))
     for k, v in state["init_sd"].items():
         out["init/" + k] = v
+    out["params_params"] = np.asarray([args.model.params[k] for k in ("min_batch_size", "max_batch_size", "starting_batch_size",
+                                                                      "target_num_samples")])
+    if K["light"]:
+        print("test psnr per image at", PSNR_AT, np.round(np.asarray(T["test_psnr"]), 3).tolist(), flush=True)
+        return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
     for k in ("chunk_num_rays", "chunk_rays_in", "chunk_kept", "chunk_n_samples", "chunk_iter", "chunk_loss",
               "chunk_max_retrace", "iter_lbatch", "iter_lr", "iter_grid", "iter_detach_N", "iter_max_retrace",
               "iter_num_chunks"):
@@ -273,18 +295,21 @@ def main():
     out["param_names"] = "\n".join(pnames)
     out["iter_param_norm"] = np.asarray([[d[n][1] for n in pnames] for d in T["iter_checksum"]])
     out["iter_param_sum"] = np.asarray([[d[n][0] for n in pnames] for d in T["iter_checksum"]])
-    out["params_params"] = np.asarray([args.model.params[k] for k in ("min_batch_size", "max_batch_size", "starting_batch_size",
-                                                                      "target_num_samples")])
     flat = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
-    path = os.path.join(HERE, "train_trace.npz")
-    np.savez_compressed(path, **flat)
-    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
     print("lbatch", out["iter_lbatch"].tolist())
     print("num_rays per chunk", out["chunk_num_rays"].tolist())
     print("max_retrace", out["iter_max_retrace"].tolist())
     print("grid", out["iter_grid"].tolist(), "optimizer", out["iter_optimizer"].tolist())
     print("loss", [round(v, 5) for v in out["chunk_loss"].tolist()][:40])
     print("test psnr per image at", PSNR_AT, T["test_psnr"])
+    return flat
+
+
+def main():
+    flat = run()
+    path = os.path.join(HERE, "train_trace.npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
 if __name__ == "__main__":

@@ -115,15 +115,14 @@ def test_microfacet_forward_reference_signature():
         nrm = O.normals(sd, cfg, xyz)
     b, N = ray_valid.shape
     viewdirs = rays[:, 3:6].view(-1, 1, 3).expand(b, N, 3)[ray_valid]
-    noise = ReplayNoise(DEV, g.tape())                                   # eval: the sampler draws nothing
-    nerf.model.forced = {"retrace_order0": trace["retrace_order0"]}
-    c0 = torch.zeros(trace["bounce_mask0"].shape[0], dtype=torch.int32)
-    c0[trace["bounce_mask0"]] = trace["ray_mask0"].sum(1).int()
-    nerf.model.forced["counts0"] = c0
-    if "bounce_mask1" in trace:
-        c1 = torch.zeros(trace["bounce_mask1"].shape[0], dtype=torch.int32)
-        c1[trace["bounce_mask1"]] = trace["ray_mask1"].sum(1).int()
-        nerf.model.forced["counts1"] = c1
+    from nmf_amd.noise import Pins
+    pins = Pins(retrace_order={0: trace["retrace_order0"]}, trace=False)
+    for lvl in (0, 1):
+        if f"bounce_mask{lvl}" in trace:
+            c = torch.zeros(trace[f"bounce_mask{lvl}"].shape[0], dtype=torch.int32)
+            c[trace[f"bounce_mask{lvl}"]] = trace[f"ray_mask{lvl}"].sum(1).int()
+            pins.counts[lvl] = c
+    noise = ReplayNoise(DEV, g.tape(), pins=pins)                        # eval: the sampler draws nothing
 
     def render_reflection(brays, mipval, retrace=False):                 # modules/tensor_nerf.py:291-317
         if retrace:

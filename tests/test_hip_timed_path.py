@@ -1,0 +1,242 @@
+"""The path bench.py TIMES -- `Trainer.step` through the tape-free training pass (nmf_amd/fast_step.py: sparse normals, value-only
+queries and walks, side streams) -- against the REFERENCE's full-size fixtures and the CPU oracle directly, not through a
+comparison with the autograd operator graph ("what's weak", first item).
+
+The reference run's bookkeeping decisions (bounce counts, re-trace order, occupancy bits of the secondary rays) and its random
+stream are replayed through noise.ReplayNoise + noise.Pins; everything else is the product path exactly as bench.py runs it."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, assert_close
+from nmf_amd import synthetic
+from oracle import nmf_oracle as O
+from test_hip_e2e import (DEV, _check_gradients, _early_phase_order, _frac_close, _full_size_model,
+                          _pin_reference_bookkeeping)
+from test_hip_parity import _field_tables, _hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _timed_step(nerf, g, pins, n_rays=None):
+    """one Trainer.step on the fixture's rays with the optimizer update switched off -> (StepStats, trace record, calls)"""
+    from nmf_amd.config import resolved_config
+    from nmf_amd.noise import ReplayNoise
+    from nmf_amd.trainer import Trainer
+    tr = Trainer(nerf, resolved_config()["params"])
+    assert tr.fast is not None and tr.fast.supported()
+    tr.optimizer.step = lambda: None                               # keep the gradients, leave the parameters alone
+    tr.optimizer.step_unhooked = lambda: None
+    calls = []
+    orig = tr.fast.chunk
+
+    def chunk(*a, **k):                                             # the chunk must not fall back to the autograd path
+        out = orig(*a, **k)
+        calls.append(out)
+        return out
+
+    tr.fast.chunk = chunk
+    B = g["n_rays"]
+    rays, focal = synthetic.camera_rays(B, seed=g["ray_seed"])
+    gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(9)).to(DEV)       # as make_golden.py draws it
+    torch.manual_seed(g["noise_seed"])
+    rec = []
+    out = tr.step(rays.to(DEV), gt, focal, noise=ReplayNoise(DEV, None, pins=pins), update_controllers=False, fixed_chunk=B,
+                  global_rays=4096, trace=rec)
+    assert len(calls) == 1 and calls[0] is not None and out["chunks"] == 1, "the chunk left the tape-free pass"
+    return out, rec[0]
+
+
+@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_full_seeded"])
+def test_timed_path_vs_reference(name):
+    """Trainer.step (tape-free) on the reference's 4096-ray / 128^3 steady-state run, its 300^3 run and its early-phase run:
+    sample counts and the budget mask bit-exact, radiance 1e-4, loss 1e-4, FULL parameter gradients at the tolerances of the
+    module-path tests (tests/test_hip_e2e.py::_check_loss_and_gradients)."""
+    g = Golden(name)
+    nerf = _full_size_model(g)
+    pins = _pin_reference_bookkeeping(g, order=name != "e2e_full_seeded")
+    if name == "e2e_full_seeded":
+        pins.retrace_order[0] = _early_phase_order(g)
+    out, rec = _timed_step(nerf, g, pins)
+    tr = pins.trace
+    assert list(rec["n_samples"]) == [int(v) for v in g.np("n_samples")]
+    assert torch.equal(tr["whole_valid0"].cpu(), g["whole_valid"]) and rec["kept"] == int(g["whole_valid"].sum())
+    if "valid1" in g:
+        n_cand = int(np.prod(g.np("valid1_shape")))
+        assert pins.valid_flips <= max(4, n_cand // 10_000_000), pins.valid_flips
+    for lvl in (0, 1):
+        own, pinned = tr[f"counts_own{lvl}"].cpu(), pins.counts[lvl]
+        flips = int((own != pinned).sum())
+        assert flips <= max(8, own.shape[0] // 20000) and int((own - pinned).abs().max()) <= 1, (lvl, flips)
+    assert_close(tr["acc_map0"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
+    frac, worst = _frac_close(tr["rgb_map0"].cpu(), g["rgb_map"], 1e-4, 1e-4)
+    print(f"{name} (tape-free pass): rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
+    assert frac >= 0.999, (frac, worst)
+    assert_close(torch.tensor(out["loss"]), g["loss"], rtol=1e-4, what="loss")
+    assert_close(rec["total"].cpu().reshape(()), g["total"], rtol=1e-4, what="total")
+    _check_gradients(nerf, g, full_tol=3e-2 if "g300" in name else 5e-3)
+
+
+@pytest.mark.parametrize("G,M,seed", [(128, 60000, 2), (300, 20000, 3)])
+def test_value_only_query_rows_query_and_walks_vs_oracle(G, M, seed):
+    """The kernels that exist only on the timed path, at the benchmarked grid sizes, against the CPU oracle:
+    k_vm_sigma (density value of the re-traced samples), k_vm_rows_dn (value + gradient + normal of the bounce rows),
+    k_vm_bwd_density<false> (value-only walk) and the rows' normal-adjoint walk with a zero d_sigma -- table gradients against
+    the oracle's autograd (fields/tensoRF.py:161-205,392-400, fields/tensor_base.py:83-129)."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(seed)
+    cfg = O.Cfg(grid=G)
+    sd = {}
+    for i in range(3):
+        sd[f"rf.density_rf.app_plane.{i}"] = (0.3 * torch.randn(1, 16, G, G, generator=gen)).requires_grad_(True)
+        sd[f"rf.density_rf.app_line.{i}"] = (0.3 * torch.randn(1, 16, G, 1, generator=gen)).requires_grad_(True)
+        sd[f"rf.app_rf.app_plane.{i}"] = 0.3 * torch.randn(1, 24, G, G, generator=gen)
+        sd[f"rf.app_rf.app_line.{i}"] = 0.3 * torch.randn(1, 24, G, 1, generator=gen)
+    sd["rf.basis_mat.weight"] = 0.2 * torch.randn(24, 72, generator=gen)
+    xyz = torch.cat([(torch.rand(M, 3, generator=gen) * 2 - 1) * 1.5, torch.rand(M, 1, generator=gen)], -1)
+    rows = torch.arange(0, M, 7)
+    xyz_rows = xyz[rows].contiguous()
+    dnames = [k for k in sd if "density_rf" in k]
+    sf_o, sg_o = O.density_feature(sd, cfg, xyz), O.density(sd, cfg, xyz)
+    g_o = O.density_gradient(sd, cfg, xyz_rows)
+    nr_o = O.normals(sd, cfg, xyz_rows)
+    ca, cc = torch.randn(M, generator=gen), torch.randn(rows.shape[0], 3, generator=gen)
+    gn = g_o.detach().norm(dim=-1)
+    cc = cc * (gn > (0.05 if G <= 128 else 0.3) * float(gn.median()))[:, None]      # d normalize / dg ~ 1 / |g|
+    ref_val = dict(zip(dnames, torch.autograd.grad((sg_o * ca).sum(), [sd[k] for k in dnames], retain_graph=True)))
+    ref_nrm = dict(zip(dnames, torch.autograd.grad((nr_o * cc).sum(), [sd[k] for k in dnames])))
+    p, dpk, dlk, apl, ali, basis = _field_tables(hip, sd, cfg)
+    xyz_d, rows_d = xyz.to(DEV).contiguous(), xyz_rows.to(DEV)
+    ga = max(1.0, G / 128)
+    # ---- k_vm_sigma
+    sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, xyz_d, dpk, dlk, apl, ali, basis, want_density=True, want_normal=False,
+                                            want_app=False)
+    assert gr is None and nr is None
+    assert_close(sf.cpu(), sf_o.detach(), rtol=1e-5, atol=2e-5 * ga, what="sigma_feat (value-only query)")
+    assert_close(sg.cpu(), sg_o.detach(), rtol=2e-5 * ga, atol=1e-6 * ga, what="sigma (value-only query)")
+    # ---- k_vm_rows_dn
+    sf_r, gr_r, nr_r = hip.vm_query_rows(p, rows_d, dpk, dlk)
+    assert_close(sf_r.cpu(), sf_o.detach()[rows], rtol=1e-5, atol=2e-5 * ga, what="sigma_feat (rows query)")
+    assert_close(gr_r.cpu(), g_o.detach(), rtol=1e-4, atol=2e-5 * ga * float(g_o.abs().max()), what="density gradient (rows)")
+    ok = gn > 0.05 * float(gn.median())
+    assert int(ok.sum()) > 0.9 * rows.shape[0]
+    assert_close(nr_r.cpu()[ok], nr_o.detach()[ok], rtol=1e-4, atol=2e-4 * ga, what="normals (rows)")
+    # ---- the two walks of a re-traced level, as fast_step.TrainPass issues them
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)  # noqa: E731
+
+    def walk(seg):
+        g_dpk, g_dlk = [z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)]
+        hip.vm_query_bwd_segments(p, [seg], dpk, dlk, apl, ali, basis, g_dpk, g_dlk, [z(G, G, 24) for _ in range(3)],
+                                  [z(G, 24) for _ in range(3)], None)
+        gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+        out = {}
+        for i in range(3):
+            out[f"rf.density_rf.app_plane.{i}"], out[f"rf.density_rf.app_line.{i}"] = gp[i].cpu(), gl[i].cpu()
+        return out
+
+    got_val = walk((xyz_d, sf, None, ca.to(DEV), None, None, None))
+    got_nrm = walk((rows_d, sf_r, gr_r, z(rows.shape[0]), None, cc.to(DEV).contiguous(), None))
+    for k in dnames:
+        for got, ref, what in ((got_val[k], ref_val[k], "value-only walk"), (got_nrm[k], ref_nrm[k], "rows normal walk")):
+            assert float(ref.abs().max()) > 0
+            assert_close(got, ref, rtol=5e-4 * ga, atol=5e-5 * ga * float(ref.abs().max()), what=f"{what}: grad {k}")
+
+
+def test_bf16_tables_full_size_step():
+    """BASELINE configs[1] at the benchmarked size (4096 rays, 128^3, every secondary ray re-traced): with master tables that
+    are exactly representable in bfloat16, a training step that reads bf16 table copies in its forward queries
+    (TensorVMSplit.set_table_dtype('bf16')) must produce the radiance of the fp32 step bit for bit and the same gradients
+    (the backward walks the fp32 masters either way; float atomics reorder sums)."""
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device(DEV)
+    res = {}
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(3)
+        nerf, params = bench.build(dev)
+        with torch.no_grad():
+            for prm in nerf.rf._param_list()[:12]:
+                prm.copy_(prm.bfloat16().float())
+        nerf.sampler.update(nerf.rf, init=False)
+        nerf.sampler.update(nerf.rf, init=True)
+        if mode == "bf16":
+            nerf.rf.set_table_dtype("bf16")
+        tr = Trainer(nerf, params)
+        assert tr.fast is not None and tr.fast.supported()
+        tr.optimizer.step = lambda: None
+        tr.optimizer.step_unhooked = lambda: None
+        from nmf_amd.noise import Pins
+        noise = DeviceNoise(dev, seed=77, pooled=False)
+        noise.pins = Pins(trace=True, trace_scores=False)         # record only: keep the identity order of the steady state
+        rays, focal = synthetic.camera_rays(4096, seed=21)
+        gt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+        out = tr.step(rays.to(dev), gt, focal, noise=noise, update_controllers=False, fixed_chunk=4096)
+        res[mode] = (noise.pins.trace["rgb_map0"].clone(), out["n_samples"], out["loss"],
+                     {k: p.grad.detach().clone() for k, p in nerf.named_parameters() if p.grad is not None})
+    a, b = res["f32"], res["bf16"]
+    assert a[1] == b[1] and a[1][0] > 100000 and a[1][1] > 500000, (a[1], b[1])
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    assert abs(a[2] - b[2]) <= 1e-6 * abs(a[2])
+    assert set(a[3]) == set(b[3])
+    for k in a[3]:
+        rel = float((a[3][k].double() - b[3][k].double()).norm() / a[3][k].double().norm().clip(min=1e-30))
+        assert rel <= 2e-5, (k, rel)
+
+
+def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
+    """backend 'nccl' (= RCCL) on the one GPU of this box: a process group of ONE rank, the flat gradient all-reduce entered
+    anyway (FlatGradAllReduce.single_rank).  The sum over one rank is the identity, so every gradient must come back bit for
+    bit: proves that RCCL loads and runs, that pack -> all-reduce -> unpack are ordered behind the tape-free pass (whose field
+    walks / env-map table backward finish on side streams) and ahead of the optimizer, and gives a first comm time."""
+    import socket
+    import torch.distributed as dist
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        dist.all_reduce(torch.zeros(1, device=dev))
+        saved = bench.GRID
+        try:
+            bench.GRID = 64
+            nerf, params = bench.build(dev)
+        finally:
+            bench.GRID = saved
+        tr = Trainer(nerf, params)
+        assert tr.fast is not None and tr.fast.supported()
+        tr.optimizer.step = lambda: None
+        tr.optimizer.step_unhooked = lambda: None
+        tr.reduce.single_rank = True
+        inner, seen = tr.reduce, []
+
+        class Checked:
+            comm_ms = inner.comm_ms
+
+            def __call__(self, group=None):
+                ps = [p for p in inner.params if p.grad is not None]
+                before = [p.grad.clone() for p in ps]                      # queued on the stream the collective is queued on
+                n = inner(group)
+                # compared right away: the gradient tensors of the tape-free pass are persistent buffers, the next step reuses them
+                seen.append((n, len(ps), all(torch.equal(p.grad, b) and bool(torch.isfinite(b).all()) for p, b in zip(ps, before)),
+                             sum(float(b.abs().max()) > 0 for b in before)))
+                return n
+
+        tr.reduce = Checked()
+        rays, focal = synthetic.camera_rays(2048, seed=21)
+        gt = torch.rand(2048, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+        for it in range(3):
+            out = tr.step(rays.to(dev), gt, focal, noise=DeviceNoise(dev, seed=70 + it), update_controllers=False, fixed_chunk=1024)
+            assert out["comm_bytes"] == 4 * inner.numel and out["comm_bytes"] > 1e6
+            assert out["comm_ms"] is not None and out["comm_ms"] > 0
+        torch.cuda.synchronize()
+        assert len(seen) == 3
+        for n, n_grads, same, nonzero in seen:
+            assert n_grads >= 25 and same and nonzero >= 25, (n_grads, same, nonzero)
+    finally:
+        dist.destroy_process_group()
