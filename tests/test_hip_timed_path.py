@@ -23,6 +23,8 @@ def _timed_step(nerf, g, pins, n_rays=None):
     from nmf_amd.config import resolved_config
     from nmf_amd.noise import ReplayNoise
     from nmf_amd.trainer import Trainer
+    # the two lr-0 scalars of the env map (microfacet_tensorf2.yaml:150-151) get a gradient only when they are trained
+    nerf.bg_module.brightness_lr = nerf.bg_module.mul_lr = 1e-12
     tr = Trainer(nerf, resolved_config()["params"])
     assert tr.fast is not None and tr.fast.supported()
     tr.optimizer.step = lambda: None                               # keep the gradients, leave the parameters alone
@@ -142,46 +144,37 @@ def test_value_only_query_rows_query_and_walks_vs_oracle(G, M, seed):
             assert_close(got, ref, rtol=5e-4 * ga, atol=5e-5 * ga * float(ref.abs().max()), what=f"{what}: grad {k}")
 
 
-def test_bf16_tables_full_size_step():
-    """BASELINE configs[1] at the benchmarked size (4096 rays, 128^3, every secondary ray re-traced): with master tables that
-    are exactly representable in bfloat16, a training step that reads bf16 table copies in its forward queries
-    (TensorVMSplit.set_table_dtype('bf16')) must produce the radiance of the fp32 step bit for bit and the same gradients
-    (the backward walks the fp32 masters either way; float atomics reorder sums)."""
-    import bench
-    from nmf_amd.noise import DeviceNoise
-    from nmf_amd.trainer import Trainer
-    dev = torch.device(DEV)
-    res = {}
-    for mode in ("f32", "bf16"):
-        torch.manual_seed(3)
-        nerf, params = bench.build(dev)
-        with torch.no_grad():
-            for prm in nerf.rf._param_list()[:12]:
-                prm.copy_(prm.bfloat16().float())
-        nerf.sampler.update(nerf.rf, init=False)
-        nerf.sampler.update(nerf.rf, init=True)
-        if mode == "bf16":
-            nerf.rf.set_table_dtype("bf16")
-        tr = Trainer(nerf, params)
-        assert tr.fast is not None and tr.fast.supported()
-        tr.optimizer.step = lambda: None
-        tr.optimizer.step_unhooked = lambda: None
-        from nmf_amd.noise import Pins
-        noise = DeviceNoise(dev, seed=77, pooled=False)
-        noise.pins = Pins(trace=True, trace_scores=False)         # record only: keep the identity order of the steady state
-        rays, focal = synthetic.camera_rays(4096, seed=21)
-        gt = torch.rand(4096, 3, generator=torch.Generator().manual_seed(5)).to(dev)
-        out = tr.step(rays.to(dev), gt, focal, noise=noise, update_controllers=False, fixed_chunk=4096)
-        res[mode] = (noise.pins.trace["rgb_map0"].clone(), out["n_samples"], out["loss"],
-                     {k: p.grad.detach().clone() for k, p in nerf.named_parameters() if p.grad is not None})
-    a, b = res["f32"], res["bf16"]
-    assert a[1] == b[1] and a[1][0] > 100000 and a[1][1] > 500000, (a[1], b[1])
-    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
-    assert abs(a[2] - b[2]) <= 1e-6 * abs(a[2])
-    assert set(a[3]) == set(b[3])
-    for k in a[3]:
-        rel = float((a[3][k].double() - b[3][k].double()).norm() / a[3][k].double().norm().clip(min=1e-30))
-        assert rel <= 2e-5, (k, rel)
+def test_bf16_tables_full_size_step_vs_reference():
+    """BASELINE configs[1] at the benchmarked size: the 4096-ray / 128^3 steady-state run of the reference with the forward
+    queries reading bfloat16 copies of the factor tables (TensorVMSplit.set_table_dtype('bf16'); fp32 arithmetic, fp32 masters
+    for the backward walk and Adam).  Bookkeeping replayed as in test_timed_path_vs_reference, so the only difference to the
+    fp32 test is the 8-bit mantissa of every table entry (and of the packed derivative planes): radiance, loss and gradients
+    must stay within what that rounding allows -- bounds measured on the first run and kept with ~3x slack."""
+    g = Golden("e2e_full_steady")
+    nerf = _full_size_model(g)
+    nerf.rf.set_table_dtype("bf16")
+    pins = _pin_reference_bookkeeping(g)
+    out, rec = _timed_step(nerf, g, pins)
+    assert list(rec["n_samples"]) == [int(v) for v in g.np("n_samples")]
+    rgb, ref = pins.trace["rgb_map0"].cpu(), g["rgb_map"]
+    err = (rgb - ref).abs()
+    frac2, _ = _frac_close(rgb, ref, 2e-2, 2e-2)
+    params = dict(nerf.named_parameters())
+    worst_norm, worst_name = 0.0, None
+    for k in g.keys("gradnorm/"):
+        name = k[len("gradnorm/"):]
+        if "roughness" in name or "mipbias" in name:
+            continue
+        r, v = float(g[k]), float(params[name].grad.norm())
+        if abs(v / r - 1) > worst_norm:
+            worst_norm, worst_name = abs(v / r - 1), name
+    rel_loss = abs(out["loss"] / float(g["loss"]) - 1)
+    print(f"bf16 tables vs the fp32 reference: mean |d rgb| {float(err.mean()):.2e}, max {float(err.max()):.2e}, within 2e-2 on "
+          f"{frac2:.4f} of the rays, loss {rel_loss:+.2e}, worst gradient norm {worst_norm:.2e} ({worst_name})")
+    # first run: mean 3.6e-6, max 1.8e-3, loss 6.3e-7, worst gradient norm 5.1e-3 (density line 0)
+    assert float(err.mean()) <= 1.5e-5 and float(err.max()) <= 5e-3 and frac2 == 1.0, (float(err.mean()), float(err.max()), frac2)
+    assert rel_loss <= 1e-5, rel_loss
+    assert worst_norm <= 1.5e-2, (worst_name, worst_norm)
 
 
 def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
