@@ -242,6 +242,17 @@ int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const float* dirs
 int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
                        int64_t R, float mipbias, const float* scalars_dev, int32_t layout, const float* d_out /*[R][3]*/,
                        float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias, void* stream);
+/* The same adjoints for LARGE lookup counts (autograd of modules/integral_equirect.py:18-173,409-504): the table adjoint is
+ * binned instead of scattered with float atomics -- corners counted per 32 x 64-texel SAT tile, written as records into the
+ * caller's workspace, accumulated per tile in LDS as 64-bit fixed point (integer LDS atomics run ~8x faster than float
+ * atomics on gfx950, and the sums do not depend on the order) and flushed once.  d_sat must be given.  workspace: 16-byte
+ * aligned device memory of nmf_sat_lookup_bwd_workspace_bytes(R) bytes (content irrelevant, overwritten; a smaller pool
+ * still gives correct results: corners that do not fit take the float atomics).  Four launches on `stream`. */
+int64_t nmf_sat_lookup_bwd_workspace_bytes(int64_t R);
+int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
+                              int64_t R, float mipbias, const float* scalars_dev, int32_t layout,
+                              const float* d_out /*[R][3]*/, float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shading helpers.

@@ -154,6 +154,59 @@ __device__ __forceinline__ void box_wrap(const Rect<T>& r, Acc& acc) {
     }
 }
 
+// ---- compacted walk (round 3) ---------------------------------------------------------------------------------------
+// integrate_area_wrap adds up to nine boxes per lookup: (main | top pole wrap | bottom pole wrap) x (as is | right seam
+// wrap | left seam wrap).  Nearly every lookup has the main box only, but among the 64 lanes of a wave some lane needs the
+// seam wraps and some lane a pole wrap almost always, so a lane-per-lookup walk executes ~5 box bodies per wave with a
+// handful of active lanes in four of them.  The kernels below evaluate the MAIN box on every lane and put the extra boxes
+// of a workgroup on a queue in LDS that is then worked off densely (one queue entry per lane).
+// combo = 3 * v + h, v in {main, top, bottom}, h in {as is, right wrap, left wrap}; the order 0..8 is the order in which
+// box_wrap / box_lr add the boxes.
+template <class T>
+__device__ __forceinline__ void env_combo_rect(const Rect<T>& r, int combo, Rect<T>& out) {
+    const int v = combo / 3, h = combo % 3;
+    Rect<T> q = r;
+    if (v != 0) {
+        const float rot = val(r.x0) > 0.f ? -1.f : 1.f;
+        q.x0 = r.x0 + rot; q.x1 = r.x1 + rot;
+        if (v == 1) {
+            const T over = d_clip(r.y1 - 1.f, 0.f, 0.5f);
+            q.y1 = set_val(r.y1, 1.f);
+            q.y0 = 1.f - over;
+        } else {
+            const T over = d_clip(-1.f - r.y0, 0.f, 0.5f);
+            q.y0 = set_val(r.y0, -1.f);
+            q.y1 = over - 1.f;
+        }
+    }
+    out = q;
+    if (h == 1) { out.x0 = set_val(q.x0, -1.f); out.x1 = q.x1 - 2.f; }
+    else if (h == 2) { out.x0 = q.x0 + 2.f; out.x1 = set_val(q.x1, 1.f); }
+}
+// bit c of the result: combo c is added (c = 1..8; the main box always is)
+__device__ __forceinline__ uint32_t env_combo_mask(float x0, float x1, float y0, float y1) {
+    uint32_t m = 0;
+    if (x1 > 1.f) m |= 1u << 1;
+    if (x0 < -1.f) m |= 1u << 2;
+    const float rot = x0 > 0.f ? -1.f : 1.f;
+    const float qx0 = x0 + rot, qx1 = x1 + rot;
+    const uint32_t lr = 1u | (qx1 > 1.f ? 2u : 0u) | (qx0 < -1.f ? 4u : 0u);
+    if (y1 > 1.f) m |= lr << 3;
+    if (y0 < -1.f) m |= lr << 6;
+    return m;
+}
+struct EnvQueue {
+    uint32_t n;
+    uint16_t item[8 * 256];          // owner thread << 4 | combo
+};
+__device__ __forceinline__ void env_queue_push(EnvQueue& q, uint32_t mask) {
+    while (mask) {
+        const int c = __ffs(mask) - 1;
+        mask &= mask - 1;
+        q.item[atomicAdd(&q.n, 1u)] = (uint16_t)(threadIdx.x << 4 | c);
+    }
+}
+
 template <class T>
 struct Geometry {
     Rect<T> rect;
@@ -215,26 +268,63 @@ struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL s
 };
 
 // ---- kernels -----------------------------------------------------------------------------------
+// Forward lookup: main box on every lane, extra boxes through the queue; an owner adds its boxes in the reference's order
+// (box_wrap), each computed with the same arithmetic as before: the same bits as the lane-per-lookup walk.
 __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                         const float* __restrict__ sa, int64_t R, float mipbias,
                                                         const float* __restrict__ sc,
                                                         const float* __restrict__ pole_rows /*[2][3] top,bot*/,
                                                         float* __restrict__ out) {
+    __shared__ EnvQueue Q;
+    __shared__ float geo[256][5];            // rect + size of every lookup of the workgroup
+    __shared__ float part[256][8][3];        // value of the extra boxes, by owner and combo - 1
+    if (threadIdx.x == 0) Q.n = 0;
+    __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
     if (sc) mipbias = sc[0];
-    const float* q = dirs + r * ld + (ld - 3);            // ld = 6: [origin | direction] ray rows
-    const float a = q[0], b = q[1], c = q[2];
-    Geometry<float> g = env_geometry<float>(tab.H, tab.W, a, b, c, sa[r], mipbias);
-    SumAcc<float> acc;
-    acc.tab = tab;
-    acc.size = g.size;
-    acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
-    box_wrap(g.rect, acc);
+    float total[3] = {0.f, 0.f, 0.f};
+    uint32_t mask = 0;
+    float cy = 0.f;
+    if (r < R) {
+        const float* q = dirs + r * ld + (ld - 3);            // ld = 6: [origin | direction] ray rows
+        const Geometry<float> g = env_geometry<float>(tab.H, tab.W, q[0], q[1], q[2], sa[r], mipbias);
+        cy = g.cy;
+        geo[threadIdx.x][0] = g.rect.x0; geo[threadIdx.x][1] = g.rect.x1; geo[threadIdx.x][2] = g.rect.y0;
+        geo[threadIdx.x][3] = g.rect.y1; geo[threadIdx.x][4] = g.size;
+        SumAcc<float> acc;
+        acc.tab = tab;
+        acc.size = g.size;
+        acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
+        box(g.rect, acc);
+        total[0] = acc.total[0]; total[1] = acc.total[1]; total[2] = acc.total[2];
+        mask = env_combo_mask(g.rect.x0, g.rect.x1, g.rect.y0, g.rect.y1);
+        env_queue_push(Q, mask);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < Q.n; i += blockDim.x) {
+        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
+        Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
+        env_combo_rect(rr, combo, p);
+        SumAcc<float> acc;
+        acc.tab = tab;
+        acc.size = geo[owner][4];
+        acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
+        box(p, acc);
+        part[owner][combo - 1][0] = acc.total[0]; part[owner][combo - 1][1] = acc.total[1]; part[owner][combo - 1][2] = acc.total[2];
+    }
+    __syncthreads();
+    if (r >= R) return;
+    while (mask) {                              // in combo order = the order of integrate_area_wrap
+        const int c = __ffs(mask) - 1;
+        mask &= mask - 1;
+        total[0] = total[0] + part[threadIdx.x][c - 1][0];
+        total[1] = total[1] + part[threadIdx.x][c - 1][1];
+        total[2] = total[2] + part[threadIdx.x][c - 1][2];
+    }
     const float cutoff = 1.f - 2.f / (float)tab.H * 3.f;
-    float v[3] = {acc.total[0] * 1000.f, acc.total[1] * 1000.f, acc.total[2] * 1000.f};
-    if (g.cy > cutoff) { v[0] = pole_rows[3]; v[1] = pole_rows[4]; v[2] = pole_rows[5]; }
-    if (g.cy < -cutoff) { v[0] = pole_rows[0]; v[1] = pole_rows[1]; v[2] = pole_rows[2]; }
+    float v[3] = {total[0] * 1000.f, total[1] * 1000.f, total[2] * 1000.f};
+    if (cy > cutoff) { v[0] = pole_rows[3]; v[1] = pole_rows[4]; v[2] = pole_rows[5]; }
+    if (cy < -cutoff) { v[0] = pole_rows[0]; v[1] = pole_rows[1]; v[2] = pole_rows[2]; }
     out[r * 3] = v[0]; out[r * 3 + 1] = v[1]; out[r * 3 + 2] = v[2];
 }
 
@@ -334,6 +424,466 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_lookup_bwd(EnvTab tab, 
     if (d_mipbias) {   // wave reduction, one atomic per wave
         for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
         if (lane_id() == 0 && dm != 0.f) atomicAdd(d_mipbias, dm);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Binned table adjoint (round 3).  The scatter above sits on the rate of the memory-side float atomics (156 G lane-ops/s,
+// tools/ub/atom2.hip) and LDS float atomics are no faster (ds_add_f32: 200 G lane-ops/s chip-wide, tools/ub/lds_atom.hip),
+// but INTEGER LDS atomics are: ds_add_u64 1.1 - 1.8 T lane-ops/s (tools/ub/lds_atom_int.hip).  So:
+//   1  count    lane per lookup walks its boxes and counts corners per SAT tile (32 x 64 texels; LDS histogram, one
+//               global add per (workgroup, tile)); also the largest |d_out| * 1000 / size of the launch (fixed-point scale)
+//   2  scatter  the same walk writes one 24-byte record per corner into the tile's slice of a record pool
+//               (exclusive scan of the tile counts in every workgroup, ranges reserved per (workgroup, tile))
+//   3  accum    work items of <= ENV_ITEM records of one tile: the 2 x 2 x 3 taps of every record are added with
+//               ds_add_u64 into a (33 x 65 x 3) window of 2^e-scaled 64-bit fixed-point accumulators (e from the launch's
+//               largest contribution: >= 2^-49 of it is resolved, fp32 atomics resolve 2^-24 of the running sum, and integer
+//               sums do not depend on the order), the non-zero entries are flushed to dSAT with one float atomic each.
+// The dual-number role (d_dirs, d_mipbias, pole rows) is instruction-bound and independent of all three: its workgroups
+// are appended to the three launches in shares, so that they fill the CUs next to the LDS / memory-bound passes.
+// The texel values enter the dual numbers contracted with d_out first (one dual number per tap instead of three).
+constexpr int ENV_TILE_H = 32, ENV_TILE_W = 64, ENV_MAX_TILES = 1024, ENV_ITEM = 4096;
+constexpr int ENV_WIN_W = ENV_TILE_W + 1, ENV_WIN_H = ENV_TILE_H + 1, ENV_WIN = ENV_WIN_W * ENV_WIN_H * 3;
+
+struct EnvBinHeader {
+    uint32_t counts[ENV_MAX_TILES];     // corners per tile
+    uint32_t cursor[ENV_MAX_TILES];     // records reserved so far per tile
+    uint32_t gmax_bits;                 // bits of the largest |d_out[c]| * 1000 / size (a non-negative float)
+    uint32_t overflow;                  // corners that did not fit the pool (they took the direct float atomics)
+    uint32_t pad[2];
+};
+struct CornerRec {
+    float w, n, g[3];                   // bilinear fractions, signed contribution per channel
+    uint32_t xy;                        // (y0 - tile y) << 8 | (x0 - tile x)
+};
+
+struct EnvBwdArgs {
+    EnvTab tab;
+    const float* dirs; int ld;
+    const float* sa; int64_t R; float mipbias;
+    const float* sc;
+    const float* d_out;
+    float* d_sat4; float* d_pole; float* d_dirs; float* d_mipbias;
+    EnvBinHeader* hdr; CornerRec* recs; int64_t cap;
+    int ntx, nt;
+};
+
+// dual-number role with the channels contracted: q(x, y) = sum_c go[c] * S_c(x, y)
+struct SumAccQ {
+    EnvTab tab;
+    float go[3];
+    Dual<4> size, total, cur;
+    __device__ void begin() {}
+    __device__ void corner(const Dual<4>& x, const Dual<4>& y, int k) {
+        typedef Dual<4> D;
+        const D ix = (x + 1.f) * ((float)(tab.W - 1) * 0.5f);
+        const D iy = (y + 1.f) * ((float)(tab.H - 1) * 0.5f);
+        const float fx = floorf(ix.v), fy = floorf(iy.v);
+        const D w = ix - fx, n = iy - fy;
+        const D e = 1.f - w, s = 1.f - n;
+        const int x0 = (int)fx, y0 = (int)fy;
+        const bool xi0 = x0 >= 0 && x0 < tab.W, xi1 = x0 + 1 >= 0 && x0 + 1 < tab.W;
+        const bool yi0 = y0 >= 0 && y0 < tab.H, yi1 = y0 + 1 >= 0 && y0 + 1 < tab.H;
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tab.i4) {
+            const float4* p = reinterpret_cast<const float4*>(tab.sat);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a = (xi0 && yi0) ? p[y0 * tab.W + x0] : z;
+            const float4 b = (xi1 && yi0) ? p[y0 * tab.W + x0 + 1] : z;
+            const float4 c = (xi0 && yi1) ? p[(y0 + 1) * tab.W + x0] : z;
+            const float4 d = (xi1 && yi1) ? p[(y0 + 1) * tab.W + x0 + 1] : z;
+            q[0] = go[0] * a.x + go[1] * a.y + go[2] * a.z;
+            q[1] = go[0] * b.x + go[1] * b.y + go[2] * b.z;
+            q[2] = go[0] * c.x + go[1] * c.y + go[2] * c.z;
+            q[3] = go[0] * d.x + go[1] * d.y + go[2] * d.z;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* p = tab.sat + (int64_t)c * tab.H * tab.W;
+                q[0] += go[c] * ((xi0 && yi0) ? p[y0 * tab.W + x0] : 0.f);
+                q[1] += go[c] * ((xi1 && yi0) ? p[y0 * tab.W + x0 + 1] : 0.f);
+                q[2] += go[c] * ((xi0 && yi1) ? p[(y0 + 1) * tab.W + x0] : 0.f);
+                q[3] += go[c] * ((xi1 && yi1) ? p[(y0 + 1) * tab.W + x0 + 1] : 0.f);
+            }
+        }
+        const D v = (e * s) * q[0] + (w * s) * q[1] + (e * n) * q[2] + (w * n) * q[3];
+        if (k == 0) cur = v;
+        else if (k == 1) cur = cur + v;
+        else cur = cur - v;
+    }
+    __device__ void end() { total = total + cur / size; }
+};
+
+// LDS of the dual-number role: queue | rect + size as dual numbers [256][25] | d_out [256][3] | extra-box tangents [256][4]
+constexpr int ENV_DIRS_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (25 + 3 + 4) * 4;
+
+__device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem) {
+    typedef Dual<4> D;
+    EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
+    float (*geo)[25] = reinterpret_cast<float (*)[25]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
+    float (*gos)[3] = reinterpret_cast<float (*)[3]>(geo + 256);
+    float (*extra)[4] = reinterpret_cast<float (*)[4]>(gos + 256);
+    if (threadIdx.x == 0) Q.n = 0;
+    extra[threadIdx.x][0] = extra[threadIdx.x][1] = extra[threadIdx.x][2] = extra[threadIdx.x][3] = 0.f;
+    __syncthreads();
+    const float mipbias = A.sc ? A.sc[0] : A.mipbias;
+    const float cutoff = 1.f - 2.f / (float)A.tab.H * 3.f;
+    const int64_t r = block * ENV_BWD_THREADS + threadIdx.x;
+    float* dq = nullptr;
+    D total = mk_const<4>(0.f);
+    bool walked = false;
+    if (r < A.R) {
+        const float* q = A.dirs + r * A.ld + (A.ld - 3);
+        const float a = q[0], b = q[1], c = q[2];
+        dq = A.d_dirs ? A.d_dirs + r * A.ld + (A.ld - 3) : nullptr;
+        if (dq && A.ld == 6) { dq[-3] = 0.f; dq[-2] = 0.f; dq[-1] = 0.f; }
+        const float go[3] = {A.d_out[r * 3], A.d_out[r * 3 + 1], A.d_out[r * 3 + 2]};
+        const Geometry<float> g = env_geometry<float>(A.tab.H, A.tab.W, a, b, c, A.sa[r], mipbias);
+        const bool bot = g.cy > cutoff, top = g.cy < -cutoff;
+        if (top || bot) {
+            float* qp = A.d_pole + (top ? 0 : 3);
+            atomicAdd(qp, go[0]); atomicAdd(qp + 1, go[1]); atomicAdd(qp + 2, go[2]);
+        } else if (A.d_dirs || A.d_mipbias) {
+            D da = mk_const<4>(a), db = mk_const<4>(b), dc = mk_const<4>(c), dmb = mk_const<4>(mipbias);
+            da.d[0] = 1.f; db.d[1] = 1.f; dc.d[2] = 1.f; dmb.d[3] = 1.f;
+            const Geometry<D> gd = env_geometry<D>(A.tab.H, A.tab.W, da, db, dc, A.sa[r], dmb);
+            const D* src[5] = {&gd.rect.x0, &gd.rect.x1, &gd.rect.y0, &gd.rect.y1, &gd.size};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                geo[threadIdx.x][5 * k] = src[k]->v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) geo[threadIdx.x][5 * k + 1 + i] = src[k]->d[i];
+            }
+            gos[threadIdx.x][0] = go[0]; gos[threadIdx.x][1] = go[1]; gos[threadIdx.x][2] = go[2];
+            SumAccQ acc;
+            acc.tab = A.tab;
+            acc.go[0] = go[0]; acc.go[1] = go[1]; acc.go[2] = go[2];
+            acc.size = gd.size;
+            acc.total = mk_const<4>(0.f);
+            acc.cur = mk_const<4>(0.f);
+            box(gd.rect, acc);
+            total = acc.total;
+            walked = true;
+            env_queue_push(Q, env_combo_mask(gd.rect.x0.v, gd.rect.x1.v, gd.rect.y0.v, gd.rect.y1.v));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
+        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
+        D v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            v[k].v = geo[owner][5 * k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[k].d[j] = geo[owner][5 * k + 1 + j];
+        }
+        Rect<D> rr{v[0], v[1], v[2], v[3]}, p;
+        env_combo_rect(rr, combo, p);
+        SumAccQ acc;
+        acc.tab = A.tab;
+        acc.go[0] = gos[owner][0]; acc.go[1] = gos[owner][1]; acc.go[2] = gos[owner][2];
+        acc.size = v[4];
+        acc.total = mk_const<4>(0.f);
+        acc.cur = mk_const<4>(0.f);
+        box(p, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&extra[owner][j], acc.total.d[j]);
+    }
+    __syncthreads();
+    float dm = 0.f;
+    if (r < A.R) {
+        if (walked) {
+            if (dq) {
+                dq[0] = 1000.f * (total.d[0] + extra[threadIdx.x][0]);
+                dq[1] = 1000.f * (total.d[1] + extra[threadIdx.x][1]);
+                dq[2] = 1000.f * (total.d[2] + extra[threadIdx.x][2]);
+            }
+            dm = 1000.f * (total.d[3] + extra[threadIdx.x][3]);
+        } else if (dq) {
+            dq[0] = 0.f; dq[1] = 0.f; dq[2] = 0.f;
+        }
+    }
+    if (A.d_mipbias) {
+        for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
+        if (lane_id() == 0 && dm != 0.f) atomicAdd(A.d_mipbias, dm);
+    }
+}
+
+// Role of a workgroup when D dual-number workgroups ride along with O workgroups of a pass: every k-th one (k = (O + D) / D),
+// so that both kinds are resident from the start of the launch (appended behind the pass they would only run after it).
+// -> true: dual-number role, idx = its block; false: idx = block of the pass
+__device__ __forceinline__ bool env_role(int own_blocks, int dirs_blocks, int64_t& idx) {
+    const int b = blockIdx.x;
+    if (dirs_blocks <= 0) { idx = b; return false; }
+    const int k = (own_blocks + dirs_blocks) / dirs_blocks;
+    const int m = b / k;
+    if (b % k == k - 1 && m < dirs_blocks) { idx = m; return true; }
+    idx = b - min(dirs_blocks, m);
+    return false;
+}
+
+__device__ __forceinline__ int env_tile_of(int x0, int y0, int ntx) { return (y0 / ENV_TILE_H) * ntx + (x0 / ENV_TILE_W); }
+
+struct CountAcc {
+    uint32_t* hist; int H, W, ntx;
+    __device__ void begin() {}
+    __device__ void corner(float x, float y, int) {
+        int x0, y0; float w, n;
+        corner_taps(H, W, x, y, x0, y0, w, n);
+        atomicAdd(&hist[env_tile_of(x0, y0, ntx)], 1u);
+    }
+    __device__ void end() {}
+};
+
+// the float walk of passes 1 and 2: geometry of this thread's lookup into LDS, main box on `acc`, extra boxes queued
+// -> live (a lookup off the pole rows)
+template <class Acc>
+__device__ __forceinline__ bool env_walk_main(const EnvBwdArgs& A, int64_t r, EnvQueue& Q, float (*geo)[5], Acc& acc, float& inv_size) {
+    const float mipbias = A.sc ? A.sc[0] : A.mipbias;
+    const float cutoff = 1.f - 2.f / (float)A.tab.H * 3.f;
+    if (r >= A.R) return false;
+    const float* q = A.dirs + r * A.ld + (A.ld - 3);
+    const Geometry<float> g = env_geometry<float>(A.tab.H, A.tab.W, q[0], q[1], q[2], A.sa[r], mipbias);
+    if (g.cy > cutoff || g.cy < -cutoff) return false;
+    geo[threadIdx.x][0] = g.rect.x0; geo[threadIdx.x][1] = g.rect.x1; geo[threadIdx.x][2] = g.rect.y0;
+    geo[threadIdx.x][3] = g.rect.y1; geo[threadIdx.x][4] = g.size;
+    inv_size = 1000.f / g.size;
+    box(g.rect, acc);
+    env_queue_push(Q, env_combo_mask(g.rect.x0, g.rect.x1, g.rect.y0, g.rect.y1));
+    return true;
+}
+
+// pass 1
+__global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
+    __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS];
+    int64_t blk;
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
+    float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
+    uint32_t* hist = reinterpret_cast<uint32_t*>(geo + 256);
+    uint32_t* gmax_s = hist + ENV_MAX_TILES;
+    for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS) hist[i] = 0;
+    if (threadIdx.x == 0) { *gmax_s = 0; Q.n = 0; }
+    __syncthreads();
+    const int64_t r = blk * ENV_BWD_THREADS + threadIdx.x;
+    CountAcc acc{hist, A.tab.H, A.tab.W, A.ntx};
+    float inv_size = 0.f;
+    if (env_walk_main(A, r, Q, geo, acc, inv_size)) {
+        const float m = fmaxf(fmaxf(fabsf(A.d_out[r * 3]), fabsf(A.d_out[r * 3 + 1])), fabsf(A.d_out[r * 3 + 2])) * inv_size;
+        if (m > 0.f && m < 3.0e38f) atomicMax(gmax_s, __float_as_uint(m));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
+        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
+        Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
+        env_combo_rect(rr, combo, p);
+        box(p, acc);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS)
+        if (hist[i]) atomicAdd(&A.hdr->counts[i], hist[i]);
+    if (threadIdx.x == 0 && *gmax_s) atomicMax(&A.hdr->gmax_bits, *gmax_s);
+}
+
+// exclusive scans over the tiles (every workgroup of passes 2 and 3 does them for itself): base[i] = first record of tile i,
+// base[nt] = all records; items[i] = first work item of tile i when a tile has ceil(count / ENV_ITEM) of them (may be null)
+__device__ __forceinline__ uint32_t env_block_excl(uint32_t sum, uint32_t* tmp /*[8] LDS*/) {
+    uint32_t incl = sum;
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) tmp[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += tmp[w];
+    return off + incl - sum;
+}
+__device__ __forceinline__ void env_scan_counts(const EnvBinHeader* hdr, int nt, uint32_t* base, uint32_t* items, uint32_t* tmp) {
+    const int per = (nt + ENV_BWD_THREADS - 1) / ENV_BWD_THREADS;          // <= 4 consecutive tiles per thread
+    uint32_t loc[4] = {0, 0, 0, 0}, sum = 0, isum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int i = threadIdx.x * per + j;
+        loc[j] = i < nt ? hdr->counts[i] : 0;
+        sum += loc[j];
+        isum += (loc[j] + ENV_ITEM - 1) / ENV_ITEM;
+    }
+    uint32_t run = env_block_excl(sum, tmp);
+    for (int j = 0; j < per; ++j) {
+        const int i = threadIdx.x * per + j;
+        if (i < nt) base[i] = run;
+        run += loc[j];
+    }
+    if (threadIdx.x == ENV_BWD_THREADS - 1) base[nt] = run;
+    if (items) {
+        uint32_t irun = env_block_excl(isum, tmp);
+        for (int j = 0; j < per; ++j) {
+            const int i = threadIdx.x * per + j;
+            if (i < nt) items[i] = irun;
+            irun += (loc[j] + ENV_ITEM - 1) / ENV_ITEM;
+        }
+        if (threadIdx.x == ENV_BWD_THREADS - 1) items[nt] = irun;
+    }
+    __syncthreads();
+}
+
+struct EmitAcc {
+    uint32_t* rank;         // LDS: running rank of this workgroup inside each tile
+    const uint32_t* resv;   // LDS: first record of this workgroup's range in each tile
+    CornerRec* recs; int64_t cap;
+    float* dsat4; uint32_t* overflow;
+    int H, W, ntx;
+    float g[3];             // d_out[c] * 1000 / size
+    __device__ void begin() {}
+    __device__ void corner(float x, float y, int k) {
+        int x0, y0; float w, n;
+        corner_taps(H, W, x, y, x0, y0, w, n);
+        const int t = env_tile_of(x0, y0, ntx);
+        const int64_t pos = (int64_t)resv[t] + atomicAdd(&rank[t], 1u);
+        const float sgn = k < 2 ? 1.f : -1.f;
+        if (pos < cap) {
+            CornerRec rec;
+            rec.w = w; rec.n = n;
+            rec.g[0] = g[0] * sgn; rec.g[1] = g[1] * sgn; rec.g[2] = g[2] * sgn;
+            rec.xy = (uint32_t)((y0 % ENV_TILE_H) << 8 | (x0 % ENV_TILE_W));
+            recs[pos] = rec;
+        } else {            // pool exhausted: the direct float atomics (correct, slower)
+            if (overflow) atomicAdd(overflow, 1u);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int X = x0 + dx, Y = y0 + dy;
+                    if (X < W && Y < H) {
+                        const float wt = (dx ? w : 1.f - w) * (dy ? n : 1.f - n) * sgn;
+                        float* p = dsat4 + ((int64_t)Y * W + X) * 4;
+                        atomicAdd(p, g[0] * wt); atomicAdd(p + 1, g[1] * wt); atomicAdd(p + 2, g[2] * wt);
+                    }
+                }
+        }
+    }
+    __device__ void end() {}
+};
+
+// pass 2
+constexpr int ENV_SCATTER_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (5 + 3) * 4 + (3 * ENV_MAX_TILES + 1 + 8) * 4;
+__global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
+    __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > ENV_SCATTER_LDS ? ENV_DIRS_LDS : ENV_SCATTER_LDS];
+    int64_t blk;
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
+    float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
+    float (*gs)[3] = reinterpret_cast<float (*)[3]>(geo + 256);
+    uint32_t* base = reinterpret_cast<uint32_t*>(gs + 256);          // [nt + 1]
+    uint32_t* hist = base + ENV_MAX_TILES + 1;
+    uint32_t* resv = hist + ENV_MAX_TILES;
+    uint32_t* tmp = resv + ENV_MAX_TILES;
+    for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS) hist[i] = 0;
+    if (threadIdx.x == 0) Q.n = 0;
+    env_scan_counts(A.hdr, A.nt, base, nullptr, tmp);
+    const int64_t r = blk * ENV_BWD_THREADS + threadIdx.x;
+    // walk 1: corners of this workgroup per tile
+    CountAcc cnt{hist, A.tab.H, A.tab.W, A.ntx};
+    float inv_size = 0.f;
+    const bool live = env_walk_main(A, r, Q, geo, cnt, inv_size);
+    if (live) {
+        gs[threadIdx.x][0] = A.d_out[r * 3] * inv_size; gs[threadIdx.x][1] = A.d_out[r * 3 + 1] * inv_size;
+        gs[threadIdx.x][2] = A.d_out[r * 3 + 2] * inv_size;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
+        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
+        Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
+        env_combo_rect(rr, combo, p);
+        box(p, cnt);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS) {
+        const uint32_t c = hist[i];
+        resv[i] = c ? base[i] + atomicAdd(&A.hdr->cursor[i], c) : 0;
+        hist[i] = 0;
+    }
+    __syncthreads();
+    // walk 2: the records
+    EmitAcc acc;
+    acc.rank = hist; acc.resv = resv; acc.recs = A.recs; acc.cap = A.cap; acc.dsat4 = A.d_sat4; acc.overflow = &A.hdr->overflow;
+    acc.H = A.tab.H; acc.W = A.tab.W; acc.ntx = A.ntx;
+    if (live) {
+        acc.g[0] = gs[threadIdx.x][0]; acc.g[1] = gs[threadIdx.x][1]; acc.g[2] = gs[threadIdx.x][2];
+        Rect<float> rr{geo[threadIdx.x][0], geo[threadIdx.x][1], geo[threadIdx.x][2], geo[threadIdx.x][3]};
+        box(rr, acc);
+    }
+    for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
+        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
+        Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
+        env_combo_rect(rr, combo, p);
+        acc.g[0] = gs[owner][0]; acc.g[1] = gs[owner][1]; acc.g[2] = gs[owner][2];
+        box(p, acc);
+    }
+}
+
+// pass 3
+__global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_accum(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
+    constexpr int OWN_LDS = ENV_WIN * 8 + (2 * ENV_MAX_TILES + 2 + 8) * 4;
+    __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > OWN_LDS ? ENV_DIRS_LDS : OWN_LDS];
+    int64_t blk;
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    unsigned long long* win = reinterpret_cast<unsigned long long*>(smem);
+    uint32_t* base = reinterpret_cast<uint32_t*>(win + ENV_WIN);
+    uint32_t* items = base + ENV_MAX_TILES + 1;
+    uint32_t* tmp = items + ENV_MAX_TILES + 1;
+    env_scan_counts(A.hdr, A.nt, base, items, tmp);
+    const uint32_t n_items = items[A.nt];
+    const float gmax = __uint_as_float(A.hdr->gmax_bits);
+    if (n_items == 0 || !(gmax > 0.f)) return;
+    // |sum| <= ENV_ITEM * gmax < 2^(12 + ilogb(gmax) + 1): scaled by 2^e it stays below 2^62
+    const int e = 49 - ilogbf(gmax);
+    const double scale = ldexp(1.0, e), inv_scale = ldexp(1.0, -e);
+    for (uint32_t item = (uint32_t)blk; item < n_items; item += own_blocks) {
+        int lo = 0, hi = A.nt - 1;                       // the tile whose item range holds `item`
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (items[mid] <= item) lo = mid; else hi = mid - 1;
+        }
+        // (the LAST tile with items[tile] <= item: tiles without records share their prefix value with the next one)
+        const int tile = lo;
+        const uint32_t first = base[tile] + (item - items[tile]) * ENV_ITEM;
+        const uint32_t last = min(first + (uint32_t)ENV_ITEM, base[tile + 1]);
+        for (int i = threadIdx.x; i < ENV_WIN; i += ENV_BWD_THREADS) win[i] = 0ull;
+        __syncthreads();
+        for (uint32_t i = first + threadIdx.x; i < last; i += ENV_BWD_THREADS) {
+            if ((int64_t)i >= A.cap) break;               // (went the direct way in pass 2)
+            const CornerRec rec = A.recs[i];
+            const int lx = rec.xy & 255, ly = rec.xy >> 8;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float wt = (dx ? rec.w : 1.f - rec.w) * (dy ? rec.n : 1.f - rec.n);
+                    if (wt != 0.f) {
+                        unsigned long long* p = win + ((ly + dy) * ENV_WIN_W + lx + dx) * 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            atomicAdd(p + c, (unsigned long long)__double2ll_rn((double)(rec.g[c] * wt) * scale));
+                    }
+                }
+        }
+        __syncthreads();
+        const int ty = tile / A.ntx, tx = tile % A.ntx;
+        // flush: a lane per (texel, channel slot), so that 64 lanes cover 16 consecutive texels = two 128-byte lines
+        for (int i = threadIdx.x; i < ENV_WIN_W * ENV_WIN_H * 4; i += ENV_BWD_THREADS) {
+            const int c = i & 3, t = i >> 2;
+            const int ly = t / ENV_WIN_W, lx = t % ENV_WIN_W;
+            const int Y = ty * ENV_TILE_H + ly, X = tx * ENV_TILE_W + lx;
+            if (c < 3 && Y < A.tab.H && X < A.tab.W) {
+                const long long v = (long long)win[t * 3 + c];
+                if (v != 0) atomicAdd(A.d_sat4 + ((int64_t)Y * A.tab.W + X) * 4 + c, (float)((double)v * inv_scale));
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -505,6 +1055,45 @@ extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const 
     hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
                        (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
+    return NMF_OK;
+}
+
+extern "C" int64_t nmf_sat_lookup_bwd_workspace_bytes(int64_t R) {
+    return (int64_t)sizeof(EnvBinHeader) + (R < 0 ? 0 : R) * 12 * (int64_t)sizeof(CornerRec);
+}
+
+extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
+                                         const float* sa, int64_t R, float mipbias, const float* scalars_dev, int32_t layout,
+                                         const float* d_out, float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(sat && dirs && sa && d_out && d_pole && d_sat && workspace, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: null");
+    NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: dirs_ld must be 3 or 6");
+    const int ntx = (int)cdiv(W, ENV_TILE_W), nty = (int)cdiv(H, ENV_TILE_H);
+    NMF_REQUIRE(ntx * nty <= ENV_MAX_TILES, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: map larger than 1024 tiles of 32 x 64");
+    NMF_REQUIRE(workspace_bytes >= (int64_t)sizeof(EnvBinHeader) + (int64_t)sizeof(CornerRec) && ((uintptr_t)workspace & 15) == 0,
+                NMF_EINVAL, "nmf_sat_lookup_bwd_binned: workspace too small or not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    EnvBwdArgs A;
+    A.tab = EnvTab{sat, H, W, layout == 1};
+    A.dirs = dirs; A.ld = dirs_ld; A.sa = sa; A.R = R; A.mipbias = mipbias; A.sc = scalars_dev; A.d_out = d_out;
+    A.d_sat4 = d_sat; A.d_pole = d_pole; A.d_dirs = d_dirs; A.d_mipbias = d_mipbias;
+    A.hdr = reinterpret_cast<EnvBinHeader*>(workspace);
+    A.recs = reinterpret_cast<CornerRec*>(reinterpret_cast<char*>(workspace) + sizeof(EnvBinHeader));
+    A.cap = (workspace_bytes - (int64_t)sizeof(EnvBinHeader)) / (int64_t)sizeof(CornerRec);
+    A.ntx = ntx; A.nt = ntx * nty;
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(EnvBinHeader), st);
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_sat_lookup_bwd_binned: hipMemsetAsync");
+    const int64_t nb = cdiv(R, ENV_BWD_THREADS);             // lookups: 256 per workgroup in every role
+    // shares of the dual-number workgroups next to the three passes.  Measured on the 247 k lookups of a steady-state step
+    // (tools/env_bwd_bench.py, us): all behind pass 3 155, 30/40/30 156, 50/50/0 144, all next to pass 2 138; direct scatter 176
+    const int64_t d1 = 0, d2 = nb, d3 = nb - d1 - d2;
+    const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
+    hipLaunchKernelGGL(k_env_bin_count, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
+    hipLaunchKernelGGL(k_env_bin_scatter, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
+    hipLaunchKernelGGL(k_env_bin_accum, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+    NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd_binned");
     return NMF_OK;
 }
 

@@ -315,13 +315,24 @@ Tensor segment_sum_wide(const Tensor& vals, int64_t D, const Tensor& offsets, in
 }
 
 OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const Tensor& d_out, const OT& d_sat,
-                  const OT& d_pole, const OT& d_mip, bool want_dirs, const OT& sc, int64_t stream) {
+                  const OT& d_pole, const OT& d_mip, bool want_dirs, const OT& sc, int64_t binned_from, int64_t stream) {
     const int64_t R = dirs.size(0), ld = dirs.size(1);
     const bool i4 = sat.dim() == 3 && sat.size(-1) == 4 && sat.size(0) != 3;
     const int64_t H = i4 ? sat.size(0) : sat.size(-2), W = i4 ? sat.size(1) : sat.size(-1);
     OT d_dirs;
     if (want_dirs) d_dirs = fe(dirs, {R, ld});
     Tensor go = d_out.contiguous();
+    if (d_sat.has_value() && R >= binned_from && ((H + 31) / 32) * ((W + 63) / 64) <= 1024) {
+        // binned table adjoint; the record pool comes from the stream-ordered caching allocator per call
+        const int64_t nbytes = nmf_sat_lookup_bwd_workspace_bytes(R);
+        Tensor ws = torch::empty({nbytes}, dirs.options().dtype(torch::kUInt8));
+        check(nmf_sat_lookup_bwd_binned(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
+                                        static_cast<const float*>(vptr(sc)), i4 ? 1 : 0, f32(go), static_cast<float*>(vptr(d_sat)),
+                                        static_cast<float*>(vptr(d_pole)), d_dirs.has_value() ? out(*d_dirs) : nullptr,
+                                        static_cast<float*>(vptr(d_mip)), ws.data_ptr(), nbytes, st(stream)),
+              "nmf_sat_lookup_bwd_binned");
+        return d_dirs;
+    }
     check(nmf_sat_lookup_bwd(f32(sat), (int32_t)H, (int32_t)W, f32(dirs), (int32_t)ld, f32(sa), R, (float)mipbias,
                              static_cast<const float*>(vptr(sc)), i4 ? 1 : 0, f32(go), static_cast<float*>(vptr(d_sat)),
                              static_cast<float*>(vptr(d_pole)), d_dirs.has_value() ? out(*d_dirs) : nullptr,

@@ -63,7 +63,8 @@ EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
-    "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd",
+    "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd", "nmf_sat_lookup_bwd_binned",
+    "nmf_sat_lookup_bwd_workspace_bytes",
     "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
@@ -116,6 +117,7 @@ _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 _lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
 _lib.nmf_argsort_workspace_bytes.restype = C.c_int64
 _lib.nmf_alpha_coarse_words.restype = C.c_int64
+_lib.nmf_sat_lookup_bwd_workspace_bytes.restype = C.c_int64
 
 
 def version():
@@ -560,6 +562,17 @@ def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
     return out
 
 
+# lookups per call from which the table adjoint is binned (three more launches than the direct scatter; measured with
+# tools/env_bwd_bench.py: 47 k lookups 53-73 us against 51 direct, 247 k lookups 138 against 176; in the training step the call
+# sits on a side stream and the step time is the same either way, tools/ab_inprocess.py hip:ENV_BINNED_MIN_LOOKUPS).
+# NMF_ENV_BINNED=0 keeps the direct scatter, =1 bins whatever the count -- tests compare the two
+ENV_BINNED_MIN_LOOKUPS = {"0": 1 << 62, "1": 1}.get(os.environ.get("NMF_ENV_BINNED", ""), 100000)
+
+
+def _cdiv(a, b):
+    return -(-a // b)
+
+
 def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
     """d_sat [H,W,4] / d_pole [2,3] / d_mip [1] are ACCUMULATED into (any may be None except d_pole).  Returns d_dirs; with
     want_mipbias=True (legacy form) a fresh d_mip accumulator is allocated and (d_dirs, d_mip) is returned."""
@@ -569,6 +582,17 @@ def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, wan
     legacy = want_mipbias is not None
     if legacy and want_mipbias and d_mip is None:
         d_mip = torch.zeros(1, dtype=torch.float32, device=dirs.device)
+    if d_sat is not None and R >= ENV_BINNED_MIN_LOOKUPS and _cdiv(H, 32) * _cdiv(W, 64) <= 1024:
+        # many lookups: the binned table adjoint (csrc/env.hip).  The record pool comes from torch's stream-ordered caching
+        # allocator per call: two of these calls may be in flight on different streams (fast_step's side streams)
+        nbytes = int(_lib.nmf_sat_lookup_bwd_workspace_bytes(C.c_int64(R)))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dirs.device)
+        _check(_lib.nmf_sat_lookup_bwd_binned(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
+                                              C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc),
+                                              C.c_int32(layout), _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole),
+                                              _p(d_dirs), _p(d_mip), _p(ws), C.c_int64(nbytes), _stream()),
+               "nmf_sat_lookup_bwd_binned")
+        return (d_dirs, d_mip) if legacy else d_dirs
     _check(_lib.nmf_sat_lookup_bwd(_p(sat, torch.float32), C.c_int32(H), C.c_int32(W), _p(dirs, torch.float32),
                                    C.c_int32(ld), _p(sa, torch.float32), C.c_int64(R), C.c_float(mipbias), _p(sc), C.c_int32(layout),
                                    _p(d_out.contiguous(), torch.float32), _p(d_sat), _p(d_pole), _p(d_dirs), _p(d_mip),
@@ -1071,7 +1095,8 @@ def _install_host_ext():
     def sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
         if want_mipbias is not None:      # legacy return form (tests): the Python wrapper
             return py_sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, want_mipbias, sc)
-        return fx.sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, sc, _stream())
+        return fx.sat_lookup_bwd(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, sc,
+                                 int(g["ENV_BINNED_MIN_LOOKUPS"]), _stream())
 
     def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, grads, max_workgroups=0):
         return fx.brdf_mlp_bwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, d_out, list(grads),

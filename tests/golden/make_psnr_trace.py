@@ -1,7 +1,9 @@
 """Container-only: PSNR after equal iterations at a TRAINED quality level (north_star "PSNR within
 0.05 dB of reference after equal iterations").  Runs the REFERENCE's own `reconstruction()` loop (through
 make_train_trace.run, nothing of the loop modified) on the S2 orbit data set for several seeds, long enough and large enough
-that the reference reaches a trained image, and stores per seed: the initial state dict, the calibrated biases, the CPU
+that the reference reaches a trained image (tools/psnr_probe.py sized the configuration on the GPU: 48^3 grid, 32x32 views,
+1024-ray batches, the reference's own 128 secondary rays per sample and 30000-iteration lr decay reach ~30 dB after 100 and
+~35 dB after 300 iterations; 32 rays per sample never leave 11 dB -- in the reference and in this build alike), and stores per seed: the initial state dict, the calibrated biases, the CPU
 generator state at the first iteration and the test PSNR per view at fixed iterations.  tests/golden/psnr_trace.npz holds
 arrays only.
 
@@ -23,10 +25,13 @@ import make_train_trace as mt  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=3)
-    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--iters", type=int, default=300, help="iterations actually run")
+    ap.add_argument("--lr-iters", type=int, default=30000, help="model.params.n_iters: length of the lr decay (reference default)")
+    ap.add_argument("--rpr", type=int, default=128)
+    ap.add_argument("--retrace", type=int, default=1000)
     ap.add_argument("--grid0", type=int, default=48)
-    ap.add_argument("--grid1", type=int, default=64)
-    ap.add_argument("--upsample-at", type=int, nargs="+", default=[100, 200])
+    ap.add_argument("--grid1", type=int, default=48)
+    ap.add_argument("--upsample-at", type=int, nargs="+", default=[1000000])
     ap.add_argument("--psnr-at", type=int, nargs="+", default=[100, 200, 300])
     ap.add_argument("--res", type=int, default=32)
     ap.add_argument("--train-views", type=int, default=24)
@@ -38,10 +43,10 @@ def main():
     out = {}
     for s in range(a.seeds):
         t0 = time.time()
-        r = mt.run(grid0=a.grid0, grid1=a.grid1, teacher_grid=a.grid1, bg=32, upsample_at=tuple(a.upsample_at), n_iters=a.iters,
+        r = mt.run(grid0=a.grid0, grid1=a.grid1, teacher_grid=a.grid1, bg=32, upsample_at=tuple(a.upsample_at), n_iters=a.lr_iters, stop_at=a.iters,
                    psnr_at=tuple(a.psnr_at), res=a.res, train_views=a.train_views, test_views=a.test_views, seed=20211200 + s,
                    batch=a.batch, max_batch=2 * a.batch, max_samples=40000, max_brdf_rays=(80000, 40000),
-                   target_num_samples=80000, max_retrace=200, rays_per_ray=32, light=True, threads=a.threads)
+                   target_num_samples=80000, max_retrace=a.retrace, rays_per_ray=a.rpr, light=True, threads=a.threads)
         print(f"seed {s}: {time.time() - t0:.0f} s", flush=True)
         for k, v in r.items():
             if k.startswith("init/") or k in ("rng_state_at_loop", "biases", "test_psnr", "seed"):

@@ -36,7 +36,7 @@ from nmf_amd import synthetic, yaml_config  # noqa: E402
 KNOBS = dict(grid0=32, grid1=40, teacher_grid=32, bg=32, upsample_at=(15,), n_iters=40, psnr_at=(10, 20, 30, 40), res=20,
              train_views=10, test_views=2, seed=20211200, batch=512, max_batch=1000, max_samples=20000,
              max_brdf_rays=(40000, 20000), target_num_samples=40000, max_retrace=200, rays_per_ray=32, light=False,
-             threads=8)
+             threads=8, stop_at=None)       # stop_at: leave the loop after that many iterations (n_iters keeps sizing the lr decay)
 
 
 class Cfg(dict):
@@ -248,10 +248,16 @@ def run(**knobs):
     T["test_psnr"] = []
     inner_step = spy_step
 
+    class _Stop(Exception):
+        pass
+
     def spy_step_psnr(opt, *a, **kw):
         out = inner_step(opt, *a, **kw)
         if state["it"] in PSNR_AT:
             T["test_psnr"].append(test_psnr(state["tensorf"]))
+            print(f"iteration {state['it']}: test PSNR {np.round(T['test_psnr'][-1], 3).tolist()}", flush=True)
+        if K["stop_at"] is not None and state["it"] >= K["stop_at"]:
+            raise _Stop()                 # the loop is left as it is; only its length is cut
         return out
 
     torch.optim.Adam.step = spy_step_psnr
@@ -261,13 +267,15 @@ def run(**knobs):
     args.model.arch.rf = args.field                # train.py:911
     try:
         ref_train.reconstruction(args)
+    except _Stop:
+        pass
     finally:
         torch.Tensor.backward = orig_backward
         torch.optim.Adam.step = orig_step
         ref_train.SimpleSampler.nextids = orig_nextids
         ref_train.renderer = orig_renderer
     nerf = state["tensorf"]
-    assert state["it"] == N_ITERS, state["it"]
+    assert state["it"] == (K["stop_at"] or N_ITERS), state["it"]
     per_img = T["test_psnr"][-1]
 
     out = dict(grid0=GRID0, grid1=GRID1, bg_res=BG, upsample_at=UPSAMPLE_AT[0] if len(UPSAMPLE_AT) == 1 else np.asarray(UPSAMPLE_AT),

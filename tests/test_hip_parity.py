@@ -468,6 +468,87 @@ def test_env_interleaved_table_gives_the_same_bits():
         assert float(outs[0][2].abs().sum()) > 0          # the pole rows were exercised
 
 
+@pytest.mark.parametrize("H,R", [(32, 3000), (64, 20000), (512, 250000)])
+def test_env_binned_table_adjoint(H, R, monkeypatch):
+    """nmf_sat_lookup_bwd_binned (corners binned per SAT tile, 64-bit fixed-point LDS accumulation, dual-number role with the
+    channels contracted first) against nmf_sat_lookup_bwd (direct float atomics) on the same lookups -- poles, the phi seam,
+    both ray-row pitches, every footprint size -- and, through the map gradient, against the oracle's autograd
+    (modules/integral_equirect.py:18-173,409-504).  Also: bit-reproducible table adjoint per work item is NOT claimed (the
+    flush of several work items of one tile are float atomics), but two runs must agree to fp32 round-off; a record pool that
+    is far too small still gives the same result (the corners that do not fit take the direct atomics)."""
+    hip = _hip()
+    import ctypes as C
+    gen = torch.Generator().manual_seed(H)
+    W = 2 * H
+    bg = (-0.6 + 0.7 * torch.randn(1, 3, H, W, generator=gen)).to(DEV)
+    act, sat, pole, sat4 = hip.sat_build(bg, pole=True, interleaved=True)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    dirs[:200, 2] = torch.sign(dirs[:200, 2]) * 50.0                     # pole rows
+    dirs[:200] = torch.nn.functional.normalize(dirs[:200], dim=-1)
+    dirs[200:400, 1] = 1e-4 * torch.randn(200, generator=gen)            # the phi = +-pi seam
+    dirs[200:400, 0] = -dirs[200:400, 0].abs()
+    sa = torch.rand(R, generator=gen) * 12 - 10
+    c = torch.randn(R, 3, generator=gen)
+    c[400:500] = 0                                                        # lookups without an adjoint
+    res = {}
+    sd0 = _env_sd(bg.cpu())
+    sd0["bg_module.mipbias"] = torch.tensor(0.3, dtype=torch.float64)
+    mw, mh = O.env_mip_levels(sd0, dirs, sa)
+    size = (((2 ** mw / H / 2) / 2 * (2 * H)) * ((2 ** mh / H) / 2 * H)).detach().float()
+    for ld in (3, 6):
+        rows = dirs.to(DEV) if ld == 3 else torch.cat([torch.randn(R, 3, generator=gen), dirs], dim=1).to(DEV)
+        rows = rows.contiguous()
+        for mode, thr in (("direct", 1 << 62), ("binned", 1)):
+            monkeypatch.setattr(hip, "ENV_BINNED_MIN_LOOKUPS", thr)
+            d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
+            d_dirs = hip.sat_lookup_bwd(sat4, rows, sa.to(DEV), 0.3, c.to(DEV), d_sat, d_pole, d_mip)
+            res[mode] = (d_dirs, d_sat.clone(), d_pole, d_mip, hip.sat_build_bwd(d_sat, bg, act, d_pole))
+        a, b = res["direct"], res["binned"]
+        assert b[0].shape == (R, ld)
+        if ld == 6:
+            assert float(b[0][:, :3].abs().max()) == 0.0
+        scale = float(a[0].abs().max())
+        # direction adjoint: the same derivative with the channels contracted before instead of after the dual-number taps.
+        # d/dx of a bilinear SAT sample is a DIFFERENCE of table entries of magnitude |SAT| times 1000 / size: the two
+        # association orders differ by that cancellation noise (the conditioning of the reference itself, SURVEY F14; same
+        # bound as test_env_lookup_golden_and_gradients uses against the oracle)
+        # per lookup: 8 ulp(|SAT|) * 1000 / size per corner value, times the texel-coordinate gain of a unit direction change
+        noise = (8 * 1.2e-7 * float(sat.abs().max()) * 1000 / size * W * c.abs().amax(dim=1))[:, None].to(DEV)
+        err = (b[0][:, -3:] - a[0][:, -3:]).abs()
+        ok = err <= 5e-3 * a[0][:, -3:].abs() + noise + 1e-6 * scale
+        # (the gain is 1 / sin(theta) times larger next to the poles: a few lookups there exceed the bound)
+        assert float((~ok).float().mean()) <= 2e-4, (int((~ok).sum()), float((err - noise).max()))
+        wide = (size > 16).to(DEV)
+        assert_close(b[0][wide].cpu(), a[0][wide].cpu(), rtol=5e-3, atol=2e-4 * float(a[0][wide].abs().max()), what="d_dirs, wide footprints")
+        assert_close(b[1].cpu(), a[1].cpu(), rtol=1e-4, atol=2e-6 * float(a[1].abs().max()), what="d_sat")
+        assert torch.equal(b[2], a[2]) or float((b[2] - a[2]).abs().max()) <= 1e-5 * float(a[2].abs().max())
+        assert abs(float(b[3]) - float(a[3])) <= 1e-3 * abs(float(a[3])) + 1e-4 * scale
+        assert_close(b[4].cpu(), a[4].cpu(), rtol=1e-3, atol=1e-5 * float(a[4].abs().max()), what="d_bg")
+    # a pool of 1000 records: the rest of the corners go the direct way inside the scatter pass
+    rows = dirs.to(DEV).contiguous()
+    d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
+    d_dirs = torch.empty(R, 3, device=DEV)
+    nbytes = 16 * 1024 + 1000 * 24
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    cc, sa_d = c.to(DEV).contiguous(), sa.to(DEV).contiguous()
+    rc = hip._lib.nmf_sat_lookup_bwd_binned(sat4.data_ptr(), H, W, rows.data_ptr(), 3, sa_d.data_ptr(), R, C.c_float(0.3), None, 1,
+                                            cc.data_ptr(), d_sat.data_ptr(), d_pole.data_ptr(), d_dirs.data_ptr(), d_mip.data_ptr(),
+                                            ws.data_ptr(), nbytes, hip._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    hdr = ws[:8208].view(torch.int32)
+    n_corners, overflow = int(hdr[:1024].sum()), int(hdr[2049])
+    assert n_corners >= 4 * (R - 500) and (overflow > 0) == (n_corners > (nbytes - 8208) // 24), (n_corners, overflow)
+    assert_close(d_sat.cpu(), res["direct"][1].cpu(), rtol=1e-4, atol=2e-6 * float(res["direct"][1].abs().max()), what="d_sat, small pool")
+    if H == 32:                      # the golden fixture's size: the map gradient against the oracle's autograd
+        sd = _env_sd(bg.cpu().clone().requires_grad_(True))
+        sd["bg_module.mipbias"] = torch.tensor(0.3, dtype=torch.float64)
+        d_or = dirs.clone().requires_grad_(True)
+        gb_o, gd_o = torch.autograd.grad((O.env_lookup(sd, d_or, sa) * c).sum(), [sd["bg_module.bg_mat"], d_or])
+        assert_close(res["binned"][4].cpu()[None], gb_o, rtol=2e-3, atol=2e-4 * float(gb_o.abs().max()), what="grad bg_mat vs oracle")
+        assert_close(res["binned"][0][:, 3:].cpu(), gd_o, rtol=5e-3, atol=5e-4 * float(gd_o.abs().max()), what="grad dirs vs oracle")
+
+
 def test_env_spherical_harmonics_golden():
     """a13: IntegralEquirect.get_spherical_harmonics (modules/integral_equirect.py:324-360) THROUGH THE MODULE -- 5000
     prefiltered lookups at mipval -5 on the direction lattice, projected on 9 SH terms and convolved with the clamped-cosine

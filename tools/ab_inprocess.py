@@ -7,6 +7,7 @@ thermal drift and box-to-box differences (4 % between `python bench.py` runs on 
     NAME                 os.environ[NAME] = value            (knobs that are read at call time)
     obj:ATTR             TrainPass attribute, as bool        (obj:overlap 0,1   obj:sparse_normals 0,1)
     attr:NAME            nmf_amd.fast_step module constant   (attr:MLP_SIDE_WGS 64,128,256)
+    hip:NAME             nmf_amd.hip module constant         (hip:ENV_BINNED_MIN_LOOKUPS 16384,4611686018427387904)
     delay:METHOD         busy-wait of <value> us on the host in front of TrainPass.METHOD (delay:_flush_walks 0,100) or,
                          with delay:hip.FUNC, in front of a wrapper of nmf_amd.hip (delay:hip.march_fill 0,50): shows whether
                          the host or the device bounds that stretch of the step
@@ -64,6 +65,8 @@ def main():
             setattr(tr.fast, var[4:], bool(int(v)))
         elif var.startswith("attr:"):
             setattr(fast_step, var[5:], int(v))
+        elif var.startswith("hip:"):
+            setattr(hip, var[4:], int(v))
         else:
             os.environ[var] = v
 

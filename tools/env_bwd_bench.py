@@ -1,0 +1,67 @@
+"""Isolated timing of the environment-map lookup backward on the lookups of a real training step: the arguments of every
+hip.sat_lookup_bwd call of one bench step are captured and replayed (HIP events, nothing else on the device).
+
+    python tools/env_bwd_bench.py [--reps 20]
+Prints per captured call: lookups, direct scatter us, binned us, binned without the direction adjoint us."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from nmf_amd import hip  # noqa: E402
+from nmf_amd.noise import DeviceNoise  # noqa: E402
+from nmf_amd.trainer import Trainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--grid", type=int, default=128)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    nerf, params = bench.build(dev, grid=a.grid)
+    tr = Trainer(nerf, params)
+    batches, focal = bench.make_batches(nerf, 3, bench.CHUNK, 0, dev)
+    noise = DeviceNoise(dev, seed=1)
+    for i in range(2):
+        tr.step(*batches[i], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
+    calls = []
+    orig = hip.sat_lookup_bwd
+
+    def spy(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip=None, want_dirs=True, want_mipbias=None, sc=None):
+        calls.append((sat, dirs.clone(), sa.clone(), mipbias, d_out.clone(), sc))
+        return orig(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, want_dirs, want_mipbias, sc)
+
+    hip.sat_lookup_bwd = spy
+    tr.step(*batches[2], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
+    hip.sat_lookup_bwd = orig
+    torch.cuda.synchronize()
+    H, W = nerf.bg_module.hw()
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.reps):
+            fn()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) / a.reps * 1e3
+
+    for sat, dirs, sa, mipbias, d_out, sc in calls:
+        d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=dev), torch.zeros(2, 3, device=dev), torch.zeros(1, device=dev)
+        out = {}
+        for name, thr, wd in (("direct", 1 << 62, True), ("binned", 1, True), ("binned_no_dirs", 1, False)):
+            hip.ENV_BINNED_MIN_LOOKUPS = thr
+            out[name] = timed(lambda: orig(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip if wd else None, wd, None, sc))
+        torch.cuda.synchronize()
+        print(f"lookups {dirs.shape[0]:7d}  sa mean {float(sa.mean()):6.2f}  direct {out['direct']:7.1f} us  binned {out['binned']:7.1f} us  "
+              f"binned without d_dirs {out['binned_no_dirs']:7.1f} us")
+
+
+if __name__ == "__main__":
+    main()
