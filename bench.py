@@ -367,6 +367,8 @@ def main():
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--mode", choices=("train", "infer"), default="train")
     ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32")
+    ap.add_argument("--retrace", type=int, default=None,
+                    help="max_retrace_rays (default: every secondary ray = the steady state; 1000 = the early phase)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -427,6 +429,8 @@ def main():
 
     torch.manual_seed(20211200)
     nerf, params = build(device, grid=args.grid, table_dtype=args.table_dtype)
+    if args.retrace is not None:
+        nerf.model.max_retrace_rays = [args.retrace]
     timer = KernelTimer()
     workload = (f"S1 solid-cube scene, TensoRF {args.grid}^3 (16+24 comps, {args.table_dtype} tables), env 512x1024, "
                 f"800x800 camera")

@@ -39,6 +39,17 @@ extern "C" {
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
+/* Runtime plumbing for host-side drivers that are built without the HIP headers (nmf_amd/csrc/host_ext.cpp is plain g++ against
+ * the torch headers): events without timing, stream ordering and the start of a size read-back into pinned host memory.  The
+ * reference has no counterpart (its sizes come back through tensor.item() / .sum() host syncs, e.g. samplers/alphagrid.py:357).
+ * nmf_event_synchronize is the one BLOCKING entry point of the library. */
+int nmf_event_create(void** event);
+int nmf_event_destroy(void* event);
+int nmf_event_record(void* event, void* stream);
+int nmf_event_synchronize(void* event);
+int nmf_stream_wait_event(void* stream, void* event);
+int nmf_memcpy_d2h_async(void* dst_host, const void* src_dev, int64_t nbytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sampler: AlphaGridSampler.sample / sample_ray / AlphaGridMask.sample_alpha
  * (samplers/alphagrid.py:131-207, 23-45, 279-370).

@@ -25,7 +25,7 @@ echo "built $out/libnmf_hip.so"
 # g++ against the torch headers, no device code; hip.py works without it (pure-Python wrappers), so a failure is not fatal.
 ext="$out/_nmf_host.so"
 if [ "${NMF_BUILD_HOST_EXT:-1}" = "1" ]; then
-  if [ ! -f "$ext" ] || [ "$here/host_ext.cpp" -nt "$ext" ] || [ "$here/../../include/nmf_hip.h" -nt "$ext" ]; then
+  if [ ! -f "$ext" ] || [ "$here/host_ext.cpp" -nt "$ext" ] || [ "$here/step_core.inc" -nt "$ext" ] || [ "$here/../../include/nmf_hip.h" -nt "$ext" ]; then
     tdir="$(python3 -c 'import torch, os; print(os.path.dirname(torch.__file__))' 2>/dev/null || true)"
     pyinc="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])' 2>/dev/null || true)"
     if [ -n "$tdir" ] && [ -n "$pyinc" ] && g++ -O2 -fPIC -shared -std=c++17 "$here/host_ext.cpp" \

@@ -8,6 +8,9 @@
 // present (NMF_HOST_EXT=0 keeps the pure-Python wrappers); nothing else in the package knows about it.
 #include <torch/extension.h>
 
+#include <algorithm>
+#include <functional>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -665,6 +668,8 @@ void vm_pack_density_into(int64_t p_addr, const std::vector<Tensor>& planes, con
     check(nmf_vm_pack_density(p, a.p, b.p, oc, od, st(stream)), "nmf_vm_pack_density");
 }
 
+#include "step_core.inc"
+
 }  // namespace
 
 PYBIND11_MODULE(_nmf_host, m) {
@@ -716,4 +721,22 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("view_adjoint_to_rays", &view_adjoint_to_rays);
     m.def("select_total", &select_total);
     m.def("bounce_prep_bwd", &bounce_prep_bwd);
+    py::class_<StepCore>(m, "StepCore")
+        .def(py::init<>())
+        .def("chunk", &StepCore::chunk)
+        .def("render", &StepCore::render)
+        .def("begin_step", &StepCore::begin_step)
+        .def("join_early_env", &StepCore::join_early_env)
+        .def("env_was_used", &StepCore::env_was_used)
+        .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
+#define RW(name) .def_readwrite(#name, &StepCore::name)
+        RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
+        RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
+        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
+        RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
+        RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)
+        RW(detach_n) RW(max_brdf_rays) RW(max_retrace_rays) RW(white) RW(one) RW(select_ws) RW(g_dpk) RW(g_dlk) RW(g_apl) RW(g_ali)
+        RW(g_mlp) RW(g_basis) RW(g_hW) RW(g_hb) RW(d_sat) RW(d_pole) RW(d_mip) RW(d_bg_out) RW(used_env) RW(sampler) RW(wait_tables) RW(wait_env)
+#undef RW
+        ;
 }

@@ -14,6 +14,7 @@ else raises Unsupported BEFORE touching an accumulator and the Trainer runs that
 counts, re-trace order, occupancy decisions) is honoured here exactly as in the modules, so the reference's full-size fixtures
 are checked on THIS path (tests/test_hip_timed_path.py).
 Reference spans are the ones cited in functional.py for each call."""
+import ctypes
 import os
 import types
 
@@ -80,6 +81,18 @@ class TrainPass:
         self._early_env = None
         self._side = {}
         self._main = None
+        # the same pass as ONE C++ call per chunk (csrc/step_core.inc, in lib/_nmf_host.so): the methods below stay the
+        # specification and the path for bf16 tables / NMF_STEP_CORE=0 / a missing host extension
+        self._core = None if os.environ.get("NMF_STEP_CORE", "1") != "0" else False
+        self._core_key = None
+        self._core_keep = None
+        self._core_acc = None
+        self._march_blocks = None
+        self._token_params = None
+        self._tables_token = None
+        self._table_events = None
+        self._core_static = None
+        self._core_retrace = None
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -87,12 +100,185 @@ class TrainPass:
         m = n.model
         return (len(m.max_retrace_rays) <= 1 and n.bg_module is not None and not n.hdr and getattr(m.brdf, "fused", False))
 
+    # ---- the C++ pass ----------------------------------------------------------------------------------------------
+    _CORE_STREAMS = (("mlp", 0), ("mlp", 1), ("env", 0), ("env", 1), ("walk", 1), "sat_bwd")
+
+    def core(self):
+        """-> lib/_nmf_host.so's StepCore configured for this model, or None (Python pass)"""
+        if self._core is False or self.nerf.rf.table_dtype != "f32":
+            return None
+        if self._core is None:
+            fx = hip.HOST_EXT
+            if fx is None or not hasattr(fx, "StepCore"):
+                self._core = False
+                return None
+            self._core = fx.StepCore()
+        return self._core
+
+    def _param_token(self):
+        """(version, storage) of every parameter the derived tables are built from: equal token = equal tables"""
+        ps = self._token_params
+        if ps is None:
+            n = self.nerf
+            ps = self._token_params = (list(n.rf._param_list()) + list(n.model.diffuse_module._head_params())
+                                       + list(n.model.brdf._weights()) + [n.bg_module.bg_mat, n.bg_module.mipbias,
+                                                                          n.bg_module.brightness, n.bg_module.mul])
+        return tuple([p._version for p in ps]), tuple([p.data_ptr() for p in ps])
+
+    def _core_tables(self, dev):
+        """The per-step rebuilds (packed density tables, stacked head / MLP weights, env-map SAT, SH irradiance) queued on a
+        SIDE stream, with two events the C++ pass makes the main stream wait for where the results are first read (field query;
+        first env-map use).  Called by prefetch() right after the optimizer step -- the device then rebuilds while the host
+        prepares the next step and the sampler of the next step starts without the ~130 us of rebuild kernels in front of it --
+        or by the first chunk that finds its tables stale."""
+        c, n = self._core, self.nerf
+        rf, model, bgm, smp = n.rf, n.model, n.bg_module, n.sampler
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            tb = self._side.get("tables")
+            if tb is None:
+                tb = self._side["tables"] = torch.cuda.Stream()
+                self._table_events = (torch.cuda.Event(), torch.cuda.Event())
+            tb.wait_stream(main)                      # the optimizer update of the parameters was queued on the main stream
+            torch.cuda.set_stream(tb)
+        try:
+            tab = rf._fwd_tables()
+            hp, hW, hb, _, _ = model.diffuse_module.head_pass()
+            mlp_ws, mlp_bias, _, _ = model.brdf.mlp_pass()
+            if self.overlap:
+                self._table_events[0].record(tb)
+            env = bgm._tables()
+            sc = bgm._dev_scalars()
+            conv = bgm.get_spherical_harmonics(100)[1].reshape(9, 3)
+            if self.overlap:
+                self._table_events[1].record(tb)
+        finally:
+            if self.overlap:
+                torch.cuda.set_stream(main)
+        key = (ctypes.addressof(tab[0]), tab[1][0].data_ptr(), tab[3][0].data_ptr(), tab[5].data_ptr(), bgm._cache[1][3].data_ptr(),
+               hW.data_ptr(), mlp_ws[0].data_ptr(), model.brdf_sampler.angs.data_ptr(), main.cuda_stream, self.overlap, id(smp))
+        if self._core_key != key:
+            self._core_key = key
+            p, dpk, dlk, apl, ali, basis = tab
+            c.vm_p, c.dpk, c.dlk, c.apl, c.ali, c.basis = ctypes.addressof(p), list(dpk), list(dlk), list(apl), list(ali), basis
+            c.head_W, c.head_b, c.mlp_ws = hW, hb, list(mlp_ws)
+            c.sobol = model.brdf_sampler.angs
+            c.env_table, c.env_pole, c.env_act = bgm._cache[1][3], env[2], env[0]
+            c.env_bg = bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1])
+            c.white, c.one = _white(dev), _one(dev)
+            c.select_ws = hip.select_total_workspace(dev)
+            c.scale = float(rf.distance_scale)
+            c.max_brdf_rays = [int(v) for v in model.max_brdf_rays]
+            c.rays_per_ray, c.test_rays_per_ray = float(model.rays_per_ray), float(model.test_rays_per_ray)
+            c.sampler = smp
+            c.overlap = bool(self.overlap)
+            c.main_stream, c.main_stream_obj, c.set_stream = main.cuda_stream, main, torch.cuda.set_stream
+            if self.overlap:
+                for k in self._CORE_STREAMS:
+                    if k not in self._side:
+                        self._side[k] = torch.cuda.Stream()
+                objs = [self._side[k] for k in self._CORE_STREAMS]
+                c.side_stream_objs, c.side_streams = objs, [o.cuda_stream for o in objs]
+            else:
+                c.side_stream_objs, c.side_streams = [], []
+            self._core_keep = (tab, env, hW, hb, mlp_ws, main)
+        c.head_p, c.mlp_bias = [float(v) for v in hp], float(mlp_bias)
+        c.env_sc, c.sh_conv = sc, conv
+        if self.overlap:
+            c.wait_tables, c.wait_env = self._table_events[0].cuda_event, self._table_events[1].cuda_event
+        else:
+            c.wait_tables, c.wait_env = 0, 0
+        self._tables_token = self._param_token()
+
+    @torch.no_grad()
+    def prefetch(self):
+        """Trainer.step calls this after the optimizer step (and the schedule): the next step's derived tables"""
+        if self.core() is None or self._acc_cache is None or not self.supported():
+            return
+        self._core_tables(self._acc_cache.flat.device)
+
+    def _core_sync(self, dev, focal, is_train):
+        """hands the C++ pass what it reads: the tables (rebuilt here only when no prefetch() left them current), then the few
+        per-chunk values"""
+        c, n = self._core, self.nerf
+        model, smp = n.model, n.sampler
+        if self._tables_token is None or self._tables_token != self._param_token():
+            self._core_tables(dev)
+        st = (self.sparse_normals, MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV, WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS,
+              int(hip.ENV_BINNED_MIN_LOOKUPS), int(smp.max_samples), float(model.anoise))
+        if st != self._core_static:
+            self._core_static = st
+            c.sparse_normals = bool(self.sparse_normals)
+            c.mlp_side_min_rays, c.mlp_side_min_env_rays, c.mlp_side_wgs_env = MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV
+            c.walk_side_min_samples, c.mlp_side_wgs, c.env_binned_from = WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS, int(hip.ENV_BINNED_MIN_LOOKUPS)
+            c.max_samples, c.anoise = int(smp.max_samples), float(model.anoise)
+        packed, blk0 = smp.params_block(focal, None, is_train)
+        _, blk1 = smp.params_block(focal, 3 * float(hip.host(smp.stepsize)), is_train)
+        if self._march_blocks is None or self._march_blocks[0] is not blk0 or self._march_blocks[1] is not blk1:
+            self._march_blocks = (blk0, blk1, packed)
+            c.march_p0, c.march_p1 = ctypes.addressof(blk0[1]), ctypes.addressof(blk1[1])
+            c.alpha_bits, c.alpha_coarse = (packed[1], packed[2]) if packed is not None else (None, None)
+        c.min_rough, c.detach_n = float(model.min_rough), bool(model.detach_N)
+        mr = [int(v) for v in model.max_retrace_rays]
+        if mr != self._core_retrace:
+            self._core_retrace = mr
+            c.max_retrace_rays = mr
+        return c
+
+    def _core_chunk(self, c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last):
+        rf = self.nerf.rf
+        dev = rays.device
+        mods = [m for m in (rf, self.nerf.bg_module, self.nerf.model.brdf, self.nerf.model.diffuse_module) if hasattr(m, "begin_pass")]
+        for m in mods:
+            m.begin_pass()
+        try:
+            self._core_sync(dev, focal, True)
+            a = self._accumulators(dev)
+            if self._core_acc is not a:
+                self._core_acc = a
+                c.g_dpk, c.g_dlk, c.g_apl, c.g_ali, c.g_mlp = list(a.g_dpk), list(a.g_dlk), list(a.g_apl), list(a.g_ali), list(a.g_mlp)
+                c.g_basis, c.g_hW, c.g_hb, c.d_sat, c.d_pole, c.d_mip = a.g_basis, a.g_hW, a.g_hb, a.d_sat, a.d_pole, a.d_mip
+                bgm = self.nerf.bg_module
+                if a.d_bg is None:
+                    a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
+                c.d_bg_out = a.d_bg if self.overlap else None
+            c.used_env = bool(a.used_env)
+
+            def total_of(loss, ori, acc):
+                dens = list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)
+                l1 = hip.l1_mean_fwd([x.detach() for x in dens])
+                return hip.loss_mix_fwd([loss, l1, ori, acc], wts, inv_lbatch)
+
+            try:
+                out = c.chunk(rays, gt, float(focal), noise, float(inv_lbatch), [float(w) for w in wts], bool(want_total), bool(last),
+                              total_of)
+            except RuntimeError as e:
+                if "Unsupported" in str(e):
+                    raise Unsupported(str(e)) from None
+                raise
+            a.used_env = bool(c.env_was_used())
+            if c.env_table_backward_queued():
+                self._early_env = ("core", a.d_bg)
+            if out["loss"] is None:
+                return dict(loss=None, kept=out["kept"], n_samples=[0])
+            pins = getattr(noise, "pins", None)
+            if pins is not None and pins.trace is not None:
+                pass                                  # (the C++ pass wrote rgb_map0 / acc_map0 / whole_valid0 ... itself)
+            self.n_loss_chunks += 1
+            self.l1_scale += float(wts[1]) * float(inv_lbatch)
+            return dict(loss=out["loss"], total=out["total"], kept=out["kept"], n_samples=list(out["n_samples"]))
+        finally:
+            for m in mods:
+                m.end_pass()
+
     # ---- accumulators of one optimizer step ------------------------------------------------------------------------
     def begin_step(self):
         self.acc = None
         self._early_env = None
         self.n_loss_chunks = 0
         self.l1_scale = 0.0
+        if self._core:
+            self._core.begin_step()
 
     def _accumulators(self, dev):
         """The gradient state of an optimizer step.  Allocated ONCE per (grid, env size): the flat accumulator buffer, its
@@ -489,6 +675,18 @@ class TrainPass:
         for m in mods:
             m.begin_pass()
         try:
+            core = self.core()
+            if core is not None:
+                self._core_sync(rays.device, focal, False)
+                try:
+                    out = core.render(rays, float(focal), noise)
+                except RuntimeError as e:
+                    if "Unsupported" in str(e):
+                        raise Unsupported(str(e)) from None
+                    raise
+                if out is None:
+                    raise Unsupported("no sample")
+                return out[0], out[1], out[2], list(out[3])
             self._begin(rays.device, noise)
             t = self._fwd(0, rays, focal, None, noise, is_train=False, filler=self._begin_tables)
             if t.M == 0:
@@ -507,6 +705,9 @@ class TrainPass:
         nerf = self.nerf
         if not self.supported():
             raise Unsupported("configuration")
+        core = self.core()
+        if core is not None:
+            return self._core_chunk(core, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
         dev = rays.device
         mods = [m for m in (rf, bgm, model.brdf, model.diffuse_module) if hasattr(m, "begin_pass")]
@@ -574,7 +775,10 @@ class TrainPass:
             sc = bgm._dev_scalars()
             if self._early_env is not None:
                 fork, d_bg = self._early_env
-                self._join(fork)
+                if fork == "core":
+                    self._core.join_early_env()
+                else:
+                    self._join(fork)
                 self._early_env = None
             else:
                 d_bg = a.d_bg = hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc, out=a.d_bg)

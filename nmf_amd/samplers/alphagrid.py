@@ -179,21 +179,7 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
                 seed, off = 0x9E3779B9, self._calls
             else:
                 jitter, (seed, off) = noise.jitter(B, N)
-        # the geometry half of the parameter block only changes with the mask / the step size: kept per (near, far, focal, ...)
-        # and copied (filling the ctypes struct field by field costs 10 us per call)
-        packed = self.alphaMask._packed() if use_mask else None
-        stepsize = float(hip.host(self.stepsize))
-        ck = (near, far, float(focal), N, bool(is_train), stepsize, use_mask)
-        owner = (self.aabb, self.aabb._version, self.alphaMask if use_mask else None, packed[0] if use_mask else None)
-        hit = self._params_cache.get(ck)
-        ho = hit[0] if hit is not None else None         # the entry holds its tensors: identities cannot be reused
-        if ho is None or ho[0] is not owner[0] or ho[1] != owner[1] or ho[2] is not owner[2] or ho[3] != owner[3]:
-            if len(self._params_cache) > 8:
-                self._params_cache.clear()
-            hit = self._params_cache[ck] = (owner, hip.march_params(
-                self.aabb, hip.host(self.alphaMask.invgrid_size) if use_mask else None, stepsize, near, far, focal, N,
-                [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train, 0, 0,
-                occ_box=packed[3] if use_mask else None))
+        packed, hit = self.params_block(focal, near, is_train)
         p = hip.MarchParams.from_buffer_copy(hit[1])
         p.seed, p.offset = int(seed), int(off)
         rays = rays_chunk.contiguous()
@@ -214,6 +200,30 @@ class AlphaGridSampler(FastPrivateAttrs, torch.nn.Module):
         rb = hip.Readback.of(dev)
         rb.start(totals)
         return (rb, p, rays, jitter, valid, offsets, wv, N)
+
+    def params_block(self, focal, near=None, is_train=False):
+        """-> (packed alpha mask or None, (owners, nmf_march_params block)) for rays that start at `near` (default: the scene's
+        near plane).  The geometry half of the parameter block only changes with the mask / the step size: kept per (near, far,
+        focal, ...) and copied by the caller (filling the ctypes struct field by field costs 10 us per call); seed / offset of the
+        jitter are the caller's.  The C++ training pass (csrc/step_core.inc) reads the block by address."""
+        N = int(self.nSamples)
+        far = self.near_far[1]
+        near = self.near_far[0] if near is None else float(near)
+        use_mask = self.alphaMask is not None and self.enable_alpha_mask
+        packed = self.alphaMask._packed() if use_mask else None
+        stepsize = float(hip.host(self.stepsize))
+        ck = (near, far, float(focal), N, bool(is_train), stepsize, use_mask)
+        owner = (self.aabb, self.aabb._version, self.alphaMask if use_mask else None, packed[0] if use_mask else None)
+        hit = self._params_cache.get(ck)
+        ho = hit[0] if hit is not None else None         # the entry holds its tensors: identities cannot be reused
+        if ho is None or ho[0] is not owner[0] or ho[1] != owner[1] or ho[2] is not owner[2] or ho[3] != owner[3]:
+            if len(self._params_cache) > 8:
+                self._params_cache.clear()
+            hit = self._params_cache[ck] = (owner, hip.march_params(
+                self.aabb, hip.host(self.alphaMask.invgrid_size) if use_mask else None, stepsize, near, far, focal, N,
+                [int(g) for g in hip.host(self.alphaMask.grid_size)] if use_mask else None, is_train, 0, 0,
+                occ_box=packed[3] if use_mask else None))
+        return packed, hit
 
     def sample_finish(self, pending):
         rb, p, rays, jitter, valid, offsets, wv, N = pending

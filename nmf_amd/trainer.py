@@ -318,6 +318,8 @@ class Trainer:
             self.batch.reset()
             nerf.model.reset_counter()
         self.iteration += 1
+        if fast is not None:
+            fast.prefetch()           # next step's derived tables, on a side stream behind this optimizer update
         return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes, chunks=n_chunks,
                          reduce=self.reduce)
 

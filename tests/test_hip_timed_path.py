@@ -27,6 +27,8 @@ def _timed_step(nerf, g, pins, n_rays=None):
     nerf.bg_module.brightness_lr = nerf.bg_module.mul_lr = 1e-12
     tr = Trainer(nerf, resolved_config()["params"])
     assert tr.fast is not None and tr.fast.supported()
+    if nerf.rf.table_dtype == "f32":
+        assert tr.fast.core() is not None, "the C++ pass (lib/_nmf_host.so StepCore) is what bench.py times: it must be the one tested"
     tr.optimizer.step = lambda: None                               # keep the gradients, leave the parameters alone
     tr.optimizer.step_unhooked = lambda: None
     calls = []
