@@ -72,51 +72,13 @@ def build(device, grid=None, table_dtype="f32"):
     return nerf, resolved_config()["params"]
 
 
-class KernelTimer:
-    """HIP events around every nmf_vm_query_bwd / nmf_vm_query_bwd_segments call (issued on torch's current stream, which is
-    the stream the C ABI launches on) -> per-launch duration of the dominant kernel inside the timed region."""
+class RebuildCounter:
+    """per-step derived tables must be rebuilt after every optimizer update (packed density planes, SAT): count the rebuilds
+    inside the timed region so a stale cache (= skipped work) shows up in the report"""
 
     def __init__(self):
-        import torch
-        from nmf_amd import hip, functional
-        self.torch = torch
-        self.records = []
+        from nmf_amd import hip
         self.enabled = False
-        orig = hip.vm_query_bwd
-
-        def wrapped(p, xyzt, *a, **k):
-            if not self.enabled:
-                return orig(p, xyzt, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(p, xyzt, *a, **k)
-            e.record()
-            dens = a[7] is not None or a[8] is not None or a[9] is not None      # d_sigma / d_sigma_feat / d_normal
-            app = a[10] is not None                                              # d_app
-            self.records.append((s, e, int(xyzt.shape[0]), (2 if a[9] is not None else 1) if dens else 0, app))
-            return r
-
-        hip.vm_query_bwd = wrapped
-        functional.hip.vm_query_bwd = wrapped
-        orig_segs = hip.vm_query_bwd_segments
-
-        def wrapped_segs(p, segs, *a, **k):      # the training pass walks its sample sets together (functional.py)
-            if not self.enabled:
-                return orig_segs(p, segs, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_segs(p, segs, *a, **k)
-            e.record()
-            m = sum(int(sg[0].shape[0]) for sg in segs)
-            dens = any(sg[3] is not None or sg[4] is not None or sg[5] is not None for sg in segs)
-            dens = (2 if any(sg[5] is not None for sg in segs) else 1) if dens else 0      # 2: with the normal adjoint
-            app = any(sg[6] is not None for sg in segs)
-            self.records.append((s, e, m, dens, app))
-            return r
-
-        hip.vm_query_bwd_segments = wrapped_segs
-        # per-step derived tables must be rebuilt after every optimizer update (packed density planes, SAT): count the
-        # rebuilds inside the timed region so a stale cache (= skipped work) shows up in the report
         self.rebuilds = {"vm_pack_density": 0, "sat_build": 0}
         for name in self.rebuilds:
             fn = getattr(hip, name)
@@ -128,24 +90,72 @@ class KernelTimer:
 
             setattr(hip, name, counted)
 
-    def summary(self, kind=None):
-        """-> total ms, algorithmic bytes, issued MFMA flop, samples, launches of the walks of one kind (1: value-only density
-        walk, 2: density walk with the normal adjoint, None: all calls incl. appearance)"""
-        all_records = self.records
-        if kind is not None:
-            self.records = [r for r in all_records if r[3] == kind and not r[4]]
-        try:
-            return self._summary()
-        finally:
-            self.records = all_records
 
-    def _summary(self):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        nbytes = sum(m * ((BWD_BYTES_DENSITY if d == 2 else BWD_BYTES_VALUE if d == 1 else 0) + BWD_BYTES_APP * a)
-                     for _, _, m, d, a in self.records)
-        flop = sum(m * ((MFMA_FLOP_DENSITY if d == 2 else MFMA_FLOP_VALUE if d == 1 else 0) + MFMA_FLOP_APP * a)
-                   for _, _, m, d, a in self.records)
-        return ms, nbytes, flop, sum(r[2] for r in self.records), len(self.records)
+# ---- per-call roofline models -------------------------------------------------------------------------------------------
+# Every C-ABI call of the step is timed with HIP events on the stream it launches on (csrc/host_ext.cpp CallTimer).  For the calls
+# whose ceiling has a simple algorithmic model the live fraction is computed here; `bound` says which ceiling that is:
+#   mfma     issued / algorithmic FLOP against the 157.3 TFLOP/s f32-input MFMA peak (BRDF MLP: 17 152 FLOP per ray forward,
+#            2 x that backward; field walk: issued v_mfma_f32_16x16x4_f32 FLOP, its real ceiling is MFMA + VALU issue:
+#            `alu_busy` of the counter run beside it)
+#   atomics  lane-level float atomics against the 156 G/s the memory-side units sustain on the 8-lane pattern (tools/ub/atom2.hip)
+#   hbm      algorithmic bytes against 8 TB/s (tables are L2 / MALL resident: a fraction above 1 means the model does not bound it)
+#   alu / latency   no algorithmic model: the counter fractions of profiles/<tag>_roofline.json are reported beside the time
+MLP_FWD_FLOP, ATOMIC_PEAK = 2 * 8576, 156e9
+ADAM_BYTES_PER_PARAM = 28
+
+
+def call_models(sz, n_params):
+    """sz: sizes of one step (rays B, samples M0 M1, secondary rays R0 R1, bounce rows Mb0 Mb1) -> {call: (bound, work, peak)}"""
+    B, M0, M1, R0, R1, Mb0, Mb1 = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1"))
+    walk_flop = (M0 + Mb1) * MFMA_FLOP_DENSITY + M1 * MFMA_FLOP_VALUE + (Mb0 + Mb1) * MFMA_FLOP_APP
+    return {
+        "brdf_mlp_bwd": ("mfma", 2 * MLP_FWD_FLOP * (R0 + R1), MFMA_F32_PEAK_TFLOPS * 1e12),
+        "brdf_mlp_fwd": ("mfma", MLP_FWD_FLOP * (R0 + R1), MFMA_F32_PEAK_TFLOPS * 1e12),
+        "vm_query_bwd_segments": ("mfma", walk_flop, MFMA_F32_PEAK_TFLOPS * 1e12),
+        "sat_lookup_bwd": ("atomics", 48.0 * (R0 + R1), ATOMIC_PEAK),            # 4 corners x 4 texels x 3 channels per box
+        "sat_lookup_fwd": ("hbm", 192.0 * (R0 + R1 + 5000), HBM_PEAK_GBS * 1e9),
+        "vm_query_fwd": ("hbm", float(M0 * G_DENSITY + M1 * 1152 + (Mb0 + Mb1) * G_APP), HBM_PEAK_GBS * 1e9),
+        "vm_query_rows": ("hbm", float(Mb1 * G_DENSITY), HBM_PEAK_GBS * 1e9),
+        "march_count": ("alu", None, None), "march_fill": ("alu", None, None),
+        "adam_step": ("hbm", float(ADAM_BYTES_PER_PARAM * n_params), HBM_PEAK_GBS * 1e9),
+    }
+
+
+def per_call_table(timing, steps, sz, n_params, counters):
+    """timing: {call: (ms, calls)} over `steps` instrumented steps -> rows sorted by time"""
+    models = call_models(sz, n_params)
+    ks = (counters or {}).get("kernels", {})
+    ctr_of = {"brdf_mlp_bwd": "k_brdf_mlp_bwd", "brdf_mlp_fwd": "k_brdf_mlp_fwd", "sat_lookup_bwd": "k_env_lookup_bwd",
+              "sat_lookup_fwd": "k_env_lookup_fwd", "march_count": "k_march_count16", "march_fill": "k_march_fill16",
+              "adam_step": "k_adam", "vm_query_fwd": "k_vm_sigma"}
+    rows = {}
+    for name, (ms, calls) in sorted(timing.items(), key=lambda kv: -kv[1][0]):
+        us = 1e3 * ms / steps
+        bound, work, peak = models.get(name, ("latency", None, None))
+        rec = {"us_per_step": round(us, 1), "calls_per_step": round(calls / steps, 2), "bound": bound}
+        if work is not None and us > 0:
+            rec["achieved"] = work / (us * 1e-6)
+            rec["frac"] = round(rec["achieved"] / peak, 4)
+        else:
+            rec["frac"] = None
+        d = ks.get(ctr_of.get(name, ""), {}).get("derived")
+        if d:
+            rec["counters"] = {k: d[k] for k in ("alu_busy", "mfma_busy", "hbm_frac", "l2_frac", "waves_per_simd") if k in d}
+        rows[name] = rec
+    return rows
+
+
+def step_bytes(sz, grid, n_params):
+    """SURVEY 8(d) bytes of one optimizer step (every tap charged to HBM, dense appearance and normals on every sample) and the
+    bytes the pass needs after sparse appearance / sparse normals (values for the re-traced samples, appearance + normals on the
+    bounce rows only); fwd + bwd = 4 x forward (1 read + 1 recompute read + read-modify-write of the gradients)."""
+    B, M0, M1, R0, R1, Mb0, Mb1 = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1"))
+    fixed = 2 * 3 * BG_RES * 2 * BG_RES * 4 + 3 * (3 * 16 * grid * grid * 4) + ADAM_BYTES_PER_PARAM * n_params
+    n_steps = sz.get("N", 440)
+    survey = 4 * 4800 * (M0 + M1) + 576 * (R0 + R1 + B) + n_steps * (B + R0) + 40 * B + fixed
+    needed = (4 * (M0 * G_DENSITY + M1 * 1152 + Mb1 * G_DENSITY + (Mb0 + Mb1) * G_APP) + 576 * (R0 + R1) + n_steps * (B + R0) + 40 * B
+              + fixed)
+    return survey, needed
 
 
 def physical_cores():
@@ -312,7 +322,74 @@ def time_infer(nerf, device, frames, warm_chunks=8):
     return dt, rays.shape[0] * frames, chunk
 
 
-def extras(device, params, focal):
+SCHEDULE = ((128, 2000), (162, 1000), (196, 1000), (231, 1500), (265, 1500), (300, 23000))   # grid, iterations at it
+
+
+def psnr_at_iter(device):
+    """BASELINE metric, second half ("PSNR@iter"): the 300-iteration S2 orbit run of tests/golden/psnr_trace.npz -- the
+    configuration on which the REFERENCE's own training loop was run for three seeds in the build container
+    (tests/golden/make_psnr_trace.py: 48^3, 24 views of 32 x 32, 1024-ray batches, the reference's lr schedule) -- trained
+    here from the reference's seed-0 initial parameters with device noise; test PSNR (8-bit formula, renderer.py:399-401)
+    at the iterations the reference was evaluated at, next to the reference's 3-seed mean."""
+    import numpy as np
+    import torch
+    from nmf_amd.config import build_model, resolved_config
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.renderer import psnr_8bit, render_images
+    from nmf_amd.trainer import Trainer
+    path = os.path.join(ROOT, "tests", "golden", "psnr_trace.npz")
+    if not os.path.exists(path):
+        return dict(error="tests/golden/psnr_trace.npz missing")
+    g = np.load(path)
+    G0, BG, res = int(g["grid0"]), int(g["bg_res"]), int(g["res"])
+    ov = dict(line.split("=", 1) for line in str(g["overrides"]).split("\n"))
+    ints = lambda k: [int(v) for v in ov[k].strip("[]").split(",")]  # noqa: E731
+    over = {"sampler.update_list": [10 ** 9], "rf.upsamp_list": [10 ** 9], "rf.N_voxel_init": G0 ** 3, "rf.N_voxel_final": G0 ** 3,
+            "sampler.max_samples": ints("model.arch.sampler.max_samples")[0], "model.max_brdf_rays": ints("model.arch.model.max_brdf_rays"),
+            "model.target_num_samples": ints("model.arch.model.target_num_samples"),
+            "model.max_retrace_rays": ints("model.arch.model.max_retrace_rays"), "model.rays_per_ray": ints("model.arch.model.rays_per_ray")[0]}
+    nerf, _ = build_model(grid=G0, bg_resolution=BG, device=device, overrides=over)
+    nerf.load_state_dict({k[len("s0/init/"):]: torch.as_tensor(g[k]) for k in g.files if k.startswith("s0/init/")}, strict=False)
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in g["s0/biases"])
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=True)
+    mn, mx, start, target = (int(v) for v in g["params_params"])
+    params = dict(resolved_config()["params"], n_iters=int(ov["model.params.n_iters"]), batch_size=mn, min_batch_size=mn,
+                  max_batch_size=mx, starting_batch_size=start, target_num_samples=target)
+    tr = Trainer(nerf, params)
+    rays_tr, rgb_tr = torch.as_tensor(g["rays_train"]).to(device), torch.as_tensor(g["rgb_train"]).to(device)
+    rays_te, rgb_te = torch.as_tensor(g["rays_test"]).to(device), torch.as_tensor(g["rgb_test"]).to(device)
+    focal, n_views = float(g["focal"]), rays_te.shape[0] // (res * res)
+    noise = DeviceNoise(device, seed=2024)
+    gen = torch.Generator(device=device).manual_seed(1)
+    n_total = rays_tr.shape[0]
+    perm, cur = torch.randperm(n_total, device=device, generator=gen), 0
+    at = [int(v) for v in g["psnr_at"]]
+    out, t0, rays_seen = {}, time.perf_counter(), 0
+    for it in range(at[-1]):
+        nb = tr.lbatch_size()
+        if cur + nb > n_total:
+            perm, cur = torch.randperm(n_total, device=device, generator=gen), 0
+        ids = perm[cur:cur + nb]
+        cur += nb
+        st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
+        rays_seen += st["rays"]
+        if it + 1 in at:
+            nerf.eval()
+            pred = render_images(nerf, rays_te, focal, 4096, noise, draw_debug=True)
+            nerf.train()
+            pv, gv = pred.reshape(n_views, -1, 3), rgb_te.reshape(n_views, -1, 3)
+            out[str(it + 1)] = round(float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(n_views)]).mean()), 3)
+    torch.cuda.synchronize()
+    ref = np.stack([g[f"s{s_}/test_psnr"].mean(-1) for s_ in range(int(g["n_seeds"]))])
+    return dict(test_psnr_db=out, reference_mean_db={str(a_): round(float(v), 3) for a_, v in zip(at, ref.mean(0))},
+                reference_seed_stderr_db={str(a_): round(float(v), 3) for a_, v in zip(at, ref.std(0, ddof=1) / np.sqrt(ref.shape[0]))},
+                train_rays_per_s_incl_evals=round(rays_seen / (time.perf_counter() - t0), 1),
+                config=f"S2 orbit, TensoRF {G0}^3, env {BG}x{2 * BG}, {res}x{res} views, {mn}-ray batches, one run (seed-0 initial "
+                       "parameters of the reference run); 3-seed parity test: tests/test_hip_timed_path.py")
+
+
+def extras(device, params, focal, main_ms=None, main_rays=None):
     """Driver-visible side measurements (N = 1 only, outside the timed region of `value`)."""
     import torch
     from nmf_amd.noise import DeviceNoise
@@ -342,11 +419,26 @@ def extras(device, params, focal):
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     del nerf
     torch.cuda.empty_cache()
-    nerf300, _ = build(device, grid=300)
-    out["grid_300"] = train_ms(nerf300, CHUNK, 30, 8)
+    per_grid = {}
+    for G, _w in SCHEDULE[1:]:
+        nerf_g, _ = build(device, grid=G)
+        per_grid[G] = train_ms(nerf_g, CHUNK, 30 if G == 300 else 16, 8 if G == 300 else 5)
+        del nerf_g
+        torch.cuda.empty_cache()
+    out["grid_300"] = per_grid[300]
     out["grid_300"]["note"] = "final grid of the schedule: 300^3, 1036 steps per ray, 41 MB of factor tables"
-    del nerf300
-    torch.cuda.empty_cache()
+    if main_ms is not None:
+        # the reference's 30 000-iteration schedule spends 2000 iterations at 128^3 and 23 000 at 300^3: the
+        # rays/s of a whole training run = rays of all iterations / time of all iterations, one 4096-ray chunk per iteration
+        rows = {128: dict(ms_per_step=main_ms, rays_per_step=main_rays)}
+        rows.update({G: dict(ms_per_step=r["ms_per_step"], rays_per_step=r["rays_per_s"] * r["ms_per_step"] * 1e-3) for G, r in per_grid.items()})
+        t_all = sum(w * rows[G]["ms_per_step"] * 1e-3 for G, w in SCHEDULE)
+        r_all = sum(w * rows[G]["rays_per_step"] for G, w in SCHEDULE)
+        out["schedule_weighted"] = dict(rays_per_s=r_all / t_all, hours_for_30000_iterations=t_all / 3600,
+                                        per_grid={str(G): {k: round(v, 3) for k, v in rows[G].items()} for G, _ in SCHEDULE},
+                                        note="steady-state step at every grid of the upsampling schedule, weighted by the iterations "
+                                             "spent there; kept rays per chunk fall with the grid (200 k-sample budget)")
+    out["psnr_at_iter"] = psnr_at_iter(device)
     try:
         nerf16, _ = build(device, table_dtype="bf16")
     except (AttributeError, NotImplementedError) as e:
@@ -431,7 +523,8 @@ def main():
     nerf, params = build(device, grid=args.grid, table_dtype=args.table_dtype)
     if args.retrace is not None:
         nerf.model.max_retrace_rays = [args.retrace]
-    timer = KernelTimer()
+    timer = RebuildCounter()
+    from nmf_amd import hip as hip_mod
     workload = (f"S1 solid-cube scene, TensoRF {args.grid}^3 (16+24 comps, {args.table_dtype} tables), env 512x1024, "
                 f"800x800 camera")
 
@@ -458,12 +551,24 @@ def main():
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
     noise = DeviceNoise(device, seed=1000 + rank)
     batches, focal = make_batches(nerf, args.warmup + args.steps, args.rays_per_gpu, rank, device)
+    fx = hip_mod.HOST_EXT
+    timed_calls = fx is not None and hasattr(fx, "call_timing_begin") and trainer.fast is not None and trainer.fast.core() is not None
+    n_probe = min(args.warmup, 8) if timed_calls else 0
     timer.enabled = False
+    dominant = None
     for i in range(args.warmup):
+        if n_probe and i == args.warmup - n_probe:
+            fx.call_timing_begin()                  # the last warm-up steps find the dominant call of this workload
         trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
+    if n_probe:
+        probe = fx.call_timing_end()
+        dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
     sync()
     timer.enabled = True
+    if dominant:
+        fx.call_timing_begin(dominant)              # inside the timed region: events around the dominant call only
     dt, rays_done, last, comm_ms = time_train(trainer, batches, focal, noise, 0, args.steps, CHUNK, sync)
+    dom_live = fx.call_timing_end().get(dominant) if dominant else None
     timer.enabled = False
 
     tt = torch.tensor([dt, float(rays_done), 1.0], dtype=torch.float64, device=device)
@@ -478,23 +583,60 @@ def main():
     chunks_per_step = -(-args.rays_per_gpu // CHUNK)
     if min(timer.rebuilds.values()) < args.steps:
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
+    # ---- after the timed region: every C-ABI call of the step timed (events on the launching stream), 30 more steps
+    table, sizes, n_params = None, None, sum(p.numel() for p in nerf.parameters() if p.requires_grad)
+    if timed_calls and rank == 0:
+        n_inst = 30
+        fx.call_timing_begin()
+        for i in range(n_inst):
+            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
+        timing = fx.call_timing_end()
+        ls = trainer.fast.last_sizes
+        sizes = dict(B=int(ls["rays"]), M0=int(ls["n_samples"][0]), M1=int(ls["n_samples"][1]) if len(ls["n_samples"]) > 1 else 0,
+                     R0=int(ls["n_rays"][0]), R1=int(ls["n_rays"][1]) if len(ls["n_rays"]) > 1 else 0,
+                     Mb0=int(ls["n_rows"][0]), Mb1=int(ls["n_rows"][1]) if len(ls["n_rows"]) > 1 else 0, N=int(nerf.sampler.nSamples))
+        table = per_call_table(timing, n_inst * chunks_per_step, sizes, n_params, counters_summary())
     if rank == 0:
-        # the largest field walk of the step: the value-only walk of the re-traced samples (sparse normals), else the full one
-        walk_kind = 1 if any(r[3] == 1 and not r[4] for r in timer.records) else 2
-        walk_key = "k_vm_bwd_density<value>" if walk_kind == 1 else "k_vm_bwd_density<normal>"
-        k_ms, k_bytes, k_flop, k_samples, k_launches = timer.summary(walk_kind)
-        avg_ms = k_ms / max(k_launches, 1)
-        alg_gbs = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        mfma_tflops = k_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         ctr = counters_summary()
-        traffic, per_kernel, ctr_meta = None, None, None
-        if ctr is not None:
-            ks = ctr.get("kernels", {})
-            traffic = ks.get(walk_key, ks.get("k_vm_bwd_brick<density>", {})).get("hbm_bytes_per_launch")
-            # counter-derived figures of every kernel of the step (bound = the largest of mfma_busy / valu_busy / l2 / hbm)
-            per_kernel = {k: dict(v.get("derived", {}), avg_launch_us=v.get("avg_launch_us")) for k, v in ks.items()
-                          if "derived" in v}
-            ctr_meta = {k: ctr.get(k) for k in ("tag", "commit", "command")}
+        ctr_meta = {k: ctr.get(k) for k in ("tag", "commit", "command")} if ctr else None
+        roof = {"note": "the host extension with call timing is not available: no per-call table"}
+        if table:
+            dname = dominant if dominant in table else next(iter(table))
+            drow = table[dname]
+            models = call_models(sizes, n_params)
+            bound, work, peak = models.get(dname, ("latency", None, None))
+            live_us = 1e3 * dom_live[0] / max(dom_live[1], 1) if dom_live else None          # per launch, inside the timed region
+            calls_per_step = dom_live[1] / args.steps if dom_live else drow["calls_per_step"]
+            achieved = (work / calls_per_step) / (live_us * 1e-6) if (work and live_us) else None
+            unit = {"mfma": "TFLOP/s", "hbm": "GB/s", "atomics": "G lane-atomics/s"}.get(bound, "")
+            scale = {"mfma": 1e12, "hbm": 1e9, "atomics": 1e9}.get(bound, 1.0)
+            survey_b, needed_b = step_bytes(sizes, args.grid, n_params)
+            ms_step = 1e3 * dt_max / args.steps
+            fabric = None
+            if ctr:
+                fabric = sum(v.get("hbm_bytes_per_launch", 0) * table.get(k2, {}).get("calls_per_step", 0)
+                             for k2, v in ((kk, ctr["kernels"].get(ck, {})) for kk, ck in
+                                           (("brdf_mlp_bwd", "k_brdf_mlp_bwd"), ("sat_lookup_bwd", "k_env_lookup_bwd"),
+                                            ("vm_query_bwd_segments", "k_vm_bwd_density<value>"), ("adam_step", "k_adam"))))
+            roof = {
+                # the dominant C-ABI call of the step by summed device time, found in the warm-up and timed with HIP events on its
+                # launching stream INSIDE the timed region
+                "kernel": "nmf_" + dname, "bound": "mfma" if bound == "mfma" else ("hbm" if bound in ("hbm", "atomics") else bound),
+                "bound_detail": bound, "achieved": achieved / scale if achieved else None, "peak": peak / scale if peak else None,
+                "unit": unit, "frac": (achieved / peak) if (achieved and peak) else None,
+                "traffic": (ctr or {}).get("kernels", {}).get("k_" + dname, {}).get("hbm_bytes_per_launch") if ctr else None,
+                "launches": dom_live[1] if dom_live else None, "avg_launch_us": live_us,
+                "work_per_step": work, "work_model": "2 x 17 152 FLOP per secondary ray (SURVEY 8d: the a18 contraction, backward = dX + dW)"
+                if dname == "brdf_mlp_bwd" else "see call_models() in bench.py",
+                "per_kernel": table, "sizes_per_step": sizes,
+                "step": {"survey_8d_bytes": survey_b, "algorithmic_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         "needed_bytes": needed_b, "needed_over_hbm": needed_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         "fabric_bytes_counters_partial": fabric,
+                         "device_time_sum_us": round(sum(r["us_per_step"] for r in table.values()), 1), "wall_us": round(1e3 * ms_step, 1),
+                         "note": "tables (7.5 MB at 128^3) are L2 / MALL resident: the byte models do not bound the step; it is bound by "
+                                 "the dependent chain of ~115 launches, the MLP matrix rate and float atomics (per_kernel)"},
+                "counters": ctr_meta,
+            }
         out = {
             "metric": "train rays/sec (microfacet_tensorf2, 4096-ray chunks, steady state)",
             "value": rays_all / dt_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -502,44 +644,24 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.table_dtype == "f32" else "bf16 tables / f32 arithmetic",
             "data": "synthetic",
             "config": {"workload": workload + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {CHUNK}, "
-                                   "fwd+bwd+all-reduce+Adam, all secondary rays re-traced (steady state); stands in for "
-                                   f"BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not available "
-                                   "offline)",
+                                   "fwd+bwd+all-reduce+Adam, " + ("all secondary rays re-traced (steady state)" if args.retrace is None
+                                                                  else f"{args.retrace} secondary rays re-traced") +
+                                   f"; stands in for BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not "
+                                   "available offline: scene S1 of SURVEY 8d)",
                        "rays_per_gpu": args.rays_per_gpu, "chunks_per_step": chunks_per_step, "grid": args.grid,
                        "samples_per_chunk": last["n_samples"], "samples_per_chunk_first_step": last["first_n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                        "backend": backend if (world > 1 or single_rank_comm) else None,
-                       "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"]},
-            # Dominant kernel: the backward walk of the VM field (table-gradient scatter-add on the matrix cores).  Its
-            # ceiling is the SIMD's ALU pipe: on gfx950 an fp32 MFMA and the other VALU instructions do not overlap
-            # (tools/ub/coexec.hip), so MFMA cycles and VALU cycles add up.
-            #   `achieved` / `frac`: ISSUED v_mfma_f32_16x16x4_f32 FLOP of the launches of the timed region / their HIP-event
-            #         time (events on the launch stream), against the 157.3 TFLOP/s fp32 MFMA peak = live MFMA-busy share
-            #   `alu_busy_counters`: MFMA-busy + VALU-issue share of the density walk from the committed counter run
-            #         (tools/roofline_metrics.py) -- the fraction of the kernel's real ceiling
-            #   `algorithmic_over_hbm`: SURVEY 8(d) bytes / time against 8 TB/s (can exceed 1: the 7.5 MB of factor tables
-            #         live in L2/MALL and tiles accumulate in registers); `traffic` = fabric bytes per launch from PMC
-            "roofline": {"bound": "mfma",
-                         "kernel": "nmf_vm_query_bwd_segments, " + ("value-only walk of the re-traced samples" if walk_kind == 1
-                                                                    else "density walk with normals") +
-                                   " (binning + " + walk_key + "; runs next to the shading backward on a side stream)",
-                         "achieved": mfma_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": mfma_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "launches": k_launches, "avg_launch_ms": avg_ms,
-                         "samples_per_launch": k_samples / max(k_launches, 1),
-                         "algorithmic_bytes_per_sample": {"density value (re-traced samples)": BWD_BYTES_VALUE,
-                                                          "density+normals (primary samples, bounce rows)": BWD_BYTES_DENSITY,
-                                                          "appearance (bounce rows)": BWD_BYTES_APP},
-                         "algorithmic_GBps": alg_gbs, "algorithmic_over_hbm": alg_gbs / HBM_PEAK_GBS,
-                         "hbm_frac_counters": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
-                         "alu_busy_counters": (per_kernel or {}).get(walk_key, (per_kernel or {}).get("k_vm_bwd_brick<density>", {})).get("alu_busy"),
-                         "counters": ctr_meta, "per_kernel": per_kernel},
+                       "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"],
+                       "host_pass": "C++ (csrc/step_core.inc)" if timed_calls else "python (nmf_amd/fast_step.py)"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID \
                 and args.table_dtype == "f32":
             del trainer
-            out["extras"] = extras(device, params, focal)
+            out["extras"] = extras(device, params, focal, main_ms=1e3 * dt_max / args.steps, main_rays=rays_all / args.steps)
+            out["psnr_at_iter"] = out["extras"].get("psnr_at_iter")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -44,6 +44,8 @@ const char* nmf_last_error_string(void);
  * reference has no counterpart (its sizes come back through tensor.item() / .sum() host syncs, e.g. samplers/alphagrid.py:357).
  * nmf_event_synchronize is the one BLOCKING entry point of the library. */
 int nmf_event_create(void** event);
+int nmf_event_create_timed(void** event);                        /* with timestamps, for nmf_event_elapsed_ms */
+int nmf_event_elapsed_ms(void* start, void* stop, float* ms);   /* both recorded and complete */
 int nmf_event_destroy(void* event);
 int nmf_event_record(void* event, void* stream);
 int nmf_event_synchronize(void* event);

@@ -37,3 +37,16 @@ extern "C" int nmf_memcpy_d2h_async(void* dst_host, const void* src_dev, int64_t
     hipError_t r = hipMemcpyAsync(dst_host, src_dev, (size_t)nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
     return r == hipSuccess ? NMF_OK : nmf_fail((int)r, "nmf_memcpy_d2h_async");
 }
+extern "C" int nmf_event_create_timed(void** event) {
+    NMF_REQUIRE(event, NMF_EINVAL, "nmf_event_create_timed: null");
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return nmf_fail((int)r, "nmf_event_create_timed: hipEventCreate");
+    *event = (void*)e;
+    return NMF_OK;
+}
+extern "C" int nmf_event_elapsed_ms(void* start, void* stop, float* ms) {
+    NMF_REQUIRE(ms, NMF_EINVAL, "nmf_event_elapsed_ms: null");
+    hipError_t r = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    return r == hipSuccess ? NMF_OK : nmf_fail((int)r, "nmf_event_elapsed_ms");
+}

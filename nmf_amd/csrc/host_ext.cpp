@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
 #include <memory>
 #include <string>
 #include <tuple>
@@ -66,6 +67,36 @@ Tensor ie(const Tensor& like, at::IntArrayRef shape, at::ScalarType st) { return
 float* out(Tensor& t) { return static_cast<float*>(t.data_ptr()); }
 void* st(int64_t stream) { return reinterpret_cast<void*>(stream); }
 
+// ---- optional per-call device timing (bench.py: per-kernel table of the step) --------------------------------------------
+// When a CallTimer is active, every wrapper below records an event in front of and behind its C-ABI call on the stream it
+// launches on; report() turns them into {call name: (summed ms, calls)}.  Inactive: one pointer test per call.
+struct CallTimer {
+    struct Rec { const char* name; void* a; void* b; };
+    std::vector<void*> pool;
+    size_t next = 0;
+    std::vector<Rec> recs;
+    void* ev() {
+        if (next == pool.size()) {
+            void* e = nullptr;
+            check(nmf_event_create_timed(&e), "nmf_event_create_timed");
+            pool.push_back(e);
+        }
+        return pool[next++];
+    }
+    ~CallTimer() { for (void* e : pool) nmf_event_destroy(e); }
+};
+CallTimer* g_call_timer = nullptr;
+std::string g_call_filter;           // non-empty: only the wrapper of that name is timed (the dominant call inside the timed region)
+struct TimedScope {
+    const char* name; void* stream; void* a = nullptr;
+    TimedScope(const char* n, int64_t s) : name(n), stream(reinterpret_cast<void*>(s)) {
+        if (g_call_timer && (g_call_filter.empty() || g_call_filter == n)) { a = g_call_timer->ev(); nmf_event_record(a, stream); }
+    }
+    ~TimedScope() {
+        if (a && g_call_timer) { void* b = g_call_timer->ev(); nmf_event_record(b, stream); g_call_timer->recs.push_back({name, a, b}); }
+    }
+};
+
 struct P3 {
     const float* p[3];
 };
@@ -79,6 +110,7 @@ P3 three(const std::vector<Tensor>& ts) {
 // ---- sampler --------------------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor> march_count(int64_t p_addr, const Tensor& rays, const OT& jitter, const OT& alpha_bits,
                                        const OT& alpha_coarse, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_march_params*>(p_addr);
     const int64_t B = rays.size(0), W = (p->n_steps + 63) / 64;
     Tensor valid = ie(rays, {B, W}, at::kLong), counts = ie(rays, {B}, at::kInt);
@@ -90,6 +122,7 @@ std::tuple<Tensor, Tensor> march_count(int64_t p_addr, const Tensor& rays, const
 }
 
 std::tuple<Tensor, Tensor, Tensor> march_scan(const Tensor& counts, int64_t max_samples, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t B = counts.size(0);
     Tensor offsets = ie(counts, {B + 1}, at::kLong), whole = ie(counts, {B}, at::kByte), totals = ie(counts, {2}, at::kLong);
     const int64_t nbytes = nmf_march_scan_workspace_bytes(B);
@@ -104,6 +137,7 @@ std::tuple<Tensor, Tensor, Tensor> march_scan(const Tensor& counts, int64_t max_
 std::tuple<Tensor, Tensor, Tensor, OT, Tensor> march_fill(int64_t p_addr, const Tensor& rays, int64_t b, int64_t M,
                                                          const OT& jitter, const Tensor& valid, const Tensor& offsets,
                                                          bool want_z, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_march_params*>(p_addr);
     Tensor xyzt = fe(rays, {M, 4}), ray_id = ie(rays, {M}, at::kInt), step_id = ie(rays, {M}, at::kInt), dist = fe(rays, {M});
     OT z;
@@ -120,6 +154,7 @@ std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xy
                                                 const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl,
                                                 const std::vector<Tensor>& ali, const OT& basis, bool want_density,
                                                 bool want_normal, bool want_app, bool want_coef, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     const int64_t M = xyzt.size(0);
     OT sf, sg, gr, nr, ap, cf;
@@ -142,6 +177,7 @@ std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xy
 // ---- compositing ------------------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor> composite_fwd(const Tensor& sigma, const Tensor& dist, const Tensor& offsets, int64_t b,
                                          double distance_scale, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t M = sigma.size(0);
     Tensor weight = fe(sigma, {M}), acc = fe(sigma, {b});
     if (M == 0) {
@@ -154,6 +190,7 @@ std::tuple<Tensor, Tensor> composite_fwd(const Tensor& sigma, const Tensor& dist
 }
 
 Tensor segment_sum(const Tensor& vals, const OT& scale, const Tensor& offsets, int64_t n_seg, int64_t lanes, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t D = vals.size(1);
     Tensor o = fe(vals, {n_seg, D});
     if (vals.size(0) == 0) {
@@ -169,6 +206,7 @@ Tensor segment_sum(const Tensor& vals, const OT& scale, const Tensor& offsets, i
 // ---- environment map --------------------------------------------------------------------------------------------------
 Tensor sat_lookup_fwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const OT& pole_rows,
                       const OT& sc, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = dirs.size(0), ld = dirs.size(1);
     const bool i4 = sat.dim() == 3 && sat.size(-1) == 4 && sat.size(0) != 3;          // [H][W][4] (nmf_sat_build's sat_i4)
     const int64_t H = i4 ? sat.size(0) : sat.size(-2), W = i4 ? sat.size(1) : sat.size(-1);
@@ -183,6 +221,7 @@ Tensor sat_lookup_fwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, d
 // ---- shading ------------------------------------------------------------------------------------------------------------
 Tensor select_bounces(const Tensor& weights, const Tensor& u, int64_t mode, double mul, double add, double sum_w,
                       const OT& sum_w_dev, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t M = weights.size(0);
     Tensor counts = ie(weights, {M}, at::kInt);
     check(nmf_select_bounces(f32(weights), f32(u), M, (int32_t)mode, (float)mul, (float)add,
@@ -193,6 +232,7 @@ Tensor select_bounces(const Tensor& weights, const Tensor& u, int64_t mode, doub
 }
 
 std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg, int64_t total, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor seg = ie(offsets, {total}, at::kInt), loc = ie(offsets, {total}, at::kInt);
     check(nmf_expand_segments(i64(offsets), n_seg, static_cast<int32_t*>(seg.data_ptr()),
                               static_cast<int32_t*>(loc.data_ptr()), st(stream)),
@@ -202,6 +242,7 @@ std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg,
 
 Tensor brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
                     const Tensor& rough_src, const OT& src_idx, double out_bias, int64_t max_workgroups, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     if (w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor o = fe(half_vec, {R, 3});
@@ -213,6 +254,7 @@ Tensor brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
 }
 
 Tensor heads_fwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     if (hp.size() != 5) fail("heads_fwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
     const int64_t M = feat.size(0);
     Tensor o = fe(feat, {M, 11});
@@ -226,6 +268,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> ggx_rays_fwd(const Te
                                                                         const Tensor& x, const Tensor& off, const Tensor& cnt,
                                                                         const Tensor& sobol, const Tensor& row_of_ray,
                                                                         const Tensor& j_of_ray, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor L = fe(V, {R, 3}), hl = fe(V, {R, 3}), dl = fe(V, {R, 3}), lpdf = fe(V, {R}), mip = fe(V, {R}), rays = fe(V, {R, 6});
     check(nmf_ggx_rays_fwd(f32(V), f32(N), f32(r), f32(x), f32(off), i32(cnt), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
@@ -236,6 +279,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> ggx_rays_fwd(const Te
 
 Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, const Tensor& cnt, const Tensor& row_of_ray,
                      const Tensor& L, const Tensor& inc, const Tensor& brdf, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor contrib = fe(V, {R, 3});
     check(nmf_shade_mix_fwd(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf),
@@ -245,6 +289,7 @@ Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, cons
 }
 
 py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t M = counts.size(0), M1 = M > 0 ? M : 1;
     Tensor bidx = ie(counts, {M1}, at::kInt), row_off = ie(counts, {M + 1}, at::kLong), inv = ie(counts, {M1}, at::kInt);
     Tensor cnt_rows = ie(counts, {M1}, at::kInt), totals = ie(counts, {2}, at::kLong);
@@ -266,6 +311,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_f
     const Tensor& bidx, const Tensor& normals, const Tensor& app, const Tensor& heads, const Tensor& xyzt, const Tensor& ray_id,
     const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough, int64_t row_inputs,
     int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t Mb = bidx.size(0);
     Tensor V = fe(normals, {Mb, 3}), N = fe(normals, {Mb, 3}), r1 = fe(normals, {Mb}), f0 = fe(normals, {Mb, 3});
     Tensor diff = fe(normals, {Mb, 3}), feat = fe(normals, {Mb, 24}), xyz = fe(normals, {Mb, 3});
@@ -282,6 +328,7 @@ std::tuple<Tensor, Tensor, Tensor, OT> ray_compose_fwd(const Tensor& weight, con
                                                        const OT& normals, const Tensor& rays, const Tensor& offsets, int64_t B,
                                                        const Tensor& bg, bool bg_per_ray, bool tonemap, bool noclip,
                                                        bool want_ori, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor rgb_map = fe(weight, {B, 3}), acc = fe(weight, {B}), rgb_lin = fe(weight, {B, 3});
     OT ori;
     if (want_ori) ori = fe(weight, {B});
@@ -297,6 +344,7 @@ std::tuple<Tensor, Tensor, Tensor, OT> ray_compose_fwd(const Tensor& weight, con
 // ---- backward wrappers (the step is GPU-bound there on a fast host, host-bound on a loaded one) ----------------------
 Tensor composite_bwd(const Tensor& sigma, const Tensor& dist, const Tensor& weight, const Tensor& offsets, int64_t b,
                      double distance_scale, const Tensor& d_weight, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor d_sigma = at::empty_like(sigma);
     if (sigma.size(0) == 0) return d_sigma;
     Tensor dw = d_weight.contiguous();
@@ -307,6 +355,7 @@ Tensor composite_bwd(const Tensor& sigma, const Tensor& dist, const Tensor& weig
 }
 
 Tensor segment_sum_wide(const Tensor& vals, int64_t D, const Tensor& offsets, int64_t n_seg, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor o = fe(vals, {n_seg, D});
     if (vals.size(0) == 0) {
         o.zero_();
@@ -319,6 +368,7 @@ Tensor segment_sum_wide(const Tensor& vals, int64_t D, const Tensor& offsets, in
 
 OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, double mipbias, const Tensor& d_out, const OT& d_sat,
                   const OT& d_pole, const OT& d_mip, bool want_dirs, const OT& sc, int64_t binned_from, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = dirs.size(0), ld = dirs.size(1);
     const bool i4 = sat.dim() == 3 && sat.size(-1) == 4 && sat.size(0) != 3;
     const int64_t H = i4 ? sat.size(0) : sat.size(-2), W = i4 ? sat.size(1) : sat.size(-1);
@@ -347,6 +397,7 @@ OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, doubl
 Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
                     const Tensor& rough_src, const OT& src_idx, double out_bias, const Tensor& d_out,
                     const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor d_xfeat = fe(half_vec, {R, 24});
@@ -362,6 +413,7 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
 
 Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& d_out,
                  const Tensor& gW, const Tensor& gb, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     if (hp.size() != 5) fail("heads_bwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
     const int64_t M = feat.size(0);
     Tensor d_feat = at::empty_like(feat);
@@ -374,6 +426,7 @@ Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std
 
 Tensor ggx_rays_bwd(const Tensor& V, const Tensor& N, const Tensor& r, const Tensor& off, const Tensor& sobol,
                     const Tensor& row_of_ray, const Tensor& j_of_ray, const OT& dL, const OT& d_rays, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor d_nr = fe(V, {R, 4});
     check(nmf_ggx_rays_bwd(f32(V), f32(N), f32(r), f32(off), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
@@ -385,6 +438,7 @@ Tensor ggx_rays_bwd(const Tensor& V, const Tensor& N, const Tensor& r, const Ten
 std::tuple<Tensor, Tensor, Tensor, Tensor> shade_mix_bwd(const Tensor& V, const Tensor& f0, const Tensor& diff, const Tensor& cnt,
                                                          const Tensor& row_of_ray, const Tensor& L, const Tensor& inc,
                                                          const Tensor& brdf, const Tensor& d_rows, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor d_inc = fe(V, {R, 3}), d_brdf = fe(V, {R, 3}), dL = fe(V, {R, 3}), d_fd = fe(V, {R, 6});
     check(nmf_shade_mix_bwd(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf), f32(d_rows),
@@ -397,6 +451,7 @@ std::tuple<Tensor, OT, OT> ray_compose_bwd(const Tensor& weight, const OT& refl_
                                            const Tensor& rays, const Tensor& ray_id, const Tensor& bg, bool bg_per_ray,
                                            bool tonemap, bool noclip, const OT& rgb_lin, const OT& d_rgb_map, const OT& d_acc,
                                            const OT& d_ori, bool want_d_normals, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t M = weight.size(0);
     Tensor d_weight = fe(weight, {M});
     OT d_refl, d_normals;
@@ -422,6 +477,7 @@ void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const s
                            const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
                            const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
                            int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     if (segs.size() > NMF_VM_MAX_SEGMENTS) fail("at most " + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments per walk");
     nmf_vm_bwd_segment arr[NMF_VM_MAX_SEGMENTS];
@@ -462,6 +518,7 @@ void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const s
 
 std::tuple<std::vector<Tensor>, std::vector<Tensor>> vm_unpack_density_grad(int64_t p_addr, const std::vector<Tensor>& g_dpk,
                                                                             const std::vector<Tensor>& g_dlk, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     const int64_t G = p->grid;
     P3 a = three(g_dpk), b = three(g_dlk);
@@ -495,6 +552,7 @@ std::pair<const float*, int> rows_of(const OT& t, int width, std::vector<Tensor>
 
 std::tuple<Tensor, Tensor, Tensor> vm_query_rows(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& dpk,
                                                  const std::vector<Tensor>& dlk, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     const int64_t M = xyzt.size(0);
     if (dpk.size() != 3 || dlk.size() != 3) fail("vm_query_rows: three planes / lines expected");
@@ -513,12 +571,14 @@ std::tuple<Tensor, Tensor, Tensor> vm_query_rows(int64_t p_addr, const Tensor& x
 }
 
 Tensor sqerr_fwd(const Tensor& pred, const Tensor& gt, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor o = at::zeros({}, pred.options().dtype(at::kFloat));
     if (pred.numel()) check(nmf_sqerr_fwd(f32(pred), f32(gt), pred.numel(), out(o), st(stream)), "nmf_sqerr_fwd");
     return o;
 }
 
 Tensor sqerr_bwd(const Tensor& pred, const Tensor& gt, const Tensor& d_out, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor d = at::empty_like(pred);
     if (pred.numel()) check(nmf_sqerr_bwd(f32(pred), f32(gt), pred.numel(), f32(d_out), out(d), st(stream)), "nmf_sqerr_bwd");
     return d;
@@ -528,6 +588,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> shade_mix_bwd_view(const Tens
                                                                       const Tensor& cnt, const Tensor& row_of_ray,
                                                                       const Tensor& L, const Tensor& inc, const Tensor& brdf,
                                                                       const Tensor& d_rows, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor d_inc = fe(V, {R, 3}), d_brdf = fe(V, {R, 3}), dL = fe(V, {R, 3}), d_fd = fe(V, {R, 6}), dV = fe(V, {R, 3});
     check(nmf_shade_mix_bwd_view(f32(V), f32(f0), f32(diff), i32(cnt), i32(row_of_ray), R, f32(L), f32(inc), f32(brdf),
@@ -539,6 +600,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> shade_mix_bwd_view(const Tens
 Tensor ggx_rays_bwd_view(const Tensor& V, const Tensor& N, const Tensor& r, const Tensor& off, const Tensor& sobol,
                          const Tensor& row_of_ray, const Tensor& j_of_ray, const Tensor& dL, const OT& d_rays,
                          int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t R = row_of_ray.size(0);
     Tensor d = fe(V, {R, 7});
     check(nmf_ggx_rays_bwd_view(f32(V), f32(N), f32(r), f32(off), f32(sobol), i32(row_of_ray), i32(j_of_ray), R,
@@ -550,6 +612,7 @@ Tensor ggx_rays_bwd_view(const Tensor& V, const Tensor& N, const Tensor& r, cons
 
 void view_adjoint_to_rays(const Tensor& ray_id, const Tensor& bidx, const Tensor& dv_a, const OT& dv_b, Tensor d_rays,
                           int64_t stream) {
+    TimedScope _ts(__func__, stream);
     std::vector<Tensor> keep;
     const auto a = rows_of(dv_a, 3, keep), b = rows_of(dv_b, 3, keep);
     check(nmf_view_adjoint_to_rays(i32(ray_id), i32(bidx), a.first, a.second, b.first, b.second, bidx.size(0),
@@ -558,6 +621,7 @@ void view_adjoint_to_rays(const Tensor& ray_id, const Tensor& bidx, const Tensor
 }
 
 Tensor select_total(const Tensor& weights, const Tensor& u, double extra, Tensor ws, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     Tensor total = at::empty({}, weights.options().dtype(at::kFloat));
     check(nmf_select_total(f32(weights), f32(u), weights.size(0), extra, ptr<double>(ws, at::kDouble), out(total),
                            st(stream)),
@@ -569,6 +633,7 @@ std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& 
                                                    const Tensor& rays, const Tensor& conv, double min_rough, bool detach_n,
                                                    const OT& dN, const OT& dr1, const OT& df0, const OT& ddiff, const OT& dfeat,
                                                    const OT& bidx, int64_t row_inputs, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t M = inv.has_value() ? inv->size(0) : ray_id.size(0);
     const int64_t Mb = bidx.has_value() ? bidx->size(0) : 0;
     const int64_t n_out = row_inputs ? Mb : M;
@@ -590,9 +655,11 @@ std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& 
 
 // slot tables are ctypes arrays owned by the Python side: passed by address
 void adam_step(int64_t slots_addr, int64_t n, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     check(nmf_adam_step(reinterpret_cast<const nmf_adam_slot*>(slots_addr), (int32_t)n, st(stream)), "nmf_adam_step");
 }
 void multi_copy(int64_t slots_addr, int64_t n, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     check(nmf_multi_copy(reinterpret_cast<const nmf_copy_slot*>(slots_addr), (int32_t)n, st(stream)), "nmf_multi_copy");
 }
 
@@ -604,6 +671,7 @@ const float* dense_f32(const Tensor& t) {       // hip._dense_f32: contiguous or
 
 std::vector<Tensor> loss_mix_bwd(const std::vector<std::vector<int64_t>>& shapes, const std::vector<double>& weights,
                                  double scale, const Tensor& d_out, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const size_t n = shapes.size();
     if (weights.size() != n || n > 16) fail("loss_mix_bwd: shapes / weights");
     std::vector<Tensor> grads;
@@ -621,6 +689,7 @@ std::vector<Tensor> loss_mix_bwd(const std::vector<std::vector<int64_t>>& shapes
 }
 
 void l1_mean_bwd_into(const std::vector<Tensor>& tensors, const Tensor& d_out, std::vector<Tensor> grads, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const size_t n = tensors.size();
     if (grads.size() != n || n > 32) fail("l1_mean_bwd: tensors / gradients");
     const float* x[32];
@@ -637,6 +706,7 @@ void l1_mean_bwd_into(const std::vector<Tensor>& tensors, const Tensor& d_out, s
 
 void sat_build_bwd_into(Tensor d_sat, const Tensor& bg, const Tensor& act, const OT& d_pole, double brightness, double mul,
                         const OT& sc, Tensor d_bg, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t H = bg.size(-2), W = bg.size(-1);
     check(nmf_sat_build_bwd(ptr<float>(d_sat, at::kFloat), f32(bg), f32(act), (int32_t)H, (int32_t)W, (float)brightness,
                             (float)mul, static_cast<const float*>(vptr(sc)), static_cast<const float*>(vptr(d_pole)),
@@ -646,6 +716,7 @@ void sat_build_bwd_into(Tensor d_sat, const Tensor& bg, const Tensor& act, const
 
 void sat_build_into(const Tensor& bg, double brightness, double mul, const OT& sc, Tensor act, Tensor sat, const OT& pole,
                     const OT& sat_i4, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const int64_t H = bg.size(-2), W = bg.size(-1);
     check(nmf_sat_build(f32(bg), (int32_t)H, (int32_t)W, (float)brightness, (float)mul, static_cast<const float*>(vptr(sc)),
                         ptr<float>(act, at::kFloat), ptr<float>(sat, at::kFloat), static_cast<float*>(vptr(pole)),
@@ -654,6 +725,7 @@ void sat_build_into(const Tensor& bg, double brightness, double mul, const OT& s
 }
 
 void sh_project_into(const Tensor& vals, const Tensor& wq, const Tensor& sh_A, Tensor coeffs, Tensor conv, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     check(nmf_sh_project(f32(vals), f32(wq), wq.size(0), (int32_t)wq.size(1), f32(sh_A), ptr<float>(coeffs, at::kFloat),
                          ptr<float>(conv, at::kFloat), st(stream)),
           "nmf_sh_project");
@@ -661,6 +733,7 @@ void sh_project_into(const Tensor& vals, const Tensor& wq, const Tensor& sh_A, T
 
 void vm_pack_density_into(int64_t p_addr, const std::vector<Tensor>& planes, const std::vector<Tensor>& lines,
                           const std::vector<Tensor>& dpk, const std::vector<Tensor>& dlk, int64_t stream) {
+    TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     P3 a = three(planes), b = three(lines), c = three(dpk), d = three(dlk);
     float *oc[3], *od[3];
@@ -679,6 +752,30 @@ PYBIND11_MODULE(_nmf_host, m) {
         Py_XINCREF(g_error_class);
     });
     m.def("abi_version", []() { return nmf_version(); });
+    m.def("call_timing_begin", [](const std::string& only) {
+        if (!g_call_timer) g_call_timer = new CallTimer();
+        g_call_timer->next = 0;
+        g_call_timer->recs.clear();
+        g_call_filter = only;
+    }, py::arg("only") = "");
+    m.def("call_timing_end", []() {        // waits for the recorded work; -> {name: (ms, calls)}
+        py::dict out;
+        if (!g_call_timer) return out;
+        CallTimer* t = g_call_timer;
+        g_call_timer = nullptr;
+        std::map<std::string, std::pair<double, int64_t>> acc;
+        for (auto& r : t->recs) {
+            float ms = 0.f;
+            check(nmf_event_synchronize(r.b), "nmf_event_synchronize");
+            check(nmf_event_elapsed_ms(r.a, r.b, &ms), "nmf_event_elapsed_ms");
+            auto& e = acc[r.name];
+            e.first += ms;
+            e.second += 1;
+        }
+        for (auto& kv : acc) out[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+        delete t;
+        return out;
+    });
     m.def("march_count", &march_count);
     m.def("march_scan", &march_scan);
     m.def("march_fill", &march_fill);

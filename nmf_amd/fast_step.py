@@ -93,6 +93,7 @@ class TrainPass:
         self._table_events = None
         self._core_static = None
         self._core_retrace = None
+        self.last_sizes = None            # sizes of the last chunk the C++ pass ran (reports)
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -266,6 +267,8 @@ class TrainPass:
                 pass                                  # (the C++ pass wrote rgb_map0 / acc_map0 / whole_valid0 ... itself)
             self.n_loss_chunks += 1
             self.l1_scale += float(wts[1]) * float(inv_lbatch)
+            self.last_sizes = dict(rays=int(out["kept"]), n_samples=list(out["n_samples"]), n_rays=list(out["n_rays"]),
+                                   n_rows=list(out["n_rows"]))
             return dict(loss=out["loss"], total=out["total"], kept=out["kept"], n_samples=list(out["n_samples"]))
         finally:
             for m in mods:
