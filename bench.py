@@ -624,7 +624,12 @@ def main():
                 "kernel": "nmf_" + dname, "bound": "mfma" if bound == "mfma" else ("hbm" if bound in ("hbm", "atomics") else bound),
                 "bound_detail": bound, "achieved": achieved / scale if achieved else None, "peak": peak / scale if peak else None,
                 "unit": unit, "frac": (achieved / peak) if (achieved and peak) else None,
-                "traffic": (ctr or {}).get("kernels", {}).get("k_" + dname, {}).get("hbm_bytes_per_launch") if ctr else None,
+                "traffic": (ctr or {}).get("kernels", {}).get(
+                    {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd",
+                     "sat_lookup_bwd": "k_env_lookup_bwd"}.get(dname, "k_" + dname), {}).get("hbm_bytes_per_launch") if ctr else None,
+                "alu_busy_counters": (ctr or {}).get("kernels", {}).get(
+                    {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd"}.get(dname, ""), {}).get(
+                        "derived", {}).get("alu_busy") if ctr else None,
                 "launches": dom_live[1] if dom_live else None, "avg_launch_us": live_us,
                 "work_per_step": work, "work_model": "2 x 17 152 FLOP per secondary ray (SURVEY 8d: the a18 contraction, backward = dX + dW)"
                 if dname == "brdf_mlp_bwd" else "see call_models() in bench.py",

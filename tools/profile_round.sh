@@ -56,7 +56,9 @@ KEYS = {"k_vm_bwd_density<false": "k_vm_bwd_density<value>", "k_vm_bwd_density<t
         "k_brdf_mlp_bwd": "k_brdf_mlp_bwd", "k_brdf_mlp_fwd": "k_brdf_mlp_fwd", "k_env_lookup_bwd": "k_env_lookup_bwd",
         "k_env_lookup_fwd": "k_env_lookup_fwd", "k_vm_fwd": "k_vm_fwd", "k_march_count16": "k_march_count16",
         "k_march_fill16": "k_march_fill16", "k_brick_scatter": "k_brick_scatter", "k_ggx_rays_bwd": "k_ggx_rays_bwd",
-        "k_composite_bwd": "k_composite_bwd", "k_adam": "k_adam"}
+        "k_composite_bwd": "k_composite_bwd", "k_adam": "k_adam", "k_env_bin_count": "k_env_bin_count",
+        "k_env_bin_scatter": "k_env_bin_scatter", "k_env_bin_accum": "k_env_bin_accum", "k_segment_sum_wide": "k_segment_sum_wide",
+        "k_march_count(": "k_march_count", "k_brick_hist": "k_brick_hist", "k_bins_final": "k_bins_final"}
 def key_of(name):
     for sub, k in KEYS.items():
         if sub in name:
@@ -116,9 +118,13 @@ for k in sums:
     kernels[k] = rec
 walk = kernels.get("k_vm_bwd_density<value>", kernels.get("k_vm_bwd_density<normal>", kernels.get("k_vm_bwd_brick<density>", {})))
 try:
-    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
-    commit = "unknown (no .git on the GPU box; see the tag)"
+    # no .git on the GPU box: the container writes the SHA next to the sources before the snapshot is taken (tools/gpu_profile.sh)
+    try:
+        commit = open(root + "/.git_sha").read().strip()
+    except OSError:
+        commit = "unknown"
 res = {"tag": tag, "commit": commit,
        "command": "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras, one "
                   "run per counter group (tools/profile_round.sh); durations from the --kernel-trace --stats run of the same command",
