@@ -464,6 +464,9 @@ typedef struct {
     int32_t reserved;
 } nmf_adam_slot;
 int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream);
+/* The same update gated by a device float (e.g. the summed loss of the step): not finite -> no parameter and no moment changes.
+ * train.py:704-705 skips a chunk whose loss is NaN after a host read-back; this keeps the decision on the device. */
+int nmf_adam_step_guarded(const nmf_adam_slot* slots, int32_t n_slots, const float* guard, void* stream);
 
 /* Multi-tensor copy with fp32 <-> fp64 conversion, all slots in one launch (slots: HOST array, passed by value): packs the
  * per-parameter gradients into the flat fp32 all-reduce buffer and unpacks the reduced sums (ONE collective

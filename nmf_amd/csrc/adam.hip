@@ -45,16 +45,21 @@ __device__ void adam_slot(const nmf_adam_slot& s) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const T gg = g[i];
-        // NaN guard (train.py:704-705 drops a chunk whose loss is NaN, after a host read-back): an element whose gradient
-        // is not finite keeps its parameter and its moments, so one bad chunk cannot poison the optimizer state
-        if (!(fabs(gg) <= (T)3.0e38)) continue;
+        // last line of defence (the step-level guard below is the first): an element whose gradient is not finite keeps its
+        // parameter and its moments
+        if (!isfinite(gg)) continue;
         T pp = p[i], mm = m[i], vv = v[i];
         adam_one<T>(pp, gg, mm, vv, wd, omb1, b2, omb2, step, bc2s, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
 
-__global__ void __launch_bounds__(256) k_adam(Batch b) {
+// guard: a device float, e.g. the summed loss of the step's chunks.  train.py:704-705 drops a chunk whose loss is NaN after a
+// host read-back of the loss; here the loss stays on the device and a non-finite value makes the WHOLE update a no-op
+// (parameters, moments): the gradients of such a step are contaminated whatever chunk produced the NaN, and with one chunk
+// per step -- the usual case -- this is the reference's behaviour without its synchronisation.
+__global__ void __launch_bounds__(256) k_adam(Batch b, const float* __restrict__ guard) {
+    if (guard && !isfinite(*guard)) return;
     const nmf_adam_slot& s = b.s[blockIdx.y];
     if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;
     if (s.is_f64) adam_slot<double>(s);
@@ -131,6 +136,10 @@ extern "C" int nmf_multi_copy(const nmf_copy_slot* slots, int32_t n_slots, void*
 }
 
 extern "C" int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* stream) {
+    return nmf_adam_step_guarded(slots, n_slots, nullptr, stream);
+}
+
+extern "C" int nmf_adam_step_guarded(const nmf_adam_slot* slots, int32_t n_slots, const float* guard, void* stream) {
     NMF_REQUIRE(slots != nullptr || n_slots == 0, NMF_EINVAL, "nmf_adam_step: null slot table");
     NMF_REQUIRE(n_slots >= 0, NMF_EINVAL, "nmf_adam_step: negative slot count");
     for (int32_t i = 0; i < n_slots; ++i) {
@@ -152,7 +161,7 @@ extern "C" int nmf_adam_step(const nmf_adam_slot* slots, int32_t n_slots, void* 
         int64_t bx = cdiv(biggest, 256 * 4);
         if (bx > 1024) bx = 1024;
         if (bx < 1) bx = 1;
-        hipLaunchKernelGGL(k_adam, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b, guard);
         NMF_CHECK_LAUNCH("k_adam");
     }
     return NMF_OK;

@@ -654,9 +654,10 @@ std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& 
 }
 
 // slot tables are ctypes arrays owned by the Python side: passed by address
-void adam_step(int64_t slots_addr, int64_t n, int64_t stream) {
+void adam_step(int64_t slots_addr, int64_t n, const OT& guard, int64_t stream) {
     TimedScope _ts(__func__, stream);
-    check(nmf_adam_step(reinterpret_cast<const nmf_adam_slot*>(slots_addr), (int32_t)n, st(stream)), "nmf_adam_step");
+    check(nmf_adam_step_guarded(reinterpret_cast<const nmf_adam_slot*>(slots_addr), (int32_t)n, of32(guard), st(stream)),
+          "nmf_adam_step");
 }
 void multi_copy(int64_t slots_addr, int64_t n, int64_t stream) {
     TimedScope _ts(__func__, stream);

@@ -68,7 +68,7 @@ EXPORTS = [
     "nmf_sat_lookup_bwd_workspace_bytes",
     "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
-    "nmf_adam_step", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
+    "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
@@ -785,9 +785,10 @@ def shade_mix_bwd(V, f0, diff, cnt, row_of_ray, L, inc, brdf, d_rows):
 
 
 # ---- optimizer ----------------------------------------------------------------------------------
-def adam_step(slots, n):
-    """slots: (AdamSlot * k) host array, the first n entries are applied in one launch (nmf_adam_step)."""
-    _check(_lib.nmf_adam_step(slots, C.c_int32(n), _stream()), "nmf_adam_step")
+def adam_step(slots, n, guard=None):
+    """slots: (AdamSlot * k) host array, the first n entries are applied in one launch (nmf_adam_step); guard: optional 0-d fp32
+    device tensor, a non-finite value turns the launch into a no-op"""
+    _check(_lib.nmf_adam_step_guarded(slots, C.c_int32(n), _p(guard, torch.float32), _stream()), "nmf_adam_step")
 
 
 # ---- shading glue --------------------------------------------------------------------------------
@@ -1159,8 +1160,8 @@ def _install_host_ext():
         return fx.bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, float(min_rough), bool(detach_n), dN, dr1, df0, ddiff,
                                   dfeat, bidx, int(row_inputs), _stream())
 
-    def adam_step(slots, n):
-        return fx.adam_step(C.addressof(slots), int(n), _stream())
+    def adam_step(slots, n, guard=None):
+        return fx.adam_step(C.addressof(slots), int(n), guard, _stream())
 
     def multi_copy(slots, n):
         return fx.multi_copy(C.addressof(slots), int(n), _stream())

@@ -18,6 +18,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._slots = None
         self._plan = None
         self._last_grads = None
+        # 0-d fp32 device tensor or None: a non-finite value makes the next step() a no-op on the device (Trainer: the summed
+        # loss of the step's chunks -- train.py:704-705 without the host read-back)
+        self.guard = None
         self._gidx = None
         self._touched = None
         super().__init__(params, defaults)
@@ -113,7 +116,7 @@ class FusedAdam(torch.optim.Optimizer):
                 col_u64[:n, 1] = gptr
             col_f64[:n, 9] = step_size
             col_f64[:n, 10] = bc2
-            hip.adam_step(slots, n)
+            hip.adam_step(slots, n, self.guard)
             torch.autograd.graph.increment_version(self._touched if self._touched is not None and len(self._touched) == n
                                                    else [e[0] for e in entries])
         return True
@@ -161,7 +164,7 @@ class FusedAdam(torch.optim.Optimizer):
                 touched.append(p)
                 entries.append((p, st, gi, p.data_ptr(), p.grad.stride()))
         if n:
-            hip.adam_step(slots, n)
+            hip.adam_step(slots, n, self.guard)
             # the kernel writes through raw pointers: tell autograd (and every cache keyed on Tensor._version -- packed
             # density tables, SAT, stacked head weights, host mirrors of scalars) that the parameters changed
             torch.autograd.graph.increment_version(touched)

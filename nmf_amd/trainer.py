@@ -290,8 +290,7 @@ class Trainer:
                 terms.append(st["prediction_loss"]); wts.append(self.pred_lambda)
             total = LossMix.apply(1.0 / lbatch, wts, *terms)
             # train.py:704-705 skips a chunk whose loss is NaN (a host read-back per chunk); here the chunk is
-            # back-propagated regardless and nmf_adam_step leaves every element with a non-finite gradient untouched, so a
-            # NaN never reaches the moments or the parameters and no synchronisation is needed
+            # back-propagated regardless and the optimizer launch is gated by the step's summed loss on the device (below)
             total.backward(_one(total))
             if trace is not None:
                 trace[-1]["total"] = total.detach()
@@ -309,6 +308,10 @@ class Trainer:
         comm_bytes = self.reduce()
         if p.get("clip_grad") is not None:                                                       # train.py:744-745
             torch.nn.utils.clip_grad_norm_([q for q in nerf.parameters() if q.grad is not None], p["clip_grad"])
+        # NaN guard (train.py:704-705 reads the loss back and skips a NaN chunk): the summed loss of the step stays on the
+        # device and gates the fused Adam launch -- a non-finite loss leaves parameters and moments untouched, no host sync
+        if hasattr(self.optimizer, "guard"):
+            self.optimizer.guard = None if not losses else (losses[0] if len(losses) == 1 else torch.stack(losses).sum())
         (getattr(self.optimizer, "step_unhooked", None) or self.optimizer.step)()
         self.scheduler.step()
         self.ori_lambda *= self.ori_decay                                                        # train.py:748-749
@@ -339,7 +342,10 @@ class StepStats(dict):
             return self[key]
         if key not in ("loss", "psnr"):
             raise KeyError(key)
-        loss_sum = float(torch.stack(self._losses).sum()) if self._losses else 0.0
+        vals = torch.stack(self._losses).tolist() if self._losses else []
+        good = [v for v in vals if math.isfinite(v)]           # a chunk whose loss is not finite is left out of the statistics
+        self["nan_chunks"] = len(vals) - len(good)
+        loss_sum = float(sum(good))
         self["loss"] = loss_sum
         self["psnr"] = -10.0 * math.log10(max(loss_sum / max(self["rays"] * 3, 1), 1e-12))
         return self[key]

@@ -998,6 +998,23 @@ def test_fused_adam_matches_torch_adam():
         assert_close(ob.state[b]["exp_avg_sq"].cpu(), oa.state[a]["exp_avg_sq"].cpu(), rtol=2e-6, atol=1e-12, what=f"v {i}")
     ob2 = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-8)
     ob2.load_state_dict(ob.state_dict())             # state_dict is interchangeable with torch.optim.Adam
+    # ---- NaN guard (train.py:704-705 without the host read-back): a non-finite guard value makes the launch a no-op ...
+    before = [(b.detach().clone(), ob.state[b]["exp_avg"].clone(), ob.state[b]["exp_avg_sq"].clone()) for b in pb]
+    for b in pb:
+        b.grad = torch.ones_like(b)
+    ob.guard = torch.tensor(float("nan"), device=DEV)
+    ob.step()
+    for b, (p0, m0, v0) in zip(pb, before):
+        assert torch.equal(b.detach(), p0) and torch.equal(ob.state[b]["exp_avg"], m0) and torch.equal(ob.state[b]["exp_avg_sq"], v0)
+    # ... a finite one lets it through, elements with a non-finite gradient keep their state (per dtype: a large but finite
+    # float64 gradient of the env-map scalar is applied)
+    ob.guard = torch.tensor(3.5, device=DEV)
+    pb[1].grad[7] = float("inf")
+    pb[3].grad = torch.tensor(1e39, dtype=torch.float64, device=DEV)
+    ob.step()
+    assert float(pb[1].detach()[7]) == float(before[1][0][7]) and float(pb[1].detach()[8]) != float(before[1][0][8])
+    assert float(pb[3].detach()) != float(before[3][0]) and bool(torch.isfinite(pb[3].detach()))
+    assert all(bool(torch.isfinite(b.detach()).all()) for b in pb)
 
 
 @pytest.mark.parametrize("M,p", [(1, 1.0), (5, 0.0), (1023, 0.3), (1025, 0.5), (300001, 0.07), (1024 * 1024, 0.2),
