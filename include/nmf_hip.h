@@ -279,9 +279,12 @@ int nmf_select_bounces(const float* weights, const float* u, int64_t M, int32_t 
                        float add, float sum_w, const float* sum_w_dev, int32_t* counts, void* stream);
 /* Normaliser of the level >= 1 selection above (pt_selectors.py:24-31), on the device in one launch:
  * total = clip(float(sum(weights) + 1e-3 * (sum(u) + extra)), 1e-3), float64 sums.  `extra` = the caller's value for the sum
- * of the uniforms at the culled entries of the dense matrix.  workspace3: 24 bytes the caller zeroes ONCE (the kernel leaves
- * it zeroed).  The result is what nmf_select_bounces takes as sum_w_dev. */
-int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace3, float* total,
+ * of the uniforms at the culled entries of the dense matrix.  workspace: NMF_SELECT_TOTAL_WS doubles the caller zeroes ONCE
+ * (a ticket + per-workgroup partial sums that the last workgroup adds in workgroup order: the result does not depend on the
+ * scheduling; the kernel leaves the ticket zeroed); one workspace per stream.  The result is what nmf_select_bounces takes as
+ * sum_w_dev. */
+#define NMF_SELECT_TOTAL_WS 258
+int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace, float* total,
                      void* stream);
 /* Adjoint of the bounce rows' view vector (V = -ray direction: bV = -viewdirs, models/microfacet.py:354) scattered to the
  * rays: d_rays[ray_id[bidx[row]]][3..5] -= dv_a[row] (+ dv_b[row]); dv_* rows of pitch lda / ldb floats, dv_b nullable. */

@@ -44,8 +44,8 @@ __global__ void __launch_bounds__(256) k_expand_segments(const int64_t* __restri
 
 // total = clip(float(sum(w) + 1e-3 * (sum(u) + extra)), 1e-3) with float64 sums: the normaliser of the level >= 1 bounce
 // selection (modules/pt_selectors.py:24-31: the dense weight matrix perturbed by 1e-3 U, then divided by its sum).  One
-// launch: every workgroup adds its partial sums to two float64 accumulators, the last one to arrive (ticket counter)
-// writes the result and resets the workspace {sum_w, sum_u, ticket} for the next call.
+// launch: every workgroup stores its partial sums, the last one to arrive (ticket counter) adds them in workgroup order,
+// writes the result and resets the ticket for the next call.  ws = {ticket, unused, (sum_w, sum_u) per workgroup}.
 __global__ void __launch_bounds__(256) k_select_total(const float* __restrict__ w, const float* __restrict__ u, int64_t M,
                                                       double extra, double* __restrict__ ws, float* __restrict__ total) {
     double a = 0.0, b = 0.0;
@@ -73,15 +73,22 @@ __global__ void __launch_bounds__(256) k_select_total(const float* __restrict__ 
     if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    atomicAdd(&ws[0], sa[0] + sa[1] + sa[2] + sa[3]);
-    atomicAdd(&ws[1], sb[0] + sb[1] + sb[2] + sb[3]);
+    // per-workgroup partial sums, added by the last workgroup in workgroup order: the total does not depend on the order in
+    // which the workgroups finish (float64 atomics did: the last fp32 bit of `total`, hence a floor() in select_bounces, could
+    // differ from run to run under a fixed seed -- ADVICE round 2)
+    ws[2 + 2 * blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3];
+    ws[3 + 2 * blockIdx.x] = sb[0] + sb[1] + sb[2] + sb[3];
     __threadfence();
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws + 2);
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws);
     if (atomicAdd(ticket, 1ull) + 1ull == (unsigned long long)gridDim.x) {
         __threadfence();
-        const double sw = atomicAdd(&ws[0], 0.0), su = atomicAdd(&ws[1], 0.0);      // coherent reads of the final sums
+        double sw = 0.0, su = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) {
+            sw += __builtin_nontemporal_load(&ws[2 + 2 * b]);
+            su += __builtin_nontemporal_load(&ws[3 + 2 * b]);
+        }
         *total = fmaxf((float)(sw + 1e-3 * (su + extra)), 1e-3f);
-        ws[0] = 0.0; ws[1] = 0.0; *ticket = 0ull;
+        *ticket = 0ull;
     }
 }
 
@@ -105,15 +112,15 @@ __global__ void __launch_bounds__(256) k_view_adjoint_to_rays(const int32_t* __r
 
 }  // namespace
 
-extern "C" int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace3,
+extern "C" int nmf_select_total(const float* weights, const float* u, int64_t M, double extra, double* workspace,
                                 float* total, void* stream) {
-    NMF_REQUIRE(M > 0 && weights && u && workspace3 && total, NMF_EINVAL, "nmf_select_total: null / empty");
+    NMF_REQUIRE(M > 0 && weights && u && workspace && total, NMF_EINVAL, "nmf_select_total: null / empty");
     // every workgroup ends in two float64 atomics on the same words, a fence and the ticket: 128 workgroups (0.9 M
     // samples: 14.5 us) beat 512 (24 us) and 64 (20.7 us)
     int64_t blocks = cdiv(M, 256 * 8);
     blocks = blocks > 128 ? 128 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(k_select_total, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weights, u, M, extra,
-                       workspace3, total);
+                       workspace, total);
     NMF_CHECK_LAUNCH("nmf_select_total");
     return NMF_OK;
 }

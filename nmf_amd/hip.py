@@ -620,7 +620,7 @@ _select_ws = {}
 def select_total_workspace(dev):
     ws = _select_ws.get(dev)
     if ws is None:
-        ws = _select_ws[dev] = torch.zeros(3, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+        ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
     return ws
 
 
@@ -629,7 +629,7 @@ def select_total(weights, u, extra):
     dev = weights.device
     ws = _select_ws.get(dev)
     if ws is None:
-        ws = _select_ws[dev] = torch.zeros(3, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+        ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
     total = torch.empty((), dtype=torch.float32, device=dev)
     _check(_lib.nmf_select_total(_p(weights, torch.float32), _p(u, torch.float32), C.c_int64(weights.shape[0]),
                                  C.c_double(float(extra)), _p(ws), _p(total), _stream()), "nmf_select_total")
@@ -1152,7 +1152,7 @@ def _install_host_ext():
         dev = weights.device
         ws = _select_ws.get(dev)
         if ws is None:
-            ws = _select_ws[dev] = torch.zeros(3, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+            ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
         return fx.select_total(weights, u, float(extra), ws, _stream())
 
     def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat,

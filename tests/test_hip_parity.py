@@ -1513,6 +1513,11 @@ def test_select_total_and_view_adjoint_scatter():
     ref = (w[1:M - 2].double().sum() + 1e-3 * (u[3:].double().sum() + extra)).float().clip(min=1e-3)
     assert abs(float(hip.select_total(wd, ud, extra)) - float(ref)) <= 1.2e-7 * abs(float(ref))
     assert float(hip.select_total(torch.zeros(5, device=DEV), torch.zeros(5, device=DEV), 0.0)) == pytest.approx(1e-3)
+    # the partial sums are added in workgroup order: the same bits on every call (bounce counts are reproducible under a seed)
+    gen2 = torch.Generator().manual_seed(9)
+    wl, ul = torch.rand(900001, generator=gen2).to(DEV), torch.rand(900001, generator=gen2).to(DEV)
+    vals = {float(hip.select_total(wl, ul, 123.5)) for _ in range(20)}
+    assert len(vals) == 1, vals
     B, Msmp, Mb = 50, 400, 120
     ray_id = torch.sort(torch.randint(0, B, (Msmp,), generator=gen)).values.int()
     bidx = torch.sort(torch.randperm(Msmp, generator=gen)[:Mb]).values.int()
