@@ -585,7 +585,7 @@ def main():
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
     # ---- after the timed region: every C-ABI call of the step timed (events on the launching stream), 30 more steps
     table, sizes, n_params = None, None, sum(p.numel() for p in nerf.parameters() if p.requires_grad)
-    if timed_calls and rank == 0:
+    if timed_calls:                       # (every rank: the steps contain the gradient all-reduce)
         n_inst = 30
         fx.call_timing_begin()
         for i in range(n_inst):
@@ -595,7 +595,7 @@ def main():
         sizes = dict(B=int(ls["rays"]), M0=int(ls["n_samples"][0]), M1=int(ls["n_samples"][1]) if len(ls["n_samples"]) > 1 else 0,
                      R0=int(ls["n_rays"][0]), R1=int(ls["n_rays"][1]) if len(ls["n_rays"]) > 1 else 0,
                      Mb0=int(ls["n_rows"][0]), Mb1=int(ls["n_rows"][1]) if len(ls["n_rows"]) > 1 else 0, N=int(nerf.sampler.nSamples))
-        table = per_call_table(timing, n_inst * chunks_per_step, sizes, n_params, counters_summary())
+        table = per_call_table(timing, n_inst * chunks_per_step, sizes, n_params, counters_summary()) if rank == 0 else None
     if rank == 0:
         ctr = counters_summary()
         ctr_meta = {k: ctr.get(k) for k in ("tag", "commit", "command")} if ctr else None

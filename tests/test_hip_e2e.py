@@ -401,7 +401,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = _json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["parallelism"] == "dp2"
