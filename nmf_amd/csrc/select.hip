@@ -72,24 +72,28 @@ __global__ void __launch_bounds__(256) k_select_total(const float* __restrict__ 
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    // per-workgroup partial sums, added by the last workgroup in workgroup order: the total does not depend on the order in
-    // which the workgroups finish (float64 atomics did: the last fp32 bit of `total`, hence a floor() in select_bounces, could
-    // differ from run to run under a fixed seed -- ADVICE round 2)
-    ws[2 + 2 * blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3];
-    ws[3 + 2 * blockIdx.x] = sb[0] + sb[1] + sb[2] + sb[3];
-    __threadfence();
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws);
-    if (atomicAdd(ticket, 1ull) + 1ull == (unsigned long long)gridDim.x) {
+    // per-workgroup partial sums, added by the last workgroup in a FIXED order (strided pairs, then a shuffle tree): the total
+    // does not depend on the order in which the workgroups finish (float64 atomics did: the last fp32 bit of `total`, hence a
+    // floor() in select_bounces, could differ from run to run under a fixed seed -- ADVICE round 2)
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        ws[2 + 2 * blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3];
+        ws[3 + 2 * blockIdx.x] = sb[0] + sb[1] + sb[2] + sb[3];
         __threadfence();
-        double sw = 0.0, su = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) {
-            sw += __builtin_nontemporal_load(&ws[2 + 2 * b]);
-            su += __builtin_nontemporal_load(&ws[3 + 2 * b]);
-        }
-        *total = fmaxf((float)(sw + 1e-3 * (su + extra)), 1e-3f);
-        *ticket = 0ull;
+        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws);
+        is_last = atomicAdd(ticket, 1ull) + 1ull == (unsigned long long)gridDim.x;
+        if (is_last) *ticket = 0ull;
     }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 64) return;
+    __threadfence();
+    double sw = 0.0, su = 0.0;
+    for (unsigned bb = threadIdx.x; bb < gridDim.x; bb += 64) {       // <= 128 workgroups: two per lane
+        sw += __builtin_nontemporal_load(&ws[2 + 2 * bb]);
+        su += __builtin_nontemporal_load(&ws[3 + 2 * bb]);
+    }
+    for (int d = 32; d > 0; d >>= 1) { sw += __shfl_down(sw, d, 64); su += __shfl_down(su, d, 64); }
+    if (threadIdx.x == 0) *total = fmaxf((float)(sw + 1e-3 * (su + extra)), 1e-3f);
 }
 
 // d_rays[ray_of(row)][3 + k] -= dv_a[row][k] + dv_b[row][k]: the adjoint of the rows' view vector V = -direction scattered

@@ -2,16 +2,23 @@
 # Collect the per-round rocprofv3 evidence on an MI355X box:  tools/profile_round.sh <tag>   (e.g. r01_q)
 # Writes gpurun_out/<tag>_bench.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv and
 # pmc_vm_bwd.json; copy what is to be judged into profiles/.  PMC passes are separate runs with --kernel-trace only.
+# Optional: BENCH_ARGS="--grid 300" (or "--retrace 1000", "--mode infer --steps 2") profiles another regime: the first, full
+# bench.py run then also takes those arguments (without extras / CPU baseline).
 set -u
 TAG=${1:-rXX}
+BENCH_ARGS=${BENCH_ARGS:-}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-python "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+if [ -n "$BENCH_ARGS" ]; then
+  python "$ROOT/bench.py" $BENCH_ARGS --no-extras --no-cpu-baseline > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+else
+  python "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+fi
 rm -rf /tmp/prof_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/${TAG}_prof_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > "$OUT/${TAG}_prof_bench.log" 2>&1
 cp "$(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 # steady-state view: only the kernels between the last optimizer launches (setup / warm-up launches excluded)
 python - "$(find /tmp/prof_ks -name '*kernel_trace.csv' | head -1)" "$OUT/${TAG}_steady_state_per_step.csv" <<'PY'
@@ -43,10 +50,10 @@ i=0
 for G in $PMC_SETS; do
   i=$((i+1))
   rm -rf /tmp/prof_pmc_$i
-  timeout 300 rocprofv3 --pmc $(echo $G | tr ',' ' ') --kernel-trace --output-format csv -d /tmp/prof_pmc_$i -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/${TAG}_pmc_$i.log" 2>&1 || echo "counter group $G failed (see ${TAG}_pmc_$i.log)"
+  timeout 300 rocprofv3 --pmc $(echo $G | tr ',' ' ') --kernel-trace --output-format csv -d /tmp/prof_pmc_$i -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > "$OUT/${TAG}_pmc_$i.log" 2>&1 || echo "counter group $G failed (see ${TAG}_pmc_$i.log)"
 done
 python - "$TAG" "$OUT" "$ROOT" <<'PY'
-import csv, glob, json, subprocess, sys, collections, re
+import csv, glob, json, os, subprocess, sys, collections, re
 tag, out, root = sys.argv[1], sys.argv[2], sys.argv[3]
 # kernels of the steady-state step, by substring of the demangled name -> report key
 KEYS = {"k_vm_bwd_density<false": "k_vm_bwd_density<value>", "k_vm_bwd_density<true": "k_vm_bwd_density<normal>",
@@ -126,7 +133,8 @@ except Exception:
     except OSError:
         commit = "unknown"
 res = {"tag": tag, "commit": commit,
-       "command": "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras, one "
+       "bench_args": os.environ.get("BENCH_ARGS", ""),
+       "command": "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras [bench_args], one "
                   "run per counter group (tools/profile_round.sh); durations from the --kernel-trace --stats run of the same command",
        "units": "FETCH_SIZE / WRITE_SIZE in KB as reported (uncorrected: MI355X_MICROARCH.md calibrates the x2 only for 16 B/lane "
                 "streaming reads, this path gathers 64-192 B runs); *_frac relative to 8 TB/s HBM, 34.5 TB/s L2, 157.3 TFLOP/s f32 MFMA",
