@@ -259,6 +259,7 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
                      global_rays=global_rays)
     sync()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     rays_done, last, comm, first = 0, None, [], None
     for i in range(warmup, warmup + steps):
         last = trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
@@ -271,6 +272,8 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
     dt = time.perf_counter() - t0
     comm_ms = [c["comm_ms"] for c in comm[-50:]] if comm else []
     last["first_n_samples"] = first["n_samples"]
+    # CPU time of THIS process over the timed steps (all its threads): what one rank needs of the host; 8 ranks on a node need 8 x
+    last["host_cpu_ms_per_step"] = 1e3 * (time.process_time() - cpu0) / max(steps, 1)
     return dt, rays_done, last, (sum(comm_ms) / len(comm_ms) if comm_ms else None)
 
 
@@ -659,6 +662,7 @@ def main():
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                        "backend": backend if (world > 1 or single_rank_comm) else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"],
+                       "host_cpu_ms_per_step": last.get("host_cpu_ms_per_step"),
                        "host_pass": "C++ (csrc/step_core.inc)" if timed_calls else "python (nmf_amd/fast_step.py)"},
             "roofline": roof,
         }
