@@ -345,22 +345,32 @@ int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, 
                   float* d_feat, float* gW, float* gb, void* stream);
 /* Fused MLPBRDF (modules/brdf.py:177-261): out[r] = sigmoid(MLP(X[r])[0:3] + out_bias) with X as above and
  * MLP = Linear(66,64) ReLU Linear(64,64) ReLU Linear(64,4) (weights row-major [out][in], torch layout).
- * Dense layers run on v_mfma_f32_32x32x2_f32 (exact fp32).  Nothing but out [R][3] is written. */
+ * The dense layers run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six products
+ * per K block, fp32 accumulation: fp32-class accuracy, csrc/brdf_mlp.hip).  Writes out [R][3] and, when act_mask is not
+ * NULL, the ReLU masks of the two hidden layers for the backward: act_mask [R][4] uint32 = per ray {layer-1 mask,
+ * layer-2 mask} of lane half 0, then of lane half 1 (bit 16 ub + q = unit 32 ub + (q & 3) + 8 (q >> 2) + 4 half). */
 int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                      const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                      const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
-                     int32_t max_workgroups /* 0 = default; see nmf_brdf_mlp_bwd */, void* stream);
-/* Backward (recomputes the forward per 64-ray tile).  d_xfeat [R][24] = adjoint of the gathered feature
- * columns (overwritten; reduce it per bounce point with nmf_segment_sum_wide); gW* / gb* are ACCUMULATED
- * (caller zeroes): gW0 [64][66], gb0 [64], gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4].
- * max_workgroups: 0 = the kernel's own choice (one or two persistent workgroups per CU); > 0 caps the persistent
- * workgroups, for callers that run this launch on a second stream NEXT TO other kernels and want it to leave
- * registers / LDS on every CU free for them (the training pass: csrc/brdf_mlp.hip, nmf_amd/fast_step.py). */
+                     uint32_t* act_mask, int32_t max_workgroups /* 0 = default; see nmf_brdf_mlp_bwd */, void* stream);
+/* Backward of the call above for the SAME inputs: fwd_out [R][3] and act_mask [R][4] are that call's outputs (the
+ * sigmoid adjoint and the ReLU decisions come from them; the hidden activations are recomputed per 32-ray tile as
+ * values, two bf16 terms per operand).  d_xfeat [R][24] = adjoint of the gathered feature columns (overwritten; reduce
+ * it per bounce point with nmf_segment_sum_wide); gW* / gb* are ACCUMULATED (caller zeroes): gW0 [64][66], gb0 [64],
+ * gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4] (row 3 of gW4 / gb4 stays untouched: the fourth output is unused).
+ * max_workgroups: 0 = the kernel's own choice (one persistent workgroup per CU, fewer for short launches); > 0 caps
+ * them, for callers that run this launch on a second stream NEXT TO other kernels and want it to leave CUs free for
+ * them (the training pass: nmf_amd/fast_step.py, csrc/step_core.inc).
+ * workspace (device, nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups) bytes, need not be initialised): one partial
+ * sum of the weight gradients per workgroup; a second small launch adds them in workgroup order, so a gradient element
+ * receives one atomic per call instead of one per workgroup. */
 int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                      const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
-                     const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias,
-                     const float* d_out, float* d_xfeat, float* gW0, float* gb0, float* gW2, float* gb2,
-                     float* gW4, float* gb4, int32_t max_workgroups, void* stream);
+                     const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
+                     const uint32_t* act_mask, const float* d_out, float* d_xfeat, float* gW0, float* gb0,
+                     float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups);
 /* out[s][0:D] = sum_{r in segment s} vals[r*row_stride + 0:D], D <= 64 (adjoint of the feature gather). */
 int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
                          int64_t n_seg, float* out, void* stream);

@@ -1,36 +1,70 @@
 // Fused BRDF MLP for gfx950: feature build (gather + ISH encodings) -> 66->64->64->4 MLP -> sigmoid,
-// forward and backward, with the dense layers on the matrix cores.
+// forward and backward, with the dense layers on the bf16 matrix cores at fp32-class accuracy.
 // Replaces MLPBRDF.forward (reference: modules/brdf.py:177-261, modules/ish.py:94-105,
 // modules/sh.py:251-308) and its autograd.
 //
-// Why a kernel: the only dense contraction of the hot path has N = 64 and K <= 66 -- rocBLAS runs these
-// skinny GEMMs at ~2 TFLOP/s and they cost 38 % of the first end-to-end step (profiles/r01_a).  Here a
-// workgroup owns a tile of 64 secondary rays that never leaves LDS: X (64x66) -> H1 -> H2 -> out.
-// fp32 parity (1e-4 on radiance) rules out bf16 inputs, so the exact-fp32 MFMA
-// v_mfma_f32_32x32x2_f32 is used: each of the 4 waves owns one 32x32 quadrant of a 64x64 layer output,
-// its weight slice stays in VGPRs for the whole (persistent) kernel, the activation operand is read from
-// LDS with an odd row stride (67) so the 32 rows of an operand column hit 32 different banks.
-// The backward re-computes the forward per tile, forms dH2/dH1 with two more MFMA passes, accumulates
-// dW2 = dH2^T H1 and dW0 = dH1^T X over ALL its tiles in MFMA accumulators (K = rays) and flushes them
-// once per workgroup.
+// Round 3 design (rounds 1-2: exact-fp32 v_mfma_f32_32x32x2_f32, a 64-ray tile shared by four waves, 11 barrier
+// phases per tile: 26-29 % MFMA-busy at 0.9 waves per SIMD -- a latency machine).
 //
-// Measured on MI355X (round 2, scratch micro-benchmark of dependent v_mfma_f32_32x32x2_f32 chains): an fp32 MFMA occupies
-// its SIMD for 64 cycles and NO other VALU instruction of any wave of that SIMD issues meanwhile
-// (SQ_VALU_MFMA_COEXEC_CYCLES = 0; "MFMA wave + FMA wave" on one SIMD takes longer than the two one after the other) --
-// the fp32 matrix rate equals the packed-FMA rate, the instructions seem to share the lanes.  So the floor of this kernel
-// is MFMA cycles + VALU cycles, not their maximum; a second workgroup per CU only hides LDS / barrier / global latency.
+// * Arithmetic: an fp32 operand v is carried as a sum of bf16 numbers (v = h + m [+ l], each the bf16 rounding of what
+//   the ones before left over: 2^-18 |v| left after two terms, 2^-27 after three) and a matrix product is a handful of
+//   v_mfma_f32_32x32x16_bf16 with fp32 accumulation (32 matrix-core cycles per K = 16; the fp32-input instruction
+//   needs 512).  The FORWARD uses three terms and the six products down to 2^-18 (hh hm mh mm hl lh): its
+//   pre-activations are fp32-accurate, which matters because a ReLU decides on their sign -- with two terms a few units
+//   in 10^5 flip against an fp32 evaluation and the gradients of those rays change by finite amounts.  The forward
+//   therefore also writes the two ReLU masks (16 bytes per ray), and the BACKWARD takes them together with the forward's
+//   output: what it recomputes (H1, H2 as VALUES in dW2 / dW4) and its adjoint products use two terms and three
+//   products (relative error 4e-6), nothing discontinuous depends on them.
+// * Work split: ONE WAVE owns a tile of 32 rays through every phase -- no workgroup barrier inside the loop.  Its
+//   activations live in a wave-private LDS region as row-major bf16 planes [ray][unit] (row stride an odd number of
+//   16-byte slots: conflict-free ds_read_b128 operand reads); the weights (planes of W0 | b0, W2, W2^T,
+//   W0[:, :24]^T) are staged once per workgroup in LDS and shared by its waves.
+// * Layer products are "swapped" (D^T[unit][ray] = W . act^T): a lane then holds 4 CONSECUTIVE units of its ray per
+//   accumulator quad = one ds_write_b64 into the row-major plane the next product reads.
+// * Weight gradients (K = rays) need the activations with the unit per lane and the rays along the registers.  That
+//   transposition is done by the matrix core too: D = act . E with E a 0/1 selector matrix (exact: every output is one
+//   bf16 input), which lands in exactly the register layout an MFMA operand of the dW products wants.  Any bijection
+//   between (lane half, element) and k is fine as long as both operands of a product use the same one, so none of this
+//   depends on how the hardware orders k inside an operand register.
+// * dW2, dW0 accumulate in MFMA accumulators over ALL tiles of a wave (the 5 trailing input columns through a
+//   transposed product whose 4 useful rows are kept), dW4 / db2 / db4 on the VALU; one LDS reduction over the waves
+//   and one atomic flush per workgroup at the end.  b0 rides as an input column that is 1.0.
 #include "common.hpp"
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IN = NMF_MLP_IN;     // 66
 constexpr int HID = NMF_MLP_HID;   // 64
-constexpr int TR = 64;             // rays per tile
-constexpr int LS = 67;             // LDS row stride (odd -> conflict-free column reads)
-constexpr int K1 = IN / 2;         // 33 mfma k-steps for layer 1
-constexpr int K2 = HID / 2;        // 32
+constexpr int RT = 32;             // rays per wave tile
+constexpr int SXB = 176;           // bytes per row of an input plane  (80 columns + 8 pad, bf16): 11 slots of 16 B
+constexpr int SHB = 144;           // bytes per row of a 64-wide plane (64 + 8 pad): 9 slots
+// input columns of the LDS image: 0-20 half vector (18 ISH + xyz) | 21-44 features | 45 = 1.0 (b0) | 46-47 zero |
+// 48-68 diff vector (18 ISH + xyz) | 69-79 zero.  Lane half 0 of a wave builds columns 0-47, half 1 columns 48-79 (the
+// encoded direction comes first in both, so the two halves run the same code on different inputs).
+constexpr int COL_FEAT = 21, COL_BIAS = 45, COL_DIFF = 48;
+constexpr int PX = RT * SXB, PH = RT * SHB;           // one plane of a wave's input tile / of a 64-wide tile
+constexpr int PW0 = HID * SXB, PW2 = HID * SHB;       // one plane of W0 | b0 / of W2
+
+// LDS maps (bytes).  Forward: three planes of everything.
+constexpr int F_W0 = 0, F_W2 = F_W0 + 3 * PW0, F_W4 = F_W2 + 3 * PW2, F_B2 = F_W4 + 3 * HID * 4, F_B4 = F_B2 + HID * 4;
+constexpr int FWD_SHARED = F_B4 + 16;
+constexpr int FWD_PRIVATE = 3 * PX;                   // the hidden planes overwrite the input planes
+constexpr int FWD_WAVES = 4;
+constexpr int FWD_LDS = FWD_SHARED + FWD_WAVES * FWD_PRIVATE;
+// Backward: two planes.
+constexpr int B_W0 = 0, B_W2 = B_W0 + 2 * PW0, B_W2T = B_W2 + 2 * PW2, B_WFT = B_W2T + 2 * PW2;
+constexpr int B_W4 = B_WFT + 2 * 32 * SHB, B_B2 = B_W4 + 3 * HID * 4;
+constexpr int BWD_SHARED = B_B2 + HID * 4;
+constexpr int BWD_PRIVATE = 2 * PX + 2 * PH + RT * 16;
+constexpr int BWD_WAVES = 4;
+constexpr int BWD_LDS = BWD_SHARED + BWD_WAVES * BWD_PRIVATE;
+static_assert(FWD_SHARED % 16 == 0 && BWD_SHARED % 16 == 0 && BWD_PRIVATE % 16 == 0, "LDS alignment");
+static_assert(BWD_LDS <= 160 * 1024 && FWD_LDS <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void ish18(float x, float y, float z, float kappa, float* o) {
     const float k = kappa + 1e-8f;
@@ -60,299 +94,690 @@ struct MlpW {
     const float *W0, *b0, *W2, *b2, *W4, *b4;   // [64][66],[64],[64][64],[64],[4][64],[4]
 };
 
-// fills rows of the X tile: thread t -> ray t>>2, part t&3 (0: features, 1: half, 2: diff, 3: idle)
-__device__ __forceinline__ void build_x_tile(float* Xs, int64_t r0, int64_t R, const float* __restrict__ half_v,
-                                             const float* __restrict__ diff_v, const float* __restrict__ feat_src,
-                                             const float* __restrict__ rough_src, const int32_t* __restrict__ src_idx) {
-    const int t = threadIdx.x, ray = t >> 2, part = t & 3;
-    const int64_t r = r0 + ray;
-    float* x = Xs + ray * LS;
-    if (r >= R) {
-        if (part == 0) for (int i = 0; i < 24; ++i) x[i] = 0.f;
-        if (part == 1) for (int i = 24; i < 45; ++i) x[i] = 0.f;
-        if (part == 2) for (int i = 45; i < 66; ++i) x[i] = 0.f;
-        return;
-    }
-    const int64_t b = src_idx ? src_idx[r] : r;
-    if (part == 0) {
-        const float4* f = reinterpret_cast<const float4*>(feat_src + b * NMF_APP_DIM);
+// v = p[0] + p[1] (+ p[2]) + O(2^-9 NP |v|)
+template <int NP>
+__device__ __forceinline__ void split(float v, __bf16 (&p)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float4 v = f[i];
-            x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
-        }
-    } else if (part < 3) {
-        const float* v = (part == 1 ? half_v : diff_v) + r * 3;
-        const float kappa = 1.f / (rough_src[b] + 1e-3f);
-        float o[18];
-        ish18(v[0], v[1], v[2], kappa, o);
-        float* q = x + (part == 1 ? 24 : 45);
-#pragma unroll
-        for (int i = 0; i < 18; ++i) q[i] = o[i];
-        q[18] = v[0]; q[19] = v[1]; q[20] = v[2];
+    for (int i = 0; i < NP; ++i) {
+        p[i] = (__bf16)v;
+        if (i + 1 < NP) v -= (float)p[i];
     }
 }
-
-// A chain of N dependent v_mfma_f32_32x32x2_f32 on one accumulator runs at 64 cycles per instruction at best.  Left to
-// itself the compiler issues each pair's ds_read right after the previous pair and waits for it (lgkmcnt(0)) in front of
-// the next one, which exposes the LDS latency once per pair (~170 instead of 128 cycles, ISA of round 2).  Here the
-// operands of chunk c+1 are requested before the instructions of chunk c issue; the empty asm keeps the loads above it.
-constexpr int CH = 8;
-template <int N, class FA, class FB>
-__device__ __forceinline__ void mfma_chain(floatx16& acc, FA load_a, FB load_b) {
-    constexpr int NC = (N + CH - 1) / CH;
-    float a[2][CH], b[2][CH];
+// plane i of an LDS image lies `plane` bytes behind plane i - 1
+template <int NP>
+__device__ __forceinline__ void st_split(char* s, int off, int plane, float v) {
+    __bf16 p[NP];
+    split<NP>(v, p);
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        a[0][i] = load_a(i);
-        b[0][i] = load_b(i);
-    }
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<__bf16*>(s + off + i * plane) = p[i];
+}
+template <int NP>
+struct Op {
+    bf16x8 p[NP];
+};
+template <int NP>
+__device__ __forceinline__ Op<NP> ldop(const char* s, int off, int plane) {
+    Op<NP> o;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (c + 1 < NC) {
+    for (int i = 0; i < NP; ++i) o.p[i] = *reinterpret_cast<const bf16x8*>(s + off + i * plane);
+    return o;
+}
+__device__ __forceinline__ floatx16 mfma(bf16x8 a, bf16x8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// The same instruction with the accumulator pinned to the accumulation registers (AGPRs): the backward keeps 128 of
+// them alive across its whole loop, and everything the VALU touches has to fit into the 256 architectural VGPRs next to
+// them (built with -amdgpu-mfma-vgpr-form the compiler's own MFMAs write VGPRs; without the flag it would route EVERY
+// MFMA result of a 512-register kernel through AGPRs and copy it out).  The accumulators are read only after the loop.
+__device__ __forceinline__ void mfma_acc(floatx16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// c += a b with the terms down to 2^-9 NP, smallest first: NP = 2: lh hl hh; NP = 3: lh hl mm mh hm hh  (a index, b index)
+template <int NP>
+struct Terms;
+template <>
+struct Terms<2> {
+    static constexpr int N = 3;
+    static constexpr int A[3] = {1, 0, 0};
+    static constexpr int B[3] = {0, 1, 0};
+};
+template <>
+struct Terms<3> {
+    static constexpr int N = 6;
+    static constexpr int A[6] = {2, 0, 1, 1, 0, 0};
+    static constexpr int B[6] = {0, 2, 1, 0, 1, 0};
+};
+template <int NP>
+__device__ __forceinline__ floatx16 mfma_n(const Op<NP>& a, const Op<NP>& b, floatx16 c) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                if ((c + 1) * CH + i < N) {
-                    a[(c + 1) & 1][i] = load_a((c + 1) * CH + i);
-                    b[(c + 1) & 1][i] = load_b((c + 1) * CH + i);
-                }
+    for (int i = 0; i < Terms<NP>::N; ++i) c = mfma(a.p[Terms<NP>::A[i]], b.p[Terms<NP>::B[i]], c);
+    return c;
+}
+// acc[ub] += A(ub, kk) . B(ub, kk) over NK k blocks for NB output blocks, the operands of block kk + 1 requested before the
+// matrix instructions of block kk issue (one wave per SIMD: nothing else hides the LDS latency), the chains of the output
+// blocks interleaved.  SA / SB: that operand is the same for every output block (loaded once per k block).
+template <int NP, int NK, int NB, bool SA, bool SB, class FA, class FB>
+__device__ __forceinline__ void product(floatx16 (&acc)[NB], FA load_a, FB load_b) {
+    constexpr int NA_ = SA ? 1 : NB, NB_ = SB ? 1 : NB;
+    Op<NP> a[2][NA_], b[2][NB_];
+#pragma unroll
+    for (int ub = 0; ub < NA_; ++ub) a[0][ub] = load_a(ub, 0);
+#pragma unroll
+    for (int ub = 0; ub < NB_; ++ub) b[0][ub] = load_b(ub, 0);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        if (kk + 1 < NK) {
+#pragma unroll
+            for (int ub = 0; ub < NA_; ++ub) a[(kk + 1) & 1][ub] = load_a(ub, kk + 1);
+#pragma unroll
+            for (int ub = 0; ub < NB_; ++ub) b[(kk + 1) & 1][ub] = load_b(ub, kk + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (c * CH + i < N) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][i], b[c & 1][i], acc, 0, 0, 0);
+        for (int i = 0; i < Terms<NP>::N; ++i)
+#pragma unroll
+            for (int ub = 0; ub < NB; ++ub)
+                acc[ub] = mfma(a[kk & 1][SA ? 0 : ub].p[Terms<NP>::A[i]], b[kk & 1][SB ? 0 : ub].p[Terms<NP>::B[i]], acc[ub]);
+    }
+}
+// row of accumulator register r (C/D layout of the 32x32 MFMAs): (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// input column (LDS image) -> column of W0 / gW0, -1 = the bias column, -2 = padding
+__device__ __forceinline__ int col_orig(int c) {
+    if (c < COL_FEAT) return 24 + c;
+    if (c < COL_BIAS) return c - COL_FEAT;
+    if (c == COL_BIAS) return -1;
+    if (c >= COL_DIFF && c < COL_DIFF + 21) return c - 3;
+    return -2;
+}
+
+// 8 consecutive columns of one row of an LDS image as NP planes (one 16-byte store per plane)
+template <int NP>
+__device__ __forceinline__ void st_group(char* s, int off, int plane, const float (&v)[8]) {
+    bf16x8 a[NP];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 p[NP];
+        split<NP>(v[i], p);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) a[k][i] = p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(s + off + k * plane) = a[k];
+}
+// Weight images (once per workgroup).  Every thread first REQUESTS all the values it converts (groups of 8 columns), then
+// splits and stores them: one memory round trip instead of one per element.
+template <int NP, bool BWD, int NT>
+__device__ __forceinline__ void stage_weights(char* s, int off_w0, int off_w2, int off_w2t, int off_wft, const MlpW& w, int t) {
+    constexpr int G0 = (HID * 10 + NT - 1) / NT, G2 = (HID * 8 + NT - 1) / NT, GF = (32 * 8 + NT - 1) / NT;
+    float v0[G0][8], v2[G2][8], v2t[BWD ? G2 : 1][8], vf[BWD ? GF : 1][8];
+#pragma unroll
+    for (int k = 0; k < G0; ++k) {
+        const int g = t + k * NT, u = g / 10, c0 = 8 * (g % 10);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int co = col_orig(c0 + i);
+            v0[k][i] = g < HID * 10 ? (co >= 0 ? w.W0[u * IN + co] : (co == -1 ? w.b0[u] : 0.f)) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G2; ++k) {
+        const int g = t + k * NT, r = g / 8, c0 = 8 * (g % 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v2[k][i] = g < HID * 8 ? w.W2[r * HID + c0 + i] : 0.f;
+            if (BWD) v2t[k][i] = g < HID * 8 ? w.W2[(c0 + i) * HID + r] : 0.f;      // row r of W2^T
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < GF; ++k) {
+            const int g = t + k * NT, f = g / 8, c0 = 8 * (g % 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[k][i] = (g < 32 * 8 && f < 24) ? w.W0[(c0 + i) * IN + f] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G0; ++k) {
+        const int g = t + k * NT;
+        if (g < HID * 10) st_group<NP>(s, off_w0 + (g / 10) * SXB + 16 * (g % 10), PW0, v0[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < G2; ++k) {
+        const int g = t + k * NT;
+        if (g < HID * 8) {
+            st_group<NP>(s, off_w2 + (g / 8) * SHB + 16 * (g % 8), PW2, v2[k]);
+            if (BWD) st_group<NP>(s, off_w2t + (g / 8) * SHB + 16 * (g % 8), PW2, v2t[k]);
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < GF; ++k) {
+            const int g = t + k * NT;
+            if (g < 32 * 8) st_group<NP>(s, off_wft + (g / 8) * SHB + 16 * (g % 8), 32 * SHB, vf[k]);
+        }
     }
 }
 
-// one 32x32 quadrant of  act_out = relu(act_in[64 x K] * W^T + bias)  on the matrix core.
-// wreg[kk] = W[32*wc + (lane&31)][2*kk + (lane>>5)]
-template <int KS>
-__device__ __forceinline__ void layer_quadrant(const float* in_s, float* out_s, const float (&wreg)[KS],
-                                               const float* __restrict__ bias, int wr, int wc, int lane, bool relu) {
-    floatx16 acc = {0};
-    const float* arow = in_s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
-    float a[KS];
+// The global inputs of one lane: ray (lane & 31) of a tile, lane half 0: half vector, half 1: diff vector, both: the
+// feature row (half 1 does not use it; loading it everywhere keeps the code free of branches, so that the compiler can
+// schedule it between the matrix instructions of the tile before).  Loaded ahead in two stages: the row index first, what
+// it addresses later.  Rays past the end read the last ray (their adjoint is zero, their outputs are not stored).
+struct RayIn {
+    int64_t r, rc, b;
+    bool valid;
+    float d0, d1, d2, rough;
+    float4 f[6];
+};
+__device__ __forceinline__ void ray_in_stage1(RayIn& in, int64_t tile, int64_t R, int ray, int h,
+                                              const float* __restrict__ half_v, const float* __restrict__ diff_v,
+                                              const int32_t* __restrict__ src_idx) {
+    in.r = tile * RT + ray;
+    in.valid = in.r < R;
+    in.rc = in.valid ? in.r : R - 1;
+    in.b = src_idx ? (int64_t)src_idx[in.rc] : in.rc;
+    const float* d = (h == 0 ? half_v : diff_v) + in.rc * 3;
+    in.d0 = d[0]; in.d1 = d[1]; in.d2 = d[2];
+}
+__device__ __forceinline__ void ray_in_stage2(RayIn& in, const float* __restrict__ feat_src,
+                                              const float* __restrict__ rough_src) {
+    in.rough = rough_src[in.b];
+    const float4* f = reinterpret_cast<const float4*>(feat_src + in.b * NMF_APP_DIM);
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = arow[2 * kk];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 6; ++i) in.f[i] = f[i];
+}
+
+// lane (ray = lane & 31, half h): h = 0 writes input columns 0-47, h = 1 columns 48-79 of its ray
+template <int NP>
+__device__ __forceinline__ void build_x(char* x, const RayIn& in, int ray, int h) {
+    float v[48];
+    {
+        const float kappa = 1.f / (in.rough + 1e-3f);
+        ish18(in.d0, in.d1, in.d2, kappa, v);
+        v[18] = in.d0; v[19] = in.d1; v[20] = in.d2;
+    }
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wreg[kk], acc, 0, 0, 0);
-    const int col = 32 * wc + (lane & 31);
-    const float bv = bias[col];
+    for (int i = 0; i < 6; ++i) {
+        v[COL_FEAT + 4 * i] = in.f[i].x; v[COL_FEAT + 4 * i + 1] = in.f[i].y;
+        v[COL_FEAT + 4 * i + 2] = in.f[i].z; v[COL_FEAT + 4 * i + 3] = in.f[i].w;
+    }
+    v[COL_BIAS] = 1.f; v[46] = 0.f; v[47] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[r] + bv;
-        out_s[row * LS + col] = relu ? fmaxf(v, 0.f) : v;
+    for (int i = COL_FEAT; i < 32; ++i) v[i] = h ? 0.f : v[i];     // half 1: zero padding behind its 21 columns
+    const int base = ray * SXB + (h ? 2 * COL_DIFF : 0);
+    auto put = [&](int g) {
+        bf16x8 a[NP];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __bf16 p[NP];
+            split<NP>(v[8 * g + i], p);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) a[k][i] = p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(x + k * PX + base + 16 * g) = a[k];
+    };
+#pragma unroll
+    for (int g = 0; g < 4; ++g) put(g);
+    if (h == 0) {
+        put(4);
+        put(5);
     }
 }
 
-template <int KS>
-__device__ __forceinline__ void load_wreg(float (&wreg)[KS], const float* __restrict__ W, int ldw, int kmax, int wc,
-                                          int lane) {
+// acc (swapped layout: register r = unit acc_row(r, h) of block ub, lane & 31 = ray) -> row-major planes
+template <int NP>
+__device__ __forceinline__ void write_rows(char* pl, int ray, int ub, int h, const floatx16& v) {
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int k = 2 * kk + (lane >> 5);
-        wreg[kk] = k < kmax ? W[(32 * wc + (lane & 31)) * ldw + k] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+        bf16x4 a[NP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __bf16 p[NP];
+            split<NP>(v[4 * q + i], p);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) a[k][i] = p[k];
+        }
+        const int off = ray * SHB + 2 * (32 * ub + 8 * q + 4 * h);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(pl + k * PH + off) = a[k];
     }
 }
 
-__global__ void __launch_bounds__(256) k_brdf_mlp_fwd(MlpW w, const float* __restrict__ half_v,
-                                                      const float* __restrict__ diff_v,
-                                                      const float* __restrict__ feat_src,
-                                                      const float* __restrict__ rough_src,
-                                                      const int32_t* __restrict__ src_idx, int64_t R, float out_bias,
-                                                      float* __restrict__ out) {
-    __shared__ float Xs[TR * LS], H1s[TR * LS], H2s[TR * LS];
-    __shared__ float W4s[4 * HID], b4s[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-    float w0reg[K1], w2reg[K2];
-    load_wreg<K1>(w0reg, w.W0, IN, IN, wc, lane);
-    load_wreg<K2>(w2reg, w.W2, HID, HID, wc, lane);
-    W4s[t] = w.W4[t];
-    if (t < 4) b4s[t] = w.b4[t];
-    const int64_t n_tiles = (R + TR - 1) / TR;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * TR;
-        __syncthreads();
-        build_x_tile(Xs, r0, R, half_v, diff_v, feat_src, rough_src, src_idx);
-        __syncthreads();
-        layer_quadrant<K1>(Xs, H1s, w0reg, w.b0, wr, wc, lane, true);
-        __syncthreads();
-        layer_quadrant<K2>(H1s, H2s, w2reg, w.b2, wr, wc, lane, true);
-        __syncthreads();
-        const int ray = t >> 2, j = t & 3;
-        if (j < 3 && r0 + ray < R) {
-            float o = b4s[j];
-            const float* h = H2s + ray * LS;
-#pragma unroll 8
-            for (int k = 0; k < HID; ++k) o += h[k] * W4s[j * HID + k];
-            out[(r0 + ray) * 3 + j] = 1.f / (1.f + expf(-(o + out_bias)));      // modules/brdf.py:131
-        }
-    }
+__device__ __forceinline__ bf16x8 pack8(const floatx16& t, int o) {
+    bf16x8 p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = (__bf16)t[o + i];
+    return p;
 }
 
-// dW (64 x 64 block) += A^T B over the 64 rays of the tile:  A[ray][i], B[ray][j] both LDS tiles (stride LS)
-__device__ __forceinline__ void outer_quadrant(floatx16& acc, const float* a_s, const float* b_s, int wr, int wc,
-                                               int lane) {
-    const float* ap = a_s + (lane >> 5) * LS + 32 * wr + (lane & 31);
-    const float* bp = b_s + (lane >> 5) * LS + 32 * wc + (lane & 31);
-    mfma_chain<TR / 2>(acc, [&](int kk) { return ap[2 * kk * LS]; }, [&](int kk) { return bp[2 * kk * LS]; });
-}
+// ------------------------------------------------------------------------------------------------------------------
+// Forward: three bf16 terms per operand, six products per K block.  act_mask (optional) [R][4]: per ray the ReLU masks
+// of the two hidden layers as 64-bit sets, {layer 1 units 0-31, 32-63, layer 2 units 0-31, 32-63}.
+// bit position of accumulator register q inside its 32-unit block, lane half 0 (half 1: 4 higher)
+__device__ __forceinline__ constexpr int acc_bit(int q) { return (q & 3) + 8 * (q >> 2); }
 
-__global__ void __launch_bounds__(256, 2) k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v,
-                                                      const float* __restrict__ diff_v,
-                                                      const float* __restrict__ feat_src,
-                                                      const float* __restrict__ rough_src,
-                                                      const int32_t* __restrict__ src_idx, int64_t R, float out_bias,
-                                                      const float* __restrict__ d_out, float* __restrict__ d_xfeat,
-                                                      float* __restrict__ gW0, float* __restrict__ gb0,
-                                                      float* __restrict__ gW2, float* __restrict__ gb2,
-                                                      float* __restrict__ gW4, float* __restrict__ gb4) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                    // [64][67]
-    float* H1s = Xs + TR * LS;           // H1, later dH1
-    float* H2s = H1s + TR * LS;          // H2, later dH2
-    float* W2s = H2s + TR * LS;          // [64][64]  (row = unit of layer 2)
-    float* W0f = W2s + HID * HID;        // [64][24]  feature columns of W0
-    float* W4s = W0f + HID * 24;         // [4][64]
-    float* dOs = W4s + 4 * HID;          // [64][4]
-    float* b4s = dOs + TR * 4;           // [4]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-    float w0reg[K1], w2reg[K2];
-    load_wreg<K1>(w0reg, w.W0, IN, IN, wc, lane);
-    load_wreg<K2>(w2reg, w.W2, HID, HID, wc, lane);
-    for (int i = t; i < HID * HID; i += 256) W2s[i] = w.W2[i];
-    for (int i = t; i < HID * 24; i += 256) W0f[i] = w.W0[(i / 24) * IN + (i % 24)];
-    W4s[t] = w.W4[t];
-    if (t < 4) b4s[t] = w.b4[t];
-    // persistent accumulators
-    floatx16 accW2 = {0}, accW0 = {0};
-    float accW4 = 0.f;                   // thread (j = t>>6, k = t&63)
-    float accb = 0.f;                    // 64<=t<128: db2[t-64]; 128<=t<132: db4
-    float accW0tail = 0.f;               // waves 1, 3: dW0[lane][64 + (wave >> 1)]
-    float accb0 = 0.f;                   // wave 1: db0[lane]
-    const int64_t n_tiles = (R + TR - 1) / TR;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * TR;
-        __syncthreads();
-        build_x_tile(Xs, r0, R, half_v, diff_v, feat_src, rough_src, src_idx);
-        __syncthreads();
-        layer_quadrant<K1>(Xs, H1s, w0reg, w.b0, wr, wc, lane, true);
-        __syncthreads();
-        layer_quadrant<K2>(H1s, H2s, w2reg, w.b2, wr, wc, lane, true);
-        __syncthreads();
-        {   // output layer + adjoint of the sigmoid
-            const int ray = t >> 2, j = t & 3;
-            float g = 0.f;
-            if (j < 3 && r0 + ray < R) {
-                float o = b4s[j];
-                const float* h = H2s + ray * LS;
-#pragma unroll 8
-                for (int k = 0; k < HID; ++k) o += h[k] * W4s[j * HID + k];
-                const float s = 1.f / (1.f + expf(-(o + out_bias)));
-                g = d_out[(r0 + ray) * 3 + j] * s * (1.f - s);
-            }
-            dOs[ray * 4 + j] = g;
-        }
-        __syncthreads();
-        {   // dW4[j][k] += sum_ray dO[ray][j] H2[ray][k]
-            const int j = t >> 6, k = t & 63;
-            float a = 0.f;
-#pragma unroll 8
-            for (int ray = 0; ray < TR; ++ray) a += dOs[ray * 4 + j] * H2s[ray * LS + k];
-            accW4 += a;
-            if (t >= 128 && t < 132) {
-                float b = 0.f;
-                for (int ray = 0; ray < TR; ++ray) b += dOs[ray * 4 + (t - 128)];
-                accb += b;
-            }
-        }
-        __syncthreads();
-        {   // dH2 = (dO W4) * [H2 > 0]   (in place)
-            const int ray = t >> 2, k0 = (t & 3) * 16;
-            const float d0 = dOs[ray * 4], d1 = dOs[ray * 4 + 1], d2 = dOs[ray * 4 + 2];
+__global__ void __launch_bounds__(64 * FWD_WAVES)
+k_brdf_mlp_fwd(MlpW w, const float* __restrict__ half_v, const float* __restrict__ diff_v,
+               const float* __restrict__ feat_src, const float* __restrict__ rough_src,
+               const int32_t* __restrict__ src_idx, int64_t R, float out_bias, float* __restrict__ out,
+               uint4* __restrict__ act_mask) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
+    const int64_t n_tiles = (R + RT - 1) / RT, stride = (int64_t)gridDim.x * FWD_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
+    RayIn cur;
+    ray_in_stage1(cur, tile, R, ray, h, half_v, diff_v, src_idx);
+    stage_weights<3, false, 64 * FWD_WAVES>(smem, F_W0, F_W2, 0, 0, w, t);
+    float* W4w = reinterpret_cast<float*>(smem + F_W4);
+    for (int i = t; i < 3 * HID; i += 64 * FWD_WAVES) W4w[i] = w.W4[i];
+    if (t < HID) reinterpret_cast<float*>(smem + F_B2)[t] = w.b2[t];
+    if (t < 4) reinterpret_cast<float*>(smem + F_B4)[t] = w.b4[t];
+    ray_in_stage2(cur, feat_src, rough_src);
+    char* x = smem + FWD_SHARED + wave * FWD_PRIVATE;      // input planes, then the planes of H1
+    const float* W4s = reinterpret_cast<const float*>(smem + F_W4);
+    const float* b2s = reinterpret_cast<const float*>(smem + F_B2);
+    const float* b4s = reinterpret_cast<const float*>(smem + F_B4);
+    const int ox = ray * SXB + 16 * h, oh = ray * SHB + 16 * h;
+    __syncthreads();
+    for (; tile < n_tiles; tile += stride) {
+        RayIn nxt;
+        ray_in_stage1(nxt, tile + stride, R, ray, h, half_v, diff_v, src_idx);
+        build_x<3>(x, cur, ray, h);
+        __builtin_amdgcn_wave_barrier();
+        floatx16 a1[2] = {{0}, {0}};
+        product<3, 5, 2, false, true>(
+            a1, [&](int ub, int kk) { return ldop<3>(smem, F_W0 + 32 * ub * SXB + ox + 32 * kk, PW0); },
+            [&](int, int kk) { return ldop<3>(x, ox + 32 * kk, PX); });
+        ray_in_stage2(nxt, feat_src, rough_src);
+        uint32_t m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
 #pragma unroll
-            for (int k = k0; k < k0 + 16; ++k) {
-                float* h = H2s + ray * LS + k;
-                const float v = d0 * W4s[k] + d1 * W4s[HID + k] + d2 * W4s[2 * HID + k];
-                *h = *h > 0.f ? v : 0.f;
-            }
-        }
-        __syncthreads();
-        outer_quadrant(accW2, H2s, H1s, wr, wc, lane);                 // dW2 += dH2^T H1
-        if (t >= 64 && t < 128) {                                      // db2
-            float b = 0.f;
-            for (int ray = 0; ray < TR; ++ray) b += H2s[ray * LS + (t - 64)];
-            accb += b;
-        }
-        floatx16 acc = {0};                                            // dH1 = dH2 W2 (pre-mask), quadrant (wr, wc)
-        {
-            const float* arow = H2s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
-            const float* brow = W2s + (lane >> 5) * HID + 32 * wc + (lane & 31);
-            mfma_chain<K2>(acc, [&](int kk) { return arow[2 * kk]; }, [&](int kk) { return brow[2 * kk * HID]; });
-        }
-        __syncthreads();                                               // everyone is done reading H1
-        {
-            const int col = 32 * wc + (lane & 31);
+        for (int ub = 0; ub < 2; ++ub) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* h = H1s + row * LS + col;
-                *h = *h > 0.f ? acc[r] : 0.f;                          // relu'
+            for (int q = 0; q < 16; ++q) {
+                m1[ub] |= a1[ub][q] > 0.f ? (1u << acc_bit(q)) : 0u;
+                a1[ub][q] = fmaxf(a1[ub][q], 0.f);
             }
+            write_rows<3>(x, ray, ub, h, a1[ub]);
         }
-        __syncthreads();
-        outer_quadrant(accW0, H1s, Xs, wr, wc, lane);                  // dW0[:, 0:64] += dH1^T X[:, 0:64]
-        if (wc == 0) {
-            // dX[:, 0:24] = dH1 W0[:, 0:24] -> adjoint of the gathered feature row, on the matrix core: waves 0 and 2 own
-            // the ray blocks 0-31 / 32-63 of a 64 x 32 product (feature columns 24..31 are padding), K = 64 units
-            floatx16 dx = {0};
-            const float* arow = H1s + (32 * wr + (lane & 31)) * LS + (lane >> 5);
-            const int col = lane & 31;
-            const float* brow = W0f + (lane >> 5) * 24 + (col < 24 ? col : 0);
-            const float bmask = col < 24 ? 1.f : 0.f;
-            mfma_chain<K2>(dx, [&](int kk) { return arow[2 * kk]; }, [&](int kk) { return brow[2 * kk * 24] * bmask; });
-            if (col < 24) {
+        __builtin_amdgcn_wave_barrier();
+        floatx16 a2[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = r0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < R) d_xfeat[row * 24 + col] = dx[r];
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const floatx4v b = *reinterpret_cast<const floatx4v*>(b2s + 32 * ub + 8 * q + 4 * h);
+                a2[ub][4 * q] = b[0]; a2[ub][4 * q + 1] = b[1]; a2[ub][4 * q + 2] = b[2]; a2[ub][4 * q + 3] = b[3];
+            }
+        product<3, 4, 2, false, true>(
+            a2, [&](int ub, int kk) { return ldop<3>(smem, F_W2 + 32 * ub * SHB + oh + 32 * kk, PW2); },
+            [&](int, int kk) { return ldop<3>(x, oh + 32 * kk, PH); });
+        // output layer (fp32 on the VALU): o_j = sum_u relu(H2)[u] W4[j][u], the units of both lane halves
+        float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u0 = 32 * ub + 8 * q + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m2[ub] |= a2[ub][4 * q + i] > 0.f ? (1u << acc_bit(4 * q + i)) : 0u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const floatx4v wv = *reinterpret_cast<const floatx4v*>(W4s + j * HID + u0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[j] += fmaxf(a2[ub][4 * q + i], 0.f) * wv[i];
                 }
             }
-        } else {
-            // meanwhile waves 1 and 3: the two trailing input columns 64, 65 of dW0, then db0 on wave 1
-            const int i = lane, c = 64 + wr;
-            float a = 0.f;
-#pragma unroll 8
-            for (int ray = 0; ray < TR; ++ray) a += H1s[ray * LS + i] * Xs[ray * LS + c];
-            accW0tail += a;
-            if (wr == 0) {
-                float b = 0.f;
-#pragma unroll 8
-                for (int ray = 0; ray < TR; ++ray) b += H1s[ray * LS + lane];
-                accb0 += b;
-            }
-        }
-    }
-    // flush the per-workgroup weight gradients
-    {
-        const int col = 32 * wc + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(gW2 + row * HID + col, accW2[r]);
-            atomicAdd(gW0 + row * IN + col, accW0[r]);
+        for (int j = 0; j < 3; ++j) {
+            o[j] += __shfl_xor(o[j], 32, 64);
+            const float s = 1.f / (1.f + expf(-(o[j] + b4s[j] + out_bias)));      // modules/brdf.py:131
+            if (cur.valid && h == 0) out[cur.r * 3 + j] = s;
         }
-        if (wc == 1) atomicAdd(gW0 + lane * IN + 64 + wr, accW0tail);
-        atomicAdd(gW4 + (t >> 6) * HID + (t & 63), accW4);
-        if (wave == 1) atomicAdd(gb0 + lane, accb0);
-        if (t >= 64 && t < 128) atomicAdd(gb2 + (t - 64), accb);
-        else if (t >= 128 && t < 132) atomicAdd(gb4 + (t - 128), accb);
+        if (act_mask) {
+            uint4 mk = make_uint4(m1[0] << (4 * h), m1[1] << (4 * h), m2[0] << (4 * h), m2[1] << (4 * h));
+            mk.x |= __shfl_xor(mk.x, 32, 64); mk.y |= __shfl_xor(mk.y, 32, 64);
+            mk.z |= __shfl_xor(mk.z, 32, 64); mk.w |= __shfl_xor(mk.w, 32, 64);
+            if (cur.valid && h == 0) act_mask[cur.r] = mk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
     }
 }
 
-constexpr int BWD_LDS = (3 * TR * LS + HID * HID + HID * 24 + 4 * HID + TR * 4 + 4) * sizeof(float);
+// ------------------------------------------------------------------------------------------------------------------
+// The operand registers of a 64-wide activation tile (rows = rays, 16-column blocks) -> the same tile with the UNIT on
+// the lane and the rays along the registers, as operand registers of the weight-gradient products ([kp] = the
+// accumulator registers 8 kp .. 8 kp + 7).  sum (optional) += the column sums (a bias gradient).
+struct UOp {
+    Op<2> k[2];
+};
+__device__ __forceinline__ UOp transpose_block(const Op<2>& c0, const Op<2>& c1, bf16x8 e0, bf16x8 e1, float* sum) {
+    floatx16 th = {0}, tl = {0};
+    th = mfma(c0.p[0], e0, th);
+    tl = mfma(c0.p[1], e0, tl);
+    th = mfma(c1.p[0], e1, th);
+    tl = mfma(c1.p[1], e1, tl);
+    if (sum) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += th[r] + tl[r];
+        *sum += s;
+    }
+    UOp u;
+    u.k[0].p[0] = pack8(th, 0); u.k[1].p[0] = pack8(th, 8);
+    u.k[0].p[1] = pack8(tl, 0); u.k[1].p[1] = pack8(tl, 8);
+    return u;
+}
+
+constexpr int N_PERSIST = 64 + 64 + 8 + 6 + 2 + 3;   // per-lane partial sums that are reduced over the waves at the end
+
+// Backward.  fwd_out / act_mask are the forward's outputs for the same inputs.
+__global__ void __launch_bounds__(64 * BWD_WAVES)
+k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict__ diff_v,
+               const float* __restrict__ feat_src, const float* __restrict__ rough_src,
+               const int32_t* __restrict__ src_idx, int64_t R, const float* __restrict__ fwd_out,
+               const uint4* __restrict__ act_mask, const float* __restrict__ d_out, float* __restrict__ d_xfeat,
+               float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
+    const int64_t n_tiles = (R + RT - 1) / RT, stride = (int64_t)gridDim.x * NW;
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    // the forward's outputs and the incoming adjoint of a lane's ray, one tile ahead like RayIn
+    struct Adj {
+        uint4 mk;
+        float g[3];
+    };
+    auto load_adj = [&](Adj& a, const RayIn& in) {
+        a.mk = act_mask[in.rc];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float s = fwd_out[in.rc * 3 + j];
+            a.g[j] = in.valid ? d_out[in.rc * 3 + j] * s * (1.f - s) : 0.f;
+        }
+    };
+    RayIn cur;
+    Adj adj;
+    ray_in_stage1(cur, tile, R, ray, h, half_v, diff_v, src_idx);
+    load_adj(adj, cur);
+    stage_weights<2, true, NT>(smem, B_W0, B_W2, B_W2T, B_WFT, w, t);
+    float* W4w = reinterpret_cast<float*>(smem + B_W4);
+    for (int i = t; i < 3 * HID; i += NT) W4w[i] = w.W4[i];
+    if (t < HID) reinterpret_cast<float*>(smem + B_B2)[t] = w.b2[t];
+    ray_in_stage2(cur, feat_src, rough_src);
+    char* priv = smem + BWD_SHARED + wave * BWD_PRIVATE;
+    char* x = priv;                                                 // input planes
+    char* pl = priv + 2 * PX;                                       // 64-wide planes: H1, then dH2, then dH1
+    float* gs = reinterpret_cast<float*>(priv + 2 * PX + 2 * PH);   // adjoint of the pre-sigmoid outputs [32][4]
+    const float* W4s = reinterpret_cast<const float*>(smem + B_W4);
+    const float* b2s = reinterpret_cast<const float*>(smem + B_B2);
+    // selector operands of the transposition: E_s[k][j] = 1 iff j == 16 s + k
+    bf16x8 e0, e1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        e0[e] = (__bf16)(ray == 8 * h + e ? 1.f : 0.f);
+        e1[e] = (__bf16)(ray == 16 + 8 * h + e ? 1.f : 0.f);
+    }
+    // operand offsets of this lane: row (lane & 31), 16-byte half h of a 32-byte k block
+    const int ox = ray * SXB + 16 * h, oh = ray * SHB + 16 * h;
+    floatx16 accW2[2][2], accW0[2][2];
+    float accTail[2][4], accW4[3][2], accb2[2], accb4[3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accW2[a][b][q] = 0.f, accW0[a][b][q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accTail[a][q] = 0.f;
+        accb2[a] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) accW4[j][a] = 0.f;
+    }
+    accb4[0] = accb4[1] = accb4[2] = 0.f;
+    __syncthreads();
+    build_x<2>(x, cur, ray, h);
+    __builtin_amdgcn_wave_barrier();
+    for (; tile < n_tiles; tile += stride) {
+        // the input planes of this tile are in LDS; the row indices / adjoints of the next one are requested now
+        RayIn nxt;
+        Adj nadj;
+        ray_in_stage1(nxt, tile + stride, R, ray, h, half_v, diff_v, src_idx);
+        load_adj(nadj, nxt);
+        const uint32_t m1[2] = {adj.mk.x >> (4 * h), adj.mk.y >> (4 * h)}, m2[2] = {adj.mk.z >> (4 * h), adj.mk.w >> (4 * h)};
+        if (h == 0) {
+            floatx4v gv = {adj.g[0], adj.g[1], adj.g[2], 0.f};
+            *reinterpret_cast<floatx4v*>(gs + 4 * ray) = gv;
+            accb4[0] += adj.g[0]; accb4[1] += adj.g[1]; accb4[2] += adj.g[2];
+        }
+        // ---- layer 1 (values; the forward's mask decides which units are alive): H1^T = [m1] (W0 X^T)
+        {
+            floatx16 a1[2] = {{0}, {0}};
+            product<2, 5, 2, false, true>(
+                a1, [&](int ub, int kk) { return ldop<2>(smem, B_W0 + 32 * ub * SXB + ox + 32 * kk, PW0); },
+                [&](int, int kk) { return ldop<2>(x, ox + 32 * kk, PX); });
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a1[ub][q] = (m1[ub] >> acc_bit(q)) & 1u ? a1[ub][q] : 0.f;
+                write_rows<2>(pl, ray, ub, h, a1[ub]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        UOp h1u[2];
+        {
+            Op<2> hb[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) hb[kk] = ldop<2>(pl, oh + 32 * kk, PH);
+            // ---- layer 2 with the unit on the lane (rows = rays): relu(H2) as values for dW4
+            floatx16 a2u[2] = {{0}, {0}};
+            product<2, 4, 2, true, false>(
+                a2u, [&](int, int kk) { return hb[kk]; },
+                [&](int ub, int kk) { return ldop<2>(smem, B_W2 + 32 * ub * SHB + oh + 32 * kk, PW2); });
+            h1u[0] = transpose_block(hb[0], hb[1], e0, e1, nullptr);
+            h1u[1] = transpose_block(hb[2], hb[3], e0, e1, nullptr);
+            // dW4[j][u] += sum_ray g[ray][j] relu(H2)[ray][u]
+            const float bu0 = b2s[ray], bu1 = b2s[32 + ray];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const floatx4v gv = *reinterpret_cast<const floatx4v*>(gs + 4 * acc_row(q, h));
+                const float v0 = fmaxf(a2u[0][q] + bu0, 0.f), v1 = fmaxf(a2u[1][q] + bu1, 0.f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) accW4[j][0] += gv[j] * v0, accW4[j][1] += gv[j] * v1;
+            }
+        }
+        // ---- dH2 = [m2] (g W4)  -> row-major planes (H1's operands are in registers by now)
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            floatx16 d2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u0 = 32 * ub + 8 * q + 4 * h;
+                const floatx4v w0 = *reinterpret_cast<const floatx4v*>(W4s + u0);
+                const floatx4v w1 = *reinterpret_cast<const floatx4v*>(W4s + HID + u0);
+                const floatx4v w2 = *reinterpret_cast<const floatx4v*>(W4s + 2 * HID + u0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = adj.g[0] * w0[i] + adj.g[1] * w1[i] + adj.g[2] * w2[i];
+                    d2[4 * q + i] = (m2[ub] >> acc_bit(4 * q + i)) & 1u ? d : 0.f;
+                }
+            }
+            write_rows<2>(pl, ray, ub, h, d2);
+        }
+        __builtin_amdgcn_wave_barrier();
+        ray_in_stage2(nxt, feat_src, rough_src);     // the next tile's feature rows: used at the end of this iteration
+        {
+            Op<2> dh[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dh[kk] = ldop<2>(pl, oh + 32 * kk, PH);
+            // dH1^T = [m1] (W2^T dH2^T)
+            floatx16 d1[2] = {{0}, {0}};
+            product<2, 4, 2, false, true>(
+                d1, [&](int ub, int kk) { return ldop<2>(smem, B_W2T + 32 * ub * SHB + oh + 32 * kk, PW2); },
+                [&](int, int kk) { return dh[kk]; });
+            // dW2 += dH2^T H1, db2 += column sums of dH2 (register operands only)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const UOp d2u = transpose_block(dh[2 * a], dh[2 * a + 1], e0, e1, &accb2[a]);
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            mfma_acc(accW2[a][b], d2u.k[kp].p[Terms<2>::A[i]], h1u[b].k[kp].p[Terms<2>::B[i]]);
+            }
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d1[ub][q] = (m1[ub] >> acc_bit(q)) & 1u ? d1[ub][q] : 0.f;
+                write_rows<2>(pl, ray, ub, h, d1[ub]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        floatx16 dx[1] = {{0}};
+        {
+            Op<2> dh[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dh[kk] = ldop<2>(pl, oh + 32 * kk, PH);
+            // adjoint of the gathered feature columns: dX[:, 0:24]^T = W0[:, 0:24]^T dH1^T
+            product<2, 4, 1, false, true>(
+                dx, [&](int, int kk) { return ldop<2>(smem, B_WFT + oh + 32 * kk, 32 * SHB); },
+                [&](int, int kk) { return dh[kk]; });
+            // dW0 += dH1^T X (input columns 0-63 as two 32-column blocks; 64-79 through the transposed product)
+            UOp d1u[2];
+            d1u[0] = transpose_block(dh[0], dh[1], e0, e1, nullptr);
+            d1u[1] = transpose_block(dh[2], dh[3], e0, e1, nullptr);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const UOp xu = transpose_block(ldop<2>(x, ox + 64 * cb, PX), ldop<2>(x, ox + 64 * cb + 32, PX), e0, e1, nullptr);
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            mfma_acc(accW0[a][cb], d1u[a].k[kp].p[Terms<2>::A[i]], xu.k[kp].p[Terms<2>::B[i]]);
+            }
+            {
+                const Op<2> xt = ldop<2>(x, ox + 128, PX);
+                floatx16 th = {0}, tl = {0};
+                th = mfma(xt.p[0], e0, th);
+                tl = mfma(xt.p[1], e0, tl);
+                Op<2> xk[2];
+                xk[0].p[0] = pack8(th, 0); xk[1].p[0] = pack8(th, 8);
+                xk[0].p[1] = pack8(tl, 0); xk[1].p[1] = pack8(tl, 8);
+                floatx16 tt[2] = {{0}, {0}};
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            tt[a] = mfma(xk[kp].p[Terms<2>::A[i]], d1u[a].k[kp].p[Terms<2>::B[i]], tt[a]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) accTail[a][q] += tt[a][q];
+            }
+        }
+        // ---- the input planes of the next tile (this tile's have been read)
+        __builtin_amdgcn_wave_barrier();
+        build_x<2>(x, nxt, ray, h);
+        if (cur.valid) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                floatx4v v = {dx[0][4 * q], dx[0][4 * q + 1], dx[0][4 * q + 2], dx[0][4 * q + 3]};
+                *reinterpret_cast<floatx4v*>(d_xfeat + cur.r * 24 + 8 * q + 4 * h) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+        adj = nadj;
+    }
+    // ---- the per-lane sums of the four waves -> one partial per workgroup in the workspace (k_brdf_mlp_reduce adds the
+    //      partials of all workgroups in a fixed order: one atomic per gradient element and call instead of one per workgroup)
+    asm volatile("s_nop 15\n\ts_nop 15");      // the last accumulator MFMAs have retired before their registers are read
+    __syncthreads();
+    {
+        float* red = reinterpret_cast<float*>(smem) + wave * (N_PERSIST * 64);      // the weight images are dead by now
+        int idx = 0;
+        auto put = [&](float v) {
+            red[idx * 64 + lane] = v;
+            ++idx;
+        };
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) put(accW2[a][b][q]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) put(accW0[a][b][q]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) put(accTail[a][q]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) put(accW4[j][a]);
+        put(accb2[0]);
+        put(accb2[1]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) put(h == 0 ? accb4[j] : 0.f);
+    }
+    __syncthreads();
+    {
+        const float* red = reinterpret_cast<const float*>(smem);
+        float* part = partials + (int64_t)blockIdx.x * (N_PERSIST * 64);
+        for (int e = t; e < N_PERSIST * 64; e += NT) {
+            float v = red[e];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) v += red[wv * (N_PERSIST * 64) + e];
+            part[e] = v;
+        }
+    }
+}
+
+// gradient element e of a workgroup partial (layout: k_brdf_mlp_bwd's `put` order x 64 lanes) += sum over the workgroups
+__global__ void __launch_bounds__(256)
+k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restrict__ gW0, float* __restrict__ gb0,
+                  float* __restrict__ gW2, float* __restrict__ gb2, float* __restrict__ gW4, float* __restrict__ gb4) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N_PERSIST * 64) return;
+    const int per = (n_wg + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = min(n_wg, w0 + per);
+    float v = 0.f;
+    for (int wg = w0; wg < w1; ++wg) v += partials[(int64_t)wg * (N_PERSIST * 64) + e];
+    if (w0 >= w1) return;
+    const int idx = e >> 6, ln = e & 63, hh = ln >> 5, c = ln & 31;
+    if (idx < 64) {                                   // dW2[a][b]: row = u2, column = u1
+        const int a = idx >> 5, b = (idx >> 4) & 1, q = idx & 15;
+        atomicAdd(gW2 + (32 * a + acc_row(q, hh)) * HID + 32 * b + c, v);
+    } else if (idx < 128) {                           // dW0[a][cb]: row = u1, column = input column 32 cb + c
+        const int k = idx - 64, a = k >> 5, cb = (k >> 4) & 1, q = k & 15;
+        const int u = 32 * a + acc_row(q, hh), co = col_orig(32 * cb + c);
+        if (co >= 0) atomicAdd(gW0 + u * IN + co, v);
+        else if (co == -1) atomicAdd(gb0 + u, v);
+    } else if (idx < 136) {                           // input columns 64 + acc_row(q, hh), unit 32 a + c
+        const int k = idx - 128, a = k >> 2, q = k & 3;
+        const int co = col_orig(64 + acc_row(q, hh));
+        if (co >= 0) atomicAdd(gW0 + (32 * a + c) * IN + co, v);
+    } else if (idx < 142) {
+        const int k = idx - 136, j = k >> 1, a = k & 1;
+        atomicAdd(gW4 + j * HID + 32 * a + c, v);
+    } else if (idx < 144) {
+        atomicAdd(gb2 + 32 * (idx - 142) + c, v);
+    } else {
+        atomicAdd(gb4 + (idx - 144), v);
+    }
+}
 
 }  // namespace
 
@@ -365,45 +790,63 @@ static int check_w(const float* const* p) {
 extern "C" int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                                 const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
-                                int32_t max_workgroups, void* stream) {
+                                uint32_t* act_mask, int32_t max_workgroups, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_fwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
     NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && out, NMF_EINVAL, "nmf_brdf_mlp_fwd: null");
     MlpW w{W0, b0, W2, b2, W4, b4};
-    const int64_t tiles = cdiv(R, TR);
-    int64_t cap = 1024;
+    hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_fwd: hipFuncSetAttribute");
+    const int64_t wgs = cdiv(cdiv(R, RT), FWD_WAVES);
+    int64_t cap = 256;                                  // one workgroup per CU (127 KB of LDS)
     if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
-    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-    hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, half_vec, diff_vec, feat_src,
-                       rough_src, src_idx, R, out_bias, out);
+    const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
+    hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(64 * FWD_WAVES), FWD_LDS, (hipStream_t)stream, w, half_vec,
+                       diff_vec, feat_src, rough_src, src_idx, R, out_bias, out, reinterpret_cast<uint4*>(act_mask));
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_fwd");
     return NMF_OK;
 }
 
+static unsigned bwd_grid(int64_t R, int32_t max_workgroups) {
+    // One workgroup of 4 waves per CU (150 KB of LDS, one wave per SIMD).  Every workgroup stages the weight images (~5 us)
+    // and writes a 37 KB partial, so short launches use fewer of them: at least 4 tiles per wave.
+    const int64_t wgs = cdiv(cdiv(R, RT), BWD_WAVES * 4);
+    int64_t cap = 256;
+    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
+    return (unsigned)(wgs < cap ? wgs : cap);
+}
+
+extern "C" int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups) {
+    return R <= 0 ? 0 : (int64_t)bwd_grid(R, max_workgroups) * N_PERSIST * 64 * (int64_t)sizeof(float);
+}
+
 extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
-                                const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias,
-                                const float* d_out, float* d_xfeat, float* gW0, float* gb0, float* gW2, float* gb2,
-                                float* gW4, float* gb4, int32_t max_workgroups, void* stream) {
+                                const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
+                                const uint32_t* act_mask, const float* d_out, float* d_xfeat, float* gW0, float* gb0,
+                                float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
-    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && d_out && d_xfeat && gW0 && gb0 && gW2 &&
-                    gb2 && gW4 && gb4,
+    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_xfeat &&
+                    gW0 && gb0 && gW2 && gb2 && gW4 && gb4,
                 NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
+    NMF_REQUIRE(workspace && workspace_bytes >= nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups), NMF_EINVAL,
+                "nmf_brdf_mlp_bwd: workspace too small (nmf_brdf_mlp_bwd_workspace_bytes)");
+    static_assert(BWD_WAVES * N_PERSIST * 64 * 4 <= BWD_LDS, "the per-wave sums fit into the kernel's LDS");
     MlpW w{W0, b0, W2, b2, W4, b4};
     hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
-    const int64_t tiles = cdiv(R, TR);
-    // The kernel is compiled for two workgroups per CU (<= 256 registers, 2 x 76 KB of LDS).  The second one hides barrier
-    // and LDS latency of the first but doubles the weight staging and the 8.5 k flush atomics per workgroup, so it only
-    // pays for long launches (measured: 242 k rays 210 -> 187 us, 46 k rays 60 -> 68 us).
-    int64_t cap = tiles >= 2048 ? 512 : 256;
-    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
-    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(256), BWD_LDS, (hipStream_t)stream, w, half_vec, diff_vec,
-                       feat_src, rough_src, src_idx, R, out_bias, d_out, d_xfeat, gW0, gb0, gW2, gb2, gW4, gb4);
+    const unsigned grid = bwd_grid(R, max_workgroups);
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, half_vec,
+                       diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
+                       d_out, d_xfeat, partials);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
+    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), grid >= 64 ? 4 : 1), dim3(256), 0,
+                       (hipStream_t)stream, partials, (int)grid, gW0, gb0, gW2, gb2, gW4, gb4);
+    NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;
 }

@@ -12,7 +12,12 @@ for f in "$here"/*.hip; do
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$here/common.hpp" -nt "$o" ] || [ "$here/../../include/nmf_hip.h" -nt "$o" ]; then
     extra=""
     # bookkeeping kernels must reproduce the CPU oracle bit-for-bit: no a*b+c -> fma contraction there
-    case "$(basename "$f")" in march.hip|select.hip|composite.hip|env.hip) extra="-ffp-contract=off" ;; esac
+    case "$(basename "$f")" in
+      march.hip|select.hip|composite.hip|env.hip) extra="-ffp-contract=off" ;;
+      # the MLP backward keeps 128 accumulator registers alive across its loop: transient MFMA results go to VGPRs directly
+      # (the default picks the AGPR form for every MFMA of a 512-register kernel and copies each result out)
+      brdf_mlp.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1" ;;
+    esac
     "$HIPCC" $FLAGS $extra -c "$f" -o "$o" &
   fi
   objs+=("$o")

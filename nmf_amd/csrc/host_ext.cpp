@@ -240,17 +240,22 @@ std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg,
     return {seg, loc};
 }
 
-Tensor brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
-                    const Tensor& rough_src, const OT& src_idx, double out_bias, int64_t max_workgroups, int64_t stream) {
+// returns {out [R,3], act_mask [R,4] int32 (undefined tensor without with_mask)}
+std::tuple<Tensor, Tensor> brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec,
+                                        const Tensor& feat_src, const Tensor& rough_src, const OT& src_idx, double out_bias,
+                                        bool with_mask, int64_t max_workgroups, int64_t stream) {
     TimedScope _ts(__func__, stream);
     if (w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor o = fe(half_vec, {R, 3});
+    Tensor mask;
+    if (with_mask) mask = ie(half_vec, {R, 4}, at::kInt);
     check(nmf_brdf_mlp_fwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
                            f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
-                           (int32_t)max_workgroups, st(stream)),
+                           with_mask ? static_cast<uint32_t*>(mask.data_ptr()) : nullptr, (int32_t)max_workgroups,
+                           st(stream)),
           "nmf_brdf_mlp_fwd");
-    return o;
+    return {o, mask};
 }
 
 Tensor heads_fwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, int64_t stream) {
@@ -395,8 +400,8 @@ OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, doubl
 }
 
 Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
-                    const Tensor& rough_src, const OT& src_idx, double out_bias, const Tensor& d_out,
-                    const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream) {
+                    const Tensor& rough_src, const OT& src_idx, const Tensor& fwd_out, const Tensor& act_mask,
+                    const Tensor& d_out, const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream) {
     TimedScope _ts(__func__, stream);
     if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
     const int64_t R = half_vec.size(0);
@@ -404,9 +409,12 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     Tensor go = d_out.contiguous();
     float* g[6];
     for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
+    const int64_t nws = nmf_brdf_mlp_bwd_workspace_bytes(R, (int32_t)max_workgroups);
+    Tensor ws = fe(half_vec, {std::max<int64_t>(nws, 4) / 4});
     check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
-                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, f32(go),
-                           out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, st(stream)),
+                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, f32(fwd_out),
+                           static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, out(ws), nws,
+                           st(stream)),
           "nmf_brdf_mlp_bwd");
     return d_xfeat;
 }

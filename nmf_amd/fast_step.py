@@ -418,11 +418,13 @@ class TrainPass:
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, off, cnt32, sobol, row_of_ray, j_of_ray)
         sorts = pins is not None and pins.sorts(lvl)
         full_retrace = lvl < len(model.max_retrace_rays) and min(R, model.max_retrace_rays[lvl]) >= R and not sorts
-        brdf = None if full_retrace else hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
+        brdf = brdf_mask = None
+        if not full_retrace:
+            brdf, brdf_mask = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias, with_mask=True)
         t.__dict__.update(offsets=offsets, sf=sf, sg=sg, gr=gr, nr=nr, w=w, conv=conv, bidx=bidx, row_off=row_off, cnt32=cnt32,
                           inv=inv, R=R, Mb=Mb, row_of_ray=row_of_ray, j_of_ray=j_of_ray, off=off, xyz_rows=xyz_rows, app=app,
                           heads=heads, V=V, N=N, r1=r1, f0=f0, diff=diff, feat=feat, L=L, hl=hl, dl=dl, mip=mip, brays=brays,
-                          brdf=brdf, child=None, idx_re=None, idx_no=None, sparse_n=sparse_n, sf_rows=sf_rows, gr_rows=gr_rows)
+                          brdf=brdf, brdf_mask=brdf_mask, child=None, idx_re=None, idx_no=None, sparse_n=sparse_n, sf_rows=sf_rows, gr_rows=gr_rows)
         # ---- incoming radiance of the secondary rays (models/microfacet.py:475-563)
         if lvl < len(model.max_retrace_rays):
             num_retrace = min(R, model.max_retrace_rays[lvl])
@@ -430,7 +432,8 @@ class TrainPass:
                 noise.skip("rand", (R,))
 
                 def mlp():          # needs nothing of the level below: runs under its sampler's read-back
-                    t.brdf = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias)
+                    t.brdf, t.brdf_mask = hip.brdf_mlp_fwd(self.mlp_ws, hl, dl, feat, r1, row_of_ray, self.mlp_bias,
+                                                           with_mask=True)
                 t.child = self._fwd(lvl + 1, brays, focal, mip, noise, is_train, filler=mlp)
                 brdf = t.brdf
                 if t.child.M == 0:
@@ -536,8 +539,8 @@ class TrainPass:
         fork = self._fork(("mlp", lvl)) if (below or n_env >= MLP_SIDE_MIN_ENV_RAYS) else None
         if fork is not None:
             with _on(fork):
-                d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp,
-                                           max_workgroups=MLP_SIDE_WGS if below else MLP_SIDE_WGS_ENV)
+                d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf,
+                                           a.g_mlp, max_workgroups=MLP_SIDE_WGS if below else MLP_SIDE_WGS_ENV)
         # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
         if t.idx_re is None and t.child is not None:
             d_brays = self._bwd(t.child, d_inc, None, None)
@@ -567,7 +570,7 @@ class TrainPass:
         if fork is not None:
             self._join(fork, d_xfeat)
         else:
-            d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, self.mlp_bias, d_brdf, a.g_mlp)
+            d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf, a.g_mlp)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, t.row_off, t.Mb)
         sobol = self.nerf.model.brdf_sampler.angs
         if view:

@@ -374,16 +374,16 @@ class BrdfMLP(torch.autograd.Function):
         hv, dv = half_vec.contiguous(), diff_vec.contiguous()
         fr, rr = feat_rows.contiguous(), rough_rows.contiguous()
         ws = [w.detach().contiguous() for w in weights]
-        out = hip.brdf_mlp_fwd(ws, hv, dv, fr, rr, row_of_ray, out_bias)
-        ctx.save_for_backward(hv, dv, fr, rr, row_of_ray, row_offsets, *ws)
-        ctx.out_bias, ctx.holder = out_bias, holder
+        out, mask = hip.brdf_mlp_fwd(ws, hv, dv, fr, rr, row_of_ray, out_bias, with_mask=True)
+        ctx.save_for_backward(hv, dv, fr, rr, row_of_ray, row_offsets, out, mask, *ws)
+        ctx.holder = holder
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        hv, dv, fr, rr, row_of_ray, row_offsets, *ws = ctx.saved_tensors
+        hv, dv, fr, rr, row_of_ray, row_offsets, out, mask, *ws = ctx.saved_tensors
         grads = grad_views(ctx.holder, ws) if ctx.holder is not None else [torch.zeros_like(w) for w in ws]
-        d_xfeat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, ctx.out_bias, d_out, grads)
+        d_xfeat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, out, mask, d_out, grads)
         d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
         return (None, None, d_feat, None, None, None, None, None,
                 ctx.holder.token_grad(d_out) if ctx.holder is not None else None) + (None,) * len(ws)
@@ -616,9 +616,9 @@ class BounceRays(torch.autograd.Function):
         V, N, r1, f0, diff, feat, xyz = hip.bounce_prep_fwd(c.bidx, normals, app, heads, c.xyzt, c.ray_id, c.rays, c.conv,
                                                            c.feat_noise, c.anoise, c.min_rough, True)
         L, hl, dl, lpdf, mip, brays = hip.ggx_rays_fwd(V, N, r1, xyz, c.off, c.cnt, c.sobol, c.row_of_ray, c.j_of_ray)
-        brdf = hip.brdf_mlp_fwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias)
+        brdf, brdf_mask = hip.brdf_mlp_fwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias, with_mask=True)
         ctx.c = c
-        ctx.save_for_backward(normals, app, heads, V, N, r1, feat, hl, dl)
+        ctx.save_for_backward(normals, app, heads, V, N, r1, feat, hl, dl, brdf, brdf_mask)
         N_out = N.detach().clone()
         if ctx.view_grad:
             ctx.mark_non_differentiable(hl, dl, lpdf, mip, N_out)
@@ -630,13 +630,13 @@ class BounceRays(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dL, _hl, _dl, _lp, _mip, d_brays, d_brdf, dV_in, d_f0, d_diff, _dN):
         c = ctx.c
-        normals, app, heads, V, N, r1, feat, hl, dl = ctx.saved_tensors
+        normals, app, heads, V, N, r1, feat, hl, dl, brdf, brdf_mask = ctx.saved_tensors
         Mb = V.shape[0]
         cc = lambda t: None if t is None else t.contiguous()  # noqa: E731
         d_feat = None
         if d_brdf is not None:
             grads = grad_views(c.mlp_holder, c.mlp_ws) if c.mlp_holder is not None else [torch.zeros_like(w) for w in c.mlp_ws]
-            d_xfeat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, c.mlp_bias, d_brdf, grads)
+            d_xfeat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, brdf, brdf_mask, cc(d_brdf), grads)
             d_feat = hip.segment_sum_wide(d_xfeat, 24, c.row_off, Mb)
         dN = dr1 = dV_rows = None
         if dL is not None or d_brays is not None:
