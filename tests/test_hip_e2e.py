@@ -240,7 +240,14 @@ def _pin_reference_bookkeeping(g, order=True, valid=True, exact=False):
     and the re-trace order, which pairs each secondary ray with a jitter row.  Pinned for the radiance comparison; what
     the HIP path decides on its own is compared with them separately (counts_own, test_retrace_order_*)."""
     from nmf_amd.noise import Pins
-    pins = Pins(counts={0: g["counts0"].int(), 1: g["counts1"].int()}, exact_retrace_order=exact)
+    # The level-1 counts are indexed by the reference's level-1 SAMPLE LIST: they mean something only when the occupancy
+    # decisions that produce that list are replayed too.  Otherwise level 1 keeps its own counts (Pins only applies pinned
+    # counts of matching length, which used to drop them silently -- until an own list happened to have the reference's
+    # length, 867 946 samples in a different order, and the reference's counts landed on the wrong samples).
+    counts = {0: g["counts0"].int()}
+    if valid:
+        counts[1] = g["counts1"].int()
+    pins = Pins(counts=counts, exact_retrace_order=exact)
     if order and "retrace_order0" in g:
         pins.retrace_order[0] = g["retrace_order0"].long()
     if valid and "valid1" in g:
