@@ -35,8 +35,10 @@ MLP_SIDE_MIN_ENV_RAYS = 200000   # ... or when this many of the level's own boun
 MLP_SIDE_WGS_ENV = 256           # workgroups next to that env-map adjoint alone (atomic-bound, needs little of a CU): 128 made
                                  # the MLP the long pole (0.5 M rays at half the re-trace count: 3.78 ms against 3.39 / 3.51 without fork)
 WALK_SIDE_MIN_SAMPLES = 200000
-MLP_SIDE_WGS = 256      # persistent workgroups of a BRDF-MLP backward that shares the chip (in-process A/B at the end of round
-                        # 2: 64 +15 %, 96 +1.5 %, 128 +0.6 %, 192 / 256 best, 384 +4 %, uncapped (512) +8 %; csrc/brdf_mlp.hip)
+MLP_SIDE_WGS = 96       # persistent workgroups of a BRDF-MLP backward that shares the chip.  Round 3 (split-bf16 kernel, one
+                        # workgroup of 4 waves and 150 KB of LDS per CU): in-process A/B 32: 1.812 ms, 64: 1.628, 96: 1.608,
+                        # 128: 1.625, 192: 1.678, 256: 1.696 -- the launch is short now, and every CU it occupies is a CU whose
+                        # LDS the kernels of the main stream cannot use (round 2, fp32 kernel: 192 / 256 best)
 
 
 def _ns(**kw):
