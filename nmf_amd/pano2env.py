@@ -8,7 +8,8 @@ Same recipe: an `IntegralEquirect(bg_resolution=res, mipbias=0, activation='exp'
 brightness_lr=0, betas=[0,0])`, Adam over its param groups with cosine annealing (eta_min 0.01), batches of 4096*50 random
 panorama pixels looked up along their directions at a sharp footprint (log-solid-angle log 1e-5), Huber loss; the state_dict is
 written with torch.save and the fitted map as `<prefix>pano.exr` next to it.  The panorama is read by nmf_amd.exr (the
-image has no imageio / OpenEXR; NONE / RLE / ZIP(S) compressed files).  `render.py --fixed-bg` loads the result at ITS OWN
+image has no imageio / OpenEXR; NONE / RLE / ZIP(S) / DWAA / DWAB compressed files, i.e. the reference's backgrounds/*.exr as
+they are).  `render.py --fixed-bg` loads the result at ITS OWN
 resolution (the reference hard-codes 512 there while this tool's default is 1024)."""
 import argparse
 import json
