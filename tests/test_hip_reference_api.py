@@ -199,3 +199,27 @@ def test_pano2env_fits_an_exr_panorama(tmp_path):
     assert float(err) < 0.05, float(err)
     fitted = exr.imread(str(tmp_path / "env" / "pano_pano.exr"))
     assert fitted.shape == (32, 64, 3) and np.isfinite(fitted).all()
+
+
+def test_pano2env_reads_a_reference_background_as_it_is(tmp_path):
+    """the reference's relighting inputs are DWAB files (backgrounds/*.exr -> scripts/pano2cube.py -> fixed_bg=....th, train.py:96-138):
+    the CC0 studio panorama of that directory (committed data fixture) goes through the same tool unchanged."""
+    import os
+    from nmf_amd import exr, pano2env
+    from nmf_amd.render import load_fixed_bg
+    src = os.path.join(os.path.dirname(__file__), "golden", "studio_dwab.exr")
+    out = str(tmp_path / "env" / "studio.th")
+    rec = pano2env.main([src, "--output", out, "--res", "64", "--epochs", "200", "--batch", "16384"])
+    assert rec["panorama"] == [512, 1024, 3] and rec["resolution"] == 64
+    bg = load_fixed_bg(out, DEV)
+    pano = torch.from_numpy(exr.imread(src))
+    # the fitted map against the panorama averaged over the map's 8 x 8-pixel texels, in the log domain (lamps at 100+, walls at 0.01)
+    coarse = torch.nn.functional.avg_pool2d(pano.permute(2, 0, 1)[None], 8)[0].permute(1, 2, 0)
+    rows, cols = torch.meshgrid(torch.arange(4, 60, dtype=torch.float32) * 8 + 3.5, torch.arange(128, dtype=torch.float32) * 8 + 3.5,
+                                indexing="ij")
+    dirs = pano2env.pixel_directions(rows.reshape(-1), cols.reshape(-1), 512, 1024).to(DEV)
+    with torch.no_grad():
+        got = bg(dirs, torch.full((dirs.shape[0],), float(np.log(1e-3)), device=DEV)).cpu().reshape(56, 128, 3)
+    a, b = torch.log(got.clamp(min=1e-3)).reshape(-1), torch.log(coarse[4:60].clamp(min=1e-3)).reshape(-1)
+    corr = float(torch.corrcoef(torch.stack([a, b]))[0, 1])
+    assert corr > 0.9, corr
