@@ -147,6 +147,13 @@ int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, 
                           const uint16_t* const dlk[3], const uint16_t* const app_planes[3],
                           const uint16_t* const app_lines[3], const float* basis, float* sigma_feat, float* sigma,
                           float* grad, float* normal, float* app, float* coef, void* stream);
+/* Density VALUE of M samples from the density factors THEMSELVES: planes[i] [G][G][16] (channel-last storage of
+ * rf.density_rf.app_plane.i), lines[i] [G][16] -- what fields/tensoRF.py:181-190 + tensor_base.py:85 compute, for the levels
+ * of a pass that need no normals (nmf_amd/fast_step.py "sparse normals").  Same taps, same order of the sums as
+ * nmf_vm_query_fwd: identical bits; it touches a third of the cache lines the packed value + derivative tables spread the same
+ * numbers over.  tables_bf16 != 0: bfloat16 copies of the factors. */
+int nmf_vm_query_sigma(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
+                       const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma, void* stream);
 /* The density part of the query (value, sigma, gradient, normal; any output may be NULL) for a FEW rows -- the bounce rows
  * of a re-traced level, where the training pass needs normals (fields/tensor_base.py:66-129 on xyz[bounce_mask]) -- with
  * 16 lanes per row (one per plane tap); the sums are combined in nmf_vm_query_fwd's order: identical bits.

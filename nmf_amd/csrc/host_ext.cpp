@@ -578,6 +578,28 @@ std::tuple<Tensor, Tensor, Tensor> vm_query_rows(int64_t p_addr, const Tensor& x
     return {sf, gr, nr};
 }
 
+// density value of all samples from the density factors themselves: -> (sigma_feat [M], sigma [M])
+std::tuple<Tensor, Tensor> vm_query_sigma(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& planes,
+                                          const std::vector<Tensor>& lines, int64_t stream) {
+    TimedScope _ts(__func__, stream);
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    const int64_t M = xyzt.size(0);
+    if (planes.size() != 3 || lines.size() != 3) fail("vm_query_sigma: three planes / lines expected");
+    const bool bf16 = planes[0].scalar_type() == at::kBFloat16;
+    const void *a[3], *b[3];
+    for (int i = 0; i < 3; ++i) {
+        if (planes[i].scalar_type() != planes[0].scalar_type() || lines[i].scalar_type() != planes[0].scalar_type())
+            fail("vm_query_sigma: mixed table dtypes");
+        if (planes[i].size(-1) != 16 || lines[i].size(-1) != 16 || !planes[i].is_contiguous() || !lines[i].is_contiguous())
+            fail("vm_query_sigma: density factors [G,G,16] / [G,16] (channel-last views) expected");
+        a[i] = vptr(planes[i]);
+        b[i] = vptr(lines[i]);
+    }
+    Tensor sf = fe(xyzt, {M}), sg = fe(xyzt, {M});
+    check(nmf_vm_query_sigma(p, f32(xyzt), M, a, b, bf16 ? 1 : 0, out(sf), out(sg), st(stream)), "nmf_vm_query_sigma");
+    return {sf, sg};
+}
+
 Tensor sqerr_fwd(const Tensor& pred, const Tensor& gt, int64_t stream) {
     TimedScope _ts(__func__, stream);
     Tensor o = at::zeros({}, pred.options().dtype(at::kFloat));
@@ -820,6 +842,7 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("sh_project_into", &sh_project_into);
     m.def("vm_pack_density_into", &vm_pack_density_into);
     m.def("vm_query_rows", &vm_query_rows);
+    m.def("vm_query_sigma", &vm_query_sigma);
     m.def("sqerr_fwd", &sqerr_fwd);
     m.def("sqerr_bwd", &sqerr_bwd);
     m.def("shade_mix_bwd_view", &shade_mix_bwd_view);
@@ -838,7 +861,7 @@ PYBIND11_MODULE(_nmf_host, m) {
 #define RW(name) .def_readwrite(#name, &StepCore::name)
         RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
-        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
+        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
         RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)
         RW(detach_n) RW(max_brdf_rays) RW(max_retrace_rays) RW(white) RW(one) RW(select_ws) RW(g_dpk) RW(g_dlk) RW(g_apl) RW(g_ali)

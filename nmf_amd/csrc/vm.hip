@@ -365,8 +365,10 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
 // ------------------------------------------------------------------------------------------------
 template <class TT>
 __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
-                                                  PtrsT3<TT> dpk, PtrsT3<TT> dlk, float* __restrict__ sigma_feat,
-                                                  float* __restrict__ sigma) {
+                                                  PtrsT3<TT> dpk, PtrsT3<TT> dlk, int plane_stride, int line_stride,
+                                                  float* __restrict__ sigma_feat, float* __restrict__ sigma) {
+    // plane_stride / line_stride: elements per texel / line entry of the tables handed in -- DP / DL for the packed value +
+    // derivative tables, CD for the density factors themselves (nmf_vm_query_sigma: a third of the cache lines)
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int G = p.grid;
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
         for (int t = 0; t < 2; ++t) {
             if (tl.idx[t] < 0) continue;
             float run[CD];
-            load_run<CD / 4>(dlk.p[i] + (int64_t)tl.idx[t] * DL, run);
+            load_run<CD / 4>(dlk.p[i] + (int64_t)tl.idx[t] * line_stride, run);
 #pragma unroll
             for (int c = 0; c < CD; ++c) Lc[c] = fmaf(tl.w[t], run[c], Lc[c]);
         }
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
         for (int t = 0; t < 4; ++t) {
             if (tp.idx[t] < 0) continue;
             float run[CD];
-            load_run<CD / 4>(dpk.p[i] + (int64_t)tp.idx[t] * DP, run);
+            load_run<CD / 4>(dpk.p[i] + (int64_t)tp.idx[t] * plane_stride, run);
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < CD; ++c) a = fmaf(run[c], Lc[c], a);
@@ -1358,7 +1360,7 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
                 NMF_EINVAL, "nmf_vm_query_fwd: appearance tables missing");
     if (want_d && !want_a && !grad && !normal) {      // density value only
         hipLaunchKernelGGL(k_vm_sigma<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                           (const float4*)xyzt, M, mkT<TT>(dpk, true), mkT<TT>(dlk, true), sigma_feat, sigma);
+                           (const float4*)xyzt, M, mkT<TT>(dpk, true), mkT<TT>(dlk, true), DP, DL, sigma_feat, sigma);
         NMF_CHECK_LAUNCH(what);
         return NMF_OK;
     }
@@ -1381,6 +1383,29 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
                                 float* grad, float* normal, float* app, float* coef, void* stream) {
     return vm_query_fwd_impl<float>("nmf_vm_query_fwd", p, xyzt, M, dpk, dlk, app_planes, app_lines, basis, sigma_feat, sigma,
                                     grad, normal, app, coef, stream);
+}
+
+extern "C" int nmf_vm_query_sigma(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
+                                  const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma,
+                                  void* stream) {
+    NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_sigma: params");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(xyzt && planes && lines && planes[0] && planes[1] && planes[2] && lines[0] && lines[1] && lines[2] &&
+                    (sigma_feat || sigma),
+                NMF_EINVAL, "nmf_vm_query_sigma: null");
+    if (tables_bf16) {
+        const uint16_t* pl[3] = {(const uint16_t*)planes[0], (const uint16_t*)planes[1], (const uint16_t*)planes[2]};
+        const uint16_t* li[3] = {(const uint16_t*)lines[0], (const uint16_t*)lines[1], (const uint16_t*)lines[2]};
+        hipLaunchKernelGGL(k_vm_sigma<uint16_t>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                           (const float4*)xyzt, M, mkT<uint16_t>(pl, true), mkT<uint16_t>(li, true), CD, CD, sigma_feat, sigma);
+    } else {
+        const float* pl[3] = {(const float*)planes[0], (const float*)planes[1], (const float*)planes[2]};
+        const float* li[3] = {(const float*)lines[0], (const float*)lines[1], (const float*)lines[2]};
+        hipLaunchKernelGGL(k_vm_sigma<float>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                           (const float4*)xyzt, M, mkT<float>(pl, true), mkT<float>(li, true), CD, CD, sigma_feat, sigma);
+    }
+    NMF_CHECK_LAUNCH("nmf_vm_query_sigma");
+    return NMF_OK;
 }
 
 extern "C" int nmf_vm_query_rows(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const dpk[3],

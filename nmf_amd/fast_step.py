@@ -164,6 +164,8 @@ class TrainPass:
             self._core_key = key
             p, dpk, dlk, apl, ali, basis = tab
             c.vm_p, c.dpk, c.dlk, c.apl, c.ali, c.basis = ctypes.addressof(p), list(dpk), list(dlk), list(apl), list(ali), basis
+            vt = rf._value_tables()
+            c.dpl, c.dli = (list(vt[0]), list(vt[1])) if vt is not None else ([], [])
             c.head_W, c.head_b, c.mlp_ws = hW, hb, list(mlp_ws)
             c.sobol = model.brdf_sampler.angs
             c.env_table, c.env_pole, c.env_act = bgm._cache[1][3], env[2], env[0]
@@ -362,8 +364,12 @@ class TrainPass:
         # table bytes and of the products) and the bounce rows are queried for value + gradient + appearance afterwards;
         # the backward mirrors it: a value-only walk over all samples, the normal adjoint walked with the rows.
         sparse_n = lvl > 0 and self.sparse_normals
-        sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, S.xyzt, dpk, dlk, apl, ali, basis, want_density=True,
-                                                want_normal=not sparse_n, want_app=False, want_coef=False)
+        vt = rf._value_tables() if sparse_n else None
+        if vt is not None:          # the density factors themselves: a third of the cache lines of the packed tables
+            (sf, sg), gr, nr = hip.vm_query_sigma(p, S.xyzt, vt[0], vt[1]), None, None
+        else:
+            sf, sg, gr, nr, _, _ = hip.vm_query_fwd(p, S.xyzt, dpk, dlk, apl, ali, basis, want_density=True,
+                                                    want_normal=not sparse_n, want_app=False, want_coef=False)
         w, _acc = hip.composite_fwd(sg, S.dist, offsets, B, self.scale)
         # ---- Microfacet.shade_compact, sparse appearance (same draw order as the autograd path)
         deferred = noise.normal_deferred((M, 24))

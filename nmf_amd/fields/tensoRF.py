@@ -235,6 +235,14 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         self._bf16 = None
         self._fwd_memo = None
 
+    def _value_tables(self):
+        """(planes [G,G,16] x 3, lines [G,16] x 3): the density factors themselves, for value-only queries (hip.vm_query_sigma);
+        None with bf16 tables (those queries then read the bf16 copies of the packed tables)"""
+        if self.table_dtype != "f32":
+            return None
+        self._tables()
+        return self._cache[3]
+
     def _fwd_tables(self):
         """(p, dpk, dlk, apl, ali, basis) as the forward kernel should read them"""
         if self.table_dtype == "f32":

@@ -62,7 +62,7 @@ class CopySlot(C.Structure):
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_event_create", "nmf_event_create_timed", "nmf_event_elapsed_ms", "nmf_event_destroy", "nmf_event_record", "nmf_event_synchronize",
     "nmf_stream_wait_event", "nmf_memcpy_d2h_async", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
-    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_bwd",
+    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_sigma", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd", "nmf_sat_lookup_bwd_binned",
     "nmf_sat_lookup_bwd_workspace_bytes",
@@ -377,6 +377,22 @@ def vm_query_rows(p, xyzt, dpk, dlk):
                                   C.c_int32(1 if td == torch.bfloat16 else 0), _p(sf), None, _p(gr), _p(nr), _stream()),
            "nmf_vm_query_rows")
     return sf, gr, nr
+
+
+def vm_query_sigma(p, xyzt, planes, lines):
+    """density value of all samples from the density factors themselves (planes [G,G,16], lines [G,16], fp32 or bfloat16):
+    -> (sigma_feat [M], sigma [M]), the bits of vm_query_fwd"""
+    M = xyzt.shape[0]
+    sf = torch.empty(M, dtype=torch.float32, device=xyzt.device)
+    sg = torch.empty(M, dtype=torch.float32, device=xyzt.device)
+    td = planes[0].dtype
+    for t in list(planes) + list(lines):
+        if t.shape[-1] != 16:
+            raise NmfHipError("vm_query_sigma: density factors [G,G,16] / [G,16] expected")
+    _check(_lib.nmf_vm_query_sigma(C.byref(p), _p(xyzt, torch.float32), C.c_int64(M), _p3(planes, td), _p3(lines, td),
+                                   C.c_int32(1 if td == torch.bfloat16 else 0), _p(sf), _p(sg), _stream()),
+           "nmf_vm_query_sigma")
+    return sf, sg
 
 
 def to_bf16_tables(srcs, dsts=None):
@@ -1139,6 +1155,9 @@ def _install_host_ext():
 
     def vm_query_rows(p, xyzt, dpk, dlk):
         return fx.vm_query_rows(addr(p), xyzt, list(dpk), list(dlk), _stream())
+
+    def vm_query_sigma(p, xyzt, planes, lines):
+        return fx.vm_query_sigma(addr(p), xyzt, list(planes), list(lines), _stream())
 
     def sqerr_fwd(pred, gt):
         return fx.sqerr_fwd(pred, gt, _stream())
