@@ -180,6 +180,18 @@ __device__ __forceinline__ void product(floatx16 (&acc)[NB], FA load_a, FB load_
                 acc[ub] = mfma(a[kk & 1][SA ? 0 : ub].p[Terms<NP>::A[i]], b[kk & 1][SB ? 0 : ub].p[Terms<NP>::B[i]], acc[ub]);
     }
 }
+// both lane halves' values of x: lanes l and l + 32 exchanged on the VALU (v_permlane32_swap_b32; a ds_bpermute shuffle is an
+// LDS round trip, seven of them cost the forward ~700 cycles per tile)
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uintx2 both_halves(unsigned int x) { return __builtin_amdgcn_permlane32_swap(x, x, false, false); }
+__device__ __forceinline__ float half_sum(float x) {
+    const uintx2 r = both_halves(__float_as_uint(x));
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ unsigned int half_or(unsigned int x) {
+    const uintx2 r = both_halves(x);
+    return r[0] | r[1];
+}
 // row of accumulator register r (C/D layout of the 32x32 MFMAs): (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -416,29 +428,32 @@ k_brdf_mlp_fwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         // output layer (fp32 on the VALU): o_j = sum_u relu(H2)[u] W4[j][u], the units of both lane halves
         float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
+        for (int ub = 0; ub < 2; ++ub) {
+            floatx4v w4[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w4[j][q] = *reinterpret_cast<const floatx4v*>(W4s + j * HID + 32 * ub + 8 * q + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int u0 = 32 * ub + 8 * q + 4 * h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m2[ub] |= a2[ub][4 * q + i] > 0.f ? (1u << acc_bit(4 * q + i)) : 0u;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const floatx4v wv = *reinterpret_cast<const floatx4v*>(W4s + j * HID + u0);
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[j] += fmaxf(a2[ub][4 * q + i], 0.f) * wv[i];
-                }
+                    for (int i = 0; i < 4; ++i) o[j] += fmaxf(a2[ub][4 * q + i], 0.f) * w4[j][q][i];
             }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            o[j] += __shfl_xor(o[j], 32, 64);
+            o[j] = half_sum(o[j]);
             const float s = 1.f / (1.f + expf(-(o[j] + b4s[j] + out_bias)));      // modules/brdf.py:131
             if (cur.valid && h == 0) out[cur.r * 3 + j] = s;
         }
         if (act_mask) {
-            uint4 mk = make_uint4(m1[0] << (4 * h), m1[1] << (4 * h), m2[0] << (4 * h), m2[1] << (4 * h));
-            mk.x |= __shfl_xor(mk.x, 32, 64); mk.y |= __shfl_xor(mk.y, 32, 64);
-            mk.z |= __shfl_xor(mk.z, 32, 64); mk.w |= __shfl_xor(mk.w, 32, 64);
+            const uint4 mk = make_uint4(half_or(m1[0] << (4 * h)), half_or(m1[1] << (4 * h)), half_or(m2[0] << (4 * h)),
+                                        half_or(m2[1] << (4 * h)));
             if (cur.valid && h == 0) act_mask[cur.r] = mk;
         }
         __builtin_amdgcn_wave_barrier();
@@ -485,17 +500,21 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
     const int64_t n_tiles = (R + RT - 1) / RT, stride = (int64_t)gridDim.x * NW;
     int64_t tile = (int64_t)blockIdx.x * NW + wave;
-    // the forward's outputs and the incoming adjoint of a lane's ray, one tile ahead like RayIn
+    // the forward's outputs and the incoming adjoint of a lane's ray, requested one tile ahead like RayIn (raw values: nothing
+    // is computed from them before the tile that uses them, so the loads stay in flight across the tile before)
     struct Adj {
         uint4 mk;
-        float g[3];
+        float s[3], go[3];
+        bool valid;
+        __device__ __forceinline__ float g(int j) const { return valid ? go[j] * s[j] * (1.f - s[j]) : 0.f; }
     };
     auto load_adj = [&](Adj& a, const RayIn& in) {
         a.mk = act_mask[in.rc];
+        a.valid = in.valid;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float s = fwd_out[in.rc * 3 + j];
-            a.g[j] = in.valid ? d_out[in.rc * 3 + j] * s * (1.f - s) : 0.f;
+            a.s[j] = fwd_out[in.rc * 3 + j];
+            a.go[j] = d_out[in.rc * 3 + j];
         }
     };
     RayIn cur;
@@ -547,10 +566,11 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         ray_in_stage1(nxt, tile + stride, R, ray, h, half_v, diff_v, src_idx);
         load_adj(nadj, nxt);
         const uint32_t m1[2] = {adj.mk.x >> (4 * h), adj.mk.y >> (4 * h)}, m2[2] = {adj.mk.z >> (4 * h), adj.mk.w >> (4 * h)};
+        const float g[3] = {adj.g(0), adj.g(1), adj.g(2)};
         if (h == 0) {
-            floatx4v gv = {adj.g[0], adj.g[1], adj.g[2], 0.f};
+            floatx4v gv = {g[0], g[1], g[2], 0.f};
             *reinterpret_cast<floatx4v*>(gs + 4 * ray) = gv;
-            accb4[0] += adj.g[0]; accb4[1] += adj.g[1]; accb4[2] += adj.g[2];
+            accb4[0] += g[0]; accb4[1] += g[1]; accb4[2] += g[2];
         }
         // ---- layer 1 (values; the forward's mask decides which units are alive): H1^T = [m1] (W0 X^T)
         {
@@ -578,32 +598,39 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                 [&](int ub, int kk) { return ldop<2>(smem, B_W2 + 32 * ub * SHB + oh + 32 * kk, PW2); });
             h1u[0] = transpose_block(hb[0], hb[1], e0, e1, nullptr);
             h1u[1] = transpose_block(hb[2], hb[3], e0, e1, nullptr);
-            // dW4[j][u] += sum_ray g[ray][j] relu(H2)[ray][u]
+            // dW4[j][u] += sum_ray g[ray][j] relu(H2)[ray][u]   (the 16 adjoint rows requested in two batches, then used)
             const float bu0 = b2s[ray], bu1 = b2s[32 + ray];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const floatx4v gv = *reinterpret_cast<const floatx4v*>(gs + 4 * acc_row(q, h));
-                const float v0 = fmaxf(a2u[0][q] + bu0, 0.f), v1 = fmaxf(a2u[1][q] + bu1, 0.f);
+            for (int qb = 0; qb < 16; qb += 8) {
+                floatx4v gv[8];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) accW4[j][0] += gv[j] * v0, accW4[j][1] += gv[j] * v1;
+                for (int q = 0; q < 8; ++q) gv[q] = *reinterpret_cast<const floatx4v*>(gs + 4 * acc_row(qb + q, h));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v0 = fmaxf(a2u[0][qb + q] + bu0, 0.f), v1 = fmaxf(a2u[1][qb + q] + bu1, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) accW4[j][0] += gv[q][j] * v0, accW4[j][1] += gv[q][j] * v1;
+                }
             }
         }
         // ---- dH2 = [m2] (g W4)  -> row-major planes (H1's operands are in registers by now)
 #pragma unroll
         for (int ub = 0; ub < 2; ++ub) {
+            floatx4v w4[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w4[j][q] = *reinterpret_cast<const floatx4v*>(W4s + j * HID + 32 * ub + 8 * q + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
             floatx16 d2;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u0 = 32 * ub + 8 * q + 4 * h;
-                const floatx4v w0 = *reinterpret_cast<const floatx4v*>(W4s + u0);
-                const floatx4v w1 = *reinterpret_cast<const floatx4v*>(W4s + HID + u0);
-                const floatx4v w2 = *reinterpret_cast<const floatx4v*>(W4s + 2 * HID + u0);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float d = adj.g[0] * w0[i] + adj.g[1] * w1[i] + adj.g[2] * w2[i];
+                    const float d = g[0] * w4[0][q][i] + g[1] * w4[1][q][i] + g[2] * w4[2][q][i];
                     d2[4 * q + i] = (m2[ub] >> acc_bit(4 * q + i)) & 1u ? d : 0.f;
                 }
-            }
             write_rows<2>(pl, ray, ub, h, d2);
         }
         __builtin_amdgcn_wave_barrier();
@@ -753,9 +780,15 @@ k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restric
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= N_PERSIST * 64) return;
     const int per = (n_wg + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = min(n_wg, w0 + per);
-    float v = 0.f;
-    for (int wg = w0; wg < w1; ++wg) v += partials[(int64_t)wg * (N_PERSIST * 64) + e];
     if (w0 >= w1) return;
+    // a handful of independent loads in flight per thread (one dependent chain of 64 round trips took 25 us)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int wg = w0;
+    for (; wg + 4 <= w1; wg += 4)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += partials[(int64_t)(wg + k) * (N_PERSIST * 64) + e];
+    for (; wg < w1; ++wg) acc[0] += partials[(int64_t)wg * (N_PERSIST * 64) + e];
+    const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     const int idx = e >> 6, ln = e & 63, hh = ln >> 5, c = ln & 31;
     if (idx < 64) {                                   // dW2[a][b]: row = u2, column = u1
         const int a = idx >> 5, b = (idx >> 4) & 1, q = idx & 15;
@@ -810,8 +843,9 @@ extern "C" int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W
 
 static unsigned bwd_grid(int64_t R, int32_t max_workgroups) {
     // One workgroup of 4 waves per CU (150 KB of LDS, one wave per SIMD).  Every workgroup stages the weight images (~5 us)
-    // and writes a 37 KB partial, so short launches use fewer of them: at least 4 tiles per wave.
-    const int64_t wgs = cdiv(cdiv(R, RT), BWD_WAVES * 4);
+    // and writes a 37 KB partial, so short launches use fewer of them: at least 2 tiles per wave (45 k rays: 54 us against 63
+    // with 4 tiles per wave).
+    const int64_t wgs = cdiv(cdiv(R, RT), BWD_WAVES * 2);
     int64_t cap = 256;
     if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
     return (unsigned)(wgs < cap ? wgs : cap);
@@ -845,7 +879,7 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
                        diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
                        d_out, d_xfeat, partials);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
-    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), grid >= 64 ? 4 : 1), dim3(256), 0,
+    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), grid >= 32 ? 8 : (grid >= 8 ? 2 : 1)), dim3(256), 0,
                        (hipStream_t)stream, partials, (int)grid, gW0, gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;
