@@ -94,13 +94,20 @@ class RebuildCounter:
 # ---- per-call roofline models -------------------------------------------------------------------------------------------
 # Every C-ABI call of the step is timed with HIP events on the stream it launches on (csrc/host_ext.cpp CallTimer).  For the calls
 # whose ceiling has a simple algorithmic model the live fraction is computed here; `bound` says which ceiling that is:
-#   mfma     issued / algorithmic FLOP against the 157.3 TFLOP/s f32-input MFMA peak (BRDF MLP: 17 152 FLOP per ray forward,
-#            2 x that backward; field walk: issued v_mfma_f32_16x16x4_f32 FLOP, its real ceiling is MFMA + VALU issue:
-#            `alu_busy` of the counter run beside it)
+#   mfma     issued FLOP against the matrix peak of the instruction: BRDF MLP = v_mfma_f32_32x32x16_bf16 against the 2.5 PFLOP/s dense
+#            bf16 peak (the kernel is bound by the VALU work around its matrix instructions and by latency at one wave per SIMD,
+#            DESIGN.md section 0); field walk = issued v_mfma_f32_16x16x4_f32 FLOP against the 157.3 TFLOP/s f32-input peak, its
+#            real ceiling is MFMA + VALU issue: `alu_busy` of the counter run beside it
 #   atomics  lane-level float atomics against the 156 G/s the memory-side units sustain on the 8-lane pattern (tools/ub/atom2.hip)
 #   hbm      algorithmic bytes against 8 TB/s (tables are L2 / MALL resident: a fraction above 1 means the model does not bound it)
 #   alu / latency   no algorithmic model: the counter fractions of profiles/<tag>_roofline.json are reported beside the time
 MLP_FWD_FLOP, ATOMIC_PEAK = 2 * 8576, 156e9
+# csrc/brdf_mlp.hip (round 3): v_mfma_f32_32x32x16_bf16 (2 x 32 x 32 x 16 FLOP each) issued per 32-ray tile: the forward splits
+# every fp32 operand into three bf16 terms (six products per K block: 60 + 48 instructions), the backward into two (three products;
+# 186 instructions incl. the transpositions on the matrix core).  Priced against the dense bf16 matrix peak.
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MLP_FWD_ISSUED_FLOP = 108 * 32768 / 32
+MLP_BWD_ISSUED_FLOP = 186 * 32768 / 32
 ADAM_BYTES_PER_PARAM = 28
 
 
@@ -109,12 +116,13 @@ def call_models(sz, n_params):
     B, M0, M1, R0, R1, Mb0, Mb1 = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1"))
     walk_flop = (M0 + Mb1) * MFMA_FLOP_DENSITY + M1 * MFMA_FLOP_VALUE + (Mb0 + Mb1) * MFMA_FLOP_APP
     return {
-        "brdf_mlp_bwd": ("mfma", 2 * MLP_FWD_FLOP * (R0 + R1), MFMA_F32_PEAK_TFLOPS * 1e12),
-        "brdf_mlp_fwd": ("mfma", MLP_FWD_FLOP * (R0 + R1), MFMA_F32_PEAK_TFLOPS * 1e12),
+        "brdf_mlp_bwd": ("mfma", MLP_BWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
+        "brdf_mlp_fwd": ("mfma", MLP_FWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
         "vm_query_bwd_segments": ("mfma", walk_flop, MFMA_F32_PEAK_TFLOPS * 1e12),
         "sat_lookup_bwd": ("atomics", 48.0 * (R0 + R1), ATOMIC_PEAK),            # 4 corners x 4 texels x 3 channels per box
         "sat_lookup_fwd": ("hbm", 192.0 * (R0 + R1 + 5000), HBM_PEAK_GBS * 1e9),
-        "vm_query_fwd": ("hbm", float(M0 * G_DENSITY + M1 * 1152 + (Mb0 + Mb1) * G_APP), HBM_PEAK_GBS * 1e9),
+        "vm_query_fwd": ("hbm", float(M0 * G_DENSITY + (Mb0 + Mb1) * G_APP), HBM_PEAK_GBS * 1e9),
+        "vm_query_sigma": ("hbm", float(M1 * 1152), HBM_PEAK_GBS * 1e9),        # 18 taps x 16 channels x 4 B, value only
         "vm_query_rows": ("hbm", float(Mb1 * G_DENSITY), HBM_PEAK_GBS * 1e9),
         "march_count": ("alu", None, None), "march_fill": ("alu", None, None),
         "adam_step": ("hbm", float(ADAM_BYTES_PER_PARAM * n_params), HBM_PEAK_GBS * 1e9),
@@ -127,7 +135,7 @@ def per_call_table(timing, steps, sz, n_params, counters):
     ks = (counters or {}).get("kernels", {})
     ctr_of = {"brdf_mlp_bwd": "k_brdf_mlp_bwd", "brdf_mlp_fwd": "k_brdf_mlp_fwd", "sat_lookup_bwd": "k_env_lookup_bwd",
               "sat_lookup_fwd": "k_env_lookup_fwd", "march_count": "k_march_count16", "march_fill": "k_march_fill16",
-              "adam_step": "k_adam", "vm_query_fwd": "k_vm_sigma"}
+              "adam_step": "k_adam", "vm_query_sigma": "k_vm_sigma", "vm_query_fwd": "k_vm_fwd"}
     rows = {}
     for name, (ms, calls) in sorted(timing.items(), key=lambda kv: -kv[1][0]):
         us = 1e3 * ms / steps
@@ -634,7 +642,8 @@ def main():
                     {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd"}.get(dname, ""), {}).get(
                         "derived", {}).get("alu_busy") if ctr else None,
                 "launches": dom_live[1] if dom_live else None, "avg_launch_us": live_us,
-                "work_per_step": work, "work_model": "2 x 17 152 FLOP per secondary ray (SURVEY 8d: the a18 contraction, backward = dX + dW)"
+                "work_per_step": work, "work_model": "186 v_mfma_f32_32x32x16_bf16 per 32 rays (split-bf16 products, csrc/brdf_mlp.hip) against the dense bf16 peak; "
+                                                "SURVEY 8d's algorithmic figure is 2 x 17 152 FLOP per secondary ray"
                 if dname == "brdf_mlp_bwd" else "see call_models() in bench.py",
                 "per_kernel": table, "sizes_per_step": sizes,
                 "step": {"survey_8d_bytes": survey_b, "algorithmic_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),

@@ -60,7 +60,7 @@ KEYS = {"k_vm_bwd_density<false": "k_vm_bwd_density<value>", "k_vm_bwd_density<t
         "k_vm_bwd_brick<true": "k_vm_bwd_brick<density>", "k_vm_sigma": "k_vm_sigma", "k_vm_rows_dn": "k_vm_rows_dn",
         "k_vm_app_rows": "k_vm_app_rows",
         "k_vm_bwd_brick<false": "k_vm_bwd_brick<appearance>",
-        "k_brdf_mlp_bwd": "k_brdf_mlp_bwd", "k_brdf_mlp_fwd": "k_brdf_mlp_fwd", "k_env_lookup_bwd": "k_env_lookup_bwd",
+        "k_brdf_mlp_bwd": "k_brdf_mlp_bwd", "k_brdf_mlp_fwd": "k_brdf_mlp_fwd", "k_brdf_mlp_reduce": "k_brdf_mlp_reduce", "k_env_lookup_bwd": "k_env_lookup_bwd",
         "k_env_lookup_fwd": "k_env_lookup_fwd", "k_vm_fwd": "k_vm_fwd", "k_march_count16": "k_march_count16",
         "k_march_fill16": "k_march_fill16", "k_brick_scatter": "k_brick_scatter", "k_ggx_rays_bwd": "k_ggx_rays_bwd",
         "k_composite_bwd": "k_composite_bwd", "k_adam": "k_adam", "k_env_bin_count": "k_env_bin_count",
