@@ -779,16 +779,17 @@ k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restric
                   float* __restrict__ gW2, float* __restrict__ gb2, float* __restrict__ gW4, float* __restrict__ gb4) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= N_PERSIST * 64) return;
-    const int per = (n_wg + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = min(n_wg, w0 + per);
+    // up to 32 partials per thread in batches of 8 independent loads (the launch is bound by the latency of these loads, and
+    // every extra slice along y costs 9 408 more atomics onto the same addresses)
+    const int w0 = blockIdx.y * 32, w1 = min(n_wg, w0 + 32);
     if (w0 >= w1) return;
-    // a handful of independent loads in flight per thread (one dependent chain of 64 round trips took 25 us)
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int wg = w0;
-    for (; wg + 4 <= w1; wg += 4)
+    float v = 0.f;
+    for (int wb = w0; wb < w1; wb += 8) {
+        float acc[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += partials[(int64_t)(wg + k) * (N_PERSIST * 64) + e];
-    for (; wg < w1; ++wg) acc[0] += partials[(int64_t)wg * (N_PERSIST * 64) + e];
-    const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        for (int k = 0; k < 8; ++k) acc[k] = wb + k < w1 ? partials[(int64_t)(wb + k) * (N_PERSIST * 64) + e] : 0.f;
+        v += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
     const int idx = e >> 6, ln = e & 63, hh = ln >> 5, c = ln & 31;
     if (idx < 64) {                                   // dW2[a][b]: row = u2, column = u1
         const int a = idx >> 5, b = (idx >> 4) & 1, q = idx & 15;
@@ -879,7 +880,7 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
                        diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
                        d_out, d_xfeat, partials);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
-    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), grid >= 32 ? 8 : (grid >= 8 ? 2 : 1)), dim3(256), 0,
+    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), cdiv(grid, 32)), dim3(256), 0,
                        (hipStream_t)stream, partials, (int)grid, gW0, gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;

@@ -95,11 +95,40 @@ __global__ void __launch_bounds__(256) k_composite_bwd_wave(const float* __restr
                                                             const float* __restrict__ weight,
                                                             const int64_t* __restrict__ offsets, int64_t b, float scale,
                                                             const float* __restrict__ d_weight,
-                                                            float* __restrict__ d_sigma) {
+                                                            float* __restrict__ d_sigma, int one_chunk_path) {
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / W;
     const int lane = threadIdx.x & (W - 1);
     const bool ray_ok = r < b;
     const int64_t s = ray_ok ? offsets[r] : 0, e = ray_ok ? offsets[r + 1] : 0;
+    if (one_chunk_path && e - s <= W) {
+        // The whole ray sits in one chunk of the group (the re-traced rays keep ~4 samples): both passes below on ONE set of loads.
+        // Pass 1 runs with lane 0 = last sample, pass 2 with lane 0 = first sample, exactly as in the loops -- the values change
+        // lane mapping through a reversal shuffle instead of a second trip to memory, and the two terms are added in registers
+        // instead of through a read-modify-write of d_sigma: the same operations on the same numbers (a carry of 0.0 / 1.0 is
+        // exact), two dependent memory round trips instead of four.
+        const int n = (int)(e - s);
+        const bool in = lane < n;
+        const int64_t k = e - 1 - lane;
+        float dw = 0.f, d = 0.f, ex = 1.f, f = 1.0f;
+        double v = 0.0;
+        if (in) {
+            dw = d_weight[k];
+            v = (double)dw * (double)weight[k];
+            d = fmul(dist[k], scale);
+            ex = expf(-fmul(sigma[k], d));
+            f = fadd(fsub(1.0f, 1.0f - ex), 1e-10f);
+        }
+        const double incl = group_incl_sum<W>(v, lane);
+        const float A = in ? (-(float)(0.0 + incl - v) / f) * (d * ex) : 0.f;
+        const int src = in ? n - 1 - lane : lane;                       // forward mapping: lane L = sample s + L
+        const float d2 = __shfl(d, src, W), ex2 = __shfl(ex, src, W), dw2 = __shfl(dw, src, W), A2 = __shfl(A, src, W);
+        const float f2 = in ? __shfl(f, src, W) : 1.0f;
+        const double incl2 = group_incl_prod<W>((double)f2, lane);
+        const double below = lane_below<W, 1>(incl2);
+        const double T = 1.0 * (lane >= 1 ? below : 1.0);
+        if (in) d_sigma[s + lane] = A2 + dw2 * (float)T * (d2 * ex2);
+        return;
+    }
     // pass 1 (back to front): suffix_k = sum_{j>k} dw_j w_j, second term of dL/da_k
     double carry = 0.0;
     for (int64_t k1 = e; k1 > s; k1 -= W) {
@@ -203,12 +232,14 @@ extern "C" int nmf_composite_bwd(const float* sigma, const float* dist, const fl
     NMF_REQUIRE(b >= 0, NMF_EINVAL, "nmf_composite_bwd: b < 0");
     if (b == 0) return NMF_OK;
     NMF_REQUIRE(sigma && dist && weight && offsets && d_weight && d_sigma, NMF_EINVAL, "nmf_composite_bwd: null");
+    // NMF_COMPOSITE_ONE_CHUNK=0 (tests): every ray through the chunk loops -- the one-chunk path must give the same bits
+    static const int one_chunk = !(getenv("NMF_COMPOSITE_ONE_CHUNK") && atoi(getenv("NMF_COMPOSITE_ONE_CHUNK")) == 0);
     if (b <= WPR_MAX_RAYS)
         hipLaunchKernelGGL(k_composite_bwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
-                           dist, weight, offsets, b, distance_scale, d_weight, d_sigma);
+                           dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     else
         hipLaunchKernelGGL(k_composite_bwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
-                           dist, weight, offsets, b, distance_scale, d_weight, d_sigma);
+                           dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     NMF_CHECK_LAUNCH("nmf_composite_bwd");
     return NMF_OK;
 }

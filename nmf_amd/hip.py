@@ -634,18 +634,19 @@ _select_ws = {}
 
 
 def select_total_workspace(dev):
-    ws = _select_ws.get(dev)
+    """the partial-sum / ticket workspace of nmf_select_total: one per (device, stream) -- launches on different streams (the
+    chunks of a frame rendered by two host threads, nmf_amd/renderer.py) must not share it"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _select_ws.get(key)
     if ws is None:
-        ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+        ws = _select_ws[key] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
     return ws
 
 
 def select_total(weights, u, extra):
     """-> 0-d fp32 device tensor clip(float(sum(w) + 1e-3 * (sum(u) + extra)), 1e-3) (one launch, float64 sums)"""
     dev = weights.device
-    ws = _select_ws.get(dev)
-    if ws is None:
-        ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
+    ws = select_total_workspace(dev)
     total = torch.empty((), dtype=torch.float32, device=dev)
     _check(_lib.nmf_select_total(_p(weights, torch.float32), _p(u, torch.float32), C.c_int64(weights.shape[0]),
                                  C.c_double(float(extra)), _p(ws), _p(total), _stream()), "nmf_select_total")
@@ -1176,10 +1177,7 @@ def _install_host_ext():
 
     def select_total(weights, u, extra):
         dev = weights.device
-        ws = _select_ws.get(dev)
-        if ws is None:
-            ws = _select_ws[dev] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it
-        return fx.select_total(weights, u, float(extra), ws, _stream())
+        return fx.select_total(weights, u, float(extra), g["select_total_workspace"](dev), _stream())
 
     def bounce_prep_bwd(inv, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, dfeat,
                         bidx=None, row_inputs=False):

@@ -590,6 +590,40 @@ def test_env_lookup_full_size_properties():
     assert abs(float(v.cpu()[big].mean()) - target) < 1e-3 * target
 
 
+def test_composite_bwd_one_chunk_path_gives_the_bits_of_the_chunk_loops():
+    """nmf_composite_bwd keeps a ray that fits one chunk of its lane group (8 samples for many short rays, 64 for few long ones) in
+    registers for both passes; NMF_COMPOSITE_ONE_CHUNK=0 sends every ray through the chunk loops.  Same operations on the same
+    numbers: the adjoints must be identical bit for bit (two processes: the switch is read once per process)."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from nmf_amd import hip
+gen = torch.Generator().manual_seed(7)
+h = hashlib.sha256()
+for b, N, p in ((20000, 24, 0.3), (20000, 12, 0.25), (300, 500, 0.05), (300, 500, 0.4)):
+    mask = torch.rand(b, N, generator=gen) < p
+    cnt = mask.sum(1)
+    off = torch.zeros(b + 1, dtype=torch.int64); off[1:] = cnt.cumsum(0)
+    M = int(cnt.sum())
+    sigma = (torch.rand(M, generator=gen) * 3).cuda(); dist = (torch.rand(M, generator=gen) * 0.01).cuda()
+    dw = torch.randn(M, generator=gen).cuda()
+    w, _ = hip.composite_fwd(sigma, dist, off.cuda(), b, 25.0)
+    ds = hip.composite_bwd(sigma, dist, w, off.cuda(), b, 25.0, dw)
+    h.update(ds.cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, NMF_COMPOSITE_ONE_CHUNK=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert out[0] == out[1], out
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("R", [1, 257, 5000])
 def test_brdf_mlp_fused_matches_oracle(R):
