@@ -660,6 +660,22 @@ def test_brdf_mlp_fused_matches_oracle(R):
     for k, gq in zip(order, gh[1:]):
         r = gref[1 + names.index("model.brdf.mlp." + k)]
         assert_close(gq.cpu(), r, rtol=2e-4, atol=2e-5 * float(r.abs().max() + 1e-3), what="d " + k)
+    # the ReLU masks the forward hands to the backward (act_mask [R,4]: layer 1 units 0-31 | 32-63, layer 2 units 0-31 | 32-63)
+    # against a float64 evaluation of the hidden layers: bit u set <=> pre-activation u > 0, except within fp32 round-off of 0
+    out2, mask = hip.brdf_mlp_fwd([w.detach() for w in ws], hv.to(DEV), dv.to(DEV), feat_d.detach(), rough.to(DEV), rows.int().to(DEV),
+                                  0.37, with_mask=True)
+    assert torch.equal(out2, out.detach()) and mask.shape == (R, 4) and mask.dtype == torch.int32
+    W0, b0, W2, b2 = (sd["model.brdf.mlp." + k].detach().double() for k in ("0.weight", "0.bias", "2.weight", "2.bias"))
+    kappa = (1 / (rough[rows] + 1e-3)).double()                     # the oracle's feature row (oracle/nmf_oracle.py: brdf_mlp)
+    X = torch.cat([feat.detach()[rows].double(), O.ish_basis(cfg.ish_degs, hv.double(), kappa), hv.double(),
+                   O.ish_basis(cfg.ish_degs, dv.double(), kappa), dv.double()], dim=-1)
+    a1 = X @ W0.T + b0
+    a2 = torch.relu(a1) @ W2.T + b2
+    bits = (mask.cpu().long() & 0xffffffff)
+    for lay, a in ((0, a1), (1, a2)):
+        got = torch.stack([(bits[:, 2 * lay + u // 32] >> (u % 32)) & 1 for u in range(64)], 1).bool()
+        sure = a.abs() > 1e-5 * (1 + a.abs().max())
+        assert bool((got == (a > 0))[sure].all()), int((got != (a > 0))[sure].sum())
     if R == 257:      # golden (reference) values for exactly this input set
         w = brdf_mlp(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
                      g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
