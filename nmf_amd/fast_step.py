@@ -32,8 +32,9 @@ MLP_SIDE_MIN_RAYS = 100000   # the capped launch runs at about half speed: it pa
                              # under 0.1 M+ MLP rows the main stream ran dry and waited for it (-4 %), and at the deepest level
                              # the 46 k-row launch next to the env adjoint was no faster than the two one after the other
 MLP_SIDE_MIN_ENV_RAYS = 200000   # ... or when this many of the level's own bounce rays go to the env map (partial re-trace)
-MLP_SIDE_WGS_ENV = 256           # workgroups next to that env-map adjoint alone (atomic-bound, needs little of a CU): 128 made
-                                 # the MLP the long pole (0.5 M rays at half the re-trace count: 3.78 ms against 3.39 / 3.51 without fork)
+MLP_SIDE_WGS_ENV = 96            # workgroups next to that env-map adjoint alone.  Round 3 (split-bf16 kernel): early phase, in-process
+                                 # A/B 64: 1.661 ms, 96: 1.664, 128: 1.669, 256: 1.742 (round 2, fp32 kernel: 256; 128 had made the
+                                 # MLP the long pole at 0.5 M rays)
 WALK_SIDE_MIN_SAMPLES = 200000
 MLP_SIDE_WGS = 96       # persistent workgroups of a BRDF-MLP backward that shares the chip.  Round 3 (split-bf16 kernel, one
                         # workgroup of 4 waves and 150 KB of LDS per CU): in-process A/B 32: 1.812 ms, 64: 1.628, 96: 1.608,
