@@ -20,9 +20,19 @@ __global__ void __launch_bounds__(256) k_segment_sum_wide(const float* __restric
     const int ch = lane & (G - 1), slot = lane / G;
     constexpr int SLOTS = 64 / G;
     const int64_t b = offsets[s], e = offsets[s + 1];
+    // four rows of a slot in flight (one dependent load per iteration made a 33-row segment 17 memory round trips long)
     float a = 0.f;
-    if (ch < D)
-        for (int64_t r = b + slot; r < e; r += SLOTS) a += vals[r * stride + ch];
+    if (ch < D) {
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = b + slot;
+        for (; r + 3 * SLOTS < e; r += 4 * SLOTS) {
+            const float v0 = vals[r * stride + ch], v1 = vals[(r + SLOTS) * stride + ch];
+            const float v2 = vals[(r + 2 * SLOTS) * stride + ch], v3 = vals[(r + 3 * SLOTS) * stride + ch];
+            a += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < e; r += SLOTS) a += vals[r * stride + ch];
+        a = (a + a1) + (a2 + a3);
+    }
 #pragma unroll
     for (int sh = 32; sh >= G; sh >>= 1) a += __shfl_down(a, sh, 64);
     if (lane < D) out[s * D + lane] = a;
