@@ -362,8 +362,9 @@ int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const fl
                      uint32_t* act_mask, int32_t max_workgroups /* 0 = default; see nmf_brdf_mlp_bwd */, void* stream);
 /* Backward of the call above for the SAME inputs: fwd_out [R][3] and act_mask [R][4] are that call's outputs (the
  * sigmoid adjoint and the ReLU decisions come from them; the hidden activations are recomputed per 32-ray tile as
- * values, two bf16 terms per operand).  d_xfeat [R][24] = adjoint of the gathered feature columns (overwritten; reduce
- * it per bounce point with nmf_segment_sum_wide); gW* / gb* are ACCUMULATED (caller zeroes): gW0 [64][66], gb0 [64],
+ * values, two bf16 terms per operand).  d_feat [rows of feat_src][24] = adjoint of feat_src, ACCUMULATED (caller zeroes):
+ * the adjoints of the rays that gathered a row (src_idx non-decreasing: consecutive rays) are summed inside the kernel,
+ * one atomic per (row, column) run of a 32-ray tile.  gW* / gb* are ACCUMULATED (caller zeroes): gW0 [64][66], gb0 [64],
  * gW2 [64][64], gb2 [64], gW4 [4][64], gb4 [4] (row 3 of gW4 / gb4 stays untouched: the fourth output is unused).
  * max_workgroups: 0 = the kernel's own choice (one persistent workgroup per CU, fewer for short launches); > 0 caps
  * them, for callers that run this launch on a second stream NEXT TO other kernels and want it to leave CUs free for
@@ -374,7 +375,7 @@ int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const fl
 int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                      const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                      const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
-                     const uint32_t* act_mask, const float* d_out, float* d_xfeat, float* gW0, float* gb0,
+                     const uint32_t* act_mask, const float* d_out, float* d_feat, float* gW0, float* gb0,
                      float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups);

@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES)
 k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict__ diff_v,
                const float* __restrict__ feat_src, const float* __restrict__ rough_src,
                const int32_t* __restrict__ src_idx, int64_t R, const float* __restrict__ fwd_out,
-               const uint4* __restrict__ act_mask, const float* __restrict__ d_out, float* __restrict__ d_xfeat,
+               const uint4* __restrict__ act_mask, const float* __restrict__ d_out, float* __restrict__ d_feat,
                float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
@@ -713,12 +713,32 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         // ---- the input planes of the next tile (this tile's have been read)
         __builtin_amdgcn_wave_barrier();
         build_x<2>(x, nxt, ray, h);
-        if (cur.valid) {
+        // ---- adjoint of the gathered feature rows (dx: lane = ray, registers = columns 8 q + 4 h + i): the rays of a bounce row
+        //      are consecutive, so the tile's 32 x 24 block goes through LDS once (the planes of dH1 are in registers by now),
+        //      24 lanes walk it ray by ray and issue ONE atomic per (row, column) run -- instead of [R][24] floats to memory and a
+        //      segmented-sum launch behind this kernel.  The run boundaries are wave-uniform (v_readlane of the row index).
+        {
+            float* xs = reinterpret_cast<float*>(pl);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 floatx4v v = {dx[0][4 * q], dx[0][4 * q + 1], dx[0][4 * q + 2], dx[0][4 * q + 3]};
-                *reinterpret_cast<floatx4v*>(d_xfeat + cur.r * 24 + 8 * q + 4 * h) = v;
+                *reinterpret_cast<floatx4v*>(xs + ray * 24 + 8 * q + 4 * h) = v;
             }
+            __builtin_amdgcn_wave_barrier();
+            const int brow = (int)cur.b, col = lane < 24 ? lane : 0;
+            int prev = __builtin_amdgcn_readlane(brow, 0);
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < RT; ++j) {
+                const int bj = __builtin_amdgcn_readlane(brow, j);
+                if (bj != prev) {
+                    if (lane < 24) atomicAdd(d_feat + (int64_t)prev * 24 + lane, acc);
+                    acc = 0.f;
+                    prev = bj;
+                }
+                acc += xs[j * 24 + col];
+            }
+            if (lane < 24) atomicAdd(d_feat + (int64_t)prev * 24 + lane, acc);
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
@@ -859,13 +879,13 @@ extern "C" int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workg
 extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                                 const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
-                                const uint32_t* act_mask, const float* d_out, float* d_xfeat, float* gW0, float* gb0,
+                                const uint32_t* act_mask, const float* d_out, float* d_feat, float* gW0, float* gb0,
                                 float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
-    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_xfeat &&
+    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_feat &&
                     gW0 && gb0 && gW2 && gb2 && gW4 && gb4,
                 NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
     NMF_REQUIRE(workspace && workspace_bytes >= nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups), NMF_EINVAL,
@@ -878,7 +898,7 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
     float* partials = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, half_vec,
                        diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
-                       d_out, d_xfeat, partials);
+                       d_out, d_feat, partials);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
     hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), cdiv(grid, 32)), dim3(256), 0,
                        (hipStream_t)stream, partials, (int)grid, gW0, gb0, gW2, gb2, gW4, gb4);

@@ -405,7 +405,7 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     TimedScope _ts(__func__, stream);
     if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
     const int64_t R = half_vec.size(0);
-    Tensor d_xfeat = fe(half_vec, {R, 24});
+    Tensor d_feat = at::zeros({feat_src.size(0), 24}, half_vec.options().dtype(at::kFloat));      // summed per row of feat_src
     Tensor go = d_out.contiguous();
     float* g[6];
     for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
@@ -413,10 +413,10 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     Tensor ws = fe(half_vec, {std::max<int64_t>(nws, 4) / 4});
     check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
                            f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, f32(fwd_out),
-                           static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_xfeat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, out(ws), nws,
+                           static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_feat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, out(ws), nws,
                            st(stream)),
           "nmf_brdf_mlp_bwd");
-    return d_xfeat;
+    return d_feat;
 }
 
 Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& d_out,

@@ -548,7 +548,7 @@ class TrainPass:
         fork = self._fork(("mlp", lvl)) if (below or n_env >= MLP_SIDE_MIN_ENV_RAYS) else None
         if fork is not None:
             with _on(fork):
-                d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf,
+                d_feat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf,
                                            a.g_mlp, max_workgroups=MLP_SIDE_WGS if below else MLP_SIDE_WGS_ENV)
         # ---- adjoint of the incoming radiance -> adjoint of the bounce rays [R,6]
         if t.idx_re is None and t.child is not None:
@@ -577,10 +577,9 @@ class TrainPass:
                 self._early_env = (sfork, d_bg)
         # ---- BounceRays backward: BRDF MLP, GGX rays, row preparation, heads, appearance rows
         if fork is not None:
-            self._join(fork, d_xfeat)
+            self._join(fork, d_feat)
         else:
-            d_xfeat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf, a.g_mlp)
-        d_feat = hip.segment_sum_wide(d_xfeat, 24, t.row_off, t.Mb)
+            d_feat = hip.brdf_mlp_bwd(self.mlp_ws, t.hl, t.dl, t.feat, t.r1, t.row_of_ray, t.brdf, t.brdf_mask, d_brdf, a.g_mlp)
         sobol = self.nerf.model.brdf_sampler.angs
         if view:
             d_nrv = hip.ggx_rays_bwd_view(t.V, t.N, t.r1, t.off, sobol, t.row_of_ray, t.j_of_ray, dL, d_brays)

@@ -383,8 +383,7 @@ class BrdfMLP(torch.autograd.Function):
     def backward(ctx, d_out):
         hv, dv, fr, rr, row_of_ray, row_offsets, out, mask, *ws = ctx.saved_tensors
         grads = grad_views(ctx.holder, ws) if ctx.holder is not None else [torch.zeros_like(w) for w in ws]
-        d_xfeat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, out, mask, d_out, grads)
-        d_feat = hip.segment_sum_wide(d_xfeat, 24, row_offsets, fr.shape[0])
+        d_feat = hip.brdf_mlp_bwd(ws, hv, dv, fr, rr, row_of_ray, out, mask, d_out, grads)
         return (None, None, d_feat, None, None, None, None, None,
                 ctx.holder.token_grad(d_out) if ctx.holder is not None else None) + (None,) * len(ws)
 
@@ -636,8 +635,7 @@ class BounceRays(torch.autograd.Function):
         d_feat = None
         if d_brdf is not None:
             grads = grad_views(c.mlp_holder, c.mlp_ws) if c.mlp_holder is not None else [torch.zeros_like(w) for w in c.mlp_ws]
-            d_xfeat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, brdf, brdf_mask, cc(d_brdf), grads)
-            d_feat = hip.segment_sum_wide(d_xfeat, 24, c.row_off, Mb)
+            d_feat = hip.brdf_mlp_bwd(c.mlp_ws, hl, dl, feat, r1, c.row_of_ray, brdf, brdf_mask, cc(d_brdf), grads)
         dN = dr1 = dV_rows = None
         if dL is not None or d_brays is not None:
             if ctx.view_grad:

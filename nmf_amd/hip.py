@@ -697,19 +697,20 @@ def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_
 def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out, grads, max_workgroups=0):
     """fwd_out, act_mask: what brdf_mlp_fwd(..., with_mask=True) returned for the same inputs.  grads: six fp32 tensors
     shaped like `weights`, ACCUMULATED into (caller zeroes them once per pass).  max_workgroups > 0 caps the persistent
-    workgroups (a launch that shares the chip with kernels of another stream)."""
+    workgroups (a launch that shares the chip with kernels of another stream).  -> d_feat [rows of feat_src, 24]: the adjoint of
+    feat_src, summed over the rays that gathered each row (src_idx must be non-decreasing)."""
     R = half_vec.shape[0]
     dev = half_vec.device
-    d_xfeat = torch.empty((R, 24), dtype=torch.float32, device=dev)
+    d_feat = torch.zeros((feat_src.shape[0], 24), dtype=torch.float32, device=dev)
     nws = int(_lib.nmf_brdf_mlp_bwd_workspace_bytes(C.c_int64(R), C.c_int32(max_workgroups)))
     ws = torch.empty(max(nws, 4) // 4, dtype=torch.float32, device=dev)
     _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
                                  _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
                                  _p(src_idx, torch.int32), C.c_int64(R), _p(fwd_out, torch.float32),
-                                 _p(act_mask, torch.int32), _p(d_out.contiguous(), torch.float32), _p(d_xfeat),
+                                 _p(act_mask, torch.int32), _p(d_out.contiguous(), torch.float32), _p(d_feat),
                                  *[_p(g) for g in grads], C.c_int32(max_workgroups), _p(ws), C.c_int64(nws), _stream()),
            "nmf_brdf_mlp_bwd")
-    return d_xfeat
+    return d_feat
 
 
 def heads_fwd(feat, W, b, hp):

@@ -39,9 +39,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(HERE, "psnr_trace.npz"))
+    ap.add_argument("--first-seed", type=int, default=0, help="> 0: keep the seeds already in --out and add seeds first-seed .. first-seed + seeds - 1")
     a = ap.parse_args()
     out = {}
-    for s in range(a.seeds):
+    if a.first_seed > 0:
+        with np.load(a.out) as old:
+            out = {k: old[k] for k in old.files}
+        assert int(out["n_seeds"]) == a.first_seed, (int(out["n_seeds"]), a.first_seed)
+    for s in range(a.first_seed, a.first_seed + a.seeds):
         t0 = time.time()
         r = mt.run(grid0=a.grid0, grid1=a.grid1, teacher_grid=a.grid1, bg=32, upsample_at=tuple(a.upsample_at), n_iters=a.lr_iters, stop_at=a.iters,
                    psnr_at=tuple(a.psnr_at), res=a.res, train_views=a.train_views, test_views=a.test_views, seed=20211200 + s,
@@ -53,10 +58,10 @@ def main():
                 out[f"s{s}/{k}"] = v
             else:
                 out[k] = v                       # data set + configuration: identical for every seed
-    out["n_seeds"] = np.asarray(a.seeds)
+    out["n_seeds"] = np.asarray(a.first_seed + a.seeds)
     np.savez_compressed(a.out, **out)
     print(f"wrote {a.out} ({os.path.getsize(a.out) / 1e6:.2f} MB)")
-    ps = np.stack([out[f"s{s}/test_psnr"] for s in range(a.seeds)])          # [seed, eval, view]
+    ps = np.stack([out[f"s{s}/test_psnr"] for s in range(a.first_seed + a.seeds)])          # [seed, eval, view]
     print("reference test PSNR, mean over views, per seed and evaluation:\n", np.round(ps.mean(-1), 3))
 
 
