@@ -163,10 +163,25 @@ std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xy
     if (want_app) ap = fe(xyzt, {M, 24});
     if (want_coef) cf = fe(xyzt, {M, 72});
     const bool need_d = want_density || want_normal, need_a = want_app || want_coef;
+    auto o = [](OT& t) { return t.has_value() ? static_cast<float*>(t->data_ptr()) : nullptr; };
+    const bool bf16 = (need_d ? dpk : apl).at(0).scalar_type() == at::kBFloat16;
+    if (bf16) {        // bfloat16 copies of the tables (BASELINE configs[1]); fp32 arithmetic
+        const uint16_t *a[3], *b[3], *c[3], *d[3];
+        for (int i = 0; i < 3; ++i) {
+            a[i] = need_d ? static_cast<const uint16_t*>(vptr(dpk.at(i))) : nullptr;
+            b[i] = need_d ? static_cast<const uint16_t*>(vptr(dlk.at(i))) : nullptr;
+            c[i] = need_a ? static_cast<const uint16_t*>(vptr(apl.at(i))) : nullptr;
+            d[i] = need_a ? static_cast<const uint16_t*>(vptr(ali.at(i))) : nullptr;
+        }
+        check(nmf_vm_query_fwd_bf16(p, f32(xyzt), M, need_d ? a : nullptr, need_d ? b : nullptr, need_a ? c : nullptr,
+                                    need_a ? d : nullptr, need_a ? of32(basis) : nullptr, o(sf), o(sg), o(gr), o(nr), o(ap), o(cf),
+                                    st(stream)),
+              "nmf_vm_query_fwd_bf16");
+        return {sf, sg, gr, nr, ap, cf};
+    }
     P3 a{}, b{}, c{}, d{};
     if (need_d) { a = three(dpk); b = three(dlk); }
     if (need_a) { c = three(apl); d = three(ali); }
-    auto o = [](OT& t) { return t.has_value() ? static_cast<float*>(t->data_ptr()) : nullptr; };
     check(nmf_vm_query_fwd(p, f32(xyzt), M, need_d ? a.p : nullptr, need_d ? b.p : nullptr, need_a ? c.p : nullptr,
                            need_a ? d.p : nullptr, need_a ? of32(basis) : nullptr, o(sf), o(sg), o(gr), o(nr), o(ap), o(cf),
                            st(stream)),
@@ -861,7 +876,7 @@ PYBIND11_MODULE(_nmf_host, m) {
 #define RW(name) .def_readwrite(#name, &StepCore::name)
         RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
-        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
+        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
         RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)
         RW(detach_n) RW(max_brdf_rays) RW(max_retrace_rays) RW(white) RW(one) RW(select_ws) RW(g_dpk) RW(g_dlk) RW(g_apl) RW(g_ali)

@@ -109,7 +109,7 @@ class TrainPass:
 
     def core(self):
         """-> lib/_nmf_host.so's StepCore configured for this model, or None (Python pass)"""
-        if self._core is False or self.nerf.rf.table_dtype != "f32":
+        if self._core is False:
             return None
         if self._core is None:
             fx = hip.HOST_EXT
@@ -163,8 +163,12 @@ class TrainPass:
                hW.data_ptr(), mlp_ws[0].data_ptr(), model.brdf_sampler.angs.data_ptr(), main.cuda_stream, self.overlap, id(smp))
         if self._core_key != key:
             self._core_key = key
-            p, dpk, dlk, apl, ali, basis = tab
+            p, dpk, dlk, apl, ali, basis = rf._tables()          # fp32 masters: the backward walks
             c.vm_p, c.dpk, c.dlk, c.apl, c.ali, c.basis = ctypes.addressof(p), list(dpk), list(dlk), list(apl), list(ali), basis
+            if rf.table_dtype == "f32":
+                c.f_dpk, c.f_dlk, c.f_apl, c.f_ali = [], [], [], []
+            else:                                                # bf16 copies for the forward queries
+                c.f_dpk, c.f_dlk, c.f_apl, c.f_ali = list(tab[1]), list(tab[2]), list(tab[3]), list(tab[4])
             vt = rf._value_tables()
             c.dpl, c.dli = (list(vt[0]), list(vt[1])) if vt is not None else ([], [])
             c.head_W, c.head_b, c.mlp_ws = hW, hb, list(mlp_ws)

@@ -237,9 +237,11 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
 
     def _value_tables(self):
         """(planes [G,G,16] x 3, lines [G,16] x 3): the density factors themselves, for value-only queries (hip.vm_query_sigma);
-        None with bf16 tables (those queries then read the bf16 copies of the packed tables)"""
+        with bf16 tables their bfloat16 copies (refreshed with the other copies, _fwd_tables)"""
         if self.table_dtype != "f32":
-            return None
+            self._fwd_tables()
+            c = self._bf16[1]
+            return c[12:15], c[15:18]
         self._tables()
         return self._cache[3]
 
@@ -252,11 +254,12 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
         tab = self._tables()
         p, dpk, dlk, apl, ali, basis = tab
         key = (self._cache[0], self._cache[2])
+        srcs = list(dpk) + list(dlk) + list(apl) + list(ali) + list(self._cache[3][0]) + list(self._cache[3][1])
         if self._bf16 is None or self._bf16[0][1] != key[1]:
-            copies = hip.to_bf16_tables(list(dpk) + list(dlk) + list(apl) + list(ali))
+            copies = hip.to_bf16_tables(srcs)
             self._bf16 = (key, copies)
         elif self._bf16[0][0] != key[0]:
-            hip.to_bf16_tables(list(dpk) + list(dlk) + list(apl) + list(ali), self._bf16[1])
+            hip.to_bf16_tables(srcs, self._bf16[1])
             self._bf16 = (key, self._bf16[1])
         c = self._bf16[1]
         out = (p, c[0:3], c[3:6], c[6:9], c[9:12], basis)

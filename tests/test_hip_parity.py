@@ -853,12 +853,13 @@ def test_vm_value_only_query_and_row_normals():
     sf2, sg2 = hip.vm_query_sigma(p, xyz, vpl, vli)
     assert torch.equal(sf2, sf) and torch.equal(sg2, sg)
     rf.set_table_dtype("bf16")
-    assert rf._value_tables() is None
     pb, dpk_b, dlk_b, apl_b, ali_b, _ = rf._fwd_tables()
     a = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_app=False)
     b = hip.vm_query_fwd(pb, xyz, dpk_b, dlk_b, apl_b, ali_b, basis, want_normal=False, want_app=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    sf3, sg3 = hip.vm_query_sigma(pb, xyz, [t.bfloat16().contiguous() for t in vpl], [t.bfloat16().contiguous() for t in vli])
+    vpl_b, vli_b = rf._value_tables()                       # bfloat16 copies of the density factors
+    assert vpl_b[0].dtype == torch.bfloat16 and torch.equal(vpl_b[0], vpl[0].bfloat16())
+    sf3, sg3 = hip.vm_query_sigma(pb, xyz, vpl_b, vli_b)
     assert torch.equal(sf3, a[0]) and torch.equal(sg3, a[1])
     # the 16-lanes-per-row query of a few rows (a lane per plane tap, combined in the full query's order): the same bits
     for tabs in ((pb, dpk_b, dlk_b, a), (p, dpk, dlk, (sf, sg, gr, nr))):
