@@ -676,6 +676,16 @@ def test_brdf_mlp_fused_matches_oracle(R):
         got = torch.stack([(bits[:, 2 * lay + u // 32] >> (u % 32)) & 1 for u in range(64)], 1).bool()
         sure = a.abs() > 1e-5 * (1 + a.abs().max())
         assert bool((got == (a > 0))[sure].all()), int((got != (a > 0))[sure].sum())
+    # src_idx = NULL (one feature row per ray): the same numbers, and the per-row sums of the backward are the per-ray adjoints
+    feat_rays, rough_rays = feat.detach()[rows].to(DEV).contiguous(), rough[rows].to(DEV).contiguous()
+    wsd = [w.detach() for w in ws]
+    out3, mask3 = hip.brdf_mlp_fwd(wsd, hv.to(DEV), dv.to(DEV), feat_rays, rough_rays, None, 0.37, with_mask=True)
+    assert torch.equal(out3, out2) and torch.equal(mask3, mask)
+    g3 = [torch.zeros_like(w) for w in wsd]
+    d_rays = hip.brdf_mlp_bwd(wsd, hv.to(DEV), dv.to(DEV), feat_rays, rough_rays, None, out3, mask3, c.to(DEV), g3)
+    assert d_rays.shape == (R, 24)
+    per_row = torch.zeros(Mb, 24, device=DEV).index_add_(0, rows.to(DEV), d_rays)
+    assert_close(per_row.cpu(), gref[0], rtol=1e-4, atol=1e-5 * float(gref[0].abs().max() + 1), what="d feat (per ray)")
     if R == 257:      # golden (reference) values for exactly this input set
         w = brdf_mlp(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
                      g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
