@@ -33,10 +33,12 @@ __global__ void __launch_bounds__(256) k_select_bounces(const float* __restrict_
 // seg_id[r] = index of the segment that owns element r, local[r] = r - offsets[seg]
 __global__ void __launch_bounds__(256) k_expand_segments(const int64_t* __restrict__ offsets, int64_t n_seg,
                                                          int32_t* __restrict__ seg_id, int32_t* __restrict__ local) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // eight lanes per segment, consecutive lanes on consecutive elements (a thread per segment wrote its ~30 elements one
+    // after the other: 7 k threads for 0.24 M elements, 12 us)
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (i >= n_seg) return;
     const int64_t s = offsets[i], e = offsets[i + 1];
-    for (int64_t r = s; r < e; ++r) {
+    for (int64_t r = s + (threadIdx.x & 7); r < e; r += 8) {
         if (seg_id) seg_id[r] = (int32_t)i;
         if (local) local[r] = (int32_t)(r - s);
     }
@@ -158,7 +160,7 @@ extern "C" int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_
     NMF_REQUIRE(n_seg >= 0, NMF_EINVAL, "nmf_expand_segments: n_seg < 0");
     if (n_seg == 0) return NMF_OK;
     NMF_REQUIRE(offsets && (seg_id || local), NMF_EINVAL, "nmf_expand_segments: null");
-    hipLaunchKernelGGL(k_expand_segments, dim3((unsigned)cdiv(n_seg, 256)), dim3(256), 0, (hipStream_t)stream, offsets,
+    hipLaunchKernelGGL(k_expand_segments, dim3((unsigned)cdiv(n_seg, 32)), dim3(256), 0, (hipStream_t)stream, offsets,
                        n_seg, seg_id, local);
     NMF_CHECK_LAUNCH("nmf_expand_segments");
     return NMF_OK;
