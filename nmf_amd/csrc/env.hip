@@ -421,9 +421,19 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_lookup_bwd(EnvTab tab, 
             dm = gsum[3];
         }
     }
-    if (d_mipbias) {   // wave reduction, one atomic per wave
+    if (d_mipbias) {
+        // float atomics onto ONE address retire one after the other (13 ns each, tools/ub/same_addr_atomic.hip: a wave's worth per
+        // lookup block of a 0.24 M launch = 50 us): one per workgroup
+        __shared__ float s_dm[ENV_BWD_THREADS / 64];
         for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
-        if (lane_id() == 0 && dm != 0.f) atomicAdd(d_mipbias, dm);
+        if (lane_id() == 0) s_dm[threadIdx.x >> 6] = dm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < ENV_BWD_THREADS / 64; ++w) t += s_dm[w];
+            if (t != 0.f) atomicAdd(d_mipbias, t);
+        }
     }
 }
 
@@ -451,6 +461,8 @@ struct EnvBinHeader {
     uint32_t gmax_bits;                 // bits of the largest |d_out[c]| * 1000 / size (a non-negative float)
     uint32_t overflow;                  // corners that did not fit the pool (they took the direct float atomics)
     uint32_t pad[2];
+    float mip_slots[64];                // d_mipbias of the dual-number workgroups, spread over 64 addresses (pass 3 adds them up)
+    uint32_t gmax_slots[64];            // gmax_bits spread the same way (one atomicMax per workgroup of pass 1; pass 3 takes the max)
 };
 struct CornerRec {
     float w, n, g[3];                   // bilinear fractions, signed contribution per channel
@@ -517,7 +529,7 @@ struct SumAccQ {
 // LDS of the dual-number role: queue | rect + size as dual numbers [256][25] | d_out [256][3] | extra-box tangents [256][4]
 constexpr int ENV_DIRS_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (25 + 3 + 4) * 4;
 
-__device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem) {
+__device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem, bool to_slots) {
     typedef Dual<4> D;
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[25] = reinterpret_cast<float (*)[25]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
@@ -604,8 +616,14 @@ __device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block
         }
     }
     if (A.d_mipbias) {
+        // one float atomic per wave onto the single address of d_mipbias would retire one after the other (13 ns each: 50 us for
+        // the 3.8 k waves of a 0.24 M-lookup launch, all of what this role used to cost next to the passes): spread over 64
+        // slots of the header here, summed by pass 3 (riders of pass 3 itself -- none with today's shares -- go direct)
         for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
-        if (lane_id() == 0 && dm != 0.f) atomicAdd(A.d_mipbias, dm);
+        if (lane_id() == 0 && dm != 0.f) {
+            if (to_slots) atomicAdd(&A.hdr->mip_slots[(block * (ENV_BWD_THREADS / 64) + (threadIdx.x >> 6)) & 63], dm);
+            else atomicAdd(A.d_mipbias, dm);
+        }
     }
 }
 
@@ -657,7 +675,7 @@ __device__ __forceinline__ bool env_walk_main(const EnvBwdArgs& A, int64_t r, En
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, true); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     uint32_t* hist = reinterpret_cast<uint32_t*>(geo + 256);
@@ -682,7 +700,7 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A,
     __syncthreads();
     for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS)
         if (hist[i]) atomicAdd(&A.hdr->counts[i], hist[i]);
-    if (threadIdx.x == 0 && *gmax_s) atomicMax(&A.hdr->gmax_bits, *gmax_s);
+    if (threadIdx.x == 0 && *gmax_s) atomicMax(&A.hdr->gmax_slots[blockIdx.x & 63], *gmax_s);
 }
 
 // exclusive scans over the tiles (every workgroup of passes 2 and 3 does them for itself): base[i] = first record of tile i,
@@ -773,7 +791,7 @@ constexpr int ENV_SCATTER_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (5 + 3) * 4 + 
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > ENV_SCATTER_LDS ? ENV_DIRS_LDS : ENV_SCATTER_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, true); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     float (*gs)[3] = reinterpret_cast<float (*)[3]>(geo + 256);
@@ -830,14 +848,22 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_accum(EnvBwdArgs A,
     constexpr int OWN_LDS = ENV_WIN * 8 + (2 * ENV_MAX_TILES + 2 + 8) * 4;
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > OWN_LDS ? ENV_DIRS_LDS : OWN_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, false); return; }
+    if (blk == 0 && A.d_mipbias && threadIdx.x < 64) {      // the mip-bias adjoint the riders of passes 1 and 2 left in 64 slots
+        float v = A.hdr->mip_slots[threadIdx.x];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+        if (threadIdx.x == 0 && v != 0.f) atomicAdd(A.d_mipbias, v);
+    }
     unsigned long long* win = reinterpret_cast<unsigned long long*>(smem);
     uint32_t* base = reinterpret_cast<uint32_t*>(win + ENV_WIN);
     uint32_t* items = base + ENV_MAX_TILES + 1;
     uint32_t* tmp = items + ENV_MAX_TILES + 1;
     env_scan_counts(A.hdr, A.nt, base, items, tmp);
     const uint32_t n_items = items[A.nt];
-    const float gmax = __uint_as_float(A.hdr->gmax_bits);
+    uint32_t gbits = 0;                                      // (every lane reads all 64 slots: the same cache line, no shuffle)
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) gbits = max(gbits, A.hdr->gmax_slots[i]);
+    const float gmax = __uint_as_float(gbits);
     if (n_items == 0 || !(gmax > 0.f)) return;
     // |sum| <= ENV_ITEM * gmax < 2^(12 + ilogb(gmax) + 1): scaled by 2^e it stays below 2^62
     const int e = 49 - ilogbf(gmax);
