@@ -456,8 +456,13 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
         out["bf16_tables"] = dict(error=str(e))
     else:
         out["bf16_tables"] = train_ms(nerf16, CHUNK, 40, 10)
-        out["bf16_tables"]["note"] = ("BASELINE configs[1]: factor tables read as bf16 (fp32 master copy for Adam, fp32 "
-                                      "accumulation); PSNR delta in DESIGN.md")
+        del nerf16
+        nerf32, _ = build(device)
+        out["bf16_tables"]["f32_tables_same_protocol_ms"] = train_ms(nerf32, CHUNK, 40, 10)["ms_per_step"]
+        out["bf16_tables"]["note"] = ("BASELINE configs[1]: factor tables read as bf16 by the forward queries (fp32 master copy for "
+                                      "Adam and the backward walks, fp32 arithmetic); f32_tables_same_protocol_ms = the fp32 tables "
+                                      "over the same 10 + 40 steps of this leg (random targets: the scene drifts, so not the headline "
+                                      "number); PSNR delta in DESIGN.md")
     return out
 
 
