@@ -346,10 +346,12 @@ int nmf_shade_mix_bwd_view(const float* V_rows, const float* f0_rows, const floa
  * the four Linear layers stacked in that order. */
 int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
                   float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, float* out, void* stream);
-/* d_feat [M][24] overwritten; gW [11][24], gb [11] ACCUMULATED (caller zeroes). */
+/* d_feat [M][24] overwritten; gW [11][24], gb [11] ACCUMULATED (caller zeroes).  d_feat_add (may be NULL, may be d_feat
+ * itself): another adjoint of the same rows, d_feat = d_feat_add + (this adjoint) -- the sum the caller would otherwise
+ * spend a launch on. */
 int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
                   float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, const float* d_out,
-                  float* d_feat, float* gW, float* gb, void* stream);
+                  const float* d_feat_add, float* d_feat, float* gW, float* gb, void* stream);
 /* Fused MLPBRDF (modules/brdf.py:177-261): out[r] = sigmoid(MLP(X[r])[0:3] + out_bias) with X as above and
  * MLP = Linear(66,64) ReLU Linear(64,64) ReLU Linear(64,4) (weights row-major [out][in], torch layout).
  * The dense layers run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six products
@@ -433,6 +435,9 @@ int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, const int32
                         int32_t tonemap, int32_t noclip, const float* rgb_lin, const float* d_rgb_map,
                         const float* d_acc, const float* d_ori, float* d_weight, float* d_refl, float* d_normals,
                         void* stream);
+/* ... which is this: d_bg [B][3] = (1 - acc[B]) * d_rgb_map [B][3] (tensor_nerf.py:658-659 backward for a per-ray
+ * background: the adjoint handed to nmf_sat_lookup_bwd). */
+int nmf_bg_adjoint(const float* acc, const float* d_rgb_map, int64_t B, float* d_bg, void* stream);
 
 /* Retrace selection (models/microfacet.py:475-537, csrc/retrace.hip).
  * score[r] = max_c(brdf[r][c]) * [V.N > 0 of the ray's row] * exp(lpdf[r]) * w_rows[row] / (cnt_rows[row] + 1e-8). */
@@ -466,6 +471,18 @@ int nmf_loss_mix_fwd(const float* const x[], const int64_t numel[], const float 
                      float* out, void* stream);
 int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t count, float scale, const float* d_out,
                      float* const g[], void* stream);
+/* The head of a training chunk's backward in ONE launch (train.py:598-601 + 640-677; the same values as nmf_sqerr_fwd +
+ * nmf_loss_mix_bwd + nmf_sqerr_bwd, which stay for callers that need the pieces): loss[0] = sum (clip(pred,0,1) -
+ * clip(gt,0,1))^2 over [n_rays][3], WRITTEN (per-workgroup sums added in workgroup order by the workgroup that finishes
+ * last: no zero fill, no float atomics, run-to-run identical); d_pred = 2 (pred - clip(gt)) * (d_out scale w_pred) inside
+ * [0,1], 0 outside; g_a / g_b [n_rays] (each may be NULL) filled with d_out scale w_a / w_b (the constant adjoints of the
+ * per-ray acc / orientation terms).  d_out: device scalar.  workspace: nmf_loss_head_workspace_bytes(n_rays) bytes, 16-byte
+ * aligned, whose first 4 bytes are ZERO before the first use (a ticket counter the launch leaves at zero again); one
+ * workspace serves one stream at a time. */
+int64_t nmf_loss_head_workspace_bytes(int64_t n_rays);
+int nmf_loss_head(const float* pred, const float* gt, int64_t n_rays, const float* d_out, float scale, float w_pred,
+                  float w_a, float w_b, float* loss, float* d_pred, float* g_a, float* g_b, void* workspace,
+                  int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam over the per-module param groups (train.py:443-469), every tensor in one launch.

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) k_heads_fwd(const float* __restrict__ fea
 
 __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ feat, int64_t M, const float* __restrict__ W,
                                                    const float* __restrict__ b, HeadP hp,
-                                                   const float* __restrict__ d_out, float* __restrict__ d_feat,
+                                                   const float* __restrict__ d_out,
+                                                   const float* d_feat_add, float* d_feat,   // may be the same buffer
                                                    float* __restrict__ gW, float* __restrict__ gb) {
     __shared__ float s_da[256 * (O + 1)];
     __shared__ float s_f[256 * (F + 1)];
@@ -93,6 +94,15 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
 #pragma unroll
                 for (int k = 0; k < F; ++k) df[k] += da[j] * W[j * F + k];
             float4* q = reinterpret_cast<float4*>(d_feat + m * F);
+            if (d_feat_add) {                                           // another adjoint of the same rows, added here (may alias d_feat)
+                const float4* qa = reinterpret_cast<const float4*>(d_feat_add + m * F);
+#pragma unroll
+                for (int i = 0; i < F / 4; ++i) {
+                    const float4 a = qa[i];
+                    df[4 * i] = a.x + df[4 * i]; df[4 * i + 1] = a.y + df[4 * i + 1];
+                    df[4 * i + 2] = a.z + df[4 * i + 2]; df[4 * i + 3] = a.w + df[4 * i + 3];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < F / 4; ++i) q[i] = make_float4(df[4 * i], df[4 * i + 1], df[4 * i + 2], df[4 * i + 3]);
         } else {
@@ -146,14 +156,14 @@ extern "C" int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const
 
 extern "C" int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const float* b, float diffuse_mul,
                              float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, const float* d_out,
-                             float* d_feat, float* gW, float* gb, void* stream) {
+                             const float* d_feat_add, float* d_feat, float* gW, float* gb, void* stream) {
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_heads_bwd: M < 0");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(feat && W && b && d_out && d_feat && gW && gb, NMF_EINVAL, "nmf_heads_bwd: null");
     HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
     const int64_t n_it = cdiv(M, 256);
     const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
-    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat, gW, gb);
+    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat_add, d_feat, gW, gb);
     NMF_CHECK_LAUNCH("nmf_heads_bwd");
     return NMF_OK;
 }

@@ -435,16 +435,42 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
 }
 
 Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& d_out,
-                 const Tensor& gW, const Tensor& gb, int64_t stream) {
+                 const Tensor& gW, const Tensor& gb, const OT& add_into, int64_t stream) {
+    // add_into: another adjoint of the same rows [M,24] (dense fp32); the result is added to it IN PLACE and it is returned
     TimedScope _ts(__func__, stream);
     if (hp.size() != 5) fail("heads_bwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
     const int64_t M = feat.size(0);
-    Tensor d_feat = at::empty_like(feat);
+    if (add_into.has_value() && (add_into->scalar_type() != at::kFloat || !add_into->is_contiguous() || add_into->numel() != feat.numel()))
+        fail("heads_bwd: add_into must be a dense float32 [M,24] tensor");
+    Tensor d_feat = add_into.has_value() ? *add_into : at::empty_like(feat);
     Tensor go = d_out.contiguous();
     check(nmf_heads_bwd(f32(feat), M, f32(W), f32(b), (float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3], (float)hp[4],
-                        f32(go), out(d_feat), static_cast<float*>(vptr(gW)), static_cast<float*>(vptr(gb)), st(stream)),
+                        f32(go), add_into.has_value() ? f32(d_feat) : nullptr, out(d_feat), static_cast<float*>(vptr(gW)),
+                        static_cast<float*>(vptr(gb)), st(stream)),
           "nmf_heads_bwd");
     return d_feat;
+}
+
+// photometric term + constant adjoints of a chunk in one launch -> (loss 0-d, d_pred [B,3], g_a [B], g_b [B]);
+// ws: uint8 workspace of nmf_loss_head_workspace_bytes(B) bytes created with zeros (hip.loss_head_workspace)
+std::tuple<Tensor, Tensor, Tensor, Tensor> loss_head(const Tensor& pred, const Tensor& gt, const Tensor& d_out, double scale,
+                                                     double w_pred, double w_a, double w_b, const Tensor& ws, int64_t stream) {
+    TimedScope _ts(__func__, stream);
+    const int64_t B = pred.size(0);
+    Tensor loss = at::empty({}, pred.options().dtype(at::kFloat));
+    Tensor d_pred = at::empty_like(pred), g_a = fe(pred, {B}), g_b = fe(pred, {B});
+    check(nmf_loss_head(f32(pred), f32(gt), B, f32(d_out), (float)scale, (float)w_pred, (float)w_a, (float)w_b, out(loss),
+                        out(d_pred), out(g_a), out(g_b), ws.data_ptr(), ws.numel() * ws.element_size(), st(stream)),
+          "nmf_loss_head");
+    return {loss, d_pred, g_a, g_b};
+}
+
+Tensor bg_adjoint(const Tensor& acc, const Tensor& d_rgb, int64_t stream) {
+    TimedScope _ts(__func__, stream);
+    Tensor d_bg = at::empty_like(d_rgb);
+    Tensor go = d_rgb.contiguous();
+    check(nmf_bg_adjoint(f32(acc), f32(go), acc.size(0), out(d_bg), st(stream)), "nmf_bg_adjoint");
+    return d_bg;
 }
 
 Tensor ggx_rays_bwd(const Tensor& V, const Tensor& N, const Tensor& r, const Tensor& off, const Tensor& sobol,
@@ -858,6 +884,8 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("vm_pack_density_into", &vm_pack_density_into);
     m.def("vm_query_rows", &vm_query_rows);
     m.def("vm_query_sigma", &vm_query_sigma);
+    m.def("loss_head", &loss_head);
+    m.def("bg_adjoint", &bg_adjoint);
     m.def("sqerr_fwd", &sqerr_fwd);
     m.def("sqerr_bwd", &sqerr_bwd);
     m.def("shade_mix_bwd_view", &shade_mix_bwd_view);
@@ -875,7 +903,7 @@ PYBIND11_MODULE(_nmf_host, m) {
         .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
 #define RW(name) .def_readwrite(#name, &StepCore::name)
         RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
-        RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(walk_late) RW(mlp_side_wgs)
+        RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(walk_late) RW(launch_diet) RW(mlp_side_wgs)
         RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
         RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)

@@ -104,6 +104,52 @@ __global__ void __launch_bounds__(256) k_sqerr_bwd(const float* __restrict__ pre
     d_pred[k] = pass ? 2.f * (p - clip01(gt[k])) * d_out[0] : 0.f;
 }
 
+// The photometric term and the constant adjoints of one training chunk in ONE launch (the step's critical path pays ~5 us per
+// tiny launch).  Every block writes its 256 entries of d_pred exactly as k_mix_bwd + k_sqerr_bwd would (same operations in
+// the same order), fills the per-ray constants g_a / g_b and leaves the sum of its squared errors in the workspace; the block
+// that finishes LAST (ticket counter, reset for the next launch) adds the partial sums in block order and WRITES the loss:
+// no zero fill, no float atomics, the same bits every time.
+__global__ void __launch_bounds__(256) k_loss_head(const float* __restrict__ pred, const float* __restrict__ gt, int64_t n,
+                                                   int64_t n_rays, const float* __restrict__ d_out, float scale, float w_pred,
+                                                   float w_a, float w_b, float* __restrict__ loss,
+                                                   float* __restrict__ d_pred, float* __restrict__ g_a,
+                                                   float* __restrict__ g_b, uint32_t* __restrict__ ticket,
+                                                   float* __restrict__ partial) {
+    __shared__ float ws[4];
+    __shared__ bool last;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float dv = d_out[0];
+    float sq = 0.f;
+    if (k < n) {
+        const float s = dv * scale * w_pred;
+        const float p = pred[k], c = clip01(gt[k]);
+        const float d = clip01(p) - c;
+        sq = d * d;
+        const bool pass = p >= 0.f && p <= 1.f;
+        d_pred[k] = pass ? 2.f * (p - c) * s : 0.f;
+    }
+    if (k < n_rays) {
+        if (g_a) g_a[k] = dv * scale * w_a;
+        if (g_b) g_b[k] = dv * scale * w_b;
+    }
+    const float t = block_sum(sq, ws);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = t;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float a = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) a += __builtin_nontemporal_load(partial + i);
+    const float total = block_sum(a, ws);
+    if (threadIdx.x == 0) {
+        loss[0] = total;
+        *ticket = 0u;
+    }
+}
+
 static int fill_tab(L1Tab& t, const float* const x[], float* const g[], const int64_t n[], int count, bool need_g) {
     for (int i = 0; i < count; ++i) {
         if (n[i] < 0 || (n[i] > 0 && (!x[i] || (need_g && !g[i])))) return -1;
@@ -202,5 +248,23 @@ extern "C" int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t 
     hipLaunchKernelGGL(k_mix_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
                        scale, d_out);
     NMF_CHECK_LAUNCH("nmf_loss_mix_bwd");
+    return NMF_OK;
+}
+
+extern "C" int64_t nmf_loss_head_workspace_bytes(int64_t n_rays) { return 16 + 4 * cdiv(3 * (n_rays > 0 ? n_rays : 0), 256); }
+
+extern "C" int nmf_loss_head(const float* pred, const float* gt, int64_t n_rays, const float* d_out, float scale, float w_pred,
+                             float w_a, float w_b, float* loss, float* d_pred, float* g_a, float* g_b, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(n_rays >= 0, NMF_EINVAL, "nmf_loss_head: n_rays < 0");
+    NMF_REQUIRE(loss && d_out && workspace && (n_rays == 0 || (pred && gt && d_pred)), NMF_EINVAL, "nmf_loss_head: null");
+    NMF_REQUIRE(workspace_bytes >= nmf_loss_head_workspace_bytes(n_rays) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                NMF_EINVAL, "nmf_loss_head: workspace too small or not 16-byte aligned");
+    const int64_t n = 3 * n_rays;
+    const int64_t blocks = n ? cdiv(n, 256) : 1;
+    hipLaunchKernelGGL(k_loss_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, n, n_rays, d_out, scale,
+                       w_pred, w_a, w_b, loss, d_pred, g_a, g_b, static_cast<uint32_t*>(workspace),
+                       reinterpret_cast<float*>(static_cast<char*>(workspace) + 16));
+    NMF_CHECK_LAUNCH("nmf_loss_head");
     return NMF_OK;
 }

@@ -397,6 +397,14 @@ __global__ void __launch_bounds__(256) k_ray_compose_bwd(
     }
 }
 
+// d_bg[r][c] = (1 - acc[r]) * d_rgb[r][c]: the background adjoint nmf_ray_compose_bwd leaves to the caller (three torch
+// launches as `(1 - acc).unsqueeze(1) * d_rgb`, the same two roundings)
+__global__ void __launch_bounds__(256) k_bg_adjoint(const float* __restrict__ acc, const float* __restrict__ d_rgb, int64_t n,
+                                                    float* __restrict__ d_bg) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) d_bg[k] = (1.f - acc[k / 3]) * d_rgb[k];
+}
+
 }  // namespace
 
 extern "C" int64_t nmf_bounce_index_workspace_bytes(int64_t M) { return (cdiv(M > 0 ? M : 1, IDX_CHUNK) + 1) * 8; }
@@ -513,5 +521,15 @@ extern "C" int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, 
                        refl_rows, inv, normals, rays, ray_id, M, bg, (int)bg_per_ray, (int)tonemap, (int)noclip, rgb_lin,
                        d_rgb_map, d_acc, d_ori, d_weight, d_refl, d_normals);
     NMF_CHECK_LAUNCH("nmf_ray_compose_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_bg_adjoint(const float* acc, const float* d_rgb_map, int64_t B, float* d_bg, void* stream) {
+    NMF_REQUIRE(B >= 0, NMF_EINVAL, "nmf_bg_adjoint: B < 0");
+    if (B == 0) return NMF_OK;
+    NMF_REQUIRE(acc && d_rgb_map && d_bg, NMF_EINVAL, "nmf_bg_adjoint: null");
+    hipLaunchKernelGGL(k_bg_adjoint, dim3((unsigned)cdiv(3 * B, 256)), dim3(256), 0, (hipStream_t)stream, acc, d_rgb_map, 3 * B,
+                       d_bg);
+    NMF_CHECK_LAUNCH("nmf_bg_adjoint");
     return NMF_OK;
 }

@@ -36,6 +36,7 @@ MLP_SIDE_WGS_ENV = 96            # workgroups next to that env-map adjoint alone
                                  # A/B 64: 1.661 ms, 96: 1.664, 128: 1.669, 256: 1.742 (round 2, fp32 kernel: 256; 128 had made the
                                  # MLP the long pole at 0.5 M rays)
 WALK_SIDE_MIN_SAMPLES = 200000
+LAUNCH_DIET = 1         # 0: the separate loss / background-adjoint / head-adjoint launches of round 2 (A/B knob)
 WALK_LATE = 0           # 1: that walk is queued after the levels below instead of before them (A/B knob)
 MLP_SIDE_WGS = 96       # persistent workgroups of a BRDF-MLP backward that shares the chip.  Round 3 (split-bf16 kernel, one
                         # workgroup of 4 waves and 150 KB of LDS per CU): in-process A/B 32: 1.812 ms, 64: 1.628, 96: 1.608,
@@ -215,7 +216,7 @@ class TrainPass:
         model, smp = n.model, n.sampler
         if self._tables_token is None or self._tables_token != self._param_token():
             self._core_tables(dev)
-        st = (self.sparse_normals, WALK_LATE, MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV, WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS,
+        st = (self.sparse_normals, WALK_LATE, LAUNCH_DIET, MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV, WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS,
               int(hip.ENV_BINNED_MIN_LOOKUPS), int(smp.max_samples), float(model.anoise))
         if st != self._core_static:
             self._core_static = st
@@ -223,7 +224,7 @@ class TrainPass:
             c.mlp_side_min_rays, c.mlp_side_min_env_rays, c.mlp_side_wgs_env = MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV
             c.walk_side_min_samples, c.mlp_side_wgs, c.env_binned_from = WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS, int(hip.ENV_BINNED_MIN_LOOKUPS)
             c.max_samples, c.anoise = int(smp.max_samples), float(model.anoise)
-            c.walk_late = int(WALK_LATE)
+            c.walk_late, c.launch_diet = int(WALK_LATE), int(LAUNCH_DIET)
         packed, blk0 = smp.params_block(focal, None, is_train)
         _, blk1 = smp.params_block(focal, 3 * float(hip.host(smp.stepsize)), is_train)
         if self._march_blocks is None or self._march_blocks[0] is not blk0 or self._march_blocks[1] is not blk1:
@@ -599,7 +600,7 @@ class TrainPass:
                                                         self.min_rough, self.detach_n, dN, dr1, rows6[:, 0:3], rows6[:, 3:6],
                                                         d_feat, bidx=t.bidx, row_inputs=2 if t.sparse_n else 1)
         hp, hW, hb = self.heads
-        d_app.add_(hip.heads_bwd(t.app, hW, hb, hp, d_heads, a.g_hW, a.g_hb))
+        d_app = hip.heads_bwd(t.app, hW, hb, hp, d_heads, a.g_hW, a.g_hb, add_into=d_app)
         self.app_segs.append((t.xyz_rows, None, None, None, None, None, d_app))
         if self.detach_n:
             d_normal = d_nrm

@@ -70,7 +70,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_brdf_mlp_bwd_workspace_bytes", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_vm_query_bwd_segments", "nmf_sh_project",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -722,12 +722,16 @@ def heads_fwd(feat, W, b, hp):
     return out
 
 
-def heads_bwd(feat, W, b, hp, d_out, gW, gb):
-    """gW [11,24] / gb [11] are ACCUMULATED into."""
+def heads_bwd(feat, W, b, hp, d_out, gW, gb, add_into=None):
+    """gW [11,24] / gb [11] are ACCUMULATED into.  add_into: another adjoint of the same rows (dense fp32 [M,24]); the result is
+    added to it in place and it is returned (one launch less than `add_into += heads_bwd(...)`, the same bits)."""
     M = feat.shape[0]
-    d_feat = torch.empty_like(feat)
+    if add_into is not None and (add_into.dtype != torch.float32 or not add_into.is_contiguous() or add_into.numel() != feat.numel()):
+        raise ValueError("heads_bwd: add_into must be a dense float32 [M,24] tensor")
+    d_feat = torch.empty_like(feat) if add_into is None else add_into
     _check(_lib.nmf_heads_bwd(_p(feat, torch.float32), C.c_int64(M), _p(W, torch.float32), _p(b, torch.float32),
-                              *[C.c_float(v) for v in hp], _p(d_out.contiguous(), torch.float32), _p(d_feat), _p(gW),
+                              *[C.c_float(v) for v in hp], _p(d_out.contiguous(), torch.float32),
+                              None if add_into is None else _p(add_into, torch.float32), _p(d_feat), _p(gW),
                               _p(gb), _stream()), "nmf_heads_bwd")
     return d_feat
 
@@ -976,6 +980,44 @@ def loss_mix_bwd(shapes, weights, scale, d_out):
     return grads
 
 
+_loss_ws = {}
+
+
+def loss_head_workspace(device, n_rays):
+    """zeroed workspace of nmf_loss_head, one per (device, current stream), grown on demand (its ticket counter is zero between
+    launches)"""
+    key = (device, _stream())
+    need = int(_lib.nmf_loss_head_workspace_bytes(C.c_int64(n_rays)))
+    ws = _loss_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _loss_ws[key] = torch.zeros(max(2 * need, 4096), dtype=torch.uint8, device=device)
+    return ws
+
+
+def loss_head(pred, gt, d_out, scale, w_pred, w_a, w_b):
+    """sqerr_fwd + loss_mix_bwd + sqerr_bwd of one chunk in one launch -> (loss 0-d, d_pred [B,3], g_a [B], g_b [B]):
+    loss = sum (clip(pred) - clip(gt))^2 (summed in a fixed order, written: no zero fill), d_pred = 2 (pred - clip(gt)) *
+    (d_out scale w_pred) inside [0,1], g_a / g_b filled with d_out scale w_a / w_b."""
+    B = pred.shape[0]
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    d_pred = torch.empty_like(pred)
+    g_a = torch.empty(B, dtype=torch.float32, device=pred.device)
+    g_b = torch.empty(B, dtype=torch.float32, device=pred.device)
+    ws = loss_head_workspace(pred.device, B)
+    _check(_lib.nmf_loss_head(_p(pred, torch.float32), _p(gt, torch.float32), C.c_int64(B), _p(d_out, torch.float32),
+                              C.c_float(scale), C.c_float(w_pred), C.c_float(w_a), C.c_float(w_b), _p(loss), _p(d_pred),
+                              _p(g_a), _p(g_b), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), _stream()), "nmf_loss_head")
+    return loss, d_pred, g_a, g_b
+
+
+def bg_adjoint(acc, d_rgb):
+    """(1 - acc)[:, None] * d_rgb in one launch (the background adjoint nmf_ray_compose_bwd leaves to the caller)"""
+    d_bg = torch.empty_like(d_rgb)
+    _check(_lib.nmf_bg_adjoint(_p(acc, torch.float32), _p(d_rgb.contiguous(), torch.float32), C.c_int64(acc.shape[0]), _p(d_bg),
+                               _stream()), "nmf_bg_adjoint")
+    return d_bg
+
+
 def sqerr_fwd(pred, gt):
     out = torch.zeros((), dtype=torch.float32, device=pred.device)
     if pred.numel():
@@ -1136,8 +1178,8 @@ def _install_host_ext():
         return fx.brdf_mlp_bwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out,
                                list(grads), int(max_workgroups), _stream())
 
-    def heads_bwd(feat, W, b, hp, d_out, gW, gb):
-        return fx.heads_bwd(feat, W, b, list(hp), d_out, gW, gb, _stream())
+    def heads_bwd(feat, W, b, hp, d_out, gW, gb, add_into=None):
+        return fx.heads_bwd(feat, W, b, list(hp), d_out, gW, gb, add_into, _stream())
 
     def ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays=None):
         return fx.ggx_rays_bwd(V, N, r, off, sobol, row_of_ray, j_of_ray, dL, d_rays, _stream())

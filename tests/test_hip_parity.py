@@ -1280,6 +1280,46 @@ def test_loss_kernels_vs_torch():
     assert_close(g_h.cpu(), g_r, rtol=1e-6, atol=1e-7, what="sq err grad")
 
 
+@pytest.mark.parametrize("B", [1, 4096, 33001])
+def test_fused_launches_give_the_bits_of_their_pieces(B):
+    """nmf_loss_head == nmf_sqerr_fwd + nmf_loss_mix_bwd + nmf_sqerr_bwd (train.py:598-601, 640-677), nmf_bg_adjoint == the torch
+    expression (1 - acc)[:, None] * d_rgb, nmf_heads_bwd with d_feat_add == the separate sum: gradients bit for bit, the loss value
+    (another summation order) to fp32 rounding and against float64."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(B)
+    pred = (torch.rand(B, 3, generator=gen) * 1.6 - 0.3)
+    pred[0, 0], pred[0, 1] = 0.0, 1.0
+    gt = (torch.rand(B, 3, generator=gen) * 1.2).to(DEV)
+    pred = pred.to(DEV)
+    one = torch.full((), 1.0, device=DEV)
+    wts, scale = [1.0, 0.37, 0.013, 0.21], 1.0 / 7.0
+    loss, d_pred, g_a, g_b = hip.loss_head(pred, gt, one, scale, wts[0], wts[2], wts[3])
+    ref_loss = hip.sqerr_fwd(pred, gt)
+    dl = hip.loss_mix_bwd([(), (), (B,), (B,)], wts, scale, one)
+    ref_d = hip.sqerr_bwd(pred, gt, dl[0])
+    assert torch.equal(d_pred, ref_d) and torch.equal(g_a, dl[2]) and torch.equal(g_b, dl[3])
+    exact = float(((pred.double().clip(0, 1) - gt.double().clip(0, 1)) ** 2).sum())
+    assert abs(float(loss) - exact) <= 2e-6 * exact + 1e-7 and abs(float(ref_loss) - exact) <= 2e-6 * exact + 1e-7
+    assert float(d_pred[0, 0]) == float(ref_d[0, 0]) and float(d_pred[0, 1]) == float(ref_d[0, 1])       # closed-interval clamp
+    acc = torch.rand(B, generator=gen).to(DEV)
+    d_rgb = torch.randn(B, 3, generator=gen).to(DEV)
+    assert torch.equal(hip.bg_adjoint(acc, d_rgb), (1 - acc)[:, None] * d_rgb)
+    feat = (torch.randn(B, 24, generator=gen) * 2).to(DEV)
+    W, b = (torch.randn(11, 24, generator=gen) * 0.3).to(DEV), (torch.randn(11, generator=gen) * 0.1).to(DEV)
+    hp = (1.3, -0.4, 0.1, -0.2, -0.7)
+    d_out = torch.randn(B, 11, generator=gen).to(DEV)
+    other = torch.randn(B, 24, generator=gen).to(DEV)
+    gW0, gb0, gW1, gb1 = (torch.zeros_like(W), torch.zeros_like(b), torch.zeros_like(W), torch.zeros_like(b))
+    sep = other.clone()
+    sep.add_(hip.heads_bwd(feat, W, b, hp, d_out, gW0, gb0))
+    into = other.clone()
+    got = hip.heads_bwd(feat, W, b, hp, d_out, gW1, gb1, add_into=into)
+    assert got.data_ptr() == into.data_ptr() and torch.equal(got, sep)
+    assert_close(gW1.cpu(), gW0.cpu(), rtol=1e-5, atol=1e-5 * float(gW0.abs().max()), what="heads gW (atomic order)")
+    with pytest.raises((ValueError, hip.NmfHipError)):
+        hip.heads_bwd(feat, W, b, hp, d_out, gW1, gb1, add_into=other[:, :12])
+
+
 @pytest.mark.parametrize("R", [1, 1000, 250001])
 def test_retrace_scores_and_argsort(R):
     """nmf_retrace_scores / nmf_argsort_f32 against the torch expressions of models/microfacet.py:480-537."""
