@@ -309,8 +309,12 @@ def make_batches(nerf, n, rays_per_gpu, rank, device, distinct=48):
     return out, focal
 
 
-def time_infer(nerf, device, frames, warm_chunks=8):
-    """full FRAME x FRAME frames of the S1 camera, eval_batch_size rays per chunk, rendered to completion"""
+def time_infer(nerf, device, frames, warm_frames=1):
+    """full FRAME x FRAME frames of the S1 camera, eval_batch_size rays per chunk, rendered to completion.  The warm-up is
+    one whole frame: the chunks of a frame differ in their sample counts, and the first pass over them is the caching
+    allocator growing its pools (tools/infer_host_profile.py: 333 ms for the first frame, 101 ms for every later one) --
+    eight warm chunks, as rounds 1-3 used, left most of that inside the timed region.
+    -> (seconds of the timed frames, rays rendered, chunk size, seconds of the first (cold) frame)"""
     import torch
     from nmf_amd import synthetic
     from nmf_amd.noise import DeviceNoise
@@ -321,8 +325,12 @@ def time_infer(nerf, device, frames, warm_chunks=8):
     was_training = nerf.training
     nerf.eval()
     chunk = nerf.eval_batch_size
-    render_images(nerf, rays[: warm_chunks * chunk], focal, chunk, noise)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(warm_frames, 1)):
+        render_images(nerf, rays, focal, chunk, noise)
+    torch.cuda.synchronize()
+    cold = (time.perf_counter() - t0) / max(warm_frames, 1)
     t0 = time.perf_counter()
     for _ in range(frames):
         rgb = render_images(nerf, rays, focal, chunk, noise)
@@ -330,7 +338,7 @@ def time_infer(nerf, device, frames, warm_chunks=8):
     dt = time.perf_counter() - t0
     nerf.train(was_training)
     assert rgb.shape[0] == rays.shape[0]
-    return dt, rays.shape[0] * frames, chunk
+    return dt, rays.shape[0] * frames, chunk, cold
 
 
 SCHEDULE = ((128, 2000), (162, 1000), (196, 1000), (231, 1500), (265, 1500), (300, 23000))   # grid, iterations at it
@@ -419,9 +427,10 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
                     steps=steps, rays_per_step=rays_per_gpu)
 
     nerf, _ = build(device)
-    dt, n, chunk = time_infer(nerf, device, frames=2)
-    out["inference"] = dict(rays_per_s=n / dt, s_per_frame=dt / 2, frame=f"{FRAME}x{FRAME}", chunk=chunk,
-                            note="eval mode, render to completion (renderer.py:56-106), rgb/acc outputs, S1 at 128^3")
+    dt, n, chunk, cold = time_infer(nerf, device, frames=2)
+    out["inference"] = dict(rays_per_s=n / dt, s_per_frame=dt / 2, first_frame_s=cold, frame=f"{FRAME}x{FRAME}", chunk=chunk,
+                            note="eval mode, render to completion (renderer.py:56-106), rgb/acc outputs, S1 at 128^3; one "
+                                 "whole warm-up frame (first_frame_s: the caching allocator grows its pools), two timed")
     nerf.model.max_retrace_rays = [1000]
     out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
@@ -545,7 +554,7 @@ def main():
                 f"800x800 camera")
 
     if args.mode == "infer":
-        dt, n_rays, chunk = time_infer(nerf, device, frames=max(args.steps, 1))
+        dt, n_rays, chunk, _cold = time_infer(nerf, device, frames=max(args.steps, 1))
         tt = torch.tensor([dt, float(n_rays)], dtype=torch.float64, device=device)
         if world > 1:
             tmax = tt.clone()
