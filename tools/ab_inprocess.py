@@ -35,7 +35,8 @@ def main():
     retrace = int(sys.argv[4]) if len(sys.argv) > 4 else None      # partial re-trace instead of bench.py's steady state
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    nerf, params = bench.build(dev)
+    grid = int(os.environ.get("NMF_AB_GRID", "128"))          # NMF_AB_GRID=300: the final grid of the schedule
+    nerf, params = bench.build(dev, grid=grid)
     if retrace is not None:
         nerf.model.max_retrace_rays = [retrace]
     tr = Trainer(nerf, params)
