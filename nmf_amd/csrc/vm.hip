@@ -871,7 +871,6 @@ constexpr int BWD_THREADS = 64;               // one single-wave workgroup per (
 constexpr int NRB = (TL * TL + 15) / 16;     // tile cells -> row blocks of 16 (BR 8: 81 -> 6, BR 4: 25 -> 2)
 constexpr int BWD_ITEM = 256;                // samples per work item (brick slice); 128 below 400 k samples
 constexpr int BWD_ITEM_MIN = 64;             // smallest item size the workspace is sized for (tuning knob)
-constexpr int AROW_BASE = 256;               // float4 index of the A-operand rows in LDS (behind the 64 footprint records)
 
 // Scatter-add on the matrix cores.
 //
@@ -953,12 +952,11 @@ __device__ __forceinline__ float a_weight(const float4& W, int jc /* = j - c00 *
 }
 
 // one pipeline stage of the density walk: a sample's record (broadcast LDS reads) and its 12 + 4 table taps
-template <bool WITH_NORMAL, bool AROWS>
+template <bool WITH_NORMAL>
 struct DGrp {
     float4 W, A;
     int c00, lcell;
     float l0, l1;
-    float ar[NRB]; // AROWS: the A operands of this lane (weight of its sample on tile cell 16 rb + j), read from LDS
     float t[12];   // P, X, Y at the nw, ne, sw, se texels
     float u[4];    // L (2 taps), DL (2 taps)
     // T / TLn: the plane / line table of this walk (uniform), j4 = 4 * channel lane.  Taps are addressed as a uniform base +
@@ -967,11 +965,6 @@ struct DGrp {
     __device__ __forceinline__ void load(const float4* lds, int k, int g, const float* __restrict__ T,
                                          const float* __restrict__ TLn, int G, uint32_t j4) {
         const float4* r = lds + (4 * g + k) * 4;
-        if (AROWS) {
-            const float* arow = reinterpret_cast<const float*>(lds + AROW_BASE) + g * (NRB * 64) + (threadIdx.x & 63);
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) ar[rb] = arow[rb * 64];
-        }
         W = r[0];
         const float4 Q = r[1], L = r[2];
         A = r[3];
@@ -1000,11 +993,13 @@ struct DGrp {
     }
 };
 
-// AROWS: slot of (sample slot sl = 4 g + k, tile cell) in the A-operand rows: [g][rb][k][j], so that the 64 lanes (k, j) of a
-// group step read 64 consecutive floats per row block
-__device__ __forceinline__ int arow_slot(int sl, int cell) { return ((sl >> 2) * NRB + (cell >> 4)) * 64 + (sl & 3) * 16 + (cell & 15); }
-
-template <bool WITH_NORMAL, bool AROWS>
+// Tried and dropped (R3, commit d86b52d): the A operands (a_weight: four compares + four selects per row block and group
+// step, a third of the loop's VALU instructions -- 110 -> 74 per two group steps of the value-only walk) laid out once per
+// sample as rows in LDS and read with one ds_read per row block.  Same bits, but 12 KB of LDS per wave instead of 4: next
+// to the BRDF-MLP backward (150 KB of a CU's 160 KB) the walk's waves no longer fit on those CUs, and the step got SLOWER
+// (in-process A/B: 1.577 -> 1.611 ms at 128^3, 1.654 -> 1.718 ms at 300^3).  The loop is bound by the latency of its table
+// taps and by where its waves can be resident, not by its VALU count.
+template <bool WITH_NORMAL>
 __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* __restrict__ rec0,
                                                 const float4* __restrict__ rec1, int brick, int s, int e, int i, int nbx,
                                                 Ptrs3 dpk, Ptrs3 dlk, MPtrs3 g_dpk, MPtrs3 g_dlk, float4* __restrict__ lds) {
@@ -1020,8 +1015,6 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
     floatx4 accL = {0, 0, 0, 0}, accDL = {0, 0, 0, 0};
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) { accP[rb] = accX[rb] = accY[rb] = floatx4{0, 0, 0, 0}; }
-    float* arows = reinterpret_cast<float*>(lds + AROW_BASE);      // AROWS: [16][NRB][4][16] floats, all-zero between batches
-    int my_c00 = 0;
 
     for (int base = s; base < e; base += 64) {
         {   // one sample per lane
@@ -1038,21 +1031,13 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
             lds[lane * 4 + 1] = Q;
             lds[lane * 4 + 2] = L;
             lds[lane * 4 + 3] = make_float4(vz * adj.x, vz * dga, vz * dgb, vz * dgw);
-            if (AROWS) {       // the sample's four weights at their tile cells; everything else in the rows is zero
-                my_c00 = __float_as_int(Q.x);
-                const int cw[4] = {my_c00, my_c00 + 1, my_c00 + TL, my_c00 + TL + 1};
-                const float ww[4] = {W.x, W.y, W.z, W.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (cw[q] >= 0 && cw[q] < 16 * NRB) arows[arow_slot(lane, cw[q])] = ww[q];
-            }
         }
         __syncthreads();
         const int ng = min(16, (e - base + 3) >> 2);
         // software pipeline (ping-pong stages, scheduling barriers keep the order): the record + table taps of group g+1
         // are in flight while group g feeds the matrix pipe
-        DGrp<WITH_NORMAL, AROWS> st0, st1;
-        auto step = [&](DGrp<WITH_NORMAL, AROWS>& cur, DGrp<WITH_NORMAL, AROWS>& nxt, int g) {
+        DGrp<WITH_NORMAL> st0, st1;
+        auto step = [&](DGrp<WITH_NORMAL>& cur, DGrp<WITH_NORMAL>& nxt, int g) {
             nxt.load(lds, k, min(g + 1, 15), T, TLn, G, j4);  // branch-free: slots past the end hold zero adjoints
             __builtin_amdgcn_sched_barrier(0);
             const float4 W = cur.W, A = cur.A;
@@ -1070,7 +1055,7 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
             const int jc = j - cur.c00;
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const float a = AROWS ? cur.ar[rb] : a_weight(W, jc, rb);
+                const float a = a_weight(W, jc, rb);
                 accP[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bP, accP[rb], 0, 0, 0);
                 if (WITH_NORMAL) {
                     accX[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bX, accX[rb], 0, 0, 0);
@@ -1089,12 +1074,6 @@ __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* _
             step(st1, st0, g + 1);
         }
         __syncthreads();
-        if (AROWS) {           // the rows go back to all-zero for the next batch / item
-            const int cw[4] = {my_c00, my_c00 + 1, my_c00 + TL, my_c00 + TL + 1};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (cw[q] >= 0 && cw[q] < 16 * NRB) arows[arow_slot(lane, cw[q])] = 0.f;
-        }
     }
     flush_plane_tile(accP, pick3(g_dpk, i), DP, j, true, ox, oy, G, lane);
     if (WITH_NORMAL) {
@@ -1284,7 +1263,7 @@ __device__ __forceinline__ void vm_bwd_app2(nmf_vm_params p, const float4* __res
         const int2 *__restrict__ items, const int32_t *__restrict__ n_items, int item_size, int nbx, Ptrs3 dpk, Ptrs3 dlk,  \
         Ptrs3 apl, Ptrs3 ali, const float *__restrict__ dcoef, const float *__restrict__ d_app, MPtrs3 g_dpk, MPtrs3 g_dlk, \
         MPtrs3 g_apl, MPtrs3 g_ali, float *__restrict__ g_basis, int z_density, int z_app
-template <bool WITH_NORMAL, int HALVES, bool AROWS = false>
+template <bool WITH_NORMAL, int HALVES>
 __device__ __forceinline__ void walk_items(NMF_BWD_ARGS) {
     // The item count lives on the device; the grid is a fixed number of single-wave workgroups that stride over the list
     // (a grid sized by the host-side upper bound -- non-empty bricks <= all bricks -- would be 100 k-1 M mostly idle
@@ -1294,18 +1273,12 @@ __device__ __forceinline__ void walk_items(NMF_BWD_ARGS) {
     extern __shared__ float4 lds[];
     const int n = *n_items;
     const int half = (int)blockIdx.y / 3, i = (int)blockIdx.y % 3;
-    if (AROWS) {               // A-operand rows: zero once, every batch restores the zeros it overwrote
-        float4* z = lds + AROW_BASE;
-#pragma unroll
-        for (int q = 0; q < (16 * NRB * 64) / (4 * 64); ++q) z[q * 64 + (threadIdx.x & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-    }
     for (int item = (int)blockIdx.x; item < n; item += (int)gridDim.x) {
         const int2 it = items[item];
         const int brick = it.x;
         const int s = bin_off[brick] + it.y * item_size, e = min(s + item_size, bin_off[brick + 1]);
         if (HALVES == 0 || (HALVES == 2 && half == z_density))
-            vm_bwd_density2<WITH_NORMAL, AROWS>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
+            vm_bwd_density2<WITH_NORMAL>(p, rec0, rec1, brick, s, e, i, nbx, dpk, dlk, g_dpk, g_dlk, lds);
         else if (HALVES == 1 || (HALVES == 2 && half == z_app))
             vm_bwd_app2(p, rec0, brick, s, e, i, nbx, apl, ali, dcoef, d_app, g_apl, g_ali, g_basis, lds);
         __syncthreads();
@@ -1318,13 +1291,9 @@ template <bool WITH_NORMAL, int HALVES>
 __global__ void __launch_bounds__(BWD_THREADS) k_vm_bwd_brick(NMF_BWD_ARGS) {
     walk_items<WITH_NORMAL, HALVES>(NMF_BWD_PASS);
 }
-// AROWS: the A operands (bilinear weight of sample k on tile cell 16 rb + j: four compares + four selects per row block and
-// group step, a quarter of the loop's VALU instructions in a kernel that is VALU-bound at 3 VALU cycles per matrix cycle) are
-// laid out ONCE per sample in LDS rows instead -- the sample's lane writes its four weights at their cells, a group step
-// reads its operand with one ds_read per row block.  Same operand values, same matrix instructions, same bits.
-template <bool WITH_NORMAL, bool AROWS>
+template <bool WITH_NORMAL>
 __global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(3))) k_vm_bwd_density(NMF_BWD_ARGS) {
-    walk_items<WITH_NORMAL, 0, AROWS>(NMF_BWD_PASS);
+    walk_items<WITH_NORMAL, 0>(NMF_BWD_PASS);
 }
 
 Ptrs3 mk(const float* const a[3]) {
@@ -1591,10 +1560,7 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
     if (const char* ev = getenv("NMF_BWD_GRID")) gcap = atoi(ev) > 0 ? atoi(ev) : gcap;   // tuning knob
     const int64_t grid_x = max_items < gcap ? max_items : gcap;       // single-wave workgroups per plane
     const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);
-    bool arows = true;
-    if (const char* ev = getenv("NMF_WALK_AROWS")) arows = atoi(ev) != 0;                 // tuning knob (A/B)
-    arows = arows && want_d && !want_a;
-    const size_t lds_bytes = sizeof(float4) * 64 * (want_a ? 16 : 4) + (arows ? sizeof(float) * 16 * NRB * 64 : 0);
+    const size_t lds_bytes = sizeof(float4) * 64 * (want_a ? 16 : 4);
 #define NMF_LAUNCH_BWD_KERNEL(KERNEL)                                                                                            \
     hipLaunchKernelGGL(KERNEL, grid, block, lds_bytes, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
                        mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \
@@ -1603,10 +1569,8 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
         if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<true, 2>));
         else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 2>));
     } else if (want_d) {
-        if (d_normal && arows) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<true, true>));
-        else if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<true, false>));
-        else if (arows) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<false, true>));
-        else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<false, false>));
+        if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<true>));
+        else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_density<false>));
     } else
         NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 1>));
 #undef NMF_LAUNCH_BWD_KERNEL
