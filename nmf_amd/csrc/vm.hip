@@ -998,7 +998,9 @@ struct DGrp {
 // sample as rows in LDS and read with one ds_read per row block.  Same bits, but 12 KB of LDS per wave instead of 4: next
 // to the BRDF-MLP backward (150 KB of a CU's 160 KB) the walk's waves no longer fit on those CUs, and the step got SLOWER
 // (in-process A/B: 1.577 -> 1.611 ms at 128^3, 1.654 -> 1.718 ms at 300^3).  The loop is bound by the latency of its table
-// taps and by where its waves can be resident, not by its VALU count.
+// taps and by where its waves can be resident, not by its VALU count.  More resident waves do nothing either: the value-only
+// walk forced to 80 / 64 registers (6 / 8 waves per SIMD instead of 5) measures 1.562 / 1.566 / 1.572 ms and 1.638 / 1.627 /
+// 1.650 ms (300^3) -- inside the noise; the walk is not what bounds the window of the backward it runs in.
 template <bool WITH_NORMAL>
 __device__ __forceinline__ void vm_bwd_density2(nmf_vm_params p, const float4* __restrict__ rec0,
                                                 const float4* __restrict__ rec1, int brick, int s, int e, int i, int nbx,
