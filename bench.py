@@ -260,6 +260,17 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def flush_c_stdio():
+    """fflush(NULL) + Python's own buffers: what native libraries (RCCL's banner) have queued on stdout goes out now"""
+    import ctypes
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, global_rays=None):
     import torch  # noqa: F401
     for i in range(warmup):
@@ -561,16 +572,23 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             dt, n_rays = float(tmax[0]), float(tt[1])
+        line = None
         if rank == 0:
-            print(json.dumps({
+            line = json.dumps({
                 "metric": "inference rays/sec (microfacet_tensorf2, full 800x800 frame, render to completion)",
                 "value": n_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": 0,
                 "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": workload + f", eval mode, {chunk} rays per chunk; stands in for BASELINE configs[4]",
-                           "parallelism": f"replicas x{world}" if world > 1 else "dp1"}}))
-        if world > 1:
+                           "parallelism": f"replicas x{world}" if world > 1 else "dp1"}})
+        if world > 1:                         # the JSON line last (see the end of main)
+            flush_c_stdio()
+            dist.barrier()
             dist.destroy_process_group()
+        flush_c_stdio()
+        if line is not None:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
         return
 
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
@@ -696,10 +714,23 @@ def main():
             out["psnr_at_iter"] = out["extras"].get("psnr_at_iter")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
+    # The JSON line is the LAST thing this job writes to stdout: RCCL prints a version banner through C stdio (buffered when
+    # stdout is a pipe or a file, so it would otherwise come out at process exit, BEHIND the line), and the other ranks
+    # share rank 0's stdout under torch.distributed.run.  Every rank tears the process group down and flushes its C
+    # stdio first; rank 0 prints after the last barrier.
     if world > 1 or single_rank_comm:
+        flush_c_stdio()
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if line is not None:
+        if world > 1:
+            time.sleep(0.3)                   # the other ranks flush what their teardown printed
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

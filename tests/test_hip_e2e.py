@@ -414,6 +414,26 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["comm_bytes_per_step"] > 10e6 and rec["config"]["comm_ms_per_step"] > 0
     assert rec["value"] > 0 and rec["steps"] == 4
+    assert r.stdout.rstrip().splitlines()[-1].startswith('{"metric"'), "the JSON line must be the last line on stdout"
+
+
+def test_bench_json_is_the_last_stdout_line_with_rccl():
+    """RCCL prints a version banner through C stdio; with stdout on a pipe it is buffered and used to come out at process
+    exit, behind the bench line.  One rank over backend nccl (NMF_BENCH_BACKEND=nccl): the JSON line is the last line."""
+    import json as _json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMF_BENCH_BACKEND="nccl")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NMF_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.rstrip().splitlines()[-1]
+    assert last.startswith('{"metric"'), r.stdout[-600:]
+    rec = _json.loads(last)
+    assert rec["config"]["backend"] == "nccl" and rec["config"]["comm_bytes_per_step"] > 10e6
 
 
 def test_edge_cases_all_rays_miss_and_single_ray():
