@@ -320,7 +320,7 @@ def make_batches(nerf, n, rays_per_gpu, rank, device, distinct=48):
     return out, focal
 
 
-def time_infer(nerf, device, frames, warm_frames=1):
+def time_infer(nerf, device, frames, warm_frames=1, chunk=None):
     """full FRAME x FRAME frames of the S1 camera, eval_batch_size rays per chunk, rendered to completion.  The warm-up is
     one whole frame: the chunks of a frame differ in their sample counts, and the first pass over them is the caching
     allocator growing its pools (tools/infer_host_profile.py: 333 ms for the first frame, 101 ms for every later one) --
@@ -335,7 +335,7 @@ def time_infer(nerf, device, frames, warm_frames=1):
     noise = DeviceNoise(device, seed=11)
     was_training = nerf.training
     nerf.eval()
-    chunk = nerf.eval_batch_size
+    chunk = chunk or nerf.eval_batch_size
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(max(warm_frames, 1)):
@@ -442,6 +442,13 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["inference"] = dict(rays_per_s=n / dt, s_per_frame=dt / 2, first_frame_s=cold, frame=f"{FRAME}x{FRAME}", chunk=chunk,
                             note="eval mode, render to completion (renderer.py:56-106), rgb/acc outputs, S1 at 128^3; one "
                                  "whole warm-up frame (first_frame_s: the caching allocator grows its pools), two timed")
+    # eval_batch_size is a key of the reference's model config (4096 in microfacet_tensorf2.yaml): the evaluation path has no
+    # sample budget, so larger chunks only amortise the ~45 dependent launches and four size read-backs of a chunk
+    by_chunk = {}
+    for c in (16384, 32768):
+        dtc, nc, _, _ = time_infer(nerf, device, frames=2, chunk=c)
+        by_chunk[str(c)] = nc / dtc
+    out["inference"]["rays_per_s_by_eval_batch_size"] = by_chunk
     nerf.model.max_retrace_rays = [1000]
     out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
