@@ -260,6 +260,14 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def scale_budgets(nerf, f):
+    """per-chunk budgets of the reference's config times f (the chunk grows with them): sampler.max_samples, model.max_brdf_rays;
+    every secondary ray stays re-traced"""
+    nerf.sampler.max_samples = int(nerf.sampler.max_samples) * f
+    nerf.model.max_brdf_rays = [int(v) * f for v in nerf.model.max_brdf_rays]
+    nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
+
+
 def flush_c_stdio():
     """fflush(NULL) + Python's own buffers: what native libraries (RCCL's banner) have queued on stdout goes out now"""
     import ctypes
@@ -429,10 +437,10 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     def sync():
         torch.cuda.synchronize()
 
-    def train_ms(nerf, rays_per_gpu, steps, warmup):
+    def train_ms(nerf, rays_per_gpu, steps, warmup, chunk=CHUNK):
         tr = Trainer(nerf, params)
         batches, f = make_batches(nerf, steps + warmup, rays_per_gpu, 0, device, distinct=12)
-        dt, rays_done, last, _ = time_train(tr, batches, f, DeviceNoise(device, seed=5), warmup, steps, CHUNK, sync)
+        dt, rays_done, last, _ = time_train(tr, batches, f, DeviceNoise(device, seed=5), warmup, steps, chunk, sync)
         return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=last["n_samples"],
                     samples_per_chunk_first_step=last["first_n_samples"],
                     steps=steps, rays_per_step=rays_per_gpu)
@@ -455,6 +463,14 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
+    # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
+    # [650 000, 450 000]: sized for a 24 GB card) scaled by 4: two chunks of 16 384 rays, 2.3 GiB peak -- per-ray statistics
+    # unchanged (the bounce budget grows with the chunk's weight total), the ~115 dependent launches of a chunk paid twice
+    # instead of eight times (tools/big_chunk.py: x2 / x4 / x8)
+    scale_budgets(nerf, 4)
+    out["rays_32768_per_gpu_budgets_x4"] = train_ms(nerf, 32768, 8, 2, chunk=4 * CHUNK)
+    out["rays_32768_per_gpu_budgets_x4"]["note"] = ("the same 32 768-ray optimizer step as 2 chunks of 16 384 rays: sampler.max_samples / "
+                                                    "model.max_brdf_rays x 4 (config keys of the reference; `bench.py --budget-scale 4`)")
     del nerf
     torch.cuda.empty_cache()
     per_grid = {}
@@ -499,6 +515,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays-per-gpu", type=int, default=CHUNK)
+    ap.add_argument("--budget-scale", type=int, default=1,
+                    help="per-chunk budgets (sampler.max_samples, model.max_brdf_rays) and the chunk size times this factor")
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--mode", choices=("train", "infer"), default="train")
     ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32")
@@ -564,6 +582,9 @@ def main():
 
     torch.manual_seed(20211200)
     nerf, params = build(device, grid=args.grid, table_dtype=args.table_dtype)
+    chunk_rays = CHUNK * max(args.budget_scale, 1)
+    if args.budget_scale > 1:
+        scale_budgets(nerf, args.budget_scale)
     if args.retrace is not None:
         nerf.model.max_retrace_rays = [args.retrace]
     timer = RebuildCounter()
@@ -609,7 +630,7 @@ def main():
     for i in range(args.warmup):
         if n_probe and i == args.warmup - n_probe:
             fx.call_timing_begin()                  # the last warm-up steps find the dominant call of this workload
-        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
+        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
     if n_probe:
         probe = fx.call_timing_end()
         dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
@@ -617,7 +638,7 @@ def main():
     timer.enabled = True
     if dominant:
         fx.call_timing_begin(dominant)              # inside the timed region: events around the dominant call only
-    dt, rays_done, last, comm_ms = time_train(trainer, batches, focal, noise, 0, args.steps, CHUNK, sync)
+    dt, rays_done, last, comm_ms = time_train(trainer, batches, focal, noise, 0, args.steps, chunk_rays, sync)
     dom_live = fx.call_timing_end().get(dominant) if dominant else None
     timer.enabled = False
 
@@ -630,7 +651,7 @@ def main():
     else:
         dt_max, rays_all, ranks_seen = dt, float(rays_done), 1
 
-    chunks_per_step = -(-args.rays_per_gpu // CHUNK)
+    chunks_per_step = -(-args.rays_per_gpu // chunk_rays)
     if min(timer.rebuilds.values()) < args.steps:
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
     # ---- after the timed region: every C-ABI call of the step timed (events on the launching stream), 30 more steps
@@ -639,7 +660,7 @@ def main():
         n_inst = 30
         fx.call_timing_begin()
         for i in range(n_inst):
-            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
+            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
         timing = fx.call_timing_end()
         ls = trainer.fast.last_sizes
         sizes = dict(B=int(ls["rays"]), M0=int(ls["n_samples"][0]), M1=int(ls["n_samples"][1]) if len(ls["n_samples"]) > 1 else 0,
@@ -694,12 +715,13 @@ def main():
                 "counters": ctr_meta,
             }
         out = {
-            "metric": "train rays/sec (microfacet_tensorf2, 4096-ray chunks, steady state)",
+            "metric": f"train rays/sec (microfacet_tensorf2, {chunk_rays}-ray chunks, steady state)",
             "value": rays_all / dt_max, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.table_dtype == "f32" else "bf16 tables / f32 arithmetic",
             "data": "synthetic",
-            "config": {"workload": workload + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {CHUNK}, "
+            "config": {"workload": workload + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {chunk_rays}"
+                                   + (f" (per-chunk budgets x{args.budget_scale})" if args.budget_scale > 1 else "") + ", "
                                    "fwd+bwd+all-reduce+Adam, " + ("all secondary rays re-traced (steady state)" if args.retrace is None
                                                                   else f"{args.retrace} secondary rays re-traced") +
                                    f"; stands in for BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not "
@@ -714,7 +736,7 @@ def main():
                        "host_pass": "C++ (csrc/step_core.inc)" if timed_calls else "python (nmf_amd/fast_step.py)"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID \
+        if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID and args.budget_scale == 1 \
                 and args.table_dtype == "f32":
             del trainer
             out["extras"] = extras(device, params, focal, main_ms=1e3 * dt_max / args.steps, main_rays=rays_all / args.steps)
