@@ -237,6 +237,49 @@ def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
         dist.destroy_process_group()
 
 
+def test_scaled_budgets_run_the_same_step_in_one_larger_chunk():
+    """The per-chunk budgets are configuration (sampler.max_samples, model.max_brdf_rays: sized for a 24 GB card in the
+    reference's yaml).  16 384 rays at BASELINE size once as four chunks under the reference's budgets and once as ONE chunk
+    with both budgets x 4 (`bench.py --budget-scale`): every ray kept, more primary samples in the chunk than the
+    reference's cap admits, and the same loss and gradients up to the Monte-Carlo noise of two independent sets of draws."""
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    rays, focal = synthetic.camera_rays(16384, seed=77)
+    rays = rays.to(dev)
+    gt = torch.rand(16384, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    res = {}
+    for f in (1, 4):
+        nerf, params = bench.build(dev)
+        if f > 1:
+            bench.scale_budgets(nerf, f)
+        else:
+            nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
+        tr = Trainer(nerf, params)
+        assert tr.fast is not None and tr.fast.supported()
+        tr.optimizer.step = lambda: None
+        tr.optimizer.step_unhooked = lambda: None
+        out = tr.step(rays, gt, focal, noise=DeviceNoise(dev, seed=300 + f), update_controllers=False, fixed_chunk=4096 * f)
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().double().clone() for k, p in nerf.named_parameters() if p.grad is not None}
+        res[f] = (out, grads, int(nerf.sampler.max_samples))
+    (o1, g1, cap1), (o4, g4, cap4) = res[1], res[4]
+    assert o1["chunks"] == 4 and o4["chunks"] == 1
+    assert o4["rays"] == 16384 and o1["rays"] <= 16384
+    assert cap1 < o4["n_samples"][0] <= cap4, (o4["n_samples"], cap1, cap4)
+    l1, l4 = float(o1["loss"]), float(o4["loss"])
+    assert np.isfinite(l4) and abs(l4 / l1 * o1["rays"] / o4["rays"] - 1.0) < 0.05, (l1, l4, o1["rays"])
+    # the density factors also carry the L1 regulariser, which the reference adds once per CHUNK (train.py:640-677): four
+    # times in the chunked step, once in the other -- compared are the tensors that only see the data terms
+    big = [k for k in g1 if g1[k].numel() >= 100000 and k in g4 and "density_rf" not in k]
+    assert len(big) >= 4, sorted(g1)
+    for k in big:                              # two independent Monte-Carlo estimates of the same gradient
+        a, b = g1[k].flatten() * (o4["rays"] / o1["rays"]), g4[k].flatten()
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert 0.8 < float(b.norm() / a.norm()) < 1.25 and cos > 0.7, (k, float(a.norm()), float(b.norm()), cos)
+
+
 def test_psnr_after_equal_iterations_at_a_trained_level():
     """north_star "PSNR within 0.05 dB of reference after equal iterations", at a TRAINED quality level: the reference's own
     `reconstruction()` loop was run for 300 iterations on the S2 orbit data set for SIX seeds (tests/golden/make_psnr_trace.py:
