@@ -49,6 +49,13 @@ int nmf_event_elapsed_ms(void* start, void* stop, float* ms);   /* both recorded
 int nmf_event_destroy(void* event);
 int nmf_event_record(void* event, void* stream);
 int nmf_event_synchronize(void* event);
+/* Size read-back without a copy command or an event (runtime plumbing like the calls above; the reference reads its sizes with
+ * implicit .item() synchronisations, e.g. samplers/alphagrid.py:353-364, models/microfacet.py:318-331): the sizes are published by a
+ * one-thread kernel into mapped, coherent host memory [value0, value1, seq] and the host spins on seq.  nmf_wait_seq is blocking. */
+int nmf_host_alloc_mapped(void** host_ptr, void** dev_ptr, int64_t nbytes);
+int nmf_host_free_mapped(void* host_ptr);
+int nmf_publish_i64x2(const int64_t* src_dev, void* dst_mapped_dev, int64_t seq, void* stream);
+int nmf_wait_seq(const void* host_ptr, int64_t seq, double timeout_s);
 int nmf_stream_wait_event(void* stream, void* event);
 int nmf_memcpy_d2h_async(void* dst_host, const void* src_dev, int64_t nbytes, void* stream);
 
