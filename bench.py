@@ -493,19 +493,26 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
                                         note="steady-state step at every grid of the upsampling schedule, weighted by the iterations "
                                              "spent there; kept rays per chunk fall with the grid (200 k-sample budget)")
     out["psnr_at_iter"] = psnr_at_iter(device)
-    try:
-        nerf16, _ = build(device, table_dtype="bf16")
-    except (AttributeError, NotImplementedError) as e:
-        out["bf16_tables"] = dict(error=str(e))
+    # bf16 factor tables (BASELINE configs[1]) against fp32 tables, each in a FRESH process: inside this one, whichever model
+    # is built third or later runs 0.1-0.25 ms per step slower than the same model as the first of its process (tools/
+    # _bf16_check.py: f32 1.60 ms alone, 1.72-1.86 ms after a 300^3 model, the PSNR run or a large-chunk leg had been through
+    # the allocator) -- two in-process legs compared the order of construction, not the table type
+    legs = {}
+    for name in ("bf16", "f32"):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--table-dtype", name, "--steps", "80", "--warmup", "20",
+                            "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        legs[name] = json.loads(lines[-1]) if r.returncode == 0 and lines else None
+    if legs["bf16"] is None or legs["f32"] is None:
+        out["bf16_tables"] = dict(error="the fresh-process legs did not finish")
     else:
-        out["bf16_tables"] = train_ms(nerf16, CHUNK, 40, 10)
-        del nerf16
-        nerf32, _ = build(device)
-        out["bf16_tables"]["f32_tables_same_protocol_ms"] = train_ms(nerf32, CHUNK, 40, 10)["ms_per_step"]
-        out["bf16_tables"]["note"] = ("BASELINE configs[1]: factor tables read as bf16 by the forward queries (fp32 master copy for "
-                                      "Adam and the backward walks, fp32 arithmetic); f32_tables_same_protocol_ms = the fp32 tables "
-                                      "over the same 10 + 40 steps of this leg (random targets: the scene drifts, so not the headline "
-                                      "number); PSNR delta in DESIGN.md")
+        out["bf16_tables"] = dict(ms_per_step=legs["bf16"]["ms_per_step"], rays_per_s=legs["bf16"]["value"],
+                                  f32_tables_same_protocol_ms=legs["f32"]["ms_per_step"], steps=80, rays_per_step=CHUNK,
+                                  samples_per_chunk=legs["bf16"]["config"]["samples_per_chunk"],
+                                  note=("BASELINE configs[1]: factor tables read as bf16 by the forward queries (fp32 master copy "
+                                        "for Adam and the backward walks, fp32 arithmetic); both numbers are `python bench.py "
+                                        "--table-dtype bf16|f32 --steps 80 --warmup 20` in a fresh process each (the workload of "
+                                        "the headline number); PSNR delta in DESIGN.md"))
     return out
 
 
