@@ -84,7 +84,12 @@ class TrainPass:
         self._owner_slots = None
         self.sparse_normals = os.environ.get("NMF_SPARSE_NORMALS", "1") != "0"
         self._early_env = None
-        self._side = {}
+        # Side streams are PROCESS-WIDE, one per role and device: HIP maps streams onto a few hardware queues in creation
+        # order (GPU_MAX_HW_QUEUES, 4 by default), and which roles end up sharing a queue decides what can overlap.  With
+        # streams of its own, the second, third, ... TrainPass of a process got another role -> queue assignment than the
+        # first and ran up to 0.25 ms per step slower (tools/model_order_check.py); passes of one process run one after the
+        # other, so they can share the streams.
+        self._side = _SIDE_STREAMS.setdefault(torch.cuda.current_device() if torch.cuda.is_available() else -1, {})
         self._main = None
         # the same pass as ONE C++ call per chunk (csrc/step_core.inc, in lib/_nmf_host.so): the methods below stay the
         # specification and the path for bf16 tables / NMF_STEP_CORE=0 / a missing host extension
@@ -144,6 +149,7 @@ class TrainPass:
             tb = self._side.get("tables")
             if tb is None:
                 tb = self._side["tables"] = torch.cuda.Stream()
+            if self._table_events is None:
                 self._table_events = (torch.cuda.Event(), torch.cuda.Event())
             tb.wait_stream(main)                      # the optimizer update of the parameters was queued on the main stream
             torch.cuda.set_stream(tb)
@@ -819,6 +825,7 @@ class TrainPass:
 
 
 _CONST = {}
+_SIDE_STREAMS = {}          # device index -> {role: torch.cuda.Stream}, shared by every TrainPass of the process
 
 
 def _white(dev):
