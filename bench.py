@@ -28,6 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as nmf_amd/__init__.py: before the first HIP call of the process
 
 CHUNK = 4096                    # rays per forward/backward chunk (train.py `num_rays` at ~200 k primary samples)
 GRID = 128
@@ -493,10 +494,9 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
                                         note="steady-state step at every grid of the upsampling schedule, weighted by the iterations "
                                              "spent there; kept rays per chunk fall with the grid (200 k-sample budget)")
     out["psnr_at_iter"] = psnr_at_iter(device)
-    # bf16 factor tables (BASELINE configs[1]) against fp32 tables, each in a FRESH process: inside this one, whichever model
-    # is built third or later runs 0.1-0.25 ms per step slower than the same model as the first of its process (tools/
-    # _bf16_check.py: f32 1.60 ms alone, 1.72-1.86 ms after a 300^3 model, the PSNR run or a large-chunk leg had been through
-    # the allocator) -- two in-process legs compared the order of construction, not the table type
+    # bf16 factor tables (BASELINE configs[1]) against fp32 tables, each in a FRESH process = the protocol of the headline
+    # number (before the side streams became process-wide, two in-process legs compared the order in which the two trainers
+    # were built, not the table type: DESIGN 0.2)
     legs = {}
     for name in ("bf16", "f32"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--table-dtype", name, "--steps", "80", "--warmup", "20",
