@@ -183,12 +183,14 @@ def physical_cores():
     return max(len(cores), 1)
 
 
-def cpu_baseline(budget_s=150.0):
+def cpu_baseline(budget_s=150.0, warm=1, timed=3):
     """The CPU oracle (validated against the reference, tests/test_oracle_golden.py) timed on the host cores with the
     SURVEY 8(d) protocol: the SAME workload as the GPU step (S1, 128^3, B = 4096 rays, forward + backward of the training
     loss), one thread per physical core, one warm-up step and up to three timed steps in each phase -- early (1000 rays
     re-traced, the first 19 chunks after every (re)start) and steady state (all re-traced, what `value` is quoted on) --
-    bounded to ~`budget_s` seconds of CPU work: a phase stops timing once its share of the budget is spent."""
+    bounded to ~`budget_s` seconds of CPU work: a phase stops timing once its share of the budget is spent.
+    `--cpu-baseline-steps 3,10` is SURVEY 8(d)'s full protocol (3 warm-up + 10 timed steps per phase, ~6 minutes of host time,
+    no budget): run once per round and kept in profiles/."""
     import torch
     from nmf_amd import synthetic
     from oracle import nmf_oracle as O
@@ -205,7 +207,7 @@ def cpu_baseline(budget_s=150.0):
         cfg = O.Cfg(grid=GRID, detach_N=False, max_retrace_rays=(retrace,))
         times, n_samples = [], None
         t_phase = time.time()
-        for i in range(4):                                  # step 0 = warm-up
+        for i in range(warm + timed):                       # the first `warm` steps are warm-up
             rays, focal = synthetic.camera_rays(CHUNK, seed=500 + i)
             gt = torch.rand(CHUNK, 3, generator=torch.Generator().manual_seed(i))
             for v in sd.values():
@@ -217,17 +219,17 @@ def cpu_baseline(budget_s=150.0):
             total.backward()
             dt = time.time() - t0
             n_samples = [int(x) for x in st["n_samples"]]
-            if i > 0:
+            if i >= warm:
                 times.append(dt)
-            if i >= 1 and time.time() - t_phase + dt > share * budget_s:
+            if budget_s is not None and i >= warm and time.time() - t_phase + dt > share * budget_s:
                 break
         out[phase] = dict(rays_per_s=CHUNK / (sum(times) / len(times)), s_per_step=sum(times) / len(times),
-                          timed_steps=len(times), warmup_steps=1, n_samples=n_samples)
+                          timed_steps=len(times), warmup_steps=warm, n_samples=n_samples)
     torch.set_num_threads(prev_threads)
     st = out["steady"]
     return dict(value=st["rays_per_s"], unit="rays/s", cores=cores, kind="port",
                 sample=f"B={CHUNK} rays of S1 at 128^3, forward+backward of the training loss, steady state "
-                       f"(samples {st['n_samples']}): 1 warm-up + {st['timed_steps']} timed steps, {st['s_per_step']:.1f} s "
+                       f"(samples {st['n_samples']}): {warm} warm-up + {st['timed_steps']} timed steps, {st['s_per_step']:.1f} s "
                        f"each, {cores} threads (physical cores); early phase beside it",
                 early_phase=out["early"], steady_state=st)
 
@@ -530,6 +532,7 @@ def main():
     ap.add_argument("--retrace", type=int, default=None,
                     help="max_retrace_rays (default: every secondary ray = the steady state; 1000 = the early phase)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", default=None, help="W,K: W warm-up + K timed CPU steps per phase, no time budget")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
@@ -749,7 +752,11 @@ def main():
             out["extras"] = extras(device, params, focal, main_ms=1e3 * dt_max / args.steps, main_rays=rays_all / args.steps)
             out["psnr_at_iter"] = out["extras"].get("psnr_at_iter")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            if args.cpu_baseline_steps:
+                w_, k_ = (int(v) for v in args.cpu_baseline_steps.split(","))
+                out["cpu_baseline"] = cpu_baseline(budget_s=None, warm=w_, timed=k_)
+            else:
+                out["cpu_baseline"] = cpu_baseline()
         line = json.dumps(out)
     else:
         line = None
