@@ -10,6 +10,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from nmf_amd.noise import DeviceNoise  # noqa: E402
 from nmf_amd.trainer import Trainer  # noqa: E402
+import nmf_amd.fast_step as fast_step  # noqa: E402
+
+if os.environ.get("NMF_MLP_SIDE_WGS"):          # workgroup cap of the side-stream BRDF-MLP backward (tuned at 4096-ray chunks: 96)
+    fast_step.MLP_SIDE_WGS = fast_step.MLP_SIDE_WGS_ENV = int(os.environ["NMF_MLP_SIDE_WGS"])
 
 RAYS = 32768
 dev = torch.device("cuda", 0)
