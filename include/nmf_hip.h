@@ -36,6 +36,9 @@ extern "C" {
 #define NMF_MLP_IN 66     /* MLPBRDF input width, modules/brdf.py:73-120 */
 #define NMF_MLP_HID 64
 
+/* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
+ * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
+#define NMF_ABI_VERSION 104
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -104,6 +107,12 @@ int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_
                    uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
                    void* stream);
 int64_t nmf_march_scan_workspace_bytes(int64_t B);
+/* The same scan; the thread that writes totals also PUBLISHES them: [M, b, publish_seq] into mapped host memory
+ * (nmf_host_alloc_mapped's device pointer; NULL = nmf_march_scan) for a host that waits with nmf_wait_seq -- the size
+ * read-back of alphagrid.py:353-364 (`ray_valid.sum() > max_samples`, a host sync) without a launch of its own. */
+int nmf_march_scan_publish(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
+                           uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
+                           void* publish_mapped_dev, int64_t publish_seq, void* stream);
 
 /* Pass 3: emit the compacted samples of the first b rays: xyzt [M][4] (world xyz, t/focal),
  * ray_id [M], step_id [M], z [M], dist [M] (= z[k+1]-z[k] over ALL candidates, 0 for the last,
@@ -208,6 +217,25 @@ int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* 
                               const float* basis, float* const g_dpk[3], float* const g_dlk[3],
                               float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The brick sort of a walk as a PLAN: it depends on the sample positions alone (not on the adjoints), so a training pass
+ * builds it when the positions become known -- under its forward, on a side stream -- and the backward only permutes the
+ * adjoints (autograd of fields/tensoRF.py:181-205 sees the same sample set twice: forward and backward).
+ *   nmf_vm_bin_plan            positions of up to NMF_VM_MAX_SEGMENTS sample sets -> plan (opaque device buffer of
+ *                              nmf_vm_bin_plan_bytes(total M, grid) bytes: slots, brick offsets, work items, sorted positions)
+ *   nmf_vm_query_bwd_planned   nmf_vm_query_bwd_segments over the SAME segment sizes in the same order with that plan;
+ *                              workspace >= nmf_vm_walk_workspace_bytes(total M).
+ * nmf_vm_query_bwd_segments = plan + planned walk inside one workspace (nmf_vm_bwd_workspace_bytes = the two sizes added). */
+int64_t nmf_vm_bin_plan_bytes(int64_t M, int32_t grid);
+int64_t nmf_vm_walk_workspace_bytes(int64_t M);
+int nmf_vm_bin_plan(const nmf_vm_params* p, const float* const* xyzt /*HOST array of device pointers*/,
+                    const int64_t* Ms /*HOST array*/, int32_t n_segs, void* plan, int64_t plan_bytes, void* stream);
+int nmf_vm_query_bwd_planned(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs /*HOST array*/, int32_t n_segs,
+                             const float* const dpk[3], const float* const dlk[3],
+                             const float* const app_planes[3], const float* const app_lines[3],
+                             const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                             float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                             const void* plan, int64_t plan_bytes, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Folds the packed gradient back onto the factors (transpose of nmf_vm_pack_density):
  * g_planes[i] [G][G][16], g_lines[i] [G][16] are OVERWRITTEN. */
@@ -405,6 +433,10 @@ int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* r
                      int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int64_t nmf_bounce_index_workspace_bytes(int64_t M);
+/* nmf_bounce_index that also publishes [R, Mb, publish_seq] into mapped host memory (see nmf_march_scan_publish). */
+int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off, int32_t* cnt_rows,
+                             int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
+                             int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq, void* stream);
 /* Per bounce row (models/microfacet.py:297,304-316,352-361): V = -ray direction, N = normal facing V
  * (n * sign(V.n)), r1 = max(roughness, min_rough), f0, diffuse = albedo * E(n) with E the 9-term SH irradiance
  * (conv [9][3] DEVICE pointer, modules/sh.py:97-142), feat = app + anoise * feat_noise (feat_noise may be NULL),

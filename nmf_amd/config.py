@@ -48,6 +48,69 @@ MODEL = dict(
         lr_delay_steps=100, bg_col="white"))
 
 
+# configs/default.yaml: the top-level keys of a run.  The reference's defaults list names dataset=materials, model=brdf_tcnn;
+# brdf_tcnn is outside this package's path, so the built-in tree defaults to the headline configuration.
+DEFAULT = dict(
+    defaults=["_self_", {"dataset": "lego"}, {"model": "microfacet_tensorf2"}, {"field": "tensorf_og"}],
+    basedir="./log", filter_rays=False, expname="test", datadir="/data", render_only=False, render_train=False,
+    render_test=True, render_path=False, add_timestamp=False, nSamples=1e6, N_vis=5, vis_every=5000,
+    progress_refresh_rate=1, rm_weight_mask_thre=1e-4, step_ratio=0.5, ckpt=None, lr_decay_iters=-1,
+    lr_decay_target_ratio=0.1, lr_upsample_reset=1, fp16=False, n_bg_iters=1000, save_often=False, fixed_bg=None,
+    seed=20211200, gt_bg=None, render_mode="center")
+
+# the keys of configs/model/microfacet_tensorf2.yaml:params that Trainer does not read (they switch off terms of train.py this
+# path does not have) -- carried so that a resolved config.yaml has the reference's key set
+PARAMS_UNUSED = dict(
+    TV_weight_density=0.0, TV_weight_app=0.0, TV_weight_bg=0, envmap_lambda=0, final_pred_lambda=None, diffuse_lambda=0,
+    final_ori_lambda=None, brdf_lambda=0, normal_err_lambda=0, distortion_lambda=0, visibility_lambda=0, charbonier_eps=1e-3,
+    ortho_weight=0, N_visibility_rays=128, charbonier_loss=False, start_density=1e-3, lr=None)
+
+
+def _blender(scene, near_far, gt_bg=None, **extra):
+    d = dict(scenedir=f"nerf_synthetic/{scene}", dataset_name="blender", downsample_train=1, downsample_test=1, ndc_ray=False,
+             near_far=list(near_far))
+    d.update(extra)
+    if gt_bg is not None:
+        d["gt_bg"] = gt_bg
+    return d
+
+
+# configs/dataset/<name>.yaml (values only; BASELINE.json's four scenes first)
+DATASETS = dict(
+    lego=_blender("lego", [2.5, 7], "lego_bg.exr"), ship=_blender("ship", [1, 6], "sunrise.exr"),
+    materials=_blender("materials", [2, 6], "forest.exr", stack_norms=False),
+    helmet=_blender("helmet", [3, 5], "abandoned_factory_canteen_01_4k.exr", aabb_scale=2),
+    car=_blender("car", [2, 5], "forest.exr", stack_norms=False), chair=_blender("chair", [1, 6], "interior.exr"),
+    drums=_blender("drums", [2.5, 6], "interior.exr"), ficus=_blender("ficus", [1, 6], "interior.exr"),
+    hotdog=_blender("hotdog", [2, 5], "sunrise.exr"), mic=_blender("mic", [2, 6], "courtyard.exr"),
+    toaster=_blender("toaster", [2.5, 5], "interior.exr"), coffee=_blender("coffee", [3, 5]),
+    teapot=_blender("teapot", [3, 5], "sunset_jhbcentral_4k.exr", aabb_scale=0.75),
+    ball=_blender("ball", [2.5, 5], "forest.exr", aabb_scale=2),
+    # not a reference file: the offline stand-in of SURVEY 8(d) (views rendered from scene S1 on an orbit; no files read)
+    s2_orbit=dict(scenedir=None, dataset_name="synthetic_orbit", downsample_train=1, downsample_test=1, ndc_ray=False,
+                  near_far=[2.5, 7], views=24, test_views=4, res=64))
+
+
+def builtin_tree():
+    """The config tree `compose()` reads when no --config-dir is given: {relative path without .yaml: dict}, same layout
+    as the reference's configs/ directory (default.yaml, model/<name>.yaml, field/<name>.yaml, dataset/<name>.yaml)."""
+    model = copy.deepcopy(MODEL)
+    order = ["L1_weight_initial", "L1_weight_rest", "clip_grad", "weight_decay", "eps", "betas", "starting_batch_size",
+             "min_batch_size", "max_batch_size", "target_num_samples", "TV_weight_density", "TV_weight_app", "TV_weight_bg",
+             "envmap_lambda", "pred_lambda", "final_pred_lambda", "diffuse_lambda", "ori_lambda", "final_ori_lambda",
+             "brdf_lambda", "normal_err_lambda", "distortion_lambda", "visibility_lambda", "charbonier_eps", "ortho_weight",
+             "N_visibility_rays", "n_iters", "charbonier_loss", "start_density", "batch_size", "lr", "lr_init", "lr_final",
+             "lr_delay_mult", "lr_delay_steps", "bg_col"]
+    allp = dict(PARAMS_UNUSED, **model["params"])
+    model["params"] = {k: allp[k] for k in order}
+    _mark_partial(model)
+    tree = {"default": copy.deepcopy(DEFAULT), "model/microfacet_tensorf2": model,
+            "field/tensorf_og": _mark_partial(copy.deepcopy(FIELD))}
+    for name, d in DATASETS.items():
+        tree[f"dataset/{name}"] = copy.deepcopy(d)
+    return tree
+
+
 def resolved_config():
     cfg = copy.deepcopy(MODEL)
     cfg["arch"]["rf"] = copy.deepcopy(FIELD)          # train.py:911: cfg.model.arch.rf = cfg.field

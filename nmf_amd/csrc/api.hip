@@ -5,7 +5,7 @@
 
 thread_local char nmf_err_buf[256] = "no error";
 
-extern "C" int nmf_version(void) { return 100; }   // 0.1.0
+extern "C" int nmf_version(void) { return NMF_ABI_VERSION; }
 
 extern "C" const char* nmf_last_error_string(void) { return nmf_err_buf; }
 
@@ -95,8 +95,16 @@ extern "C" int nmf_wait_seq(const void* host_ptr, int64_t seq, double timeout_s)
     for (uint64_t spin = 0;; ++spin) {
         if (__atomic_load_n(p + 2, __ATOMIC_ACQUIRE) == seq) return NMF_OK;
         if ((spin & 0xfff) == 0xfff &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-            return nmf_fail(NMF_EINVAL, "nmf_wait_seq: timed out");
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            // slow is not lost (a counter-collecting profiler serialises kernels, a shared GPU, code objects still loading):
+            // wait for the device to drain, which also reports a device that is gone, then look once more
+            const hipError_t r = hipDeviceSynchronize();
+            if (r != hipSuccess) return nmf_fail((int)r, "nmf_wait_seq: hipDeviceSynchronize after the spin timed out");
+            if (__atomic_load_n(p + 2, __ATOMIC_ACQUIRE) == seq) return NMF_OK;
+            return nmf_fail(NMF_EINVAL, "nmf_wait_seq: the device is idle and the sequence number never arrived");
+        }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
     }
 }

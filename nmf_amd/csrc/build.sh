@@ -9,7 +9,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-fast-
 objs=()
 for f in "$here"/*.hip; do
   o="$out/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$here/common.hpp" -nt "$o" ] || [ "$here/../../include/nmf_hip.h" -nt "$o" ]; then
+  stale=0
+  for h in "$here"/*.hpp "$here/../../include/nmf_hip.h"; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$stale" = 1 ]; then
     extra=""
     # bookkeeping kernels must reproduce the CPU oracle bit-for-bit: no a*b+c -> fma contraction there
     case "$(basename "$f")" in

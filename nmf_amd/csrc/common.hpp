@@ -100,3 +100,14 @@ __device__ __forceinline__ double wave_incl_scan(double v) {
     }
     return v;
 }
+
+// two sizes + a sequence number into mapped, coherent host memory (nmf_host_alloc_mapped): the producing kernel itself
+// publishes what the host is waiting for (nmf_wait_seq) -- no extra one-thread launch on the dependency chain
+__device__ __forceinline__ void publish_sizes(int64_t* dst, int64_t a, int64_t b, int64_t seq) {
+    if (!dst) return;
+    volatile int64_t* d = dst;
+    d[0] = a;
+    d[1] = b;
+    __threadfence_system();
+    d[2] = seq;
+}

@@ -9,6 +9,7 @@
 #include <torch/extension.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <map>
 #include <memory>
@@ -71,7 +72,7 @@ void* st(int64_t stream) { return reinterpret_cast<void*>(stream); }
 // When a CallTimer is active, every wrapper below records an event in front of and behind its C-ABI call on the stream it
 // launches on; report() turns them into {call name: (summed ms, calls)}.  Inactive: one pointer test per call.
 struct CallTimer {
-    struct Rec { const char* name; void* a; void* b; };
+    struct Rec { const char* name; void* a; void* b; void* stream; double host_us; };
     std::vector<void*> pool;
     size_t next = 0;
     std::vector<Rec> recs;
@@ -86,14 +87,23 @@ struct CallTimer {
     ~CallTimer() { for (void* e : pool) nmf_event_destroy(e); }
 };
 CallTimer* g_call_timer = nullptr;
-std::string g_call_filter;           // non-empty: only the wrapper of that name is timed (the dominant call inside the timed region)
+std::string g_call_filter;           // non-empty: only the wrapper of that name (or of a comma-separated list of names) is timed
 struct TimedScope {
     const char* name; void* stream; void* a = nullptr;
     TimedScope(const char* n, int64_t s) : name(n), stream(reinterpret_cast<void*>(s)) {
-        if (g_call_timer && (g_call_filter.empty() || g_call_filter == n)) { a = g_call_timer->ev(); nmf_event_record(a, stream); }
+        if (g_call_timer && (g_call_filter.empty() || g_call_filter == n ||
+                             (g_call_filter.find(',') != std::string::npos && (',' + g_call_filter + ',').find(',' + std::string(n) + ',') != std::string::npos))) {
+            a = g_call_timer->ev();
+            nmf_event_record(a, stream);
+        }
     }
     ~TimedScope() {
-        if (a && g_call_timer) { void* b = g_call_timer->ev(); nmf_event_record(b, stream); g_call_timer->recs.push_back({name, a, b}); }
+        if (a && g_call_timer) {
+            void* b = g_call_timer->ev();
+            nmf_event_record(b, stream);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            g_call_timer->recs.push_back({name, a, b, stream, us});
+        }
     }
 };
 
@@ -121,15 +131,17 @@ std::tuple<Tensor, Tensor> march_count(int64_t p_addr, const Tensor& rays, const
     return {valid, counts};
 }
 
-std::tuple<Tensor, Tensor, Tensor> march_scan(const Tensor& counts, int64_t max_samples, int64_t stream) {
+// pub / pub_seq: mapped host memory (device pointer) the scan publishes its totals into, with that sequence number (0: none)
+std::tuple<Tensor, Tensor, Tensor> march_scan(const Tensor& counts, int64_t max_samples, int64_t stream, int64_t pub = 0,
+                                              int64_t pub_seq = 0) {
     TimedScope _ts(__func__, stream);
     const int64_t B = counts.size(0);
     Tensor offsets = ie(counts, {B + 1}, at::kLong), whole = ie(counts, {B}, at::kByte), totals = ie(counts, {2}, at::kLong);
     const int64_t nbytes = nmf_march_scan_workspace_bytes(B);
     Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
-    check(nmf_march_scan(i32(counts), B, max_samples, static_cast<int64_t*>(offsets.data_ptr()),
-                         static_cast<uint8_t*>(whole.data_ptr()), static_cast<int64_t*>(totals.data_ptr()), ws.data_ptr(),
-                         nbytes, st(stream)),
+    check(nmf_march_scan_publish(i32(counts), B, max_samples, static_cast<int64_t*>(offsets.data_ptr()),
+                                 static_cast<uint8_t*>(whole.data_ptr()), static_cast<int64_t*>(totals.data_ptr()), ws.data_ptr(),
+                                 nbytes, reinterpret_cast<void*>(pub), pub_seq, st(stream)),
           "nmf_march_scan");
     return {offsets, whole, totals};
 }
@@ -308,7 +320,7 @@ Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, cons
     return contrib;
 }
 
-py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream) {
+py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream, int64_t pub = 0, int64_t pub_seq = 0) {
     TimedScope _ts(__func__, stream);
     const int64_t M = counts.size(0), M1 = M > 0 ? M : 1;
     Tensor bidx = ie(counts, {M1}, at::kInt), row_off = ie(counts, {M + 1}, at::kLong), inv = ie(counts, {M1}, at::kInt);
@@ -317,11 +329,11 @@ py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream) {
     Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
     Tensor rows;
     if (xyzt.has_value()) rows = at::empty({M1, 4}, counts.options().dtype(at::kFloat));
-    check(nmf_bounce_index(M ? i32(counts) : nullptr, M, static_cast<int32_t*>(bidx.data_ptr()),
-                           static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
-                           static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()),
-                           (xyzt.has_value() && M) ? f32(*xyzt) : nullptr, xyzt.has_value() ? out(rows) : nullptr, ws.data_ptr(),
-                           nbytes, st(stream)),
+    check(nmf_bounce_index_publish(M ? i32(counts) : nullptr, M, static_cast<int32_t*>(bidx.data_ptr()),
+                                   static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
+                                   static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()),
+                                   (xyzt.has_value() && M) ? f32(*xyzt) : nullptr, xyzt.has_value() ? out(rows) : nullptr,
+                                   ws.data_ptr(), nbytes, reinterpret_cast<void*>(pub), pub_seq, st(stream)),
           "nmf_bounce_index");
     if (xyzt.has_value()) return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals, rows);
     return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals);
@@ -521,12 +533,31 @@ std::tuple<Tensor, OT, OT> ray_compose_bwd(const Tensor& weight, const OT& refl_
 // ---- field backward (FieldGrads.backward: two walks + the unpack, ~180 us of Python per step) -------------------------
 using Seg = std::tuple<Tensor, OT, OT, OT, OT, OT, OT>;     // xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app
 
-void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
-                           const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
-                           const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
-                           const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
-                           int64_t stream) {
+// the brick sort of a walk, built from the positions alone (nmf_vm_bin_plan): -> opaque plan buffer
+Tensor vm_bin_plan(int64_t p_addr, const std::vector<Tensor>& xyzts, int64_t stream, const OT& into = OT()) {
     TimedScope _ts(__func__, stream);
+    const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
+    if (xyzts.empty() || xyzts.size() > NMF_VM_MAX_SEGMENTS) fail("vm_bin_plan: 1.." + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments");
+    const float* ptrs[NMF_VM_MAX_SEGMENTS];
+    int64_t Ms[NMF_VM_MAX_SEGMENTS], M = 0;
+    for (size_t i = 0; i < xyzts.size(); ++i) {
+        ptrs[i] = f32(xyzts[i]);
+        Ms[i] = xyzts[i].size(0);
+        M += Ms[i];
+    }
+    const int64_t nbytes = nmf_vm_bin_plan_bytes(M, p->grid);
+    Tensor plan = into.has_value() ? *into : ie(xyzts[0], {(nbytes + 3) / 4}, at::kInt);
+    if (plan.numel() * plan.element_size() < nbytes) fail("vm_bin_plan: the buffer passed in is too small");
+    check(nmf_vm_bin_plan(p, ptrs, Ms, (int32_t)xyzts.size(), plan.data_ptr(), nbytes, st(stream)), "nmf_vm_bin_plan");
+    return plan;
+}
+
+void vm_query_bwd_impl(const char* name, int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
+                       const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
+                       const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
+                       const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis, const OT& plan,
+                       int64_t stream) {
+    TimedScope _ts(name, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     if (segs.size() > NMF_VM_MAX_SEGMENTS) fail("at most " + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments per walk");
     nmf_vm_bwd_segment arr[NMF_VM_MAX_SEGMENTS];
@@ -547,7 +578,7 @@ void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const s
         want_a = want_a || std::get<6>(segs[i]).has_value();
     }
     if (M == 0) return;
-    const int64_t nbytes = nmf_vm_bwd_workspace_bytes(M, p->grid);
+    const int64_t nbytes = plan.has_value() ? nmf_vm_walk_workspace_bytes(M) : nmf_vm_bwd_workspace_bytes(M, p->grid);
     Tensor ws = ie(std::get<0>(segs[0]), {(nbytes + 3) / 4}, at::kInt);
     P3 a{}, b{}, c{}, d{};
     float *ga[3] = {nullptr, nullptr, nullptr}, *gb[3] = {nullptr, nullptr, nullptr}, *gc[3] = {nullptr, nullptr, nullptr},
@@ -558,11 +589,35 @@ void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const s
     };
     if (want_d) { a = three(dpk); b = three(dlk); three_out(g_dpk, ga); three_out(g_dlk, gb); }
     if (want_a) { c = three(apl); d = three(ali); three_out(g_apl, gc); three_out(g_ali, gd); }
-    check(nmf_vm_query_bwd_segments(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
-                                    want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
-                                    want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
-                                    want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, ws.data_ptr(), nbytes, st(stream)),
-          "nmf_vm_query_bwd_segments");
+    if (plan.has_value())
+        check(nmf_vm_query_bwd_planned(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
+                                       want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
+                                       want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
+                                       want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, vptr(plan), plan->numel() * 4,
+                                       ws.data_ptr(), nbytes, st(stream)),
+              "nmf_vm_query_bwd_planned");
+    else
+        check(nmf_vm_query_bwd_segments(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
+                                        want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
+                                        want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
+                                        want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, ws.data_ptr(), nbytes, st(stream)),
+              "nmf_vm_query_bwd_segments");
+}
+
+void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
+                           const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
+                           const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
+                           const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
+                           int64_t stream) {
+    vm_query_bwd_impl(__func__, p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(), stream);
+}
+
+void vm_query_bwd_planned(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
+                          const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
+                          const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
+                          const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
+                          const Tensor& plan, int64_t stream) {
+    vm_query_bwd_impl(__func__, p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(plan), stream);
 }
 
 std::tuple<std::vector<Tensor>, std::vector<Tensor>> vm_unpack_density_grad(int64_t p_addr, const std::vector<Tensor>& g_dpk,
@@ -823,7 +878,7 @@ PYBIND11_MODULE(_nmf_host, m) {
         g_error_class = cls.ptr();
         Py_XINCREF(g_error_class);
     });
-    m.def("abi_version", []() { return nmf_version(); });
+    m.def("abi_version", []() { return (int)NMF_ABI_VERSION; });     // what THIS module was compiled against (hip.py compares)
     m.def("call_timing_begin", [](const std::string& only) {
         if (!g_call_timer) g_call_timer = new CallTimer();
         g_call_timer->next = 0;
@@ -848,8 +903,27 @@ PYBIND11_MODULE(_nmf_host, m) {
         delete t;
         return out;
     });
+    m.def("call_timing_timeline", []() {   // waits for the recorded work; -> [(name, stream, start_us, end_us, host_issue_us)], times
+        py::list out;                      // relative to the first recorded call (device clock / host clock)
+        if (!g_call_timer) return out;
+        CallTimer* t = g_call_timer;
+        g_call_timer = nullptr;
+        if (!t->recs.empty()) {
+            void* ref = t->recs[0].a;
+            const double h0 = t->recs[0].host_us;
+            for (auto& r : t->recs) {
+                float s_ms = 0.f, e_ms = 0.f;
+                check(nmf_event_synchronize(r.b), "nmf_event_synchronize");
+                check(nmf_event_elapsed_ms(ref, r.a, &s_ms), "nmf_event_elapsed_ms");
+                check(nmf_event_elapsed_ms(ref, r.b, &e_ms), "nmf_event_elapsed_ms");
+                out.append(py::make_tuple(std::string(r.name), reinterpret_cast<int64_t>(r.stream), 1e3 * s_ms, 1e3 * e_ms, r.host_us - h0));
+            }
+        }
+        delete t;
+        return out;
+    });
     m.def("march_count", &march_count);
-    m.def("march_scan", &march_scan);
+    m.def("march_scan", &march_scan, py::arg("counts"), py::arg("max_samples"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0);
     m.def("march_fill", &march_fill);
     m.def("vm_query_fwd", &vm_query_fwd);
     m.def("composite_fwd", &composite_fwd);
@@ -861,7 +935,7 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("heads_fwd", &heads_fwd);
     m.def("ggx_rays_fwd", &ggx_rays_fwd);
     m.def("shade_mix_fwd", &shade_mix_fwd);
-    m.def("bounce_index", &bounce_index);
+    m.def("bounce_index", &bounce_index, py::arg("counts"), py::arg("xyzt"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0);
     m.def("bounce_prep_fwd", &bounce_prep_fwd);
     m.def("ray_compose_fwd", &ray_compose_fwd);
     m.def("composite_bwd", &composite_bwd);
@@ -873,6 +947,8 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("shade_mix_bwd", &shade_mix_bwd);
     m.def("ray_compose_bwd", &ray_compose_bwd);
     m.def("vm_query_bwd_segments", &vm_query_bwd_segments);
+    m.def("vm_query_bwd_planned", &vm_query_bwd_planned);
+    m.def("vm_bin_plan", &vm_bin_plan, py::arg("p_addr"), py::arg("xyzts"), py::arg("stream"), py::arg("into") = py::none());
     m.def("vm_unpack_density_grad", &vm_unpack_density_grad);
     m.def("adam_step", &adam_step);
     m.def("multi_copy", &multi_copy);

@@ -676,7 +676,7 @@ __device__ __forceinline__ int64_t block_scan_incl(int64_t v, int64_t* ws, int t
 __global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __restrict__ counts, int64_t B, int64_t max_samples,
                                                            const int64_t* __restrict__ chunk_sum, int n_chunks,
                                                            int64_t* __restrict__ offsets, uint8_t* __restrict__ whole_valid,
-                                                           int64_t* __restrict__ totals) {
+                                                           int64_t* __restrict__ totals, int64_t* pub, int64_t pub_seq) {
     __shared__ int64_t ws[16];
     __shared__ int64_t s_base, s_cbase, s_direct[4];
     __shared__ int s_cstar;
@@ -742,9 +742,13 @@ __global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __rest
             totals[0] = M;
             totals[1] = (int64_t)cstar * SCAN_CHUNK + n_ok;
             offsets[B] = M;
+            publish_sizes(pub, M, (int64_t)cstar * SCAN_CHUNK + n_ok, pub_seq);
         }
     }
-    if (!budget && my == 0 && tid == 0) { totals[0] = total; totals[1] = B; offsets[B] = total; }
+    if (!budget && my == 0 && tid == 0) {
+        totals[0] = total; totals[1] = B; offsets[B] = total;
+        publish_sizes(pub, total, B, pub_seq);
+    }
     if (i < B) {
         whole_valid[i] = ok ? 1 : 0;
         offsets[i] = ok ? cum - v : M;
@@ -824,6 +828,14 @@ extern "C" int64_t nmf_march_scan_workspace_bytes(int64_t B) {
 extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
                               uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
                               void* stream) {
+    return nmf_march_scan_publish(counts, B, max_samples, offsets, whole_valid, totals, workspace, workspace_bytes, nullptr, 0,
+                                  stream);
+}
+
+extern "C" int nmf_march_scan_publish(const int32_t* counts, int64_t B, int64_t max_samples, int64_t* offsets,
+                                      uint8_t* whole_valid, int64_t* totals, void* workspace, int64_t workspace_bytes,
+                                      void* publish_mapped_dev, int64_t publish_seq, void* stream) {
+    int64_t* pub = static_cast<int64_t*>(publish_mapped_dev);
     NMF_REQUIRE(counts && offsets && whole_valid && totals && B > 0, NMF_EINVAL, "nmf_march_scan: null/empty");
     const int64_t n_chunks = cdiv(B, SCAN_CHUNK);
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_march_scan: B too large");
@@ -836,7 +848,7 @@ extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samp
     if (n_chunks <= 4096 && !three_pass) {
         if (n_chunks > 4) hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
         hipLaunchKernelGGL(k_scan_fused, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples,
-                           n_chunks > 4 ? chunk : nullptr, (int)n_chunks, offsets, whole_valid, totals);
+                           n_chunks > 4 ? chunk : nullptr, (int)n_chunks, offsets, whole_valid, totals, pub, publish_seq);
         NMF_CHECK_LAUNCH("nmf_march_scan");
         return NMF_OK;
     }
@@ -847,6 +859,7 @@ extern "C" int nmf_march_scan(const int32_t* counts, int64_t B, int64_t max_samp
                        meta, offsets, whole_valid, totals);
     hipLaunchKernelGGL(k_scan_clamp, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, st, offsets, B, meta, totals);
     NMF_CHECK_LAUNCH("nmf_march_scan");
+    if (pub) return nmf_publish_i64x2(totals, pub, publish_seq, stream);
     return NMF_OK;
 }
 

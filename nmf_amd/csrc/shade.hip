@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
                                                               int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
                                                               int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
                                                               int32_t* __restrict__ inv, const float4* __restrict__ xyzt,
-                                                              float4* __restrict__ xyzt_rows) {
+                                                              float4* __restrict__ xyzt_rows, int64_t* pub, int64_t pub_seq) {
     __shared__ int64_t ws[17];
     __shared__ int64_t base_s;
     const int tid = threadIdx.x;
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
         row_off[Mb] = R;
         totals[0] = R;
         totals[1] = Mb;
+        publish_sizes(pub, R, Mb, pub_seq);
     }
 }
 
@@ -412,13 +413,24 @@ extern "C" int64_t nmf_bounce_index_workspace_bytes(int64_t M) { return (cdiv(M 
 extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
                                 int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    return nmf_bounce_index_publish(counts, M, bidx, row_off, cnt_rows, inv, totals, xyzt, xyzt_rows, workspace, workspace_bytes,
+                                    nullptr, 0, stream);
+}
+
+extern "C" int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
+                                        int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
+                                        void* workspace, int64_t workspace_bytes, void* publish_mapped_dev,
+                                        int64_t publish_seq, void* stream) {
+    int64_t* pub = static_cast<int64_t*>(publish_mapped_dev);
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_index: M < 0");
     NMF_REQUIRE(totals && row_off, NMF_EINVAL, "nmf_bounce_index: null");
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
         hipError_t e = hipMemsetAsync(totals, 0, 16, st);
         if (e == hipSuccess) e = hipMemsetAsync(row_off, 0, 8, st);
-        return e == hipSuccess ? NMF_OK : nmf_fail((int)e, "nmf_bounce_index: memset");
+        if (e != hipSuccess) return nmf_fail((int)e, "nmf_bounce_index: memset");
+        if (pub) return nmf_publish_i64x2(totals, pub, publish_seq, stream);
+        return NMF_OK;
     }
     NMF_REQUIRE(counts && bidx && cnt_rows && inv && workspace, NMF_EINVAL, "nmf_bounce_index: null");
     NMF_REQUIRE(!xyzt_rows || xyzt, NMF_EINVAL, "nmf_bounce_index: xyzt_rows needs xyzt");
@@ -431,13 +443,14 @@ extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx,
     hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk);
     if (n_chunks <= IDX_CHUNK) {
         hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
-                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4);
+                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq);
     } else {
         hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
         hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
                            row_off, cnt_rows, inv, x4, r4);
     }
     NMF_CHECK_LAUNCH("nmf_bounce_index");
+    if (pub && n_chunks > IDX_CHUNK) return nmf_publish_i64x2(totals, pub, publish_seq, stream);
     return NMF_OK;
 }
 

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(256) k_vm_app_rows(nmf_vm_params p, const floa
 // A per-sample scatter with global atomics (768 density + 432 appearance adds per sample) runs at
 // ~14 G atomics/s on MI355X -- device-scope float atomics execute at the memory side -- i.e. ~90 ms
 // for the 1.1 M samples of a steady-state step.  Instead the samples are counting-sorted by the
-// BR^3-voxel brick of their lower corner (k_brick_hist / k_bins_partial+k_bins_final / k_brick_scatter);
+// BR^3-voxel brick of their lower corner (k_plan_hist / k_bins_partial+k_bins_final / k_plan_place, then k_brick_records);
 // a wave then owns a slice of one brick and accumulates every gradient that brick can touch -- three
 // TLxTL plane tiles (density: 48 ch, appearance: 24 ch) and three TL-entry line segments -- ON THE
 // MATRIX CORES (see k_vm_bwd_brick), flushing the non-zero entries once.  BR = 4 (TL = 5): a 25-cell
@@ -663,22 +663,45 @@ __device__ __forceinline__ int seg_of(const Segs& sg, int64_t m, int64_t& local)
     return k;
 }
 
-__global__ void __launch_bounds__(256) k_brick_hist(nmf_vm_params p, Segs sg, int64_t M,
-                                                    int nbx, int kc, int32_t* __restrict__ counts,
-                                                    int32_t* __restrict__ brick_id) {
+// ---- the sort as a PLAN (R4): it depends on the sample positions alone, which the forward knows ----------------------
+// The three walks of a training step used to redo histogram + scan + atomic scatter inside the backward (300 us of kernel
+// time per step, 80 of them in the serial tail of the step).  nmf_vm_bin_plan runs these once, as soon as the positions
+// exist (on a side stream under the forward), with ONE atomic pass: the counter add of the histogram already returns the
+// sample's rank inside its (brick, counter copy), so slot[m] = start(brick, copy) + rank once the scan has run -- no
+// second pass of cursor atomics.  What is left for the backward is k_brick_records: one permuted 16-byte store per sample.
+__global__ void __launch_bounds__(256) k_plan_hist(nmf_vm_params p, Segs sg, int64_t M, int nbx, int kc,
+                                                   int32_t* __restrict__ counts, int2* __restrict__ keyrank) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = m < M;
     int b = -1;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         int64_t l;
         const int k = seg_of(sg, m, l);
         float xn[3];
-        normalized(p, reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l], xn);
+        x = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
+        normalized(p, x, xn);
         b = brick_of(p, xn, nbx);
-        brick_id[m] = b;
     }
     const RunInfo r = wave_runs(b, active);
-    if (r.head) atomicAdd(counts + b * kc + bin_copy(kc), r.len);
+    const int key = b * kc + bin_copy(kc);
+    int base = 0;
+    if (r.head) base = atomicAdd(counts + key, r.len);
+    base = __shfl(base, lane_id() - r.off, 64);
+    if (active) keyrank[m] = make_int2(key, base + r.off);
+}
+
+__global__ void __launch_bounds__(256) k_plan_place(Segs sg, int64_t M, const int2* __restrict__ keyrank,
+                                                    const int32_t* __restrict__ cursor, int32_t* __restrict__ slot,
+                                                    float4* __restrict__ rec0) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int2 kr = keyrank[m];
+    const int pos = cursor[kr.x] + kr.y;
+    slot[m] = pos;
+    int64_t l;
+    const int k = seg_of(sg, m, l);
+    rec0[pos] = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
 }
 
 // Exclusive scan of the n brick counts -> offsets[n+1], the scatter cursors, and the work-item list of the backward walk:
@@ -779,29 +802,9 @@ __global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __rest
     }
 }
 
-// Scatter into brick order.  Besides the permutation, the per-sample inputs of the backward walk are written in
-// SORTED order so that the brick kernels stream them without an indirection: rec0 = xyzt, rec1 = (adjoint of the raw
-// density feature, adjoint of the raw density gradient in normalised-coordinate units).  The softplus / normalize
-// backward is evaluated here, once per sample, fully parallel.
-// APP = false: the density walk (no coefficient adjoints): a third of the registers, twice the waves to hide the cursor atomics
-template <bool APP>
-__global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, Segs sg,
-                                                       const int32_t* __restrict__ brick_id, int64_t M, int kc,
-                                                       int32_t* __restrict__ cursor, float4* __restrict__ rec0,
-                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted,
-                                                       const float* __restrict__ basis, float* __restrict__ dcoef) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = m < M;
-    const int b = active ? brick_id[m] : -1;
-    const RunInfo r = wave_runs(b, active);
-    int base = 0;
-    if (r.head) base = atomicAdd(cursor + b * kc + bin_copy(kc), r.len);
-    base = __shfl(base, lane_id() - r.off, 64);          // the run's head lane broadcasts its base
-    if (!active) return;
-    const int pos = base + r.off;
-    int64_t l;
-    const int k = seg_of(sg, m, l);
-    rec0[pos] = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
+// adjoint of the raw density feature and of the raw density gradient (normalised-coordinate units) of sample l of segment k:
+// the softplus / normalize backward, once per sample
+__device__ __forceinline__ float4 sample_adjoint(const nmf_vm_params& p, const Segs& sg, int k, int64_t l) {
     const float* d_sigma_feat = pick4(sg.d_sigma_feat, k);
     float dsf = d_sigma_feat ? d_sigma_feat[l] : 0.f;
     if (sg.d_sigma[0]) {
@@ -826,8 +829,22 @@ __global__ void __launch_bounds__(256) k_brick_scatter(nmf_vm_params p, Segs sg,
         dg1 = (-dn1 * inv + kk * g1) * p.inv_size[1];
         dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
     }
-    rec1[pos] = make_float4(dsf, dg0, dg1, dg2);
-    if constexpr (APP) {   // d_app row in brick order; its 72 coefficient adjoints follow in k_dcoef
+    return make_float4(dsf, dg0, dg1, dg2);
+}
+
+// The per-sample inputs of the backward walk, written in SORTED order so that the brick kernels stream them without an
+// indirection: rec1 = (adjoint of the raw density feature, adjoint of the raw density gradient); APP: the d_app row (its
+// 72 coefficient adjoints follow in k_dcoef).  slot[] and the sorted positions rec0 come from the plan.
+template <bool APP>
+__global__ void __launch_bounds__(256) k_brick_records(nmf_vm_params p, Segs sg, const int32_t* __restrict__ slot, int64_t M,
+                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int pos = slot[m];
+    int64_t l;
+    const int k = seg_of(sg, m, l);
+    rec1[pos] = sample_adjoint(p, sg, k, l);
+    if constexpr (APP) {
         float da[AD];
         load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
         float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);
@@ -988,7 +1005,7 @@ struct DGrp {
         const uint32_t a0 = __umul24((uint32_t)__float_as_int(L.z), (uint32_t)(DL * 4)) + j4;
         const uint32_t a1 = __umul24((uint32_t)__float_as_int(L.w), (uint32_t)(DL * 4)) + j4;
         u[0] = ld(lb, a0, 0); u[1] = ld(lb, a1, 0);
-        // the derivative line taps only meet dgw, which the value-only walk does not have (k_brick_scatter writes 0 for it)
+        // the derivative line taps only meet dgw, which the value-only walk does not have (k_brick_records writes 0 for it)
         if (WITH_NORMAL) { u[2] = ld(lb, a0, CD * 4); u[3] = ld(lb, a1, CD * 4); }
     }
 };
@@ -1459,41 +1476,136 @@ static int bin_copies(int64_t nb) {
     return nb <= 32768 ? 4 : 1;
 }
 
-extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
-    const int64_t nbx = (grid + BR - 1) / BR;
-    const int64_t nb = nbx * nbx * nbx;
-    const int64_t max_items = M / BWD_ITEM_MIN + nb + 1;
-    const int64_t kc = bin_copies(nb);
-    return (M + (2 * kc + 1) * (nb + 1) + 4 + 2 * max_items + 4) * (int64_t)sizeof(int32_t) +
-           ((nb + SB_CHUNK - 1) / SB_CHUNK + 1) * (int64_t)sizeof(int64_t) + 2 * M * (int64_t)sizeof(float4) +
-           M * (3 * CA + AD) * (int64_t)sizeof(float) + BASIS_COPIES * AD * 3 * CA * (int64_t)sizeof(float) + 64;
+// ---- layout of a plan (nmf_vm_bin_plan) and of the scratch of the walk itself ------------------------------------------
+namespace {
+struct PlanLayout {
+    int nbx, nb, kc, item_size, n_chunks;
+    int64_t max_items;
+    int2* keyrank;        // [M]   (brick * kc + counter copy, rank inside it)
+    int32_t* slot;        // [M]   position of sample m in brick order
+    int32_t* counts;      // [(nb+1)*kc]
+    int32_t* offsets;     // [nb+1]
+    int32_t* cursor;      // [(nb+1)*kc]  start of every (brick, copy)
+    int32_t* n_items;     // [2]
+    int64_t* chunk_tot;   // [n_chunks]
+    int2* items;          // [max_items]
+    float4* rec0;         // [M]   positions in brick order
+    int64_t bytes;
+};
+inline uintptr_t up16(uintptr_t q) { return (q + 15) & ~(uintptr_t)15; }
+PlanLayout plan_layout(void* base, int64_t M, int32_t grid) {
+    PlanLayout L;
+    L.nbx = (grid + BR - 1) / BR;
+    L.nb = L.nbx * L.nbx * L.nbx;
+    L.kc = bin_copies(L.nb);
+    int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
+    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
+    L.item_size = (item_size + 3) & ~3;
+    L.max_items = M / BWD_ITEM_MIN + L.nb + 1;
+    L.n_chunks = (L.nb + SB_CHUNK - 1) / SB_CHUNK;
+    uintptr_t q = up16((uintptr_t)base);
+    L.keyrank = (int2*)q;                q = up16(q + sizeof(int2) * M);
+    L.slot = (int32_t*)q;                q = up16(q + sizeof(int32_t) * M);
+    L.counts = (int32_t*)q;              q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc);
+    L.offsets = (int32_t*)q;             q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1));
+    L.cursor = (int32_t*)q;              q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc);
+    L.n_items = (int32_t*)q;             q = up16(q + sizeof(int32_t) * 2);
+    L.chunk_tot = (int64_t*)q;           q = up16(q + sizeof(int64_t) * (size_t)(L.n_chunks + 1));
+    L.items = (int2*)q;                  q = up16(q + sizeof(int2) * (size_t)L.max_items);
+    L.rec0 = (float4*)q;                 q = up16(q + sizeof(float4) * M);
+    L.bytes = (int64_t)(q - (uintptr_t)base) + 16;
+    return L;
+}
+struct WalkLayout {
+    float4* rec1;          // [M]
+    float* dcoef;          // [M][72]
+    float* d_app_sorted;   // [M][24]
+    float* basis_copies;   // [BASIS_COPIES][24][72]
+    int64_t bytes;
+};
+WalkLayout walk_layout(void* base, int64_t M) {
+    WalkLayout W;
+    uintptr_t q = up16((uintptr_t)base);
+    W.rec1 = (float4*)q;                 q = up16(q + sizeof(float4) * M);
+    W.dcoef = (float*)q;                 q = up16(q + sizeof(float) * M * 3 * CA);
+    W.d_app_sorted = (float*)q;          q = up16(q + sizeof(float) * M * AD);
+    W.basis_copies = (float*)q;          q = up16(q + sizeof(float) * BASIS_COPIES * AD * 3 * CA);
+    W.bytes = (int64_t)(q - (uintptr_t)base) + 16;
+    return W;
 }
 
-extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
-                                         const float* const dpk[3], const float* const dlk[3],
-                                         const float* const app_planes[3], const float* const app_lines[3],
-                                         const float* basis, float* const g_dpk[3], float* const g_dlk[3],
-                                         float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
-                                         void* workspace, int64_t workspace_bytes, void* stream) {
-    NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
-                "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
-    Segs sg;
+// host array of segments -> the kernels' view; returns the total sample count (or < 0 with the error set)
+int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg, int& n) {
     memset(&sg, 0, sizeof(sg));
     int64_t M = 0;
-    int n = 0;
+    n = 0;
     for (int i = 0; i < n_segs; ++i) {
         const nmf_vm_bwd_segment& q = segs[i];
-        NMF_REQUIRE(q.M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: M < 0");
+        if (q.M < 0 || (q.M > 0 && !q.xyzt)) return -1;
         if (q.M == 0) continue;
-        NMF_REQUIRE(q.xyzt, NMF_EINVAL, "nmf_vm_query_bwd: xyzt null");
         sg.xyzt[n] = q.xyzt; sg.sigma_feat[n] = q.sigma_feat; sg.grad[n] = q.grad; sg.d_sigma[n] = q.d_sigma;
         sg.d_sigma_feat[n] = q.d_sigma_feat; sg.d_normal[n] = q.d_normal; sg.d_app[n] = q.d_app;
         sg.start[n] = M;
         M += q.M;
         ++n;
     }
-    if (M == 0) return NMF_OK;
     for (int i = n; i <= MAX_SEG; ++i) sg.start[i] = M;      // unused segments start past the end
+    return M;
+}
+
+int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(L.counts, 0, sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc, st);
+    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
+    hipLaunchKernelGGL(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+    hipLaunchKernelGGL(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
+    hipLaunchKernelGGL(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
+                       L.cursor, L.item_size, L.items, L.n_items);
+    hipLaunchKernelGGL(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
+    NMF_CHECK_LAUNCH("nmf_vm_bin_plan");
+    return NMF_OK;
+}
+}  // namespace
+
+extern "C" int64_t nmf_vm_bin_plan_bytes(int64_t M, int32_t grid) {
+    return plan_layout(nullptr, M < 0 ? 0 : M, grid).bytes;
+}
+
+extern "C" int64_t nmf_vm_walk_workspace_bytes(int64_t M) { return walk_layout(nullptr, M < 0 ? 0 : M).bytes; }
+
+extern "C" int64_t nmf_vm_bwd_workspace_bytes(int64_t M, int32_t grid) {
+    return nmf_vm_bin_plan_bytes(M, grid) + nmf_vm_walk_workspace_bytes(M);
+}
+
+extern "C" int nmf_vm_bin_plan(const nmf_vm_params* p, const float* const* xyzt, const int64_t* Ms, int32_t n_segs,
+                               void* plan, int64_t plan_bytes, void* stream) {
+    NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && ((xyzt && Ms) || n_segs == 0), NMF_EINVAL,
+                "nmf_vm_bin_plan: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
+    nmf_vm_bwd_segment segs[MAX_SEG];
+    memset(segs, 0, sizeof(segs));
+    for (int i = 0; i < n_segs; ++i) { segs[i].xyzt = xyzt[i]; segs[i].M = Ms[i]; }
+    Segs sg;
+    int n;
+    const int64_t M = gather_segments(segs, n_segs, sg, n);
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_vm_bin_plan: M < 0 or xyzt null");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_bin_plan: M >= 2^31");
+    NMF_REQUIRE(plan && plan_bytes >= nmf_vm_bin_plan_bytes(M, p->grid), NMF_EINVAL,
+                "nmf_vm_bin_plan: plan buffer too small (see nmf_vm_bin_plan_bytes)");
+    return launch_plan(p, sg, M, plan_layout(plan, M, p->grid), (hipStream_t)stream);
+}
+
+static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs, const float* const dpk[3],
+                       const float* const dlk[3], const float* const app_planes[3], const float* const app_lines[3],
+                       const float* basis, float* const g_dpk[3], float* const g_dlk[3], float* const g_app_planes[3],
+                       float* const g_app_lines[3], float* g_basis, const void* plan, int64_t plan_bytes, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
+                "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
+    Segs sg;
+    int n;
+    const int64_t M = gather_segments(segs, n_segs, sg, n);
+    NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_vm_query_bwd: M < 0 or xyzt null");
+    if (M == 0) return NMF_OK;
     NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_bwd: M >= 2^31");
     for (int i = 1; i < n; ++i)                              // the kernels branch on segment 0's adjoint set
         NMF_REQUIRE(!sg.d_sigma[i] == !sg.d_sigma[0] && !sg.d_normal[i] == !sg.d_normal[0] && !sg.d_app[i] == !sg.d_app[0],
@@ -1511,62 +1623,51 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
                 "nmf_vm_query_bwd: density tables missing");
     NMF_REQUIRE(!want_a || (all3(app_planes) && all3(app_lines) && basis && all3m(g_app_planes) && all3m(g_app_lines)),
                 NMF_EINVAL, "nmf_vm_query_bwd: appearance tables missing");
-    NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
-                "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
     if (!want_d && !want_a) return NMF_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nbx = (p->grid + BR - 1) / BR;
-    const int nb = nbx * nbx * nbx;
-    int32_t* ws = (int32_t*)workspace;
-    int32_t* brick_id = ws;            // [M]
-    const int kc = bin_copies(nb);
-    auto align16 = [](int32_t* q) { return (int32_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15); };
-    int32_t* counts = align16(ws + M);            // [(nb+1)*kc]  copy k of brick b at b*kc + k (int4 per brick at kc = 4)
-    float* basis_copies = (float*)(counts + (nb + 1) * kc);      // [BASIS_COPIES][24][72], zeroed with the counters
-    int32_t* offsets = (int32_t*)(basis_copies + BASIS_COPIES * AD * 3 * CA);   // [nb+1]
-    int32_t* cursor = align16(offsets + nb + 1);  // [(nb+1)*kc]
-    int32_t* n_items = cursor + (nb + 1) * kc;    // [2] (8-byte aligned start of the item list follows)
-    int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
-    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
-    item_size = (item_size + 3) & ~3;
-    const int64_t max_items = M / item_size + nb + 1;
-    const int n_chunks_ws = (nb + SB_CHUNK - 1) / SB_CHUNK;
-    int64_t* chunk_tot = (int64_t*)(((uintptr_t)(n_items + 2) + 7) & ~(uintptr_t)7);   // [n_chunks] (samples | items) per 4096 bricks
-    int2* items = (int2*)(chunk_tot + n_chunks_ws);                            // [max_items]
+    PlanLayout L;
+    void* walk_ws = workspace;
+    int64_t walk_bytes = workspace_bytes;
+    if (plan) {          // the sort was done when the positions became known (nmf_vm_bin_plan over the same segment sizes)
+        NMF_REQUIRE(plan_bytes >= nmf_vm_bin_plan_bytes(M, p->grid), NMF_EINVAL, "nmf_vm_query_bwd_planned: plan buffer too small");
+        L = plan_layout(const_cast<void*>(plan), M, p->grid);
+    } else {             // sort here: the plan lives at the front of the workspace
+        NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
+                    "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
+        L = plan_layout(workspace, M, p->grid);
+        const int rc = launch_plan(p, sg, M, L, st);
+        if (rc != NMF_OK) return rc;
+        walk_ws = (char*)workspace + L.bytes;
+        walk_bytes = workspace_bytes - L.bytes;
+    }
+    NMF_REQUIRE(walk_ws && walk_bytes >= nmf_vm_walk_workspace_bytes(M), NMF_EINVAL,
+                "nmf_vm_query_bwd: workspace too small (see nmf_vm_walk_workspace_bytes)");
+    const WalkLayout W = walk_layout(walk_ws, M);
     const bool use_copies = want_a && g_basis;
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (nb + 1) * kc +
-                                  (use_copies ? sizeof(float) * BASIS_COPIES * AD * 3 * CA : 0), st);
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
-    hipLaunchKernelGGL(k_brick_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, nbx, kc, counts, brick_id);
-    const int n_chunks = (nb + SB_CHUNK - 1) / SB_CHUNK;
-    hipLaunchKernelGGL(k_bins_partial, dim3(n_chunks), dim3(SB_THREADS), 0, st, counts, nb, kc, item_size, chunk_tot);
-    hipLaunchKernelGGL(k_bins_final, dim3(n_chunks), dim3(SB_THREADS), 0, st, counts, nb, kc, chunk_tot, offsets, cursor,
-                       item_size, items, n_items);
-    // 16-byte aligned record arrays behind the integer scratch
-    uintptr_t rp = ((uintptr_t)(items + (M / BWD_ITEM_MIN + nb + 1)) + 15) & ~(uintptr_t)15;
-    float4* rec0 = (float4*)rp;
-    float4* rec1 = rec0 + M;
-    float* dcoef = (float*)(rec1 + M);              // [M][72]
-    float* d_app_sorted = dcoef + M * 3 * CA;       // [M][24]
+    if (use_copies) {
+        hipError_t e = hipMemsetAsync(W.basis_copies, 0, sizeof(float) * BASIS_COPIES * AD * 3 * CA, st);
+        if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
+    }
     if (want_a) {
-        hipLaunchKernelGGL(k_brick_scatter<true>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc,
-                           cursor, rec0, rec1, d_app_sorted, basis, dcoef);
-        hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, d_app_sorted, basis, M,
-                           dcoef);
+        hipLaunchKernelGGL(k_brick_records<true>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, L.slot, M, W.rec1,
+                           W.d_app_sorted);
+        hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, W.d_app_sorted, basis, M,
+                           W.dcoef);
     } else
-        hipLaunchKernelGGL(k_brick_scatter<false>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, brick_id, M, kc,
-                           cursor, rec0, rec1, d_app_sorted, basis, dcoef);
+        hipLaunchKernelGGL(k_brick_records<false>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, L.slot, M, W.rec1,
+                           W.d_app_sorted);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     int64_t gcap = 16384;
     if (const char* ev = getenv("NMF_BWD_GRID")) gcap = atoi(ev) > 0 ? atoi(ev) : gcap;   // tuning knob
+    const int64_t max_items = M / L.item_size + L.nb + 1;
     const int64_t grid_x = max_items < gcap ? max_items : gcap;       // single-wave workgroups per plane
     const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);
     const size_t lds_bytes = sizeof(float4) * 64 * (want_a ? 16 : 4);
-#define NMF_LAUNCH_BWD_KERNEL(KERNEL)                                                                                            \
-    hipLaunchKernelGGL(KERNEL, grid, block, lds_bytes, st, *p, rec0, rec1, offsets, items, n_items, item_size, nbx, \
-                       mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), dcoef, d_app_sorted, mkm(g_dpk), mkm(g_dlk),      \
-                       mkm(g_app_planes), mkm(g_app_lines), use_copies ? basis_copies : nullptr, z_density, z_app)
+#define NMF_LAUNCH_BWD_KERNEL(KERNEL)                                                                                         \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds_bytes, st, *p, L.rec0, W.rec1, L.offsets, L.items, L.n_items, L.item_size,    \
+                       L.nbx, mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), W.dcoef, W.d_app_sorted, mkm(g_dpk),           \
+                       mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), use_copies ? W.basis_copies : nullptr, z_density, z_app)
     if (want_d && want_a) {
         if (d_normal) NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<true, 2>));
         else NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 2>));
@@ -1577,9 +1678,31 @@ extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bw
         NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 1>));
 #undef NMF_LAUNCH_BWD_KERNEL
     if (use_copies)
-        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, basis_copies, g_basis);
+        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, W.basis_copies, g_basis);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
+}
+
+extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
+                                         const float* const dpk[3], const float* const dlk[3],
+                                         const float* const app_planes[3], const float* const app_lines[3],
+                                         const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                         float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    return vm_bwd_impl(p, segs, n_segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis,
+                       nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nmf_vm_query_bwd_planned(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
+                                        const float* const dpk[3], const float* const dlk[3],
+                                        const float* const app_planes[3], const float* const app_lines[3],
+                                        const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                        float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                        const void* plan, int64_t plan_bytes, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+    NMF_REQUIRE(plan, NMF_EINVAL, "nmf_vm_query_bwd_planned: plan null");
+    return vm_bwd_impl(p, segs, n_segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis,
+                       plan, plan_bytes, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nmf_vm_query_bwd(const nmf_vm_params* p, const float* xyzt, int64_t M, const float* const dpk[3],

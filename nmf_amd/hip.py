@@ -61,7 +61,7 @@ class CopySlot(C.Structure):
 
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_event_create", "nmf_event_create_timed", "nmf_event_elapsed_ms", "nmf_event_destroy", "nmf_event_record", "nmf_event_synchronize",
-    "nmf_stream_wait_event", "nmf_memcpy_d2h_async", "nmf_host_alloc_mapped", "nmf_host_free_mapped", "nmf_publish_i64x2", "nmf_wait_seq", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes",
+    "nmf_stream_wait_event", "nmf_memcpy_d2h_async", "nmf_host_alloc_mapped", "nmf_host_free_mapped", "nmf_publish_i64x2", "nmf_wait_seq", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes", "nmf_march_scan_publish", "nmf_bounce_index_publish",
     "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_sigma", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd", "nmf_sat_lookup_bwd_binned",
@@ -70,7 +70,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_brdf_mlp_bwd_workspace_bytes", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_sh_project",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -114,6 +114,8 @@ _declare_from_header()
 _lib.nmf_last_error_string.restype = C.c_char_p
 _lib.nmf_version.restype = C.c_int
 _lib.nmf_vm_bwd_workspace_bytes.restype = C.c_int64
+_lib.nmf_vm_bin_plan_bytes.restype = C.c_int64
+_lib.nmf_vm_walk_workspace_bytes.restype = C.c_int64
 _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 _lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
 _lib.nmf_argsort_workspace_bytes.restype = C.c_int64
@@ -436,10 +438,27 @@ class VmBwdSegment(C.Structure):
 VM_MAX_SEGMENTS = 4
 
 
+def vm_bin_plan(p, xyzts):
+    """The brick sort of a backward walk over the sample sets `xyzts` ([M_i,4] each), from the positions alone -> opaque plan
+    tensor for vm_query_bwd_segments(..., plan=) over the same sets in the same order (a training pass builds it under its
+    forward; the backward then only permutes the adjoints)."""
+    n = len(xyzts)
+    if n == 0 or n > VM_MAX_SEGMENTS:
+        raise NmfHipError(f"1..{VM_MAX_SEGMENTS} segments per plan")
+    ptrs = (C.c_void_p * n)(*[_p(x, torch.float32) for x in xyzts])
+    Ms = (C.c_int64 * n)(*[int(x.shape[0]) for x in xyzts])
+    M = sum(int(x.shape[0]) for x in xyzts)
+    nbytes = _lib.nmf_vm_bin_plan_bytes(C.c_int64(M), C.c_int32(p.grid))
+    plan = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=xyzts[0].device)
+    _check(_lib.nmf_vm_bin_plan(C.byref(p), ptrs, Ms, C.c_int32(n), _p(plan), C.c_int64(nbytes), _stream()), "nmf_vm_bin_plan")
+    return plan
+
+
 def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
-                          g_basis=None):
+                          g_basis=None, plan=None):
     """One backward walk over several sample sets (no concatenation).  segs: list of tuples
-    (xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app) -- the argument order of vm_query_bwd."""
+    (xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app) -- the argument order of vm_query_bwd.
+    plan: vm_bin_plan of the same sample sets (the sort is then not redone)."""
     n = len(segs)
     if n > VM_MAX_SEGMENTS:
         raise NmfHipError(f"at most {VM_MAX_SEGMENTS} segments per walk")
@@ -451,6 +470,19 @@ def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk
         want_d = want_d or ds is not None or dsf is not None or dn is not None
         want_a = want_a or da is not None
     if M == 0:
+        return
+    if plan is not None:
+        nbytes = _lib.nmf_vm_walk_workspace_bytes(C.c_int64(M))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=segs[0][0].device)
+        _check(_lib.nmf_vm_query_bwd_planned(C.byref(p), arr, C.c_int32(n),
+                                             _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
+                                             _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
+                                             _p(basis) if want_a else None,
+                                             _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
+                                             _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
+                                             _p(g_basis if want_a else None), _p(plan), C.c_int64(plan.numel() * 4), _p(ws),
+                                             C.c_int64(nbytes), _stream()),
+               "nmf_vm_query_bwd_planned")
         return
     nbytes = _lib.nmf_vm_bwd_workspace_bytes(C.c_int64(M), C.c_int32(p.grid))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=segs[0][0].device)
@@ -1193,7 +1225,10 @@ def _install_host_ext():
                                   bool(noclip), rgb_lin, d_rgb_map, d_acc, d_ori, bool(want_d_normals), _stream())
 
     def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
-                              g_basis=None):
+                              g_basis=None, plan=None):
+        if plan is not None:
+            return fx.vm_query_bwd_planned(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
+                                           g_app_lines, g_basis, plan, _stream())
         return fx.vm_query_bwd_segments(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
                                         g_app_lines, g_basis, _stream())
 

@@ -60,10 +60,36 @@ def _set(cfg, dotted, value):
     node[keys[-1]] = value
 
 
+def _reader(config_dir):
+    """relative path without extension -> dict: a configs/ directory, or (config_dir None) the built-in tree of
+    nmf_amd/config.py -- the same files as values, so the package composes without the reference checkout"""
+    if config_dir is not None:
+        def read(rel):
+            path = os.path.join(config_dir, rel + ".yaml")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"no config file {path}")
+            node = _load(path)
+            if not isinstance(node, dict):
+                raise ValueError(f"{path}: a config file must hold a mapping")
+            return node
+        return read
+    from .config import builtin_tree
+    tree = builtin_tree()
+
+    def read(rel):
+        if rel not in tree:
+            have = sorted(k.split("/", 1)[1] for k in tree if k.startswith(rel.split("/")[0] + "/"))
+            raise FileNotFoundError(f"{rel} is not part of the built-in config tree (have: {have}); pass --config-dir "
+                                    "to compose from a configs/ directory")
+        return copy.deepcopy(tree[rel])
+    return read
+
+
 def compose(config_dir, overrides=(), config_name="default"):
     """-> resolved config dict (one run).  overrides: ["model=microfacet_tensorf2", "dataset=lego", "expname=x",
-    "model.arch.model.anoise=0.1", ...]."""
-    base = _load(os.path.join(config_dir, config_name + ".yaml"))
+    "model.arch.model.anoise=0.1", ...].  config_dir None: the built-in tree."""
+    read = _reader(config_dir)
+    base = read(config_name)
     defaults = base.pop("defaults", ["_self_"])
     groups = [next(iter(d)) for d in defaults if isinstance(d, dict)]
     choice, dotted = {}, []
@@ -83,8 +109,7 @@ def compose(config_dir, overrides=(), config_name="default"):
             name = choice.get(group, name)
             if name in (None, "null"):
                 continue
-            cfg[group] = _merge(cfg.get(group, {}) if isinstance(cfg.get(group), dict) else {},
-                                _load(os.path.join(config_dir, group, f"{name}.yaml")))
+            cfg[group] = _merge(cfg.get(group, {}) if isinstance(cfg.get(group), dict) else {}, read(f"{group}/{name}"))
     if "_self_" not in defaults:
         _merge(cfg, base)
     for key, val in dotted:

@@ -1522,6 +1522,65 @@ def test_vm_backward_segments_equal_concatenation(with_app):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("with_app", [False, True])
+@pytest.mark.parametrize("grid", [32, 57])
+def test_vm_backward_with_a_plan_of_the_forward_equals_the_self_sorting_walk(with_app, grid):
+    """nmf_vm_bin_plan (the brick sort, from the positions alone) + nmf_vm_query_bwd_planned accumulate what
+    nmf_vm_query_bwd_segments does when it sorts by itself (autograd of fields/tensoRF.py:181-205); the plan is reusable
+    (two walks with different adjoints over one plan), through the Python wrappers and the host extension."""
+    from nmf_amd import hip, synthetic
+    G = grid
+    cfg = O.Cfg(grid=G)
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=8, seed=3)
+    p, dpk, dlk, apl, ali, basis = _field_tables(hip, sd, cfg)
+    g = torch.Generator().manual_seed(5)
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)  # noqa: E731
+    sizes = [2500, 0, 129, 7000]
+    xyzs = []
+    for n in sizes:
+        # clustered like ray samples (runs of equal bricks inside a wave) plus points outside the box
+        c = (torch.rand(n // 50 + 1, 3, generator=g) * 2 - 1) * 1.4
+        x = c.repeat_interleave(50, 0)[:n] + 0.02 * torch.randn(n, 3, generator=g)
+        if n:
+            x[::97] *= 1.2
+        xyzs.append(torch.cat([x, torch.zeros(n, 1)], 1).to(DEV).contiguous())
+
+    def make_segs(seed):
+        gg = torch.Generator().manual_seed(seed)
+        segs = []
+        for xyz in xyzs:
+            n = xyz.shape[0]
+            if with_app:
+                segs.append((xyz, None, None, None, None, None, torch.randn(n, 24, generator=gg).to(DEV)))
+            else:
+                sf, sg, gr, nr, ap, cf = (hip.vm_query_fwd(p, xyz, dpk, dlk, apl, ali, basis) if n
+                                          else (z(0), z(0), z(0, 3), z(0, 3), z(0, 24), None))
+                segs.append((xyz, sf, gr, torch.randn(n, generator=gg).to(DEV), None, torch.randn(n, 3, generator=gg).to(DEV), None))
+        return segs
+
+    def bufs():
+        return ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)], [z(G, G, 24) for _ in range(3)],
+                [z(G, 24) for _ in range(3)], z(24, 72))
+
+    flat = lambda t: torch.cat([x.reshape(-1) for x in (t[0] + t[1] + t[2] + t[3] + [t[4]])]).cpu()  # noqa: E731
+    plan = hip.vm_bin_plan(p, xyzs)
+    for impl in ([hip.vm_query_bwd_segments] + ([hip.PY_WRAPPERS["vm_query_bwd_segments"]] if hip.HOST_EXT is not None else [])):
+        for seed in (1, 2):
+            segs = make_segs(seed)
+            a, b = bufs(), bufs()
+            impl(p, segs, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], a[4] if with_app else None)
+            impl(p, segs, dpk, dlk, apl, ali, basis, b[0], b[1], b[2], b[3], b[4] if with_app else None, plan=plan)
+            fa, fb = flat(a), flat(b)
+            assert fa.abs().max() > 0
+            assert_close(fb, fa, rtol=2e-5, atol=2e-5 * float(fa.abs().max()), what="planned walk vs self-sorting walk")
+    with pytest.raises(hip.NmfHipError):                       # a plan of fewer samples than the walk is refused
+        small = hip.vm_bin_plan(p, [xyzs[2]])
+        segs = make_segs(1)
+        a = bufs()
+        hip.vm_query_bwd_segments(p, segs, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], a[4] if with_app else None, plan=small)
+
+
+@pytest.mark.gpu
 def test_host_extension_matches_python_wrappers():
     """lib/_nmf_host.so (csrc/host_ext.cpp) replaces the forward wrappers of hip.py with C++ ones over the same C ABI:
     same outputs bit for bit, same error type."""

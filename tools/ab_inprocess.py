@@ -8,6 +8,7 @@ thermal drift and box-to-box differences (4 % between `python bench.py` runs on 
     obj:ATTR             TrainPass attribute, as bool        (obj:overlap 0,1   obj:sparse_normals 0,1)
     attr:NAME            nmf_amd.fast_step module constant   (attr:MLP_SIDE_WGS 64,128,256)
     hip:NAME             nmf_amd.hip module constant         (hip:ENV_BINNED_MIN_LOOKUPS 16384,4611686018427387904)
+    prio                 0,1: the training pass on torch's default stream / on a high-priority stream (side streams stay normal)
     delay:METHOD         busy-wait of <value> us on the host in front of TrainPass.METHOD (delay:_flush_walks 0,100) or,
                          with delay:hip.FUNC, in front of a wrapper of nmf_amd.hip (delay:hip.march_fill 0,50): shows whether
                          the host or the device bounds that stretch of the step
@@ -60,7 +61,10 @@ def main():
         install_delay(var[6:])
 
     def set_variant(v):
-        if var.startswith("delay:"):
+        if var == "prio":                      # prio 0,1: torch's default stream / a high-priority stream as the pass's main stream
+            torch.cuda.synchronize()
+            use_hi[0] = bool(int(v))
+        elif var.startswith("delay:"):
             delay_us[0] = float(v)
         elif var.startswith("obj:"):
             setattr(tr.fast, var[4:], bool(int(v)))
@@ -71,7 +75,16 @@ def main():
         else:
             os.environ[var] = v
 
+    hi_stream = torch.cuda.Stream(priority=-1)
+    use_hi = [os.environ.get("NMF_MAIN_PRIO") == "1"]     # the pass's main stream at high priority, its side streams stay normal
+
     def run(n):
+        hi = hi_stream if use_hi[0] else None
+        if hi is not None:
+            with torch.cuda.stream(hi):
+                for i in range(n):
+                    tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
+            return
         for i in range(n):
             tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
 
