@@ -2,9 +2,18 @@
 synthetic "S2 orbit" data set (nerf_synthetic is not available offline): ground-truth images are
 rendered from the S1 scene itself (eval mode), then a freshly initialised model is fitted to them.
 
+    python -m nmf_amd.train model=microfacet_tensorf2 field=tensorf_og dataset=lego datadir=/data expname=lego [a.b.c=value ...]
     python -m nmf_amd.train --iters 200 --views 24 --res 64 [--grid 64] [--eval-every 100]
     python -m nmf_amd.train --datadir /data/nerf_synthetic/lego --near-far 2.5 7 --iters 30000 --grid 128 --bg 512
     python -m torch.distributed.run --nproc-per-node N -m nmf_amd.train ...        (data parallel, RCCL)
+
+The first form is the reference's hydra command line (train.py:904-921): `group=name` choices and dotted overrides are composed by
+nmf_amd/yaml_config.py -- from the built-in tree of nmf_amd/config.py (the values of configs/default.yaml, model/
+microfacet_tensorf2.yaml, field/tensorf_og.yaml, dataset/<scene>.yaml) or, with --config-dir, from a configs/ directory such as
+the reference's --, the model is built by `instantiate_arch` from the composed `model.arch` (`_target_` / `_partial_`,
+train.py:239-247), the trainer reads `model.params`, and the resolved config is written to <basedir>/<expname>/config.yaml
+(train.py:485).  The flags of the other forms are shorthands for overrides of the same tree (--grid = field.grid_size, --bg =
+model.arch.bg_module.bg_resolution, ...); dataset=s2_orbit (the default without a data directory) is the offline stand-in.
 
 With --datadir the rays and colours come from a Blender / nerf_synthetic scene directory (nmf_amd/dataLoader/blender.py,
 RGBA frames blended onto the white background as train.py:525-530 does); --save writes a checkpoint readable by
@@ -21,7 +30,7 @@ import time
 import torch
 
 from . import synthetic
-from .config import build_model, resolved_config
+from . import yaml_config
 from .noise import DeviceNoise
 from .renderer import psnr_8bit, render_images as _render_images
 from .trainer import Trainer, agree, rank_slice
@@ -32,16 +41,47 @@ def render_images(nerf, rays, focal, chunk, noise):
     return _render_images(nerf, rays, focal, chunk, noise, draw_debug=True)
 
 
+def compose_run(args, overrides):
+    """argparse flags + hydra-style tokens -> the resolved config of the run (flags are shorthands for overrides)"""
+    ov = []
+    if args.datadir:
+        # a scene directory given directly: the dataset entry points at it (the reference splits it into datadir / scenedir)
+        ov += ["dataset=lego", f"datadir={os.path.dirname(os.path.abspath(args.datadir)) or '/'}",
+               f"dataset.scenedir={os.path.basename(os.path.abspath(args.datadir))}"]
+        if args.near_far:
+            ov.append(f"dataset.near_far=[{args.near_far[0]},{args.near_far[1]}]")
+        if args.downsample != 1.0:
+            ov += [f"dataset.downsample_train={args.downsample}", f"dataset.downsample_test={args.downsample}"]
+    elif not any(o.split("=")[0] in ("dataset", "datadir") for o in overrides):
+        ov += ["dataset=s2_orbit"]
+    if args.grid is not None:
+        ov.append(f"field.grid_size=[{args.grid},{args.grid},{args.grid}]")
+    if args.bg is not None:
+        ov.append(f"model.arch.bg_module.bg_resolution={args.bg}")
+    if args.seed is not None:
+        ov.append(f"seed={args.seed}")
+    if args.views is not None:
+        ov.append(f"dataset.views={args.views}")
+    if args.test_views is not None:
+        ov.append(f"N_vis={args.test_views}")
+    if args.res is not None:
+        ov.append(f"dataset.res={args.res}")
+    return yaml_config.compose(args.config_dir, ov + list(overrides))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--views", type=int, default=24)
-    ap.add_argument("--test-views", type=int, default=4)
-    ap.add_argument("--res", type=int, default=64)
-    ap.add_argument("--grid", type=int, default=64)
-    ap.add_argument("--bg", type=int, default=128)
-    ap.add_argument("--eval-every", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=20211200)
+    ap.add_argument("--config-dir", type=str, default=None,
+                    help="configs/ directory to compose from (e.g. the reference's); default: the built-in tree (nmf_amd/config.py)")
+    ap.add_argument("--iters", type=int, default=None,
+                    help="optimizer steps of this run (default: model.params.n_iters; 200 when only flags are given)")
+    ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--test-views", type=int, default=None)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--grid", type=int, default=None)
+    ap.add_argument("--bg", type=int, default=None)
+    ap.add_argument("--eval-every", type=int, default=None, help="default: vis_every of the config")
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--datadir", type=str, default=None, help="Blender scene directory (transforms_*.json + frames)")
     ap.add_argument("--near-far", type=float, nargs=2, default=None)
     ap.add_argument("--downsample", type=float, default=1.0)
@@ -51,7 +91,26 @@ def main(argv=None):
     ap.add_argument("--rays-per-gpu", type=int, default=None,
                     help="weak scaling: every rank takes this many rays per optimizer step (BASELINE configs[3]: 32768), "
                          "processed in num_rays chunks; default: the reference's lbatch_size split over the ranks")
+    ap.add_argument("--no-config-file", action="store_true", help="do not write <basedir>/<expname>/config.yaml")
+    ap.add_argument("overrides", nargs="*", help="hydra-style tokens: group=name, a.b.c=value")
     args = ap.parse_args(argv)
+    for o in args.overrides:
+        if "=" not in o:
+            ap.error(f"'{o}': overrides are key=value tokens (hydra syntax)")
+    cfg = compose_run(args, args.overrides)
+    shorthand = not args.overrides and args.config_dir is None       # the flag forms: synthetic defaults as before
+    if shorthand and not args.datadir:
+        if args.grid is None:
+            cfg["field"]["grid_size"] = cfg["model"]["arch"]["rf"]["grid_size"] = [64, 64, 64]
+        if args.bg is None:
+            cfg["model"]["arch"]["bg_module"]["bg_resolution"] = 128
+    ds = cfg["dataset"]
+    params = cfg["model"]["params"]
+    n_iters = args.iters if args.iters is not None else (200 if shorthand else int(params["n_iters"]))
+    eval_every = args.eval_every if args.eval_every is not None else (100 if shorthand else int(cfg["vis_every"]))
+    seed = int(cfg["seed"])
+    grid = int(cfg["field"]["grid_size"][0])
+    bg_res = int(cfg["model"]["arch"]["bg_module"]["bg_resolution"])
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,41 +121,58 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group(backend=os.environ.get("NMF_BACKEND", "nccl"))
 
-    near_far = (2.5, 7.0)
-    if args.datadir:
+    logfolder = os.path.join(str(cfg["basedir"]), str(cfg["expname"]))
+    if rank == 0 and not args.no_config_file and not shorthand:
+        os.makedirs(logfolder, exist_ok=True)
+        yaml_config.dump(cfg, os.path.join(logfolder, "config.yaml"))                     # train.py:485
+
+    near_far = tuple(ds["near_far"])
+    aabb_half = 1.5
+    if ds["dataset_name"] == "blender":
         # ---- real data: Blender scene (dataLoader/blender.py), colours blended onto white (train.py:525-530)
         from .dataLoader import BlenderDataset
-        tr_set = BlenderDataset(args.datadir, split="train", downsample=args.downsample, is_stack=False)
-        te_set = BlenderDataset(args.datadir, split="test", downsample=args.downsample, is_stack=True, N_vis=args.test_views)
-        near_far = tuple(args.near_far) if args.near_far else tuple(tr_set.near_far)
+        scene = os.path.join(str(cfg["datadir"]), str(ds["scenedir"]))
+        n_vis = int(cfg["N_vis"])
+        tr_set = BlenderDataset(scene, split="train", downsample=float(ds["downsample_train"]), is_stack=False)
+        te_set = BlenderDataset(scene, split="test", downsample=float(ds["downsample_test"]), is_stack=True, N_vis=n_vis)
+        if args.datadir and not args.near_far and not any(o.startswith("dataset.near_far") for o in args.overrides):
+            near_far = tuple(tr_set.near_far)
         rays_tr, rgba = tr_set.all_rays.to(dev), tr_set.all_rgbs.to(dev)
         rgb_tr = rgba[:, :3] * rgba[:, 3:] + (1 - rgba[:, 3:]) if rgba.shape[1] == 4 else rgba
         rays_te = te_set.all_rays.reshape(-1, 6).to(dev)
         rgb_te = te_set.all_rgbs.reshape(-1, 3).to(dev)
         focal = float(tr_set.fx)
-        args.test_views = te_set.all_rays.shape[0]
-    else:
+        test_views = te_set.all_rays.shape[0]
+        aabb = tr_set.scene_bbox.float() * float(ds.get("aabb_scale", 1))                # train.py:234-237
+    elif ds["dataset_name"] == "synthetic_orbit":
         # ---- ground truth from the S1 scene
-        torch.manual_seed(args.seed)
-        teacher, _ = build_model(grid=args.grid, bg_resolution=args.bg, device=dev)
-        teacher.load_state_dict(synthetic.state_dict_s1(grid=args.grid, bg_resolution=args.bg, seed=0), strict=False)
+        torch.manual_seed(seed)
+        aabb = torch.tensor([[-aabb_half] * 3, [aabb_half] * 3])
+        teacher = yaml_config.instantiate_arch(cfg, aabb, near_far).to(dev)
+        teacher.sampler.update(teacher.rf, init=True)
+        teacher.load_state_dict(synthetic.state_dict_s1(grid=grid, bg_resolution=bg_res, seed=0), strict=False)
         teacher.eval()
         teacher.sampler.update(teacher.rf, init=False)
         teacher.sampler.update(teacher.rf, init=True)
-        rays_tr, focal = synthetic.orbit_rays(args.views, args.res, seed=1)
-        rays_te, _ = synthetic.orbit_rays(args.test_views, args.res, seed=2)
+        test_views = int(ds.get("test_views", 4)) if args.test_views is None else args.test_views
+        rays_tr, focal = synthetic.orbit_rays(int(ds.get("views", 24)), int(ds.get("res", 64)), seed=1)
+        rays_te, _ = synthetic.orbit_rays(test_views, int(ds.get("res", 64)), seed=2)
         rays_tr, rays_te = rays_tr.to(dev), rays_te.to(dev)
         gt_noise = DeviceNoise(dev, seed=7)
         rgb_tr = render_images(teacher, rays_tr, focal, 4096, gt_noise)
         rgb_te = render_images(teacher, rays_te, focal, 4096, gt_noise)
         del teacher
+    else:
+        raise NotImplementedError(f"dataset_name {ds['dataset_name']}: this package reads Blender scene directories "
+                                  "(dataLoader/blender.py) and the synthetic orbit")
 
-    # ---- student: fresh initialisation, calibration (train.py:429-437)
-    torch.manual_seed(args.seed)                  # identical replicas on every rank
-    nerf, cfg = build_model(grid=args.grid, bg_resolution=args.bg, near_far=near_far, device=dev)
+    # ---- student: train.py:239-247 `hydra.utils.instantiate(cfg.model.arch)(aabb=, near_far=)`, fresh initialisation
+    # (SURVEY Appendix E), calibration (train.py:429-437)
+    torch.manual_seed(seed)                  # identical replicas on every rank
+    nerf = yaml_config.instantiate_arch(cfg, aabb, near_far).to(dev)
+    nerf.sampler.update(nerf.rf, init=True)
     nerf.train()
     nerf.rf.set_table_dtype(args.table_dtype)
-    params = resolved_config()["params"]
     with torch.no_grad():
         xyz = torch.rand(100000, 4, device=dev) * 2 - 1
         xyz[:, 3] *= 0
@@ -104,11 +180,11 @@ def main(argv=None):
         nerf.model.calibrate(None, xyz, feat, nerf.bg_module.mean_color().mean())
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
     noise = DeviceNoise(dev, seed=1000 + rank)
-    g = torch.Generator(device=dev).manual_seed(args.seed)        # same permutation on every rank
+    g = torch.Generator(device=dev).manual_seed(seed)        # same permutation on every rank
     n_total = rays_tr.shape[0]
     perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
     t0, rays_seen = time.time(), 0
-    for it in range(args.iters):
+    for it in range(n_iters):
         # The global batch must be the same number on every rank (it sizes the shards, advances the shared permutation and
         # normalises the loss, train.py:504-507,703) while each rank's ray controller follows its own chunks: agree on it.
         nb = world * args.rays_per_gpu if args.rays_per_gpu else agree(trainer.lbatch_size(), "min", device=dev)
@@ -118,23 +194,28 @@ def main(argv=None):
         cur += nb
         out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
         rays_seen += out["rays"] * world
-        if (it + 1) % args.eval_every == 0 or it + 1 == args.iters:
+        if (it + 1) % eval_every == 0 or it + 1 == n_iters:
             nerf.eval()
             pred = render_images(nerf, rays_te, focal, 4096, noise)
             nerf.train()
-            pv, gv = pred.reshape(args.test_views, -1, 3), rgb_te.reshape(args.test_views, -1, 3)
-            psnr = float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(args.test_views)]).mean())   # renderer.py:511-513
+            pv, gv = pred.reshape(test_views, -1, 3), rgb_te.reshape(test_views, -1, 3)
+            psnr = float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(test_views)]).mean())   # renderer.py:511-513
             if rank == 0:
                 print(json.dumps(dict(iteration=it + 1, train_psnr=round(out["psnr"], 3), test_psnr=round(psnr, 3),
                                       rays_per_s=round(rays_seen / (time.time() - t0), 1), num_rays=trainer.num_rays,
                                       retrace=nerf.model.max_retrace_rays, n_samples=out["n_samples"])), flush=True)
-    if args.save and rank == 0:
-        cfg["arch"]["model"]["brdf"]["bias"] = nerf.model.brdf.bias                        # calibrated values
-        cfg["arch"]["model"]["diffuse_module"]["diffuse_bias"] = nerf.model.diffuse_module.diffuse_bias
-        cfg["arch"]["model"]["diffuse_module"]["roughness_bias"] = nerf.model.diffuse_module.roughness_bias
-        nerf.save(args.save, cfg["arch"])
+    save = args.save
+    if save is None and not shorthand and not args.no_config_file:
+        save = os.path.join(logfolder, f"{cfg['expname']}.th")                              # train.py:856 (tensorf.save)
+    if save and rank == 0:
+        arch = cfg["model"]["arch"]
+        arch["model"]["brdf"]["bias"] = nerf.model.brdf.bias                        # calibrated values (train.py:429-437)
+        arch["model"]["diffuse_module"]["diffuse_bias"] = nerf.model.diffuse_module.diffuse_bias
+        arch["model"]["diffuse_module"]["roughness_bias"] = nerf.model.diffuse_module.roughness_bias
+        nerf.save(save, arch)
     if world > 1:
         dist.destroy_process_group()
+    return cfg
 
 
 if __name__ == "__main__":

@@ -31,6 +31,14 @@ def _one(like):
     return _ones((), like.device)
 
 
+def _zero_scalar(device):
+    key = ("zero", device)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.zeros((), dtype=torch.float32, device=device)
+    return t
+
+
 from .controllers import RayBatchController, learning_rate_decay  # noqa: E402,F401
 
 
@@ -79,76 +87,143 @@ class FlatGradAllReduce:
     300^3), summed over ranks (RCCL over xGMI when backend='nccl', gloo on CPU) and unpacked.  A single bucket:
     at 7 x ~153 GB/s per GPU the ring time (<1 ms) is far below the step time, so overlap buys nothing here.
 
-    The buffer layout is FIXED: every parameter of the list owns its slot whether or not this rank produced a gradient
-    for it in this step (a rank whose chunk spawned no bounce rows, or whose chunks were all empty, still has to enter
-    the collective with the same element count as its peers).  Missing gradients travel as zeros and are materialised
-    on unpack, so every replica hands the same set of gradients to its optimizer."""
+    The buffer layout is FIXED: [gradients | one has-gradient flag per parameter | the step's guard value].  Every parameter
+    owns its slot whether or not this rank produced a gradient for it in this step (a rank whose chunk spawned no bounce
+    rows, or whose chunks were all empty, still has to enter the collective with the same element count as its peers); a
+    missing gradient travels as zeros.  After the sum, a parameter NO rank produced a gradient for keeps `grad = None` --
+    as in a single-process step, where Adam then leaves its moments and step count alone (materialising zeros instead would
+    move it on momentum at world > 1 and not at world = 1: two different trajectories).  The flags are only read back (one
+    host synchronisation) by a rank that itself lacks a gradient; in the steady state every rank has them all.
+
+    `guard`: 0-d device value that gates the optimizer step (the step's summed loss, train.py:704-705).  Its SUM over the
+    ranks comes back, so every replica takes the same decision (a NaN on one rank is a NaN everywhere); None = 0."""
 
     def __init__(self, params):
         self.params = [p for p in params]
         self.numel = sum(p.numel() for p in self.params)
         self.buf = None
         self._slots = None
+        self._consts = None
         self.last_comm_ms = None          # (start, end) device events of the last collective, or host seconds on CPU
+        self.mask_reads = 0               # how often the has-gradient flags had to be read back (tests)
         # NMF_ALLREDUCE_SINGLE_RANK=1: enter the collective even when the group has ONE rank (a sum over one rank is the
         # identity): exercises RCCL, the pack / unpack launches and their ordering against the training pass's side streams
         # on a 1-GPU box, and gives a first comm_ms_per_step (bench.py with NMF_BENCH_BACKEND=nccl)
         self.single_rank = os.environ.get("NMF_ALLREDUCE_SINGLE_RANK") == "1"
 
-    def __call__(self, group=None):
-        if not (dist.is_available() and dist.is_initialized()):
-            return 0
-        if dist.get_world_size(group) == 1 and not self.single_rank:
+    def active(self, group=None):
+        return (dist.is_available() and dist.is_initialized() and self.numel > 0
+                and (dist.get_world_size(group) > 1 or self.single_rank))
+
+    def __call__(self, group=None, guard=None):
+        """-> bytes of gradient exchanged (0: no collective).  With `guard`, self.guard is its sum over the ranks (a 0-d view
+        of the buffer) after the call."""
+        self.guard = guard
+        if not self.active(group):
             return 0
         ps, n = self.params, self.numel
-        if n == 0:
-            return 0
         dev = ps[0].device
-        if self.buf is None or self.buf.device != dev:
-            self.buf = torch.empty(n, dtype=torch.float32, device=dev)
-        for p in ps:                              # zero gradient for what this rank did not touch (same memory order as p)
-            if p.grad is None:
-                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+        total = n + len(ps) + 1
+        if self.buf is None or self.buf.device != dev or self.buf.numel() != total:
+            self.buf = torch.empty(total, dtype=torch.float32, device=dev)
+        have = [p.grad is not None for p in ps]
         if self.buf.is_cuda:
-            return self._reduce_device(ps, n, group)
-        off = 0                                   # host tensors (gloo tests of the sharding logic): plain torch copies
-        for p in ps:
-            self.buf[off:off + p.numel()].copy_(p.grad.reshape(-1).float())
-            off += p.numel()
-        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p in ps:
-            p.grad.copy_(self.buf[off:off + p.numel()].reshape(p.grad.shape).to(p.grad.dtype))
-            off += p.numel()
+            self._pack_device(ps, n, have, guard)
+            ev = self._events = getattr(self, "_events", None) or (torch.cuda.Event(enable_timing=True),
+                                                                   torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+            ev[1].record()
+            self.last_comm_ms = ev
+        else:                                     # host tensors (gloo tests of the sharding logic): plain torch copies
+            off = 0
+            for p, h in zip(ps, have):
+                if h:
+                    self.buf[off:off + p.numel()].copy_(p.grad.reshape(-1).float())
+                else:
+                    self.buf[off:off + p.numel()].zero_()
+                off += p.numel()
+            self.buf[n:n + len(ps)] = torch.tensor([1.0 if h else 0.0 for h in have])
+            self.buf[total - 1] = 0.0 if guard is None else float(guard)
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        # parameters without a local gradient: did any rank produce one?
+        anyone = have
+        if not all(have):
+            self.mask_reads += 1
+            flags = self.buf[n:n + len(ps)].tolist()          # (device: waits for the collective)
+            anyone = [f > 0.0 for f in flags]
+        if self.buf.is_cuda:
+            self._unpack_device(ps, n, have, anyone)
+        else:
+            off = 0
+            for p, h, a in zip(ps, have, anyone):
+                if a:
+                    if not h:
+                        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    p.grad.copy_(self.buf[off:off + p.numel()].reshape(p.grad.shape).to(p.grad.dtype))
+                off += p.numel()
+        if guard is not None:
+            self.guard = self.buf[total - 1]
         return n * 4
 
-    def _reduce_device(self, ps, n, group):
-        """pack (one launch: nmf_multi_copy over all gradients, in each tensor's own memory order) -> RCCL all-reduce
-        -> unpack (one launch)"""
+    def _pack_device(self, ps, n, have, guard):
+        """one launch: nmf_multi_copy over all gradients (each in its own memory order), the flags and the guard"""
         from . import hip
         from .optim import _dense
-        if self._slots is None or len(self._slots[0]) < len(ps):
-            self._slots = ((hip.CopySlot * len(ps))(), (hip.CopySlot * len(ps))())
-        pack, unpack = self._slots
-        base, off = self.buf.data_ptr(), 0
-        for i, p in enumerate(ps):
-            g = p.grad
-            if not _dense(g) or g.dtype not in (torch.float32, torch.float64):
-                raise hip.NmfHipError("gradient all-reduce needs dense fp32 / fp64 gradients")
-            f64 = 1 if g.dtype == torch.float64 else 0
-            a, b = pack[i], unpack[i]
-            a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = g.data_ptr(), base + 4 * off, g.numel(), f64, 0
-            b.src, b.dst, b.numel, b.src_is_f64, b.dst_is_f64 = base + 4 * off, g.data_ptr(), g.numel(), 0, f64
-            off += g.numel()
-        hip.multi_copy(pack, len(ps))
-        ev = self._events = getattr(self, "_events", None) or (torch.cuda.Event(enable_timing=True),
-                                                               torch.cuda.Event(enable_timing=True))
-        ev[0].record()
-        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
-        ev[1].record()
-        self.last_comm_ms = ev
-        hip.multi_copy(unpack, len(ps))
-        return n * 4
+        k = len(ps)
+        if self._slots is None or len(self._slots[0]) < 2 * k + 1:
+            self._slots = ((hip.CopySlot * (2 * k + 1))(), (hip.CopySlot * k)())
+        if self._consts is None or self._consts.device != self.buf.device:
+            self._consts = torch.tensor([0.0, 1.0], dtype=torch.float32, device=self.buf.device)
+        pack = self._slots[0]
+        base, off, m = self.buf.data_ptr(), 0, 0
+        zero, one = self._consts.data_ptr(), self._consts.data_ptr() + 4
+        missing = []
+        for i, (p, h) in enumerate(zip(ps, have)):
+            if h:
+                g = p.grad
+                if not _dense(g) or g.dtype not in (torch.float32, torch.float64):
+                    raise hip.NmfHipError("gradient all-reduce needs dense fp32 / fp64 gradients")
+                a = pack[m]
+                a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = g.data_ptr(), base + 4 * off, g.numel(), \
+                    (1 if g.dtype == torch.float64 else 0), 0
+                m += 1
+            else:
+                missing.append((off, p.numel()))
+            a = pack[m]
+            a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = (one if h else zero), base + 4 * (n + i), 1, 0, 0
+            m += 1
+            off += p.numel()
+        if guard is not None:
+            if guard.dtype not in (torch.float32, torch.float64) or guard.numel() != 1:
+                raise hip.NmfHipError("the guard is a single fp32 / fp64 device value")
+            a = pack[m]
+            a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = guard.data_ptr(), base + 4 * (n + k), 1, \
+                (1 if guard.dtype == torch.float64 else 0), 0
+            m += 1
+            self._keep_guard = guard
+        else:
+            self.buf[n + k:].zero_()
+        for off_, cnt in missing:                # slots of gradients this rank does not have travel as zeros
+            self.buf[off_:off_ + cnt].zero_()
+        hip.multi_copy(pack, m)
+
+    def _unpack_device(self, ps, n, have, anyone):
+        from . import hip
+        unpack = self._slots[1]
+        base, off, m = self.buf.data_ptr(), 0, 0
+        for p, h, a in zip(ps, have, anyone):
+            if a:
+                if not h:
+                    p.grad = torch.empty_like(p, memory_format=torch.preserve_format)
+                g = p.grad
+                b = unpack[m]
+                b.src, b.dst, b.numel, b.src_is_f64, b.dst_is_f64 = base + 4 * off, g.data_ptr(), g.numel(), 0, \
+                    (1 if g.dtype == torch.float64 else 0)
+                m += 1
+            off += p.numel()
+        if m:
+            hip.multi_copy(unpack, m)
 
     def comm_ms(self):
         """duration of the last device collective (blocks until it has finished); None if there was none"""
@@ -305,13 +380,20 @@ class Trainer:
                 nerf.model.update_n_samples(n_samples[1:])
         if fast is not None:
             fast.end_step()
-        comm_bytes = self.reduce()
+        # NaN guard (train.py:704-705 reads the loss back and skips a NaN chunk): the summed loss of the step stays on the
+        # device and gates the fused Adam launch -- a non-finite loss leaves parameters and moments untouched, no host sync.
+        # With several ranks the value that gates is the SUM of the ranks' guards (it rides in the gradient all-reduce): a
+        # rank-local decision would let one replica skip a step its peers take, and nothing re-synchronises parameters.
+        guard = None if not losses else (losses[0] if len(losses) == 1 else torch.stack(losses).sum())
+        if self.reduce.active() and guard is None and len(self.reduce.params):
+            guard = _zero_scalar(self.reduce.params[0].device)          # this rank's chunks were all empty: a finite contribution
+        comm_bytes = self.reduce(guard=guard)
+        if comm_bytes:
+            guard = self.reduce.guard
         if p.get("clip_grad") is not None:                                                       # train.py:744-745
             torch.nn.utils.clip_grad_norm_([q for q in nerf.parameters() if q.grad is not None], p["clip_grad"])
-        # NaN guard (train.py:704-705 reads the loss back and skips a NaN chunk): the summed loss of the step stays on the
-        # device and gates the fused Adam launch -- a non-finite loss leaves parameters and moments untouched, no host sync
         if hasattr(self.optimizer, "guard"):
-            self.optimizer.guard = None if not losses else (losses[0] if len(losses) == 1 else torch.stack(losses).sum())
+            self.optimizer.guard = guard
         (getattr(self.optimizer, "step_unhooked", None) or self.optimizer.step)()
         self.scheduler.step()
         self.ori_lambda *= self.ori_decay                                                        # train.py:748-749

@@ -42,10 +42,15 @@ def _worker(rank, world, port, out, device="cpu"):
     dist.all_gather_object(gathered, local)
     ok = nbytes == 4 * sum(p.numel() for p in params)
     for i, p in enumerate(params):
+        if i == 4:
+            continue
         want = sum(g[i].double() for g in gathered)
         ok &= p.grad is not None and bool(torch.allclose(p.grad.double().cpu(), want, rtol=1e-6, atol=1e-6))
         ok &= p.grad.shape == p.shape and p.grad.dtype == p.dtype
-    ok &= float(params[4].grad.abs().max()) == 0.0 and float(params[1].grad.abs().max()) > 0
+    # params[4]: NO rank produced a gradient -> it stays None on every rank, as in a single-process step (Adam then leaves its
+    # moments alone instead of moving it on momentum); params[1]: produced on rank 0 only -> materialised on rank 1
+    ok &= params[4].grad is None and float(params[1].grad.abs().max()) > 0
+    ok &= red.mask_reads == 1                 # both ranks lacked a gradient this step: the flags were read
     ok &= params[2].grad.is_contiguous(memory_format=torch.channels_last)
     # a rank with NO local gradient at all (every chunk of its shard was empty, trainer.py `continue`) still enters the
     # collective with the same element count
@@ -54,7 +59,20 @@ def _worker(rank, world, port, out, device="cpu"):
     if rank == 0:
         params[0].grad = torch.ones_like(params[0])
     ok &= red() == nbytes and bool(torch.equal(params[0].grad.cpu(), torch.ones(3, 5)))
-    ok &= all(p.grad is not None for p in params)
+    ok &= all((p.grad is not None) == (i == 0) for i, p in enumerate(params))
+    # steady state: every rank has every gradient -> the flags are not read back (no host synchronisation)
+    for p in params:
+        p.grad = torch.full_like(p, float(rank + 1))
+    reads = red.mask_reads
+    ok &= red() == nbytes and red.mask_reads == reads
+    ok &= all(bool(torch.equal(p.grad.cpu(), torch.full(p.shape, 3.0, dtype=p.dtype))) for p in params)
+    # the guard of the optimizer step rides along: its SUM comes back, so a NaN on ONE rank gates the step on EVERY rank
+    g = torch.tensor(float("nan") if rank == 1 else 0.25, dtype=torch.float32, device=device)
+    red(guard=g)
+    ok &= bool(torch.isnan(red.guard).item())
+    g = torch.tensor(0.25 + rank, dtype=torch.float32, device=device)
+    red(guard=g)
+    ok &= abs(float(red.guard) - 1.5) < 1e-6
     # agree(): one scalar, identical on every rank afterwards
     from nmf_amd.trainer import agree
     ok &= agree(4096 + 100 * rank, "min", device=device) == 4096 and agree(1, "sum", device=device) == world

@@ -1,0 +1,156 @@
+"""Data parallelism of the training step on hardware, as far as a 1-GPU box allows: two ranks share cuda:0 and
+exchange through gloo (production: one rank per GPU, backend nccl = RCCL over xGMI; same Trainer / FlatGradAllReduce code).
+
+The reference has no data-parallel path; the statement checked here is the one that makes the sharded step THE SAME
+estimator as the single-process step of train.py:497-747: an optimizer step over 2 x 4096 rays as two chunks of one process
+accumulates the gradient that two ranks with one chunk each obtain from their all-reduce, given the same noise per chunk
+(a split of the rays alone is not comparable: bounce budgets and normalisers are per chunk, models/microfacet.py:318-331)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+GRID, BG, CHUNK = 48, 64, 2048
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _PerChunkNoise:
+    """chunk k of a step draws from source k: the single process replays what rank k draws for its one chunk"""
+
+    pins = None
+
+    def __init__(self, sources):
+        self.sources, self.k = sources, -1
+
+    def begin_pass(self):
+        self.k = (self.k + 1) % len(self.sources)
+        self.sources[self.k].begin_pass()
+
+    def __getattr__(self, name):
+        return getattr(self.sources[self.k], name)
+
+
+def _build(dev):
+    from nmf_amd import synthetic
+    from nmf_amd.config import build_model, resolved_config
+    torch.manual_seed(0)
+    over = {"sampler.max_samples": 60000, "model.max_brdf_rays": [120000, 80000], "model.rays_per_ray": 32}
+    nerf, _ = build_model(grid=GRID, bg_resolution=BG, device=dev, overrides=over)
+    nerf.load_state_dict(synthetic.state_dict_s1(grid=GRID, bg_resolution=BG, seed=0), strict=False)
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    nerf.model.detach_N = False
+    nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
+    return nerf, resolved_config()["params"]
+
+
+def _flat_grad(tr):
+    ps = tr.reduce.params
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
+
+
+def _checksum(tr):
+    return [float(p.detach().double().sum()) for p in tr.reduce.params]
+
+
+def _data(dev):
+    from nmf_amd import synthetic
+    rays, focal = synthetic.camera_rays(2 * CHUNK, seed=77)
+    gt = torch.rand(2 * CHUNK, 3, generator=torch.Generator().manual_seed(5)) * 0.6 + 0.2
+    return rays.to(dev), gt.to(dev), focal
+
+
+def _worker(rank, world, port, out, nan_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer, rank_slice
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    nerf, params = _build(dev)
+    tr = Trainer(nerf, params, world_size=world, rank=rank)
+    rays, gt, focal = _data(dev)
+    sl = rank_slice(2 * CHUNK, world, rank)
+    res = {"sums": [], "skipped": None}
+    # step 1 of the comparison: this rank's chunk with ITS noise source; the reduced gradient is left in p.grad
+    p0 = [p.detach().clone() for p in tr.reduce.params]
+    tr.step(rays[sl], gt[sl], focal, noise=DeviceNoise(dev, seed=100 + rank), update_controllers=False, fixed_chunk=CHUNK,
+            global_rays=2 * CHUNK)
+    res["grad"] = _flat_grad(tr).cpu()
+    res["sums"].append(_checksum(tr))
+    # replica consistency over further steps (each rank its own rays and noise): bit-identical parameters on both ranks
+    noise = DeviceNoise(dev, seed=200 + rank)
+    for it in range(4):
+        r2, g2, _ = _data(dev)
+        perm = torch.randperm(2 * CHUNK, generator=torch.Generator().manual_seed(it)).to(dev)
+        ids = perm[sl]
+        tr.step(r2[ids], g2[ids], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK, global_rays=2 * CHUNK)
+        res["sums"].append(_checksum(tr))
+    # a non-finite loss on ONE rank: the step is skipped on EVERY rank (the guard rides in the all-reduce)
+    # (the gradients stay finite: only the step-level guard can stop the update, and only if it is the reduced one)
+    before = [p.detach().clone() for p in tr.reduce.params]
+    if rank == nan_rank:
+        chunk = tr.fast.chunk
+
+        def nan_loss(*a, **k):
+            o = chunk(*a, **k)
+            if o.get("loss") is not None:
+                o["loss"] = o["loss"] * float("nan")
+            return o
+        tr.fast.chunk = nan_loss
+    tr.step(rays[sl], gt[sl], focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK, global_rays=2 * CHUNK)
+    res["skipped"] = all(bool(torch.equal(a, b.detach())) for a, b in zip(before, tr.reduce.params))
+    res["moved"] = any(not torch.equal(a, b.detach()) for a, b in zip(p0, before))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_process_with_two_chunks():
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 1)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        res = dict(out)
+    a, b = res[0], res[1]
+    # every replica holds the same reduced gradient and, step after step, bit-identical parameters
+    assert torch.equal(a["grad"], b["grad"])
+    assert a["sums"] == b["sums"] and len(a["sums"]) == 5
+    assert a["moved"] and b["moved"]
+    assert a["skipped"] and b["skipped"], "a NaN loss on one rank must gate the optimizer step on every rank"
+    # ---- the single process: the same 2 x CHUNK rays as two chunks of one step, chunk k with rank k's noise
+    dev = torch.device("cuda", 0)
+    nerf, params = _build(dev)
+    tr = Trainer(nerf, params)
+    rays, gt, focal = _data(dev)
+    noise = _PerChunkNoise([DeviceNoise(dev, seed=100), DeviceNoise(dev, seed=101)])
+    tr.step(rays, gt, focal, noise=noise, update_controllers=False, fixed_chunk=CHUNK)
+    one = _flat_grad(tr).cpu()
+    two = a["grad"]
+    assert float(one.abs().max()) > 0
+    # float atomics accumulate in another order, nothing else differs
+    err = float((one - two).abs().max())
+    assert err <= 2e-5 * float(one.abs().max()) + 1e-9, (err, float(one.abs().max()))
+    rel = float((one - two).norm() / one.norm())
+    assert rel < 1e-5, rel
