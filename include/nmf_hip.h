@@ -487,6 +487,14 @@ int nmf_retrace_scores(const float* brdf /*[R][3]*/, const float* V_rows, const 
  * (key, index) pairs on the caller's workspace. */
 int nmf_argsort_f32(const float* keys, int64_t n, int32_t* order, void* workspace, int64_t workspace_bytes,
                     void* stream);
+/* The partition the reference takes from that argsort (models/microfacet.py:506-537: retrace_ray_inds = cc_as[M:], notrace_ray_inds =
+ * cc_as[:M]) WITHOUT sorting all n keys: a radix select (three histogram passes of 11 / 11 / 10 bits over the keys find the key of ascending rank
+ * n - k; ties at the cut go the way a stable ascending sort places them).  idx_top [k] = argsort(keys)[n-k:] exactly, in that order
+ * (the re-traced rays are processed in it); idx_rest [n-k] = the indices of argsort(keys)[:n-k] in INDEX order (their order is never
+ * used).  Either output may be NULL when empty. */
+int64_t nmf_topk_select_workspace_bytes(int64_t n);
+int nmf_topk_select(const float* keys, int64_t n, int64_t k, int32_t* idx_top, int32_t* idx_rest, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 int64_t nmf_argsort_workspace_bytes(int64_t n);
 
 /* ------------------------------------------------------------------------------------------

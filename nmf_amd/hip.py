@@ -71,7 +71,7 @@ EXPORTS = [
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
-    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -119,6 +119,7 @@ _lib.nmf_vm_walk_workspace_bytes.restype = C.c_int64
 _lib.nmf_march_scan_workspace_bytes.restype = C.c_int64
 _lib.nmf_bounce_index_workspace_bytes.restype = C.c_int64
 _lib.nmf_argsort_workspace_bytes.restype = C.c_int64
+_lib.nmf_topk_select_workspace_bytes.restype = C.c_int64
 _lib.nmf_alpha_coarse_words.restype = C.c_int64
 _lib.nmf_sat_lookup_bwd_workspace_bytes.restype = C.c_int64
 
@@ -1088,6 +1089,21 @@ def argsort_f32(keys):
         _check(_lib.nmf_argsort_f32(_p(keys, torch.float32), C.c_int64(n), _p(order), _p(ws), C.c_int64(nbytes),
                                     _stream()), "nmf_argsort_f32")
     return order
+
+
+def topk_select(keys, k):
+    """The partition models/microfacet.py:506-537 takes from `color_contribution.argsort()`, by radix select (no full sort):
+    -> (idx_top [k] int32 = argsort(keys)[n-k:] in that order, idx_rest [n-k] int32 = the other indices in index order)"""
+    n = keys.shape[0]
+    k = int(k)
+    top = torch.empty(k, dtype=torch.int32, device=keys.device)
+    rest = torch.empty(n - k, dtype=torch.int32, device=keys.device)
+    if n:
+        nbytes = _lib.nmf_topk_select_workspace_bytes(C.c_int64(n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=keys.device)
+        _check(_lib.nmf_topk_select(_p(keys, torch.float32), C.c_int64(n), C.c_int64(k), _p(top) if k else None,
+                                    _p(rest) if n - k else None, _p(ws), C.c_int64(nbytes), _stream()), "nmf_topk_select")
+    return top, rest
 
 
 def multi_copy(slots, n):

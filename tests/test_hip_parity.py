@@ -1347,6 +1347,29 @@ def test_retrace_scores_and_argsort(R):
     assert torch.equal(ks, torch.sort(keys).values)
 
 
+@pytest.mark.parametrize("n,ks", [(1, [0, 1]), (1000, [0, 1, 37, 999, 1000]), (250001, [1000, 4096, 4097, 20000, 120000]),
+                                  (4096 * 3 + 5, [1, 4095])])
+def test_topk_select_is_the_partition_of_the_argsort(n, ks):
+    """nmf_topk_select (radix select) == the partition models/microfacet.py:506-537 takes from color_contribution.argsort():
+    idx_top is argsort(keys)[n-k:] bit for bit (stable order), idx_rest the remaining indices; ties at the cut, -0.0 / +0.0,
+    equal keys, negative keys and infinities included."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(n)
+    keys = torch.rand(n, generator=gen) * 3 - 1
+    if n > 100:
+        keys[::7] = keys[3]                       # a large group of equal keys (ties across the cut for some k)
+        keys[5], keys[6], keys[11], keys[12] = -0.0, 0.0, float("inf"), float("-inf")
+        keys[100:140] = torch.rand(40, generator=gen) * 1e-30
+    kd = keys.to(DEV)
+    order = torch.sort(keys, stable=True).indices                # the stable ascending order a radix sort of (key, index) gives
+    assert torch.equal(hip.argsort_f32(kd).cpu().long(), order)
+    for k in ks:
+        top, rest = hip.topk_select(kd, k)
+        assert top.dtype == torch.int32 and top.shape == (k,) and rest.shape == (n - k,)
+        assert torch.equal(top.cpu().long(), order[n - k:]), k
+        assert torch.equal(rest.cpu().long(), torch.sort(order[:n - k]).values), k
+
+
 @pytest.mark.parametrize("G,B", [(16, 300), (40, 2000), (67, 3000)])
 def test_march_coarse_mask_is_exact(G, B):
     """The coarse occupancy mask (nmf_alpha_coarse) only skips work: valid bits and counts equal the plain 8-corner test,

@@ -211,12 +211,14 @@ def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
         inner, seen = tr.reduce, []
 
         class Checked:
-            comm_ms = inner.comm_ms
+            comm_ms, active, params = inner.comm_ms, inner.active, inner.params
+            guard = None
 
-            def __call__(self, group=None):
+            def __call__(self, group=None, guard=None):
                 ps = [p for p in inner.params if p.grad is not None]
                 before = [p.grad.clone() for p in ps]                      # queued on the stream the collective is queued on
-                n = inner(group)
+                n = inner(group, guard=guard)
+                self.guard = inner.guard
                 # compared right away: the gradient tensors of the tape-free pass are persistent buffers, the next step reuses them
                 seen.append((n, len(ps), all(torch.equal(p.grad, b) and bool(torch.isfinite(b).all()) for p, b in zip(ps, before)),
                              sum(float(b.abs().max()) > 0 for b in before)))
