@@ -687,8 +687,13 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A,
     CountAcc acc{hist, A.tab.H, A.tab.W, A.ntx};
     float inv_size = 0.f;
     if (env_walk_main(A, r, Q, geo, acc, inv_size)) {
-        const float m = fmaxf(fmaxf(fabsf(A.d_out[r * 3]), fabsf(A.d_out[r * 3 + 1])), fabsf(A.d_out[r * 3 + 2])) * inv_size;
-        if (m > 0.f && m < 3.0e38f) atomicMax(gmax_s, __float_as_uint(m));
+        const float g0 = A.d_out[r * 3], g1 = A.d_out[r * 3 + 1], g2 = A.d_out[r * 3 + 2];
+        const float m = fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fabsf(g2)) * inv_size;
+        // a NaN / infinite adjoint (fmaxf drops NaNs): its bit pattern, above every finite float's, tells pass 3 to poison the
+        // table gradient
+        if (!(fabsf(g0) <= 3.0e38f) || !(fabsf(g1) <= 3.0e38f) || !(fabsf(g2) <= 3.0e38f) || !(m <= 3.0e38f))
+            atomicMax(gmax_s, 0x7fc00000u);
+        else if (m > 0.f) atomicMax(gmax_s, __float_as_uint(m));
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
@@ -864,6 +869,13 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_accum(EnvBwdArgs A,
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) gbits = max(gbits, A.hdr->gmax_slots[i]);
     const float gmax = __uint_as_float(gbits);
+    if (!(gmax <= 3.0e38f)) {
+        // a NaN / infinite record adjoint (its bit pattern wins the unsigned maximum): the fixed-point accumulation cannot carry
+        // it, so it goes into the table gradient as it is -- the reverse prefix sums spread it and the optimizer's per-element
+        // isfinite test then sees it, as on the direct (float atomic) path
+        if (blk == 0 && threadIdx.x == 0) atomicAdd(A.d_sat4, gmax != gmax ? gmax : gmax - gmax);
+        return;
+    }
     if (n_items == 0 || !(gmax > 0.f)) return;
     // |sum| <= ENV_ITEM * gmax < 2^(12 + ilogb(gmax) + 1): scaled by 2^e it stays below 2^62
     const int e = 49 - ilogbf(gmax);

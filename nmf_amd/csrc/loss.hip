@@ -251,7 +251,11 @@ extern "C" int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t 
     return NMF_OK;
 }
 
-extern "C" int64_t nmf_loss_head_workspace_bytes(int64_t n_rays) { return 16 + 4 * cdiv(3 * (n_rays > 0 ? n_rays : 0), 256); }
+// 16 bytes of ticket + one partial sum per workgroup (at least one: an empty chunk still launches a workgroup that writes loss = 0)
+extern "C" int64_t nmf_loss_head_workspace_bytes(int64_t n_rays) {
+    const int64_t blocks = cdiv(3 * (n_rays > 0 ? n_rays : 0), 256);
+    return 16 + 4 * (blocks > 0 ? blocks : 1);
+}
 
 extern "C" int nmf_loss_head(const float* pred, const float* gt, int64_t n_rays, const float* d_out, float scale, float w_pred,
                              float w_a, float w_b, float* loss, float* d_pred, float* g_a, float* g_b, void* workspace,

@@ -99,6 +99,7 @@ class TrainPass:
         self._core_acc = None
         self._march_blocks = None
         self._token_params = None
+        self._token_plist = None
         self._tables_token = None
         self._table_events = None
         self._core_static = None
@@ -129,9 +130,11 @@ class TrainPass:
     def _param_token(self):
         """(version, storage) of every parameter the derived tables are built from: equal token = equal tables"""
         ps = self._token_params
-        if ps is None:
+        plist = self.nerf.rf._param_list()        # a NEW list object after an upsample / a load_state_dict that replaced the tables
+        if ps is None or plist is not self._token_plist:
             n = self.nerf
-            ps = self._token_params = (list(n.rf._param_list()) + list(n.model.diffuse_module._head_params())
+            self._token_plist = plist
+            ps = self._token_params = (list(plist) + list(n.model.diffuse_module._head_params())
                                        + list(n.model.brdf._weights()) + [n.bg_module.bg_mat, n.bg_module.mipbias,
                                                                           n.bg_module.brightness, n.bg_module.mul])
         return tuple([p._version for p in ps]), tuple([p.data_ptr() for p in ps])

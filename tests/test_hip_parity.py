@@ -523,6 +523,16 @@ def test_env_binned_table_adjoint(H, R, monkeypatch):
         # d_mipbias sums the same cancellation noise over all lookups (H = 512: -53.9 against -46.6 with |d_dirs| up to 8703)
         assert abs(float(b[3]) - float(a[3])) <= 1e-3 * abs(float(a[3])) + 2e-3 * scale
         assert_close(b[4].cpu(), a[4].cpu(), rtol=1e-3, atol=1e-4 * float(a[4].abs().max()), what="d_bg")
+    # a non-finite adjoint is not swallowed by the fixed-point accumulation: it reaches the table gradient (and through the reverse
+    # prefix sums the map gradient), where the optimizer's isfinite test sees it, as on the direct path
+    for bad in (float("nan"), float("inf")):
+        cb = c.clone()
+        cb[777, 1] = bad
+        for thr in (1 << 62, 1):
+            monkeypatch.setattr(hip, "ENV_BINNED_MIN_LOOKUPS", thr)
+            d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
+            hip.sat_lookup_bwd(sat4, dirs.to(DEV).contiguous(), sa.to(DEV), 0.3, cb.to(DEV), d_sat, d_pole, d_mip)
+            assert not bool(torch.isfinite(d_sat).all()), (bad, thr)
     # a pool of 1000 records: the rest of the corners go the direct way inside the scatter pass
     rows = dirs.to(DEV).contiguous()
     d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
