@@ -112,14 +112,25 @@ MLP_BWD_ISSUED_FLOP = 186 * 32768 / 32
 ADAM_BYTES_PER_PARAM = 28
 
 
+_WALK_FLOP = 0.0
+L2_PEAK_GBS = 34500.0
+
+
 def call_models(sz, n_params):
     """sz: sizes of one step (rays B, samples M0 M1, secondary rays R0 R1, bounce rows Mb0 Mb1) -> {call: (bound, work, peak)}"""
     B, M0, M1, R0, R1, Mb0, Mb1 = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1"))
     walk_flop = (M0 + Mb1) * MFMA_FLOP_DENSITY + M1 * MFMA_FLOP_VALUE + (Mb0 + Mb1) * MFMA_FLOP_APP
+    global _WALK_FLOP
+    _WALK_FLOP = walk_flop
     return {
         "brdf_mlp_bwd": ("mfma", MLP_BWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
         "brdf_mlp_fwd": ("mfma", MLP_FWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
-        "vm_query_bwd_segments": ("mfma", walk_flop, MFMA_F32_PEAK_TFLOPS * 1e12),
+        # the backward walks: SURVEY 8(d)'s algorithmic bytes of what the pass walks (sparse normals / appearance: recompute read +
+        # read-modify-write of the gradients = 3 x the forward bytes of each sample set) against HBM.  The 7.5 MB of tables are
+        # L2 / MALL resident, so the fraction may exceed 1: `traffic` (counters) says how little reaches HBM; what bounds the kernel
+        # is VALU issue around its sparse-A matrix instructions: `secondary` carries alu_busy and the issued-MFMA rate
+        "vm_query_bwd_segments": ("hbm", float((M0 + Mb1) * BWD_BYTES_DENSITY + M1 * BWD_BYTES_VALUE + (Mb0 + Mb1) * BWD_BYTES_APP),
+                                  HBM_PEAK_GBS * 1e9),
         "sat_lookup_bwd": ("atomics", 48.0 * (R0 + R1), ATOMIC_PEAK),            # 4 corners x 4 texels x 3 channels per box
         "sat_lookup_fwd": ("hbm", 192.0 * (R0 + R1 + 5000), HBM_PEAK_GBS * 1e9),
         "vm_query_fwd": ("hbm", float(M0 * G_DENSITY + (Mb0 + Mb1) * G_APP), HBM_PEAK_GBS * 1e9),
@@ -231,7 +242,10 @@ def cpu_baseline(budget_s=150.0, warm=1, timed=3):
                 sample=f"B={CHUNK} rays of S1 at 128^3, forward+backward of the training loss, steady state "
                        f"(samples {st['n_samples']}): {warm} warm-up + {st['timed_steps']} timed steps, {st['s_per_step']:.1f} s "
                        f"each, {cores} threads (physical cores); early phase beside it",
-                early_phase=out["early"], steady_state=st)
+                early_phase=out["early"], steady_state=st,
+                protocol=f"{warm}+{timed} steps per phase within a {budget_s} s budget" if budget_s else f"{warm}+{timed} steps per phase (SURVEY 8d)",
+                protocol_full="profiles/r03_i_cpu_baseline_3_10.json (SURVEY 8d's 3 warm-up + 10 timed steps per phase on the GPU box's host: "
+                              "210 rays/s steady state, 551 rays/s early phase; `python bench.py --cpu-baseline-steps 3,10`)")
 
 
 def counters_summary():
@@ -464,6 +478,20 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
     nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
+    # what a maintainer of the reference gets who swaps the operator classes in and keeps train.py's loop:
+    # TensorNeRF.forward builds the autograd graph, loss.backward() walks it, FusedAdam steps -- the same kernels without the
+    # tape-free pass (NMF_FAST_STEP=0), steady state, 4096 rays
+    prev = os.environ.get("NMF_FAST_STEP")
+    os.environ["NMF_FAST_STEP"] = "0"
+    try:
+        out["module_path"] = train_ms(nerf, CHUNK, 30, 8)
+        out["module_path"]["note"] = ("TensorNeRF.forward + backward() through torch.autograd + FusedAdam (the drop-in operator classes under "
+                                      "the reference's own training loop); `value` is the tape-free pass of nmf_amd/trainer.py")
+    finally:
+        if prev is None:
+            del os.environ["NMF_FAST_STEP"]
+        else:
+            os.environ["NMF_FAST_STEP"] = prev
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
@@ -703,8 +731,16 @@ def main():
                 # the dominant C-ABI call of the step by summed device time, found in the warm-up and timed with HIP events on its
                 # launching stream INSIDE the timed region
                 "kernel": "nmf_" + dname, "bound": "mfma" if bound == "mfma" else ("hbm" if bound in ("hbm", "atomics") else bound),
-                "bound_detail": bound, "achieved": achieved / scale if achieved else None, "peak": peak / scale if peak else None,
+                "bound_detail": (bound if dname != "vm_query_bwd_segments" else
+                                 "algorithmic bytes of SURVEY 8(d) against HBM as the contract prescribes; the tables are cache resident "
+                                 "(traffic << algorithmic bytes, frac may exceed 1), the kernel's own ceiling is VALU issue: secondary.alu_busy"),
+                "achieved": achieved / scale if achieved else None, "peak": peak / scale if peak else None,
                 "unit": unit, "frac": (achieved / peak) if (achieved and peak) else None,
+                "secondary": ({"alu_busy_counters": (ctr or {}).get("kernels", {}).get("k_vm_bwd_density<value>", {}).get("derived", {}).get("alu_busy"),
+                               "issued_mfma_tflops": (_WALK_FLOP / calls_per_step) / (live_us * 1e-6) / 1e12 if live_us else None,
+                               "issued_mfma_frac_of_157.3": (_WALK_FLOP / calls_per_step) / (live_us * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12) if live_us else None,
+                               "survey_dense_bytes_frac": (14400.0 * (sizes["M0"] + sizes["M1"]) / calls_per_step) / (live_us * 1e-6) / (HBM_PEAK_GBS * 1e9) if live_us else None}
+                              if dname == "vm_query_bwd_segments" else None),
                 "traffic": (ctr or {}).get("kernels", {}).get(
                     {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd",
                      "sat_lookup_bwd": "k_env_lookup_bwd"}.get(dname, "k_" + dname), {}).get("hbm_bytes_per_launch") if ctr else None,
@@ -718,10 +754,12 @@ def main():
                 "per_kernel": table, "sizes_per_step": sizes,
                 "step": {"survey_8d_bytes": survey_b, "algorithmic_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
                          "needed_bytes": needed_b, "needed_over_hbm": needed_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         "needed_over_l2": needed_b / (ms_step * 1e-3) / (L2_PEAK_GBS * 1e9),
                          "fabric_bytes_counters_partial": fabric,
                          "device_time_sum_us": round(sum(r["us_per_step"] for r in table.values()), 1), "wall_us": round(1e3 * ms_step, 1),
-                         "note": "tables (7.5 MB at 128^3) are L2 / MALL resident: the byte models do not bound the step; it is bound by "
-                                 "the dependent chain of ~115 launches, the MLP matrix rate and float atomics (per_kernel)"},
+                         "note": "tables (7.5 MB at 128^3) are L2 / MALL resident: the byte models do not bound the step.  Half of the step is "
+                                 "the forward, a dependent chain of ~50 kernels whose own latency (not the 2.3 us between launches) adds "
+                                 "up; the backward runs up to four streams side by side and is bound by the sum of its work (DESIGN 0)"},
                 "counters": ctr_meta,
             }
         out = {
@@ -732,7 +770,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {chunk_rays}"
                                    + (f" (per-chunk budgets x{args.budget_scale})" if args.budget_scale > 1 else "") + ", "
-                                   "fwd+bwd+all-reduce+Adam, " + ("all secondary rays re-traced (steady state)" if args.retrace is None
+                                   "fwd+bwd+all-reduce+Adam, " + ("all secondary rays re-traced (steady state: the a20 score + sort of models/microfacet.py:475-537 "
+                                                                  "selects every ray and is skipped)" if args.retrace is None
                                                                   else f"{args.retrace} secondary rays re-traced") +
                                    f"; stands in for BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not "
                                    "available offline: scene S1 of SURVEY 8d)",

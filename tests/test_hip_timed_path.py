@@ -75,7 +75,7 @@ def test_timed_path_vs_reference(name):
     assert_close(tr["acc_map0"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     frac, worst = _frac_close(tr["rgb_map0"].cpu(), g["rgb_map"], 1e-4, 1e-4)
     print(f"{name} (tape-free pass): rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
-    assert frac >= 0.999, (frac, worst)
+    assert frac == 1.0 and worst < 1e-4, (frac, worst)       # EVERY ray (measured worst: 4.9e-5 at 128^3, 1.6e-5 at 300^3)
     assert_close(torch.tensor(out["loss"]), g["loss"], rtol=1e-4, what="loss")
     assert_close(rec["total"].cpu().reshape(()), g["total"], rtol=1e-4, what="total")
     _check_gradients(nerf, g, full_tol=3e-2 if "g300" in name else 5e-3)
@@ -292,12 +292,12 @@ def test_psnr_after_equal_iterations_at_a_trained_level():
     iterations the two are different realisations of the same stochastic optimisation (float atomics, a bounce count that floors
     the other way), so the comparison is between the MEANS over the seeds.
 
-    Criterion, fixed before looking at the HIP numbers: a pooled two-sample t-test per evaluation between the HIP seeds (the first
-    three of the fixture: test time) and ALL reference seeds (six), |mean_hip - mean_ref| <= max(0.05 dB, t * s_p * sqrt(1/n_hip +
-    1/n_ref)) with s_p the pooled seed-to-seed standard deviation (n_hip + n_ref - 2 = 7 degrees of freedom) and t the two-sided
-    0.2 % point of Student's t (4.8 at 7 dof): < 1 % false alarms over the three evaluations.  With a seed-to-seed spread of
-    0.3-0.4 dB that bound is ~1.3 dB wide -- which is what nine trainings can say; the measured differences of the means are
-    printed (first run with this criterion: -0.10 / -0.15 / +0.06 dB).  [History: the first versions
+    Criterion, fixed before looking at the HIP numbers: a pooled two-sample t-test per evaluation between the HIP seeds (R4: all six
+    of the fixture; rounds 2-3 ran three) and ALL reference seeds (six), |mean_hip - mean_ref| <= max(0.05 dB, t * s_p * sqrt(1/n_hip
+    + 1/n_ref)) with s_p the pooled seed-to-seed standard deviation (n_hip + n_ref - 2 = 10 degrees of freedom) and t the two-sided
+    0.2 % point of Student's t (4.1 at 10 dof): < 1 % false alarms over the three evaluations.  With a seed-to-seed spread of
+    0.3-0.4 dB that bound is ~0.8 dB wide -- which is what twelve trainings can say (the 0.05 dB of north_star would take hundreds
+    of seeds); the measured differences of the means are printed (three seeds: -0.10 / -0.15 / +0.06 dB).  [History: the first versions
     estimated the HIP spread from the three HIP values of the run alone (2 degrees of freedom) against three reference seeds: the
     bound then swings between 0.16 and 0.68 dB from run to run and a CORRECT build fails in 10-25 % of the runs -- observed:
     differences at iteration 300 of +0.22 / +0.12 / -0.08 dB (three runs of one build) and +0.29 / +0.30 / +0.06 dB (three runs of
@@ -322,7 +322,7 @@ def test_psnr_after_equal_iterations_at_a_trained_level():
     focal = g["focal"]
     n_views = rays_te.shape[0] // (res * res)
     n_seeds = int(g["n_seeds"])
-    n_hip = min(3, n_seeds)
+    n_hip = n_seeds            # every seed of the fixture on both sides (R4: six against six; three HIP seeds gave a bound 1.3 dB wide)
     got = []
     for s in range(n_hip):
         nerf, _ = build_model(grid=G0, bg_resolution=BG, device=DEV, overrides=over)
