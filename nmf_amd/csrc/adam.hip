@@ -43,7 +43,32 @@ __device__ void adam_slot(const nmf_adam_slot& s) {
             omb2 = (T)(1.0 - (double)s.beta2), step = (T)s.step_size, bc2s = (T)s.bc2_sqrt, eps = (T)s.eps;
     const int64_t n = s.numel;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int64_t done = 0;
+    if constexpr (sizeof(T) == 4) {
+        // 16 bytes per lane and array (R4): the update streams 28 B per parameter through HBM -- 3.3 TB/s with 4-byte accesses
+        if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+              reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+            const int64_t n4 = n >> 2;
+            float4* p4 = reinterpret_cast<float4*>(p);
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+            float4* m4 = reinterpret_cast<float4*>(m);
+            float4* v4 = reinterpret_cast<float4*>(v);
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+                const float4 gq = g4[i];
+                float4 pq = p4[i], mq = m4[i], vq = v4[i];
+                float gg[4] = {gq.x, gq.y, gq.z, gq.w}, pp[4] = {pq.x, pq.y, pq.z, pq.w}, mm[4] = {mq.x, mq.y, mq.z, mq.w},
+                      vv[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (isfinite(gg[q])) adam_one<T>(pp[q], gg[q], mm[q], vv[q], wd, omb1, b2, omb2, step, bc2s, eps);
+                p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                v4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+            done = n4 << 2;
+        }
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const T gg = g[i];
         // last line of defence (the step-level guard below is the first): an element whose gradient is not finite keeps its
         // parameter and its moments
@@ -61,7 +86,7 @@ __device__ void adam_slot(const nmf_adam_slot& s) {
 __global__ void __launch_bounds__(256) k_adam(Batch b, const float* __restrict__ guard) {
     if (guard && !isfinite(*guard)) return;
     const nmf_adam_slot& s = b.s[blockIdx.y];
-    if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;
+    if ((int64_t)blockIdx.x * blockDim.x >= s.numel) return;      // (no element of any loop below starts at or beyond numel)
     if (s.is_f64) adam_slot<double>(s);
     else adam_slot<float>(s);
 }

@@ -8,12 +8,12 @@ launch durations differ from the `--kernel-trace --stats` run (where up to seven
 bench run have other sizes than the steady state; rounds 1-3 divided cycles of the counter runs by durations of the stats run,
 averaged over all launches, and got "clocks" of 1.4-4.5 GHz.  Now: per counter run, only the launches of the LAST optimizer steps
 (between the last k_adam dispatches) are used, durations are taken from the dispatch timestamps of the SAME counter run, and a
-kernel whose cycles / duration is outside 1.6-2.6 GHz (the part runs at <= 2.4 GHz) gets no `derived` block: launches of a few us,
-where GRBM_GUI_ACTIVE also counts the dispatch itself, are the usual case.  A rejected kernel of >= 20 us fails the tool.
+kernel whose (cycles - dispatch cycles) / duration is outside 1.8-2.5 GHz (the part runs at <= 2.4 GHz) gets no `derived` block;
+GRBM_GUI_ACTIVE also counts the dispatch of a launch (~18 k cycles, calibrated per file from its shortest kernels and subtracted).  A rejected kernel of >= 20 us fails the tool.
 
 Normalisation on MI355X (8 XCDs x 4 SEs, 256 CUs x 4 SIMDs; checked on k_vm_bwd_brick: 16.15 M v_mfma_f32_16x16x4_f32 x 32
 cycles/SIMD = 516.8 M = SQ_VALU_MFMA_BUSY_CYCLES exactly):
-  GRBM_GUI_ACTIVE            summed over the 8 XCDs          -> active cycles of the launch = GRBM_GUI_ACTIVE / 8
+  GRBM_GUI_ACTIVE            summed over the 8 XCDs          -> active cycles of the launch = GRBM_GUI_ACTIVE / 8 - dispatch cycles
   SQ_VALU_MFMA_BUSY_CYCLES   cycles, summed over 1024 SIMDs  -> mfma_busy = it / (1024 * active cycles)
   SQ_ACTIVE_INST_VALU        quad-cycles (4 clocks) of VALU ISSUE, summed over SIMDs; an MFMA counts as one quad-cycle
                              here whatever its length (k_brdf_mlp_bwd: 16.7 M for 16.6 M VALU instructions of which
@@ -33,6 +33,22 @@ import sys
 HBM, L2, SIMDS = 8.0e12, 34.5e12, 1024
 
 
+DISPATCH_CYCLES = [0.0]      # GRBM_GUI_ACTIVE / 8 of an (almost) empty launch: calibrated per file from its shortest kernels
+
+
+def calibrate_dispatch_cycles(kernels):
+    """GRBM_GUI_ACTIVE also counts the dispatch of the launch itself: r04_a, k_bins_partial 4.8 us -> 29.6 k cycles, k_segment_sum_wide
+    5.7 us -> 32.0 k: ~18 k cycles (7.5 us at 2.4 GHz) on top of duration x clock for every kernel, which made 20-30 us launches read as
+    2.6-3.7 GHz.  Estimated as the median of (GRBM / 8 - 2400 cycles/us x duration) over the launches shorter than 8 us."""
+    est = []
+    for v in kernels.values():
+        c, t = v.get("counters_per_launch", {}), v.get("avg_launch_us")
+        if t and t < 8.0 and c.get("GRBM_GUI_ACTIVE"):
+            est.append(c["GRBM_GUI_ACTIVE"] / 8 - 2400.0 * t)
+    est.sort()
+    return max(est[len(est) // 2], 0.0) if est else 0.0
+
+
 def derive(name, rec):
     c = rec.get("counters_per_launch", {})
     t = rec.get("avg_launch_us")
@@ -41,7 +57,7 @@ def derive(name, rec):
     t *= 1e-6
     d = {}
     act = c.get("GRBM_GUI_ACTIVE")
-    cyc = act / 8 if act else None
+    cyc = max(act / 8 - DISPATCH_CYCLES[0], 1.0) if act else None
     if cyc:
         d["active_cycles"] = round(cyc)
         d["clock_GHz"] = round(cyc / t / 1e9, 2)
@@ -81,7 +97,7 @@ def derive(name, rec):
     return out
 
 
-CLOCK_LO, CLOCK_HI = 1.6, 2.6
+CLOCK_LO, CLOCK_HI = 1.8, 2.5
 
 # kernels of the steady-state step, by substring of the demangled name -> report key
 KEYS = {"k_vm_bwd_density<false": "k_vm_bwd_density<value>", "k_vm_bwd_density<true": "k_vm_bwd_density<normal>",
@@ -175,6 +191,8 @@ def collect(tag, out, root, pmc_prefix, ks_dir, last_steps=10):
 
 def main(path):
     doc = json.load(open(path))
+    DISPATCH_CYCLES[0] = calibrate_dispatch_cycles(doc["kernels"])
+    doc["dispatch_cycles_subtracted"] = round(DISPATCH_CYCLES[0])
     doc["kernels"] = {k: derive(k, v) for k, v in doc["kernels"].items()}
     bad = []
     for k, v in doc["kernels"].items():
