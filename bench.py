@@ -298,16 +298,18 @@ def flush_c_stdio():
 
 def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, global_rays=None):
     import torch  # noqa: F401
+    nb = len(batches)
     for i in range(warmup):
-        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
-                     global_rays=global_rays)
+        trainer.step(*batches[i % nb], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
+                     global_rays=global_rays, next_rays=batches[(i + 1) % nb][0])
     sync()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     rays_done, last, comm, first = 0, None, [], None
     for i in range(warmup, warmup + steps):
-        last = trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
-                            global_rays=global_rays)
+        # (the loop knows its next batch, as train.py's permutation sampler does: the sampler of its first chunk is prefetched)
+        last = trainer.step(*batches[i % nb], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
+                            global_rays=global_rays, next_rays=batches[(i + 1) % nb][0])
         first = first if first is not None else last
         rays_done += last["rays"]
         if last["comm_bytes"]:
@@ -668,7 +670,8 @@ def main():
     for i in range(args.warmup):
         if n_probe and i == args.warmup - n_probe:
             fx.call_timing_begin()                  # the last warm-up steps find the dominant call of this workload
-        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
+        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
+                         next_rays=batches[(i + 1) % len(batches)][0])
     if n_probe:
         probe = fx.call_timing_end()
         dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
@@ -698,7 +701,8 @@ def main():
         n_inst = 30
         fx.call_timing_begin()
         for i in range(n_inst):
-            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
+            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
+                         next_rays=batches[(i + 1) % len(batches)][0])
         timing = fx.call_timing_end()
         ls = trainer.fast.last_sizes
         sizes = dict(B=int(ls["rays"]), M0=int(ls["n_samples"][0]), M1=int(ls["n_samples"][1]) if len(ls["n_samples"]) > 1 else 0,

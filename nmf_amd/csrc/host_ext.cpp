@@ -88,9 +88,17 @@ struct CallTimer {
 };
 CallTimer* g_call_timer = nullptr;
 std::string g_call_filter;           // non-empty: only the wrapper of that name (or of a comma-separated list of names) is timed
+// measurement knob (tools/ab_inprocess.py calldelay:NAME): a host busy-wait in front of every call of one wrapper -- a delay the
+// step absorbs means the device bounds that stretch, a delay that shows 1:1 means the host's issue rate does
+std::string g_delay_name;
+double g_delay_us = 0.0;
 struct TimedScope {
     const char* name; void* stream; void* a = nullptr;
     TimedScope(const char* n, int64_t s) : name(n), stream(reinterpret_cast<void*>(s)) {
+        if (g_delay_us > 0.0 && g_delay_name == n) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < g_delay_us) {}
+        }
         if (g_call_timer && (g_call_filter.empty() || g_call_filter == n ||
                              (g_call_filter.find(',') != std::string::npos && (',' + g_call_filter + ',').find(',' + std::string(n) + ',') != std::string::npos))) {
             a = g_call_timer->ev();
@@ -903,6 +911,13 @@ PYBIND11_MODULE(_nmf_host, m) {
         delete t;
         return out;
     });
+    m.def("readback_wait_us", [](bool reset) { const double w = SizeReadback::waited_us(); if (reset) SizeReadback::waited_us() = 0.0; return w; });
+    m.def("readback_wait_by_slot_us", [](bool reset) {
+        std::vector<double> v(SizeReadback::waited_by_slot(), SizeReadback::waited_by_slot() + 4);
+        if (reset) for (int i = 0; i < 4; ++i) SizeReadback::waited_by_slot()[i] = 0.0;
+        return v;
+    });
+    m.def("set_call_delay", [](const std::string& name, double us) { g_delay_name = name; g_delay_us = us; });
     m.def("call_timing_timeline", []() {   // waits for the recorded work; -> [(name, stream, start_us, end_us, host_issue_us)], times
         py::list out;                      // relative to the first recorded call (device clock / host clock)
         if (!g_call_timer) return out;
@@ -978,7 +993,7 @@ PYBIND11_MODULE(_nmf_host, m) {
         .def("env_was_used", &StepCore::env_was_used)
         .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
 #define RW(name) .def_readwrite(#name, &StepCore::name)
-        RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
+        RW(next_rays) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(walk_late) RW(launch_diet) RW(mlp_side_wgs)
         RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)

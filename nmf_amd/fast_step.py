@@ -247,7 +247,7 @@ class TrainPass:
             c.max_retrace_rays = mr
         return c
 
-    def _core_chunk(self, c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last):
+    def _core_chunk(self, c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last, next_rays=None):
         rf = self.nerf.rf
         dev = rays.device
         mods = [m for m in (rf, self.nerf.bg_module, self.nerf.model.brdf, self.nerf.model.diffuse_module) if hasattr(m, "begin_pass")]
@@ -271,6 +271,7 @@ class TrainPass:
                 l1 = hip.l1_mean_fwd([x.detach() for x in dens])
                 return hip.loss_mix_fwd([loss, l1, ori, acc], wts, inv_lbatch)
 
+            c.next_rays = next_rays if (last and next_rays is not None and next_rays.is_contiguous()) else None
             try:
                 out = c.chunk(rays, gt, float(focal), noise, float(inv_lbatch), [float(w) for w in wts], bool(want_total), bool(last),
                               total_of)
@@ -728,7 +729,7 @@ class TrainPass:
 
     # ---- one chunk: forward, loss, backward ---------------------------------------------------------------------------
     @torch.no_grad()
-    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False):
+    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False, next_rays=None):
         """wts = (w_photo, w_l1, w_ori, w_acc).  Returns dict(loss 0-d tensor, kept, n_samples) -- loss None when the chunk
         had no sample (train.py:567-568 skips it).  want_total: also evaluate the chunk's total loss value (the gradients do
         not need it: every term enters linearly with a constant weight)."""
@@ -737,7 +738,7 @@ class TrainPass:
             raise Unsupported("configuration")
         core = self.core()
         if core is not None:
-            return self._core_chunk(core, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
+            return self._core_chunk(core, rays, gt, focal, noise, inv_lbatch, wts, want_total, last, next_rays)
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
         dev = rays.device
         mods = [m for m in (rf, bgm, model.brdf, model.diffuse_module) if hasattr(m, "begin_pass")]

@@ -293,7 +293,7 @@ class Trainer:
         return self.batch.lbatch_size()
 
     def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None, global_rays=None,
-             fetch=None, trace=None):
+             fetch=None, trace=None, next_rays=None):
         """One optimizer step over this rank's rays (train.py:497-747).  rays [n,6], rgb_gt [n,3] (already blended
         onto the background colour, train.py:525-530).  `global_rays`: the loss normaliser `lbatch_size` of train.py:703,
         i.e. the number of rays ALL ranks process in this step (default: n * world_size, equal shards).
@@ -301,6 +301,9 @@ class Trainer:
         train.py:509-512 (`trainingSampler.nextids(lnum_rays)` per chunk, so a re-permutation can fall inside a step);
         `n` = this rank's share of the step (rays.shape[0] when rays is given, else lbatch_size()).
         `trace`: list that receives one record per chunk (num_rays, rays in / kept, n_samples, loss, max_retrace_rays).
+        `next_rays`: the rays of the NEXT call, if the loop already knows them (its batches are drawn from a permutation that does
+        not depend on the step): the alpha-grid march of their first chunk is issued behind this step's backward, off the next
+        step's critical path (same samples: csrc/step_core.inc prefetch_sample).
         Returns a stats dict (python scalars)."""
         p = self.p
         nerf = self.nerf
@@ -327,9 +330,13 @@ class Trainer:
                 trace.append(dict(num_rays=chunk, rays_in=int(r.shape[0]), max_retrace=list(nerf.model.max_retrace_rays)))
             if fast is not None:
                 try:
+                    nxt = None
+                    if next_rays is not None and pos >= n_total:
+                        n_first = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
+                        nxt = next_rays[:n_first]
                     out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
                                      (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
-                                     want_total=trace is not None, last=pos >= n_total)
+                                     want_total=trace is not None, last=pos >= n_total, next_rays=nxt)
                 except Unsupported:
                     out = None                      # this chunk goes through the autograd path below
                 if out is not None:

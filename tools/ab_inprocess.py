@@ -8,6 +8,7 @@ thermal drift and box-to-box differences (4 % between `python bench.py` runs on 
     obj:ATTR             TrainPass attribute, as bool        (obj:overlap 0,1   obj:sparse_normals 0,1)
     attr:NAME            nmf_amd.fast_step module constant   (attr:MLP_SIDE_WGS 64,128,256)
     hip:NAME             nmf_amd.hip module constant         (hip:ENV_BINNED_MIN_LOOKUPS 16384,4611686018427387904)
+    calldelay:NAME       busy-wait of <value> us on the host in front of every call of the C++ wrapper NAME (csrc/host_ext.cpp)
     prio                 0,1: the training pass on torch's default stream / on a high-priority stream (side streams stay normal)
     delay:METHOD         busy-wait of <value> us on the host in front of TrainPass.METHOD (delay:_flush_walks 0,100) or,
                          with delay:hip.FUNC, in front of a wrapper of nmf_amd.hip (delay:hip.march_fill 0,50): shows whether
@@ -61,7 +62,9 @@ def main():
         install_delay(var[6:])
 
     def set_variant(v):
-        if var == "prio":                      # prio 0,1: torch's default stream / a high-priority stream as the pass's main stream
+        if var.startswith("calldelay:"):       # calldelay:march_fill 0,50 -- host busy-wait in front of every call of that C++ wrapper
+            hip.HOST_EXT.set_call_delay(var[10:], float(v))
+        elif var == "prio":                      # prio 0,1: torch's default stream / a high-priority stream as the pass's main stream
             torch.cuda.synchronize()
             use_hi[0] = bool(int(v))
         elif var.startswith("delay:"):
@@ -83,10 +86,10 @@ def main():
         if hi is not None:
             with torch.cuda.stream(hi):
                 for i in range(n):
-                    tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
+                    tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK, next_rays=batches[(i + 1) % 16][0])
             return
         for i in range(n):
-            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
+            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK, next_rays=batches[(i + 1) % 16][0])
 
     for v in vals:
         set_variant(v)

@@ -42,3 +42,9 @@ print(s.getvalue()[:9000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40)
 print(s.getvalue()[:9000])
+s = io.StringIO()
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("cumulative")
+for fn in ("_core_tables", "end_step", "_step_planned", "step", "_core_chunk", "_core_sync"):
+    st.print_callees(fn)
+print(s.getvalue()[:14000])
