@@ -433,6 +433,16 @@ int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* r
                      int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int64_t nmf_bounce_index_workspace_bytes(int64_t M);
+/* The same queries / index with the live element count still ON THE DEVICE (M_live: e.g. totals[0] of nmf_march_scan): the launch
+ * is sized by the bound M_cap the caller allocated for (sampler.max_samples, samplers/alphagrid.py:353-364), elements at or beyond
+ * *M_live are neither read nor written.  Lets a caller queue the level-0 pipeline behind the scan without waiting for its sizes. */
+int nmf_vm_query_fwd_live(const nmf_vm_params* p, const float* xyzt, int64_t M_cap, const int64_t* M_live,
+                          const void* const dpk[3], const void* const dlk[3], const void* const app_planes[3],
+                          const void* const app_lines[3], int32_t tables_bf16, const float* basis, float* sigma_feat,
+                          float* sigma, float* grad, float* normal, float* app, float* coef, void* stream);
+int nmf_bounce_index_live(const int32_t* counts, int64_t M_cap, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                          int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
+                          int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq, void* stream);
 /* nmf_bounce_index that also publishes [R, Mb, publish_seq] into mapped host memory (see nmf_march_scan_publish). */
 int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off, int32_t* cnt_rows,
                              int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,

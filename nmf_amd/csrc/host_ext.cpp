@@ -173,7 +173,8 @@ std::tuple<Tensor, Tensor, Tensor, OT, Tensor> march_fill(int64_t p_addr, const 
 std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& dpk,
                                                 const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl,
                                                 const std::vector<Tensor>& ali, const OT& basis, bool want_density,
-                                                bool want_normal, bool want_app, bool want_coef, int64_t stream) {
+                                                bool want_normal, bool want_app, bool want_coef, int64_t stream, int64_t live = 0) {
+    // live: device address of the sample count when xyzt is sized by a bound (nmf_vm_query_fwd_live)
     TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     const int64_t M = xyzt.size(0);
@@ -185,6 +186,20 @@ std::tuple<OT, OT, OT, OT, OT, OT> vm_query_fwd(int64_t p_addr, const Tensor& xy
     const bool need_d = want_density || want_normal, need_a = want_app || want_coef;
     auto o = [](OT& t) { return t.has_value() ? static_cast<float*>(t->data_ptr()) : nullptr; };
     const bool bf16 = (need_d ? dpk : apl).at(0).scalar_type() == at::kBFloat16;
+    if (live) {
+        const void *a[3], *b[3], *c[3], *d[3];
+        for (int i = 0; i < 3; ++i) {
+            a[i] = need_d ? vptr(dpk.at(i)) : nullptr;
+            b[i] = need_d ? vptr(dlk.at(i)) : nullptr;
+            c[i] = need_a ? vptr(apl.at(i)) : nullptr;
+            d[i] = need_a ? vptr(ali.at(i)) : nullptr;
+        }
+        check(nmf_vm_query_fwd_live(p, f32(xyzt), M, reinterpret_cast<const int64_t*>(live), need_d ? a : nullptr, need_d ? b : nullptr,
+                                    need_a ? c : nullptr, need_a ? d : nullptr, bf16 ? 1 : 0, need_a ? of32(basis) : nullptr, o(sf),
+                                    o(sg), o(gr), o(nr), o(ap), o(cf), st(stream)),
+              "nmf_vm_query_fwd_live");
+        return {sf, sg, gr, nr, ap, cf};
+    }
     if (bf16) {        // bfloat16 copies of the tables (BASELINE configs[1]); fp32 arithmetic
         const uint16_t *a[3], *b[3], *c[3], *d[3];
         for (int i = 0; i < 3; ++i) {
@@ -328,7 +343,7 @@ Tensor shade_mix_fwd(const Tensor& V, const Tensor& f0, const Tensor& diff, cons
     return contrib;
 }
 
-py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream, int64_t pub = 0, int64_t pub_seq = 0) {
+py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream, int64_t pub = 0, int64_t pub_seq = 0, int64_t live = 0) {
     TimedScope _ts(__func__, stream);
     const int64_t M = counts.size(0), M1 = M > 0 ? M : 1;
     Tensor bidx = ie(counts, {M1}, at::kInt), row_off = ie(counts, {M + 1}, at::kLong), inv = ie(counts, {M1}, at::kInt);
@@ -337,7 +352,7 @@ py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream, int
     Tensor ws = ie(counts, {nbytes / 8}, at::kLong);
     Tensor rows;
     if (xyzt.has_value()) rows = at::empty({M1, 4}, counts.options().dtype(at::kFloat));
-    check(nmf_bounce_index_publish(M ? i32(counts) : nullptr, M, static_cast<int32_t*>(bidx.data_ptr()),
+    check(nmf_bounce_index_live(M ? i32(counts) : nullptr, M, reinterpret_cast<const int64_t*>(live), static_cast<int32_t*>(bidx.data_ptr()),
                                    static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
                                    static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()),
                                    (xyzt.has_value() && M) ? f32(*xyzt) : nullptr, xyzt.has_value() ? out(rows) : nullptr,
@@ -940,7 +955,11 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("march_count", &march_count);
     m.def("march_scan", &march_scan, py::arg("counts"), py::arg("max_samples"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0);
     m.def("march_fill", &march_fill);
-    m.def("vm_query_fwd", &vm_query_fwd);
+    m.def("vm_query_fwd", [](int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& dpk, const std::vector<Tensor>& dlk,
+                             const std::vector<Tensor>& apl, const std::vector<Tensor>& ali, const OT& basis, bool want_density,
+                             bool want_normal, bool want_app, bool want_coef, int64_t stream) {
+        return vm_query_fwd(p_addr, xyzt, dpk, dlk, apl, ali, basis, want_density, want_normal, want_app, want_coef, stream, 0);
+    });
     m.def("composite_fwd", &composite_fwd);
     m.def("segment_sum", &segment_sum);
     m.def("sat_lookup_fwd", &sat_lookup_fwd);
@@ -950,7 +969,8 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("heads_fwd", &heads_fwd);
     m.def("ggx_rays_fwd", &ggx_rays_fwd);
     m.def("shade_mix_fwd", &shade_mix_fwd);
-    m.def("bounce_index", &bounce_index, py::arg("counts"), py::arg("xyzt"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0);
+    m.def("bounce_index", &bounce_index, py::arg("counts"), py::arg("xyzt"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0,
+          py::arg("live") = 0);
     m.def("bounce_prep_fwd", &bounce_prep_fwd);
     m.def("ray_compose_fwd", &ray_compose_fwd);
     m.def("composite_bwd", &composite_bwd);

@@ -52,8 +52,9 @@ __device__ __forceinline__ int64_t block_scan_i64(int64_t v, int64_t* ws /*[17]*
 }
 
 __global__ void __launch_bounds__(IDX_CHUNK) k_idx_partial(const int32_t* __restrict__ counts, int64_t M,
-                                                          int64_t* __restrict__ chunk_sum) {
+                                                          int64_t* __restrict__ chunk_sum, const int64_t* __restrict__ M_live) {
     __shared__ int64_t ws[17];
+    if (M_live && *M_live < M) M = *M_live;          // (the launch was sized by a bound: nmf_bounce_index_live)
     const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + threadIdx.x;
     const int32_t c = i < M ? counts[i] : 0;
     const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
@@ -114,9 +115,11 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
                                                               int64_t* __restrict__ totals, int32_t* __restrict__ bidx,
                                                               int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
                                                               int32_t* __restrict__ inv, const float4* __restrict__ xyzt,
-                                                              float4* __restrict__ xyzt_rows, int64_t* pub, int64_t pub_seq) {
+                                                              float4* __restrict__ xyzt_rows, int64_t* pub, int64_t pub_seq,
+                                                              const int64_t* __restrict__ M_live) {
     __shared__ int64_t ws[17];
     __shared__ int64_t base_s;
+    if (M_live && *M_live < M) M = *M_live;
     const int tid = threadIdx.x;
     const int64_t cs = tid < n_chunks ? chunk_sum[tid] : 0;
     int64_t all;
@@ -413,14 +416,22 @@ extern "C" int64_t nmf_bounce_index_workspace_bytes(int64_t M) { return (cdiv(M 
 extern "C" int nmf_bounce_index(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
                                 int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
-    return nmf_bounce_index_publish(counts, M, bidx, row_off, cnt_rows, inv, totals, xyzt, xyzt_rows, workspace, workspace_bytes,
-                                    nullptr, 0, stream);
+    return nmf_bounce_index_live(counts, M, nullptr, bidx, row_off, cnt_rows, inv, totals, xyzt, xyzt_rows, workspace, workspace_bytes,
+                                 nullptr, 0, stream);
 }
 
 extern "C" int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off,
                                         int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
                                         void* workspace, int64_t workspace_bytes, void* publish_mapped_dev,
                                         int64_t publish_seq, void* stream) {
+    return nmf_bounce_index_live(counts, M, nullptr, bidx, row_off, cnt_rows, inv, totals, xyzt, xyzt_rows, workspace, workspace_bytes,
+                                 publish_mapped_dev, publish_seq, stream);
+}
+
+extern "C" int nmf_bounce_index_live(const int32_t* counts, int64_t M, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                                     int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
+                                     void* workspace, int64_t workspace_bytes, void* publish_mapped_dev,
+                                     int64_t publish_seq, void* stream) {
     int64_t* pub = static_cast<int64_t*>(publish_mapped_dev);
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_index: M < 0");
     NMF_REQUIRE(totals && row_off, NMF_EINVAL, "nmf_bounce_index: null");
@@ -440,10 +451,11 @@ extern "C" int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_
     NMF_REQUIRE(workspace_bytes >= nmf_bounce_index_workspace_bytes(M), NMF_EINVAL, "nmf_bounce_index: workspace too small");
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
     int64_t* chunk = static_cast<int64_t*>(workspace);
-    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk);
+    NMF_REQUIRE(!M_live || n_chunks <= IDX_CHUNK, NMF_ERANGE, "nmf_bounce_index_live: bound too large for a device-side count");
+    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, M_live);
     if (n_chunks <= IDX_CHUNK) {
         hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
-                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq);
+                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq, M_live);
     } else {
         hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
         hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,

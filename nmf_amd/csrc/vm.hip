@@ -241,9 +241,10 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
                                                 const float* __restrict__ basis, float* __restrict__ sigma_feat,
                                                 float* __restrict__ sigma, float* __restrict__ grad,
                                                 float* __restrict__ normal, float* __restrict__ app,
-                                                float* __restrict__ coef_out) {
+                                                float* __restrict__ coef_out, const int64_t* __restrict__ M_live) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    // M_live: the sample count still lives on the device (the launch was sized by a bound: nmf_vm_query_fwd_live)
+    if (m >= M || (M_live && m >= *M_live)) return;
     const int G = p.grid;
     float xn[3];
     normalized(p, xyzt[m], xn);
@@ -1374,7 +1375,7 @@ template <class TT>
 static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const float* xyzt, int64_t M, const TT* const dpk[3],
                              const TT* const dlk[3], const TT* const app_planes[3], const TT* const app_lines[3],
                              const float* basis, float* sigma_feat, float* sigma, float* grad, float* normal, float* app,
-                             float* coef, void* stream) {
+                             float* coef, void* stream, const int64_t* M_live = nullptr) {
     NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_fwd: params");
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(xyzt, NMF_EINVAL, "nmf_vm_query_fwd: xyzt null");
@@ -1385,6 +1386,8 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
     NMF_REQUIRE(!want_a || (app_planes && app_lines && app_planes[0] && app_planes[1] && app_planes[2] && app_lines[0] &&
                             app_lines[1] && app_lines[2] && (!app || basis)),
                 NMF_EINVAL, "nmf_vm_query_fwd: appearance tables missing");
+    NMF_REQUIRE(!M_live || (want_d && (grad || normal)), NMF_EINVAL,
+                "nmf_vm_query_fwd_live: only the general query (density with gradient / normal) takes a device-side count");
     if (want_d && !want_a && !grad && !normal) {      // density value only
         hipLaunchKernelGGL(k_vm_sigma<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<TT>(dpk, true), mkT<TT>(dlk, true), DP, DL, sigma_feat, sigma);
@@ -1399,7 +1402,7 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
     }
     hipLaunchKernelGGL(k_vm_fwd<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        (const float4*)xyzt, M, mkT<TT>(dpk, want_d), mkT<TT>(dlk, want_d), mkT<TT>(app_planes, want_a),
-                       mkT<TT>(app_lines, want_a), basis, sigma_feat, sigma, grad, normal, app, coef);
+                       mkT<TT>(app_lines, want_a), basis, sigma_feat, sigma, grad, normal, app, coef, M_live);
     NMF_CHECK_LAUNCH(what);
     return NMF_OK;
 }
@@ -1410,6 +1413,20 @@ extern "C" int nmf_vm_query_fwd(const nmf_vm_params* p, const float* xyzt, int64
                                 float* grad, float* normal, float* app, float* coef, void* stream) {
     return vm_query_fwd_impl<float>("nmf_vm_query_fwd", p, xyzt, M, dpk, dlk, app_planes, app_lines, basis, sigma_feat, sigma,
                                     grad, normal, app, coef, stream);
+}
+
+extern "C" int nmf_vm_query_fwd_live(const nmf_vm_params* p, const float* xyzt, int64_t M_cap, const int64_t* M_live,
+                                     const void* const dpk[3], const void* const dlk[3], const void* const app_planes[3],
+                                     const void* const app_lines[3], int32_t tables_bf16, const float* basis, float* sigma_feat,
+                                     float* sigma, float* grad, float* normal, float* app, float* coef, void* stream) {
+    NMF_REQUIRE(M_live, NMF_EINVAL, "nmf_vm_query_fwd_live: M_live null");
+    if (tables_bf16)
+        return vm_query_fwd_impl<uint16_t>("nmf_vm_query_fwd_live", p, xyzt, M_cap, (const uint16_t* const*)dpk, (const uint16_t* const*)dlk,
+                                           (const uint16_t* const*)app_planes, (const uint16_t* const*)app_lines, basis, sigma_feat,
+                                           sigma, grad, normal, app, coef, stream, M_live);
+    return vm_query_fwd_impl<float>("nmf_vm_query_fwd_live", p, xyzt, M_cap, (const float* const*)dpk, (const float* const*)dlk,
+                                    (const float* const*)app_planes, (const float* const*)app_lines, basis, sigma_feat, sigma, grad,
+                                    normal, app, coef, stream, M_live);
 }
 
 extern "C" int nmf_vm_query_sigma(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],

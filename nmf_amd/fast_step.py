@@ -148,25 +148,47 @@ class TrainPass:
         c, n = self._core, self.nerf
         rf, model, bgm, smp = n.rf, n.model, n.bg_module, n.sampler
         main = torch.cuda.current_stream()
+        # NMF_TABLES_2STREAMS=1 (R4 experiment): the two rebuild chains on a stream each, the env chain (SAT columns -> rows -> poles
+        # -> 5000 lookups -> SH projection, ~90 us, read by level 0's row preparation) first.  Measured: 1.542 -> 1.540 ms, nothing;
+        # one stream stays the default (a ninth stream has to share one of the eight hardware queues).
+        two = self.overlap and os.environ.get("NMF_TABLES_2STREAMS", "0") == "1"
         if self.overlap:
             tb = self._side.get("tables")
             if tb is None:
                 tb = self._side["tables"] = torch.cuda.Stream()
+            te = tb
+            if two:
+                te = self._side.get("env_tables")
+                if te is None:
+                    te = self._side["env_tables"] = torch.cuda.Stream()
             if self._table_events is None:
                 self._table_events = (torch.cuda.Event(), torch.cuda.Event())
             tb.wait_stream(main)                      # the optimizer update of the parameters was queued on the main stream
-            torch.cuda.set_stream(tb)
-        try:
-            tab = rf._fwd_tables()
-            hp, hW, hb, _, _ = model.diffuse_module.head_pass()
-            mlp_ws, mlp_bias, _, _ = model.brdf.mlp_pass()
+            if te is not tb:
+                te.wait_stream(main)
+        def field_tables():
+            if self.overlap:
+                torch.cuda.set_stream(tb)
+            r = (rf._fwd_tables(), model.diffuse_module.head_pass(), model.brdf.mlp_pass())
             if self.overlap:
                 self._table_events[0].record(tb)
-            env = bgm._tables()
-            sc = bgm._dev_scalars()
-            conv = bgm.get_spherical_harmonics(100)[1].reshape(9, 3)
+            return r
+
+        def env_tables():
             if self.overlap:
-                self._table_events[1].record(tb)
+                torch.cuda.set_stream(te)
+            r = (bgm._tables(), bgm._dev_scalars(), bgm.get_spherical_harmonics(100)[1].reshape(9, 3))
+            if self.overlap:
+                self._table_events[1].record(te)
+            return r
+
+        try:
+            if two:                                   # the env chain is the longer one: issued first
+                env, sc, conv = env_tables()
+                tab, (hp, hW, hb, _, _), (mlp_ws, mlp_bias, _, _) = field_tables()
+            else:
+                tab, (hp, hW, hb, _, _), (mlp_ws, mlp_bias, _, _) = field_tables()
+                env, sc, conv = env_tables()
         finally:
             if self.overlap:
                 torch.cuda.set_stream(main)

@@ -59,6 +59,7 @@ class DeviceNoise:
     generator outputs to call sites differs from draw-per-call."""
 
     pins = None
+    capacity_draws = True       # i.i.d. draws with no call order to reproduce: a caller may draw for a bound instead of the exact count
 
     def __init__(self, device, seed=0, pooled=True):
         self.device = torch.device(device)
