@@ -244,8 +244,8 @@ def cpu_baseline(budget_s=150.0, warm=1, timed=3):
                        f"each, {cores} threads (physical cores); early phase beside it",
                 early_phase=out["early"], steady_state=st,
                 protocol=f"{warm}+{timed} steps per phase within a {budget_s} s budget" if budget_s else f"{warm}+{timed} steps per phase (SURVEY 8d)",
-                protocol_full="profiles/r03_i_cpu_baseline_3_10.json (SURVEY 8d's 3 warm-up + 10 timed steps per phase on the GPU box's host: "
-                              "210 rays/s steady state, 551 rays/s early phase; `python bench.py --cpu-baseline-steps 3,10`)")
+                protocol_full="profiles/r04_cpu_baseline_3_10.json (SURVEY 8d's 3 warm-up + 10 timed steps per phase on the GPU box's host: "
+                              "213 rays/s steady state, 634 rays/s early phase; `python bench.py --cpu-baseline-steps 3,10`)")
 
 
 def counters_summary():

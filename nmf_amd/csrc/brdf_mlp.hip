@@ -793,23 +793,10 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
     }
 }
 
-// gradient element e of a workgroup partial (layout: k_brdf_mlp_bwd's `put` order x 64 lanes) += sum over the workgroups
-__global__ void __launch_bounds__(256)
-k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restrict__ gW0, float* __restrict__ gb0,
-                  float* __restrict__ gW2, float* __restrict__ gb2, float* __restrict__ gW4, float* __restrict__ gb4) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N_PERSIST * 64) return;
-    // up to 32 partials per thread in batches of 8 independent loads (the launch is bound by the latency of these loads, and
-    // every extra slice along y costs 9 408 more atomics onto the same addresses)
-    const int w0 = blockIdx.y * 32, w1 = min(n_wg, w0 + 32);
-    if (w0 >= w1) return;
-    float v = 0.f;
-    for (int wb = w0; wb < w1; wb += 8) {
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = wb + k < w1 ? partials[(int64_t)(wb + k) * (N_PERSIST * 64) + e] : 0.f;
-        v += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    }
+// gradient element e of a workgroup partial (layout: k_brdf_mlp_bwd's `put` order x 64 lanes) += v
+__device__ __forceinline__ void mlp_grad_emit(int e, float v, float* __restrict__ gW0, float* __restrict__ gb0,
+                                              float* __restrict__ gW2, float* __restrict__ gb2, float* __restrict__ gW4,
+                                              float* __restrict__ gb4) {
     const int idx = e >> 6, ln = e & 63, hh = ln >> 5, c = ln & 31;
     if (idx < 64) {                                   // dW2[a][b]: row = u2, column = u1
         const int a = idx >> 5, b = (idx >> 4) & 1, q = idx & 15;
@@ -830,6 +817,33 @@ k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restric
         atomicAdd(gb2 + 32 * (idx - 142) + c, v);
     } else {
         atomicAdd(gb4 + (idx - 144), v);
+    }
+}
+
+// sum of the workgroup partials, one atomic per gradient element and CALL (R4).  A workgroup takes 32 consecutive elements (one
+// 128-byte run of every partial) and splits the partials over its eight 32-lane groups -- a lane reads n_wg / 8 values in batches of
+// eight independent loads --, the groups meet in LDS.  Rounds 3's form (a thread per element and slice of 32 partials, one atomic
+// per slice) took 18-31 us for 4-9 MB: four dependent load batches per thread and 3-8 atomics per address; finer slices were
+// worse (8 partials per thread: 112 -> 169 us for the whole backward at 242 k rays -- same-address float atomics retire one by one).
+__global__ void __launch_bounds__(256)
+k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restrict__ gW0, float* __restrict__ gb0,
+                  float* __restrict__ gW2, float* __restrict__ gb2, float* __restrict__ gW4, float* __restrict__ gb4) {
+    __shared__ float s_part[8][32];
+    const int el = threadIdx.x & 31, wl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;                     // N_PERSIST * 64 is a multiple of 32
+    float v = 0.f;
+    for (int wb = wl; wb < n_wg; wb += 64) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = wb + 8 * k < n_wg ? partials[(int64_t)(wb + 8 * k) * (N_PERSIST * 64) + e] : 0.f;
+        v += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+    s_part[wl][el] = v;
+    __syncthreads();
+    if (wl == 0) {
+        float t = ((s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el])) +
+                  ((s_part[4][el] + s_part[5][el]) + (s_part[6][el] + s_part[7][el]));
+        mlp_grad_emit(e, t, gW0, gb0, gW2, gb2, gW4, gb4);
     }
 }
 
@@ -900,8 +914,9 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
                        diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
                        d_out, d_feat, partials);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
-    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(cdiv(N_PERSIST * 64, 256), cdiv(grid, 32)), dim3(256), 0,
-                       (hipStream_t)stream, partials, (int)grid, gW0, gb0, gW2, gb2, gW4, gb4);
+    static_assert((N_PERSIST * 64) % 32 == 0, "k_brdf_mlp_reduce takes 32 elements per workgroup");
+    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
+                       gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;
 }

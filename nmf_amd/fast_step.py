@@ -38,7 +38,9 @@ MLP_SIDE_WGS_ENV = 96            # workgroups next to that env-map adjoint alone
 WALK_SIDE_MIN_SAMPLES = 200000
 LAUNCH_DIET = 1         # 0: the separate loss / background-adjoint / head-adjoint launches of round 2 (A/B knob)
 WALK_LATE = 0           # 1: that walk is queued after the levels below instead of before them (A/B knob)
-MLP_SIDE_WGS = 96       # persistent workgroups of a BRDF-MLP backward that shares the chip.  Round 3 (split-bf16 kernel, one
+MLP_SIDE_WGS = 192      # persistent workgroups of a BRDF-MLP backward that shares the chip.  R4: 192 since the partial sums of the
+                        # workgroups cost one atomic per gradient element and call (k_brdf_mlp_reduce): in-process A/B 96: 1.521 ms,
+                        # 128: 1.510, 160: 1.518, 192: 1.497-1.503, 224: 1.506, 256: 1.505.  Round 3 (split-bf16 kernel, one
                         # workgroup of 4 waves and 150 KB of LDS per CU): in-process A/B 32: 1.812 ms, 64: 1.628, 96: 1.608,
                         # 128: 1.625, 192: 1.678, 256: 1.696 -- the launch is short now, and every CU it occupies is a CU whose
                         # LDS the kernels of the main stream cannot use (round 2, fp32 kernel: 192 / 256 best)
