@@ -761,6 +761,7 @@ __global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __rest
                                                            int32_t* __restrict__ n_items) {
     __shared__ int64_t ws[SB_THREADS / 64];
     __shared__ int64_t wsum[SB_THREADS / 64];
+    __shared__ int32_t s_io[SB_CHUNK + 1];       // first work item of every brick of this chunk (R4: the item list is written in parallel)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // totals of the chunks before this one (at most a few hundred values)
     int64_t before = 0;
@@ -793,9 +794,26 @@ __global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __rest
             offsets[i0 + q] = so;
             int pos = so;
             for (int k = 0; k < kc; ++k) { cursor[(i0 + q) * kc + k] = pos; pos += ck[q][k]; }
-            for (int t = 0; t < ni[q]; ++t) items[io + t] = make_int2(i0 + q, t);
+            s_io[tid * SB_PER + q] = io;
+        } else {
+            s_io[tid * SB_PER + q] = (int)(run >> 32);
         }
         run += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    if (tid == SB_THREADS - 1) s_io[SB_CHUNK] = (int)(run >> 32);
+    __syncthreads();
+    // the work items of this chunk's bricks, a lane per item: a thread per BRICK wrote its items one after the other, and the few
+    // surface bricks that hold thousands of samples made the launch 15 us long (32 k counters: a 3 us job)
+    {
+        const int first = s_io[0], last = s_io[SB_CHUNK];
+        for (int j = first + tid; j < last; j += SB_THREADS) {
+            int lo = 0, hi = SB_CHUNK;                 // the LAST brick b of the chunk with s_io[b] <= j (empty bricks share a value)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_io[mid] <= j) lo = mid; else hi = mid;
+            }
+            items[j] = make_int2(blockIdx.x * SB_CHUNK + lo, j - s_io[lo]);
+        }
     }
     if (blockIdx.x == gridDim.x - 1 && tid == SB_THREADS - 1) {       // the last thread of the last chunk holds the grand total
         offsets[n] = (int)(run & 0xffffffffll);
