@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 104
+#define NMF_ABI_VERSION 105
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -416,6 +416,23 @@ int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const fl
                      float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups);
+/* The same two calls with the weights as a PACKED IMAGE (R4): what the kernels stage into LDS in front of their first tile --
+ * the split-bf16 planes of W0 | b0, W2 (forward: three terms; backward: two terms plus W2^T and W0[:, :24]^T) and the fp32 rows
+ * of the last layer -- written once per weight update by nmf_brdf_mlp_pack (one launch of two workgroups) into
+ * nmf_brdf_mlp_image_bytes() bytes of device memory (16-byte aligned).  A launch then starts with a byte copy instead of the
+ * conversion (the parameters are those of modules/brdf.py:177-261's `self.mlp`, which change only in the optimizer step:
+ * train.py:733-735).  Results are bit-identical to the unpacked calls. */
+int64_t nmf_brdf_mlp_image_bytes(void);
+int nmf_brdf_mlp_pack(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4, const float* b4,
+                      void* image, int64_t image_bytes, void* stream);
+int nmf_brdf_mlp_fwd_packed(const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                            const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
+                            uint32_t* act_mask, int32_t max_workgroups, void* stream);
+int nmf_brdf_mlp_bwd_packed(const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                            const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
+                            const uint32_t* act_mask, const float* d_out, float* d_feat, float* gW0, float* gb0,
+                            float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
+                            int64_t workspace_bytes, void* stream);
 /* out[s][0:D] = sum_{r in segment s} vals[r*row_stride + 0:D], D <= 64 (adjoint of the feature gather). */
 int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32_t D, const int64_t* offsets,
                          int64_t n_seg, float* out, void* stream);

@@ -38,6 +38,14 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Measurement switches of the backward (a build with -DNMF_MLP_KNOCK=bits leaves a phase out; results are then wrong, the time
+// difference is that phase's cost -- the kernel has no profiler view finer than a launch): 1 feature-row adjoint, 2 ISH
+// encoding, 4 layer 2 as values + dW4, 8 dW0's trailing columns, 16 dW0, 32 dW2, 64 no tile loop, 128 return behind the prologue.
+// R4, 242 k rays, 95 us: 14 / 2 / 6 / 1 / 5.5 / 8 us; prologue 10.3 us (4.5 of it the weight conversion), epilogue 3.3 us, the
+// first tile of a wave 17 us against 8.2 us for the later ones (tools/mlp_bench.py with NMF_HIP_LIB=<variant>).
+#ifndef NMF_MLP_KNOCK
+#define NMF_MLP_KNOCK 0
+#endif
 constexpr int IN = NMF_MLP_IN;     // 66
 constexpr int HID = NMF_MLP_HID;   // 64
 constexpr int RT = 32;             // rays per wave tile
@@ -272,6 +280,39 @@ __device__ __forceinline__ void stage_weights(char* s, int off_w0, int off_w2, i
     }
 }
 
+// The complete shared region of a kernel (weight images + the fp32 rows of the last layer) from the six parameter tensors ...
+template <int NT>
+__device__ __forceinline__ void stage_fwd(char* smem, const MlpW& w, int t) {
+    stage_weights<3, false, NT>(smem, F_W0, F_W2, 0, 0, w, t);
+    float* W4w = reinterpret_cast<float*>(smem + F_W4);
+    for (int i = t; i < 3 * HID; i += NT) W4w[i] = w.W4[i];
+    if (t < HID) reinterpret_cast<float*>(smem + F_B2)[t] = w.b2[t];
+    if (t < 4) reinterpret_cast<float*>(smem + F_B4)[t] = w.b4[t];
+}
+template <int NT>
+__device__ __forceinline__ void stage_bwd(char* smem, const MlpW& w, int t) {
+    stage_weights<2, true, NT>(smem, B_W0, B_W2, B_W2T, B_WFT, w, t);
+    float* W4w = reinterpret_cast<float*>(smem + B_W4);
+    for (int i = t; i < 3 * HID; i += NT) W4w[i] = w.W4[i];
+    if (t < HID) reinterpret_cast<float*>(smem + B_B2)[t] = w.b2[t];
+}
+// ... or as a byte copy of what k_brdf_mlp_pack left in memory (nmf_brdf_mlp_pack, once per optimizer step): every 16-byte load
+// of a thread in flight at once and ~70 instructions instead of the ~2000 of the conversion (a workgroup runs its prologue once,
+// from a cold instruction cache): 6 us less per launch, forward and backward.
+template <int BYTES, int NT>
+__device__ __forceinline__ void load_image(char* smem, const uint4* __restrict__ image, int t) {
+    static_assert(BYTES % 16 == 0, "images are copied in 16-byte pieces");
+    constexpr int N = BYTES / 16, G = (N + NT - 1) / NT;
+    uint4 v[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) v[k] = image[min(t + k * NT, N - 1)];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        if (t + k * NT < N) reinterpret_cast<uint4*>(smem)[t + k * NT] = v[k];
+}
+constexpr int IMG_FWD = (FWD_SHARED + 255) & ~255;      // offset of the backward's image inside a packed image
+constexpr int IMG_BYTES = IMG_FWD + ((BWD_SHARED + 255) & ~255);
+
 // The global inputs of one lane: ray (lane & 31) of a tile, lane half 0: half vector, half 1: diff vector, both: the
 // feature row (half 1 does not use it; loading it everywhere keeps the code free of branches, so that the compiler can
 // schedule it between the matrix instructions of the tile before).  Loaded ahead in two stages: the row index first, what
@@ -306,6 +347,10 @@ __device__ __forceinline__ void build_x(char* x, const RayIn& in, int ray, int h
     float v[48];
     {
         const float kappa = 1.f / (in.rough + 1e-3f);
+        if constexpr (NMF_MLP_KNOCK & 2) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) v[i] = kappa;
+        } else
         ish18(in.d0, in.d1, in.d2, kappa, v);
         v[18] = in.d0; v[19] = in.d1; v[20] = in.d2;
     }
@@ -374,18 +419,15 @@ __global__ void __launch_bounds__(64 * FWD_WAVES)
 k_brdf_mlp_fwd(MlpW w, const float* __restrict__ half_v, const float* __restrict__ diff_v,
                const float* __restrict__ feat_src, const float* __restrict__ rough_src,
                const int32_t* __restrict__ src_idx, int64_t R, float out_bias, float* __restrict__ out,
-               uint4* __restrict__ act_mask) {
+               uint4* __restrict__ act_mask, const uint4* __restrict__ image) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
     const int64_t n_tiles = (R + RT - 1) / RT, stride = (int64_t)gridDim.x * FWD_WAVES;
     int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
     RayIn cur;
     ray_in_stage1(cur, tile, R, ray, h, half_v, diff_v, src_idx);
-    stage_weights<3, false, 64 * FWD_WAVES>(smem, F_W0, F_W2, 0, 0, w, t);
-    float* W4w = reinterpret_cast<float*>(smem + F_W4);
-    for (int i = t; i < 3 * HID; i += 64 * FWD_WAVES) W4w[i] = w.W4[i];
-    if (t < HID) reinterpret_cast<float*>(smem + F_B2)[t] = w.b2[t];
-    if (t < 4) reinterpret_cast<float*>(smem + F_B4)[t] = w.b4[t];
+    if (image) load_image<FWD_SHARED, 64 * FWD_WAVES>(smem, image, t);
+    else stage_fwd<64 * FWD_WAVES>(smem, w, t);
     ray_in_stage2(cur, feat_src, rough_src);
     char* x = smem + FWD_SHARED + wave * FWD_PRIVATE;      // input planes, then the planes of H1
     const float* W4s = reinterpret_cast<const float*>(smem + F_W4);
@@ -494,7 +536,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                const float* __restrict__ feat_src, const float* __restrict__ rough_src,
                const int32_t* __restrict__ src_idx, int64_t R, const float* __restrict__ fwd_out,
                const uint4* __restrict__ act_mask, const float* __restrict__ d_out, float* __restrict__ d_feat,
-               float* __restrict__ partials) {
+               float* __restrict__ partials, const uint4* __restrict__ image) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
@@ -521,10 +563,8 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
     Adj adj;
     ray_in_stage1(cur, tile, R, ray, h, half_v, diff_v, src_idx);
     load_adj(adj, cur);
-    stage_weights<2, true, NT>(smem, B_W0, B_W2, B_W2T, B_WFT, w, t);
-    float* W4w = reinterpret_cast<float*>(smem + B_W4);
-    for (int i = t; i < 3 * HID; i += NT) W4w[i] = w.W4[i];
-    if (t < HID) reinterpret_cast<float*>(smem + B_B2)[t] = w.b2[t];
+    if (image) load_image<BWD_SHARED, NT>(smem, image + IMG_FWD / 16, t);
+    else stage_bwd<NT>(smem, w, t);
     ray_in_stage2(cur, feat_src, rough_src);
     char* priv = smem + BWD_SHARED + wave * BWD_PRIVATE;
     char* x = priv;                                                 // input planes
@@ -559,6 +599,8 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
     __syncthreads();
     build_x<2>(x, cur, ray, h);
     __builtin_amdgcn_wave_barrier();
+    if constexpr (NMF_MLP_KNOCK & 128) return;
+    if constexpr (!(NMF_MLP_KNOCK & 64))
     for (; tile < n_tiles; tile += stride) {
         // the input planes of this tile are in LDS; the row indices / adjoints of the next one are requested now
         RayIn nxt;
@@ -600,6 +642,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
             h1u[1] = transpose_block(hb[2], hb[3], e0, e1, nullptr);
             // dW4[j][u] += sum_ray g[ray][j] relu(H2)[ray][u]   (the 16 adjoint rows requested in two batches, then used)
             const float bu0 = b2s[ray], bu1 = b2s[32 + ray];
+            if constexpr (!(NMF_MLP_KNOCK & 4))
 #pragma unroll
             for (int qb = 0; qb < 16; qb += 8) {
                 floatx4v gv[8];
@@ -645,6 +688,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                 d1, [&](int ub, int kk) { return ldop<2>(smem, B_W2T + 32 * ub * SHB + oh + 32 * kk, PW2); },
                 [&](int, int kk) { return dh[kk]; });
             // dW2 += dH2^T H1, db2 += column sums of dH2 (register operands only)
+            if constexpr (!(NMF_MLP_KNOCK & 32))
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const UOp d2u = transpose_block(dh[2 * a], dh[2 * a + 1], e0, e1, &accb2[a]);
@@ -677,6 +721,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
             UOp d1u[2];
             d1u[0] = transpose_block(dh[0], dh[1], e0, e1, nullptr);
             d1u[1] = transpose_block(dh[2], dh[3], e0, e1, nullptr);
+            if constexpr (!(NMF_MLP_KNOCK & 16))
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const UOp xu = transpose_block(ldop<2>(x, ox + 64 * cb, PX), ldop<2>(x, ox + 64 * cb + 32, PX), e0, e1, nullptr);
@@ -688,7 +733,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                         for (int a = 0; a < 2; ++a)
                             mfma_acc(accW0[a][cb], d1u[a].k[kp].p[Terms<2>::A[i]], xu.k[kp].p[Terms<2>::B[i]]);
             }
-            {
+            if constexpr (!(NMF_MLP_KNOCK & 8)) {
                 const Op<2> xt = ldop<2>(x, ox + 128, PX);
                 floatx16 th = {0}, tl = {0};
                 th = mfma(xt.p[0], e0, th);
@@ -714,10 +759,13 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         __builtin_amdgcn_wave_barrier();
         build_x<2>(x, nxt, ray, h);
         // ---- adjoint of the gathered feature rows (dx: lane = ray, registers = columns 8 q + 4 h + i): the rays of a bounce row
-        //      are consecutive, so the tile's 32 x 24 block goes through LDS once (the planes of dH1 are in registers by now),
-        //      24 lanes walk it ray by ray and issue ONE atomic per (row, column) run -- instead of [R][24] floats to memory and a
-        //      segmented-sum launch behind this kernel.  The run boundaries are wave-uniform (v_readlane of the row index).
-        {
+        //      are consecutive, so the tile's 32 x 24 block goes through LDS once (the planes of dH1 are in registers by now) and
+        //      ONE atomic per (row, column, half tile) leaves -- instead of [R][24] floats to memory and a segmented-sum launch
+        //      behind this kernel.  Lanes 0-23 / 24-47 take column (lane % 24) of rays 0-15 / 16-31: sixteen independent LDS reads,
+        //      then a wave-uniform loop over the RUNS of equal row indices (a ballot of the run starts; 1-4 per tile), each run a
+        //      masked sum of the registers.  (R3 walked the 32 rays one by one on 24 lanes, an LDS round trip and a branch per ray:
+        //      14 of the 95 us of a 242 k-ray launch.)
+        if constexpr (!(NMF_MLP_KNOCK & 1)) {
             float* xs = reinterpret_cast<float*>(pl);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -725,20 +773,26 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                 *reinterpret_cast<floatx4v*>(xs + ray * 24 + 8 * q + 4 * h) = v;
             }
             __builtin_amdgcn_wave_barrier();
-            const int brow = (int)cur.b, col = lane < 24 ? lane : 0;
-            int prev = __builtin_amdgcn_readlane(brow, 0);
-            float acc = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < RT; ++j) {
-                const int bj = __builtin_amdgcn_readlane(brow, j);
-                if (bj != prev) {
-                    if (lane < 24) atomicAdd(d_feat + (int64_t)prev * 24 + lane, acc);
-                    acc = 0.f;
-                    prev = bj;
-                }
-                acc += xs[j * 24 + col];
+            const int part = lane >= 24 ? 1 : 0, col = lane - 24 * part;       // (lanes 48-63: no column, they only vote)
+            const bool owner = lane < 48;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = xs[(16 * part + j) * 24 + (owner ? col : 0)];
+            const int brow = (int)cur.b;                                         // lanes l and l + 32 hold the same ray
+            const int before = __shfl_up(brow, 1, 64);
+            uint32_t starts = (uint32_t)__ballot(lane < 32 && (lane == 0 || brow != before));
+            while (starts) {
+                const int s = __builtin_ctz(starts);
+                starts &= starts - 1;
+                const int e = starts ? __builtin_ctz(starts) : 32;
+                const int row = __builtin_amdgcn_readlane(brow, s);
+                // rays [s, e) as bits of this lane's sixteen
+                const uint32_t sel = (uint32_t)((((1ull << e) - 1ull) & ~((1ull << s) - 1ull)) >> (16 * part)) & 0xffffu;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += (sel >> j) & 1u ? v[j] : 0.f;
+                if (owner && sel) atomicAdd(d_feat + (int64_t)row * 24 + col, acc);
             }
-            if (lane < 24) atomicAdd(d_feat + (int64_t)prev * 24 + lane, acc);
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
@@ -847,12 +901,49 @@ k_brdf_mlp_reduce(const float* __restrict__ partials, int n_wg, float* __restric
     }
 }
 
+// both images of a packed weight set: workgroup 0 the forward's (three bf16 terms), workgroup 1 the backward's (two terms, W2^T,
+// W0[:, :24]^T), each staged exactly as the kernels stage them and copied out byte by byte
+__global__ void __launch_bounds__(256) k_brdf_mlp_pack(MlpW w, uint4* __restrict__ image) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int bytes = blockIdx.x == 0 ? FWD_SHARED : BWD_SHARED;
+    for (int i = t; i < bytes / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);      // (the row pads)
+    __syncthreads();
+    if (blockIdx.x == 0) stage_fwd<256>(smem, w, t);
+    else stage_bwd<256>(smem, w, t);
+    __syncthreads();
+    uint4* dst = image + (blockIdx.x == 0 ? 0 : IMG_FWD / 16);
+    for (int i = t; i < bytes / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
+}
+
 }  // namespace
 
 static int check_w(const float* const* p) {
     for (int i = 0; i < 6; ++i)
         if (!p[i]) return 0;
     return 1;
+}
+
+static int set_lds_once(const void* fn, int bytes, const char* what) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e == hipSuccess ? NMF_OK : nmf_fail((int)e, what);
+}
+
+static int mlp_fwd_impl(const MlpW& w, const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                        const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out, uint32_t* act_mask,
+                        int32_t max_workgroups, void* stream) {
+    NMF_REQUIRE(half_vec && diff_vec && feat_src && rough_src && out, NMF_EINVAL, "nmf_brdf_mlp_fwd: null");
+    static const int lds = set_lds_once((const void*)k_brdf_mlp_fwd, FWD_LDS, "nmf_brdf_mlp_fwd: hipFuncSetAttribute");
+    if (lds != NMF_OK) return lds;
+    const int64_t wgs = cdiv(cdiv(R, RT), FWD_WAVES);
+    int64_t cap = 256;                                  // one workgroup per CU (127 KB of LDS)
+    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
+    const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
+    hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(64 * FWD_WAVES), FWD_LDS, (hipStream_t)stream, w, half_vec,
+                       diff_vec, feat_src, rough_src, src_idx, R, out_bias, out, reinterpret_cast<uint4*>(act_mask),
+                       static_cast<const uint4*>(image));
+    NMF_CHECK_LAUNCH("nmf_brdf_mlp_fwd");
+    return NMF_OK;
 }
 
 extern "C" int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
@@ -862,22 +953,40 @@ extern "C" int nmf_brdf_mlp_fwd(const float* W0, const float* b0, const float* W
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_fwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
-    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && out, NMF_EINVAL, "nmf_brdf_mlp_fwd: null");
-    MlpW w{W0, b0, W2, b2, W4, b4};
-    hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_fwd: hipFuncSetAttribute");
-    const int64_t wgs = cdiv(cdiv(R, RT), FWD_WAVES);
-    int64_t cap = 256;                                  // one workgroup per CU (127 KB of LDS)
-    if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
-    const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
-    hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(64 * FWD_WAVES), FWD_LDS, (hipStream_t)stream, w, half_vec,
-                       diff_vec, feat_src, rough_src, src_idx, R, out_bias, out, reinterpret_cast<uint4*>(act_mask));
-    NMF_CHECK_LAUNCH("nmf_brdf_mlp_fwd");
+    NMF_REQUIRE(check_w(ws), NMF_EINVAL, "nmf_brdf_mlp_fwd: null");
+    return mlp_fwd_impl(MlpW{W0, b0, W2, b2, W4, b4}, nullptr, half_vec, diff_vec, feat_src, rough_src, src_idx, R, out_bias, out,
+                        act_mask, max_workgroups, stream);
+}
+
+extern "C" int64_t nmf_brdf_mlp_image_bytes(void) { return IMG_BYTES; }
+
+extern "C" int nmf_brdf_mlp_pack(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
+                                 const float* b4, void* image, int64_t image_bytes, void* stream) {
+    const float* ws[6] = {W0, b0, W2, b2, W4, b4};
+    NMF_REQUIRE(check_w(ws) && image, NMF_EINVAL, "nmf_brdf_mlp_pack: null");
+    NMF_REQUIRE(image_bytes >= IMG_BYTES && ((uintptr_t)image & 15) == 0, NMF_EINVAL,
+                "nmf_brdf_mlp_pack: image too small (nmf_brdf_mlp_image_bytes) or not 16-byte aligned");
+    constexpr int lds_bytes = FWD_SHARED > BWD_SHARED ? FWD_SHARED : BWD_SHARED;
+    static const int lds = set_lds_once((const void*)k_brdf_mlp_pack, lds_bytes, "nmf_brdf_mlp_pack: hipFuncSetAttribute");
+    if (lds != NMF_OK) return lds;
+    hipLaunchKernelGGL(k_brdf_mlp_pack, dim3(2), dim3(256), lds_bytes, (hipStream_t)stream, MlpW{W0, b0, W2, b2, W4, b4},
+                       static_cast<uint4*>(image));
+    NMF_CHECK_LAUNCH("nmf_brdf_mlp_pack");
     return NMF_OK;
 }
 
+extern "C" int nmf_brdf_mlp_fwd_packed(const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                                       const float* rough_src, const int32_t* src_idx, int64_t R, float out_bias, float* out,
+                                       uint32_t* act_mask, int32_t max_workgroups, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_fwd_packed: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(image && ((uintptr_t)image & 15) == 0, NMF_EINVAL, "nmf_brdf_mlp_fwd_packed: image null or not 16-byte aligned");
+    return mlp_fwd_impl(MlpW{}, image, half_vec, diff_vec, feat_src, rough_src, src_idx, R, out_bias, out, act_mask, max_workgroups,
+                        stream);
+}
+
 static unsigned bwd_grid(int64_t R, int32_t max_workgroups) {
-    // One workgroup of 4 waves per CU (150 KB of LDS, one wave per SIMD).  Every workgroup stages the weight images (~5 us)
+    // One workgroup of 4 waves per CU (150 KB of LDS, one wave per SIMD).  Every workgroup stages the weight images
     // and writes a 37 KB partial, so short launches use fewer of them: at least 2 tiles per wave (45 k rays: 54 us against 63
     // with 4 tiles per wave).
     const int64_t wgs = cdiv(cdiv(R, RT), BWD_WAVES * 2);
@@ -890,6 +999,31 @@ extern "C" int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workg
     return R <= 0 ? 0 : (int64_t)bwd_grid(R, max_workgroups) * N_PERSIST * 64 * (int64_t)sizeof(float);
 }
 
+static int mlp_bwd_impl(const MlpW& w, const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                        const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out, const uint32_t* act_mask,
+                        const float* d_out, float* d_feat, float* gW0, float* gb0, float* gW2, float* gb2, float* gW4, float* gb4,
+                        int32_t max_workgroups, void* workspace, int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_feat && gW0 && gb0 && gW2 &&
+                    gb2 && gW4 && gb4,
+                NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
+    NMF_REQUIRE(workspace && workspace_bytes >= nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups), NMF_EINVAL,
+                "nmf_brdf_mlp_bwd: workspace too small (nmf_brdf_mlp_bwd_workspace_bytes)");
+    static_assert(BWD_WAVES * N_PERSIST * 64 * 4 <= BWD_LDS, "the per-wave sums fit into the kernel's LDS");
+    static const int lds = set_lds_once((const void*)k_brdf_mlp_bwd, BWD_LDS, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
+    if (lds != NMF_OK) return lds;
+    const unsigned grid = bwd_grid(R, max_workgroups);
+    float* partials = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, half_vec,
+                       diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
+                       d_out, d_feat, partials, static_cast<const uint4*>(image));
+    NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
+    static_assert((N_PERSIST * 64) % 32 == 0, "k_brdf_mlp_reduce takes 32 elements per workgroup");
+    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
+                       gb0, gW2, gb2, gW4, gb4);
+    NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
+    return NMF_OK;
+}
+
 extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                                 const float* b4, const float* half_vec, const float* diff_vec, const float* feat_src,
                                 const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
@@ -899,24 +1033,19 @@ extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd: R < 0");
     if (R == 0) return NMF_OK;
     const float* ws[6] = {W0, b0, W2, b2, W4, b4};
-    NMF_REQUIRE(check_w(ws) && half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_feat &&
-                    gW0 && gb0 && gW2 && gb2 && gW4 && gb4,
-                NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
-    NMF_REQUIRE(workspace && workspace_bytes >= nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups), NMF_EINVAL,
-                "nmf_brdf_mlp_bwd: workspace too small (nmf_brdf_mlp_bwd_workspace_bytes)");
-    static_assert(BWD_WAVES * N_PERSIST * 64 * 4 <= BWD_LDS, "the per-wave sums fit into the kernel's LDS");
-    MlpW w{W0, b0, W2, b2, W4, b4};
-    hipError_t e = hipFuncSetAttribute((const void*)k_brdf_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
-    const unsigned grid = bwd_grid(R, max_workgroups);
-    float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, half_vec,
-                       diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
-                       d_out, d_feat, partials);
-    NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
-    static_assert((N_PERSIST * 64) % 32 == 0, "k_brdf_mlp_reduce takes 32 elements per workgroup");
-    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
-                       gb0, gW2, gb2, gW4, gb4);
-    NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
-    return NMF_OK;
+    NMF_REQUIRE(check_w(ws), NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
+    return mlp_bwd_impl(MlpW{W0, b0, W2, b2, W4, b4}, nullptr, half_vec, diff_vec, feat_src, rough_src, src_idx, R, fwd_out, act_mask,
+                        d_out, d_feat, gW0, gb0, gW2, gb2, gW4, gb4, max_workgroups, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nmf_brdf_mlp_bwd_packed(const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                                       const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out,
+                                       const uint32_t* act_mask, const float* d_out, float* d_feat, float* gW0, float* gb0,
+                                       float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd_packed: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(image && ((uintptr_t)image & 15) == 0, NMF_EINVAL, "nmf_brdf_mlp_bwd_packed: image null or not 16-byte aligned");
+    return mlp_bwd_impl(MlpW{}, image, half_vec, diff_vec, feat_src, rough_src, src_idx, R, fwd_out, act_mask, d_out, d_feat, gW0,
+                        gb0, gW2, gb2, gW4, gb4, max_workgroups, workspace, workspace_bytes, stream);
 }

@@ -293,19 +293,41 @@ std::tuple<Tensor, Tensor> expand_segments(const Tensor& offsets, int64_t n_seg,
 // returns {out [R,3], act_mask [R,4] int32 (undefined tensor without with_mask)}
 std::tuple<Tensor, Tensor> brdf_mlp_fwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec,
                                         const Tensor& feat_src, const Tensor& rough_src, const OT& src_idx, double out_bias,
-                                        bool with_mask, int64_t max_workgroups, int64_t stream) {
+                                        bool with_mask, int64_t max_workgroups, int64_t stream, const OT& image = c10::nullopt) {
+    // image: the packed weights (brdf_mlp_pack) -- the launch copies them instead of converting `w`, which may then be empty
     TimedScope _ts(__func__, stream);
-    if (w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
+    const bool packed = image.has_value() && image->defined();
+    if (!packed && w.size() != 6) fail("brdf_mlp_fwd: six weight tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor o = fe(half_vec, {R, 3});
     Tensor mask;
     if (with_mask) mask = ie(half_vec, {R, 4}, at::kInt);
-    check(nmf_brdf_mlp_fwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
-                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
-                           with_mask ? static_cast<uint32_t*>(mask.data_ptr()) : nullptr, (int32_t)max_workgroups,
-                           st(stream)),
-          "nmf_brdf_mlp_fwd");
+    if (packed)
+        check(nmf_brdf_mlp_fwd_packed(image->data_ptr(), f32(half_vec), f32(diff_vec), f32(feat_src), f32(rough_src),
+                                      optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
+                                      with_mask ? static_cast<uint32_t*>(mask.data_ptr()) : nullptr, (int32_t)max_workgroups,
+                                      st(stream)),
+              "nmf_brdf_mlp_fwd_packed");
+    else
+        check(nmf_brdf_mlp_fwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
+                               f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, (float)out_bias, out(o),
+                               with_mask ? static_cast<uint32_t*>(mask.data_ptr()) : nullptr, (int32_t)max_workgroups,
+                               st(stream)),
+              "nmf_brdf_mlp_fwd");
     return {o, mask};
+}
+
+// the packed image of six weight tensors (into `into` when given: the training pass keeps one buffer)
+Tensor brdf_mlp_pack(const std::vector<Tensor>& w, const OT& into, int64_t stream) {
+    TimedScope _ts(__func__, stream);
+    if (w.size() != 6) fail("brdf_mlp_pack: six weight tensors expected");
+    const int64_t n = nmf_brdf_mlp_image_bytes();
+    Tensor img = (into.has_value() && into->defined()) ? *into : at::empty({n}, w[0].options().dtype(at::kByte));
+    if (img.scalar_type() != at::kByte || !img.is_contiguous() || img.numel() < n || !img.is_cuda())
+        fail("brdf_mlp_pack: `into` must be a contiguous device uint8 tensor of nmf_brdf_mlp_image_bytes() bytes");
+    check(nmf_brdf_mlp_pack(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), img.data_ptr(), img.numel(), st(stream)),
+          "nmf_brdf_mlp_pack");
+    return img;
 }
 
 Tensor heads_fwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, int64_t stream) {
@@ -451,9 +473,11 @@ OT sat_lookup_bwd(const Tensor& sat, const Tensor& dirs, const Tensor& sa, doubl
 
 Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const Tensor& diff_vec, const Tensor& feat_src,
                     const Tensor& rough_src, const OT& src_idx, const Tensor& fwd_out, const Tensor& act_mask,
-                    const Tensor& d_out, const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream) {
+                    const Tensor& d_out, const std::vector<Tensor>& grads, int64_t max_workgroups, int64_t stream,
+                    const OT& image = c10::nullopt) {
     TimedScope _ts(__func__, stream);
-    if (w.size() != 6 || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
+    const bool packed = image.has_value() && image->defined();
+    if ((!packed && w.size() != 6) || grads.size() != 6) fail("brdf_mlp_bwd: six weight / gradient tensors expected");
     const int64_t R = half_vec.size(0);
     Tensor d_feat = at::zeros({feat_src.size(0), 24}, half_vec.options().dtype(at::kFloat));      // summed per row of feat_src
     Tensor go = d_out.contiguous();
@@ -461,11 +485,18 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
     const int64_t nws = nmf_brdf_mlp_bwd_workspace_bytes(R, (int32_t)max_workgroups);
     Tensor ws = fe(half_vec, {std::max<int64_t>(nws, 4) / 4});
-    check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
-                           f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, f32(fwd_out),
-                           static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_feat), g[0], g[1], g[2], g[3], g[4], g[5], (int32_t)max_workgroups, out(ws), nws,
-                           st(stream)),
-          "nmf_brdf_mlp_bwd");
+    if (packed)
+        check(nmf_brdf_mlp_bwd_packed(image->data_ptr(), f32(half_vec), f32(diff_vec), f32(feat_src), f32(rough_src),
+                                      optr<const int32_t>(src_idx, at::kInt), R, f32(fwd_out),
+                                      static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_feat), g[0], g[1], g[2], g[3],
+                                      g[4], g[5], (int32_t)max_workgroups, out(ws), nws, st(stream)),
+              "nmf_brdf_mlp_bwd_packed");
+    else
+        check(nmf_brdf_mlp_bwd(f32(w[0]), f32(w[1]), f32(w[2]), f32(w[3]), f32(w[4]), f32(w[5]), f32(half_vec), f32(diff_vec),
+                               f32(feat_src), f32(rough_src), optr<const int32_t>(src_idx, at::kInt), R, f32(fwd_out),
+                               static_cast<const uint32_t*>(act_mask.data_ptr()), f32(go), out(d_feat), g[0], g[1], g[2], g[3], g[4],
+                               g[5], (int32_t)max_workgroups, out(ws), nws, st(stream)),
+              "nmf_brdf_mlp_bwd");
     return d_feat;
 }
 
@@ -965,7 +996,10 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("sat_lookup_fwd", &sat_lookup_fwd);
     m.def("select_bounces", &select_bounces);
     m.def("expand_segments", &expand_segments);
-    m.def("brdf_mlp_fwd", &brdf_mlp_fwd);
+    m.def("brdf_mlp_fwd", &brdf_mlp_fwd, py::arg("w"), py::arg("half_vec"), py::arg("diff_vec"), py::arg("feat_src"), py::arg("rough_src"),
+          py::arg("src_idx"), py::arg("out_bias"), py::arg("with_mask"), py::arg("max_workgroups"), py::arg("stream"),
+          py::arg("image") = py::none());
+    m.def("brdf_mlp_pack", &brdf_mlp_pack);
     m.def("heads_fwd", &heads_fwd);
     m.def("ggx_rays_fwd", &ggx_rays_fwd);
     m.def("shade_mix_fwd", &shade_mix_fwd);
@@ -976,7 +1010,9 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("composite_bwd", &composite_bwd);
     m.def("segment_sum_wide", &segment_sum_wide);
     m.def("sat_lookup_bwd", &sat_lookup_bwd);
-    m.def("brdf_mlp_bwd", &brdf_mlp_bwd);
+    m.def("brdf_mlp_bwd", &brdf_mlp_bwd, py::arg("w"), py::arg("half_vec"), py::arg("diff_vec"), py::arg("feat_src"), py::arg("rough_src"),
+          py::arg("src_idx"), py::arg("fwd_out"), py::arg("act_mask"), py::arg("d_out"), py::arg("grads"), py::arg("max_workgroups"),
+          py::arg("stream"), py::arg("image") = py::none());
     m.def("heads_bwd", &heads_bwd);
     m.def("ggx_rays_bwd", &ggx_rays_bwd);
     m.def("shade_mix_bwd", &shade_mix_bwd);
@@ -1015,7 +1051,7 @@ PYBIND11_MODULE(_nmf_host, m) {
 #define RW(name) .def_readwrite(#name, &StepCore::name)
         RW(next_rays) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(walk_late) RW(launch_diet) RW(mlp_side_wgs)
-        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws)
+        RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws) RW(mlp_image)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
         RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)
         RW(detach_n) RW(max_brdf_rays) RW(max_retrace_rays) RW(white) RW(one) RW(select_ws) RW(g_dpk) RW(g_dlk) RW(g_apl) RW(g_ali)

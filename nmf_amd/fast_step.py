@@ -98,6 +98,7 @@ class TrainPass:
         self._core = None if os.environ.get("NMF_STEP_CORE", "1") != "0" else False
         self._core_key = None
         self._core_keep = None
+        self._mlp_image = None          # hip.brdf_mlp_pack of the MLP weights, rewritten with the per-step tables
         self._core_acc = None
         self._march_blocks = None
         self._token_params = None
@@ -172,6 +173,9 @@ class TrainPass:
             if self.overlap:
                 torch.cuda.set_stream(tb)
             r = (rf._fwd_tables(), model.diffuse_module.head_pass(), model.brdf.mlp_pass())
+            # the BRDF MLP's weights as the image its kernels copy into LDS (one small launch here instead of a conversion in
+            # front of the first tile of each of the step's four MLP launches)
+            self._mlp_image = hip.brdf_mlp_pack(r[2][0], self._mlp_image)
             if self.overlap:
                 self._table_events[0].record(tb)
             return r
@@ -228,6 +232,7 @@ class TrainPass:
                 c.side_stream_objs, c.side_streams = [], []
             self._core_keep = (tab, env, hW, hb, mlp_ws, main)
         c.head_p, c.mlp_bias = [float(v) for v in hp], float(mlp_bias)
+        c.mlp_image = self._mlp_image
         c.env_sc, c.sh_conv = sc, conv
         if self.overlap:
             c.wait_tables, c.wait_env = self._table_events[0].cuda_event, self._table_events[1].cuda_event

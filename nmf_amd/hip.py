@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnmf_hip.so")
+LIB_PATH = os.environ.get("NMF_HIP_LIB") or os.path.join(_HERE, "lib", "libnmf_hip.so")      # (NMF_HIP_LIB: kernel experiments, tools/)
 
 
 class NmfHipError(RuntimeError):
@@ -67,7 +67,8 @@ EXPORTS = [
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd", "nmf_sat_lookup_bwd_binned",
     "nmf_sat_lookup_bwd_workspace_bytes",
     "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
-    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_brdf_mlp_bwd_workspace_bytes", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
+    "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_brdf_mlp_bwd_workspace_bytes", "nmf_brdf_mlp_image_bytes", "nmf_brdf_mlp_pack",
+    "nmf_brdf_mlp_fwd_packed", "nmf_brdf_mlp_bwd_packed", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
@@ -713,21 +714,37 @@ def segment_sum_wide(vals, D, offsets, n_seg):
     return out
 
 
-def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0, with_mask=False):
+def brdf_mlp_pack(weights, into=None):
+    """The six weight tensors as the packed image the fused MLP kernels copy into LDS (nmf_brdf_mlp_pack): built once per weight
+    update, passed as `image=` to brdf_mlp_fwd / brdf_mlp_bwd.  into: a uint8 device tensor of nmf_brdf_mlp_image_bytes() to reuse."""
+    n = int(_lib.nmf_brdf_mlp_image_bytes())
+    img = into if into is not None else torch.empty(n, dtype=torch.uint8, device=weights[0].device)
+    if img.dtype != torch.uint8 or not img.is_contiguous() or img.numel() < n:
+        raise ValueError("brdf_mlp_pack: `into` must be a contiguous uint8 tensor of nmf_brdf_mlp_image_bytes() bytes")
+    _check(_lib.nmf_brdf_mlp_pack(*[_p(w, torch.float32) for w in weights], _p(img), C.c_int64(img.numel()), _stream()),
+           "nmf_brdf_mlp_pack")
+    return img
+
+
+def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0, with_mask=False, image=None):
     """weights = (W0 [64,66], b0, W2 [64,64], b2, W4 [4,64], b4); max_workgroups: see brdf_mlp_bwd.  with_mask: also return
-    the ReLU masks [R, 4] (int32 storage) that brdf_mlp_bwd takes together with the output."""
+    the ReLU masks [R, 4] (int32 storage) that brdf_mlp_bwd takes together with the output.  image: brdf_mlp_pack(weights) --
+    the same bits, a shorter launch (`weights` is then not read)."""
     R = half_vec.shape[0]
     out = torch.empty((R, 3), dtype=torch.float32, device=half_vec.device)
     mask = torch.empty((R, 4), dtype=torch.int32, device=half_vec.device) if with_mask else None
-    _check(_lib.nmf_brdf_mlp_fwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
-                                 _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
-                                 _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias), _p(out),
-                                 _p(mask, torch.int32), C.c_int32(max_workgroups), _stream()),
-           "nmf_brdf_mlp_fwd")
+    tail = (_p(half_vec, torch.float32), _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
+            _p(src_idx, torch.int32), C.c_int64(R), C.c_float(out_bias), _p(out), _p(mask, torch.int32), C.c_int32(max_workgroups),
+            _stream())
+    if image is not None:
+        _check(_lib.nmf_brdf_mlp_fwd_packed(_p(image), *tail), "nmf_brdf_mlp_fwd_packed")
+    else:
+        _check(_lib.nmf_brdf_mlp_fwd(*[_p(w, torch.float32) for w in weights], *tail), "nmf_brdf_mlp_fwd")
     return (out, mask) if with_mask else out
 
 
-def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out, grads, max_workgroups=0):
+def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out, grads, max_workgroups=0,
+                 image=None):
     """fwd_out, act_mask: what brdf_mlp_fwd(..., with_mask=True) returned for the same inputs.  grads: six fp32 tensors
     shaped like `weights`, ACCUMULATED into (caller zeroes them once per pass).  max_workgroups > 0 caps the persistent
     workgroups (a launch that shares the chip with kernels of another stream).  -> d_feat [rows of feat_src, 24]: the adjoint of
@@ -737,12 +754,14 @@ def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_
     d_feat = torch.zeros((feat_src.shape[0], 24), dtype=torch.float32, device=dev)
     nws = int(_lib.nmf_brdf_mlp_bwd_workspace_bytes(C.c_int64(R), C.c_int32(max_workgroups)))
     ws = torch.empty(max(nws, 4) // 4, dtype=torch.float32, device=dev)
-    _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], _p(half_vec, torch.float32),
-                                 _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
-                                 _p(src_idx, torch.int32), C.c_int64(R), _p(fwd_out, torch.float32),
-                                 _p(act_mask, torch.int32), _p(d_out.contiguous(), torch.float32), _p(d_feat),
-                                 *[_p(g) for g in grads], C.c_int32(max_workgroups), _p(ws), C.c_int64(nws), _stream()),
-           "nmf_brdf_mlp_bwd")
+    tail = (_p(half_vec, torch.float32), _p(diff_vec, torch.float32), _p(feat_src, torch.float32), _p(rough_src, torch.float32),
+            _p(src_idx, torch.int32), C.c_int64(R), _p(fwd_out, torch.float32), _p(act_mask, torch.int32),
+            _p(d_out.contiguous(), torch.float32), _p(d_feat), *[_p(g) for g in grads], C.c_int32(max_workgroups), _p(ws),
+            C.c_int64(nws), _stream())
+    if image is not None:
+        _check(_lib.nmf_brdf_mlp_bwd_packed(_p(image), *tail), "nmf_brdf_mlp_bwd_packed")
+    else:
+        _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], *tail), "nmf_brdf_mlp_bwd")
     return d_feat
 
 
@@ -1182,10 +1201,13 @@ def _install_host_ext():
     def expand_segments(offsets, n_seg, total):
         return fx.expand_segments(offsets, n_seg, total, _stream())
 
-    def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0, with_mask=False):
-        r = fx.brdf_mlp_fwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, bool(with_mask),
-                            int(max_workgroups), _stream())
+    def brdf_mlp_fwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, max_workgroups=0, with_mask=False, image=None):
+        r = fx.brdf_mlp_fwd(list(weights or ()), half_vec, diff_vec, feat_src, rough_src, src_idx, out_bias, bool(with_mask),
+                            int(max_workgroups), _stream(), image)
         return r if with_mask else r[0]
+
+    def brdf_mlp_pack(weights, into=None):
+        return fx.brdf_mlp_pack(list(weights), into, _stream())
 
     def heads_fwd(feat, W, b, hp):
         return fx.heads_fwd(feat, W, b, list(hp), _stream())
@@ -1222,9 +1244,9 @@ def _install_host_ext():
                                  int(g["ENV_BINNED_MIN_LOOKUPS"]), _stream())
 
     def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out, grads,
-                     max_workgroups=0):
-        return fx.brdf_mlp_bwd(list(weights), half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out,
-                               list(grads), int(max_workgroups), _stream())
+                     max_workgroups=0, image=None):
+        return fx.brdf_mlp_bwd(list(weights or ()), half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out,
+                               list(grads), int(max_workgroups), _stream(), image)
 
     def heads_bwd(feat, W, b, hp, d_out, gW, gb, add_into=None):
         return fx.heads_bwd(feat, W, b, list(hp), d_out, gW, gb, add_into, _stream())

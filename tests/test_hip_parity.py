@@ -696,6 +696,20 @@ def test_brdf_mlp_fused_matches_oracle(R):
     assert d_rays.shape == (R, 24)
     per_row = torch.zeros(Mb, 24, device=DEV).index_add_(0, rows.to(DEV), d_rays)
     assert_close(per_row.cpu(), gref[0], rtol=1e-4, atol=1e-5 * float(gref[0].abs().max() + 1), what="d feat (per ray)")
+    # the weights as a packed image (nmf_brdf_mlp_pack: what the training pass hands the kernels): the same bits forward, the same
+    # weight-gradient bits backward (fixed summation order), the row adjoint up to the order of its float atomics
+    img = hip.brdf_mlp_pack(wsd)
+    assert img.dtype == torch.uint8 and img.numel() == hip._lib.nmf_brdf_mlp_image_bytes()
+    out4, mask4 = hip.brdf_mlp_fwd(None, hv.to(DEV), dv.to(DEV), feat_d.detach(), rough.to(DEV), rows.int().to(DEV), 0.37,
+                                   with_mask=True, image=img)
+    assert torch.equal(out4, out2) and torch.equal(mask4, mask)
+    ga, gb = [torch.zeros_like(w) for w in wsd], [torch.zeros_like(w) for w in wsd]
+    args = (hv.to(DEV), dv.to(DEV), feat_d.detach(), rough.to(DEV), rows.int().to(DEV), out2, mask, c.to(DEV))
+    da = hip.brdf_mlp_bwd(wsd, *args, ga)
+    db = hip.brdf_mlp_bwd(None, *args, gb, image=hip.brdf_mlp_pack(wsd, into=img))
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+    assert_close(db.cpu(), da.cpu(), rtol=1e-5, atol=1e-6 * float(da.abs().max() + 1e-6), what="d feat (packed weights)")
     if R == 257:      # golden (reference) values for exactly this input set
         w = brdf_mlp(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
                      g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),

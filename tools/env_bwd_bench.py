@@ -7,7 +7,9 @@ import argparse
 import os
 import sys
 
-import torch
+os.environ["NMF_STEP_CORE"] = "0"      # the Python pass: its calls go through hip.sat_lookup_bwd, where the spy sits
+
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
@@ -20,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--modes", default="direct,binned,binned_no_dirs", help="under rocprofv3: one mode, so that the kernel stats are its own")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     nerf, params = bench.build(dev, grid=a.grid)
@@ -56,6 +59,9 @@ def main():
         d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=dev), torch.zeros(2, 3, device=dev), torch.zeros(1, device=dev)
         out = {}
         for name, thr, wd in (("direct", 1 << 62, True), ("binned", 1, True), ("binned_no_dirs", 1, False)):
+            if name not in a.modes.split(","):
+                out[name] = float("nan")
+                continue
             hip.ENV_BINNED_MIN_LOOKUPS = thr
             out[name] = timed(lambda: orig(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip if wd else None, wd, None, sc))
         torch.cuda.synchronize()

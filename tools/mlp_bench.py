@@ -49,7 +49,7 @@ def main():
     shapes = [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)]
     ws = [(torch.randn(s, generator=gen) * (0.25 if len(s) == 2 else 0.1)).to(DEV) for s in shapes]
     for R in Rs:
-        Mb = max(R // 13, 1)
+        Mb = max(R // int(os.environ.get("NMF_MLP_RUN", "13")), 1)      # rays per bounce row
         idx = torch.sort(torch.randint(0, Mb, (R,), generator=gen)).values.int().to(DEV)
         hv = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).to(DEV)
         dv = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).to(DEV)
@@ -69,8 +69,12 @@ def main():
               f"(torch f32: {float((o32.double() - o64).abs().max()):.2e})")
         for n, a, b32, b64 in zip(names, [dfeat] + grads, g32, g64):
             print(f"   {n:7s} rel-to-max err {err(a, b64):.2e}   (torch f32: {err(b32, b64):.2e})")
+        img = hip.brdf_mlp_pack(ws)
         for name, fn in (("fwd", lambda: hip.brdf_mlp_fwd(ws, hv, dv, feat, rough, idx, 0.37, with_mask=True)),
-                         ("bwd", lambda: hip.brdf_mlp_bwd(ws, hv, dv, feat, rough, idx, out, mask, c, grads))):
+                         ("bwd", lambda: hip.brdf_mlp_bwd(ws, hv, dv, feat, rough, idx, out, mask, c, grads)),
+                         ("fwd, packed weights", lambda: hip.brdf_mlp_fwd(None, hv, dv, feat, rough, idx, 0.37, with_mask=True, image=img)),
+                         ("bwd, packed weights", lambda: hip.brdf_mlp_bwd(None, hv, dv, feat, rough, idx, out, mask, c, grads, image=img)),
+                         ("pack", lambda: hip.brdf_mlp_pack(ws, img))):
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
