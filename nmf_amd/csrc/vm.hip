@@ -821,6 +821,121 @@ __global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __rest
     }
 }
 
+// The same scan in ONE launch (R4): chunks of 1024 bricks on 256-thread workgroups, the totals of the chunks before a chunk
+// obtained by look-back -- a workgroup takes its chunk number from a ticket (so every chunk before it belongs to a workgroup that
+// has started), publishes its own total (samples | items << 32 | ready bit, one relaxed device-scope 64-bit store: the word is flag
+// and payload at once, no fence) and wave 0 then reads the words of its predecessors, spinning on the ready bit.  Against
+// k_bins_partial + k_bins_final (8 workgroups of 1024 threads at 128^3, 4.7 + 13.4 us with nothing to sort): one launch less per
+// walk and 32 workgroups instead of 8.  state[0] = ticket, state[1 + c] = word of chunk c (zeroed with the counters).
+constexpr int SC_THREADS = 256, SC_PER = 4, SC_CHUNK = SC_THREADS * SC_PER;
+constexpr unsigned long long SC_READY = 1ull << 63;
+
+__global__ void __launch_bounds__(SC_THREADS) k_bins_scan(const int32_t* __restrict__ counts, int n, int kc,
+                                                          unsigned long long* __restrict__ state, int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ cursor, int item, int2* __restrict__ items,
+                                                          int32_t* __restrict__ n_items) {
+    __shared__ int64_t wsum[SC_THREADS / 64];
+    __shared__ int64_t s_carry;
+    __shared__ int s_chunk;
+    __shared__ int32_t s_io[SC_CHUNK + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_chunk = (int)atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int chunk = s_chunk;
+    const int i0 = chunk * SC_CHUNK + tid * SC_PER;
+    int c[SC_PER], ni[SC_PER], ck[SC_PER][8];
+    int64_t v = 0;
+#pragma unroll
+    for (int q = 0; q < SC_PER; ++q) {
+        c[q] = 0;
+        if (i0 + q < n) c[q] = brick_count(counts, i0 + q, kc, ck[q]);
+        ni[q] = (c[q] + item - 1) / item;
+        v += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    int64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int64_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SC_THREADS / 64; ++w) {
+        if (w < wid) woff += wsum[w];
+        total += wsum[w];
+    }
+    if (wid == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&state[1 + chunk], (unsigned long long)total | SC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t carry = 0;
+        for (int base = chunk - 1; base >= 0; base -= 64) {
+            const int cb = base - lane;
+            unsigned long long w = SC_READY;
+            if (cb >= 0) {
+                do {
+                    w = __hip_atomic_load(&state[1 + cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (!(w & SC_READY));
+            }
+            int64_t t = (int64_t)(w & ~SC_READY);
+            for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d, 64);
+            carry += __shfl(t, 0, 64);
+        }
+        if (lane == 0) s_carry = carry;
+    }
+    __syncthreads();
+    int64_t run = s_carry + woff + incl - v;
+    int so[SC_PER];
+#pragma unroll
+    for (int q = 0; q < SC_PER; ++q) {
+        so[q] = (int)(run & 0xffffffffll);
+        s_io[tid * SC_PER + q] = (int)(run >> 32);
+        run += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    if (i0 + SC_PER <= n) {        // (i0 is a multiple of 4 and the arrays are 16-byte aligned)
+        *reinterpret_cast<int4*>(offsets + i0) = make_int4(so[0], so[1], so[2], so[3]);
+        if (kc == 4) {
+#pragma unroll
+            for (int q = 0; q < SC_PER; ++q) {
+                const int a = so[q], b = a + ck[q][0], cc = b + ck[q][1], d = cc + ck[q][2];
+                reinterpret_cast<int4*>(cursor)[i0 + q] = make_int4(a, b, cc, d);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SC_PER; ++q) {
+                int pos = so[q];
+                for (int k = 0; k < kc; ++k) { cursor[(i0 + q) * kc + k] = pos; pos += ck[q][k]; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SC_PER; ++q) {
+            if (i0 + q < n) {
+                offsets[i0 + q] = so[q];
+                int pos = so[q];
+                for (int k = 0; k < kc; ++k) { cursor[(i0 + q) * kc + k] = pos; pos += ck[q][k]; }
+            }
+        }
+    }
+    if (tid == SC_THREADS - 1) s_io[SC_CHUNK] = (int)(run >> 32);
+    __syncthreads();
+    {   // the work items of this chunk's bricks, a lane per item (see k_bins_final)
+        const int first = s_io[0], last = s_io[SC_CHUNK];
+        for (int j = first + tid; j < last; j += SC_THREADS) {
+            int lo = 0, hi = SC_CHUNK;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_io[mid] <= j) lo = mid; else hi = mid;
+            }
+            items[j] = make_int2(chunk * SC_CHUNK + lo, j - s_io[lo]);
+        }
+    }
+    if (chunk == (int)gridDim.x - 1 && tid == SC_THREADS - 1) {
+        offsets[n] = (int)(run & 0xffffffffll);
+        *n_items = (int)(run >> 32);
+    }
+}
+
 // adjoint of the raw density feature and of the raw density gradient (normalised-coordinate units) of sample l of segment k:
 // the softplus / normalize backward, once per sample
 __device__ __forceinline__ float4 sample_adjoint(const nmf_vm_params& p, const Segs& sg, int k, int64_t l) {
@@ -862,6 +977,29 @@ __global__ void __launch_bounds__(256) k_brick_records(nmf_vm_params p, Segs sg,
     const int pos = slot[m];
     int64_t l;
     const int k = seg_of(sg, m, l);
+    rec1[pos] = sample_adjoint(p, sg, k, l);
+    if constexpr (APP) {
+        float da[AD];
+        load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
+        float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);
+#pragma unroll
+        for (int q = 0; q < AD / 4; ++q) srt[q] = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+    }
+}
+
+// place + records in one pass, for a walk that sorts inside its own call (no plan from the forward): the slot of a sample is used
+// where it is computed, so slot[] is neither written nor read and the launch between the two is gone
+template <bool APP>
+__global__ void __launch_bounds__(256) k_place_records(nmf_vm_params p, Segs sg, int64_t M, const int2* __restrict__ keyrank,
+                                                       const int32_t* __restrict__ cursor, float4* __restrict__ rec0,
+                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int2 kr = keyrank[m];
+    const int pos = cursor[kr.x] + kr.y;
+    int64_t l;
+    const int k = seg_of(sg, m, l);
+    rec0[pos] = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
     rec1[pos] = sample_adjoint(p, sg, k, l);
     if constexpr (APP) {
         float da[AD];
@@ -1519,6 +1657,9 @@ struct PlanLayout {
     int2* keyrank;        // [M]   (brick * kc + counter copy, rank inside it)
     int32_t* slot;        // [M]   position of sample m in brick order
     int32_t* counts;      // [(nb+1)*kc]
+    unsigned long long* scan_state;   // [1 + n_scan_chunks]: ticket, chunk words of k_bins_scan (behind the counters: one memset)
+    int n_scan_chunks;
+    size_t zero_bytes;    // counts + scan_state
     int32_t* offsets;     // [nb+1]
     int32_t* cursor;      // [(nb+1)*kc]  start of every (brick, copy)
     int32_t* n_items;     // [2]
@@ -1542,6 +1683,9 @@ PlanLayout plan_layout(void* base, int64_t M, int32_t grid) {
     L.keyrank = (int2*)q;                q = up16(q + sizeof(int2) * M);
     L.slot = (int32_t*)q;                q = up16(q + sizeof(int32_t) * M);
     L.counts = (int32_t*)q;              q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc);
+    L.n_scan_chunks = (L.nb + SC_CHUNK - 1) / SC_CHUNK;
+    L.scan_state = (unsigned long long*)q;   q = up16(q + sizeof(unsigned long long) * (size_t)(L.n_scan_chunks + 1));
+    L.zero_bytes = (size_t)(q - (uintptr_t)L.counts);
     L.offsets = (int32_t*)q;             q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1));
     L.cursor = (int32_t*)q;              q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc);
     L.n_items = (int32_t*)q;             q = up16(q + sizeof(int32_t) * 2);
@@ -1588,14 +1732,24 @@ int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg
     return M;
 }
 
-int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(L.counts, 0, sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc, st);
+// place = false: the caller follows with k_place_records (the walk that sorts inside its own call)
+int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place) {
+    hipError_t e = hipMemsetAsync(L.counts, 0, L.zero_bytes, st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
     hipLaunchKernelGGL(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
-    hipLaunchKernelGGL(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
-    hipLaunchKernelGGL(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
-                       L.cursor, L.item_size, L.items, L.n_items);
-    hipLaunchKernelGGL(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
+    const char* ev2 = getenv("NMF_BINS_TWO_PASS");       // tuning knob: 1 = k_bins_partial + k_bins_final
+    const bool two_pass = ev2 && atoi(ev2) == 1;
+    // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU)
+    if (!two_pass && L.n_scan_chunks <= 2048) {
+        hipLaunchKernelGGL(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
+                           L.cursor, L.item_size, L.items, L.n_items);
+    } else {
+        hipLaunchKernelGGL(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
+        hipLaunchKernelGGL(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
+                           L.cursor, L.item_size, L.items, L.n_items);
+    }
+    if (place)
+        hipLaunchKernelGGL(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
     NMF_CHECK_LAUNCH("nmf_vm_bin_plan");
     return NMF_OK;
 }
@@ -1626,7 +1780,7 @@ extern "C" int nmf_vm_bin_plan(const nmf_vm_params* p, const float* const* xyzt,
     NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_bin_plan: M >= 2^31");
     NMF_REQUIRE(plan && plan_bytes >= nmf_vm_bin_plan_bytes(M, p->grid), NMF_EINVAL,
                 "nmf_vm_bin_plan: plan buffer too small (see nmf_vm_bin_plan_bytes)");
-    return launch_plan(p, sg, M, plan_layout(plan, M, p->grid), (hipStream_t)stream);
+    return launch_plan(p, sg, M, plan_layout(plan, M, p->grid), (hipStream_t)stream, true);
 }
 
 static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs, const float* const dpk[3],
@@ -1670,7 +1824,7 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
         NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
                     "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
         L = plan_layout(workspace, M, p->grid);
-        const int rc = launch_plan(p, sg, M, L, st);
+        const int rc = launch_plan(p, sg, M, L, st, false);
         if (rc != NMF_OK) return rc;
         walk_ws = (char*)workspace + L.bytes;
         walk_bytes = workspace_bytes - L.bytes;
@@ -1683,14 +1837,16 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
         hipError_t e = hipMemsetAsync(W.basis_copies, 0, sizeof(float) * BASIS_COPIES * AD * 3 * CA, st);
         if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     }
+    const dim3 per_sample((unsigned)cdiv(M, 256));
     if (want_a) {
-        hipLaunchKernelGGL(k_brick_records<true>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, L.slot, M, W.rec1,
-                           W.d_app_sorted);
+        if (plan) hipLaunchKernelGGL(k_brick_records<true>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
+        else hipLaunchKernelGGL(k_place_records<true>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted);
         hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, W.d_app_sorted, basis, M,
                            W.dcoef);
-    } else
-        hipLaunchKernelGGL(k_brick_records<false>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, L.slot, M, W.rec1,
-                           W.d_app_sorted);
+    } else if (plan)
+        hipLaunchKernelGGL(k_brick_records<false>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
+    else
+        hipLaunchKernelGGL(k_place_records<false>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     int64_t gcap = 16384;
