@@ -57,9 +57,22 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
     __shared__ float s_da[256 * (O + 1)];
     __shared__ float s_f[256 * (F + 1)];
     const int t = threadIdx.x;
-    // gW has 11*24 = 264 entries: thread t owns entry t and (t < 8) entry t + 256; thread t < 11 owns gb[t]
-    const int oi0 = t / F, fj0 = t % F, oi1 = (t + 256) / F, fj1 = (t + 256) % F;
-    float acc = 0.f, acc1 = 0.f, accb = 0.f;
+    // Weight gradient gW [11][24] += da^T [11 x rows] f [rows x 24] (and gb = column sums of da: a 25th column of ones) on the
+    // matrix cores: wave w takes rows 64 w .. 64 w + 63 of a 256-row block as sixteen K = 4 steps of v_mfma_f32_16x16x4_f32
+    // (M = 16 >= 11 outputs, N = 2 x 16 >= 25 columns).  R3 gave every thread one of the 264 entries and walked the 256 rows one
+    // by one, then 8 threads a second entry, then 11 threads the bias sums: three serial passes of 256 LDS round trips, 14 us for
+    // ANY number of rows (tools/fixed_cost.py) on the serial tail of the step.
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    const int lane = t & 63, wv = t >> 6, ci = lane & 15, kg = lane >> 4;
+    floatx4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    // W and b through LDS (broadcast reads): as uniform global addresses they became ~200 scalar loads that the 100 scalar
+    // registers cannot hold at once -- 130 waits on the scalar cache per row block and 450 lane moves of spilled scalars, most
+    // of the 14 us this launch took for any number of rows
+    __shared__ float s_W[O * F];
+    __shared__ float s_b[O];
+    for (int i = t; i < O * F; i += 256) s_W[i] = W[i];
+    if (t < O) s_b[t] = b[t];
+    __syncthreads();
     const int64_t n_it = (M + 255) / 256;
     for (int64_t it = blockIdx.x; it < n_it; it += gridDim.x) {
         const int64_t m = it * 256 + t;
@@ -68,9 +81,9 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
             load_feat(feat, m, f);
 #pragma unroll
             for (int j = 0; j < O; ++j) {
-                float a = b[j];
+                float a = s_b[j];
 #pragma unroll
-                for (int k = 0; k < F; ++k) a += W[j * F + k] * f[k];
+                for (int k = 0; k < F; ++k) a += s_W[j * F + k] * f[k];
                 const float g = d_out[m * O + j];
                 float d;
                 if (j < 3) {
@@ -92,7 +105,7 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
 #pragma unroll
             for (int j = 0; j < O; ++j)
 #pragma unroll
-                for (int k = 0; k < F; ++k) df[k] += da[j] * W[j * F + k];
+                for (int k = 0; k < F; ++k) df[k] += da[j] * s_W[j * F + k];
             float4* q = reinterpret_cast<float4*>(d_feat + m * F);
             if (d_feat_add) {                                           // another adjoint of the same rows, added here (may alias d_feat)
                 const float4* qa = reinterpret_cast<const float4*>(d_feat_add + m * F);
@@ -117,27 +130,37 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
 #pragma unroll
         for (int k = 0; k < F; ++k) s_f[t * (F + 1) + k] = f[k];
         __syncthreads();
-        {
-            float a = 0.f;
-#pragma unroll 8
-            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + oi0] * s_f[s * (F + 1) + fj0];
-            acc += a;
-        }
-        if (t < O * F - 256) {
-            float a = 0.f;
-#pragma unroll 8
-            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + oi1] * s_f[s * (F + 1) + fj1];
-            acc1 += a;
-        }
-        if (t < O) {
-            float a = 0.f;
-            for (int s = 0; s < 256; ++s) a += s_da[s * (O + 1) + t];
-            accb += a;
+#pragma unroll 4
+        for (int r0 = 64 * wv; r0 < 64 * wv + 64; r0 += 4) {
+            const int row = r0 + kg;
+            const float a = ci < O ? s_da[row * (O + 1) + ci] : 0.f;
+            const float b0 = s_f[row * (F + 1) + ci];
+            const float b1 = ci < F - 16 ? s_f[row * (F + 1) + 16 + ci] : (ci == F - 16 ? 1.f : 0.f);
+            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, g1, 0, 0, 0);
         }
     }
-    atomicAdd(gW + t, acc);
-    if (t < O * F - 256) atomicAdd(gW + t + 256, acc1);
-    if (t < O) atomicAdd(gb + t, accb);
+    // the four waves' tiles meet in LDS (register r of a lane: output 4 (lane >> 4) + r, column lane & 15 of its block), one atomic
+    // per entry and workgroup
+    __syncthreads();
+    float* red = s_f;                                   // [4 waves][2 blocks][4 registers][64 lanes]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wv * 512 + r * 64 + lane] = g0[r];
+        red[wv * 512 + 256 + r * 64 + lane] = g1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = t; e < 512; e += 256) {
+        const float v = (red[e] + red[512 + e]) + (red[1024 + e] + red[1536 + e]);
+        const int blk = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        const int oi = 4 * (ln >> 4) + r, c = ln & 15;
+        if (oi < O) {
+            if (blk == 0) atomicAdd(gW + oi * F + c, v);
+            else if (c < F - 16) atomicAdd(gW + oi * F + 16 + c, v);
+            else if (c == F - 16) atomicAdd(gb + oi, v);
+        }
+    }
 }
 
 }  // namespace

@@ -243,6 +243,14 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
                                                 float* __restrict__ normal, float* __restrict__ app,
                                                 float* __restrict__ coef_out, const int64_t* __restrict__ M_live) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // basis_mat through LDS (broadcast reads) when appearance vectors are formed: as uniform global addresses its 1728 entries
+    // became 280 scalar loads with 96 waits on the scalar cache per thread (R4, found in the ISA: ~8 us of latency per launch)
+    __shared__ float s_basis[AD * 3 * CA];
+    const bool use_basis = apl.p[0] && app;
+    if (use_basis) {
+        for (int i = threadIdx.x; i < AD * 3 * CA; i += 256) s_basis[i] = basis[i];
+        __syncthreads();
+    }
     // M_live: the sample count still lives on the device (the launch was sized by a bound: nmf_vm_query_fwd_live)
     if (m >= M || (M_live && m >= *M_live)) return;
     const int G = p.grid;
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
             if (app) {
 #pragma unroll
                 for (int j = 0; j < AD; ++j) {
-                    const float* wrow = basis + j * (3 * CA) + i * CA;       // uniform -> scalar loads
+                    const float* wrow = s_basis + j * (3 * CA) + i * CA;
                     float a = 0.f;
 #pragma unroll
                     for (int c = 0; c < CA; ++c) a += wrow[c] * Pa[c];
@@ -384,23 +392,25 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
         for (int c = 0; c < CD; ++c) Lc[c] = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if (tl.idx[t] < 0) continue;
+            const int id_ = max(tl.idx[t], 0);                 // no branch around the loads: a tap outside the table reads
+            const float w_ = tl.idx[t] < 0 ? 0.f : tl.w[t];      // entry 0 with weight 0 (the sums keep their bits)
             float run[CD];
-            load_run<CD / 4>(dlk.p[i] + (int64_t)tl.idx[t] * line_stride, run);
+            load_run<CD / 4>(dlk.p[i] + (int64_t)id_ * line_stride, run);
 #pragma unroll
-            for (int c = 0; c < CD; ++c) Lc[c] = fmaf(tl.w[t], run[c], Lc[c]);
+            for (int c = 0; c < CD; ++c) Lc[c] = fmaf(w_, run[c], Lc[c]);
         }
         const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
         float s_pl = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (tp.idx[t] < 0) continue;
+            const int id_ = max(tp.idx[t], 0);                 // no branch around the loads: a tap outside the table reads
+            const float w_ = tp.idx[t] < 0 ? 0.f : tp.w[t];      // entry 0 with weight 0 (the sums keep their bits)
             float run[CD];
-            load_run<CD / 4>(dpk.p[i] + (int64_t)tp.idx[t] * plane_stride, run);
+            load_run<CD / 4>(dpk.p[i] + (int64_t)id_ * plane_stride, run);
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < CD; ++c) a = fmaf(run[c], Lc[c], a);
-            s_pl = fmaf(tp.w[t], a, s_pl);
+            s_pl = fmaf(w_, a, s_pl);
         }
         sf += s_pl;
     }
@@ -535,19 +545,21 @@ __global__ void __launch_bounds__(256) k_vm_app_rows(nmf_vm_params p, const floa
             float La[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if (tl.idx[t] < 0) continue;
-                const TT* run = ali.p[i] + (int64_t)tl.idx[t] * CA + 3 * q;
+                const int id_ = max(tl.idx[t], 0);                 // no branch around the loads: a tap outside the table reads
+                const float w_ = tl.idx[t] < 0 ? 0.f : tl.w[t];      // entry 0 with weight 0 (the sums keep their bits)
+                const TT* run = ali.p[i] + (int64_t)id_ * CA + 3 * q;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) La[k] += tl.w[t] * ld1(run + k);
+                for (int k = 0; k < 3; ++k) La[k] += w_ * ld1(run + k);
             }
             const Tap2 tp = make_tap2(xn[MAT0[i]], xn[MAT1[i]], G);
             float Pa[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (tp.idx[t] < 0) continue;
-                const TT* run = apl.p[i] + (int64_t)tp.idx[t] * CA + 3 * q;
+                const int id_ = max(tp.idx[t], 0);                 // no branch around the loads: a tap outside the table reads
+                const float w_ = tp.idx[t] < 0 ? 0.f : tp.w[t];      // entry 0 with weight 0 (the sums keep their bits)
+                const TT* run = apl.p[i] + (int64_t)id_ * CA + 3 * q;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) Pa[k] += tp.w[t] * ld1(run + k);
+                for (int k = 0; k < 3; ++k) Pa[k] += w_ * ld1(run + k);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) s_coef[r * APP_PITCH + i * CA + 3 * q + k] = Pa[k] * La[k];     // tensoRF.py:204
