@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 105
+#define NMF_ABI_VERSION 106
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -217,6 +217,18 @@ int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* 
                               const float* basis, float* const g_dpk[3], float* const g_dlk[3],
                               float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
                               void* workspace, int64_t workspace_bytes, void* stream);
+/* The same call for a caller that walks again and again (a training loop: train.py:497-747 calls backward() every iteration):
+ * the counters of the brick sort, the chunk words of its scan and the scratch copies of the basis_mat gradient live in `clean`,
+ * nmf_vm_bwd_clean_bytes(grid) bytes of device memory (16-byte aligned) that are ZERO on entry -- zeroed once, when allocated --
+ * and zero again when the kernels of the call have run (each clears what it has consumed).  No memset launch per walk (two for
+ * an appearance walk: 3.5 us + a launch gap each on the serial tail of a step).  One scratch per walk that may be in flight. */
+int64_t nmf_vm_bwd_clean_bytes(int32_t grid);
+int nmf_vm_query_bwd_segments_clean(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs /*HOST array*/, int32_t n_segs,
+                                    const float* const dpk[3], const float* const dlk[3],
+                                    const float* const app_planes[3], const float* const app_lines[3],
+                                    const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                    float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                    void* clean, int64_t clean_bytes, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* The brick sort of a walk as a PLAN: it depends on the sample positions alone (not on the adjoints), so a training pass
  * builds it when the positions become known -- under its forward, on a side stream -- and the backward only permutes the

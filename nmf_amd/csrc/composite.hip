@@ -211,6 +211,16 @@ __global__ void __launch_bounds__(256) k_segment_sum_group(const float* __restri
 
 }  // namespace
 
+// Lanes per ray of the large batches.  The BACKWARD takes 16 (R4): 23 k of the 247 k re-traced rays of a step keep more than 8
+// samples (11 k more than 16, the longest 200) and a wave is as slow as its longest ray -- every chunk of a ray beyond the first
+// costs four dependent memory round trips there; 41 -> 34 us, the same bits (tools/composite_bench.py).  The forward stays at 8:
+// no faster with 16, and its per-ray opacity sum would change its association.  NMF_COMPOSITE_W = 8 / 16 forces both (tuning knob).
+static int group_width(int dflt) {
+    const char* e = getenv("NMF_COMPOSITE_W");
+    const int w = e ? atoi(e) : 0;
+    return (w == 8 || w == 16) ? w : dflt;
+}
+
 extern "C" int nmf_composite_fwd(const float* sigma, const float* dist, const int64_t* offsets, int64_t b,
                                  float distance_scale, float* weight, float* acc, void* stream) {
     NMF_REQUIRE(b >= 0, NMF_EINVAL, "nmf_composite_fwd: b < 0");
@@ -218,6 +228,9 @@ extern "C" int nmf_composite_fwd(const float* sigma, const float* dist, const in
     NMF_REQUIRE(sigma && dist && offsets && weight, NMF_EINVAL, "nmf_composite_fwd: null");
     if (b <= WPR_MAX_RAYS)
         hipLaunchKernelGGL(k_composite_fwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
+                           dist, offsets, b, distance_scale, weight, acc);
+    else if (group_width(8) == 16)
+        hipLaunchKernelGGL(k_composite_fwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, offsets, b, distance_scale, weight, acc);
     else
         hipLaunchKernelGGL(k_composite_fwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
@@ -236,6 +249,9 @@ extern "C" int nmf_composite_bwd(const float* sigma, const float* dist, const fl
     static const int one_chunk = !(getenv("NMF_COMPOSITE_ONE_CHUNK") && atoi(getenv("NMF_COMPOSITE_ONE_CHUNK")) == 0);
     if (b <= WPR_MAX_RAYS)
         hipLaunchKernelGGL(k_composite_bwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
+                           dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
+    else if (group_width(16) == 16)
+        hipLaunchKernelGGL(k_composite_bwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     else
         hipLaunchKernelGGL(k_composite_bwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,

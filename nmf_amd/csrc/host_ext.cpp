@@ -610,7 +610,8 @@ void vm_query_bwd_impl(const char* name, int64_t p_addr, const std::vector<Seg>&
                        const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
                        const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
                        const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis, const OT& plan,
-                       int64_t stream) {
+                       int64_t stream, const OT& clean = c10::nullopt) {
+    // clean: the kept zero scratch of nmf_vm_query_bwd_segments_clean (a walk without a plan)
     TimedScope _ts(name, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     if (segs.size() > NMF_VM_MAX_SEGMENTS) fail("at most " + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments per walk");
@@ -650,6 +651,13 @@ void vm_query_bwd_impl(const char* name, int64_t p_addr, const std::vector<Seg>&
                                        want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, vptr(plan), plan->numel() * 4,
                                        ws.data_ptr(), nbytes, st(stream)),
               "nmf_vm_query_bwd_planned");
+    else if (clean.has_value() && clean->defined())
+        check(nmf_vm_query_bwd_segments_clean(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
+                                              want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
+                                              want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
+                                              want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, clean->data_ptr(), clean->numel(),
+                                              ws.data_ptr(), nbytes, st(stream)),
+              "nmf_vm_query_bwd_segments_clean");
     else
         check(nmf_vm_query_bwd_segments(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
                                         want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
@@ -664,6 +672,16 @@ void vm_query_bwd_segments(int64_t p_addr, const std::vector<Seg>& segs, const s
                            const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
                            int64_t stream) {
     vm_query_bwd_impl(__func__, p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(), stream);
+}
+
+void vm_query_bwd_clean(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
+                        const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
+                        const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
+                        const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
+                        const Tensor& clean, int64_t stream) {
+    if (clean.scalar_type() != at::kByte || !clean.is_contiguous() || !clean.is_cuda()) fail("vm_query_bwd_clean: scratch must be a device uint8 tensor");
+    vm_query_bwd_impl("vm_query_bwd_segments", p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(), stream,
+                      OT(clean));
 }
 
 void vm_query_bwd_planned(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
@@ -1019,6 +1037,7 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("ray_compose_bwd", &ray_compose_bwd);
     m.def("vm_query_bwd_segments", &vm_query_bwd_segments);
     m.def("vm_query_bwd_planned", &vm_query_bwd_planned);
+    m.def("vm_query_bwd_clean", &vm_query_bwd_clean);
     m.def("vm_bin_plan", &vm_bin_plan, py::arg("p_addr"), py::arg("xyzts"), py::arg("stream"), py::arg("into") = py::none());
     m.def("vm_unpack_density_grad", &vm_unpack_density_grad);
     m.def("adam_step", &adam_step);

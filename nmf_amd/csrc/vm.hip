@@ -842,10 +842,13 @@ __global__ void __launch_bounds__(SB_THREADS) k_bins_final(const int32_t* __rest
 constexpr int SC_THREADS = 256, SC_PER = 4, SC_CHUNK = SC_THREADS * SC_PER;
 constexpr unsigned long long SC_READY = 1ull << 63;
 
-__global__ void __launch_bounds__(SC_THREADS) k_bins_scan(const int32_t* __restrict__ counts, int n, int kc,
+// clean: the counters are handed back ZERO (every workgroup clears the counters of its own chunk once it has read them; the chunk
+// words are cleared by the launch that follows, see k_place_records) -- a caller that keeps the scratch between calls then needs no
+// memset launch in front of the next histogram (nmf_vm_query_bwd_segments_clean).
+__global__ void __launch_bounds__(SC_THREADS) k_bins_scan(int32_t* counts, int n, int kc,
                                                           unsigned long long* __restrict__ state, int32_t* __restrict__ offsets,
                                                           int32_t* __restrict__ cursor, int item, int2* __restrict__ items,
-                                                          int32_t* __restrict__ n_items) {
+                                                          int32_t* __restrict__ n_items, int clean) {
     __shared__ int64_t wsum[SC_THREADS / 64];
     __shared__ int64_t s_carry;
     __shared__ int s_chunk;
@@ -863,6 +866,15 @@ __global__ void __launch_bounds__(SC_THREADS) k_bins_scan(const int32_t* __restr
         if (i0 + q < n) c[q] = brick_count(counts, i0 + q, kc, ck[q]);
         ni[q] = (c[q] + item - 1) / item;
         v += (int64_t)c[q] | ((int64_t)ni[q] << 32);
+    }
+    if (clean) {
+#pragma unroll
+        for (int q = 0; q < SC_PER; ++q) {
+            if (i0 + q < n) {
+                if (kc == 4) reinterpret_cast<int4*>(counts)[i0 + q] = make_int4(0, 0, 0, 0);
+                else for (int k = 0; k < kc; ++k) counts[(i0 + q) * kc + k] = 0;
+            }
+        }
     }
     int64_t incl = v;
     for (int d = 1; d < 64; d <<= 1) {
@@ -1004,7 +1016,11 @@ __global__ void __launch_bounds__(256) k_brick_records(nmf_vm_params p, Segs sg,
 template <bool APP>
 __global__ void __launch_bounds__(256) k_place_records(nmf_vm_params p, Segs sg, int64_t M, const int2* __restrict__ keyrank,
                                                        const int32_t* __restrict__ cursor, float4* __restrict__ rec0,
-                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted) {
+                                                       float4* __restrict__ rec1, float* __restrict__ d_app_sorted,
+                                                       unsigned long long* __restrict__ scan_state, int n_state) {
+    // (scan_state: the ticket and chunk words of the scan that ran in front of this launch, cleared for the next walk on this scratch)
+    if (scan_state && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_state; i += 256) scan_state[i] = 0ull;
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int2 kr = keyrank[m];
@@ -1042,12 +1058,16 @@ __global__ void __launch_bounds__(256) k_dcoef(const float* __restrict__ d_app_s
     reinterpret_cast<float4*>(dcoef + pos * (3 * CA))[c4] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-__global__ void __launch_bounds__(256) k_basis_reduce(const float* __restrict__ copies, float* __restrict__ g_basis) {
+__global__ void __launch_bounds__(256) k_basis_reduce(float* copies, float* __restrict__ g_basis, int clean) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= AD * 3 * CA) return;
     float a = 0.f;
 #pragma unroll
     for (int c = 0; c < BASIS_COPIES; ++c) a += copies[c * (AD * 3 * CA) + t];
+    if (clean) {
+#pragma unroll
+        for (int c = 0; c < BASIS_COPIES; ++c) copies[c * (AD * 3 * CA) + t] = 0.f;
+    }
     if (a != 0.f) g_basis[t] += a;          // the caller's accumulator: this launch is the only writer in stream order
 }
 
@@ -1707,6 +1727,23 @@ PlanLayout plan_layout(void* base, int64_t M, int32_t grid) {
     L.bytes = (int64_t)(q - (uintptr_t)base) + 16;
     return L;
 }
+// the scratch a caller may keep between walks (nmf_vm_query_bwd_segments_clean): zero on entry, zero again on exit
+struct CleanLayout {
+    int32_t* counts;
+    unsigned long long* scan_state;
+    float* basis_copies;
+    int64_t bytes;
+};
+CleanLayout clean_layout(void* base, int32_t grid) {
+    const PlanLayout L = plan_layout(nullptr, 0, grid);
+    CleanLayout C;
+    uintptr_t q = up16((uintptr_t)base);
+    C.counts = (int32_t*)q;                       q = up16(q + sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc);
+    C.scan_state = (unsigned long long*)q;        q = up16(q + sizeof(unsigned long long) * (size_t)(L.n_scan_chunks + 1));
+    C.basis_copies = (float*)q;                   q = up16(q + sizeof(float) * BASIS_COPIES * AD * 3 * CA);
+    C.bytes = (int64_t)(q - (uintptr_t)base) + 16;
+    return C;
+}
 struct WalkLayout {
     float4* rec1;          // [M]
     float* dcoef;          // [M][72]
@@ -1745,20 +1782,29 @@ int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg
 }
 
 // place = false: the caller follows with k_place_records (the walk that sorts inside its own call)
-int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place) {
-    hipError_t e = hipMemsetAsync(L.counts, 0, L.zero_bytes, st);
-    if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
-    hipLaunchKernelGGL(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+// clean: L.counts / L.scan_state point into the caller's kept scratch (zero now, zero again afterwards): no memset
+int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false) {
     const char* ev2 = getenv("NMF_BINS_TWO_PASS");       // tuning knob: 1 = k_bins_partial + k_bins_final
     const bool two_pass = ev2 && atoi(ev2) == 1;
     // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU)
-    if (!two_pass && L.n_scan_chunks <= 2048) {
+    const bool lookback = (!two_pass || clean) && L.n_scan_chunks <= 2048;
+    const size_t count_bytes = sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc;
+    if (!clean || !lookback) {
+        hipError_t e = hipMemsetAsync(L.counts, 0, clean ? count_bytes : L.zero_bytes, st);
+        if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
+    }
+    hipLaunchKernelGGL(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+    if (lookback) {
         hipLaunchKernelGGL(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
-                           L.cursor, L.item_size, L.items, L.n_items);
+                           L.cursor, L.item_size, L.items, L.n_items, clean ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
         hipLaunchKernelGGL(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
                            L.cursor, L.item_size, L.items, L.n_items);
+        if (clean) {         // (grids beyond 500^3: the kept counters are handed back zero by a second memset)
+            hipError_t e = hipMemsetAsync(L.counts, 0, count_bytes, st);
+            if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
+        }
     }
     if (place)
         hipLaunchKernelGGL(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
@@ -1799,9 +1845,11 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
                        const float* const dlk[3], const float* const app_planes[3], const float* const app_lines[3],
                        const float* basis, float* const g_dpk[3], float* const g_dlk[3], float* const g_app_planes[3],
                        float* const g_app_lines[3], float* g_basis, const void* plan, int64_t plan_bytes, void* workspace,
-                       int64_t workspace_bytes, void* stream) {
+                       int64_t workspace_bytes, void* stream, void* clean = nullptr, int64_t clean_bytes = 0) {
     NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
                 "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
+    NMF_REQUIRE(!clean || (!plan && clean_bytes >= clean_layout(nullptr, p->grid).bytes && ((uintptr_t)clean & 15) == 0), NMF_EINVAL,
+                "nmf_vm_query_bwd_segments_clean: scratch too small (nmf_vm_bwd_clean_bytes) or not 16-byte aligned");
     Segs sg;
     int n;
     const int64_t M = gather_segments(segs, n_segs, sg, n);
@@ -1836,29 +1884,38 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
         NMF_REQUIRE(workspace && workspace_bytes >= nmf_vm_bwd_workspace_bytes(M, p->grid), NMF_EINVAL,
                     "nmf_vm_query_bwd: workspace too small (see nmf_vm_bwd_workspace_bytes)");
         L = plan_layout(workspace, M, p->grid);
-        const int rc = launch_plan(p, sg, M, L, st, false);
+        if (clean) {
+            const CleanLayout C = clean_layout(clean, p->grid);
+            L.counts = C.counts;
+            L.scan_state = C.scan_state;
+        }
+        const int rc = launch_plan(p, sg, M, L, st, false, clean != nullptr);
         if (rc != NMF_OK) return rc;
         walk_ws = (char*)workspace + L.bytes;
         walk_bytes = workspace_bytes - L.bytes;
     }
     NMF_REQUIRE(walk_ws && walk_bytes >= nmf_vm_walk_workspace_bytes(M), NMF_EINVAL,
                 "nmf_vm_query_bwd: workspace too small (see nmf_vm_walk_workspace_bytes)");
-    const WalkLayout W = walk_layout(walk_ws, M);
+    WalkLayout W = walk_layout(walk_ws, M);
     const bool use_copies = want_a && g_basis;
-    if (use_copies) {
+    if (use_copies && clean) W.basis_copies = clean_layout(clean, p->grid).basis_copies;       // (zero: no memset)
+    else if (use_copies) {
         hipError_t e = hipMemsetAsync(W.basis_copies, 0, sizeof(float) * BASIS_COPIES * AD * 3 * CA, st);
         if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_query_bwd: memset");
     }
+    // the chunk words of the look-back scan are cleared by the launch behind it
+    unsigned long long* st_clear = (clean && L.n_scan_chunks <= 2048) ? L.scan_state : nullptr;
+    const int n_state = L.n_scan_chunks + 1;
     const dim3 per_sample((unsigned)cdiv(M, 256));
     if (want_a) {
         if (plan) hipLaunchKernelGGL(k_brick_records<true>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
-        else hipLaunchKernelGGL(k_place_records<true>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted);
+        else hipLaunchKernelGGL(k_place_records<true>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
         hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, W.d_app_sorted, basis, M,
                            W.dcoef);
     } else if (plan)
         hipLaunchKernelGGL(k_brick_records<false>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
     else
-        hipLaunchKernelGGL(k_place_records<false>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted);
+        hipLaunchKernelGGL(k_place_records<false>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     int64_t gcap = 16384;
@@ -1881,9 +1938,23 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
         NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 1>));
 #undef NMF_LAUNCH_BWD_KERNEL
     if (use_copies)
-        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, W.basis_copies, g_basis);
+        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, W.basis_copies, g_basis, clean ? 1 : 0);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
+}
+
+extern "C" int64_t nmf_vm_bwd_clean_bytes(int32_t grid) { return clean_layout(nullptr, grid).bytes; }
+
+extern "C" int nmf_vm_query_bwd_segments_clean(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
+                                               const float* const dpk[3], const float* const dlk[3],
+                                               const float* const app_planes[3], const float* const app_lines[3],
+                                               const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                               float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                               void* clean, int64_t clean_bytes, void* workspace, int64_t workspace_bytes,
+                                               void* stream) {
+    NMF_REQUIRE(clean, NMF_EINVAL, "nmf_vm_query_bwd_segments_clean: scratch null");
+    return vm_bwd_impl(p, segs, n_segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis,
+                       nullptr, 0, workspace, workspace_bytes, stream, clean, clean_bytes);
 }
 
 extern "C" int nmf_vm_query_bwd_segments(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,

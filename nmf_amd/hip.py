@@ -71,7 +71,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd_packed", "nmf_brdf_mlp_bwd_packed", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -456,11 +456,16 @@ def vm_bin_plan(p, xyzts):
     return plan
 
 
+def vm_bwd_clean_scratch(p, device):
+    """the zeroed scratch a caller keeps between walks (vm_query_bwd_segments(..., clean=...)): counters that every walk hands back zero"""
+    return torch.zeros(int(_lib.nmf_vm_bwd_clean_bytes(C.c_int32(p.grid))), dtype=torch.uint8, device=device)
+
+
 def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
-                          g_basis=None, plan=None):
+                          g_basis=None, plan=None, clean=None):
     """One backward walk over several sample sets (no concatenation).  segs: list of tuples
     (xyzt, sigma_feat, grad, d_sigma, d_sigma_feat, d_normal, d_app) -- the argument order of vm_query_bwd.
-    plan: vm_bin_plan of the same sample sets (the sort is then not redone)."""
+    plan: vm_bin_plan of the same sample sets (the sort is then not redone).  clean: vm_bwd_clean_scratch (no memset launches)."""
     n = len(segs)
     if n > VM_MAX_SEGMENTS:
         raise NmfHipError(f"at most {VM_MAX_SEGMENTS} segments per walk")
@@ -488,6 +493,17 @@ def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk
         return
     nbytes = _lib.nmf_vm_bwd_workspace_bytes(C.c_int64(M), C.c_int32(p.grid))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=segs[0][0].device)
+    if clean is not None:
+        _check(_lib.nmf_vm_query_bwd_segments_clean(C.byref(p), arr, C.c_int32(n),
+                                                    _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
+                                                    _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
+                                                    _p(basis) if want_a else None,
+                                                    _p3(g_dpk) if want_d else None, _p3(g_dlk) if want_d else None,
+                                                    _p3(g_app_planes) if want_a else None, _p3(g_app_lines) if want_a else None,
+                                                    _p(g_basis if want_a else None), _p(clean), C.c_int64(clean.numel()), _p(ws),
+                                                    C.c_int64(nbytes), _stream()),
+               "nmf_vm_query_bwd_segments_clean")
+        return
     _check(_lib.nmf_vm_query_bwd_segments(C.byref(p), arr, C.c_int32(n),
                                           _p3(dpk) if want_d else None, _p3(dlk) if want_d else None,
                                           _p3(app_planes) if want_a else None, _p3(app_lines) if want_a else None,
@@ -1263,7 +1279,10 @@ def _install_host_ext():
                                   bool(noclip), rgb_lin, d_rgb_map, d_acc, d_ori, bool(want_d_normals), _stream())
 
     def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines,
-                              g_basis=None, plan=None):
+                              g_basis=None, plan=None, clean=None):
+        if clean is not None:
+            return fx.vm_query_bwd_clean(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
+                                         g_app_lines, g_basis, clean, _stream())
         if plan is not None:
             return fx.vm_query_bwd_planned(addr(p), list(segs), dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes,
                                            g_app_lines, g_basis, plan, _stream())

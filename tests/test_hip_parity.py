@@ -1620,6 +1620,22 @@ def test_vm_backward_with_a_plan_of_the_forward_equals_the_self_sorting_walk(wit
             fa, fb = flat(a), flat(b)
             assert fa.abs().max() > 0
             assert_close(fb, fa, rtol=2e-5, atol=2e-5 * float(fa.abs().max()), what="planned walk vs self-sorting walk")
+    # the counters of the sort in a scratch the caller keeps (nmf_vm_query_bwd_segments_clean): zero before, zero after, the same
+    # gradients walk after walk (each walk hands the scratch back zero instead of being preceded by memset launches)
+    for impl in ([hip.vm_query_bwd_segments] + ([hip.PY_WRAPPERS["vm_query_bwd_segments"]] if hip.HOST_EXT is not None else [])):
+        clean = hip.vm_bwd_clean_scratch(p, DEV)
+        assert clean.numel() == hip._lib.nmf_vm_bwd_clean_bytes(G) and int(clean.count_nonzero()) == 0
+        for seed in (1, 2, 3):
+            segs = make_segs(seed)
+            a, b = bufs(), bufs()
+            impl(p, segs, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], a[4] if with_app else None)
+            impl(p, segs, dpk, dlk, apl, ali, basis, b[0], b[1], b[2], b[3], b[4] if with_app else None, clean=clean)
+            fa, fb = flat(a), flat(b)
+            assert_close(fb, fa, rtol=2e-5, atol=2e-5 * float(fa.abs().max()), what="walk on a kept scratch vs walk with memsets")
+            assert int(clean.count_nonzero()) == 0, "the scratch must come back zero"
+    with pytest.raises(hip.NmfHipError):                       # a scratch that is too small is refused
+        hip.vm_query_bwd_segments(p, make_segs(1), dpk, dlk, apl, ali, basis, *bufs()[:4], bufs()[4] if with_app else None,
+                                  clean=torch.zeros(64, dtype=torch.uint8, device=DEV))
     with pytest.raises(hip.NmfHipError):                       # a plan of fewer samples than the walk is refused
         small = hip.vm_bin_plan(p, [xyzs[2]])
         segs = make_segs(1)
