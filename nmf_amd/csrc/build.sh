@@ -20,11 +20,16 @@ for f in "$here"/*.hip; do
       # (the default picks the AGPR form for every MFMA of a 512-register kernel and copies each result out)
       brdf_mlp.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1" ;;
     esac
+    # (a failed compile must not leave the previous object to be linked: remove it first, check that all exist afterwards)
+    rm -f "$o"
     "$HIPCC" $FLAGS $extra -c "$f" -o "$o" &
   fi
   objs+=("$o")
 done
 wait
+for o in "${objs[@]}"; do
+  if [ ! -f "$o" ]; then echo "build.sh: $o was not produced (compile error above)" >&2; exit 1; fi
+done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out/libnmf_hip.so"
 echo "built $out/libnmf_hip.so"
 

@@ -679,27 +679,44 @@ __global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __rest
                                                            int64_t* __restrict__ totals, int64_t* pub, int64_t pub_seq) {
     __shared__ int64_t ws[16];
     __shared__ int64_t s_base, s_cbase, s_direct[4];
+    __shared__ int s_tot[4];
     __shared__ int s_cstar;
     const int tid = threadIdx.x;
     const int my = (int)blockIdx.x;
     // ---- phase A: the chunk sums, 4 per thread (chunk 4 tid + k)
     int64_t v4[4] = {0, 0, 0, 0};
+    int64_t total, excl_t;
+    int own = 0;                                     // this thread's count in this workgroup's chunk (direct path: already loaded)
     if (chunk_sum) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int c = 4 * tid + k; v4[k] = c < n_chunks ? chunk_sum[c] : 0; }
-    } else {                                         // n_chunks <= 4: sum the chunks here
-        for (int c = 0; c < n_chunks; ++c) {
-            const int64_t i = (int64_t)c * SCAN_CHUNK + tid;
-            int64_t tot;
-            block_scan_incl(i < B ? counts[i] : 0, ws, tid, tot);
-            if (tid == 0) s_direct[c] = tot;
+        const int64_t tsum = v4[0] + v4[1] + v4[2] + v4[3];
+        excl_t = block_scan_incl(tsum, ws, tid, total) - tsum;
+    } else {
+        // n_chunks <= 4 (the primary rays of a chunk): every workgroup sums the chunks itself -- the counts of all four in flight
+        // together and ONE reduction (R3 ran a block scan with its own dependent load per chunk, then a scan over the four sums:
+        // six block scans and five memory round trips in a launch on the serial head of every step)
+        int cv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t ic = (int64_t)c * SCAN_CHUNK + tid;
+            cv[c] = (c < n_chunks && ic < B) ? counts[ic] : 0;
+        }
+        own = my == 0 ? cv[0] : (my == 1 ? cv[1] : (my == 2 ? cv[2] : cv[3]));
+        if (tid < 4) s_tot[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int r = cv[c];
+            for (int d = 32; d > 0; d >>= 1) r += __shfl_down(r, d, 64);
+            if ((tid & 63) == 0 && r) atomicAdd(&s_tot[c], r);
         }
         __syncthreads();
-        if (tid == 0) for (int c = 0; c < n_chunks; ++c) v4[c] = s_direct[c];
+        total = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { if (tid == 0) v4[c] = s_tot[c]; total += s_tot[c]; }
+        excl_t = 0;                                  // (thread 0 holds chunks 0-3)
     }
-    const int64_t tsum = v4[0] + v4[1] + v4[2] + v4[3];
-    int64_t total;
-    const int64_t excl_t = block_scan_incl(tsum, ws, tid, total) - tsum;
     const bool budget = max_samples > 0 && total > max_samples;
     {
         int64_t run = excl_t;
@@ -715,7 +732,7 @@ __global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __rest
     const int cstar = budget ? s_cstar : n_chunks;
     // ---- phase B: this chunk
     const int64_t i = (int64_t)my * SCAN_CHUNK + tid;
-    const int64_t v = i < B ? counts[i] : 0;
+    const int64_t v = chunk_sum ? (i < B ? counts[i] : 0) : own;
     int64_t dummy;
     const int64_t cum = s_base + block_scan_incl(v, ws, tid, dummy);       // inclusive cumsum(counts)[i]
     const bool ok = !budget || cum < max_samples;                          // strict '<' (alphagrid.py:359)
