@@ -66,11 +66,17 @@ __global__ void __launch_bounds__(256) k_composite_fwd_wave(const float* __restr
     const int64_t s = ray_ok ? offsets[r] : 0, e = ray_ok ? offsets[r + 1] : 0;
     double carry = 1.0;
     float a_sum = 0.f;
+    // the operands of chunk c + 1 are requested before chunk c is worked on (same arithmetic, same order: a ray of n samples is
+    // ceil(n / W) dependent memory round trips otherwise, and a wave is as slow as its longest ray)
+    float sg_n = 0.f, ds_n = 0.f;
+    if (s + lane < e) { sg_n = sigma[s + lane]; ds_n = dist[s + lane]; }
     for (int64_t k0 = s; k0 < e; k0 += W) {
         const int64_t k = k0 + lane;
         const bool in = k < e;
+        const float sg = sg_n, ds = ds_n;
+        if (k + W < e) { sg_n = sigma[k + W]; ds_n = dist[k + W]; }
         float alpha = 0.f;
-        if (in) alpha = 1.0f - expf(-fmul(sigma[k], fmul(dist[k], scale)));
+        if (in) alpha = 1.0f - expf(-fmul(sg, fmul(ds, scale)));
         const float f = in ? fadd(fsub(1.0f, alpha), 1e-10f) : 1.0f;
         const double incl = group_incl_prod<W>((double)f, lane);
         // exclusive product = the inclusive product of the lane below (a float64 division by f costs ~30 instructions and
@@ -130,15 +136,20 @@ __global__ void __launch_bounds__(256) k_composite_bwd_wave(const float* __restr
         return;
     }
     // pass 1 (back to front): suffix_k = sum_{j>k} dw_j w_j, second term of dL/da_k
+    // (both passes request the operands of the next chunk before they work on the current one: see k_composite_fwd_wave)
     double carry = 0.0;
+    float p_dw = 0.f, p_w = 0.f, p_di = 0.f, p_sg = 0.f;
+    if (e - 1 - lane >= s) { const int64_t q = e - 1 - lane; p_dw = d_weight[q]; p_w = weight[q]; p_di = dist[q]; p_sg = sigma[q]; }
     for (int64_t k1 = e; k1 > s; k1 -= W) {
         const int64_t k = k1 - 1 - lane;                      // lane 0 = last sample of the chunk
         const bool in = k >= s;
-        const double v = in ? (double)d_weight[k] * (double)weight[k] : 0.0;
+        const float c_dw = p_dw, c_w = p_w, c_di = p_di, c_sg = p_sg;
+        if (k - W >= s) { const int64_t q = k - W; p_dw = d_weight[q]; p_w = weight[q]; p_di = dist[q]; p_sg = sigma[q]; }
+        const double v = in ? (double)c_dw * (double)c_w : 0.0;
         const double incl = group_incl_sum<W>(v, lane);
         if (in) {
-            const float d = fmul(dist[k], scale);
-            const float ex = expf(-fmul(sigma[k], d));
+            const float d = fmul(c_di, scale);
+            const float ex = expf(-fmul(c_sg, d));
             const float f = fadd(fsub(1.0f, 1.0f - ex), 1e-10f);
             d_sigma[k] = (-(float)(carry + incl - v) / f) * (d * ex);      // float64 suffix sum, fp32 quotient
         }
@@ -146,16 +157,20 @@ __global__ void __launch_bounds__(256) k_composite_bwd_wave(const float* __restr
     }
     // pass 2 (front to back): first term dw_k T_k
     double cp = 1.0;
+    float q_di = 0.f, q_sg = 0.f, q_dw = 0.f, q_ds = 0.f;
+    if (s + lane < e) { const int64_t q = s + lane; q_di = dist[q]; q_sg = sigma[q]; q_dw = d_weight[q]; q_ds = d_sigma[q]; }
     for (int64_t k0 = s; k0 < e; k0 += W) {
         const int64_t k = k0 + lane;
         const bool in = k < e;
+        const float c_di = q_di, c_sg = q_sg, c_dw = q_dw, c_ds = q_ds;      // (c_ds: pass 1's term, written by this wave above)
+        if (k + W < e) { const int64_t q = k + W; q_di = dist[q]; q_sg = sigma[q]; q_dw = d_weight[q]; q_ds = d_sigma[q]; }
         float d = 0.f, ex = 1.f;
-        if (in) { d = fmul(dist[k], scale); ex = expf(-fmul(sigma[k], d)); }
+        if (in) { d = fmul(c_di, scale); ex = expf(-fmul(c_sg, d)); }
         const float f = in ? fadd(fsub(1.0f, 1.0f - ex), 1e-10f) : 1.0f;
         const double incl = group_incl_prod<W>((double)f, lane);
         const double below = lane_below<W, 1>(incl);
         const double T = cp * (lane >= 1 ? below : 1.0);
-        if (in) d_sigma[k] += d_weight[k] * (float)T * (d * ex);
+        if (in) d_sigma[k] = c_ds + c_dw * (float)T * (d * ex);
         cp *= __shfl(incl, W - 1, W);
     }
 }

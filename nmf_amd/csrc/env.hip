@@ -33,7 +33,9 @@ struct EnvTab {
 // bilinear sample of the SAT at normalised (x, y) in [-1,1] (already clipped): returns 3 channels.
 // ATen vectorised CPU kernel: ix = (x+1)*((W-1)/2); w = ix-floor; e = 1-w; nw=e*s ...;
 // out = fma(se_v,se, fma(sw_v,sw, fma(ne_v,ne, nw_v*nw)))
-template <class T>
+// LAYOUT: -1 = t.i4 decides at run time, 0 / 1 = planar / interleaved known at compile time (k_env_lookup_fwd: without the
+// run-time branch the four corners of a box are one basic block and their sixteen taps are in flight together)
+template <class T, int LAYOUT = -1>
 __device__ __forceinline__ void sat_sample(const EnvTab& t, const T& x, const T& y, T (&out)[3]) {
     const T ix = (x + 1.f) * ((float)(t.W - 1) * 0.5f);
     const T iy = (y + 1.f) * ((float)(t.H - 1) * 0.5f);
@@ -45,13 +47,19 @@ __device__ __forceinline__ void sat_sample(const EnvTab& t, const T& x, const T&
     const bool xi0 = x0 >= 0 && x0 < t.W, xi1 = x0 + 1 >= 0 && x0 + 1 < t.W;
     const bool yi0 = y0 >= 0 && y0 < t.H, yi1 = y0 + 1 >= 0 && y0 + 1 < t.H;
     float vnw[3] = {0.f, 0.f, 0.f}, vne[3] = {0.f, 0.f, 0.f}, vsw[3] = {0.f, 0.f, 0.f}, vse[3] = {0.f, 0.f, 0.f};
-    if (t.i4) {
+    if (LAYOUT < 0 ? t.i4 : LAYOUT == 1) {
+        // the four taps are loaded UNCONDITIONALLY from clamped texels and zeroed afterwards: a load under a condition is a
+        // branch, and four corners x four branches made a lookup a chain of dependent memory round trips (R4: 12 full waits on
+        // the vector memory counter in this kernel; a launch of any size took 11 us)
         const float4* p = reinterpret_cast<const float4*>(t.sat);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 a = (xi0 && yi0) ? p[y0 * t.W + x0] : z;
-        const float4 b = (xi1 && yi0) ? p[y0 * t.W + x0 + 1] : z;
-        const float4 c = (xi0 && yi1) ? p[(y0 + 1) * t.W + x0] : z;
-        const float4 d = (xi1 && yi1) ? p[(y0 + 1) * t.W + x0 + 1] : z;
+        const int xa = min(max(x0, 0), t.W - 1), xb = min(max(x0 + 1, 0), t.W - 1);
+        const int ya = min(max(y0, 0), t.H - 1), yb = min(max(y0 + 1, 0), t.H - 1);
+        const float4 la = p[ya * t.W + xa], lb = p[ya * t.W + xb], lc = p[yb * t.W + xa], ld = p[yb * t.W + xb];
+        const float4 a = (xi0 && yi0) ? la : z;
+        const float4 b = (xi1 && yi0) ? lb : z;
+        const float4 c = (xi0 && yi1) ? lc : z;
+        const float4 d = (xi1 && yi1) ? ld : z;
         vnw[0] = a.x; vnw[1] = a.y; vnw[2] = a.z;
         vne[0] = b.x; vne[1] = b.y; vne[2] = b.z;
         vsw[0] = c.x; vsw[1] = c.y; vsw[2] = c.z;
@@ -244,7 +252,7 @@ __device__ __forceinline__ Geometry<T> env_geometry(int H, int W, const T& a, co
 }
 
 // ---- accumulators ----------------------------------------------------------------------------
-template <class T>
+template <class T, int LAYOUT = -1>
 struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL size
     EnvTab tab;
     T size;
@@ -253,7 +261,7 @@ struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL s
     __device__ void begin() {}
     __device__ void corner(const T& x, const T& y, int k) {
         T s[3];
-        sat_sample(tab, x, y, s);
+        sat_sample<T, LAYOUT>(tab, x, y, s);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (k == 0) cur[c] = s[c];
@@ -270,6 +278,7 @@ struct SumAcc {   // forward value: sum of boxes, each divided by the ORIGINAL s
 // ---- kernels -----------------------------------------------------------------------------------
 // Forward lookup: main box on every lane, extra boxes through the queue; an owner adds its boxes in the reference's order
 // (box_wrap), each computed with the same arithmetic as before: the same bits as the lane-per-lookup walk.
+template <int LAYOUT>
 __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                         const float* __restrict__ sa, int64_t R, float mipbias,
                                                         const float* __restrict__ sc,
@@ -291,7 +300,7 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
         cy = g.cy;
         geo[threadIdx.x][0] = g.rect.x0; geo[threadIdx.x][1] = g.rect.x1; geo[threadIdx.x][2] = g.rect.y0;
         geo[threadIdx.x][3] = g.rect.y1; geo[threadIdx.x][4] = g.size;
-        SumAcc<float> acc;
+        SumAcc<float, LAYOUT> acc;
         acc.tab = tab;
         acc.size = g.size;
         acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(256) k_env_lookup_fwd(EnvTab tab, const float*
         const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
         Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
         env_combo_rect(rr, combo, p);
-        SumAcc<float> acc;
+        SumAcc<float, LAYOUT> acc;
         acc.tab = tab;
         acc.size = geo[owner][4];
         acc.total[0] = acc.total[1] = acc.total[2] = 0.f;
@@ -360,6 +369,7 @@ struct Scatter8Acc {
 // Round 1 did both in one 64-thread workgroup with the corners parked in 18.5 KB of LDS (8 waves per CU resident:
 // 192 us for 242 k lookups, profiles/r02_c); neither role needs LDS now.
 constexpr int ENV_BWD_THREADS = 256;
+template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_lookup_bwd(EnvTab tab, const float* __restrict__ dirs, int ld,
                                                                     const float* __restrict__ sa, int64_t R, float mipbias,
                                                                     const float* __restrict__ sc,
@@ -408,7 +418,7 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_lookup_bwd(EnvTab tab, 
             if (dq) { dq[0] = 0.f; dq[1] = 0.f; dq[2] = 0.f; }
         } else if (d_dirs || d_mipbias) {
             const Geometry<D> gd = env_geometry<D>(tab.H, tab.W, da, db, dc, sa[r], dmb);
-            SumAcc<D> acc;
+            SumAcc<D, LAYOUT> acc;
             acc.tab = tab;
             acc.size = gd.size;
             acc.total[0] = acc.total[1] = acc.total[2] = mk_const<4>(0.f);
@@ -481,6 +491,7 @@ struct EnvBwdArgs {
 };
 
 // dual-number role with the channels contracted: q(x, y) = sum_c go[c] * S_c(x, y)
+template <int LAYOUT>
 struct SumAccQ {
     EnvTab tab;
     float go[3];
@@ -497,13 +508,16 @@ struct SumAccQ {
         const bool xi0 = x0 >= 0 && x0 < tab.W, xi1 = x0 + 1 >= 0 && x0 + 1 < tab.W;
         const bool yi0 = y0 >= 0 && y0 < tab.H, yi1 = y0 + 1 >= 0 && y0 + 1 < tab.H;
         float q[4] = {0.f, 0.f, 0.f, 0.f};
-        if (tab.i4) {
+        if (LAYOUT < 0 ? tab.i4 : LAYOUT == 1) {
             const float4* p = reinterpret_cast<const float4*>(tab.sat);
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 a = (xi0 && yi0) ? p[y0 * tab.W + x0] : z;
-            const float4 b = (xi1 && yi0) ? p[y0 * tab.W + x0 + 1] : z;
-            const float4 c = (xi0 && yi1) ? p[(y0 + 1) * tab.W + x0] : z;
-            const float4 d = (xi1 && yi1) ? p[(y0 + 1) * tab.W + x0 + 1] : z;
+            const int xa = min(max(x0, 0), tab.W - 1), xb = min(max(x0 + 1, 0), tab.W - 1);      // (unconditional loads: sat_sample)
+            const int ya = min(max(y0, 0), tab.H - 1), yb = min(max(y0 + 1, 0), tab.H - 1);
+            const float4 la = p[ya * tab.W + xa], lb = p[ya * tab.W + xb], lc = p[yb * tab.W + xa], ld = p[yb * tab.W + xb];
+            const float4 a = (xi0 && yi0) ? la : z;
+            const float4 b = (xi1 && yi0) ? lb : z;
+            const float4 c = (xi0 && yi1) ? lc : z;
+            const float4 d = (xi1 && yi1) ? ld : z;
             q[0] = go[0] * a.x + go[1] * a.y + go[2] * a.z;
             q[1] = go[0] * b.x + go[1] * b.y + go[2] * b.z;
             q[2] = go[0] * c.x + go[1] * c.y + go[2] * c.z;
@@ -529,6 +543,7 @@ struct SumAccQ {
 // LDS of the dual-number role: queue | rect + size as dual numbers [256][25] | d_out [256][3] | extra-box tangents [256][4]
 constexpr int ENV_DIRS_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (25 + 3 + 4) * 4;
 
+template <int LAYOUT>
 __device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem, bool to_slots) {
     typedef Dual<4> D;
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
@@ -567,7 +582,7 @@ __device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block
                 for (int i = 0; i < 4; ++i) geo[threadIdx.x][5 * k + 1 + i] = src[k]->d[i];
             }
             gos[threadIdx.x][0] = go[0]; gos[threadIdx.x][1] = go[1]; gos[threadIdx.x][2] = go[2];
-            SumAccQ acc;
+            SumAccQ<LAYOUT> acc;
             acc.tab = A.tab;
             acc.go[0] = go[0]; acc.go[1] = go[1]; acc.go[2] = go[2];
             acc.size = gd.size;
@@ -591,7 +606,7 @@ __device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block
         }
         Rect<D> rr{v[0], v[1], v[2], v[3]}, p;
         env_combo_rect(rr, combo, p);
-        SumAccQ acc;
+        SumAccQ<LAYOUT> acc;
         acc.tab = A.tab;
         acc.go[0] = gos[owner][0]; acc.go[1] = gos[owner][1]; acc.go[2] = gos[owner][2];
         acc.size = v[4];
@@ -672,10 +687,11 @@ __device__ __forceinline__ bool env_walk_main(const EnvBwdArgs& A, int64_t r, En
 }
 
 // pass 1
+template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, true); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, true); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     uint32_t* hist = reinterpret_cast<uint32_t*>(geo + 256);
@@ -793,10 +809,11 @@ struct EmitAcc {
 
 // pass 2
 constexpr int ENV_SCATTER_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (5 + 3) * 4 + (3 * ENV_MAX_TILES + 1 + 8) * 4;
+template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > ENV_SCATTER_LDS ? ENV_DIRS_LDS : ENV_SCATTER_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, true); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, true); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     float (*gs)[3] = reinterpret_cast<float (*)[3]>(geo + 256);
@@ -849,11 +866,12 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs 
 }
 
 // pass 3
+template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_accum(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     constexpr int OWN_LDS = ENV_WIN * 8 + (2 * ENV_MAX_TILES + 2 + 8) * 4;
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > OWN_LDS ? ENV_DIRS_LDS : OWN_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs(A, dirs_block0 + blk, smem, false); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, false); return; }
     if (blk == 0 && A.d_mipbias && threadIdx.x < 64) {      // the mip-bias adjoint the riders of passes 1 and 2 left in 64 slots
         float v = A.hdr->mip_slots[threadIdx.x];
         for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
@@ -1090,8 +1108,12 @@ extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const 
     NMF_REQUIRE(sat && dirs && sa && pole_rows && out, NMF_EINVAL, "nmf_sat_lookup_fwd: null");
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_fwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W, layout == 1};
-    hipLaunchKernelGGL(k_env_lookup_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
-                       (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
+    if (layout == 1)
+        hipLaunchKernelGGL(k_env_lookup_fwd<1>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
+                           (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
+    else
+        hipLaunchKernelGGL(k_env_lookup_fwd<0>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
+                           (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
     return NMF_OK;
 }
@@ -1128,9 +1150,15 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     // (tools/env_bwd_bench.py, us): all behind pass 3 155, 30/40/30 156, 50/50/0 144, all next to pass 2 138; direct scatter 176
     const int64_t d1 = 0, d2 = nb, d3 = nb - d1 - d2;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
-    hipLaunchKernelGGL(k_env_bin_count, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
-    hipLaunchKernelGGL(k_env_bin_scatter, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
-    hipLaunchKernelGGL(k_env_bin_accum, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+    if (layout == 1) {
+        hipLaunchKernelGGL(k_env_bin_count<1>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
+        hipLaunchKernelGGL(k_env_bin_scatter<1>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
+        hipLaunchKernelGGL(k_env_bin_accum<1>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+    } else {
+        hipLaunchKernelGGL(k_env_bin_count<0>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
+        hipLaunchKernelGGL(k_env_bin_scatter<0>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
+        hipLaunchKernelGGL(k_env_bin_accum<0>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+    }
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd_binned");
     return NMF_OK;
 }
@@ -1144,9 +1172,14 @@ extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const 
     NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd: null");
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W, layout == 1};
-    hipLaunchKernelGGL(k_env_lookup_bwd, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
-                       (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
-                       d_dirs, d_mipbias);
+    if (layout == 1)
+        hipLaunchKernelGGL(k_env_lookup_bwd<1>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
+                           (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
+                           d_dirs, d_mipbias);
+    else
+        hipLaunchKernelGGL(k_env_lookup_bwd<0>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
+                           (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
+                           d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");
     return NMF_OK;
 }
