@@ -185,37 +185,48 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     float* __restrict__ diffuse, float* __restrict__ feat, float* __restrict__ xyz) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= Mb) return;
+    // every load first (three dependent round trips: bidx -> ray_id and the row's inputs -> the ray), the stores behind them:
+    // interleaved as the values are produced, the launch was a chain of seven
     const int64_t m = bidx[row];
     const int64_t ia = row_inputs ? row : m;       // app / heads / noise given per bounce row or per sample
-    const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
-    const float vx = -d[0], vy = -d[1], vz = -d[2];
     const int64_t in = row_inputs == 2 ? row : m;  // normals per bounce row as well (row_inputs 2)
+    const int64_t rid = ray_id[m];
     const float nx = normals[in * 3], ny = normals[in * 3 + 1], nz = normals[in * 3 + 2];
+    const float* h = heads + ia * HEADS;
+    const float h0 = h[0], h1 = h[1], h2 = h[2], h6 = h[6], h7 = h[7], h8 = h[8], h9 = h[9];
+    const float4 p = xyzt[m];
+    const float4* a4 = reinterpret_cast<const float4*>(app + ia * FEAT);
+    const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + ia * FEAT) : nullptr;
+    float4 av[FEAT / 4], zv[FEAT / 4];
+#pragma unroll
+    for (int i = 0; i < FEAT / 4; ++i) {
+        av[i] = a4[i];
+        zv[i] = n4 ? n4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* d = rays + rid * 6 + 3;
+    const float vx = -d[0], vy = -d[1], vz = -d[2];
     const float s = sgn(vx * nx + vy * ny + vz * nz);                       // models/microfacet.py:356
     V[row * 3] = vx; V[row * 3 + 1] = vy; V[row * 3 + 2] = vz;
     N[row * 3] = nx * s; N[row * 3 + 1] = ny * s; N[row * 3 + 2] = nz * s;
-    const float* h = heads + ia * HEADS;
-    r1[row] = fmaxf(h[9], min_rough);
+    r1[row] = fmaxf(h9, min_rough);
     float Y[9];
     sh9(nx, ny, nz, Y);
+    const float hc[3] = {h0, h1, h2}, hf[3] = {h6, h7, h8};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float E = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
-        diffuse[row * 3 + c] = h[c] * E;
-        f0[row * 3 + c] = h[6 + c];
+        diffuse[row * 3 + c] = hc[c] * E;
+        f0[row * 3 + c] = hf[c];
     }
-    const float4 p = xyzt[m];
     xyz[row * 3] = p.x; xyz[row * 3 + 1] = p.y; xyz[row * 3 + 2] = p.z;
-    const float4* a4 = reinterpret_cast<const float4*>(app + ia * FEAT);
-    const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + ia * FEAT) : nullptr;
     float4* o4 = reinterpret_cast<float4*>(feat + row * FEAT);
 #pragma unroll
     for (int i = 0; i < FEAT / 4; ++i) {
-        float4 a = a4[i];
+        float4 a = av[i];
         if (n4) {
-            const float4 z = n4[i];
+            const float4 z = zv[i];
             a.x += z.x * anoise; a.y += z.y * anoise; a.z += z.z * anoise; a.w += z.w * anoise;
         }
         o4[i] = a;
