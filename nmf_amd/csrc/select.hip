@@ -107,13 +107,20 @@ __global__ void __launch_bounds__(256) k_view_adjoint_to_rays(const int32_t* __r
                                                               float* __restrict__ d_rays) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Mb) return;
-    const int64_t ray = ray_id[bidx[r]];
+    // (the six values are requested before the first atomic: loads do not move across atomics by themselves, and the launch was a
+    // chain of seven memory round trips for 82 instructions)
+    const int64_t m = bidx[r];
+    float v[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float v = dv_a[r * lda + k];
-        if (dv_b) v += dv_b[r * ldb + k];
-        if (v != 0.f) atomicAdd(&d_rays[ray * 6 + 3 + k], -v);
+    for (int k = 0; k < 3; ++k) v[k] = dv_a[r * lda + k];
+    if (dv_b) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] += dv_b[r * ldb + k];
     }
+    const int64_t ray = ray_id[m];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (v[k] != 0.f) atomicAdd(&d_rays[ray * 6 + 3 + k], -v[k]);
 }
 
 }  // namespace

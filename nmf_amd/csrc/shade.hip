@@ -244,6 +244,52 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     const float* __restrict__ ddiff, int sN, int sr, int sf, int sd, const float* __restrict__ dfeat,
     float* __restrict__ d_normals, float* __restrict__ d_heads, float* __restrict__ d_app) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row_inputs == 2 && heads && d_heads && d_app) {
+        // Everything per bounce row (the training pass with sparse normals): the same arithmetic as the general form below with
+        // every load in front of the stores -- bidx -> ray_id -> ray is the only chain (three round trips; the general form,
+        // which interleaves loads, stores and mode tests, waits eleven times)
+        if (t >= Mb) return;
+        const bool want_n = !detach_n && dN;
+        const int64_t m = bidx[t];
+        const float nx = normals[t * 3], ny = normals[t * 3 + 1], nz = normals[t * 3 + 2];
+        float dn[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f}, d0[3] = {0.f, 0.f, 0.f}, dr = 0.f;
+        if (want_n) { dn[0] = dN[t * sN]; dn[1] = dN[t * sN + 1]; dn[2] = dN[t * sN + 2]; }
+        if (ddiff) { dd[0] = ddiff[t * sd]; dd[1] = ddiff[t * sd + 1]; dd[2] = ddiff[t * sd + 2]; }
+        if (df0) { d0[0] = df0[t * sf]; d0[1] = df0[t * sf + 1]; d0[2] = df0[t * sf + 2]; }
+        if (dr1) dr = dr1[t * sr];
+        const float h9 = heads[t * HEADS + 9];
+        float4 gf[FEAT / 4];
+#pragma unroll
+        for (int i = 0; i < FEAT / 4; ++i)
+            gf[i] = dfeat ? reinterpret_cast<const float4*>(dfeat + t * FEAT)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float gn[3] = {0.f, 0.f, 0.f};
+        if (want_n) {
+            const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
+            const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
+            gn[0] = dn[0] * s; gn[1] = dn[1] * s; gn[2] = dn[2] * s;
+        }
+        d_normals[t * 3] = gn[0]; d_normals[t * 3 + 1] = gn[1]; d_normals[t * 3 + 2] = gn[2];
+        float gh[HEADS];
+#pragma unroll
+        for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
+        float Y[9];
+        sh9(nx, ny, nz, Y);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float E = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
+            gh[c] = ddiff ? dd[c] * E : 0.f;
+            gh[6 + c] = d0[c];
+        }
+        gh[9] = (dr1 && h9 >= min_rough) ? dr : 0.f;
+        float4* o4 = reinterpret_cast<float4*>(d_app + t * FEAT);
+#pragma unroll
+        for (int i = 0; i < FEAT / 4; ++i) o4[i] = gf[i];
+#pragma unroll
+        for (int j = 0; j < HEADS; ++j) d_heads[t * HEADS + j] = gh[j];
+        return;
+    }
     if (row_inputs == 2) {          // normals and their adjoint per bounce row: [Mb][3], nothing sample-sized is touched
         if (t < Mb) {
             float gn[3] = {0.f, 0.f, 0.f};
