@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 106
+#define NMF_ABI_VERSION 107
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -428,6 +428,27 @@ int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const fl
                      float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
                      int64_t workspace_bytes, void* stream);
 int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups);
+/* The backward over ONE OR TWO ray sets in one launch (R4): the BRDF evaluations of a recursion level and of the level below it
+ * (models/microfacet.py:377-456 at recur 0 and 1) share the weights, and a launch costs ~25 us before and after its tiles whatever
+ * its size.  image: nmf_brdf_mlp_pack's output or NULL (then W0..b4 are read); per set the arguments of nmf_brdf_mlp_bwd; sets
+ * with R = 0 are skipped.  Gradients as in nmf_brdf_mlp_bwd (ACCUMULATED).  Workspace: nmf_brdf_mlp_bwd_segments_workspace_bytes. */
+typedef struct nmf_mlp_bwd_segment {
+    const float* half_vec;      /* [R][3] */
+    const float* diff_vec;      /* [R][3] */
+    const float* feat_src;      /* [rows][24] */
+    const float* rough_src;     /* [rows] */
+    const int32_t* src_idx;     /* [R] row of every ray, non-decreasing (NULL: ray r reads row r) */
+    int64_t R;
+    const float* fwd_out;       /* [R][3]  the forward's output */
+    const uint32_t* act_mask;   /* [R][4]  the forward's ReLU masks */
+    const float* d_out;         /* [R][3] */
+    float* d_feat;              /* [rows][24], ACCUMULATED */
+} nmf_mlp_bwd_segment;
+int nmf_brdf_mlp_bwd_segments(const void* image, const float* W0, const float* b0, const float* W2, const float* b2,
+                              const float* W4, const float* b4, const nmf_mlp_bwd_segment* segs /*HOST array*/, int32_t n_segs,
+                              float* gW0, float* gb0, float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int64_t nmf_brdf_mlp_bwd_segments_workspace_bytes(const int64_t* Rs /*HOST*/, int32_t n_segs, int32_t max_workgroups);
 /* The same two calls with the weights as a PACKED IMAGE (R4): what the kernels stage into LDS in front of their first tile --
  * the split-bf16 planes of W0 | b0, W2 (forward: three terms; backward: two terms plus W2^T and W0[:, :24]^T) and the fp32 rows
  * of the last layer -- written once per weight update by nmf_brdf_mlp_pack (one launch of two workgroups) into

@@ -530,18 +530,49 @@ __device__ __forceinline__ UOp transpose_block(const Op<2>& c0, const Op<2>& c1,
 
 constexpr int N_PERSIST = 64 + 64 + 8 + 6 + 2 + 3;   // per-lane partial sums that are reduced over the waves at the end
 
+// One ray set of a backward launch.  A launch takes up to TWO (R4: the BRDF evaluations of a level and of the level below it share
+// the weights; as two launches each paid ~25 us of fixed cost -- prologue, a first tile from a cold instruction cache, epilogue,
+// the reduction of the partials -- and the smaller one stood on the main stream's chain): tiles [0, tiles0) belong to set 0, the
+// rest to set 1, a tile never straddles.
+struct MlpBwdSeg {
+    const float *half_v, *diff_v, *feat_src, *rough_src;
+    const int32_t* src_idx;
+    int64_t R;
+    const float* fwd_out;
+    const uint4* act_mask;
+    const float* d_out;
+    float* d_feat;
+};
+struct MlpBwdSegs {
+    MlpBwdSeg s[2];      // (a launch with one set passes it twice: tiles past the end are prefetched, never worked on)
+    int64_t tiles0, n_tiles;
+};
+
 // Backward.  fwd_out / act_mask are the forward's outputs for the same inputs.
 __global__ void __launch_bounds__(64 * BWD_WAVES)
-k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict__ diff_v,
-               const float* __restrict__ feat_src, const float* __restrict__ rough_src,
-               const int32_t* __restrict__ src_idx, int64_t R, const float* __restrict__ fwd_out,
-               const uint4* __restrict__ act_mask, const float* __restrict__ d_out, float* __restrict__ d_feat,
-               float* __restrict__ partials, const uint4* __restrict__ image) {
+k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* __restrict__ image) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = BWD_WAVES, NT = 64 * BWD_WAVES;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, ray = lane & 31;
-    const int64_t n_tiles = (R + RT - 1) / RT, stride = (int64_t)gridDim.x * NW;
+    const int64_t n_tiles = G.n_tiles, stride = (int64_t)gridDim.x * NW;
     int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    // the ray set of a tile (wave-uniform selects of kernel arguments) and the tile's index inside it
+    auto pick = [&](int64_t tl, int64_t& local) {
+        const bool second = tl >= G.tiles0;
+        local = second ? tl - G.tiles0 : tl;
+        MlpBwdSeg S;
+        S.half_v = second ? G.s[1].half_v : G.s[0].half_v;
+        S.diff_v = second ? G.s[1].diff_v : G.s[0].diff_v;
+        S.feat_src = second ? G.s[1].feat_src : G.s[0].feat_src;
+        S.rough_src = second ? G.s[1].rough_src : G.s[0].rough_src;
+        S.src_idx = second ? G.s[1].src_idx : G.s[0].src_idx;
+        S.R = second ? G.s[1].R : G.s[0].R;
+        S.fwd_out = second ? G.s[1].fwd_out : G.s[0].fwd_out;
+        S.act_mask = second ? G.s[1].act_mask : G.s[0].act_mask;
+        S.d_out = second ? G.s[1].d_out : G.s[0].d_out;
+        S.d_feat = second ? G.s[1].d_feat : G.s[0].d_feat;
+        return S;
+    };
     // the forward's outputs and the incoming adjoint of a lane's ray, requested one tile ahead like RayIn (raw values: nothing
     // is computed from them before the tile that uses them, so the loads stay in flight across the tile before)
     struct Adj {
@@ -550,22 +581,24 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         bool valid;
         __device__ __forceinline__ float g(int j) const { return valid ? go[j] * s[j] * (1.f - s[j]) : 0.f; }
     };
-    auto load_adj = [&](Adj& a, const RayIn& in) {
-        a.mk = act_mask[in.rc];
+    auto load_adj = [&](Adj& a, const RayIn& in, const MlpBwdSeg& S) {
+        a.mk = S.act_mask[in.rc];
         a.valid = in.valid;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            a.s[j] = fwd_out[in.rc * 3 + j];
-            a.go[j] = d_out[in.rc * 3 + j];
+            a.s[j] = S.fwd_out[in.rc * 3 + j];
+            a.go[j] = S.d_out[in.rc * 3 + j];
         }
     };
     RayIn cur;
     Adj adj;
-    ray_in_stage1(cur, tile, R, ray, h, half_v, diff_v, src_idx);
-    load_adj(adj, cur);
+    int64_t tl_local;
+    MlpBwdSeg Sc = pick(tile, tl_local);
+    ray_in_stage1(cur, tl_local, Sc.R, ray, h, Sc.half_v, Sc.diff_v, Sc.src_idx);
+    load_adj(adj, cur, Sc);
     if (image) load_image<BWD_SHARED, NT>(smem, image + IMG_FWD / 16, t);
     else stage_bwd<NT>(smem, w, t);
-    ray_in_stage2(cur, feat_src, rough_src);
+    ray_in_stage2(cur, Sc.feat_src, Sc.rough_src);
     char* priv = smem + BWD_SHARED + wave * BWD_PRIVATE;
     char* x = priv;                                                 // input planes
     char* pl = priv + 2 * PX;                                       // 64-wide planes: H1, then dH2, then dH1
@@ -605,8 +638,10 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
         // the input planes of this tile are in LDS; the row indices / adjoints of the next one are requested now
         RayIn nxt;
         Adj nadj;
-        ray_in_stage1(nxt, tile + stride, R, ray, h, half_v, diff_v, src_idx);
-        load_adj(nadj, nxt);
+        int64_t nx_local;
+        const MlpBwdSeg Sn = pick(tile + stride, nx_local);
+        ray_in_stage1(nxt, nx_local, Sn.R, ray, h, Sn.half_v, Sn.diff_v, Sn.src_idx);
+        load_adj(nadj, nxt, Sn);
         const uint32_t m1[2] = {adj.mk.x >> (4 * h), adj.mk.y >> (4 * h)}, m2[2] = {adj.mk.z >> (4 * h), adj.mk.w >> (4 * h)};
         const float g[3] = {adj.g(0), adj.g(1), adj.g(2)};
         if (h == 0) {
@@ -677,7 +712,7 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
             write_rows<2>(pl, ray, ub, h, d2);
         }
         __builtin_amdgcn_wave_barrier();
-        ray_in_stage2(nxt, feat_src, rough_src);     // the next tile's feature rows: used at the end of this iteration
+        ray_in_stage2(nxt, Sn.feat_src, Sn.rough_src);     // the next tile's feature rows: used at the end of this iteration
         {
             Op<2> dh[4];
 #pragma unroll
@@ -791,12 +826,13 @@ k_brdf_mlp_bwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc += (sel >> j) & 1u ? v[j] : 0.f;
-                if (owner && sel) atomicAdd(d_feat + (int64_t)row * 24 + col, acc);
+                if (owner && sel) atomicAdd(Sc.d_feat + (int64_t)row * 24 + col, acc);
             }
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
         adj = nadj;
+        Sc = Sn;
     }
     // ---- the per-lane sums of the four waves -> one partial per workgroup in the workspace (k_brdf_mlp_reduce adds the
     //      partials of all workgroups in a fixed order: one atomic per gradient element and call instead of one per workgroup)
@@ -985,43 +1021,87 @@ extern "C" int nmf_brdf_mlp_fwd_packed(const void* image, const float* half_vec,
                         stream);
 }
 
-static unsigned bwd_grid(int64_t R, int32_t max_workgroups) {
+static unsigned bwd_grid_tiles(int64_t tiles, int32_t max_workgroups) {
     // One workgroup of 4 waves per CU (150 KB of LDS, one wave per SIMD).  Every workgroup stages the weight images
     // and writes a 37 KB partial, so short launches use fewer of them: at least 2 tiles per wave (45 k rays: 54 us against 63
     // with 4 tiles per wave).
-    const int64_t wgs = cdiv(cdiv(R, RT), BWD_WAVES * 2);
+    const int64_t wgs = cdiv(tiles, BWD_WAVES * 2);
     int64_t cap = 256;
     if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
     return (unsigned)(wgs < cap ? wgs : cap);
 }
+static unsigned bwd_grid(int64_t R, int32_t max_workgroups) { return bwd_grid_tiles(cdiv(R, RT), max_workgroups); }
 
 extern "C" int64_t nmf_brdf_mlp_bwd_workspace_bytes(int64_t R, int32_t max_workgroups) {
     return R <= 0 ? 0 : (int64_t)bwd_grid(R, max_workgroups) * N_PERSIST * 64 * (int64_t)sizeof(float);
 }
 
-static int mlp_bwd_impl(const MlpW& w, const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
-                        const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out, const uint32_t* act_mask,
-                        const float* d_out, float* d_feat, float* gW0, float* gb0, float* gW2, float* gb2, float* gW4, float* gb4,
-                        int32_t max_workgroups, void* workspace, int64_t workspace_bytes, void* stream) {
-    NMF_REQUIRE(half_vec && diff_vec && feat_src && rough_src && fwd_out && act_mask && d_out && d_feat && gW0 && gb0 && gW2 &&
-                    gb2 && gW4 && gb4,
-                NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
-    NMF_REQUIRE(workspace && workspace_bytes >= nmf_brdf_mlp_bwd_workspace_bytes(R, max_workgroups), NMF_EINVAL,
+extern "C" int64_t nmf_brdf_mlp_bwd_segments_workspace_bytes(const int64_t* Rs, int32_t n_segs, int32_t max_workgroups) {
+    int64_t tiles = 0;
+    for (int i = 0; Rs && i < n_segs; ++i) tiles += Rs[i] > 0 ? cdiv(Rs[i], RT) : 0;
+    return tiles <= 0 ? 0 : (int64_t)bwd_grid_tiles(tiles, max_workgroups) * N_PERSIST * 64 * (int64_t)sizeof(float);
+}
+
+// segs: one or two ray sets with R > 0
+static int mlp_bwd_launch(const MlpW& w, const void* image, const nmf_mlp_bwd_segment* segs, int n, float* gW0, float* gb0,
+                          float* gW2, float* gb2, float* gW4, float* gb4, int32_t max_workgroups, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(gW0 && gb0 && gW2 && gb2 && gW4 && gb4, NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
+    MlpBwdSegs G;
+    int64_t tiles[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const nmf_mlp_bwd_segment& q = segs[i];
+        NMF_REQUIRE(q.half_vec && q.diff_vec && q.feat_src && q.rough_src && q.fwd_out && q.act_mask && q.d_out && q.d_feat,
+                    NMF_EINVAL, "nmf_brdf_mlp_bwd: null");
+        G.s[i] = MlpBwdSeg{q.half_vec, q.diff_vec, q.feat_src, q.rough_src, q.src_idx, q.R, q.fwd_out,
+                           reinterpret_cast<const uint4*>(q.act_mask), q.d_out, q.d_feat};
+        tiles[i] = cdiv(q.R, RT);
+    }
+    if (n == 1) G.s[1] = G.s[0];
+    G.tiles0 = tiles[0];
+    G.n_tiles = tiles[0] + tiles[1];
+    const unsigned grid = bwd_grid_tiles(G.n_tiles, max_workgroups);
+    NMF_REQUIRE(workspace && workspace_bytes >= (int64_t)grid * N_PERSIST * 64 * (int64_t)sizeof(float), NMF_EINVAL,
                 "nmf_brdf_mlp_bwd: workspace too small (nmf_brdf_mlp_bwd_workspace_bytes)");
     static_assert(BWD_WAVES * N_PERSIST * 64 * 4 <= BWD_LDS, "the per-wave sums fit into the kernel's LDS");
     static const int lds = set_lds_once((const void*)k_brdf_mlp_bwd, BWD_LDS, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
     if (lds != NMF_OK) return lds;
-    const unsigned grid = bwd_grid(R, max_workgroups);
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, half_vec,
-                       diff_vec, feat_src, rough_src, src_idx, R, fwd_out, reinterpret_cast<const uint4*>(act_mask),
-                       d_out, d_feat, partials, static_cast<const uint4*>(image));
+    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, G, partials,
+                       static_cast<const uint4*>(image));
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
     static_assert((N_PERSIST * 64) % 32 == 0, "k_brdf_mlp_reduce takes 32 elements per workgroup");
     hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
                        gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;
+}
+
+static int mlp_bwd_impl(const MlpW& w, const void* image, const float* half_vec, const float* diff_vec, const float* feat_src,
+                        const float* rough_src, const int32_t* src_idx, int64_t R, const float* fwd_out, const uint32_t* act_mask,
+                        const float* d_out, float* d_feat, float* gW0, float* gb0, float* gW2, float* gb2, float* gW4, float* gb4,
+                        int32_t max_workgroups, void* workspace, int64_t workspace_bytes, void* stream) {
+    const nmf_mlp_bwd_segment seg{half_vec, diff_vec, feat_src, rough_src, src_idx, R, fwd_out, act_mask, d_out, d_feat};
+    return mlp_bwd_launch(w, image, &seg, 1, gW0, gb0, gW2, gb2, gW4, gb4, max_workgroups, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nmf_brdf_mlp_bwd_segments(const void* image, const float* W0, const float* b0, const float* W2, const float* b2,
+                                         const float* W4, const float* b4, const nmf_mlp_bwd_segment* segs, int32_t n_segs,
+                                         float* gW0, float* gb0, float* gW2, float* gb2, float* gW4, float* gb4,
+                                         int32_t max_workgroups, void* workspace, int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(segs && n_segs >= 1 && n_segs <= 2, NMF_EINVAL, "nmf_brdf_mlp_bwd_segments: one or two ray sets");
+    const float* ws[6] = {W0, b0, W2, b2, W4, b4};
+    NMF_REQUIRE((image && ((uintptr_t)image & 15) == 0) || check_w(ws), NMF_EINVAL,
+                "nmf_brdf_mlp_bwd_segments: a packed image (16-byte aligned) or the six weight tensors");
+    nmf_mlp_bwd_segment live[2];
+    int n = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        NMF_REQUIRE(segs[i].R >= 0, NMF_EINVAL, "nmf_brdf_mlp_bwd_segments: R < 0");
+        if (segs[i].R > 0) live[n++] = segs[i];
+    }
+    if (n == 0) return NMF_OK;
+    return mlp_bwd_launch(image ? MlpW{} : MlpW{W0, b0, W2, b2, W4, b4}, image, live, n, gW0, gb0, gW2, gb2, gW4, gb4, max_workgroups,
+                          workspace, workspace_bytes, stream);
 }
 
 extern "C" int nmf_brdf_mlp_bwd(const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,

@@ -500,6 +500,42 @@ Tensor brdf_mlp_bwd(const std::vector<Tensor>& w, const Tensor& half_vec, const 
     return d_feat;
 }
 
+// the same over ONE OR TWO ray sets in one launch (nmf_brdf_mlp_bwd_segments); a set = {half_vec, diff_vec, feat_src, rough_src,
+// src_idx, fwd_out, act_mask, d_out}; -> d_feat per set
+using MlpSet = std::tuple<Tensor, Tensor, Tensor, Tensor, OT, Tensor, Tensor, Tensor>;
+std::vector<Tensor> brdf_mlp_bwd_sets(const std::vector<Tensor>& w, const std::vector<MlpSet>& sets, const std::vector<Tensor>& grads,
+                                      int64_t max_workgroups, int64_t stream, const OT& image = c10::nullopt) {
+    TimedScope _ts("brdf_mlp_bwd", stream);
+    const bool packed = image.has_value() && image->defined();
+    if ((!packed && w.size() != 6) || grads.size() != 6) fail("brdf_mlp_bwd_sets: six weight / gradient tensors expected");
+    if (sets.empty() || sets.size() > 2) fail("brdf_mlp_bwd_sets: one or two ray sets");
+    nmf_mlp_bwd_segment arr[2];
+    int64_t Rs[2] = {0, 0};
+    std::vector<Tensor> outs, keep;
+    for (size_t i = 0; i < sets.size(); ++i) {
+        const Tensor& hv = std::get<0>(sets[i]);
+        const Tensor& feat = std::get<2>(sets[i]);
+        Tensor d_feat = at::zeros({feat.size(0), 24}, hv.options().dtype(at::kFloat));
+        Tensor go = std::get<7>(sets[i]).contiguous();
+        keep.push_back(go);
+        outs.push_back(d_feat);
+        arr[i] = nmf_mlp_bwd_segment{f32(hv), f32(std::get<1>(sets[i])), f32(feat), f32(std::get<3>(sets[i])),
+                                     optr<const int32_t>(std::get<4>(sets[i]), at::kInt), hv.size(0), f32(std::get<5>(sets[i])),
+                                     static_cast<const uint32_t*>(std::get<6>(sets[i]).data_ptr()), f32(go), out(d_feat)};
+        Rs[i] = hv.size(0);
+    }
+    float* g[6];
+    for (int i = 0; i < 6; ++i) g[i] = static_cast<float*>(vptr(grads[i]));
+    const int64_t nws = nmf_brdf_mlp_bwd_segments_workspace_bytes(Rs, (int32_t)sets.size(), (int32_t)max_workgroups);
+    Tensor ws = fe(std::get<0>(sets[0]), {std::max<int64_t>(nws, 4) / 4});
+    check(nmf_brdf_mlp_bwd_segments(packed ? image->data_ptr() : nullptr, packed ? nullptr : f32(w[0]), packed ? nullptr : f32(w[1]),
+                                    packed ? nullptr : f32(w[2]), packed ? nullptr : f32(w[3]), packed ? nullptr : f32(w[4]),
+                                    packed ? nullptr : f32(w[5]), arr, (int32_t)sets.size(), g[0], g[1], g[2], g[3], g[4], g[5],
+                                    (int32_t)max_workgroups, out(ws), nws, st(stream)),
+          "nmf_brdf_mlp_bwd_segments");
+    return outs;
+}
+
 Tensor heads_bwd(const Tensor& feat, const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& d_out,
                  const Tensor& gW, const Tensor& gb, const OT& add_into, int64_t stream) {
     // add_into: another adjoint of the same rows [M,24] (dense fp32); the result is added to it IN PLACE and it is returned
@@ -1018,6 +1054,8 @@ PYBIND11_MODULE(_nmf_host, m) {
           py::arg("src_idx"), py::arg("out_bias"), py::arg("with_mask"), py::arg("max_workgroups"), py::arg("stream"),
           py::arg("image") = py::none());
     m.def("brdf_mlp_pack", &brdf_mlp_pack);
+    m.def("brdf_mlp_bwd_sets", &brdf_mlp_bwd_sets, py::arg("w"), py::arg("sets"), py::arg("grads"), py::arg("max_workgroups"), py::arg("stream"),
+          py::arg("image") = py::none());
     m.def("heads_fwd", &heads_fwd);
     m.def("ggx_rays_fwd", &ggx_rays_fwd);
     m.def("shade_mix_fwd", &shade_mix_fwd);

@@ -68,7 +68,7 @@ EXPORTS = [
     "nmf_sat_lookup_bwd_workspace_bytes",
     "nmf_select_bounces", "nmf_select_total", "nmf_view_adjoint_to_rays", "nmf_expand_segments", "nmf_segment_sum_wide",
     "nmf_brdf_mlp_fwd", "nmf_brdf_mlp_bwd", "nmf_brdf_mlp_bwd_workspace_bytes", "nmf_brdf_mlp_image_bytes", "nmf_brdf_mlp_pack",
-    "nmf_brdf_mlp_fwd_packed", "nmf_brdf_mlp_bwd_packed", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
+    "nmf_brdf_mlp_fwd_packed", "nmf_brdf_mlp_bwd_packed", "nmf_brdf_mlp_bwd_segments", "nmf_brdf_mlp_bwd_segments_workspace_bytes", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
@@ -782,6 +782,38 @@ def brdf_mlp_bwd(weights, half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_
     else:
         _check(_lib.nmf_brdf_mlp_bwd(*[_p(w, torch.float32) for w in weights], *tail), "nmf_brdf_mlp_bwd")
     return d_feat
+
+
+class MlpBwdSegment(C.Structure):
+    _fields_ = [("half_vec", C.c_void_p), ("diff_vec", C.c_void_p), ("feat_src", C.c_void_p), ("rough_src", C.c_void_p),
+                ("src_idx", C.c_void_p), ("R", C.c_int64), ("fwd_out", C.c_void_p), ("act_mask", C.c_void_p), ("d_out", C.c_void_p),
+                ("d_feat", C.c_void_p)]
+
+
+def brdf_mlp_bwd_segments(weights, sets, grads, max_workgroups=0, image=None):
+    """brdf_mlp_bwd over one or two ray sets in ONE launch (the evaluations of a level and of the level below share the weights).
+    sets: tuples (half_vec, diff_vec, feat_src, rough_src, src_idx, fwd_out, act_mask, d_out) -> list of d_feat, one per set."""
+    if not 1 <= len(sets) <= 2:
+        raise ValueError("brdf_mlp_bwd_segments: one or two ray sets")
+    dev = sets[0][0].device
+    arr = (MlpBwdSegment * len(sets))()
+    keep, outs = [], []
+    for i, (hv, dv, feat, rough, idx, out, mask, d_out) in enumerate(sets):
+        d_feat = torch.zeros((feat.shape[0], 24), dtype=torch.float32, device=dev)
+        go = d_out.contiguous()
+        keep.append(go)
+        outs.append(d_feat)
+        arr[i] = MlpBwdSegment(_p(hv, torch.float32), _p(dv, torch.float32), _p(feat, torch.float32), _p(rough, torch.float32),
+                               _p(idx, torch.int32), hv.shape[0], _p(out, torch.float32), _p(mask, torch.int32), _p(go, torch.float32),
+                               _p(d_feat))
+    Rs = (C.c_int64 * len(sets))(*[s[0].shape[0] for s in sets])
+    nws = int(_lib.nmf_brdf_mlp_bwd_segments_workspace_bytes(Rs, C.c_int32(len(sets)), C.c_int32(max_workgroups)))
+    ws = torch.empty(max(nws, 4) // 4, dtype=torch.float32, device=dev)
+    wp = [None] * 6 if image is not None else [_p(w, torch.float32) for w in weights]
+    _check(_lib.nmf_brdf_mlp_bwd_segments(_p(image) if image is not None else None, *wp, arr, C.c_int32(len(sets)),
+                                          *[_p(g) for g in grads], C.c_int32(max_workgroups), _p(ws), C.c_int64(nws), _stream()),
+           "nmf_brdf_mlp_bwd_segments")
+    return outs
 
 
 def heads_fwd(feat, W, b, hp):

@@ -710,6 +710,25 @@ def test_brdf_mlp_fused_matches_oracle(R):
     for x, y in zip(ga, gb):
         assert torch.equal(x, y)
     assert_close(db.cpu(), da.cpu(), rtol=1e-5, atol=1e-6 * float(da.abs().max() + 1e-6), what="d feat (packed weights)")
+    # two ray sets in ONE launch (nmf_brdf_mlp_bwd_segments: a level and the level below it): the sum of two launches
+    if R >= 257:
+        R2 = R // 3
+        idx2 = rows[:R2].int().to(DEV)
+        set_a = (hv.to(DEV), dv.to(DEV), feat_d.detach(), rough.to(DEV), rows.int().to(DEV), out2, mask, c.to(DEV))
+        set_b = (hv[:R2].to(DEV).contiguous(), dv[:R2].to(DEV).contiguous(), feat_d.detach(), rough.to(DEV), idx2, out2[:R2].contiguous(),
+                 mask[:R2].contiguous(), (2 * c[:R2]).to(DEV).contiguous())
+        gs, g1 = [torch.zeros_like(w) for w in wsd], [torch.zeros_like(w) for w in wsd]
+        fa = hip.brdf_mlp_bwd(wsd, *set_a, g1)
+        fb = hip.brdf_mlp_bwd(wsd, *set_b, g1)
+        for use_img in (False, True):
+            gs = [torch.zeros_like(w) for w in wsd]
+            oa, ob = hip.brdf_mlp_bwd_segments(None if use_img else wsd, [set_a, set_b], gs, image=img if use_img else None)
+            assert_close(oa.cpu(), fa.cpu(), rtol=1e-5, atol=1e-6 * float(fa.abs().max() + 1e-6), what="two sets: d_feat of set 0")
+            assert_close(ob.cpu(), fb.cpu(), rtol=1e-5, atol=1e-6 * float(fb.abs().max() + 1e-6), what="two sets: d_feat of set 1")
+            for x, y in zip(gs, g1):
+                assert_close(x.cpu(), y.cpu(), rtol=1e-5, atol=2e-6 * float(y.abs().max() + 1e-6), what="two sets: weight gradients")
+        one = hip.brdf_mlp_bwd_segments(wsd, [set_a], [torch.zeros_like(w) for w in wsd])
+        assert_close(one[0].cpu(), fa.cpu(), rtol=1e-5, atol=1e-6 * float(fa.abs().max() + 1e-6), what="one set through the segments call")
     if R == 257:      # golden (reference) values for exactly this input set
         w = brdf_mlp(g["brdf_half"].to(DEV), g["brdf_diff"].to(DEV), g["brdf_feat"].to(DEV).contiguous(),
                      g["brdf_rough"].to(DEV), torch.arange(257, dtype=torch.int32, device=DEV),
