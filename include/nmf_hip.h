@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 107
+#define NMF_ABI_VERSION 108
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -254,6 +254,12 @@ int nmf_vm_query_bwd_planned(const nmf_vm_params* p, const nmf_vm_bwd_segment* s
 int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* const g_dpk[3],
                                const float* const g_dlk[3], float* const g_planes[3],
                                float* const g_lines[3], void* stream);
+/* The same with the gradient of the density L1 term added in the same pass: g += l1_scale_dev[0] * sgn(x) / numel(x) for each of
+ * the six density parameters x (fields/tensoRF.py:332-340 `density_L1`, weighted by train.py:640-677), given in the storage
+ * order of the gradients.  Same bits as the unpack followed by nmf_l1_mean_bwd(accumulate), one launch less at the end of a step. */
+int nmf_vm_unpack_density_grad_l1(const nmf_vm_params* p, const float* const g_dpk[3], const float* const g_dlk[3],
+                                  float* const g_planes[3], float* const g_lines[3], const float* const x_planes[3],
+                                  const float* const x_lines[3], const float* l1_scale_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Compositing: raw2alpha (modules/tensor_nerf.py:19-35) and row_mask_sum

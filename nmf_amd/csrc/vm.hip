@@ -161,8 +161,15 @@ __global__ void __launch_bounds__(256) k_pack_tables(nmf_vm_params p, Pack6 a) {
 }
 
 // transpose of the pack: gP = gdpk.P + corr^T(gdpk.DX) + corr^T(gdpk.DY)
+// x (optional, with l1): the parameter itself in the same storage order -- the gradient of l1[0] * mean |x| is added in the same
+// pass (the training step's density_L1 term: fields/tensoRF.py:332-340; one launch less on the serial tail of a step)
+__device__ __forceinline__ float l1_term(const float* __restrict__ x, const float* __restrict__ l1, int64_t idx, int64_t n) {
+    if (!x) return 0.f;
+    const float s = l1[0] / (float)n, v = x[idx];
+    return v > 0.f ? s : (v < 0.f ? -s : 0.f);
+}
 __device__ __forceinline__ void unpack_plane(const nmf_vm_params& p, const float* __restrict__ g,
-                                             float* __restrict__ gP) {
+                                             float* __restrict__ gP, const float* __restrict__ xp, const float* __restrict__ l1) {
     const int G = p.grid;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)G * G * CD) return;
@@ -184,10 +191,13 @@ __device__ __forceinline__ void unpack_plane(const nmf_vm_params& p, const float
             acc += row[j] * at(y - j + 2, x - i + 2, 2 * CD);
         }
     }
-    gP[((int64_t)y * G + x) * CD + c] = acc;
+    const int64_t idx = ((int64_t)y * G + x) * CD + c;
+    const float gv = l1_term(xp, l1, idx, (int64_t)G * G * CD);
+    gP[idx] = xp ? acc + gv : acc;
 }
 
-__device__ __forceinline__ void unpack_line(const nmf_vm_params& p, const float* __restrict__ g, float* __restrict__ gL) {
+__device__ __forceinline__ void unpack_line(const nmf_vm_params& p, const float* __restrict__ g, float* __restrict__ gL,
+                                            const float* __restrict__ xp, const float* __restrict__ l1) {
     const int G = p.grid;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * CD) return;
@@ -198,15 +208,21 @@ __device__ __forceinline__ void unpack_line(const nmf_vm_params& p, const float*
         int kk = k - i + 2;
         if (i != 2 && kk >= 0 && kk < G) acc += p.stencil[i] * g[kk * DL + CD + c];
     }
-    gL[k * CD + c] = acc;
+    const float gv = l1_term(xp, l1, (int64_t)k * CD + c, (int64_t)G * CD);
+    gL[k * CD + c] = xp ? acc + gv : acc;
 }
 
-__global__ void __launch_bounds__(256) k_unpack_tables(nmf_vm_params p, Pack6 a) {
+struct L1Six {
+    const float* x[6];      // the six density parameters (planes 0-2, lines 3-5), or all NULL
+    const float* l1;
+};
+__global__ void __launch_bounds__(256) k_unpack_tables(nmf_vm_params p, Pack6 a, L1Six q) {
     const int y = blockIdx.y;
     const float* src = y == 0 ? a.src[0] : y == 1 ? a.src[1] : y == 2 ? a.src[2] : y == 3 ? a.src[3] : y == 4 ? a.src[4] : a.src[5];
     float* dst = y == 0 ? a.dst[0] : y == 1 ? a.dst[1] : y == 2 ? a.dst[2] : y == 3 ? a.dst[3] : y == 4 ? a.dst[4] : a.dst[5];
-    if (y < 3) unpack_plane(p, src, dst);
-    else unpack_line(p, src, dst);
+    const float* xp = y == 0 ? q.x[0] : y == 1 ? q.x[1] : y == 2 ? q.x[2] : y == 3 ? q.x[3] : y == 4 ? q.x[4] : q.x[5];
+    if (y < 3) unpack_plane(p, src, dst, xp, q.l1);
+    else unpack_line(p, src, dst, xp, q.l1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1535,9 +1551,23 @@ extern "C" int nmf_vm_pack_density(const nmf_vm_params* p, const float* const pl
     return NMF_OK;
 }
 
+static int unpack_impl(const nmf_vm_params* p, const float* const g_dpk[3], const float* const g_dlk[3], float* const g_planes[3],
+                       float* const g_lines[3], const float* const x_planes[3], const float* const x_lines[3], const float* l1,
+                       void* stream);
 extern "C" int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* const g_dpk[3],
                                           const float* const g_dlk[3], float* const g_planes[3],
                                           float* const g_lines[3], void* stream) {
+    return unpack_impl(p, g_dpk, g_dlk, g_planes, g_lines, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int nmf_vm_unpack_density_grad_l1(const nmf_vm_params* p, const float* const g_dpk[3], const float* const g_dlk[3],
+                                             float* const g_planes[3], float* const g_lines[3], const float* const x_planes[3],
+                                             const float* const x_lines[3], const float* l1_scale_dev, void* stream) {
+    NMF_REQUIRE(all3(x_planes) && all3(x_lines) && l1_scale_dev, NMF_EINVAL, "nmf_vm_unpack_density_grad_l1: null");
+    return unpack_impl(p, g_dpk, g_dlk, g_planes, g_lines, x_planes, x_lines, l1_scale_dev, stream);
+}
+static int unpack_impl(const nmf_vm_params* p, const float* const g_dpk[3], const float* const g_dlk[3], float* const g_planes[3],
+                       float* const g_lines[3], const float* const x_planes[3], const float* const x_lines[3], const float* l1,
+                       void* stream) {
     NMF_REQUIRE(p && all3(g_dpk) && all3(g_dlk) && all3m(g_planes) && all3m(g_lines), NMF_EINVAL,
                 "nmf_vm_unpack_density_grad: null");
     const int G = p->grid;
@@ -1547,7 +1577,10 @@ extern "C" int nmf_vm_unpack_density_grad(const nmf_vm_params* p, const float* c
         a.src[i] = g_dpk[i]; a.dst[i] = g_planes[i];
         a.src[3 + i] = g_dlk[i]; a.dst[3 + i] = g_lines[i];
     }
-    hipLaunchKernelGGL(k_unpack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a);
+    L1Six q;
+    for (int i = 0; i < 3; ++i) { q.x[i] = x_planes ? x_planes[i] : nullptr; q.x[3 + i] = x_lines ? x_lines[i] : nullptr; }
+    q.l1 = l1;
+    hipLaunchKernelGGL(k_unpack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a, q);
     NMF_CHECK_LAUNCH("nmf_vm_unpack_density_grad");
     return NMF_OK;
 }

@@ -811,16 +811,16 @@ class TrainPass:
         nerf = self.nerf
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
         p = rf._tables()[0]
-        if a.gp is None:
-            a.gp, a.gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk)
-        else:
-            hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, out=(a.gp, a.gl))
-        gp, gl = a.gp, a.gl
-        if self.l1_scale != 0.0:
+        l1 = None
+        if self.l1_scale != 0.0:          # the L1 term's gradient rides in the unpack launch (one launch less on the step's tail)
             if a.l1 is None or a.l1[0] != self.l1_scale:
                 a.l1 = (self.l1_scale, torch.full((), self.l1_scale, dtype=torch.float32, device=a.flat.device))
-            dens = [x.detach() for x in list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)]
-            hip.l1_mean_bwd(dens, a.l1[1], out=gp + gl)
+            l1 = ([x.detach() for x in list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)], a.l1[1])
+        if a.gp is None:
+            a.gp, a.gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, l1=l1)
+        else:
+            hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, out=(a.gp, a.gl), l1=l1)
+        gp, gl = a.gp, a.gl
         if a.pairs is None:       # (parameter, gradient tensor) of everything that lives in the persistent buffers
             pairs = list(zip(rf._param_list(), rf._grads_to_param_layout(gp, gl, a.g_apl, a.g_ali, a.g_basis)))
             m = model.brdf.mlp

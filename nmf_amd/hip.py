@@ -71,7 +71,7 @@ EXPORTS = [
     "nmf_brdf_mlp_fwd_packed", "nmf_brdf_mlp_bwd_packed", "nmf_brdf_mlp_bwd_segments", "nmf_brdf_mlp_bwd_segments_workspace_bytes", "nmf_heads_fwd", "nmf_heads_bwd", "nmf_ggx_rays_fwd", "nmf_ggx_rays_bwd", "nmf_ggx_rays_bwd_view", "nmf_ggx_prob", "nmf_shade_mix_fwd", "nmf_shade_mix_bwd", "nmf_shade_mix_bwd_view",
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
-    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
+    "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_unpack_density_grad_l1", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
     "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
@@ -514,8 +514,10 @@ def vm_query_bwd_segments(p, segs, dpk, dlk, app_planes, app_lines, basis, g_dpk
            "nmf_vm_query_bwd_segments")
 
 
-def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
-    """out = (gp, gl) of an earlier call: the same tensors are overwritten (a training pass keeps its gradient tensors)"""
+def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None, l1=None):
+    """out = (gp, gl) of an earlier call: the same tensors are overwritten (a training pass keeps its gradient tensors).
+    l1 = (the six density parameters [planes + lines] in the gradients' storage order, 0-d device scale): the gradient of
+    scale * sum_i mean |x_i| is added in the same launch (same bits as l1_mean_bwd(..., out=gp + gl) behind the unpack)"""
     G = p.grid
     dev = g_dpk[0].device
     if out is not None:
@@ -527,6 +529,16 @@ def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
         gl = [torch.empty((1, 16, G, 1), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
               for _ in range(3)]
     arr_p, arr_l = (C.c_void_p * 3)(*[t.data_ptr() for t in gp]), (C.c_void_p * 3)(*[t.data_ptr() for t in gl])
+    if l1 is not None:
+        xs, scale = l1
+        for x, g in zip(xs, gp + gl):
+            if x.numel() != g.numel():
+                raise NmfHipError("vm_unpack_density_grad: parameter / gradient size mismatch")
+        xp = (C.c_void_p * 3)(*[_dense_f32(t) for t in xs[:3]])
+        xl = (C.c_void_p * 3)(*[_dense_f32(t) for t in xs[3:]])
+        _check(_lib.nmf_vm_unpack_density_grad_l1(C.byref(p), _p3(g_dpk), _p3(g_dlk), arr_p, arr_l, xp, xl, _p(scale, torch.float32),
+                                                  _stream()), "nmf_vm_unpack_density_grad_l1")
+        return gp, gl
     _check(_lib.nmf_vm_unpack_density_grad(C.byref(p), _p3(g_dpk), _p3(g_dlk), arr_p, arr_l, _stream()),
            "nmf_vm_unpack_density_grad")
     return gp, gl
@@ -1399,9 +1411,9 @@ def _install_host_ext():
 
     py_unpack = g["vm_unpack_density_grad"]
 
-    def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None):
-        if out is not None:
-            return py_unpack(p, g_dpk, g_dlk, out)
+    def vm_unpack_density_grad(p, g_dpk, g_dlk, out=None, l1=None):
+        if out is not None or l1 is not None:
+            return py_unpack(p, g_dpk, g_dlk, out, l1)
         return fx.vm_unpack_density_grad(addr(p), g_dpk, g_dlk, _stream())
 
     for name, fn in list(locals().items()):

@@ -188,6 +188,19 @@ def _vm_backward(hip, p, xyz_d, tabs, sf, gr, d_sigma, d_sf, d_normal, d_app, co
     hip.vm_query_bwd(p, xyz_d, dpk, dlk, apl, ali, basis, sf, gr, d_sigma, d_sf, d_normal, d_app, g_dpk, g_dlk,
                      g_apl, g_ali, g_basis)
     gp, gl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk)
+    # the L1 term's gradient in the same launch (nmf_vm_unpack_density_grad_l1) = unpack + nmf_l1_mean_bwd(accumulate), bit for bit
+    gq = torch.Generator().manual_seed(3)
+    xs = [torch.randn(1, 16, G, G, generator=gq).to(DEV).contiguous(memory_format=torch.channels_last) for _ in range(3)] + \
+         [torch.randn(1, 16, G, 1, generator=gq).to(DEV).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    xs[0][0, :, ::3, ::5] = 0.0
+    scale = torch.full((), 3e-4, dtype=torch.float32, device=DEV)
+    fp, fl = hip.vm_unpack_density_grad(p, g_dpk, g_dlk, l1=(xs, scale))
+    sp = [t.clone() for t in gp]
+    sl = [t.clone() for t in gl]
+    hip.l1_mean_bwd(xs, scale, out=sp + sl)
+    for a_, b_ in zip(fp + fl, sp + sl):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(fp[0], gp[0])
     # the kernel's basis_mat gradient must equal the plain GEMM d_app^T x coef
     ref_basis = d_app.t() @ coef
     assert float((g_basis - ref_basis).abs().max()) <= 2e-4 * float(ref_basis.abs().max()) + 1e-6
