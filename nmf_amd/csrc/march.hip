@@ -33,7 +33,10 @@ __device__ __forceinline__ void occ_interval(const nmf_march_params& p, const Ra
         if (fabsf(d[a]) < 1e-12f) {
             if (o[a] < p.occ_min[a] || o[a] > p.occ_max[a]) { t0 = 1.f; t1 = 0.f; return; }
         } else {
-            const float ta = (p.occ_min[a] - o[a]) / d[a], tb = (p.occ_max[a] - o[a]) / d[a];
+            // (hardware reciprocal, 1 ulp: the interval only bounds the march, every use adds a 1e-2 margin; two IEEE divisions per
+            // axis were ~70 of the ~900 instructions a wave of four secondary rays executes)
+            const float inv = __builtin_amdgcn_rcpf(d[a]);
+            const float ta = (p.occ_min[a] - o[a]) * inv, tb = (p.occ_max[a] - o[a]) * inv;
             t0 = fmaxf(t0, fminf(ta, tb));
             t1 = fminf(t1, fmaxf(ta, tb));
         }
