@@ -208,7 +208,23 @@ __global__ void __launch_bounds__(256) k_segment_sum_group(const float* __restri
     float a[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) a[d] = 0.f;
-    for (int64_t k = s + lane; k < e; k += W) {
+    // four rows of a lane in flight (a 32-row segment on 8 lanes was four dependent memory round trips; these launches have a few
+    // hundred waves and nothing else to hide them), added in the order the one-row loop added them
+    int64_t k = s + lane;
+    for (; k + 3 * W < e; k += 4 * W) {
+        float sc[4], v[4][D];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = scale ? scale[k + q * W] : 1.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) v[q][d] = vals[(k + q * W) * D + d];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int d = 0; d < D; ++d) a[d] += sc[q] * v[q][d];
+    }
+    for (; k < e; k += W) {
         const float sc = scale ? scale[k] : 1.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) a[d] += sc * vals[k * D + d];
