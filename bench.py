@@ -552,7 +552,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=60)      # (the first ~50 steps of a process run 3 % slower: allocator growth, clocks)
     ap.add_argument("--rays-per-gpu", type=int, default=CHUNK)
     ap.add_argument("--budget-scale", type=int, default=1,
                     help="per-chunk budgets (sampler.max_samples, model.max_brdf_rays) and the chunk size times this factor")
