@@ -236,6 +236,21 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
 // one thread per SAMPLE: rows scatter back through the inverse map, everything else is written as zero, so the
 // three gradient tensors need no separate fill.  With row_inputs the head / feature adjoints stay per bounce row
 // ([Mb][11], [Mb][24], written by the first Mb threads) and only d_normals covers all samples.
+// SH irradiance factors E[c] of a normal, as ONE piece of code for both forms of the backward below (not inlined: the row-based fast
+// path and the general path must give the same bits -- tests compare them -- and inlined copies are contracted into fmas differently
+// depending on what surrounds them)
+__device__ __noinline__ void irradiance_E(float nx, float ny, float nz, Conv conv, float* __restrict__ E3) {
+    float Y[9];
+    sh9(nx, ny, nz, Y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float E = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
+        E3[c] = E;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     const int32_t* __restrict__ inv, int64_t M, const int32_t* __restrict__ bidx, int64_t Mb,
     const float* __restrict__ normals, const float* __restrict__ heads,
@@ -272,14 +287,11 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
         float gh[HEADS];
 #pragma unroll
         for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
-        float Y[9];
-        sh9(nx, ny, nz, Y);
+        float E3[3];
+        irradiance_E(nx, ny, nz, conv, E3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float E = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
-            gh[c] = ddiff ? dd[c] * E : 0.f;
+            gh[c] = ddiff ? dd[c] * E3[c] : 0.f;
             gh[6 + c] = d0[c];
         }
         gh[9] = (dr1 && h9 >= min_rough) ? dr : 0.f;
@@ -325,14 +337,11 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
         const int64_t in = row_inputs == 2 ? t : m;
         const float nx = normals[in * 3], ny = normals[in * 3 + 1], nz = normals[in * 3 + 2];
         const float* h = heads + t * HEADS;
-        float Y[9];
-        sh9(nx, ny, nz, Y);
+        float E3[3];
+        irradiance_E(nx, ny, nz, conv, E3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float E = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
-            gh[c] = ddiff ? ddiff[row * sd + c] * E : 0.f;
+            gh[c] = ddiff ? ddiff[row * sd + c] * E3[c] : 0.f;
             gh[6 + c] = df0 ? df0[row * sf + c] : 0.f;
         }
         gh[9] = (dr1 && h[9] >= min_rough) ? dr1[row * sr] : 0.f;
