@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 108
+#define NMF_ABI_VERSION 109
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -499,6 +499,14 @@ int nmf_vm_query_fwd_live(const nmf_vm_params* p, const float* xyzt, int64_t M_c
 int nmf_bounce_index_live(const int32_t* counts, int64_t M_cap, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
                           int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
                           int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq, void* stream);
+/* nmf_select_bounces + nmf_bounce_index_live in the launches of the latter (R4): the bounce count of a sample is one expression
+ * of (weights[i], u[i]) (modules/pt_selectors.py:5-60; arguments as nmf_select_bounces), evaluated inside the index kernels
+ * instead of by a launch of its own on the forward's chain.  counts are not materialised.  M_cap <= 2^20; M_live may be NULL. */
+int nmf_bounce_index_select(const float* weights, const float* u, int32_t mode, float mul, float add, float sum_w,
+                            const float* sum_w_dev, int64_t M_cap, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                            int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
+                            void* workspace, int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq,
+                            void* stream);
 /* nmf_bounce_index that also publishes [R, Mb, publish_seq] into mapped host memory (see nmf_march_scan_publish). */
 int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_t* bidx, int64_t* row_off, int32_t* cnt_rows,
                              int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,

@@ -384,6 +384,29 @@ py::tuple bounce_index(const Tensor& counts, const OT& xyzt, int64_t stream, int
     return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals);
 }
 
+// select_bounces + bounce_index in the two launches of the latter (nmf_bounce_index_select); sum_w_dev: the device scalar of
+// select_total (mode 1), absent for mode 0
+py::tuple bounce_index_select(const Tensor& w, const Tensor& u, int64_t mode, double mul, double add, double sum_w, const OT& sum_w_dev,
+                              const OT& xyzt, int64_t stream, int64_t pub = 0, int64_t pub_seq = 0, int64_t live = 0) {
+    TimedScope _ts("bounce_index", stream);
+    const int64_t M = w.size(0), M1 = M > 0 ? M : 1;
+    Tensor bidx = ie(w, {M1}, at::kInt), row_off = ie(w, {M + 1}, at::kLong), inv = ie(w, {M1}, at::kInt);
+    Tensor cnt_rows = ie(w, {M1}, at::kInt), totals = ie(w, {2}, at::kLong);
+    const int64_t nbytes = nmf_bounce_index_workspace_bytes(M);
+    Tensor ws = ie(w, {nbytes / 8}, at::kLong);
+    Tensor rows;
+    if (xyzt.has_value()) rows = at::empty({M1, 4}, w.options().dtype(at::kFloat));
+    check(nmf_bounce_index_select(M ? f32(w) : nullptr, M ? f32(u) : nullptr, (int32_t)mode, (float)mul, (float)add, (float)sum_w,
+                                  of32(sum_w_dev), M, reinterpret_cast<const int64_t*>(live), static_cast<int32_t*>(bidx.data_ptr()),
+                                  static_cast<int64_t*>(row_off.data_ptr()), static_cast<int32_t*>(cnt_rows.data_ptr()),
+                                  static_cast<int32_t*>(inv.data_ptr()), static_cast<int64_t*>(totals.data_ptr()),
+                                  (xyzt.has_value() && M) ? f32(*xyzt) : nullptr, xyzt.has_value() ? out(rows) : nullptr, ws.data_ptr(),
+                                  nbytes, reinterpret_cast<void*>(pub), pub_seq, st(stream)),
+          "nmf_bounce_index_select");
+    if (xyzt.has_value()) return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals, rows);
+    return py::make_tuple(bidx, row_off, cnt_rows, inv.narrow(0, 0, M), totals);
+}
+
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_fwd(
     const Tensor& bidx, const Tensor& normals, const Tensor& app, const Tensor& heads, const Tensor& xyzt, const Tensor& ray_id,
     const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough, int64_t row_inputs,
@@ -1061,6 +1084,10 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("shade_mix_fwd", &shade_mix_fwd);
     m.def("bounce_index", &bounce_index, py::arg("counts"), py::arg("xyzt"), py::arg("stream"), py::arg("pub") = 0, py::arg("pub_seq") = 0,
           py::arg("live") = 0);
+    m.def("bounce_index_select", [](const Tensor& w, const Tensor& u, int64_t mode, double mul, double add, double sum_w, const OT& sum_w_dev,
+                                    const OT& xyzt, int64_t stream) {
+        return bounce_index_select(w, u, mode, mul, add, sum_w, sum_w_dev, xyzt, stream);
+    });
     m.def("bounce_prep_fwd", &bounce_prep_fwd);
     m.def("ray_compose_fwd", &ray_compose_fwd);
     m.def("composite_bwd", &composite_bwd);

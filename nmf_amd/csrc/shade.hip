@@ -51,12 +51,38 @@ __device__ __forceinline__ int64_t block_scan_i64(int64_t v, int64_t* ws /*[17]*
     return incl;
 }
 
+// The bounce counts of the samples computed HERE instead of read (R4, nmf_bounce_index_select): modules/pt_selectors.py:5-60 is one
+// expression per sample -- k_select_bounces (csrc/select.hip) was a launch of its own on the forward's chain for it; same operations
+// (explicitly rounded, no contraction), same bits.  w == NULL: read counts[].
+struct SelectArgs {
+    const float* w;
+    const float* u;
+    int mode;
+    float mul, add, S;
+    const float* S_dev;
+};
+__device__ __forceinline__ int32_t bounce_count(const SelectArgs& q, const int32_t* __restrict__ counts, int64_t i) {
+    if (!q.w) return counts[i];
+    const float S = q.S_dev ? *q.S_dev : q.S;
+    float pt;
+    if (q.mode == 0) {
+        pt = fsub(fadd(fmul(q.w[i], q.mul), q.u[i]), 0.5f);
+    } else {
+        const float wp = fadd(q.w[i], fmul(1e-3f, q.u[i]));
+        pt = fadd(fmul(fdiv(wp, S), q.mul), q.add);
+    }
+    float f = floorf(pt);
+    f = fminf(fmaxf(f, 0.f), 400.f);
+    return (int32_t)f;
+}
+
 __global__ void __launch_bounds__(IDX_CHUNK) k_idx_partial(const int32_t* __restrict__ counts, int64_t M,
-                                                          int64_t* __restrict__ chunk_sum, const int64_t* __restrict__ M_live) {
+                                                          int64_t* __restrict__ chunk_sum, const int64_t* __restrict__ M_live,
+                                                          SelectArgs sel) {
     __shared__ int64_t ws[17];
     if (M_live && *M_live < M) M = *M_live;          // (the launch was sized by a bound: nmf_bounce_index_live)
     const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + threadIdx.x;
-    const int32_t c = i < M ? counts[i] : 0;
+    const int32_t c = i < M ? bounce_count(sel, counts, i) : 0;
     const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
     int64_t total;
     block_scan_i64(v, ws, &total);
@@ -116,7 +142,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
                                                               int64_t* __restrict__ row_off, int32_t* __restrict__ cnt_rows,
                                                               int32_t* __restrict__ inv, const float4* __restrict__ xyzt,
                                                               float4* __restrict__ xyzt_rows, int64_t* pub, int64_t pub_seq,
-                                                              const int64_t* __restrict__ M_live) {
+                                                              const int64_t* __restrict__ M_live, SelectArgs sel) {
     __shared__ int64_t ws[17];
     __shared__ int64_t base_s;
     if (M_live && *M_live < M) M = *M_live;
@@ -128,7 +154,7 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
     __syncthreads();
     const int64_t R = all & (((int64_t)1 << FLAG_SHIFT) - 1), Mb = all >> FLAG_SHIFT;
     const int64_t i = (int64_t)blockIdx.x * IDX_CHUNK + tid;
-    const int32_t c = i < M ? counts[i] : 0;
+    const int32_t c = i < M ? bounce_count(sel, counts, i) : 0;
     const int64_t v = c > 0 ? ((int64_t)c + ((int64_t)1 << FLAG_SHIFT)) : 0;
     int64_t total;
     const int64_t excl = base_s + block_scan_i64(v, ws, &total) - v;
@@ -516,10 +542,31 @@ extern "C" int nmf_bounce_index_publish(const int32_t* counts, int64_t M, int32_
                                  publish_mapped_dev, publish_seq, stream);
 }
 
+static int bounce_index_impl(const int32_t* counts, SelectArgs sel, int64_t M, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                             int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
+                             int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq, void* stream);
 extern "C" int nmf_bounce_index_live(const int32_t* counts, int64_t M, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
                                      int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
                                      void* workspace, int64_t workspace_bytes, void* publish_mapped_dev,
                                      int64_t publish_seq, void* stream) {
+    NMF_REQUIRE(counts || M == 0, NMF_EINVAL, "nmf_bounce_index: null");
+    return bounce_index_impl(counts, SelectArgs{nullptr, nullptr, 0, 0.f, 0.f, 0.f, nullptr}, M, M_live, bidx, row_off, cnt_rows, inv, totals,
+                             xyzt, xyzt_rows, workspace, workspace_bytes, publish_mapped_dev, publish_seq, stream);
+}
+extern "C" int nmf_bounce_index_select(const float* weights, const float* u, int32_t mode, float mul, float add, float sum_w,
+                                       const float* sum_w_dev, int64_t M, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                                       int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows,
+                                       void* workspace, int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq,
+                                       void* stream) {
+    NMF_REQUIRE((weights && u) || M == 0, NMF_EINVAL, "nmf_bounce_index_select: null");
+    NMF_REQUIRE(mode == 0 || mode == 1, NMF_EINVAL, "nmf_bounce_index_select: mode");
+    NMF_REQUIRE(M <= (int64_t)IDX_CHUNK * IDX_CHUNK, NMF_ERANGE, "nmf_bounce_index_select: more than 2^20 samples (use nmf_select_bounces + nmf_bounce_index)");
+    return bounce_index_impl(nullptr, SelectArgs{weights, u, (int)mode, mul, add, sum_w, sum_w_dev}, M, M_live, bidx, row_off, cnt_rows, inv,
+                             totals, xyzt, xyzt_rows, workspace, workspace_bytes, publish_mapped_dev, publish_seq, stream);
+}
+static int bounce_index_impl(const int32_t* counts, SelectArgs sel, int64_t M, const int64_t* M_live, int32_t* bidx, int64_t* row_off,
+                             int32_t* cnt_rows, int32_t* inv, int64_t* totals, const float* xyzt, float* xyzt_rows, void* workspace,
+                             int64_t workspace_bytes, void* publish_mapped_dev, int64_t publish_seq, void* stream) {
     int64_t* pub = static_cast<int64_t*>(publish_mapped_dev);
     NMF_REQUIRE(M >= 0, NMF_EINVAL, "nmf_bounce_index: M < 0");
     NMF_REQUIRE(totals && row_off, NMF_EINVAL, "nmf_bounce_index: null");
@@ -531,7 +578,7 @@ extern "C" int nmf_bounce_index_live(const int32_t* counts, int64_t M, const int
         if (pub) return nmf_publish_i64x2(totals, pub, publish_seq, stream);
         return NMF_OK;
     }
-    NMF_REQUIRE(counts && bidx && cnt_rows && inv && workspace, NMF_EINVAL, "nmf_bounce_index: null");
+    NMF_REQUIRE((counts || sel.w) && bidx && cnt_rows && inv && workspace, NMF_EINVAL, "nmf_bounce_index: null");
     NMF_REQUIRE(!xyzt_rows || xyzt, NMF_EINVAL, "nmf_bounce_index: xyzt_rows needs xyzt");
     const float4* x4 = reinterpret_cast<const float4*>(xyzt);
     float4* r4 = reinterpret_cast<float4*>(xyzt_rows);
@@ -540,10 +587,10 @@ extern "C" int nmf_bounce_index_live(const int32_t* counts, int64_t M, const int
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
     int64_t* chunk = static_cast<int64_t*>(workspace);
     NMF_REQUIRE(!M_live || n_chunks <= IDX_CHUNK, NMF_ERANGE, "nmf_bounce_index_live: bound too large for a device-side count");
-    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, M_live);
+    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, M_live, sel);
     if (n_chunks <= IDX_CHUNK) {
         hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
-                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq, M_live);
+                           (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq, M_live, sel);
     } else {
         hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
         hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,

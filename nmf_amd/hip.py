@@ -72,7 +72,7 @@ EXPORTS = [
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_unpack_density_grad_l1", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
-    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_multi_copy",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_bounce_index_select", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -951,6 +951,30 @@ def bounce_index(counts, xyzt=None):
     _check(_lib.nmf_bounce_index(_p(counts, torch.int32) if M else C.c_void_p(0), C.c_int64(M), _p(bidx), _p(row_off),
                                  _p(cnt_rows), _p(inv), _p(totals), _p(xyzt, torch.float32) if (xyzt is not None and M) else None,
                                  _p(rows), _p(ws), C.c_int64(nbytes), _stream()), "nmf_bounce_index")
+    if xyzt is not None:
+        return bidx, row_off, cnt_rows, inv[:M], totals, rows
+    return bidx, row_off, cnt_rows, inv[:M], totals
+
+
+def bounce_index_select(weights, u, mode, mul, add=0.0, sum_w=1.0, xyzt=None):
+    """select_bounces(weights, u, mode, mul, add, sum_w) + bounce_index(counts, xyzt) without materialising the counts: the count of a
+    sample is evaluated inside the two launches of the index (nmf_bounce_index_select).  sum_w: float or 0-d device tensor."""
+    M = weights.shape[0]
+    dev = weights.device
+    rows = torch.empty((max(M, 1), 4), dtype=torch.float32, device=dev) if xyzt is not None else None
+    bidx = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    row_off = torch.empty(M + 1, dtype=torch.int64, device=dev)
+    inv = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    cnt_rows = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    nbytes = _lib.nmf_bounce_index_workspace_bytes(C.c_int64(M))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    dev_sum = sum_w if isinstance(sum_w, torch.Tensor) else None
+    _check(_lib.nmf_bounce_index_select(_p(weights, torch.float32) if M else None, _p(u, torch.float32) if M else None, C.c_int32(mode),
+                                        C.c_float(mul), C.c_float(add), C.c_float(1.0 if dev_sum is not None else sum_w),
+                                        _p(dev_sum, torch.float32), C.c_int64(M), None, _p(bidx), _p(row_off), _p(cnt_rows), _p(inv),
+                                        _p(totals), _p(xyzt, torch.float32) if (xyzt is not None and M) else None, _p(rows), _p(ws),
+                                        C.c_int64(nbytes), None, C.c_int64(0), _stream()), "nmf_bounce_index_select")
     if xyzt is not None:
         return bidx, row_off, cnt_rows, inv[:M], totals, rows
     return bidx, row_off, cnt_rows, inv[:M], totals

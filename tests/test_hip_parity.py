@@ -749,6 +749,27 @@ def test_brdf_mlp_fused_matches_oracle(R):
         assert_close(w.cpu(), g["brdf_out"], rtol=1e-5, atol=1e-6, what="brdf vs reference")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 1000, 300001])
+def test_bounce_index_with_the_selection_inside_equals_select_then_index(M):
+    """nmf_bounce_index_select evaluates pt_selectors.py:5-60 inside the index launches: the same rows, offsets, counts and inverse
+    map as nmf_select_bounces followed by nmf_bounce_index, for both selector modes."""
+    hip = _hip()
+    gen = torch.Generator().manual_seed(M)
+    w = (torch.rand(M, generator=gen) ** 6).to(DEV)
+    u = torch.rand(M, generator=gen).to(DEV)
+    xyzt = torch.randn(M, 4, generator=gen).to(DEV)
+    total = (w.double().sum() + 1e-3 * u.double().sum()).float().clamp_min(1e-3).reshape(())
+    for mode, mul, add, sw in ((0, 37.0, 0.0, 1.0), (1, 2.5 * M, 1.0, total), (1, 0.8 * M, 0.5, total)):
+        counts = hip.select_bounces(w, u, mode, mul, add, sw)
+        ref = hip.bounce_index(counts, xyzt)
+        got = hip.bounce_index_select(w, u, mode, mul, add, sw, xyzt)
+        R, Mb = (int(v) for v in ref[4].cpu())
+        assert torch.equal(ref[4], got[4]) and R > 0
+        assert torch.equal(ref[0][:Mb], got[0][:Mb]) and torch.equal(ref[1][:Mb + 1], got[1][:Mb + 1])
+        assert torch.equal(ref[2][:Mb], got[2][:Mb]) and torch.equal(ref[3], got[3]) and torch.equal(ref[5][:Mb], got[5][:Mb])
+
+
 def test_select_bounces_golden_bit_exact():
     hip = _hip()
     g = Golden("shading_parts")
