@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 109
+#define NMF_ABI_VERSION 110
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -522,6 +522,15 @@ int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float* normals, c
                         const float* xyzt, const int32_t* ray_id, const float* rays, const float* conv,
                         const float* feat_noise, float anoise, float min_rough, int32_t row_inputs, float* V, float* N,
                         float* r1, float* f0, float* diffuse, float* feat, float* xyz, void* stream);
+/* The same with the material heads evaluated inside the launch (R4): head_W [11][24], head_b [11] and the five activation
+ * parameters of nmf_heads_fwd instead of its output; heads_out [Mb][11] receives what nmf_heads_fwd(app) would have written (the
+ * backward reads it).  app must be given per bounce row (row_inputs 1 or 2).  One launch less per recursion level on the
+ * forward's chain; the same bits as nmf_heads_fwd followed by nmf_bounce_prep_fwd. */
+int nmf_bounce_prep_fwd_heads(const int32_t* bidx, int64_t Mb, const float* normals, const float* app, const float* head_W,
+                              const float* head_b, float diffuse_mul, float diffuse_bias, float tint_bias, float f0_bias,
+                              float rough_bias, const float* xyzt, const int32_t* ray_id, const float* rays, const float* conv,
+                              const float* feat_noise, float anoise, float min_rough, int32_t row_inputs, float* heads_out,
+                              float* V, float* N, float* r1, float* f0, float* diffuse, float* feat, float* xyz, void* stream);
 /* Adjoint: d_normals [M][3] written for ALL samples (zeros where inv < 0 or detach_normals); d_heads / d_app written for
  * all M samples ([M][11], [M][24], zeros where inv < 0) or, with row_inputs, per bounce row ([Mb][11], [Mb][24]; bidx
  * required); row_inputs == 2: normals AND d_normals are per bounce row ([Mb][3]), inv is not read.  Row gradients may be

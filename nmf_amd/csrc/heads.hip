@@ -5,18 +5,14 @@
 //   f0     = sigmoid(a[6:9] + f0_bias)                                     r = clip(sigmoid(a[9:11] + rough_bias)/2, 0.01, 1)
 // rocBLAS runs these N=3 GEMMs over ~1 M samples at ~1.6 ms each (12 calls per level, profiles/r01_b);
 // here the forward is one streaming pass and the weight gradient is reduced per workgroup through LDS.
-#include "common.hpp"
+#include "heads_eval.hpp"
 
 namespace {
 
-constexpr int F = NMF_APP_DIM;   // 24
-constexpr int O = 11;
-
-struct HeadP {
-    float diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias;
-};
-
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+using nmf_heads::F;
+using nmf_heads::O;
+using nmf_heads::HeadP;
+using nmf_heads::sigm;
 
 __device__ __forceinline__ void load_feat(const float* __restrict__ feat, int64_t m, float (&f)[F]) {
     const float4* q = reinterpret_cast<const float4*>(feat + m * F);
@@ -32,21 +28,12 @@ __global__ void __launch_bounds__(256) k_heads_fwd(const float* __restrict__ fea
                                                    const float* __restrict__ b, HeadP hp, float* __restrict__ out) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    float f[F];
+    float f[F], v[O];
     load_feat(feat, m, f);
+    nmf_heads::heads_eval(f, W, b, hp, v);
     float* o = out + m * O;
 #pragma unroll
-    for (int j = 0; j < O; ++j) {
-        float a = b[j];
-#pragma unroll
-        for (int k = 0; k < F; ++k) a += W[j * F + k] * f[k];          // uniform addresses -> scalar loads
-        float v;
-        if (j < 3) v = fminf(fmaxf(sigm(hp.diffuse_mul * a + hp.diffuse_bias), 0.f), 1.f);
-        else if (j < 6) v = sigm(a + hp.tint_bias);
-        else if (j < 9) v = sigm(a + hp.f0_bias);
-        else v = fminf(fmaxf(sigm(a + hp.rough_bias) * 0.5f, 1e-2f), 1.f);
-        o[j] = v;
-    }
+    for (int j = 0; j < O; ++j) o[j] = v[j];
 }
 
 __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ feat, int64_t M, const float* __restrict__ W,

@@ -424,6 +424,26 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_f
     return {V, N, r1, f0, diff, feat, xyz};
 }
 
+// heads_fwd + bounce_prep_fwd in one launch (nmf_bounce_prep_fwd_heads) -> {heads, V, N, r1, f0, diffuse, feat, xyz}
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> bounce_prep_fwd_heads(
+    const Tensor& bidx, const Tensor& normals, const Tensor& app, const Tensor& head_W, const Tensor& head_b, const std::vector<double>& hp,
+    const Tensor& xyzt, const Tensor& ray_id, const Tensor& rays, const Tensor& conv, const OT& feat_noise, double anoise, double min_rough,
+    int64_t row_inputs, int64_t stream) {
+    TimedScope _ts("bounce_prep_fwd", stream);
+    if (hp.size() != 5) fail("bounce_prep_fwd_heads: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
+    const int64_t Mb = bidx.size(0);
+    Tensor heads = fe(normals, {Mb, 11});
+    Tensor V = fe(normals, {Mb, 3}), N = fe(normals, {Mb, 3}), r1 = fe(normals, {Mb}), f0 = fe(normals, {Mb, 3});
+    Tensor diff = fe(normals, {Mb, 3}), feat = fe(normals, {Mb, 24}), xyz = fe(normals, {Mb, 3});
+    if (Mb)
+        check(nmf_bounce_prep_fwd_heads(i32(bidx), Mb, f32(normals), f32(app), f32(head_W), f32(head_b), (float)hp[0], (float)hp[1],
+                                        (float)hp[2], (float)hp[3], (float)hp[4], f32(xyzt), i32(ray_id), f32(rays), f32(conv),
+                                        static_cast<const float*>(vptr(feat_noise)), (float)anoise, (float)min_rough, (int32_t)row_inputs,
+                                        out(heads), out(V), out(N), out(r1), out(f0), out(diff), out(feat), out(xyz), st(stream)),
+              "nmf_bounce_prep_fwd_heads");
+    return {heads, V, N, r1, f0, diff, feat, xyz};
+}
+
 std::tuple<Tensor, Tensor, Tensor, OT> ray_compose_fwd(const Tensor& weight, const OT& refl_rows, const OT& inv,
                                                        const OT& normals, const Tensor& rays, const Tensor& offsets, int64_t B,
                                                        const Tensor& bg, bool bg_per_ray, bool tonemap, bool noclip,

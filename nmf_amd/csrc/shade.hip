@@ -13,6 +13,7 @@
 // All three are HBM streaming kernels (a few hundred bytes per sample); their point is launch count: the torch
 // formulation is ~150 elementwise / index launches per level and as many again in the backward.
 #include "common.hpp"
+#include "heads_eval.hpp"
 
 namespace {
 
@@ -203,12 +204,18 @@ __device__ __forceinline__ void sh9(float x, float y, float z, float (&Y)[9]) {
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+struct HeadsIn {            // W == NULL: the heads are read from `heads`
+    const float* W;
+    const float* b;
+    nmf_heads::HeadP hp;
+    float* out;
+};
 __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     const int32_t* __restrict__ bidx, int64_t Mb, const float* __restrict__ normals, const float* __restrict__ app,
     const float* __restrict__ heads, const float4* __restrict__ xyzt, const int32_t* __restrict__ ray_id,
     const float* __restrict__ rays, Conv conv, const float* __restrict__ feat_noise, float anoise, float min_rough,
     int row_inputs, float* __restrict__ V, float* __restrict__ N, float* __restrict__ r1, float* __restrict__ f0,
-    float* __restrict__ diffuse, float* __restrict__ feat, float* __restrict__ xyz) {
+    float* __restrict__ diffuse, float* __restrict__ feat, float* __restrict__ xyz, HeadsIn hin) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= Mb) return;
     // every load first (three dependent round trips: bidx -> ray_id and the row's inputs -> the ray), the stores behind them:
@@ -218,8 +225,11 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     const int64_t in = row_inputs == 2 ? row : m;  // normals per bounce row as well (row_inputs 2)
     const int64_t rid = ray_id[m];
     const float nx = normals[in * 3], ny = normals[in * 3 + 1], nz = normals[in * 3 + 2];
-    const float* h = heads + ia * HEADS;
-    const float h0 = h[0], h1 = h[1], h2 = h[2], h6 = h[6], h7 = h[7], h8 = h[8], h9 = h[9];
+    float h0, h1, h2, h6, h7, h8, h9;
+    if (!hin.W) {
+        const float* h = heads + ia * HEADS;
+        h0 = h[0]; h1 = h[1]; h2 = h[2]; h6 = h[6]; h7 = h[7]; h8 = h[8]; h9 = h[9];
+    }
     const float4 p = xyzt[m];
     const float4* a4 = reinterpret_cast<const float4*>(app + ia * FEAT);
     const float4* n4 = feat_noise ? reinterpret_cast<const float4*>(feat_noise + ia * FEAT) : nullptr;
@@ -228,6 +238,18 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
     for (int i = 0; i < FEAT / 4; ++i) {
         av[i] = a4[i];
         zv[i] = n4 ? n4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (hin.W) {
+        // the material heads of this row evaluated HERE (nmf_bounce_prep_fwd_heads: rows given per bounce row) and written out for
+        // the backward -- k_heads_fwd was a launch of its own between the appearance query and this one; nmf_heads::heads_eval is
+        // the code both run, so the bits are the same
+        float fa[nmf_heads::F], ho[nmf_heads::O];
+#pragma unroll
+        for (int i = 0; i < FEAT / 4; ++i) { fa[4 * i] = av[i].x; fa[4 * i + 1] = av[i].y; fa[4 * i + 2] = av[i].z; fa[4 * i + 3] = av[i].w; }
+        nmf_heads::heads_eval(fa, hin.W, hin.b, hin.hp, ho);
+#pragma unroll
+        for (int j = 0; j < nmf_heads::O; ++j) hin.out[ia * HEADS + j] = ho[j];
+        h0 = ho[0]; h1 = ho[1]; h2 = ho[2]; h6 = ho[6]; h7 = ho[7]; h8 = ho[8]; h9 = ho[9];
     }
     const float* d = rays + rid * 6 + 3;
     const float vx = -d[0], vy = -d[1], vz = -d[2];
@@ -618,8 +640,28 @@ extern "C" int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float*
                     diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd: null");
     hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
                        normals, app, heads, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
-                       feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz);
+                       feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz,
+                       HeadsIn{nullptr, nullptr, nmf_heads::HeadP{0.f, 0.f, 0.f, 0.f, 0.f}, nullptr});
     NMF_CHECK_LAUNCH("nmf_bounce_prep_fwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_bounce_prep_fwd_heads(const int32_t* bidx, int64_t Mb, const float* normals, const float* app, const float* head_W,
+                                         const float* head_b, float diffuse_mul, float diffuse_bias, float tint_bias, float f0_bias,
+                                         float rough_bias, const float* xyzt, const int32_t* ray_id, const float* rays,
+                                         const float* conv, const float* feat_noise, float anoise, float min_rough,
+                                         int32_t row_inputs, float* heads_out, float* V, float* N, float* r1, float* f0,
+                                         float* diffuse, float* feat, float* xyz, void* stream) {
+    NMF_REQUIRE(Mb >= 0, NMF_EINVAL, "nmf_bounce_prep_fwd_heads: Mb < 0");
+    if (Mb == 0) return NMF_OK;
+    NMF_REQUIRE(row_inputs == 1 || row_inputs == 2, NMF_EINVAL, "nmf_bounce_prep_fwd_heads: app must be given per bounce row");
+    NMF_REQUIRE(bidx && normals && app && head_W && head_b && heads_out && xyzt && ray_id && rays && conv && V && N && r1 && f0 &&
+                    diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd_heads: null");
+    hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
+                       normals, app, heads_out, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
+                       feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz,
+                       HeadsIn{head_W, head_b, nmf_heads::HeadP{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias}, heads_out});
+    NMF_CHECK_LAUNCH("nmf_bounce_prep_fwd_heads");
     return NMF_OK;
 }
 

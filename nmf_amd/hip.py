@@ -72,7 +72,7 @@ EXPORTS = [
     "nmf_adam_step", "nmf_adam_step_guarded", "nmf_bounce_index", "nmf_bounce_index_workspace_bytes", "nmf_bounce_prep_fwd", "nmf_bounce_prep_bwd",
     "nmf_ray_compose_fwd", "nmf_ray_compose_bwd", "nmf_l1_mean_fwd", "nmf_l1_mean_bwd", "nmf_sqerr_fwd", "nmf_sqerr_bwd",
     "nmf_loss_mix_fwd", "nmf_loss_mix_bwd", "nmf_loss_head", "nmf_loss_head_workspace_bytes", "nmf_bg_adjoint", "nmf_vm_query_bwd_segments", "nmf_vm_query_bwd_segments_clean", "nmf_vm_bwd_clean_bytes", "nmf_vm_unpack_density_grad_l1", "nmf_vm_bin_plan", "nmf_vm_bin_plan_bytes", "nmf_vm_walk_workspace_bytes", "nmf_vm_query_bwd_planned", "nmf_sh_project",
-    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_bounce_index_select", "nmf_multi_copy",
+    "nmf_retrace_scores", "nmf_argsort_f32", "nmf_argsort_workspace_bytes", "nmf_topk_select", "nmf_topk_select_workspace_bytes", "nmf_alpha_coarse", "nmf_alpha_coarse_words", "nmf_bounce_index_select", "nmf_bounce_prep_fwd_heads", "nmf_multi_copy",
 ]
 for _n in EXPORTS:
     if not hasattr(_lib, _n):
@@ -954,6 +954,22 @@ def bounce_index(counts, xyzt=None):
     if xyzt is not None:
         return bidx, row_off, cnt_rows, inv[:M], totals, rows
     return bidx, row_off, cnt_rows, inv[:M], totals
+
+
+def bounce_prep_fwd_heads(bidx, normals, app, head_W, head_b, hp, xyzt, ray_id, rays, conv, feat_noise, anoise, min_rough, row_inputs=1):
+    """heads_fwd(app, head_W, head_b, hp) + bounce_prep_fwd(..., heads, ...) in one launch -> (heads, V, N, r1, f0, diffuse, feat, xyz)"""
+    Mb = bidx.shape[0]
+    dev = normals.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    heads, V, N, r1, f0, diff, feat, xyz = f(Mb, 11), f(Mb, 3), f(Mb, 3), f(Mb), f(Mb, 3), f(Mb, 3), f(Mb, 24), f(Mb, 3)
+    if Mb:
+        _check(_lib.nmf_bounce_prep_fwd_heads(_p(bidx, torch.int32), C.c_int64(Mb), _p(normals, torch.float32), _p(app, torch.float32),
+                                              _p(head_W, torch.float32), _p(head_b, torch.float32), *[C.c_float(v) for v in hp],
+                                              _p(xyzt, torch.float32), _p(ray_id, torch.int32), _p(rays, torch.float32),
+                                              _p(conv, torch.float32), _p(feat_noise, torch.float32), C.c_float(anoise),
+                                              C.c_float(min_rough), C.c_int32(int(row_inputs)), _p(heads), _p(V), _p(N), _p(r1), _p(f0),
+                                              _p(diff), _p(feat), _p(xyz), _stream()), "nmf_bounce_prep_fwd_heads")
+    return heads, V, N, r1, f0, diff, feat, xyz
 
 
 def bounce_index_select(weights, u, mode, mul, add=0.0, sum_w=1.0, xyzt=None):

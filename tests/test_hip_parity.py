@@ -970,6 +970,16 @@ def test_vm_value_only_query_and_row_normals():
     o2 = hip.bounce_prep_fwd(bidx, nr_rows, app, heads, xyz, ray_id, rays, conv, noise, 0.1, 0.02, 2)
     for x, y in zip(o1, o2):
         assert torch.equal(x, y)
+    # the material heads evaluated inside the row preparation (nmf_bounce_prep_fwd_heads) = nmf_heads_fwd + nmf_bounce_prep_fwd
+    hW, hb = (torch.randn(11, 24, generator=gen) * 0.3).to(DEV), (torch.randn(11, generator=gen) * 0.2).to(DEV)
+    hp = (1.3, -0.2, 0.1, -0.4, 0.2)
+    heads_l = hip.heads_fwd(app, hW, hb, hp)
+    for ri, nrm in ((1, nr), (2, nr_rows)):
+        ref = hip.bounce_prep_fwd(bidx, nrm, app, heads_l, xyz, ray_id, rays, conv, noise, 0.1, 0.02, ri)
+        got = hip.bounce_prep_fwd_heads(bidx, nrm, app, hW, hb, hp, xyz, ray_id, rays, conv, noise, 0.1, 0.02, ri)
+        assert torch.equal(got[0], heads_l)
+        for x, y in zip(ref, got[1:]):
+            assert torch.equal(x, y)
     dN, dr1 = torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, generator=gen).to(DEV)
     df0, dd, dfeat = torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, 3, generator=gen).to(DEV), torch.randn(Mb, 24, generator=gen).to(DEV)
     g1 = hip.bounce_prep_bwd(inv, nr, heads, ray_id, rays, conv, 0.02, False, dN, dr1, df0, dd, dfeat, bidx=bidx, row_inputs=1)
