@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 110
+#define NMF_ABI_VERSION 111
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -542,6 +542,16 @@ int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t* bidx, int6
                         const float* dr1, const float* df0,
                         const float* ddiffuse, const int32_t row_strides[4], const float* dfeat, float* d_normals,
                         float* d_heads, float* d_app, void* stream);
+/* nmf_bounce_prep_bwd (everything per bounce row: row_inputs = 2) + nmf_heads_bwd in ONE launch (R4): the adjoint of the heads'
+ * outputs and the feature-row adjoint that nmf_heads_bwd adds are computed per row from the inputs of nmf_bounce_prep_bwd instead
+ * of written and read back.  d_normals [Mb][3], d_app [Mb][24] (the adjoint of `app`: heads' backward + dfeat); g_head_W / g_head_b
+ * ACCUMULATED as in nmf_heads_bwd.  One launch less per recursion level on the backward's main chain. */
+int nmf_bounce_prep_heads_bwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* heads, const int32_t* ray_id,
+                              const float* rays, const float* conv, float min_rough, int32_t detach_normals, const float* dN,
+                              const float* dr1, const float* df0, const float* ddiffuse, const int32_t row_strides[4],
+                              const float* dfeat, const float* app, const float* head_W, const float* head_b, float diffuse_mul,
+                              float diffuse_bias, float tint_bias, float f0_bias, float rough_bias, float* d_normals, float* d_app,
+                              float* g_head_W, float* g_head_b, void* stream);
 /* modules/tensor_nerf.py:448-452,583-587,658-659 + modules/tonemap.py:34-55, one thread per ray in sample order:
  * acc = sum w, rgb_lin = sum w * refl_rows[inv], ori = sum w * min(-d.n, 0)^2 (ori / normals may be NULL),
  * rgb_map = (tonemap ? srgb(rgb_lin) : rgb_lin) + (1 - acc) * bg;  bg [3] or [B][3] (bg_per_ray). */

@@ -6,6 +6,7 @@
 // rocBLAS runs these N=3 GEMMs over ~1 M samples at ~1.6 ms each (12 calls per level, profiles/r01_b);
 // here the forward is one streaming pass and the weight gradient is reduced per workgroup through LDS.
 #include "heads_eval.hpp"
+#include "rows_bwd.hpp"
 
 namespace {
 
@@ -40,7 +41,10 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
                                                    const float* __restrict__ b, HeadP hp,
                                                    const float* __restrict__ d_out,
                                                    const float* d_feat_add, float* d_feat,   // may be the same buffer
-                                                   float* __restrict__ gW, float* __restrict__ gb) {
+                                                   float* __restrict__ gW, float* __restrict__ gb, nmf_rows::RowsBwdIn rin) {
+    // rin.bidx != NULL (nmf_bounce_prep_heads_bwd): the adjoint of the heads' outputs and the feature-row adjoint that is added are
+    // not read -- they are what nmf_bounce_prep_bwd would have written for this row (row_inputs = 2), computed here from its inputs
+    // (nmf_rows::prep_bwd_row, which also writes d_normals): one launch less per level on the backward's main chain
     __shared__ float s_da[256 * (O + 1)];
     __shared__ float s_f[256 * (F + 1)];
     const int t = threadIdx.x;
@@ -66,12 +70,15 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
         float f[F], da[O];
         if (m < M) {
             load_feat(feat, m, f);
+            float gq[O];
+            float4 addv[F / 4];
+            if (rin.bidx) nmf_rows::prep_bwd_row(rin, m, gq, addv);
 #pragma unroll
             for (int j = 0; j < O; ++j) {
                 float a = s_b[j];
 #pragma unroll
                 for (int k = 0; k < F; ++k) a += s_W[j * F + k] * f[k];
-                const float g = d_out[m * O + j];
+                const float g = rin.bidx ? gq[j] : d_out[m * O + j];
                 float d;
                 if (j < 3) {
                     const float s = sigm(hp.diffuse_mul * a + hp.diffuse_bias);
@@ -94,7 +101,13 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float* __restrict__ fea
 #pragma unroll
                 for (int k = 0; k < F; ++k) df[k] += da[j] * s_W[j * F + k];
             float4* q = reinterpret_cast<float4*>(d_feat + m * F);
-            if (d_feat_add) {                                           // another adjoint of the same rows, added here (may alias d_feat)
+            if (rin.bidx) {
+#pragma unroll
+                for (int i = 0; i < F / 4; ++i) {
+                    df[4 * i] = addv[i].x + df[4 * i]; df[4 * i + 1] = addv[i].y + df[4 * i + 1];
+                    df[4 * i + 2] = addv[i].z + df[4 * i + 2]; df[4 * i + 3] = addv[i].w + df[4 * i + 3];
+                }
+            } else if (d_feat_add) {                                    // another adjoint of the same rows, added here (may alias d_feat)
                 const float4* qa = reinterpret_cast<const float4*>(d_feat_add + m * F);
 #pragma unroll
                 for (int i = 0; i < F / 4; ++i) {
@@ -173,7 +186,31 @@ extern "C" int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const
     HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
     const int64_t n_it = cdiv(M, 256);
     const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
-    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat_add, d_feat, gW, gb);
+    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat_add, d_feat, gW, gb,
+                       nmf_rows::RowsBwdIn{});
     NMF_CHECK_LAUNCH("nmf_heads_bwd");
+    return NMF_OK;
+}
+
+extern "C" int nmf_bounce_prep_heads_bwd(const int32_t* bidx, int64_t Mb, const float* normals, const float* heads,
+                                         const int32_t* ray_id, const float* rays, const float* conv, float min_rough,
+                                         int32_t detach_normals, const float* dN, const float* dr1, const float* df0,
+                                         const float* ddiffuse, const int32_t row_strides[4], const float* dfeat, const float* app,
+                                         const float* head_W, const float* head_b, float diffuse_mul, float diffuse_bias,
+                                         float tint_bias, float f0_bias, float rough_bias, float* d_normals, float* d_app,
+                                         float* g_head_W, float* g_head_b, void* stream) {
+    NMF_REQUIRE(Mb >= 0, NMF_EINVAL, "nmf_bounce_prep_heads_bwd: Mb < 0");
+    if (Mb == 0) return NMF_OK;
+    NMF_REQUIRE(bidx && normals && heads && ray_id && rays && conv && app && head_W && head_b && d_normals && d_app && g_head_W &&
+                    g_head_b, NMF_EINVAL, "nmf_bounce_prep_heads_bwd: null");
+    HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
+    nmf_rows::RowsBwdIn rin{bidx, normals, heads, ray_id, rays, nmf_rows::Conv{conv}, min_rough, (int)detach_normals, dN, dr1, df0, ddiffuse,
+                            row_strides ? row_strides[0] : 3, row_strides ? row_strides[1] : 1, row_strides ? row_strides[2] : 3,
+                            row_strides ? row_strides[3] : 3, dfeat, d_normals};
+    const int64_t n_it = cdiv(Mb, 256);
+    const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
+    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, app, Mb, head_W, head_b, hp, nullptr, nullptr, d_app,
+                       g_head_W, g_head_b, rin);
+    NMF_CHECK_LAUNCH("nmf_bounce_prep_heads_bwd");
     return NMF_OK;
 }

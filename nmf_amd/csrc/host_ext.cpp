@@ -930,6 +930,31 @@ std::tuple<Tensor, Tensor, Tensor> bounce_prep_bwd(const OT& inv, const Tensor& 
     return {d_normals, d_heads, d_app};
 }
 
+// bounce_prep_bwd (row_inputs = 2) + heads_bwd in one launch (nmf_bounce_prep_heads_bwd) -> {d_normals [Mb,3], d_app [Mb,24]}
+std::tuple<Tensor, Tensor> bounce_prep_heads_bwd(const Tensor& bidx, const Tensor& normals, const Tensor& heads, const Tensor& ray_id,
+                                                 const Tensor& rays, const Tensor& conv, double min_rough, bool detach_n, const OT& dN,
+                                                 const OT& dr1, const OT& df0, const OT& ddiff, const OT& dfeat, const Tensor& app,
+                                                 const Tensor& W, const Tensor& b, const std::vector<double>& hp, const Tensor& gW,
+                                                 const Tensor& gb, int64_t stream) {
+    TimedScope _ts("heads_bwd", stream);
+    if (hp.size() != 5) fail("bounce_prep_heads_bwd: hp = (diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias)");
+    const int64_t Mb = bidx.size(0);
+    Tensor d_normals = fe(normals, {Mb, 3}), d_app = fe(normals, {Mb, 24});
+    if (Mb) {
+        std::vector<Tensor> keep;
+        const auto a = rows_of(dN, 3, keep), b2 = rows_of(dr1, 1, keep), c = rows_of(df0, 3, keep), d = rows_of(ddiff, 3, keep);
+        const int32_t strides[4] = {a.second, b2.second, c.second, d.second};
+        OT df;
+        if (dfeat.has_value()) df = dfeat->contiguous();
+        check(nmf_bounce_prep_heads_bwd(i32(bidx), Mb, f32(normals), f32(heads), i32(ray_id), f32(rays), f32(conv), (float)min_rough,
+                                        detach_n ? 1 : 0, a.first, b2.first, c.first, d.first, strides, of32(df), f32(app), f32(W),
+                                        f32(b), (float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3], (float)hp[4], out(d_normals),
+                                        out(d_app), static_cast<float*>(vptr(gW)), static_cast<float*>(vptr(gb)), st(stream)),
+              "nmf_bounce_prep_heads_bwd");
+    }
+    return {d_normals, d_app};
+}
+
 // slot tables are ctypes arrays owned by the Python side: passed by address
 void adam_step(int64_t slots_addr, int64_t n, const OT& guard, int64_t stream) {
     TimedScope _ts(__func__, stream);
@@ -1097,6 +1122,8 @@ PYBIND11_MODULE(_nmf_host, m) {
           py::arg("src_idx"), py::arg("out_bias"), py::arg("with_mask"), py::arg("max_workgroups"), py::arg("stream"),
           py::arg("image") = py::none());
     m.def("brdf_mlp_pack", &brdf_mlp_pack);
+    m.def("bounce_prep_heads_bwd", &bounce_prep_heads_bwd);
+    m.def("bounce_prep_fwd_heads", &bounce_prep_fwd_heads);
     m.def("brdf_mlp_bwd_sets", &brdf_mlp_bwd_sets, py::arg("w"), py::arg("sets"), py::arg("grads"), py::arg("max_workgroups"), py::arg("stream"),
           py::arg("image") = py::none());
     m.def("heads_fwd", &heads_fwd);

@@ -14,6 +14,7 @@
 // formulation is ~150 elementwise / index launches per level and as many again in the backward.
 #include "common.hpp"
 #include "heads_eval.hpp"
+#include "rows_bwd.hpp"
 
 namespace {
 
@@ -180,29 +181,12 @@ __global__ void __launch_bounds__(IDX_CHUNK) k_idx_final_fused(const int32_t* __
 }
 
 // ---- bounce prep -------------------------------------------------------------------------------------------------
-constexpr int HEADS = 11;       // albedo 3 | tint 3 | f0 3 | roughness 2 (nmf_heads_fwd)
-constexpr int FEAT = NMF_APP_DIM;
-
-struct Conv {
-    const float* c;   // [9][3] device pointer, uniform -> scalar loads
-};
-
-// the 9 real SH bases of modules/sh.py:97-142 (all-positive SH_C2 table of :67-73)
-__device__ __forceinline__ void sh9(float x, float y, float z, float (&Y)[9]) {
-    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-    const float C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
-    Y[0] = C0;
-    Y[1] = C1 * y;
-    Y[2] = C1 * z;
-    Y[3] = C1 * x;
-    Y[4] = C20 * (x * y);
-    Y[5] = C20 * (y * z);
-    Y[6] = C22 * (3.f * (z * z) - 1.f);
-    Y[7] = C20 * (x * z);
-    Y[8] = C24 * (x * x - y * y);
-}
-
-__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+using nmf_rows::HEADS;
+using nmf_rows::FEAT;
+using nmf_rows::Conv;
+using nmf_rows::sh9;
+using nmf_rows::sgn;
+using nmf_rows::irradiance_E;
 
 struct HeadsIn {            // W == NULL: the heads are read from `heads`
     const float* W;
@@ -284,21 +268,6 @@ __global__ void __launch_bounds__(256) k_bounce_prep_fwd(
 // one thread per SAMPLE: rows scatter back through the inverse map, everything else is written as zero, so the
 // three gradient tensors need no separate fill.  With row_inputs the head / feature adjoints stay per bounce row
 // ([Mb][11], [Mb][24], written by the first Mb threads) and only d_normals covers all samples.
-// SH irradiance factors E[c] of a normal, as ONE piece of code for both forms of the backward below (not inlined: the row-based fast
-// path and the general path must give the same bits -- tests compare them -- and inlined copies are contracted into fmas differently
-// depending on what surrounds them)
-__device__ __noinline__ void irradiance_E(float nx, float ny, float nz, Conv conv, float* __restrict__ E3) {
-    float Y[9];
-    sh9(nx, ny, nz, Y);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float E = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) E += conv.c[k * 3 + c] * Y[k];
-        E3[c] = E;
-    }
-}
-
 __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
     const int32_t* __restrict__ inv, int64_t M, const int32_t* __restrict__ bidx, int64_t Mb,
     const float* __restrict__ normals, const float* __restrict__ heads,
@@ -312,37 +281,11 @@ __global__ void __launch_bounds__(256) k_bounce_prep_bwd(
         // every load in front of the stores -- bidx -> ray_id -> ray is the only chain (three round trips; the general form,
         // which interleaves loads, stores and mode tests, waits eleven times)
         if (t >= Mb) return;
-        const bool want_n = !detach_n && dN;
-        const int64_t m = bidx[t];
-        const float nx = normals[t * 3], ny = normals[t * 3 + 1], nz = normals[t * 3 + 2];
-        float dn[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f}, d0[3] = {0.f, 0.f, 0.f}, dr = 0.f;
-        if (want_n) { dn[0] = dN[t * sN]; dn[1] = dN[t * sN + 1]; dn[2] = dN[t * sN + 2]; }
-        if (ddiff) { dd[0] = ddiff[t * sd]; dd[1] = ddiff[t * sd + 1]; dd[2] = ddiff[t * sd + 2]; }
-        if (df0) { d0[0] = df0[t * sf]; d0[1] = df0[t * sf + 1]; d0[2] = df0[t * sf + 2]; }
-        if (dr1) dr = dr1[t * sr];
-        const float h9 = heads[t * HEADS + 9];
-        float4 gf[FEAT / 4];
-#pragma unroll
-        for (int i = 0; i < FEAT / 4; ++i)
-            gf[i] = dfeat ? reinterpret_cast<const float4*>(dfeat + t * FEAT)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float gn[3] = {0.f, 0.f, 0.f};
-        if (want_n) {
-            const float* d = rays + (int64_t)ray_id[m] * 6 + 3;
-            const float s = sgn(-(d[0] * nx + d[1] * ny + d[2] * nz));
-            gn[0] = dn[0] * s; gn[1] = dn[1] * s; gn[2] = dn[2] * s;
-        }
-        d_normals[t * 3] = gn[0]; d_normals[t * 3 + 1] = gn[1]; d_normals[t * 3 + 2] = gn[2];
+        nmf_rows::RowsBwdIn rin{bidx, normals, heads, ray_id, rays, conv, min_rough, detach_n, dN, dr1, df0, ddiff, sN, sr, sf, sd, dfeat,
+                                d_normals};
         float gh[HEADS];
-#pragma unroll
-        for (int j = 0; j < HEADS; ++j) gh[j] = 0.f;
-        float E3[3];
-        irradiance_E(nx, ny, nz, conv, E3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            gh[c] = ddiff ? dd[c] * E3[c] : 0.f;
-            gh[6 + c] = d0[c];
-        }
-        gh[9] = (dr1 && h9 >= min_rough) ? dr : 0.f;
+        float4 gf[FEAT / 4];
+        nmf_rows::prep_bwd_row(rin, t, gh, gf);
         float4* o4 = reinterpret_cast<float4*>(d_app + t * FEAT);
 #pragma unroll
         for (int i = 0; i < FEAT / 4; ++i) o4[i] = gf[i];

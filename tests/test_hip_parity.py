@@ -989,6 +989,18 @@ def test_vm_value_only_query_and_row_normals():
     outside[bidx.long()] = False
     assert float(g1[0][outside].abs().max()) == 0.0 and float(g2[0].abs().max()) > 0          # nothing outside the rows
     assert torch.equal(g1[1], g2[1]) and torch.equal(g1[2], g2[2])
+    # the row preparation's adjoint inside the heads' backward (nmf_bounce_prep_heads_bwd) = nmf_bounce_prep_bwd + nmf_heads_bwd
+    if hip.HOST_EXT is not None:
+        gW_a, gb_a = torch.zeros(11, 24, device=DEV), torch.zeros(11, device=DEV)
+        gW_b, gb_b = torch.zeros(11, 24, device=DEV), torch.zeros(11, device=DEV)
+        d_app_a = hip.heads_bwd(app, hW, hb, hp, g2[1], gW_a, gb_a, add_into=g2[2].clone())
+        stream = torch.cuda.current_stream().cuda_stream
+        dn_b, d_app_b = hip.HOST_EXT.bounce_prep_heads_bwd(bidx, nr_rows, heads, ray_id, rays, conv, 0.02, False, dN, dr1, df0, dd, dfeat,
+                                                           app, hW, hb, list(hp), gW_b, gb_b, stream)
+        assert torch.equal(dn_b, g2[0])
+        assert_close(d_app_b.cpu(), d_app_a.cpu(), rtol=1e-6, atol=1e-7 * float(d_app_a.abs().max()), what="fused row adjoint: d_app")
+        assert_close(gW_b.cpu(), gW_a.cpu(), rtol=1e-5, atol=1e-6 * float(gW_a.abs().max()), what="fused row adjoint: head weights")
+        assert_close(gb_b.cpu(), gb_a.cpu(), rtol=1e-5, atol=1e-6 * float(gb_a.abs().max()), what="fused row adjoint: head biases")
 
 
 @pytest.mark.parametrize("M", [1, 31, 33, 5000])
