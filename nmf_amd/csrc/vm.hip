@@ -978,22 +978,37 @@ __global__ void __launch_bounds__(SC_THREADS) k_bins_scan(int32_t* counts, int n
 
 // adjoint of the raw density feature and of the raw density gradient (normalised-coordinate units) of sample l of segment k:
 // the softplus / normalize backward, once per sample
-__device__ __forceinline__ float4 sample_adjoint(const nmf_vm_params& p, const Segs& sg, int k, int64_t l) {
+// One sample's adjoint inputs, and what is made of them: two functions so that a caller can put its own loads between the two
+// (with each load next to its use the placing kernel waited four times in a row).
+struct AdjIn { float dsf, f, dsv, g0, g1, g2, dn0, dn1, dn2; };
+__device__ __forceinline__ AdjIn sample_adjoint_load(const Segs& sg, int k, int64_t l) {
+    AdjIn a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* d_sigma_feat = pick4(sg.d_sigma_feat, k);
-    float dsf = d_sigma_feat ? d_sigma_feat[l] : 0.f;
+    if (d_sigma_feat) a.dsf = d_sigma_feat[l];
     if (sg.d_sigma[0]) {
-        const float f = pick4(sg.sigma_feat, k)[l];
+        a.f = pick4(sg.sigma_feat, k)[l];
+        a.dsv = pick4(sg.d_sigma, k)[l];
+    }
+    if (sg.d_normal[0]) {
+        const float* grad = pick4(sg.grad, k);
+        const float* d_normal = pick4(sg.d_normal, k);
+        a.g0 = grad[l * 3], a.g1 = grad[l * 3 + 1], a.g2 = grad[l * 3 + 2];
+        a.dn0 = d_normal[l * 3], a.dn1 = d_normal[l * 3 + 1], a.dn2 = d_normal[l * 3 + 2];
+    }
+    return a;
+}
+__device__ __forceinline__ float4 sample_adjoint_finish(const nmf_vm_params& p, const Segs& sg, const AdjIn& a) {
+    float dsf = a.dsf;
+    if (sg.d_sigma[0]) {
+        const float f = a.f;
         const float x = fminf(fmaxf(f, -15.f), 1e3f) + p.density_shift;
         float ds = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));          // softplus'
         if (f < -15.f || f > 1e3f) ds = 0.f;                         // clamp'
-        dsf += pick4(sg.d_sigma, k)[l] * ds;
+        dsf += a.dsv * ds;
     }
     float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
     if (sg.d_normal[0]) {   // through n = -g / sqrt(max(|g|^2, eps))
-        const float* grad = pick4(sg.grad, k);
-        const float* d_normal = pick4(sg.d_normal, k);
-        const float g0 = grad[l * 3], g1 = grad[l * 3 + 1], g2 = grad[l * 3 + 2];
-        const float dn0 = d_normal[l * 3], dn1 = d_normal[l * 3 + 1], dn2 = d_normal[l * 3 + 2];
+        const float g0 = a.g0, g1 = a.g1, g2 = a.g2, dn0 = a.dn0, dn1 = a.dn1, dn2 = a.dn2;
         const float n2 = g0 * g0 + g1 * g1 + g2 * g2;
         const float eps = 1.1920929e-07f;
         const float inv = 1.f / sqrtf(fmaxf(n2, eps));
@@ -1004,6 +1019,9 @@ __device__ __forceinline__ float4 sample_adjoint(const nmf_vm_params& p, const S
         dg2 = (-dn2 * inv + kk * g2) * p.inv_size[2];
     }
     return make_float4(dsf, dg0, dg1, dg2);
+}
+__device__ __forceinline__ float4 sample_adjoint(const nmf_vm_params& p, const Segs& sg, int k, int64_t l) {
+    return sample_adjoint_finish(p, sg, sample_adjoint_load(sg, k, l));
 }
 
 // The per-sample inputs of the backward walk, written in SORTED order so that the brick kernels stream them without an
@@ -1039,15 +1057,20 @@ __global__ void __launch_bounds__(256) k_place_records(nmf_vm_params p, Segs sg,
         for (int i = threadIdx.x; i < n_state; i += 256) scan_state[i] = 0ull;
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    // what does not depend on the slot is requested first: keyrank -> cursor is a chain of two round trips, the sample's position and
+    // adjoints one more next to it (they used to follow it: four)
     const int2 kr = keyrank[m];
-    const int pos = cursor[kr.x] + kr.y;
     int64_t l;
     const int k = seg_of(sg, m, l);
-    rec0[pos] = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
-    rec1[pos] = sample_adjoint(p, sg, k, l);
+    const float4 x = reinterpret_cast<const float4*>(pick4(sg.xyzt, k))[l];
+    const AdjIn ain = sample_adjoint_load(sg, k, l);
+    float da[APP ? AD : 1];
+    if constexpr (APP) load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
+    const int pos = cursor[kr.x] + kr.y;
+    const float4 adj = sample_adjoint_finish(p, sg, ain);
+    rec0[pos] = x;
+    rec1[pos] = adj;
     if constexpr (APP) {
-        float da[AD];
-        load_run<AD / 4>(pick4(sg.d_app, k) + l * AD, da);
         float4* srt = reinterpret_cast<float4*>(d_app_sorted + (int64_t)pos * AD);
 #pragma unroll
         for (int q = 0; q < AD / 4; ++q) srt[q] = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
