@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 111
+#define NMF_ABI_VERSION 112
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -319,8 +319,11 @@ int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const float* dirs
  * binned instead of scattered with float atomics -- corners counted per 32 x 64-texel SAT tile, written as records into the
  * caller's workspace, accumulated per tile in LDS as 64-bit fixed point (integer LDS atomics run ~8x faster than float
  * atomics on gfx950, and the sums do not depend on the order) and flushed once.  d_sat must be given.  workspace: 16-byte
- * aligned device memory of nmf_sat_lookup_bwd_workspace_bytes(R) bytes (content irrelevant, overwritten; a smaller pool
- * still gives correct results: corners that do not fit take the float atomics).  Four launches on `stream`. */
+ * aligned device memory of nmf_sat_lookup_bwd_workspace_bytes(R) bytes (content irrelevant, overwritten): a header, one
+ * 32-bit slot per (workgroup of 256 lookups, tile) -- the counting pass hands every workgroup its place in each tile's range,
+ * so the record pass walks the footprints once -- and the record pool.  A smaller pool still gives correct results (corners
+ * that do not fit take the float atomics); a workspace without room for header + slots + one record is NMF_EINVAL.  Four
+ * launches on `stream`. */
 int64_t nmf_sat_lookup_bwd_workspace_bytes(int64_t R);
 int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
                               int64_t R, float mipbias, const float* scalars_dev, int32_t layout,

@@ -488,6 +488,7 @@ struct EnvBwdArgs {
     float* d_sat4; float* d_pole; float* d_dirs; float* d_mipbias;
     EnvBinHeader* hdr; CornerRec* recs; int64_t cap;
     int ntx, nt;
+    uint32_t* blockres;                 // [lookup workgroups][nt]: where in its tile's range a workgroup's records start (pass 1 -> pass 2)
 };
 
 // dual-number role with the channels contracted: q(x, y) = sum_c go[c] * S_c(x, y)
@@ -719,8 +720,10 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A,
         box(p, acc);
     }
     __syncthreads();
+    // counting IS reserving: what the counter held before this workgroup's corners is where its records start inside the tile's
+    // range (pass 2 used to walk every footprint twice, once to find this out)
     for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS)
-        if (hist[i]) atomicAdd(&A.hdr->counts[i], hist[i]);
+        if (hist[i]) A.blockres[blk * A.nt + i] = atomicAdd(&A.hdr->counts[i], hist[i]);
     if (threadIdx.x == 0 && *gmax_s) atomicMax(&A.hdr->gmax_slots[blockIdx.x & 63], *gmax_s);
 }
 
@@ -823,39 +826,44 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs 
     uint32_t* tmp = resv + ENV_MAX_TILES;
     for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS) hist[i] = 0;
     if (threadIdx.x == 0) Q.n = 0;
+    const uint32_t* mine = A.blockres + blk * A.nt;          // (only the tiles this workgroup has corners in were written, and only
+    uint32_t own[ENV_MAX_TILES / ENV_BWD_THREADS];           //  those are looked up below)
+#pragma unroll
+    for (int j = 0; j < ENV_MAX_TILES / ENV_BWD_THREADS; ++j) {
+        const int i = threadIdx.x + j * ENV_BWD_THREADS;
+        own[j] = i < A.nt ? mine[i] : 0;
+    }
     env_scan_counts(A.hdr, A.nt, base, nullptr, tmp);
+#pragma unroll
+    for (int j = 0; j < ENV_MAX_TILES / ENV_BWD_THREADS; ++j) {
+        const int i = threadIdx.x + j * ENV_BWD_THREADS;
+        if (i < A.nt) resv[i] = base[i] + own[j];
+    }
+    __syncthreads();
+    // one walk: the records (same lookups per workgroup as in pass 1, whose counters handed out the ranges)
     const int64_t r = blk * ENV_BWD_THREADS + threadIdx.x;
-    // walk 1: corners of this workgroup per tile
-    CountAcc cnt{hist, A.tab.H, A.tab.W, A.ntx};
-    float inv_size = 0.f;
-    const bool live = env_walk_main(A, r, Q, geo, cnt, inv_size);
-    if (live) {
-        gs[threadIdx.x][0] = A.d_out[r * 3] * inv_size; gs[threadIdx.x][1] = A.d_out[r * 3 + 1] * inv_size;
-        gs[threadIdx.x][2] = A.d_out[r * 3 + 2] * inv_size;
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
-        const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
-        Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
-        env_combo_rect(rr, combo, p);
-        box(p, cnt);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < A.nt; i += ENV_BWD_THREADS) {
-        const uint32_t c = hist[i];
-        resv[i] = c ? base[i] + atomicAdd(&A.hdr->cursor[i], c) : 0;
-        hist[i] = 0;
-    }
-    __syncthreads();
-    // walk 2: the records
     EmitAcc acc;
     acc.rank = hist; acc.resv = resv; acc.recs = A.recs; acc.cap = A.cap; acc.dsat4 = A.d_sat4; acc.overflow = &A.hdr->overflow;
     acc.H = A.tab.H; acc.W = A.tab.W; acc.ntx = A.ntx;
-    if (live) {
-        acc.g[0] = gs[threadIdx.x][0]; acc.g[1] = gs[threadIdx.x][1]; acc.g[2] = gs[threadIdx.x][2];
-        Rect<float> rr{geo[threadIdx.x][0], geo[threadIdx.x][1], geo[threadIdx.x][2], geo[threadIdx.x][3]};
-        box(rr, acc);
+    {
+        const float mipbias = A.sc ? A.sc[0] : A.mipbias;
+        const float cutoff = 1.f - 2.f / (float)A.tab.H * 3.f;
+        if (r < A.R) {
+            const float* q = A.dirs + r * A.ld + (A.ld - 3);
+            const float go0 = A.d_out[r * 3], go1 = A.d_out[r * 3 + 1], go2 = A.d_out[r * 3 + 2];
+            const Geometry<float> g = env_geometry<float>(A.tab.H, A.tab.W, q[0], q[1], q[2], A.sa[r], mipbias);
+            if (!(g.cy > cutoff || g.cy < -cutoff)) {
+                geo[threadIdx.x][0] = g.rect.x0; geo[threadIdx.x][1] = g.rect.x1; geo[threadIdx.x][2] = g.rect.y0;
+                geo[threadIdx.x][3] = g.rect.y1; geo[threadIdx.x][4] = g.size;
+                const float inv_size = 1000.f / g.size;
+                acc.g[0] = go0 * inv_size; acc.g[1] = go1 * inv_size; acc.g[2] = go2 * inv_size;
+                gs[threadIdx.x][0] = acc.g[0]; gs[threadIdx.x][1] = acc.g[1]; gs[threadIdx.x][2] = acc.g[2];
+                box(g.rect, acc);
+                env_queue_push(Q, env_combo_mask(g.rect.x0, g.rect.x1, g.rect.y0, g.rect.y1));
+            }
+        }
     }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < Q.n; i += ENV_BWD_THREADS) {
         const int owner = Q.item[i] >> 4, combo = Q.item[i] & 15;
         Rect<float> rr{geo[owner][0], geo[owner][1], geo[owner][2], geo[owner][3]}, p;
@@ -1119,7 +1127,8 @@ extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const 
 }
 
 extern "C" int64_t nmf_sat_lookup_bwd_workspace_bytes(int64_t R) {
-    return (int64_t)sizeof(EnvBinHeader) + (R < 0 ? 0 : R) * 12 * (int64_t)sizeof(CornerRec);
+    const int64_t r = R < 0 ? 0 : R;      // header | one slot per (workgroup of 256 lookups, tile) | 12 corner records per lookup
+    return (int64_t)sizeof(EnvBinHeader) + cdiv(r, ENV_BWD_THREADS) * ENV_MAX_TILES * 4 + r * 12 * (int64_t)sizeof(CornerRec);
 }
 
 extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
@@ -1132,7 +1141,9 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: dirs_ld must be 3 or 6");
     const int ntx = (int)cdiv(W, ENV_TILE_W), nty = (int)cdiv(H, ENV_TILE_H);
     NMF_REQUIRE(ntx * nty <= ENV_MAX_TILES, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: map larger than 1024 tiles of 32 x 64");
-    NMF_REQUIRE(workspace_bytes >= (int64_t)sizeof(EnvBinHeader) + (int64_t)sizeof(CornerRec) && ((uintptr_t)workspace & 15) == 0,
+    const int64_t nb = cdiv(R, ENV_BWD_THREADS);             // lookups: 256 per workgroup in every role
+    const int64_t res_bytes = (nb * (int64_t)(ntx * nty) * 4 + 15) & ~(int64_t)15;
+    NMF_REQUIRE(workspace_bytes >= (int64_t)sizeof(EnvBinHeader) + res_bytes + (int64_t)sizeof(CornerRec) && ((uintptr_t)workspace & 15) == 0,
                 NMF_EINVAL, "nmf_sat_lookup_bwd_binned: workspace too small or not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     EnvBwdArgs A;
@@ -1140,15 +1151,20 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     A.dirs = dirs; A.ld = dirs_ld; A.sa = sa; A.R = R; A.mipbias = mipbias; A.sc = scalars_dev; A.d_out = d_out;
     A.d_sat4 = d_sat; A.d_pole = d_pole; A.d_dirs = d_dirs; A.d_mipbias = d_mipbias;
     A.hdr = reinterpret_cast<EnvBinHeader*>(workspace);
-    A.recs = reinterpret_cast<CornerRec*>(reinterpret_cast<char*>(workspace) + sizeof(EnvBinHeader));
-    A.cap = (workspace_bytes - (int64_t)sizeof(EnvBinHeader)) / (int64_t)sizeof(CornerRec);
+    A.blockres = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + sizeof(EnvBinHeader));
+    A.recs = reinterpret_cast<CornerRec*>(reinterpret_cast<char*>(workspace) + sizeof(EnvBinHeader) + res_bytes);
+    A.cap = (workspace_bytes - (int64_t)sizeof(EnvBinHeader) - res_bytes) / (int64_t)sizeof(CornerRec);
     A.ntx = ntx; A.nt = ntx * nty;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(EnvBinHeader), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_sat_lookup_bwd_binned: hipMemsetAsync");
-    const int64_t nb = cdiv(R, ENV_BWD_THREADS);             // lookups: 256 per workgroup in every role
     // shares of the dual-number workgroups next to the three passes.  Measured on the 247 k lookups of a steady-state step
-    // (tools/env_bwd_bench.py, us): all behind pass 3 155, 30/40/30 156, 50/50/0 144, all next to pass 2 138; direct scatter 176
-    const int64_t d1 = 0, d2 = nb, d3 = nb - d1 - d2;
+    // (tools/env_bwd_bench.py, us).  With pass 2 walking every footprint twice: all behind pass 3 155, 30/40/30 156, 50/50/0 144,
+    // all next to pass 2 138 (direct scatter 176).  Since pass 1 hands out the record ranges and pass 2 walks once (81 us
+    // without riders): all next to pass 2 111, 50/50/0 101, 80/20/0 104, all next to pass 1 -- LDS counting only, the
+    // riders' arithmetic fills it -- 98.  NMF_ENV_RIDERS1 / NMF_ENV_RIDERS2: percent next to passes 1 / 2 (the rest: pass 3)
+    static const int split1 = [] { const char* e = getenv("NMF_ENV_RIDERS1"); return e ? atoi(e) : 100; }();
+    static const int split2 = [] { const char* e = getenv("NMF_ENV_RIDERS2"); return e ? atoi(e) : 0; }();
+    const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = nb - d1 - d2;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
     if (layout == 1) {
         hipLaunchKernelGGL(k_env_bin_count<1>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);

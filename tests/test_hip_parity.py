@@ -550,7 +550,9 @@ def test_env_binned_table_adjoint(H, R, monkeypatch):
     rows = dirs.to(DEV).contiguous()
     d_sat, d_pole, d_mip = torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV)
     d_dirs = torch.empty(R, 3, device=DEV)
-    nbytes = 16 * 1024 + 1000 * 24
+    # workspace = header (8720 B) | one slot per (workgroup of 256 lookups, tile of 32 x 64 texels) | the record pool
+    res_bytes = (-(-R // 256) * (-(-H // 32) * -(-W // 64)) * 4 + 15) & ~15
+    nbytes = 8720 + res_bytes + 1000 * 24
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     cc, sa_d = c.to(DEV).contiguous(), sa.to(DEV).contiguous()
     rc = hip._lib.nmf_sat_lookup_bwd_binned(sat4.data_ptr(), H, W, rows.data_ptr(), 3, sa_d.data_ptr(), R, C.c_float(0.3), None, 1,
@@ -560,7 +562,12 @@ def test_env_binned_table_adjoint(H, R, monkeypatch):
     torch.cuda.synchronize()
     hdr = ws[:8208].view(torch.int32)
     n_corners, overflow = int(hdr[:1024].sum()), int(hdr[2049])
-    assert n_corners >= 4 * (R - 500) and (overflow > 0) == (n_corners > (nbytes - 8208) // 24), (n_corners, overflow)
+    assert n_corners >= 4 * (R - 500) and (overflow > 0) == (n_corners > 1000), (n_corners, overflow)
+    assert overflow == max(n_corners - 1000, 0), (n_corners, overflow)
+    # a workspace without room for the slots is refused
+    assert hip._lib.nmf_sat_lookup_bwd_binned(sat4.data_ptr(), H, W, rows.data_ptr(), 3, sa_d.data_ptr(), R, C.c_float(0.3), None, 1,
+                                              cc.data_ptr(), d_sat.data_ptr(), d_pole.data_ptr(), d_dirs.data_ptr(), d_mip.data_ptr(),
+                                              ws.data_ptr(), 8720 + res_bytes, hip._stream()) != 0
     assert_close(d_sat.cpu(), res["direct"][1].cpu(), rtol=1e-4, atol=2e-6 * float(res["direct"][1].abs().max()), what="d_sat, small pool")
     if H == 32:                      # the golden fixture's size: the map gradient against the oracle's autograd
         sd = _env_sd(bg.cpu().clone().requires_grad_(True))
