@@ -1161,9 +1161,10 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     // (tools/env_bwd_bench.py, us).  With pass 2 walking every footprint twice: all behind pass 3 155, 30/40/30 156, 50/50/0 144,
     // all next to pass 2 138 (direct scatter 176).  Since pass 1 hands out the record ranges and pass 2 walks once (81 us
     // without riders): all next to pass 2 111, 50/50/0 101, 80/20/0 104, all next to pass 1 -- LDS counting only, the
-    // riders' arithmetic fills it -- 98.  NMF_ENV_RIDERS1 / NMF_ENV_RIDERS2: percent next to passes 1 / 2 (the rest: pass 3)
-    static const int split1 = [] { const char* e = getenv("NMF_ENV_RIDERS1"); return e ? atoi(e) : 100; }();
-    static const int split2 = [] { const char* e = getenv("NMF_ENV_RIDERS2"); return e ? atoi(e) : 0; }();
+    // riders' arithmetic fills it -- 98.  NMF_ENV_RIDERS="p1,p2": percent next to passes 1 / 2 (the rest: pass 3)
+    int split1 = 100, split2 = 0;
+    if (const char* e = getenv("NMF_ENV_RIDERS")) sscanf(e, "%d:%d", &split1, &split2);      // (read per call: tools/ab_inprocess.py)
+    split1 = std::min(std::max(split1, 0), 100); split2 = std::min(std::max(split2, 0), 100);
     const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = nb - d1 - d2;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
     if (layout == 1) {
