@@ -467,7 +467,7 @@ constexpr int ENV_WIN_W = ENV_TILE_W + 1, ENV_WIN_H = ENV_TILE_H + 1, ENV_WIN = 
 
 struct EnvBinHeader {
     uint32_t counts[ENV_MAX_TILES];     // corners per tile
-    uint32_t cursor[ENV_MAX_TILES];     // records reserved so far per tile
+    uint32_t cursor[ENV_MAX_TILES];     // (unused since pass 1 hands out the ranges: kept so that the words behind it stay where they were)
     uint32_t gmax_bits;                 // bits of the largest |d_out[c]| * 1000 / size (a non-negative float)
     uint32_t overflow;                  // corners that did not fit the pool (they took the direct float atomics)
     uint32_t pad[2];
