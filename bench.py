@@ -34,27 +34,12 @@ CHUNK = 4096                    # rays per forward/backward chunk (train.py `num
 GRID = 128
 BG_RES = 512
 FRAME = 800
-# Algorithmic bytes per kept sample, forward (SURVEY 8d, fp32 tables, 18 taps): density value 1152 + density gradient
-# 1920 + appearance 1728 = G_s = 4800.  Backward = recompute read + read-modify-write of the gradients = 3 x forward.
-# The density / normal walk runs over all kept samples, the appearance walk only over the bounce rows (sparse appearance).
+# SURVEY 8(d)'s byte figures per kept sample, forward (fp32 tables, 18 taps): density value 1152 + density gradient 1920 +
+# appearance 1728 = G_s = 4800; fwd + bwd = 4 x forward.  The 7.5 MB of tables are L2 / MALL resident, so these bytes never
+# bounded anything (round 4: 1.8 x the HBM peak at step level): they are reported as `survey_8d_over_hbm` for the record only;
+# the fractions of the `roofline` object are the useful-work models of kernel_models() below.
 G_DENSITY, G_APP = 1152 + 1920, 1728
-BWD_BYTES_DENSITY, BWD_BYTES_APP = 3 * G_DENSITY, 3 * G_APP
 HBM_PEAK_GBS = 8000.0
-# The dominant kernel (k_vm_bwd_brick) performs the scatter-add of the table gradients on the matrix cores.  Per group of 4
-# samples and per plane/line pair it issues NRB row blocks x (value + 2 derivative taps) + 2 line tiles (density), or
-# NRB x 2 channel halves + 2 line tiles (appearance; + 4 for the basis matrix once per group) v_mfma_f32_16x16x4_f32 of
-# 16*16*4*2 = 2048 FLOP each.  NRB = ceil((BR+1)^2 / 16) = 2 for the 4^3 bricks of vm.hip (it was 6 with the 8^3 bricks
-# of the r02_b profile: a third of the matrix instructions per sample now, so `achieved` counts ISSUED FLOP and fell with
-# them while the launch got 1.5x faster).  f32-input MFMA peak = 157.3 TFLOP/s dense (MI355X_MICROARCH.md).
-VM_BWD_NRB = 2
-MFMA_FLOP_DENSITY = 3 * (3 * VM_BWD_NRB + 2) * 2048 / 4
-# value-only walk (the re-traced samples: sparse normals, nmf_amd/fast_step.py): NRB value blocks + 1 line tile, and a third
-# of the density-table bytes of SURVEY 8(d) (16 of the 48 packed floats per tap, 16 of 32 per line tap)
-MFMA_FLOP_VALUE = 3 * (VM_BWD_NRB + 1) * 2048 / 4
-BWD_BYTES_VALUE = 3 * (1152 + 1920) // 3
-MFMA_FLOP_APP = (3 * (2 * VM_BWD_NRB + 2) + 4) * 2048 / 4
-MFMA_F32_PEAK_TFLOPS = 157.3
-
 
 def build(device, grid=None, table_dtype="f32"):
     import torch  # noqa: F401
@@ -92,73 +77,141 @@ class RebuildCounter:
             setattr(hip, name, counted)
 
 
-# ---- per-call roofline models -------------------------------------------------------------------------------------------
-# Every C-ABI call of the step is timed with HIP events on the stream it launches on (csrc/host_ext.cpp CallTimer).  For the calls
-# whose ceiling has a simple algorithmic model the live fraction is computed here; `bound` says which ceiling that is:
-#   mfma     issued FLOP against the matrix peak of the instruction: BRDF MLP = v_mfma_f32_32x32x16_bf16 against the 2.5 PFLOP/s dense
-#            bf16 peak (the kernel is bound by the VALU work around its matrix instructions and by latency at one wave per SIMD,
-#            DESIGN.md section 0); field walk = issued v_mfma_f32_16x16x4_f32 FLOP against the 157.3 TFLOP/s f32-input peak, its
-#            real ceiling is MFMA + VALU issue: `alu_busy` of the counter run beside it
-#   atomics  lane-level float atomics against the 156 G/s the memory-side units sustain on the 8-lane pattern (tools/ub/atom2.hip)
-#   hbm      algorithmic bytes against 8 TB/s (tables are L2 / MALL resident: a fraction above 1 means the model does not bound it)
-#   alu / latency   no algorithmic model: the counter fractions of profiles/<tag>_roofline.json are reported beside the time
-MLP_FWD_FLOP, ATOMIC_PEAK = 2 * 8576, 156e9
-# csrc/brdf_mlp.hip (round 3): v_mfma_f32_32x32x16_bf16 (2 x 32 x 32 x 16 FLOP each) issued per 32-ray tile: the forward splits
-# every fp32 operand into three bf16 terms (six products per K block: 60 + 48 instructions), the backward into two (three products;
-# 186 instructions incl. the transpositions on the matrix core).  Priced against the dense bf16 matrix peak.
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+# ---- per-kernel roofline models ------------------------------------------------------------------------------------------
+# Every kernel launch of libnmf_hip.so is timed with HIP events on the stream it is launched on (nmf_set_launch_probe -> the
+# kernel timer of csrc/host_ext.cpp); names are the kernels' own (what rocprofv3 --kernel-trace prints).  A kernel with a
+# model gets frac = USEFUL work / its own duration / peak, with the work stated per unit below and in DESIGN.md section 0.R5, so that
+# every fraction can be recomputed by hand from `sizes_per_step` and profiles/<tag>_steady_state_per_step.csv and is <= 1 by
+# construction (useful <= issued <= peak x time).  The arithmetic of the path is fp32; MI355X's fp32 vector rate and its
+# fp32-input matrix rate are the same 157.3 TFLOP/s (MI355X_MICROARCH.md), so that ONE peak prices VALU, MFMA and mixed
+# kernels alike: `bound` = "mfma" for the kernels whose useful FLOP run on the matrix cores, "valu" otherwise.
+#   BRDF MLP          SURVEY 8(d): 17 152 FLOP per secondary ray forward (66x64 + 64x64 + 64x4 multiply-adds), twice that
+#                     backward (adjoint + weight-gradient products).  The kernels ISSUE 108 / 186 v_mfma_f32_32x32x16_bf16 per
+#                     32 rays (split-bf16 operands): `issued_bf16_frac` prices those against the 2.5 PFLOP/s dense bf16 peak.
+#   field queries     a "tap-channel" = one table entry met by one interpolation weight.  density value: 3 x (4 x 16 plane +
+#                     2 x 16 line) = 288; density gradient (normals): 3 x (2 x 4 x 16 + 2 x 16) = 480 more (two derivative planes,
+#                     one derivative line per pair); appearance: 3 x (4 x 24 + 2 x 24) = 432 and the 72 x 24 basis matrix.
+#                     forward  = 1 FMA per tap-channel + 1 multiply per (pair, channel, product term)
+#                     backward = forward recompute + 1 scatter FMA per tap-channel + 1 multiply per product term
+#   marcher           20 lane-operations per candidate step (Philox4x32-10 shared by 4 steps: 12, running sum 1, position 3,
+#                     coarse occupancy test 4) x rays x N steps -- the reference evaluates every one of them -- against the
+#                     VALU issue peak 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+#   env-map adjoint   48 table updates per lookup (4 corners x 4 texels x 3 channels) against the 156 G lane-atomics/s of the
+#                     memory-side units (tools/ub/atom2.hip)
+#   byte-bound kernels   their compulsory bytes against 8 TB/s (Adam: 28 B per parameter; compositing, segment sums: the
+#                     arrays they read and write once)
+MLP_FWD_FLOP = 2 * 8576
+FP32_PEAK, BF16_PEAK, HBM_PEAK, LANE_OP_PEAK, ATOMIC_PEAK = 157.3e12, 2500.0e12, 8000.0e9, 256 * 4 * 32 * 2.4e9, 156e9
+MFMA_F32_PEAK_TFLOPS, MFMA_BF16_PEAK_TFLOPS = 157.3, 2500.0
+# csrc/brdf_mlp.hip: v_mfma_f32_32x32x16_bf16 (2 x 32 x 32 x 16 FLOP each) issued per 32-ray tile
 MLP_FWD_ISSUED_FLOP = 108 * 32768 / 32
 MLP_BWD_ISSUED_FLOP = 186 * 32768 / 32
 ADAM_BYTES_PER_PARAM = 28
-
-
-_WALK_FLOP = 0.0
+TAPCH_VALUE, TAPCH_GRAD, TAPCH_APP = 288, 480, 432
+FWD_VALUE = 2 * TAPCH_VALUE + 48                          # FLOP per sample: density value
+FWD_GRAD = 2 * TAPCH_GRAD + 3 * 48                        # ... the gradient of the density on top of it (three product terms per pair)
+FWD_APP = 2 * TAPCH_APP + 72 + 2 * 72 * 24                # ... appearance features incl. basis_mat
+BWD_VALUE, BWD_GRAD, BWD_APP = 2 * FWD_VALUE, 2 * FWD_GRAD, 2 * FWD_APP
+MARCH_LANE_OPS = 20
 L2_PEAK_GBS = 34500.0
 
 
-def call_models(sz, n_params):
-    """sz: sizes of one step (rays B, samples M0 M1, secondary rays R0 R1, bounce rows Mb0 Mb1) -> {call: (bound, work, peak)}"""
-    B, M0, M1, R0, R1, Mb0, Mb1 = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1"))
-    walk_flop = (M0 + Mb1) * MFMA_FLOP_DENSITY + M1 * MFMA_FLOP_VALUE + (Mb0 + Mb1) * MFMA_FLOP_APP
-    global _WALK_FLOP
-    _WALK_FLOP = walk_flop
-    return {
-        "brdf_mlp_bwd": ("mfma", MLP_BWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
-        "brdf_mlp_fwd": ("mfma", MLP_FWD_ISSUED_FLOP * (R0 + R1), MFMA_BF16_PEAK_TFLOPS * 1e12),
-        # the backward walks: SURVEY 8(d)'s algorithmic bytes of what the pass walks (sparse normals / appearance: recompute read +
-        # read-modify-write of the gradients = 3 x the forward bytes of each sample set) against HBM.  The 7.5 MB of tables are
-        # L2 / MALL resident, so the fraction may exceed 1: `traffic` (counters) says how little reaches HBM; what bounds the kernel
-        # is VALU issue around its sparse-A matrix instructions: `secondary` carries alu_busy and the issued-MFMA rate
-        "vm_query_bwd_segments": ("hbm", float((M0 + Mb1) * BWD_BYTES_DENSITY + M1 * BWD_BYTES_VALUE + (Mb0 + Mb1) * BWD_BYTES_APP),
-                                  HBM_PEAK_GBS * 1e9),
-        "sat_lookup_bwd": ("atomics", 48.0 * (R0 + R1), ATOMIC_PEAK),            # 4 corners x 4 texels x 3 channels per box
-        "sat_lookup_fwd": ("hbm", 192.0 * (R0 + R1 + 5000), HBM_PEAK_GBS * 1e9),
-        "vm_query_fwd": ("hbm", float(M0 * G_DENSITY + (Mb0 + Mb1) * G_APP), HBM_PEAK_GBS * 1e9),
-        "vm_query_sigma": ("hbm", float(M1 * 1152), HBM_PEAK_GBS * 1e9),        # 18 taps x 16 channels x 4 B, value only
-        "vm_query_rows": ("hbm", float(Mb1 * G_DENSITY), HBM_PEAK_GBS * 1e9),
-        "march_count": ("alu", None, None), "march_fill": ("alu", None, None),
-        "adam_step": ("hbm", float(ADAM_BYTES_PER_PARAM * n_params), HBM_PEAK_GBS * 1e9),
+def kernel_models(sz, n_params):
+    """sz: sizes of one step (rays B, samples M0 M1, secondary rays R0 R1, bounce rows Mb0 Mb1, N steps per ray)
+    -> {kernel name: (bound, useful work per STEP, peak, unit)}; names as libnmf_hip.so launches them"""
+    B, M0, M1, R0, R1, Mb0, Mb1, N = (sz[k] for k in ("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1", "N"))
+    R = R0 + R1
+    F, H, A = "TFLOP/s", "GB/s", "G updates/s"
+    m = {
+        "k_brdf_mlp_bwd": ("mfma", 2.0 * MLP_FWD_FLOP * R, FP32_PEAK, F),
+        "k_brdf_mlp_fwd": ("mfma", 1.0 * MLP_FWD_FLOP * R, FP32_PEAK, F),
+        # backward walks: value-only over the re-traced samples; value + gradient over the primary samples and the bounce rows
+        # of the re-traced level (their normals); appearance over the bounce rows of both levels
+        "k_vm_bwd_density<false>": ("mfma", float(BWD_VALUE * M1), FP32_PEAK, F),
+        "k_vm_bwd_density<true>": ("mfma", float((BWD_VALUE + BWD_GRAD) * (M0 + Mb1)), FP32_PEAK, F),
+        "k_vm_bwd_brick<false, 1>": ("mfma", float(BWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
+        "k_vm_fwd<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * M0), FP32_PEAK, F),
+        "k_vm_sigma<float>": ("valu", float(FWD_VALUE * M1), FP32_PEAK, F),
+        "k_vm_rows_dn<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * Mb1), FP32_PEAK, F),
+        "k_vm_app_rows<float>": ("valu", float(FWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
+        "k_march_count16": ("valu", float(MARCH_LANE_OPS) * R0 * N, LANE_OP_PEAK, "T lane-ops/s"),
+        "k_march_fill16": ("valu", float(MARCH_LANE_OPS) * R0 * N, LANE_OP_PEAK, "T lane-ops/s"),
+        "k_march_count": ("valu", float(MARCH_LANE_OPS) * B * N, LANE_OP_PEAK, "T lane-ops/s"),
+        "k_march_fill": ("valu", float(MARCH_LANE_OPS) * B * N, LANE_OP_PEAK, "T lane-ops/s"),
+        # (the binned env-map adjoint is three kernels over the same lookups: priced as a group, KERNEL_GROUPS)
+        "group:env_adjoint": ("atomics", 48.0 * R, ATOMIC_PEAK, A),
+        "group:brdf_mlp_backward": ("mfma", 2.0 * MLP_FWD_FLOP * R, FP32_PEAK, F),
+        "k_env_lookup_fwd<1>": ("hbm", 192.0 * (R + 5000), HBM_PEAK, H),
+        "k_adam": ("hbm", float(ADAM_BYTES_PER_PARAM * n_params), HBM_PEAK, H),
+        "k_composite_bwd_wave<16>": ("hbm", 20.0 * M1, HBM_PEAK, H),
+        "k_composite_fwd_wave<8>": ("hbm", 16.0 * M1, HBM_PEAK, H),
+        "k_plan_hist": ("hbm", 20.0 * (M0 + M1 + 2 * Mb1 + Mb0), HBM_PEAK, H),
+        "k_place_records<false>": ("hbm", 56.0 * (M0 + M1 + Mb1), HBM_PEAK, H),
     }
+    return m
 
 
-def per_call_table(timing, steps, sz, n_params, counters):
-    """timing: {call: (ms, calls)} over `steps` instrumented steps -> rows sorted by time"""
-    models = call_models(sz, n_params)
+# kernels that are one operation of the pass (the numbers VERDICT r04 tracks): summed rows "group:<name>" in per_kernel
+KERNEL_GROUPS = {
+    "brdf_mlp_backward": ("k_brdf_mlp_bwd", "k_brdf_mlp_reduce"),
+    "brick_sort": ("k_plan_hist", "k_bins_scan", "k_place_records<false>", "k_place_records<true>", "k_bins_partial", "k_bins_final",
+                   "k_plan_place", "k_brick_records<false>", "k_brick_records<true>"),
+    "env_adjoint": ("k_env_bin_count<1>", "k_env_bin_scatter<1>", "k_env_bin_accum<1>", "k_env_lookup_bwd<1>"),
+    "field_walks": ("k_vm_bwd_density<false>", "k_vm_bwd_density<true>", "k_vm_bwd_brick<false, 1>", "k_vm_bwd_brick<false, 2>",
+                    "k_vm_bwd_brick<true, 2>"),
+    "marcher": ("k_march_count16", "k_march_fill16", "k_march_count", "k_march_fill", "k_scan_fused", "k_scan_partial"),
+}
+
+
+def issued_beside(name, sz):
+    """what a kernel issues next to what it usefully computes (per step)"""
+    R = sz["R0"] + sz["R1"]
+    if name == "k_brdf_mlp_bwd":
+        return dict(issued_bf16_flop=MLP_BWD_ISSUED_FLOP * R, issued_peak=BF16_PEAK)
+    if name == "k_brdf_mlp_fwd":
+        return dict(issued_bf16_flop=MLP_FWD_ISSUED_FLOP * R, issued_peak=BF16_PEAK)
+    return None
+
+
+# rocprofv3 prints template kernels as "void k_name<args>(...)"; the counter files of tools/roofline_metrics.py key them without
+# the template arguments except for the two walks
+def counter_key(name):
+    if name == "k_vm_bwd_density<false>":
+        return "k_vm_bwd_density<value>"
+    if name == "k_vm_bwd_density<true>":
+        return "k_vm_bwd_density<normal>"
+    if name.startswith("k_vm_bwd_brick<false, 1>"):
+        return "k_vm_bwd_brick<appearance>"
+    return name.split("<")[0]
+
+
+def per_kernel_table(timing, steps, sz, n_params, counters):
+    """timing: {kernel: (ms, launches)} over `steps` instrumented steps (keys starting with '@' are per-stream sums) -> rows sorted
+    by time"""
+    models = kernel_models(sz, n_params)
     ks = (counters or {}).get("kernels", {})
-    ctr_of = {"brdf_mlp_bwd": "k_brdf_mlp_bwd", "brdf_mlp_fwd": "k_brdf_mlp_fwd", "sat_lookup_bwd": "k_env_lookup_bwd",
-              "sat_lookup_fwd": "k_env_lookup_fwd", "march_count": "k_march_count16", "march_fill": "k_march_fill16",
-              "adam_step": "k_adam", "vm_query_sigma": "k_vm_sigma", "vm_query_fwd": "k_vm_fwd"}
     rows = {}
-    for name, (ms, calls) in sorted(timing.items(), key=lambda kv: -kv[1][0]):
+    timing = dict(timing)
+    for gname, members in KERNEL_GROUPS.items():
+        got = [timing[k] for k in members if k in timing]
+        if got:
+            timing["group:" + gname] = (sum(g[0] for g in got), sum(g[1] for g in got))
+    for name, (ms, calls) in sorted(((k, v) for k, v in timing.items() if not k.startswith("@")), key=lambda kv: -kv[1][0]):
         us = 1e3 * ms / steps
-        bound, work, peak = models.get(name, ("latency", None, None))
-        rec = {"us_per_step": round(us, 1), "calls_per_step": round(calls / steps, 2), "bound": bound}
+        bound, work, peak, unit = models.get(name, ("latency", None, None, None))
+        rec = {"us_per_step": round(us, 1), "launches_per_step": round(calls / steps, 2), "bound": bound}
         if work is not None and us > 0:
+            rec["useful_per_step"] = work
             rec["achieved"] = work / (us * 1e-6)
+            rec["peak"] = peak
+            rec["unit_base"] = unit
             rec["frac"] = round(rec["achieved"] / peak, 4)
+            extra = issued_beside(name, sz)
+            if extra:
+                rec["issued_bf16_frac"] = round(extra["issued_bf16_flop"] / (us * 1e-6) / extra["issued_peak"], 4)
         else:
             rec["frac"] = None
-        d = ks.get(ctr_of.get(name, ""), {}).get("derived")
+        d = ks.get(counter_key(name), {}).get("derived") or ks.get(name, {}).get("derived")
         if d:
             rec["counters"] = {k: d[k] for k in ("alu_busy", "mfma_busy", "hbm_frac", "l2_frac", "waves_per_simd") if k in d}
         rows[name] = rec
@@ -663,24 +716,24 @@ def main():
     noise = DeviceNoise(device, seed=1000 + rank)
     batches, focal = make_batches(nerf, args.warmup + args.steps, args.rays_per_gpu, rank, device)
     fx = hip_mod.HOST_EXT
-    timed_calls = fx is not None and hasattr(fx, "call_timing_begin") and trainer.fast is not None and trainer.fast.core() is not None
+    timed_calls = fx is not None and hasattr(fx, "kernel_timing_begin") and trainer.fast is not None and trainer.fast.core() is not None
     n_probe = min(args.warmup, 8) if timed_calls else 0
     timer.enabled = False
     dominant = None
     for i in range(args.warmup):
         if n_probe and i == args.warmup - n_probe:
-            fx.call_timing_begin()                  # the last warm-up steps find the dominant call of this workload
+            fx.kernel_timing_begin()                # the last warm-up steps find the dominant KERNEL of this workload
         trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
                          next_rays=batches[(i + 1) % len(batches)][0])
     if n_probe:
-        probe = fx.call_timing_end()
+        probe = {k: v for k, v in fx.kernel_timing_end().items() if not k.startswith("@")}
         dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
     sync()
     timer.enabled = True
     if dominant:
-        fx.call_timing_begin(dominant)              # inside the timed region: events around the dominant call only
+        fx.kernel_timing_begin(dominant)            # inside the timed region: events around the launches of the dominant kernel only
     dt, rays_done, last, comm_ms = time_train(trainer, batches, focal, noise, 0, args.steps, chunk_rays, sync)
-    dom_live = fx.call_timing_end().get(dominant) if dominant else None
+    dom_live = fx.kernel_timing_end().get(dominant) if dominant else None
     timer.enabled = False
 
     tt = torch.tensor([dt, float(rays_done), 1.0], dtype=torch.float64, device=device)
@@ -695,75 +748,71 @@ def main():
     chunks_per_step = -(-args.rays_per_gpu // chunk_rays)
     if min(timer.rebuilds.values()) < args.steps:
         raise SystemExit(f"derived tables were not rebuilt every step: {timer.rebuilds} for {args.steps} steps")
-    # ---- after the timed region: every C-ABI call of the step timed (events on the launching stream), 30 more steps
+    # ---- after the timed region: every kernel launch of the step timed (events on the launching stream), 30 more steps
     table, sizes, n_params = None, None, sum(p.numel() for p in nerf.parameters() if p.requires_grad)
+    main_stream_us = None
     if timed_calls:                       # (every rank: the steps contain the gradient all-reduce)
         n_inst = 30
-        fx.call_timing_begin()
+        main_id = torch.cuda.current_stream().cuda_stream
+        fx.kernel_timing_begin()
         for i in range(n_inst):
             trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
                          next_rays=batches[(i + 1) % len(batches)][0])
-        timing = fx.call_timing_end()
+        timing = fx.kernel_timing_end()
+        if f"@{main_id}" in timing:
+            main_stream_us = 1e3 * timing[f"@{main_id}"][0] / n_inst
         ls = trainer.fast.last_sizes
         sizes = dict(B=int(ls["rays"]), M0=int(ls["n_samples"][0]), M1=int(ls["n_samples"][1]) if len(ls["n_samples"]) > 1 else 0,
                      R0=int(ls["n_rays"][0]), R1=int(ls["n_rays"][1]) if len(ls["n_rays"]) > 1 else 0,
                      Mb0=int(ls["n_rows"][0]), Mb1=int(ls["n_rows"][1]) if len(ls["n_rows"]) > 1 else 0, N=int(nerf.sampler.nSamples))
-        table = per_call_table(timing, n_inst * chunks_per_step, sizes, n_params, counters_summary()) if rank == 0 else None
+        # (sizes are those of ONE chunk; the table is per chunk when a step has several)
+        table = per_kernel_table(timing, n_inst * chunks_per_step, sizes, n_params, counters_summary()) if rank == 0 else None
     if rank == 0:
         ctr = counters_summary()
         ctr_meta = {k: ctr.get(k) for k in ("tag", "commit", "command")} if ctr else None
-        roof = {"note": "the host extension with call timing is not available: no per-call table"}
+        roof = {"note": "the host extension with kernel timing is not available: no per-kernel table"}
         if table:
-            dname = dominant if dominant in table else next(iter(table))
+            dname = dominant if dominant in table else next(k_ for k_ in table if not k_.startswith("group:"))
             drow = table[dname]
-            models = call_models(sizes, n_params)
-            bound, work, peak = models.get(dname, ("latency", None, None))
+            models = kernel_models(sizes, n_params)
+            bound, work, peak, unit = models.get(dname, ("latency", None, None, None))
             live_us = 1e3 * dom_live[0] / max(dom_live[1], 1) if dom_live else None          # per launch, inside the timed region
-            calls_per_step = dom_live[1] / args.steps if dom_live else drow["calls_per_step"]
-            achieved = (work / calls_per_step) / (live_us * 1e-6) if (work and live_us) else None
-            unit = {"mfma": "TFLOP/s", "hbm": "GB/s", "atomics": "G lane-atomics/s"}.get(bound, "")
-            scale = {"mfma": 1e12, "hbm": 1e9, "atomics": 1e9}.get(bound, 1.0)
+            launches_per_chunk = dom_live[1] / (args.steps * chunks_per_step) if dom_live else drow["launches_per_step"]
+            # achieved = useful work of one launch / that launch's duration (launches of different sizes: work and time are both
+            # summed over the launches of a chunk, i.e. work per chunk / (launches per chunk x average launch duration))
+            achieved = work / (launches_per_chunk * live_us * 1e-6) if (work and live_us) else None
+            scale = {"TFLOP/s": 1e12, "GB/s": 1e9, "G updates/s": 1e9, "T lane-ops/s": 1e12}.get(unit, 1.0)
             survey_b, needed_b = step_bytes(sizes, args.grid, n_params)
             ms_step = 1e3 * dt_max / args.steps
-            fabric = None
-            if ctr:
-                fabric = sum(v.get("hbm_bytes_per_launch", 0) * table.get(k2, {}).get("calls_per_step", 0)
-                             for k2, v in ((kk, ctr["kernels"].get(ck, {})) for kk, ck in
-                                           (("brdf_mlp_bwd", "k_brdf_mlp_bwd"), ("sat_lookup_bwd", "k_env_lookup_bwd"),
-                                            ("vm_query_bwd_segments", "k_vm_bwd_density<value>"), ("adam_step", "k_adam"))))
+            ck = (ctr or {}).get("kernels", {}).get(counter_key(dname), {}) if ctr else {}
+            extra = issued_beside(dname, sizes)
+            dev_sum = round(sum(r["us_per_step"] for k_, r in table.items() if not k_.startswith("group:")), 1)
             roof = {
-                # the dominant C-ABI call of the step by summed device time, found in the warm-up and timed with HIP events on its
-                # launching stream INSIDE the timed region
-                "kernel": "nmf_" + dname, "bound": "mfma" if bound == "mfma" else ("hbm" if bound in ("hbm", "atomics") else bound),
-                "bound_detail": (bound if dname != "vm_query_bwd_segments" else
-                                 "algorithmic bytes of SURVEY 8(d) against HBM as the contract prescribes; the tables are cache resident "
-                                 "(traffic << algorithmic bytes, frac may exceed 1), the kernel's own ceiling is VALU issue: secondary.alu_busy"),
+                # the dominant KERNEL of the step by summed device time, found in the warm-up and timed with HIP events on its
+                # launching stream INSIDE the timed region; frac = useful work / duration / peak (kernel_models())
+                "kernel": dname, "bound": "mfma" if bound == "mfma" else ("hbm" if bound in ("hbm", "atomics") else bound),
+                "bound_detail": {"mfma": "useful fp32 FLOP on the matrix cores against the 157.3 TFLOP/s fp32-input MFMA peak (= the fp32 vector peak)",
+                                 "valu": "useful fp32 FLOP / lane operations against the VALU peak", "hbm": "compulsory bytes against 8 TB/s",
+                                 "atomics": "table updates against the rate of the memory-side atomic units"}.get(bound, bound),
                 "achieved": achieved / scale if achieved else None, "peak": peak / scale if peak else None,
                 "unit": unit, "frac": (achieved / peak) if (achieved and peak) else None,
-                "secondary": ({"alu_busy_counters": (ctr or {}).get("kernels", {}).get("k_vm_bwd_density<value>", {}).get("derived", {}).get("alu_busy"),
-                               "issued_mfma_tflops": (_WALK_FLOP / calls_per_step) / (live_us * 1e-6) / 1e12 if live_us else None,
-                               "issued_mfma_frac_of_157.3": (_WALK_FLOP / calls_per_step) / (live_us * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12) if live_us else None,
-                               "survey_dense_bytes_frac": (14400.0 * (sizes["M0"] + sizes["M1"]) / calls_per_step) / (live_us * 1e-6) / (HBM_PEAK_GBS * 1e9) if live_us else None}
-                              if dname == "vm_query_bwd_segments" else None),
-                "traffic": (ctr or {}).get("kernels", {}).get(
-                    {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd",
-                     "sat_lookup_bwd": "k_env_lookup_bwd"}.get(dname, "k_" + dname), {}).get("hbm_bytes_per_launch") if ctr else None,
-                "alu_busy_counters": (ctr or {}).get("kernels", {}).get(
-                    {"vm_query_bwd_segments": "k_vm_bwd_density<value>", "brdf_mlp_bwd": "k_brdf_mlp_bwd"}.get(dname, ""), {}).get(
-                        "derived", {}).get("alu_busy") if ctr else None,
+                "issued_bf16_frac": (extra["issued_bf16_flop"] / (launches_per_chunk * live_us * 1e-6) / extra["issued_peak"]) if (extra and live_us) else None,
+                "traffic": ck.get("hbm_bytes_per_launch"),
+                "counters_of_kernel": {k: ck.get("derived", {}).get(k) for k in ("alu_busy", "mfma_busy", "waves_per_simd", "hbm_frac", "l2_frac")} if ck else None,
                 "launches": dom_live[1] if dom_live else None, "avg_launch_us": live_us,
-                "work_per_step": work, "work_model": "186 v_mfma_f32_32x32x16_bf16 per 32 rays (split-bf16 products, csrc/brdf_mlp.hip) against the dense bf16 peak; "
-                                                "SURVEY 8d's algorithmic figure is 2 x 17 152 FLOP per secondary ray"
-                if dname == "brdf_mlp_bwd" else "see call_models() in bench.py",
+                "useful_work_per_chunk": work,
+                "work_model": "kernel_models() in bench.py / DESIGN.md section 0.R5: SURVEY 8(d)'s FLOP per unit x the units of `sizes_per_step`",
                 "per_kernel": table, "sizes_per_step": sizes,
-                "step": {"survey_8d_bytes": survey_b, "algorithmic_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                         "needed_bytes": needed_b, "needed_over_hbm": needed_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                         "needed_over_l2": needed_b / (ms_step * 1e-3) / (L2_PEAK_GBS * 1e9),
-                         "fabric_bytes_counters_partial": fabric,
-                         "device_time_sum_us": round(sum(r["us_per_step"] for r in table.values()), 1), "wall_us": round(1e3 * ms_step, 1),
-                         "note": "tables (7.5 MB at 128^3) are L2 / MALL resident: the byte models do not bound the step.  Half of the step is "
-                                 "the forward, a dependent chain of ~50 kernels whose own latency (not the 2.3 us between launches) adds "
-                                 "up; the backward runs up to four streams side by side and is bound by the sum of its work (DESIGN 0)"},
+                "step": {"wall_us": round(1e3 * ms_step, 1), "main_stream_kernel_us": round(main_stream_us, 1) if main_stream_us else None,
+                         # the main stream carries the dependency chain of the step (side streams only ever run next to it): the share
+                         # of the wall time in which a kernel of the chain is executing
+                         "critical_path_frac": round(main_stream_us / (1e3 * ms_step), 4) if main_stream_us else None,
+                         "device_time_sum_us": dev_sum,
+                         "survey_8d_bytes": survey_b, "survey_8d_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         "needed_bytes": needed_b, "needed_over_l2": needed_b / (ms_step * 1e-3) / (L2_PEAK_GBS * 1e9),
+                         "note": "survey_8d_over_hbm is SURVEY 8(d)'s byte model kept for the record: the tables (7.5 MB at 128^3) are L2 / MALL "
+                                 "resident and it exceeds 1, so it bounds nothing.  The step is a dependent chain of ~75 launches on the main "
+                                 "stream with side streams next to it in the backward (DESIGN 0)"},
                 "counters": ctr_meta,
             }
         out = {
@@ -786,7 +835,7 @@ def main():
                        "backend": backend if (world > 1 or single_rank_comm) else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"],
                        "host_cpu_ms_per_step": last.get("host_cpu_ms_per_step"),
-                       "host_pass": "C++ (csrc/step_core.inc)" if timed_calls else "python (nmf_amd/fast_step.py)"},
+                       "host_pass": "C++ (csrc/step_core.inc)" if (trainer.fast is not None and trainer.fast.core() is not None) else "python"},
             "roofline": roof,
         }
         if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID and args.budget_scale == 1 \

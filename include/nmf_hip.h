@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 112
+#define NMF_ABI_VERSION 113
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -61,6 +61,11 @@ int nmf_publish_i64x2(const int64_t* src_dev, void* dst_mapped_dev, int64_t seq,
 int nmf_wait_seq(const void* host_ptr, int64_t seq, double timeout_s);
 int nmf_stream_wait_event(void* stream, void* event);
 int nmf_memcpy_d2h_async(void* dst_host, const void* src_dev, int64_t nbytes, void* stream);
+/* Launch probe (measurement plumbing: bench.py's per-kernel HIP-event timing on the launching stream): when set, EVERY kernel launch
+ * of the library calls probe(kernel_name, stream, 0) in front of and probe(kernel_name, stream, 1) behind the launch, on the calling
+ * thread.  kernel_name is the kernel's identifier as rocprofv3 --kernel-trace prints it (without arguments).  NULL removes it. */
+typedef void (*nmf_launch_probe_fn)(const char* kernel_name, void* stream, int phase);
+int nmf_set_launch_probe(void (*probe)(const char* kernel_name, void* stream, int phase));
 
 /* ------------------------------------------------------------------------------------------
  * Sampler: AlphaGridSampler.sample / sample_ray / AlphaGridMask.sample_alpha

@@ -154,7 +154,7 @@ extern "C" int nmf_multi_copy(const nmf_copy_slot* slots, int32_t n_slots, void*
         if (biggest == 0) continue;
         int64_t bx = cdiv(biggest, 256 * 4);
         bx = bx > 1024 ? 1024 : (bx < 1 ? 1 : bx);
-        hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        NMF_LAUNCH(k_multi_copy, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
         NMF_CHECK_LAUNCH("k_multi_copy");
     }
     return NMF_OK;
@@ -186,7 +186,7 @@ extern "C" int nmf_adam_step_guarded(const nmf_adam_slot* slots, int32_t n_slots
         int64_t bx = cdiv(biggest, 256 * 4);
         if (bx > 1024) bx = 1024;
         if (bx < 1) bx = 1;
-        hipLaunchKernelGGL(k_adam, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b, guard);
+        NMF_LAUNCH(k_adam, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b, guard);
         NMF_CHECK_LAUNCH("k_adam");
     }
     return NMF_OK;

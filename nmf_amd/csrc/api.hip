@@ -9,6 +9,12 @@ extern "C" int nmf_version(void) { return NMF_ABI_VERSION; }
 
 extern "C" const char* nmf_last_error_string(void) { return nmf_err_buf; }
 
+nmf_launch_probe_fn nmf_launch_probe = nullptr;
+extern "C" int nmf_set_launch_probe(nmf_launch_probe_fn probe) {
+    nmf_launch_probe = probe;
+    return NMF_OK;
+}
+
 // ---- runtime plumbing for host-side drivers that do not include the HIP headers (csrc/host_ext.cpp is plain g++) -------
 extern "C" int nmf_event_create(void** event) {
     NMF_REQUIRE(event, NMF_EINVAL, "nmf_event_create: null");
@@ -84,7 +90,7 @@ extern "C" int nmf_host_free_mapped(void* host_ptr) {
 }
 extern "C" int nmf_publish_i64x2(const int64_t* src_dev, void* dst_mapped_dev, int64_t seq, void* stream) {
     NMF_REQUIRE(src_dev && dst_mapped_dev, NMF_EINVAL, "nmf_publish_i64x2: args");
-    hipLaunchKernelGGL(k_publish_i64x2, dim3(1), dim3(1), 0, (hipStream_t)stream, src_dev, (volatile int64_t*)dst_mapped_dev, seq);
+    NMF_LAUNCH(k_publish_i64x2, dim3(1), dim3(1), 0, (hipStream_t)stream, src_dev, (volatile int64_t*)dst_mapped_dev, seq);
     NMF_CHECK_LAUNCH("nmf_publish_i64x2");
     return NMF_OK;
 }
@@ -96,12 +102,12 @@ extern "C" int nmf_wait_seq(const void* host_ptr, int64_t seq, double timeout_s)
         if (__atomic_load_n(p + 2, __ATOMIC_ACQUIRE) == seq) return NMF_OK;
         if ((spin & 0xfff) == 0xfff &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-            // slow is not lost (a counter-collecting profiler serialises kernels, a shared GPU, code objects still loading):
-            // wait for the device to drain, which also reports a device that is gone, then look once more
-            const hipError_t r = hipDeviceSynchronize();
-            if (r != hipSuccess) return nmf_fail((int)r, "nmf_wait_seq: hipDeviceSynchronize after the spin timed out");
-            if (__atomic_load_n(p + 2, __ATOMIC_ACQUIRE) == seq) return NMF_OK;
-            return nmf_fail(NMF_EINVAL, "nmf_wait_seq: the device is idle and the sequence number never arrived");
+            // slow is not lost (a counter-collecting profiler serialises kernels, a shared GPU, code objects still loading): keep
+            // looking under a second, longer deadline -- never a call that may not return (a device synchronisation on a wedged
+            // queue would hang here for good, and on the wrong device if the caller's current device is not the buffer's)
+            const double hard = timeout_s < 30.0 ? 300.0 : 10.0 * timeout_s;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > hard)
+                return nmf_fail(NMF_EINVAL, "nmf_wait_seq: the sequence number never arrived (soft and hard deadline passed)");
         }
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();

@@ -48,10 +48,10 @@ extern "C" int nmf_segment_sum_wide(const float* vals, int64_t row_stride, int32
     NMF_REQUIRE(vals && offsets && out && D > 0 && D <= 64 && row_stride >= D, NMF_EINVAL, "nmf_segment_sum_wide: args");
     const dim3 grid((unsigned)cdiv(n_seg, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 8) hipLaunchKernelGGL(k_segment_sum_wide<8>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
-    else if (D <= 16) hipLaunchKernelGGL(k_segment_sum_wide<16>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
-    else if (D <= 32) hipLaunchKernelGGL(k_segment_sum_wide<32>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
-    else hipLaunchKernelGGL(k_segment_sum_wide<64>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    if (D <= 8) NMF_LAUNCH(k_segment_sum_wide<8>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else if (D <= 16) NMF_LAUNCH(k_segment_sum_wide<16>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else if (D <= 32) NMF_LAUNCH(k_segment_sum_wide<32>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
+    else NMF_LAUNCH(k_segment_sum_wide<64>, grid, block, 0, st, vals, row_stride, D, offsets, n_seg, out);
     NMF_CHECK_LAUNCH("nmf_segment_sum_wide");
     return NMF_OK;
 }

@@ -975,7 +975,7 @@ static int mlp_fwd_impl(const MlpW& w, const void* image, const float* half_vec,
     int64_t cap = 256;                                  // one workgroup per CU (127 KB of LDS)
     if (max_workgroups > 0 && max_workgroups < cap) cap = max_workgroups;
     const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
-    hipLaunchKernelGGL(k_brdf_mlp_fwd, dim3(grid), dim3(64 * FWD_WAVES), FWD_LDS, (hipStream_t)stream, w, half_vec,
+    NMF_LAUNCH(k_brdf_mlp_fwd, dim3(grid), dim3(64 * FWD_WAVES), FWD_LDS, (hipStream_t)stream, w, half_vec,
                        diff_vec, feat_src, rough_src, src_idx, R, out_bias, out, reinterpret_cast<uint4*>(act_mask),
                        static_cast<const uint4*>(image));
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_fwd");
@@ -1005,7 +1005,7 @@ extern "C" int nmf_brdf_mlp_pack(const float* W0, const float* b0, const float* 
     constexpr int lds_bytes = FWD_SHARED > BWD_SHARED ? FWD_SHARED : BWD_SHARED;
     static const int lds = set_lds_once((const void*)k_brdf_mlp_pack, lds_bytes, "nmf_brdf_mlp_pack: hipFuncSetAttribute");
     if (lds != NMF_OK) return lds;
-    hipLaunchKernelGGL(k_brdf_mlp_pack, dim3(2), dim3(256), lds_bytes, (hipStream_t)stream, MlpW{W0, b0, W2, b2, W4, b4},
+    NMF_LAUNCH(k_brdf_mlp_pack, dim3(2), dim3(256), lds_bytes, (hipStream_t)stream, MlpW{W0, b0, W2, b2, W4, b4},
                        static_cast<uint4*>(image));
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_pack");
     return NMF_OK;
@@ -1067,11 +1067,11 @@ static int mlp_bwd_launch(const MlpW& w, const void* image, const nmf_mlp_bwd_se
     static const int lds = set_lds_once((const void*)k_brdf_mlp_bwd, BWD_LDS, "nmf_brdf_mlp_bwd: hipFuncSetAttribute");
     if (lds != NMF_OK) return lds;
     float* partials = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, G, partials,
+    NMF_LAUNCH(k_brdf_mlp_bwd, dim3(grid), dim3(64 * BWD_WAVES), BWD_LDS, (hipStream_t)stream, w, G, partials,
                        static_cast<const uint4*>(image));
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd");
     static_assert((N_PERSIST * 64) % 32 == 0, "k_brdf_mlp_reduce takes 32 elements per workgroup");
-    hipLaunchKernelGGL(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
+    NMF_LAUNCH(k_brdf_mlp_reduce, dim3(N_PERSIST * 64 / 32), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, gW0,
                        gb0, gW2, gb2, gW4, gb4);
     NMF_CHECK_LAUNCH("nmf_brdf_mlp_bwd (reduce)");
     return NMF_OK;

@@ -31,6 +31,19 @@ static inline int nmf_fail(int code, const char* what) {
         }                                                                 \
     } while (0)
 
+// Every kernel of the library is launched through this: with a probe installed (nmf_set_launch_probe) the launch is bracketed by
+// calls the measuring host turns into HIP events on the launching stream; without one it is two pointer tests.
+extern nmf_launch_probe_fn nmf_launch_probe;
+#define NMF_LAUNCH_NAMED(name, kernel, grid, block, lds, stream, ...)                       \
+    do {                                                                                    \
+        nmf_launch_probe_fn probe_ = nmf_launch_probe;                                      \
+        const char* name_ = (name);                                                         \
+        if (probe_) probe_(name_, (void*)(stream), 0);                                      \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                  \
+        if (probe_) probe_(name_, (void*)(stream), 1);                                      \
+    } while (0)
+#define NMF_LAUNCH(kernel, grid, block, lds, stream, ...) NMF_LAUNCH_NAMED(#kernel, kernel, grid, block, lds, stream, __VA_ARGS__)
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Non-contracted fp32 arithmetic: bookkeeping that must be bit-exact against the CPU oracle

@@ -258,13 +258,13 @@ extern "C" int nmf_composite_fwd(const float* sigma, const float* dist, const in
     if (b == 0) return NMF_OK;
     NMF_REQUIRE(sigma && dist && offsets && weight, NMF_EINVAL, "nmf_composite_fwd: null");
     if (b <= WPR_MAX_RAYS)
-        hipLaunchKernelGGL(k_composite_fwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_fwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, offsets, b, distance_scale, weight, acc);
     else if (group_width(8) == 16)
-        hipLaunchKernelGGL(k_composite_fwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_fwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, offsets, b, distance_scale, weight, acc);
     else
-        hipLaunchKernelGGL(k_composite_fwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_fwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, offsets, b, distance_scale, weight, acc);
     NMF_CHECK_LAUNCH("nmf_composite_fwd");
     return NMF_OK;
@@ -279,13 +279,13 @@ extern "C" int nmf_composite_bwd(const float* sigma, const float* dist, const fl
     // NMF_COMPOSITE_ONE_CHUNK=0 (tests): every ray through the chunk loops -- the one-chunk path must give the same bits
     static const int one_chunk = !(getenv("NMF_COMPOSITE_ONE_CHUNK") && atoi(getenv("NMF_COMPOSITE_ONE_CHUNK")) == 0);
     if (b <= WPR_MAX_RAYS)
-        hipLaunchKernelGGL(k_composite_bwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_bwd_wave<64>, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     else if (group_width(16) == 16)
-        hipLaunchKernelGGL(k_composite_bwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_bwd_wave<16>, dim3((unsigned)cdiv(b, 16)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     else
-        hipLaunchKernelGGL(k_composite_bwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
+        NMF_LAUNCH(k_composite_bwd_wave<8>, dim3((unsigned)cdiv(b, 32)), dim3(256), 0, (hipStream_t)stream, sigma,
                            dist, weight, offsets, b, distance_scale, d_weight, d_sigma, one_chunk);
     NMF_CHECK_LAUNCH("nmf_composite_bwd");
     return NMF_OK;
@@ -301,10 +301,10 @@ extern "C" int nmf_segment_sum(const float* vals, const float* scale, const int6
     if (lanes == 8) {
         dim3 grid((unsigned)cdiv(n_seg, 32)), block(256);
         switch (D) {
-            case 1: hipLaunchKernelGGL((k_segment_sum_group<1, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-            case 2: hipLaunchKernelGGL((k_segment_sum_group<2, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-            case 3: hipLaunchKernelGGL((k_segment_sum_group<3, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-            case 4: hipLaunchKernelGGL((k_segment_sum_group<4, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+            case 1: NMF_LAUNCH((k_segment_sum_group<1, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+            case 2: NMF_LAUNCH((k_segment_sum_group<2, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+            case 3: NMF_LAUNCH((k_segment_sum_group<3, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+            case 4: NMF_LAUNCH((k_segment_sum_group<4, 8>), grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
             default: return nmf_fail(NMF_ERANGE, "nmf_segment_sum: D must be 1..4");
         }
         NMF_CHECK_LAUNCH("nmf_segment_sum");
@@ -312,10 +312,10 @@ extern "C" int nmf_segment_sum(const float* vals, const float* scale, const int6
     }
     dim3 grid((unsigned)cdiv(n_seg, 256)), block(256);
     switch (D) {
-        case 1: hipLaunchKernelGGL(k_segment_sum<1>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-        case 2: hipLaunchKernelGGL(k_segment_sum<2>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-        case 3: hipLaunchKernelGGL(k_segment_sum<3>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
-        case 4: hipLaunchKernelGGL(k_segment_sum<4>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+        case 1: NMF_LAUNCH(k_segment_sum<1>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+        case 2: NMF_LAUNCH(k_segment_sum<2>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+        case 3: NMF_LAUNCH(k_segment_sum<3>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
+        case 4: NMF_LAUNCH(k_segment_sum<4>, grid, block, 0, st, vals, scale, offsets, n_seg, out); break;
         default: return nmf_fail(NMF_ERANGE, "nmf_segment_sum: D must be 1..4");
     }
     NMF_CHECK_LAUNCH("nmf_segment_sum");

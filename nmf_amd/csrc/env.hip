@@ -1079,10 +1079,10 @@ extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float br
                              void* stream) {
     NMF_REQUIRE(bg_mat && activated && sat && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build: null/size");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sat_cols, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
+    NMF_LAUNCH(k_sat_cols, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, bg_mat, H, W, brightness, mul,
                        scalars_dev, activated, sat);
-    hipLaunchKernelGGL(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W, sat_i4);
-    if (pole_rows) hipLaunchKernelGGL(k_pole_rows, dim3(6), dim3(64), 0, st, activated, H, W, pole_rows);
+    NMF_LAUNCH(k_sat_rows, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, sat, H, W, sat_i4);
+    if (pole_rows) NMF_LAUNCH(k_pole_rows, dim3(6), dim3(64), 0, st, activated, H, W, pole_rows);
     NMF_CHECK_LAUNCH("nmf_sat_build");
     return NMF_OK;
 }
@@ -1090,7 +1090,7 @@ extern "C" int nmf_sat_build(const float* bg_mat, int32_t H, int32_t W, float br
 extern "C" int nmf_sh_project(const float* vals, const float* wq, int64_t n, int32_t K, const float* sh_A, float* coeffs,
                               float* conv, void* stream) {
     NMF_REQUIRE(vals && wq && coeffs && n > 0 && K > 0 && K <= 64 && (!conv || sh_A), NMF_EINVAL, "nmf_sh_project: args");
-    hipLaunchKernelGGL(k_sh_project, dim3((unsigned)(3 * K)), dim3(256), 0, (hipStream_t)stream, vals, wq, n, (int)K, sh_A,
+    NMF_LAUNCH(k_sh_project, dim3((unsigned)(3 * K)), dim3(256), 0, (hipStream_t)stream, vals, wq, n, (int)K, sh_A,
                        coeffs, conv);
     NMF_CHECK_LAUNCH("nmf_sh_project");
     return NMF_OK;
@@ -1101,8 +1101,8 @@ extern "C" int nmf_sat_build_bwd(float* d_sat, const float* bg_mat, const float*
                                  void* stream) {
     NMF_REQUIRE(d_sat && bg_mat && activated && d_bg && H > 1 && W > 1, NMF_EINVAL, "nmf_sat_build_bwd: null/size");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sat_rows_rev, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, d_sat, H, W);
-    hipLaunchKernelGGL(k_sat_cols_rev, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, d_sat, bg_mat, activated, H,
+    NMF_LAUNCH(k_sat_rows_rev, dim3((unsigned)cdiv(3 * H, 4)), dim3(256), 0, st, d_sat, H, W);
+    NMF_LAUNCH(k_sat_cols_rev, dim3((unsigned)cdiv(3 * W, 4)), dim3(256), 0, st, d_sat, bg_mat, activated, H,
                        W, brightness, mul, scalars_dev, d_pole, d_bg);
     NMF_CHECK_LAUNCH("nmf_sat_build_bwd");
     return NMF_OK;
@@ -1117,10 +1117,10 @@ extern "C" int nmf_sat_lookup_fwd(const float* sat, int32_t H, int32_t W, const 
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_fwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W, layout == 1};
     if (layout == 1)
-        hipLaunchKernelGGL(k_env_lookup_fwd<1>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
+        NMF_LAUNCH(k_env_lookup_fwd<1>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
                            (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     else
-        hipLaunchKernelGGL(k_env_lookup_fwd<0>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
+        NMF_LAUNCH(k_env_lookup_fwd<0>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, tab, dirs,
                            (int)dirs_ld, sa, R, mipbias, scalars_dev, pole_rows, out);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_fwd");
     return NMF_OK;
@@ -1168,13 +1168,13 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = nb - d1 - d2;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
     if (layout == 1) {
-        hipLaunchKernelGGL(k_env_bin_count<1>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
-        hipLaunchKernelGGL(k_env_bin_scatter<1>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
-        hipLaunchKernelGGL(k_env_bin_accum<1>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+        NMF_LAUNCH(k_env_bin_count<1>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
+        NMF_LAUNCH(k_env_bin_scatter<1>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
+        NMF_LAUNCH(k_env_bin_accum<1>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
     } else {
-        hipLaunchKernelGGL(k_env_bin_count<0>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
-        hipLaunchKernelGGL(k_env_bin_scatter<0>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
-        hipLaunchKernelGGL(k_env_bin_accum<0>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
+        NMF_LAUNCH(k_env_bin_count<0>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
+        NMF_LAUNCH(k_env_bin_scatter<0>, dim3((unsigned)(nb + d2)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d2, d1);
+        NMF_LAUNCH(k_env_bin_accum<0>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
     }
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd_binned");
     return NMF_OK;
@@ -1190,11 +1190,11 @@ extern "C" int nmf_sat_lookup_bwd(const float* sat, int32_t H, int32_t W, const 
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd: dirs_ld must be 3 or 6");
     EnvTab tab{sat, H, W, layout == 1};
     if (layout == 1)
-        hipLaunchKernelGGL(k_env_lookup_bwd<1>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
+        NMF_LAUNCH(k_env_lookup_bwd<1>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
                            (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
                            d_dirs, d_mipbias);
     else
-        hipLaunchKernelGGL(k_env_lookup_bwd<0>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
+        NMF_LAUNCH(k_env_lookup_bwd<0>, dim3((unsigned)(9 * cdiv(R, ENV_BWD_THREADS))), dim3(ENV_BWD_THREADS), 0,
                            (hipStream_t)stream, tab, dirs, (int)dirs_ld, sa, R, mipbias, scalars_dev, d_out, d_sat, d_pole,
                            d_dirs, d_mipbias);
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd");

@@ -274,7 +274,7 @@ extern "C" int nmf_ggx_rays_fwd(const float* V_rows, const float* N_rows, const 
     NMF_REQUIRE(V_rows && N_rows && r_rows && x_rows && off_rows && cnt_rows && sobol && row_of_ray && j_of_ray && L &&
                     half_local && diff_local && lpdf && mipval && rays,
                 NMF_EINVAL, "nmf_ggx_rays_fwd: null");
-    hipLaunchKernelGGL(k_ggx_rays_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+    NMF_LAUNCH(k_ggx_rays_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
                        mk_rows(V_rows, N_rows, r_rows, x_rows, off_rows, cnt_rows), sobol, row_of_ray, j_of_ray, R, L,
                        half_local, diff_local, lpdf, mipval, rays);
     NMF_CHECK_LAUNCH("nmf_ggx_rays_fwd");
@@ -296,7 +296,7 @@ extern "C" int nmf_ggx_prob(const float* dir_in_local, const float* dir_out_loca
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_ggx_prob: R < 0");
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(dir_in_local && dir_out_local && half_local && rough && prob, NMF_EINVAL, "nmf_ggx_prob: null");
-    hipLaunchKernelGGL(k_ggx_prob, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, dir_in_local,
+    NMF_LAUNCH(k_ggx_prob, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, dir_in_local,
                        dir_out_local, half_local, rough, R, prob);
     NMF_CHECK_LAUNCH("nmf_ggx_prob");
     return NMF_OK;
@@ -309,7 +309,7 @@ extern "C" int nmf_ggx_rays_bwd(const float* V_rows, const float* N_rows, const 
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && d_nr, NMF_EINVAL,
                 "nmf_ggx_rays_bwd: null");
-    hipLaunchKernelGGL(k_ggx_rays_bwd<4>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+    NMF_LAUNCH(k_ggx_rays_bwd<4>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
                        mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL, d_rays,
                        d_nr);
     NMF_CHECK_LAUNCH("nmf_ggx_rays_bwd");
@@ -323,7 +323,7 @@ extern "C" int nmf_ggx_rays_bwd_view(const float* V_rows, const float* N_rows, c
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(V_rows && N_rows && r_rows && off_rows && sobol && row_of_ray && j_of_ray && d_nrv, NMF_EINVAL,
                 "nmf_ggx_rays_bwd_view: null");
-    hipLaunchKernelGGL(k_ggx_rays_bwd<7>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+    NMF_LAUNCH(k_ggx_rays_bwd<7>, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
                        mk_rows(V_rows, N_rows, r_rows, nullptr, off_rows, nullptr), sobol, row_of_ray, j_of_ray, R, dL, d_rays,
                        d_nrv);
     NMF_CHECK_LAUNCH("nmf_ggx_rays_bwd_view");
@@ -337,7 +337,7 @@ extern "C" int nmf_shade_mix_fwd(const float* V_rows, const float* f0_rows, cons
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(V_rows && f0_rows && diffuse_rows && cnt_rows && row_of_ray && L && incoming && brdf && contrib,
                 NMF_EINVAL, "nmf_shade_mix_fwd: null");
-    hipLaunchKernelGGL(k_shade_mix_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, V_rows, f0_rows,
+    NMF_LAUNCH(k_shade_mix_fwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, V_rows, f0_rows,
                        diffuse_rows, cnt_rows, row_of_ray, R, L, incoming, brdf, contrib);
     NMF_CHECK_LAUNCH("nmf_shade_mix_fwd");
     return NMF_OK;
@@ -360,7 +360,7 @@ extern "C" int nmf_shade_mix_bwd_view(const float* V_rows, const float* f0_rows,
     NMF_REQUIRE(V_rows && f0_rows && diffuse_rows && cnt_rows && row_of_ray && L && incoming && brdf && d_rows &&
                     d_incoming && d_brdf && dL && d_f0diff,
                 NMF_EINVAL, "nmf_shade_mix_bwd: null");
-    hipLaunchKernelGGL(k_shade_mix_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, V_rows, f0_rows,
+    NMF_LAUNCH(k_shade_mix_bwd, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, V_rows, f0_rows,
                        diffuse_rows, cnt_rows, row_of_ray, R, L, incoming, brdf, d_rows, d_incoming, d_brdf, dL, d_f0diff, dV);
     NMF_CHECK_LAUNCH("nmf_shade_mix_bwd");
     return NMF_OK;

@@ -172,7 +172,7 @@ extern "C" int nmf_heads_fwd(const float* feat, int64_t M, const float* W, const
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(feat && W && b && out, NMF_EINVAL, "nmf_heads_fwd: null");
     HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
-    hipLaunchKernelGGL(k_heads_fwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, out);
+    NMF_LAUNCH(k_heads_fwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, out);
     NMF_CHECK_LAUNCH("nmf_heads_fwd");
     return NMF_OK;
 }
@@ -186,7 +186,7 @@ extern "C" int nmf_heads_bwd(const float* feat, int64_t M, const float* W, const
     HeadP hp{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias};
     const int64_t n_it = cdiv(M, 256);
     const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
-    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat_add, d_feat, gW, gb,
+    NMF_LAUNCH(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, M, W, b, hp, d_out, d_feat_add, d_feat, gW, gb,
                        nmf_rows::RowsBwdIn{});
     NMF_CHECK_LAUNCH("nmf_heads_bwd");
     return NMF_OK;
@@ -209,7 +209,7 @@ extern "C" int nmf_bounce_prep_heads_bwd(const int32_t* bidx, int64_t Mb, const 
                             row_strides ? row_strides[3] : 3, dfeat, d_normals};
     const int64_t n_it = cdiv(Mb, 256);
     const unsigned grid = (unsigned)(n_it < 1024 ? n_it : 1024);
-    hipLaunchKernelGGL(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, app, Mb, head_W, head_b, hp, nullptr, nullptr, d_app,
+    NMF_LAUNCH(k_heads_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, app, Mb, head_W, head_b, hp, nullptr, nullptr, d_app,
                        g_head_W, g_head_b, rin);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_heads_bwd");
     return NMF_OK;

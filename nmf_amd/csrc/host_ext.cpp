@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -114,6 +115,33 @@ struct TimedScope {
         }
     }
 };
+
+// ---- per-KERNEL device timing (bench.py: roofline of the dominant kernel) ---------------------------------------------------
+// libnmf_hip.so calls a probe in front of and behind every kernel launch (nmf_set_launch_probe); while a kernel timer is active the
+// probe records a timed event on the launching stream on either side.  Names are the kernels' identifiers as rocprofv3 prints them.
+CallTimer* g_kernel_timer = nullptr;
+std::string g_kernel_filter;         // non-empty: only kernels whose name contains it
+void* g_probe_open = nullptr;
+void launch_probe(const char* name, void* stream, int phase) {
+    CallTimer* t = g_kernel_timer;
+    if (!t) return;
+    if (phase == 0) {
+        g_probe_open = nullptr;
+        if (!g_kernel_filter.empty() && std::strstr(name, g_kernel_filter.c_str()) == nullptr) return;
+        g_probe_open = t->ev();
+        nmf_event_record(g_probe_open, stream);
+    } else if (g_probe_open) {
+        void* b = t->ev();
+        nmf_event_record(b, stream);
+        t->recs.push_back({name, g_probe_open, b, stream, 0.0});
+        g_probe_open = nullptr;
+    }
+}
+std::string kernel_name(const char* raw) {        // "(k_foo<1, 8>)" -> "k_foo<1, 8>"
+    std::string s(raw);
+    if (!s.empty() && s.front() == '(' && s.back() == ')') s = s.substr(1, s.size() - 2);
+    return s;
+}
 
 struct P3 {
     const float* p[3];
@@ -1074,6 +1102,36 @@ PYBIND11_MODULE(_nmf_host, m) {
             auto& e = acc[r.name];
             e.first += ms;
             e.second += 1;
+        }
+        for (auto& kv : acc) out[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+        delete t;
+        return out;
+    });
+    m.def("kernel_timing_begin", [](const std::string& only) {
+        if (!g_kernel_timer) g_kernel_timer = new CallTimer();
+        g_kernel_timer->next = 0;
+        g_kernel_timer->recs.clear();
+        g_kernel_filter = only;
+        g_probe_open = nullptr;
+        check(nmf_set_launch_probe(&launch_probe), "nmf_set_launch_probe");
+    }, py::arg("only") = "");
+    m.def("kernel_timing_end", []() {      // waits for the recorded work; -> {kernel: (ms, launches)}
+        py::dict out;
+        check(nmf_set_launch_probe(nullptr), "nmf_set_launch_probe");
+        if (!g_kernel_timer) return out;
+        CallTimer* t = g_kernel_timer;
+        g_kernel_timer = nullptr;
+        std::map<std::string, std::pair<double, int64_t>> acc;
+        for (auto& r : t->recs) {
+            float ms = 0.f;
+            check(nmf_event_synchronize(r.b), "nmf_event_synchronize");
+            check(nmf_event_elapsed_ms(r.a, r.b, &ms), "nmf_event_elapsed_ms");
+            auto& e = acc[kernel_name(r.name)];
+            e.first += ms;
+            e.second += 1;
+            auto& q = acc["@" + std::to_string(reinterpret_cast<int64_t>(r.stream))];      // per-stream sums (the main stream = the chain)
+            q.first += ms;
+            q.second += 1;
         }
         for (auto& kv : acc) out[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
         delete t;

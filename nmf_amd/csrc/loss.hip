@@ -176,7 +176,7 @@ extern "C" int nmf_l1_mean_fwd(const float* const x[], const int64_t numel[], in
     L1Tab t;
     memset(&t, 0, sizeof(t));
     NMF_REQUIRE(fill_tab(t, x, nullptr, numel, count, false) == 0, NMF_EINVAL, "nmf_l1_mean_fwd: bad tensor");
-    hipLaunchKernelGGL(k_l1_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t, out);
+    NMF_LAUNCH(k_l1_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t, out);
     NMF_CHECK_LAUNCH("nmf_l1_mean_fwd");
     return NMF_OK;
 }
@@ -189,7 +189,7 @@ extern "C" int nmf_l1_mean_bwd(const float* const x[], const int64_t numel[], in
     L1Tab t;
     memset(&t, 0, sizeof(t));
     NMF_REQUIRE(fill_tab(t, x, g, numel, count, true) == 0, NMF_EINVAL, "nmf_l1_mean_bwd: bad tensor");
-    hipLaunchKernelGGL(k_l1_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+    NMF_LAUNCH(k_l1_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
                        d_out, (int)accumulate);
     NMF_CHECK_LAUNCH("nmf_l1_mean_bwd");
     return NMF_OK;
@@ -201,7 +201,7 @@ extern "C" int nmf_sqerr_fwd(const float* pred, const float* gt, int64_t n, floa
     NMF_REQUIRE(pred && gt, NMF_EINVAL, "nmf_sqerr_fwd: null");
     int64_t b = cdiv(n, 256 * 4);
     b = b > 256 ? 256 : b;
-    hipLaunchKernelGGL(k_sqerr_fwd, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, pred, gt, n, out);
+    NMF_LAUNCH(k_sqerr_fwd, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, pred, gt, n, out);
     NMF_CHECK_LAUNCH("nmf_sqerr_fwd");
     return NMF_OK;
 }
@@ -211,7 +211,7 @@ extern "C" int nmf_sqerr_bwd(const float* pred, const float* gt, int64_t n, cons
     NMF_REQUIRE(n >= 0, NMF_EINVAL, "nmf_sqerr_bwd: n < 0");
     if (n == 0) return NMF_OK;
     NMF_REQUIRE(pred && gt && d_out && d_pred, NMF_EINVAL, "nmf_sqerr_bwd: null");
-    hipLaunchKernelGGL(k_sqerr_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
+    NMF_LAUNCH(k_sqerr_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
                        d_pred);
     NMF_CHECK_LAUNCH("nmf_sqerr_bwd");
     return NMF_OK;
@@ -228,7 +228,7 @@ extern "C" int nmf_loss_mix_fwd(const float* const x[], const int64_t numel[], c
         NMF_REQUIRE(numel[i] >= 0 && (numel[i] == 0 || x[i]), NMF_EINVAL, "nmf_loss_mix_fwd: bad tensor");
         t.x[i] = x[i]; t.n[i] = numel[i]; t.w[i] = w[i];
     }
-    hipLaunchKernelGGL(k_mix_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+    NMF_LAUNCH(k_mix_fwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
                        scale, out);
     NMF_CHECK_LAUNCH("nmf_loss_mix_fwd");
     return NMF_OK;
@@ -245,7 +245,7 @@ extern "C" int nmf_loss_mix_bwd(const int64_t numel[], const float w[], int32_t 
         NMF_REQUIRE(numel[i] >= 0 && (numel[i] == 0 || g[i]), NMF_EINVAL, "nmf_loss_mix_bwd: bad tensor");
         t.g[i] = g[i]; t.n[i] = numel[i]; t.w[i] = w[i];
     }
-    hipLaunchKernelGGL(k_mix_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
+    NMF_LAUNCH(k_mix_bwd, dim3(blocks_for(numel, count), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t,
                        scale, d_out);
     NMF_CHECK_LAUNCH("nmf_loss_mix_bwd");
     return NMF_OK;
@@ -266,7 +266,7 @@ extern "C" int nmf_loss_head(const float* pred, const float* gt, int64_t n_rays,
                 NMF_EINVAL, "nmf_loss_head: workspace too small or not 16-byte aligned");
     const int64_t n = 3 * n_rays;
     const int64_t blocks = n ? cdiv(n, 256) : 1;
-    hipLaunchKernelGGL(k_loss_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, n, n_rays, d_out, scale,
+    NMF_LAUNCH(k_loss_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, n, n_rays, d_out, scale,
                        w_pred, w_a, w_b, loss, d_pred, g_a, g_b, static_cast<uint32_t*>(workspace),
                        reinterpret_cast<float*>(static_cast<char*>(workspace) + 16));
     NMF_CHECK_LAUNCH("nmf_loss_head");

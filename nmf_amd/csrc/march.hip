@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(SCAN_CHUNK) k_scan_fused(const int32_t* __rest
 
 extern "C" int nmf_alpha_pack(const float* volume, int64_t n_voxels, uint32_t* bits, void* stream) {
     NMF_REQUIRE(volume && bits && n_voxels > 0, NMF_EINVAL, "nmf_alpha_pack: null/empty");
-    hipLaunchKernelGGL(k_alpha_pack, dim3((unsigned)cdiv(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, volume,
+    NMF_LAUNCH(k_alpha_pack, dim3((unsigned)cdiv(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, volume,
                        n_voxels, bits);
     NMF_CHECK_LAUNCH("nmf_alpha_pack");
     return NMF_OK;
@@ -801,7 +801,7 @@ extern "C" int64_t nmf_alpha_coarse_words(const int32_t grid[3]) {
 extern "C" int nmf_alpha_coarse(const uint32_t* bits, const int32_t grid[3], uint32_t* coarse, void* stream) {
     NMF_REQUIRE(bits && grid && coarse && grid[0] > 0 && grid[1] > 0 && grid[2] > 0, NMF_EINVAL, "nmf_alpha_coarse: null/size");
     const int64_t words = nmf_alpha_coarse_words(grid);
-    hipLaunchKernelGGL(k_alpha_coarse, dim3((unsigned)cdiv(words * 32, 256)), dim3(256), 0, (hipStream_t)stream, bits,
+    NMF_LAUNCH(k_alpha_coarse, dim3((unsigned)cdiv(words * 32, 256)), dim3(256), 0, (hipStream_t)stream, bits,
                        grid[0], grid[1], grid[2], coarse);
     NMF_CHECK_LAUNCH("nmf_alpha_coarse");
     return NMF_OK;
@@ -828,14 +828,14 @@ extern "C" int nmf_march_count(const nmf_march_params* p, const float* rays, int
     if (lanes_per_ray(B) == 16) {      // many rays (the re-traced secondary rays): four rays per wave, rounds of 16 steps
         int64_t blocks = cdiv(cdiv(B, 4), 4);
         if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_march_count16, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p,
+        NMF_LAUNCH(k_march_count16, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p,
                            rays, B, jitter, alpha_bits, alpha_coarse, (int)words, valid_bits, counts);
         NMF_CHECK_LAUNCH("nmf_march_count");
         return NMF_OK;
     }
     int64_t blocks = cdiv(B, 4);
     if (blocks > 256 * 16) blocks = 256 * 16;                                 // persistent: 16 workgroups per CU
-    hipLaunchKernelGGL(k_march_count, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p, rays,
+    NMF_LAUNCH(k_march_count, dim3((unsigned)blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, *p, rays,
                        B, jitter, alpha_bits, alpha_coarse, (int)words, valid_bits, counts);
     NMF_CHECK_LAUNCH("nmf_march_count");
     return NMF_OK;
@@ -866,18 +866,18 @@ extern "C" int nmf_march_scan_publish(const int32_t* counts, int64_t B, int64_t 
     int64_t* meta = chunk + n_chunks;
     const bool three_pass = getenv("NMF_SCAN_3PASS") != nullptr;             // the round-1 form (tests compare the two)
     if (n_chunks <= 4096 && !three_pass) {
-        if (n_chunks > 4) hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
-        hipLaunchKernelGGL(k_scan_fused, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples,
+        if (n_chunks > 4) NMF_LAUNCH(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
+        NMF_LAUNCH(k_scan_fused, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples,
                            n_chunks > 4 ? chunk : nullptr, (int)n_chunks, offsets, whole_valid, totals, pub, publish_seq);
         NMF_CHECK_LAUNCH("nmf_march_scan");
         return NMF_OK;
     }
-    hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, chunk, (int)n_chunks, B, max_samples, offsets, totals,
+    NMF_LAUNCH(k_scan_partial, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, chunk);
+    NMF_LAUNCH(k_scan_top, dim3(1), dim3(1024), 0, st, chunk, (int)n_chunks, B, max_samples, offsets, totals,
                        meta);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples, chunk,
+    NMF_LAUNCH(k_scan_final, dim3((unsigned)n_chunks), dim3(SCAN_CHUNK), 0, st, counts, B, max_samples, chunk,
                        meta, offsets, whole_valid, totals);
-    hipLaunchKernelGGL(k_scan_clamp, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, st, offsets, B, meta, totals);
+    NMF_LAUNCH(k_scan_clamp, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, st, offsets, B, meta, totals);
     NMF_CHECK_LAUNCH("nmf_march_scan");
     if (pub) return nmf_publish_i64x2(totals, pub, publish_seq, stream);
     return NMF_OK;
@@ -890,10 +890,10 @@ extern "C" int nmf_march_fill(const nmf_march_params* p, const float* rays, int6
     NMF_REQUIRE(b >= 0 && (b == 0 || (rays && valid_bits && offsets)), NMF_EINVAL, "nmf_march_fill: null");
     if (b == 0) return NMF_OK;
     if (lanes_per_ray(b) == 16)
-        hipLaunchKernelGGL(k_march_fill16, dim3((unsigned)cdiv(cdiv(b, 4), 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b,
+        NMF_LAUNCH(k_march_fill16, dim3((unsigned)cdiv(cdiv(b, 4), 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b,
                            jitter, valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
     else
-        hipLaunchKernelGGL(k_march_fill, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
+        NMF_LAUNCH(k_march_fill, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
                            valid_bits, offsets, (float4*)xyzt, ray_id, step_id, z, dist);
     NMF_CHECK_LAUNCH("nmf_march_fill");
     return NMF_OK;
@@ -904,7 +904,7 @@ extern "C" int nmf_march_dense(const nmf_march_params* p, const float* rays, int
     if (int e = check_params(p)) return e;
     NMF_REQUIRE(b >= 0 && (b == 0 || (rays && valid_bits)), NMF_EINVAL, "nmf_march_dense: null");
     if (b == 0) return NMF_OK;
-    hipLaunchKernelGGL(k_march_dense, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
+    NMF_LAUNCH(k_march_dense, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, (hipStream_t)stream, *p, rays, b, jitter,
                        valid_bits, ray_valid, z_vals);
     NMF_CHECK_LAUNCH("nmf_march_dense");
     return NMF_OK;

@@ -55,7 +55,7 @@ extern "C" int nmf_retrace_scores(const float* brdf, const float* V_rows, const 
     if (R == 0) return NMF_OK;
     NMF_REQUIRE(brdf && V_rows && N_rows && lpdf && w_rows && cnt_rows && row_of_ray && score, NMF_EINVAL,
                 "nmf_retrace_scores: null");
-    hipLaunchKernelGGL(k_retrace_scores, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, brdf, V_rows,
+    NMF_LAUNCH(k_retrace_scores, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, brdf, V_rows,
                        N_rows, lpdf, w_rows, cnt_rows, row_of_ray, R, score);
     NMF_CHECK_LAUNCH("nmf_retrace_scores");
     return NMF_OK;
@@ -322,7 +322,7 @@ extern "C" int nmf_argsort_f32(const float* keys, int64_t n, int32_t* order, voi
     int32_t* iota = (int32_t*)(base + align256((size_t)n * 4));
     void* temp = base + 2 * align256((size_t)n * 4);
     size_t temp_bytes = sort_temp_bytes(n);
-    hipLaunchKernelGGL(k_iota, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, iota, n);
+    NMF_LAUNCH(k_iota, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, iota, n);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, (const int32_t*)iota, order, (size_t)n, 0,
                                              32, st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_argsort_f32: rocprim::radix_sort_pairs");
@@ -356,7 +356,7 @@ extern "C" int nmf_topk_select(const float* keys, int64_t n, int64_t k, int32_t*
     int32_t* order = (int32_t*)base;                        base += align256((size_t)n * 4);
     void* sort_ws = base;
     if (k == 0) {                     // nothing selected: the rest is every index
-        hipLaunchKernelGGL(k_iota, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, idx_rest, n);
+        NMF_LAUNCH(k_iota, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, idx_rest, n);
         NMF_CHECK_LAUNCH("nmf_topk_select");
         return NMF_OK;
     }
@@ -364,24 +364,24 @@ extern "C" int nmf_topk_select(const float* keys, int64_t n, int64_t k, int32_t*
     hipError_t e = hipMemsetAsync(state, 0, sizeof(SelState), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_topk_select: memset");
     const dim3 grid((unsigned)n_chunks), block(SEL_THREADS);
-    hipLaunchKernelGGL(k_sel_hist<0>, grid, block, 0, st, keys, n, k, state);
-    hipLaunchKernelGGL(k_sel_pick<0>, dim3(1), block, 0, st, n, k, state);
-    hipLaunchKernelGGL(k_sel_hist<1>, grid, block, 0, st, keys, n, k, state);
-    hipLaunchKernelGGL(k_sel_pick<1>, dim3(1), block, 0, st, n, k, state);
-    hipLaunchKernelGGL(k_sel_hist<2>, grid, block, 0, st, keys, n, k, state);
-    hipLaunchKernelGGL(k_sel_pick<2>, dim3(1), block, 0, st, n, k, state);
-    hipLaunchKernelGGL(k_sel_count, grid, block, 0, st, keys, n, state, chunk);
-    hipLaunchKernelGGL(k_sel_chunk_scan, dim3(1), block, 0, st, state, chunk, (int)n_chunks);
+    NMF_LAUNCH(k_sel_hist<0>, grid, block, 0, st, keys, n, k, state);
+    NMF_LAUNCH(k_sel_pick<0>, dim3(1), block, 0, st, n, k, state);
+    NMF_LAUNCH(k_sel_hist<1>, grid, block, 0, st, keys, n, k, state);
+    NMF_LAUNCH(k_sel_pick<1>, dim3(1), block, 0, st, n, k, state);
+    NMF_LAUNCH(k_sel_hist<2>, grid, block, 0, st, keys, n, k, state);
+    NMF_LAUNCH(k_sel_pick<2>, dim3(1), block, 0, st, n, k, state);
+    NMF_LAUNCH(k_sel_count, grid, block, 0, st, keys, n, state, chunk);
+    NMF_LAUNCH(k_sel_chunk_scan, dim3(1), block, 0, st, state, chunk, (int)n_chunks);
     const bool in_lds = k <= TOPK_SORT_IN_LDS;
-    hipLaunchKernelGGL(k_sel_scatter, grid, block, 0, st, keys, n, k, state, chunk, k ? top_raw : nullptr, idx_rest,
+    NMF_LAUNCH(k_sel_scatter, grid, block, 0, st, keys, n, k, state, chunk, k ? top_raw : nullptr, idx_rest,
                        (k && in_lds) ? key64 : nullptr);
     if (in_lds) {
-        hipLaunchKernelGGL(k_sel_sort, dim3(1), block, 0, st, key64, (int)k, idx_top);
+        NMF_LAUNCH(k_sel_sort, dim3(1), block, 0, st, key64, (int)k, idx_top);
     } else {             // many selected rays (a transient of the re-trace controller): the library sort, over the k keys only
-        hipLaunchKernelGGL(k_sel_gather_keys, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, st, keys, top_raw, k, top_keys);
+        NMF_LAUNCH(k_sel_gather_keys, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, st, keys, top_raw, k, top_keys);
         const int rc = nmf_argsort_f32(top_keys, k, order, sort_ws, nmf_argsort_workspace_bytes(k), stream);
         if (rc != NMF_OK) return rc;
-        hipLaunchKernelGGL(k_sel_compose, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, st, top_raw, order, k, idx_top);
+        NMF_LAUNCH(k_sel_compose, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, st, top_raw, order, k, idx_top);
     }
     NMF_CHECK_LAUNCH("nmf_topk_select");
     return NMF_OK;

@@ -132,7 +132,7 @@ extern "C" int nmf_select_total(const float* weights, const float* u, int64_t M,
     // samples: 14.5 us) beat 512 (24 us) and 64 (20.7 us)
     int64_t blocks = cdiv(M, 256 * 8);
     blocks = blocks > 128 ? 128 : (blocks < 1 ? 1 : blocks);
-    hipLaunchKernelGGL(k_select_total, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weights, u, M, extra,
+    NMF_LAUNCH(k_select_total, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weights, u, M, extra,
                        workspace, total);
     NMF_CHECK_LAUNCH("nmf_select_total");
     return NMF_OK;
@@ -144,7 +144,7 @@ extern "C" int nmf_view_adjoint_to_rays(const int32_t* ray_id, const int32_t* bi
     if (Mb == 0) return NMF_OK;
     NMF_REQUIRE(ray_id && bidx && dv_a && d_rays && lda >= 3 && (!dv_b || ldb >= 3), NMF_EINVAL,
                 "nmf_view_adjoint_to_rays: null");
-    hipLaunchKernelGGL(k_view_adjoint_to_rays, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, ray_id, bidx,
+    NMF_LAUNCH(k_view_adjoint_to_rays, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, ray_id, bidx,
                        dv_a, (int)lda, dv_b, (int)ldb, Mb, d_rays);
     NMF_CHECK_LAUNCH("nmf_view_adjoint_to_rays");
     return NMF_OK;
@@ -156,7 +156,7 @@ extern "C" int nmf_select_bounces(const float* weights, const float* u, int64_t 
     if (M == 0) return NMF_OK;
     NMF_REQUIRE(weights && u && counts, NMF_EINVAL, "nmf_select_bounces: null");
     NMF_REQUIRE(mode == 0 || mode == 1, NMF_EINVAL, "nmf_select_bounces: mode");
-    hipLaunchKernelGGL(k_select_bounces, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weights, u, M,
+    NMF_LAUNCH(k_select_bounces, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weights, u, M,
                        mode, mul, add, sum_w, sum_w_dev, counts);
     NMF_CHECK_LAUNCH("nmf_select_bounces");
     return NMF_OK;
@@ -167,7 +167,7 @@ extern "C" int nmf_expand_segments(const int64_t* offsets, int64_t n_seg, int32_
     NMF_REQUIRE(n_seg >= 0, NMF_EINVAL, "nmf_expand_segments: n_seg < 0");
     if (n_seg == 0) return NMF_OK;
     NMF_REQUIRE(offsets && (seg_id || local), NMF_EINVAL, "nmf_expand_segments: null");
-    hipLaunchKernelGGL(k_expand_segments, dim3((unsigned)cdiv(n_seg, 32)), dim3(256), 0, (hipStream_t)stream, offsets,
+    NMF_LAUNCH(k_expand_segments, dim3((unsigned)cdiv(n_seg, 32)), dim3(256), 0, (hipStream_t)stream, offsets,
                        n_seg, seg_id, local);
     NMF_CHECK_LAUNCH("nmf_expand_segments");
     return NMF_OK;

@@ -552,13 +552,13 @@ static int bounce_index_impl(const int32_t* counts, SelectArgs sel, int64_t M, c
     NMF_REQUIRE(n_chunks <= (1 << 22), NMF_ERANGE, "nmf_bounce_index: M too large");
     int64_t* chunk = static_cast<int64_t*>(workspace);
     NMF_REQUIRE(!M_live || n_chunks <= IDX_CHUNK, NMF_ERANGE, "nmf_bounce_index_live: bound too large for a device-side count");
-    hipLaunchKernelGGL(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, M_live, sel);
+    NMF_LAUNCH(k_idx_partial, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, M_live, sel);
     if (n_chunks <= IDX_CHUNK) {
-        hipLaunchKernelGGL(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
+        NMF_LAUNCH(k_idx_final_fused, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk,
                            (int)n_chunks, totals, bidx, row_off, cnt_rows, inv, x4, r4, pub, publish_seq, M_live, sel);
     } else {
-        hipLaunchKernelGGL(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
-        hipLaunchKernelGGL(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
+        NMF_LAUNCH(k_idx_top, dim3(1), dim3(IDX_CHUNK), 0, st, chunk, (int)n_chunks, totals);
+        NMF_LAUNCH(k_idx_final, dim3((unsigned)n_chunks), dim3(IDX_CHUNK), 0, st, counts, M, chunk, totals, bidx,
                            row_off, cnt_rows, inv, x4, r4);
     }
     NMF_CHECK_LAUNCH("nmf_bounce_index");
@@ -581,7 +581,7 @@ extern "C" int nmf_bounce_prep_fwd(const int32_t* bidx, int64_t Mb, const float*
     if (Mb == 0) return NMF_OK;
     NMF_REQUIRE(bidx && normals && app && heads && xyzt && ray_id && rays && conv && V && N && r1 && f0 &&
                     diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd: null");
-    hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
+    NMF_LAUNCH(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
                        normals, app, heads, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
                        feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz,
                        HeadsIn{nullptr, nullptr, nmf_heads::HeadP{0.f, 0.f, 0.f, 0.f, 0.f}, nullptr});
@@ -600,7 +600,7 @@ extern "C" int nmf_bounce_prep_fwd_heads(const int32_t* bidx, int64_t Mb, const 
     NMF_REQUIRE(row_inputs == 1 || row_inputs == 2, NMF_EINVAL, "nmf_bounce_prep_fwd_heads: app must be given per bounce row");
     NMF_REQUIRE(bidx && normals && app && head_W && head_b && heads_out && xyzt && ray_id && rays && conv && V && N && r1 && f0 &&
                     diffuse && feat && xyz, NMF_EINVAL, "nmf_bounce_prep_fwd_heads: null");
-    hipLaunchKernelGGL(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
+    NMF_LAUNCH(k_bounce_prep_fwd, dim3((unsigned)cdiv(Mb, 256)), dim3(256), 0, (hipStream_t)stream, bidx, Mb,
                        normals, app, heads_out, reinterpret_cast<const float4*>(xyzt), ray_id, rays, load_conv(conv),
                        feat_noise, anoise, min_rough, (int)row_inputs, V, N, r1, f0, diffuse, feat, xyz,
                        HeadsIn{head_W, head_b, nmf_heads::HeadP{diffuse_mul, diffuse_bias, tint_bias, f0_bias, rough_bias}, heads_out});
@@ -624,7 +624,7 @@ extern "C" int nmf_bounce_prep_bwd(const int32_t* inv, int64_t M, const int32_t*
     NMF_REQUIRE((row_inputs ? Mb == 0 : false) || (heads && d_heads && d_app), NMF_EINVAL, "nmf_bounce_prep_bwd: null");
     NMF_REQUIRE(!row_inputs || Mb == 0 || bidx, NMF_EINVAL, "nmf_bounce_prep_bwd: row_inputs needs bidx");
     const int64_t n_threads = row_inputs == 2 ? (Mb > 0 ? Mb : 1) : M;
-    hipLaunchKernelGGL(k_bounce_prep_bwd, dim3((unsigned)cdiv(n_threads, 256)), dim3(256), 0, (hipStream_t)stream, inv, M, bidx,
+    NMF_LAUNCH(k_bounce_prep_bwd, dim3((unsigned)cdiv(n_threads, 256)), dim3(256), 0, (hipStream_t)stream, inv, M, bidx,
                        Mb, normals, heads, ray_id, rays, load_conv(conv), min_rough, (int)detach_normals, (int)row_inputs,
                        dN, dr1, df0, ddiffuse, sN, sr, sf, sd, dfeat, d_normals, d_heads, d_app);
     NMF_CHECK_LAUNCH("nmf_bounce_prep_bwd");
@@ -641,11 +641,11 @@ extern "C" int nmf_ray_compose_fwd(const float* weight, const float* refl_rows, 
     NMF_REQUIRE(rays && offsets && bg && rgb_map && acc && rgb_lin, NMF_EINVAL, "nmf_ray_compose_fwd: null");
     NMF_REQUIRE(!ori || normals, NMF_EINVAL, "nmf_ray_compose_fwd: ori needs normals");
     if (B <= 16384)      // few rays with long segments (primary rays): one wave per ray
-        hipLaunchKernelGGL(k_ray_compose_fwd_wave<64>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, weight,
+        NMF_LAUNCH(k_ray_compose_fwd_wave<64>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, weight,
                            refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
                            rgb_map, acc, rgb_lin, ori);
     else                 // many rays with short segments (re-traced rays): eight lanes per ray
-        hipLaunchKernelGGL(k_ray_compose_fwd_wave<8>, dim3((unsigned)cdiv(B, 32)), dim3(256), 0, (hipStream_t)stream, weight,
+        NMF_LAUNCH(k_ray_compose_fwd_wave<8>, dim3((unsigned)cdiv(B, 32)), dim3(256), 0, (hipStream_t)stream, weight,
                            refl_rows, inv, normals, rays, offsets, B, bg, (int)bg_per_ray, (int)tonemap, (int)noclip,
                            rgb_map, acc, rgb_lin, ori);
     NMF_CHECK_LAUNCH("nmf_ray_compose_fwd");
@@ -662,7 +662,7 @@ extern "C" int nmf_ray_compose_bwd(const float* weight, const float* refl_rows, 
     NMF_REQUIRE(weight && rays && ray_id && bg && rgb_lin && d_weight, NMF_EINVAL, "nmf_ray_compose_bwd: null");
     NMF_REQUIRE(!(inv && refl_rows) || d_refl, NMF_EINVAL, "nmf_ray_compose_bwd: d_refl missing");
     NMF_REQUIRE(!d_ori || normals, NMF_EINVAL, "nmf_ray_compose_bwd: d_ori needs normals");
-    hipLaunchKernelGGL(k_ray_compose_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+    NMF_LAUNCH(k_ray_compose_bwd, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, weight,
                        refl_rows, inv, normals, rays, ray_id, M, bg, (int)bg_per_ray, (int)tonemap, (int)noclip, rgb_lin,
                        d_rgb_map, d_acc, d_ori, d_weight, d_refl, d_normals);
     NMF_CHECK_LAUNCH("nmf_ray_compose_bwd");
@@ -673,7 +673,7 @@ extern "C" int nmf_bg_adjoint(const float* acc, const float* d_rgb_map, int64_t 
     NMF_REQUIRE(B >= 0, NMF_EINVAL, "nmf_bg_adjoint: B < 0");
     if (B == 0) return NMF_OK;
     NMF_REQUIRE(acc && d_rgb_map && d_bg, NMF_EINVAL, "nmf_bg_adjoint: null");
-    hipLaunchKernelGGL(k_bg_adjoint, dim3((unsigned)cdiv(3 * B, 256)), dim3(256), 0, (hipStream_t)stream, acc, d_rgb_map, 3 * B,
+    NMF_LAUNCH(k_bg_adjoint, dim3((unsigned)cdiv(3 * B, 256)), dim3(256), 0, (hipStream_t)stream, acc, d_rgb_map, 3 * B,
                        d_bg);
     NMF_CHECK_LAUNCH("nmf_bg_adjoint");
     return NMF_OK;

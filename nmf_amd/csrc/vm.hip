@@ -1569,7 +1569,7 @@ extern "C" int nmf_vm_pack_density(const nmf_vm_params* p, const float* const pl
         a.src[i] = planes[i]; a.dst[i] = dpk[i];
         a.src[3 + i] = lines[i]; a.dst[3 + i] = dlk[i];
     }
-    hipLaunchKernelGGL(k_pack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a);
+    NMF_LAUNCH(k_pack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a);
     NMF_CHECK_LAUNCH("nmf_vm_pack_density");
     return NMF_OK;
 }
@@ -1603,7 +1603,7 @@ static int unpack_impl(const nmf_vm_params* p, const float* const g_dpk[3], cons
     L1Six q;
     for (int i = 0; i < 3; ++i) { q.x[i] = x_planes ? x_planes[i] : nullptr; q.x[3 + i] = x_lines ? x_lines[i] : nullptr; }
     q.l1 = l1;
-    hipLaunchKernelGGL(k_unpack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a, q);
+    NMF_LAUNCH(k_unpack_tables, dim3((unsigned)cdiv(n, 256), 6), dim3(256), 0, (hipStream_t)stream, *p, a, q);
     NMF_CHECK_LAUNCH("nmf_vm_unpack_density_grad");
     return NMF_OK;
 }
@@ -1633,18 +1633,18 @@ static int vm_query_fwd_impl(const char* what, const nmf_vm_params* p, const flo
     NMF_REQUIRE(!M_live || (want_d && (grad || normal)), NMF_EINVAL,
                 "nmf_vm_query_fwd_live: only the general query (density with gradient / normal) takes a device-side count");
     if (want_d && !want_a && !grad && !normal) {      // density value only
-        hipLaunchKernelGGL(k_vm_sigma<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+        NMF_LAUNCH_NAMED(sizeof(TT) == 4 ? "k_vm_sigma<float>" : "k_vm_sigma<unsigned short>", k_vm_sigma<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<TT>(dpk, true), mkT<TT>(dlk, true), DP, DL, sigma_feat, sigma);
         NMF_CHECK_LAUNCH(what);
         return NMF_OK;
     }
     if (!want_d && app && !coef) {      // appearance of the bounce rows: 8 lanes per row
-        hipLaunchKernelGGL(k_vm_app_rows<TT>, dim3((unsigned)cdiv(M, APP_ROWS)), dim3(256), 0, (hipStream_t)stream, *p,
+        NMF_LAUNCH_NAMED(sizeof(TT) == 4 ? "k_vm_app_rows<float>" : "k_vm_app_rows<unsigned short>", k_vm_app_rows<TT>, dim3((unsigned)cdiv(M, APP_ROWS)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<TT>(app_planes, true), mkT<TT>(app_lines, true), basis, app);
         NMF_CHECK_LAUNCH(what);
         return NMF_OK;
     }
-    hipLaunchKernelGGL(k_vm_fwd<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+    NMF_LAUNCH_NAMED(sizeof(TT) == 4 ? "k_vm_fwd<float>" : "k_vm_fwd<unsigned short>", k_vm_fwd<TT>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        (const float4*)xyzt, M, mkT<TT>(dpk, want_d), mkT<TT>(dlk, want_d), mkT<TT>(app_planes, want_a),
                        mkT<TT>(app_lines, want_a), basis, sigma_feat, sigma, grad, normal, app, coef, M_live);
     NMF_CHECK_LAUNCH(what);
@@ -1684,12 +1684,12 @@ extern "C" int nmf_vm_query_sigma(const nmf_vm_params* p, const float* xyzt, int
     if (tables_bf16) {
         const uint16_t* pl[3] = {(const uint16_t*)planes[0], (const uint16_t*)planes[1], (const uint16_t*)planes[2]};
         const uint16_t* li[3] = {(const uint16_t*)lines[0], (const uint16_t*)lines[1], (const uint16_t*)lines[2]};
-        hipLaunchKernelGGL(k_vm_sigma<uint16_t>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+        NMF_LAUNCH(k_vm_sigma<uint16_t>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<uint16_t>(pl, true), mkT<uint16_t>(li, true), CD, CD, sigma_feat, sigma);
     } else {
         const float* pl[3] = {(const float*)planes[0], (const float*)planes[1], (const float*)planes[2]};
         const float* li[3] = {(const float*)lines[0], (const float*)lines[1], (const float*)lines[2]};
-        hipLaunchKernelGGL(k_vm_sigma<float>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+        NMF_LAUNCH(k_vm_sigma<float>, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                            (const float4*)xyzt, M, mkT<float>(pl, true), mkT<float>(li, true), CD, CD, sigma_feat, sigma);
     }
     NMF_CHECK_LAUNCH("nmf_vm_query_sigma");
@@ -1707,12 +1707,12 @@ extern "C" int nmf_vm_query_rows(const nmf_vm_params* p, const float* xyzt, int6
     if (tables_bf16) {
         PtrsT3<uint16_t> a, b;
         for (int i = 0; i < 3; ++i) { a.p[i] = (const uint16_t*)dpk[i]; b.p[i] = (const uint16_t*)dlk[i]; }
-        hipLaunchKernelGGL(k_vm_rows_dn<uint16_t>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
+        NMF_LAUNCH(k_vm_rows_dn<uint16_t>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
                            sigma_feat, sigma, grad, normal);
     } else {
         PtrsT3<float> a, b;
         for (int i = 0; i < 3; ++i) { a.p[i] = (const float*)dpk[i]; b.p[i] = (const float*)dlk[i]; }
-        hipLaunchKernelGGL(k_vm_rows_dn<float>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
+        NMF_LAUNCH(k_vm_rows_dn<float>, grid, block, 0, (hipStream_t)stream, *p, (const float4*)xyzt, M, a, b,
                            sigma_feat, sigma, grad, normal);
     }
     NMF_CHECK_LAUNCH("nmf_vm_query_rows");
@@ -1849,13 +1849,13 @@ int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLay
         hipError_t e = hipMemsetAsync(L.counts, 0, clean ? count_bytes : L.zero_bytes, st);
         if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
     }
-    hipLaunchKernelGGL(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+    NMF_LAUNCH(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
     if (lookback) {
-        hipLaunchKernelGGL(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
+        NMF_LAUNCH(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
                            L.cursor, L.item_size, L.items, L.n_items, clean ? 1 : 0);
     } else {
-        hipLaunchKernelGGL(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
-        hipLaunchKernelGGL(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
+        NMF_LAUNCH(k_bins_partial, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.item_size, L.chunk_tot);
+        NMF_LAUNCH(k_bins_final, dim3(L.n_chunks), dim3(SB_THREADS), 0, st, L.counts, L.nb, L.kc, L.chunk_tot, L.offsets,
                            L.cursor, L.item_size, L.items, L.n_items);
         if (clean) {         // (grids beyond 500^3: the kept counters are handed back zero by a second memset)
             hipError_t e = hipMemsetAsync(L.counts, 0, count_bytes, st);
@@ -1863,7 +1863,7 @@ int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLay
         }
     }
     if (place)
-        hipLaunchKernelGGL(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
+        NMF_LAUNCH(k_plan_place, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, sg, M, L.keyrank, L.cursor, L.slot, L.rec0);
     NMF_CHECK_LAUNCH("nmf_vm_bin_plan");
     return NMF_OK;
 }
@@ -1964,14 +1964,14 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
     const int n_state = L.n_scan_chunks + 1;
     const dim3 per_sample((unsigned)cdiv(M, 256));
     if (want_a) {
-        if (plan) hipLaunchKernelGGL(k_brick_records<true>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
-        else hipLaunchKernelGGL(k_place_records<true>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
-        hipLaunchKernelGGL(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, W.d_app_sorted, basis, M,
+        if (plan) NMF_LAUNCH(k_brick_records<true>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
+        else NMF_LAUNCH(k_place_records<true>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
+        NMF_LAUNCH(k_dcoef, dim3((unsigned)cdiv(M * (3 * CA / 4), 256)), dim3(256), 0, st, W.d_app_sorted, basis, M,
                            W.dcoef);
     } else if (plan)
-        hipLaunchKernelGGL(k_brick_records<false>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
+        NMF_LAUNCH(k_brick_records<false>, per_sample, dim3(256), 0, st, *p, sg, L.slot, M, W.rec1, W.d_app_sorted);
     else
-        hipLaunchKernelGGL(k_place_records<false>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
+        NMF_LAUNCH(k_place_records<false>, per_sample, dim3(256), 0, st, *p, sg, M, L.keyrank, L.cursor, L.rec0, W.rec1, W.d_app_sorted, st_clear, n_state);
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     int64_t gcap = 16384;
@@ -1981,7 +1981,7 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
     const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);
     const size_t lds_bytes = sizeof(float4) * 64 * (want_a ? 16 : 4);
 #define NMF_LAUNCH_BWD_KERNEL(KERNEL)                                                                                         \
-    hipLaunchKernelGGL(KERNEL, grid, block, lds_bytes, st, *p, L.rec0, W.rec1, L.offsets, L.items, L.n_items, L.item_size,    \
+    NMF_LAUNCH(KERNEL, grid, block, lds_bytes, st, *p, L.rec0, W.rec1, L.offsets, L.items, L.n_items, L.item_size,    \
                        L.nbx, mk(dpk), mk(dlk), mk(app_planes), mk(app_lines), W.dcoef, W.d_app_sorted, mkm(g_dpk),           \
                        mkm(g_dlk), mkm(g_app_planes), mkm(g_app_lines), use_copies ? W.basis_copies : nullptr, z_density, z_app)
     if (want_d && want_a) {
@@ -1994,7 +1994,7 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
         NMF_LAUNCH_BWD_KERNEL((k_vm_bwd_brick<false, 1>));
 #undef NMF_LAUNCH_BWD_KERNEL
     if (use_copies)
-        hipLaunchKernelGGL(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, W.basis_copies, g_basis, clean ? 1 : 0);
+        NMF_LAUNCH(k_basis_reduce, dim3((unsigned)cdiv(AD * 3 * CA, 256)), dim3(256), 0, st, W.basis_copies, g_basis, clean ? 1 : 0);
     NMF_CHECK_LAUNCH("nmf_vm_query_bwd");
     return NMF_OK;
 }
