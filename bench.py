@@ -354,7 +354,7 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
     nb = len(batches)
     for i in range(warmup):
         trainer.step(*batches[i % nb], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
-                     global_rays=global_rays, next_rays=batches[(i + 1) % nb][0])
+                     global_rays=global_rays)
     sync()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
@@ -362,7 +362,7 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
     for i in range(warmup, warmup + steps):
         # (the loop knows its next batch, as train.py's permutation sampler does: the sampler of its first chunk is prefetched)
         last = trainer.step(*batches[i % nb], focal, noise=noise, update_controllers=False, fixed_chunk=chunk,
-                            global_rays=global_rays, next_rays=batches[(i + 1) % nb][0])
+                            global_rays=global_rays)
         first = first if first is not None else last
         rays_done += last["rays"]
         if last["comm_bytes"]:
@@ -374,6 +374,45 @@ def time_train(trainer, batches, focal, noise, warmup, steps, chunk, sync, globa
     # CPU time of THIS process over the timed steps (all its threads): what one rank needs of the host; 8 ranks on a node need 8 x
     last["host_cpu_ms_per_step"] = 1e3 * (time.process_time() - cpu0) / max(steps, 1)
     return dt, rays_done, last, (sum(comm_ms) / len(comm_ms) if comm_ms else None)
+
+
+def reference_style_step(nerf, optimizer, rays, rgb_gt, focal, params, noise, chunk, ori_lambda=None, pred_lambda=None):
+    """One optimizer step written the way the reference's own loop writes it (train.py:497-747): per chunk `nerf(...)` ->
+    (images, statistics), the loss assembled with plain torch operations from rgb_map and EVERY statistic the reference reads
+    (prediction / distortion / orientation terms, the three zero-weight regularisers, density_L1), `total_loss.backward()`, then
+    `optimizer.step()`.  Nothing of nmf_amd.trainer: this is what a maintainer gets who swaps the operator classes in under
+    train.py.  -> (rays used, n_samples of the last chunk, summed photometric loss as a tensor)"""
+    import torch
+    optimizer.zero_grad(set_to_none=True)
+    n_total = rays.shape[0]
+    lbatch = n_total
+    ori_lambda = params["ori_lambda"] if ori_lambda is None else ori_lambda
+    pred_lambda = params["pred_lambda"] if pred_lambda is None else pred_lambda
+    bg_col = torch.ones(3, device=rays.device)
+    used, n_samples, photo = 0, None, None
+    for s in range(0, n_total, chunk):
+        r, gt = rays[s:s + chunk], rgb_gt[s:s + chunk]
+        ims, st = nerf(r, focal, bg_col=bg_col, is_train=True, ndc_ray=False, noise=noise)
+        n_samples = st["n_samples"]
+        if n_samples[0] == 0:
+            continue
+        rgb_map = ims["rgb_map"].clip(max=1)
+        whole_valid = st["whole_valid"]
+        kept = rgb_map.shape[0]
+        assert whole_valid.shape[0] == r.shape[0]
+        gt_kept = gt[:kept]                       # (= rgb_train[whole_valid]: the kept rays are a prefix, alphagrid.py:353-364)
+        loss = ((rgb_map.clip(0, 1) - gt_kept.clip(0, 1)) ** 2).sum()
+        total = (loss + params.get("distortion_lambda", 0) * st["distortion_loss"].sum() + ori_lambda * st["ori_loss"].sum()
+                 + params.get("envmap_lambda", 0) * st["envmap_reg"].sum() + params.get("diffuse_lambda", 0) * st["diffuse_reg"].sum()
+                 + params.get("brdf_lambda", 0) * st["brdf_reg"].sum() + pred_lambda * st["prediction_loss"].sum())
+        if params["L1_weight_initial"] > 0:
+            total = total + params["L1_weight_initial"] * nerf.rf.density_L1()
+        total = total / lbatch
+        total.backward()
+        used += kept
+        photo = loss.detach() if photo is None else photo + loss.detach()
+    optimizer.step()
+    return used, n_samples, photo
 
 
 def make_batches(nerf, n, rays_per_gpu, rank, device, distinct=48):
@@ -534,19 +573,34 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
     nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
     # what a maintainer of the reference gets who swaps the operator classes in and keeps train.py's loop:
-    # TensorNeRF.forward builds the autograd graph, loss.backward() walks it, FusedAdam steps -- the same kernels without the
-    # tape-free pass (NMF_FAST_STEP=0), steady state, 4096 rays
-    prev = os.environ.get("NMF_FAST_STEP")
-    os.environ["NMF_FAST_STEP"] = "0"
-    try:
-        out["module_path"] = train_ms(nerf, CHUNK, 30, 8)
-        out["module_path"]["note"] = ("TensorNeRF.forward + backward() through torch.autograd + FusedAdam (the drop-in operator classes under "
-                                      "the reference's own training loop); `value` is the tape-free pass of nmf_amd/trainer.py")
-    finally:
-        if prev is None:
-            del os.environ["NMF_FAST_STEP"]
-        else:
-            os.environ["NMF_FAST_STEP"] = prev
+    # reference_style_step above -- TensorNeRF.forward, the loss in torch operations, total_loss.backward(), optimizer.step() --
+    # steady state, 4096 rays.  The forward / backward of a chunk enter the same C++ pass as `value` through ONE autograd node.
+    def reference_loop_ms(steps, warmup, fused):
+        from nmf_amd.optim import FusedAdam
+        nerf.fused_training_pass = fused
+        opt = FusedAdam(nerf.get_optparam_groups(), betas=tuple(params["betas"]), eps=params["eps"], weight_decay=params["weight_decay"])
+        batches, f = make_batches(nerf, steps + warmup, CHUNK, 0, device, distinct=12)
+        nz = DeviceNoise(device, seed=5)
+        for i in range(warmup):
+            reference_style_step(nerf, opt, *batches[i % len(batches)], f, params, nz, CHUNK)
+        sync()
+        t0 = time.perf_counter()
+        rays_done = 0
+        for i in range(warmup, warmup + steps):
+            used, n_samples, _ = reference_style_step(nerf, opt, *batches[i % len(batches)], f, params, nz, CHUNK)
+            rays_done += used
+        sync()
+        dt = time.perf_counter() - t0
+        nerf.fused_training_pass = True
+        return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=n_samples, steps=steps, rays_per_step=CHUNK)
+
+    out["reference_loop"] = reference_loop_ms(60, 20, True)
+    out["reference_loop"]["note"] = ("the loop of the reference's train.py:497-747 (bench.reference_style_step: TensorNeRF.forward, loss in torch "
+                                     "operations incl. every statistic train.py reads, total_loss.backward(), FusedAdam.step()) on the drop-in "
+                                     "operator classes: one autograd node per chunk over the C++ pass; `value` is nmf_amd.trainer.Trainer")
+    out["module_path"] = reference_loop_ms(30, 8, False)
+    out["module_path"]["note"] = ("the same loop with nerf.fused_training_pass = False: the autograd operator graph of nmf_amd/functional.py "
+                                  "(what rounds 1-4 delivered to that loop)")
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
@@ -723,8 +777,7 @@ def main():
     for i in range(args.warmup):
         if n_probe and i == args.warmup - n_probe:
             fx.kernel_timing_begin()                # the last warm-up steps find the dominant KERNEL of this workload
-        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
-                         next_rays=batches[(i + 1) % len(batches)][0])
+        trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
     if n_probe:
         probe = {k: v for k, v in fx.kernel_timing_end().items() if not k.startswith("@")}
         dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
@@ -756,8 +809,7 @@ def main():
         main_id = torch.cuda.current_stream().cuda_stream
         fx.kernel_timing_begin()
         for i in range(n_inst):
-            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays,
-                         next_rays=batches[(i + 1) % len(batches)][0])
+            trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
         timing = fx.kernel_timing_end()
         if f"@{main_id}" in timing:
             main_stream_us = 1e3 * timing[f"@{main_id}"][0] / n_inst

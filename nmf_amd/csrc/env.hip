@@ -1157,14 +1157,11 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     A.ntx = ntx; A.nt = ntx * nty;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(EnvBinHeader), st);
     if (e != hipSuccess) return nmf_fail((int)e, "nmf_sat_lookup_bwd_binned: hipMemsetAsync");
-    // shares of the dual-number workgroups next to the three passes.  Measured on the 247 k lookups of a steady-state step
-    // (tools/env_bwd_bench.py, us).  With pass 2 walking every footprint twice: all behind pass 3 155, 30/40/30 156, 50/50/0 144,
-    // all next to pass 2 138 (direct scatter 176).  Since pass 1 hands out the record ranges and pass 2 walks once (81 us
-    // without riders): all next to pass 2 111, 50/50/0 101, 80/20/0 104, all next to pass 1 -- LDS counting only, the
-    // riders' arithmetic fills it -- 98.  NMF_ENV_RIDERS="p1,p2": percent next to passes 1 / 2 (the rest: pass 3)
-    int split1 = 100, split2 = 0;
-    if (const char* e = getenv("NMF_ENV_RIDERS")) sscanf(e, "%d:%d", &split1, &split2);      // (read per call: tools/ab_inprocess.py)
-    split1 = std::min(std::max(split1, 0), 100); split2 = std::min(std::max(split2, 0), 100);
+    // The dual-number workgroups (d_dirs, d_mipbias) ride next to the COUNTING pass: that pass is LDS counting only, the riders'
+    // arithmetic fills it.  Measured on the 247 k lookups of a steady-state step (tools/env_bwd_bench.py, us): all next to pass 1
+    // 98, 50 / 50 next to passes 1 / 2 101, 80 / 20 104, all next to pass 2 111, all behind pass 3 155 (direct scatter: 176).
+    // (Round 4 read the split from the environment on every call; the measurement is in, the split is fixed.)
+    const int split1 = 100, split2 = 0;
     const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = nb - d1 - d2;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
     if (layout == 1) {

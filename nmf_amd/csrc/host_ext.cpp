@@ -1232,14 +1232,18 @@ PYBIND11_MODULE(_nmf_host, m) {
     py::class_<StepCore>(m, "StepCore")
         .def(py::init<>())
         .def("chunk", &StepCore::chunk)
+        .def("train_forward", &StepCore::train_forward)
+        .def("train_backward", &StepCore::train_backward)
+        .def("has_pending", &StepCore::has_pending)
+        .def("drop_pending", &StepCore::drop_pending)
         .def("render", &StepCore::render)
         .def("begin_step", &StepCore::begin_step)
         .def("join_early_env", &StepCore::join_early_env)
         .def("env_was_used", &StepCore::env_was_used)
         .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
 #define RW(name) .def_readwrite(#name, &StepCore::name)
-        RW(next_rays) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
-        RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(walk_late) RW(launch_diet) RW(mlp_side_wgs)
+        RW(env_keep_sat) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
+        RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
         RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws) RW(mlp_image)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)
         RW(max_samples) RW(alpha_bits) RW(alpha_coarse) RW(scale) RW(anoise) RW(min_rough) RW(rays_per_ray) RW(test_rays_per_ray)

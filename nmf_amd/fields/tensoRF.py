@@ -349,8 +349,11 @@ class TensorVMSplit(FastPrivateAttrs, torch.nn.Module):
 
     def density_L1(self, with_pass=False):
         """fields/tensoRF.py:332-340.  with_pass: the caller adds this term to the loss of the rendering pass that has just
-        been evaluated (the trainer does), so its gradient can ride on that pass's table-gradient node."""
-        holder = self._last_holder if with_pass else None
+        been evaluated (the trainer does), so its gradient can ride on that pass's table-gradient node.  After a training forward
+        through the fused pass (TensorNeRF.fused_training_pass) the term always rides on that chunk's node -- the reference's loop
+        adds it to the chunk's loss (train.py:672-677), and the node writes .grad itself."""
+        h = self._last_holder
+        holder = h if (with_pass or (h is not None and getattr(h, "chunk_pass", False) and not h.done and h.l1 is None)) else None
         return L1Mean.apply(holder, *self.density_rf.app_plane, *self.density_rf.app_line)
 
     @torch.no_grad()

@@ -1,7 +1,7 @@
 """BRDF MLP -- host-side mirror of the reference's modules/brdf.py (MLPBRDF :72-261) for the
 microfacet_tensorf2 configuration (feape=0, dotpe=-1, h/d encoders = ListISH([0,1,2,4]), 66 -> 64 -> 64 -> 4).
 Feature build (gather + two ISH encodings) and the three dense layers are ONE fused kernel (nmf_brdf_mlp_fwd / _bwd:
-v_mfma_f32_32x32x2_f32 tiles); `forward` keeps the reference's per-ray signature, `forward_compact` is what the hot path
+v_mfma_f32_32x32x16_bf16 tiles on split-bf16 operands, fp32-class accuracy: csrc/brdf_mlp.hip); `forward` keeps the reference's per-ray signature, `forward_compact` is what the hot path
 calls (per-row features / roughness gathered inside the kernel)."""
 import torch
 

@@ -2,6 +2,8 @@
 sample -> density -> weights -> appearance + normals -> microfacet shading (recursive) -> composite ->
 tonemap, with the same constructor keywords, __call__ signature, returned image / statistics keys and
 state_dict layout.  Every stage runs on the compact sample list produced by the HIP sampler."""
+import os
+
 import torch
 
 from .. import hip
@@ -37,6 +39,14 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         self.align_pred_norms = use_predicted_normals | align_pred_norms
         self.orient_world_normals = orient_world_normals | (not self.align_pred_norms)
         self._noise = None
+        # One training chunk as ONE autograd node over the C++ pass (nmf_amd/fast_step.py: ChunkPass over csrc/step_core.inc) whenever
+        # the call is the training forward of microfacet_tensorf2.yaml; False: always the operator graph of nmf_amd/functional.py.
+        self.fused_training_pass = True
+        # The regulariser statistics envmap_reg / brdf_reg / diffuse_reg (modules/tensor_nerf.py:600-649) need the material heads on
+        # EVERY sample; the fused pass evaluates them on the bounce rows only and reports 0 for the three (their weights are 0 in
+        # microfacet_tensorf2.yaml:208-214).  True: the operator graph, which evaluates them (differentiably) on first read.
+        self.regulariser_stats = False
+        self._fused_pass = None
 
     def get_device(self):
         return self.rf.units.device
@@ -112,6 +122,13 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
                 override_near=None, output_alpha=None, dynamic_batch_size=True, gt_normals=None,
                 override_alpha_thres=None, is_train=False, ndc_ray=False, N_samples=-1, tonemap=True, draw_debug=True,
                 max_weight_N=-1, noise=None):
+        if (recur == 0 and is_train and self.fused_training_pass and not self.regulariser_stats and rays.is_cuda
+                and torch.is_grad_enabled() and start_mipval is None and stepmul == 1 and override_near is None and output_alpha is None
+                and dynamic_batch_size and gt_normals is None and override_alpha_thres is None and not ndc_ray and N_samples == -1
+                and tonemap and max_weight_N == -1 and bg_col is not None and os.environ.get("NMF_FAST_STEP", "1") != "0"):
+            out = self._forward_fused(rays, focal, bg_col, noise)
+            if out is not None:
+                return out
         if recur == 0:          # one gradient pass: primary and re-traced rays share the table-gradient nodes
             passes = [m for m in (self.rf, self.bg_module, getattr(self.model, "brdf", None),
                                   getattr(self.model, "diffuse_module", None)) if hasattr(m, "begin_pass")]
@@ -144,6 +161,40 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         return self._render(rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
                             dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples, tonemap,
                             draw_debug, max_weight_N, noise)
+
+    def _forward_fused(self, rays, focal, bg_col, noise):
+        """the training forward as ONE autograd node (fast_step.ChunkPass): -> (images, stats) like _render, or None when the pass
+        does not cover this call (configuration, no host extension, a chunk without a bounce row): the caller then builds the
+        operator graph.  What a training loop reads of the result (train.py:541-577): rgb_map, whole_valid, n_samples, ori_loss,
+        prediction_loss -- and the three zero-weight regularisers, see regulariser_stats."""
+        from ..fast_step import TrainPass, Unsupported
+        tp = self._fused_pass
+        if tp is None:
+            tp = self._fused_pass = TrainPass(self)
+        if not tp.supported():
+            return None
+        dev = rays.device
+        if noise is None:
+            if self._noise is None:
+                self._noise = DeviceNoise(dev, seed=20211200)
+            noise = self._noise
+        c = tp.core()
+        bg = bg_col.detach().to(device=dev, dtype=torch.float32).reshape(1, 3)
+        c.white = bg                                # (the background colour of the primary rays; the Trainer passes white)
+        try:
+            res = tp.forward_autograd(rays if rays.is_contiguous() else rays.contiguous(), focal, noise)
+        except Unsupported:
+            return None
+        if res is None:                             # no sample kept (train.py:567-568 skips the chunk): background only, the module
+            return None
+        rgb_map, acc_map, ori, out = res
+        stats = dict(recur=0, whole_valid=out["whole_valid"], n_samples=list(out["n_samples"]), rays_kept=int(out["kept"]),
+                     ori_terms=ori, acc_terms=acc_map)
+        stats = LazyStats(stats, self, None, None, int(out["n_samples"][0]))
+        images = LazyImages(None)
+        images["rgb_map"] = rgb_map
+        images["acc_map"] = acc_map.detach()
+        return images, stats
 
     def _render(self, rays, focal, start_mipval, bg_col, stepmul, recur, override_near, output_alpha,
                 dynamic_batch_size, gt_normals, override_alpha_thres, is_train, ndc_ray, N_samples, tonemap, draw_debug,
@@ -258,13 +309,15 @@ class LazyStats(dict):
         if key not in self._LAZY:
             raise KeyError(key)
         nerf, shaded, weight, M = self._src
-        dev = weight.device
+        dev = self["acc_terms"].device if weight is None else weight.device
         if key == "ori_loss":
             ori = self["ori_terms"]
             v = ori.sum() if ori is not None else torch.zeros((), device=dev)
         elif key == "prediction_loss":
             v = 2.0 * self["acc_terms"].sum()
         elif key == "distortion_loss":
+            v = torch.zeros((), device=dev)
+        elif shaded is None:        # the fused training pass (TensorNeRF.regulariser_stats): the three zero-weight regularisers
             v = torch.zeros((), device=dev)
         elif key == "envmap_reg":
             v = (nerf.bg_module.mean_color().mean() - 0.05).clip(min=0)
@@ -293,7 +346,8 @@ class LazyImages(dict):
 
     def __missing__(self, key):
         if self._shaded is None:
-            raise KeyError(key)
+            raise KeyError(f"{key}: the fused training pass returns rgb_map / acc_map only (what train.py:541-577 reads); set "
+                           "nerf.fused_training_pass = False for the per-sample debug maps of a training forward")
         d = self._shaded.debug()
         if key not in d:
             raise KeyError(key)

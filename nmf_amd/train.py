@@ -3,6 +3,7 @@ synthetic "S2 orbit" data set (nerf_synthetic is not available off
 rendered from the S1 scene itself (eval mode), then a freshly initialised model is fitted to them.
 
     python -m nmf_amd.train model=microfacet_tensorf2 field=tensorf_og dataset=lego datadir=/data expname=lego [a.b.c=value ...]
+    python -m nmf_amd.train -m expname=v38 model=microfacet_tensorf2 dataset=ficus,drums,ship datadir=/data     (hydra multirun, README.md:10)
     python -m nmf_amd.train --iters 200 --views 24 --res 64 [--grid 64] [--eval-every 100]
     python -m nmf_amd.train --datadir /data/nerf_synthetic/lego --near-far 2.5 7 --iters 30000 --grid 128 --bg 512
     python -m torch.distributed.run --nproc-per-node N -m nmf_amd.train ...        (data parallel, RCCL)
@@ -11,8 +12,9 @@ The first form is the reference's hydra command line (train.py:904-921): `group=
 nmf_amd/yaml_config.py -- from the built-in tree of nmf_amd/config.py (the values of configs/default.yaml, model/
 microfacet_tensorf2.yaml, field/tensorf_og.yaml, dataset/<scene>.yaml) or, with --config-dir, from a configs/ directory such as
 the reference's --, the model is built by `instantiate_arch` from the composed `model.arch` (`_target_` / `_partial_`,
-train.py:239-247), the trainer reads `model.params`, and the resolved config is written to <basedir>/<expname>/config.yaml
-(train.py:485).  The flags of the other forms are shorthands for overrides of the same tree (--grid = field.grid_size, --bg =
+train.py:239-247), the trainer reads `model.params`, and the resolved config is written to <basedir>/<scene>_<expname>/config.yaml
+(train.py:193,226,485).  `-m` / `--multirun`: every comma-separated override value spans an axis and the runs of the product are carried
+out one after the other in this process (hydra's basic sweeper); each writes its own <scene>_<expname> folder.  The flags of the other forms are shorthands for overrides of the same tree (--grid = field.grid_size, --bg =
 model.arch.bg_module.bg_resolution, ...); dataset=s2_orbit (the default without a data directory) is the offline stand-in.
 
 With --datadir the rays and colours come from a Blender / nerf_synthetic scene directory (nmf_amd/dataLoader/blender.py,
@@ -45,9 +47,9 @@ def compose_run(args, overrides):
     """argparse flags + hydra-style tokens -> the resolved config of the run (flags are shorthands for overrides)"""
     ov = []
     if args.datadir:
-        # a scene directory given directly: the dataset entry points at it (the reference splits it into datadir / scenedir)
-        ov += ["dataset=lego", f"datadir={os.path.dirname(os.path.abspath(args.datadir)) or '/'}",
-               f"dataset.scenedir={os.path.basename(os.path.abspath(args.datadir))}"]
+        # a scene directory given directly: the dataset entry points at it (the reference splits it into datadir / scenedir; the two
+        # paths are set on the composed tree below -- file-system paths do not go through the YAML value parser: '007' is not 7)
+        ov += ["dataset=lego"]
         if args.near_far:
             ov.append(f"dataset.near_far=[{args.near_far[0]},{args.near_far[1]}]")
         if args.downsample != 1.0:
@@ -66,7 +68,11 @@ def compose_run(args, overrides):
         ov.append(f"N_vis={args.test_views}")
     if args.res is not None:
         ov.append(f"dataset.res={args.res}")
-    return yaml_config.compose(args.config_dir, ov + list(overrides))
+    cfg = yaml_config.compose(args.config_dir, ov + list(overrides))
+    if args.datadir:
+        path = os.path.abspath(args.datadir)
+        cfg["datadir"], cfg["dataset"]["scenedir"] = os.path.dirname(path) or "/", os.path.basename(path)
+    return cfg
 
 
 def main(argv=None):
@@ -92,18 +98,32 @@ def main(argv=None):
                     help="weak scaling: every rank takes this many rays per optimizer step (BASELINE configs[3]: 32768), "
                          "processed in num_rays chunks; default: the reference's lbatch_size split over the ranks")
     ap.add_argument("--no-config-file", action="store_true", help="do not write <basedir>/<expname>/config.yaml")
+    ap.add_argument("-m", "--multirun", action="store_true",
+                    help="hydra multirun (README.md:10): comma-separated override values span a sweep, run job by job")
     ap.add_argument("overrides", nargs="*", help="hydra-style tokens: group=name, a.b.c=value")
     args = ap.parse_args(argv)
     for o in args.overrides:
         if "=" not in o:
             ap.error(f"'{o}': overrides are key=value tokens (hydra syntax)")
+    if args.multirun:
+        # the product of the comma-separated values, in hydra's order (the last axis varies fastest); one job after the other
+        jobs = [combo for combo, _cfg in yaml_config.sweep(args.config_dir, args.overrides)]
+        flags = [a for a in (argv if argv is not None else os.sys.argv[1:]) if a not in ("-m", "--multirun") and a not in args.overrides]
+        done = []
+        for i, combo in enumerate(jobs):
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(json.dumps(dict(multirun_job=i, of=len(jobs), overrides=combo)), flush=True)
+            done.append(main(flags + list(combo)))
+        return done
     cfg = compose_run(args, args.overrides)
-    shorthand = not args.overrides and args.config_dir is None       # the flag forms: synthetic defaults as before
-    if shorthand and not args.datadir:
+    shorthand = not args.overrides and args.config_dir is None       # the flag forms: small defaults (grid 64^3, env 128 x 256, 4 test views)
+    if shorthand:
         if args.grid is None:
             cfg["field"]["grid_size"] = cfg["model"]["arch"]["rf"]["grid_size"] = [64, 64, 64]
         if args.bg is None:
             cfg["model"]["arch"]["bg_module"]["bg_resolution"] = 128
+        if args.test_views is None and args.datadir:
+            cfg["N_vis"] = 4
     ds = cfg["dataset"]
     params = cfg["model"]["params"]
     n_iters = args.iters if args.iters is not None else (200 if shorthand else int(params["n_iters"]))
@@ -121,7 +141,9 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group(backend=os.environ.get("NMF_BACKEND", "nccl"))
 
-    logfolder = os.path.join(str(cfg["basedir"]), str(cfg["expname"]))
+    # train.py:193,226: <basedir>/<last component of the scene directory>_<expname>
+    expname = f"{str(ds.get('scenedir') or ds['dataset_name']).split('/')[-1]}_{cfg['expname']}"
+    logfolder = os.path.join(str(cfg["basedir"]), expname)
     if rank == 0 and not args.no_config_file and not shorthand:
         os.makedirs(logfolder, exist_ok=True)
         yaml_config.dump(cfg, os.path.join(logfolder, "config.yaml"))                     # train.py:485
@@ -206,7 +228,7 @@ def main(argv=None):
                                       retrace=nerf.model.max_retrace_rays, n_samples=out["n_samples"])), flush=True)
     save = args.save
     if save is None and not shorthand and not args.no_config_file:
-        save = os.path.join(logfolder, f"{cfg['expname']}.th")                              # train.py:856 (tensorf.save)
+        save = os.path.join(logfolder, f"{expname}.th")                                     # train.py:856 (tensorf.save)
     if save and rank == 0:
         arch = cfg["model"]["arch"]
         arch["model"]["brdf"]["bias"] = nerf.model.brdf.bias                        # calibrated values (train.py:429-437)

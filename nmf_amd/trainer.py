@@ -260,7 +260,10 @@ class Trainer:
         self.ori_decay = math.exp(math.log(fo / self.ori_lambda) / n_it) if self.ori_lambda > 0 and fo is not None else 1.0
         self.pred_decay = math.exp(math.log(fp / self.pred_lambda) / n_it) if self.pred_lambda > 0 and fp is not None else 1.0
         self._make_optimizer()
-        # tape-free training pass (nmf_amd/fast_step.py): same kernels, no autograd engine; NMF_FAST_STEP=0 keeps autograd
+        # tape-free training pass (nmf_amd/fast_step.py over csrc/step_core.inc): forward + loss head + backward of a chunk in one C++
+        # call.  NMF_FAST_STEP=0: every chunk goes through TensorNeRF.forward + backward() instead -- the loop of the reference's
+        # train.py, which enters the same C++ pass through ONE autograd node per chunk (or, with nerf.fused_training_pass = False, the
+        # operator graph of nmf_amd/functional.py)
         self.fast = None
         if os.environ.get("NMF_FAST_STEP", "1") != "0":
             from .fast_step import TrainPass
@@ -293,7 +296,7 @@ class Trainer:
         return self.batch.lbatch_size()
 
     def step(self, rays, rgb_gt, focal, noise=None, update_controllers=True, fixed_chunk=None, global_rays=None,
-             fetch=None, trace=None, next_rays=None):
+             fetch=None, trace=None):
         """One optimizer step over this rank's rays (train.py:497-747).  rays [n,6], rgb_gt [n,3] (already blended
         onto the background colour, train.py:525-530).  `global_rays`: the loss normaliser `lbatch_size` of train.py:703,
         i.e. the number of rays ALL ranks process in this step (default: n * world_size, equal shards).
@@ -301,9 +304,6 @@ class Trainer:
         train.py:509-512 (`trainingSampler.nextids(lnum_rays)` per chunk, so a re-permutation can fall inside a step);
         `n` = this rank's share of the step (rays.shape[0] when rays is given, else lbatch_size()).
         `trace`: list that receives one record per chunk (num_rays, rays in / kept, n_samples, loss, max_retrace_rays).
-        `next_rays`: the rays of the NEXT call, if the loop already knows them (its batches are drawn from a permutation that does
-        not depend on the step): the alpha-grid march of their first chunk is issued behind this step's backward, off the next
-        step's critical path (same samples: csrc/step_core.inc prefetch_sample).
         Returns a stats dict (python scalars)."""
         p = self.p
         nerf = self.nerf
@@ -330,13 +330,9 @@ class Trainer:
                 trace.append(dict(num_rays=chunk, rays_in=int(r.shape[0]), max_retrace=list(nerf.model.max_retrace_rays)))
             if fast is not None:
                 try:
-                    nxt = None
-                    if next_rays is not None and pos >= n_total:
-                        n_first = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
-                        nxt = next_rays[:n_first]
                     out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
                                      (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
-                                     want_total=trace is not None, last=pos >= n_total, next_rays=nxt)
+                                     want_total=trace is not None, last=pos >= n_total)
                 except Unsupported:
                     out = None                      # this chunk goes through the autograd path below
                 if out is not None:

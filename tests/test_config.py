@@ -156,3 +156,21 @@ def test_train_cli_composes_hydra_tokens_and_flags():
     cfg = T.compose_run(a, [])
     assert os.path.join(cfg["datadir"], cfg["dataset"]["scenedir"]) == "/tmp/scenes/lego" and cfg["dataset"]["near_far"] == [2.0, 6.0]
     assert cfg["model"]["arch"]["rf"]["grid_size"] == [16, 16, 16] and cfg["model"]["arch"]["bg_module"]["bg_resolution"] == 32
+
+
+def test_datadir_flag_is_not_parsed_as_yaml_and_multirun_axes():
+    """`--datadir /data/007` must open /data/007 (the YAML value parser reads '007' as 7, 'yes' as True, 'a: b' as a
+    mapping); `-m` sweeps are the product of the comma-separated values in hydra's order (README.md:10)."""
+    import argparse
+    from nmf_amd import train as T
+    from nmf_amd import yaml_config as yc
+    ns = argparse.Namespace(datadir="/data/007", near_far=None, downsample=1.0, grid=None, bg=None, seed=None, views=None,
+                            test_views=None, res=None, config_dir=None)
+    cfg = T.compose_run(ns, [])
+    assert cfg["datadir"] == "/data" and cfg["dataset"]["scenedir"] == "007" and cfg["dataset"]["dataset_name"] == "blender"
+    for name in ("yes", "1e3", "0x10", "null", "a: b", "[x"):
+        ns.datadir = "/data/" + name
+        assert T.compose_run(ns, [])["dataset"]["scenedir"] == name
+    jobs = [c for c, _ in yc.sweep(None, ["expname=v", "dataset=ficus,drums,ship", "model.arch.model.rays_per_ray=16,32"])]
+    assert len(jobs) == 6 and jobs[0] == ["expname=v", "dataset=ficus", "model.arch.model.rays_per_ray=16"]
+    assert jobs[1][2].endswith("=32") and jobs[2][1] == "dataset=drums"

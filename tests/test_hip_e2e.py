@@ -34,6 +34,10 @@ def _build(g, is_train=True):
     nerf.model.diffuse_module.roughness_bias = g["roughness_bias"]
     nerf.train(is_train)
     nerf.sampler.update(nerf.rf, init=True)
+    # these fixtures hold per-sample debug maps, regulariser values and the gradients of every parameter: the operator graph of
+    # nmf_amd/functional.py (the fused training pass is checked against the same reference runs by tests/test_hip_timed_path.py and
+    # against this graph by test_tape_free_training_pass_equals_autograd_path)
+    nerf.fused_training_pass = False
     return nerf, sd
 
 
@@ -171,6 +175,7 @@ def _full_size_model(g):
     nerf.sampler.update(nerf.rf, init=True)
     assert int(nerf.sampler.alphaMask.alpha_volume.sum()) == g["n_alpha"]
     nerf.model.detach_N = False
+    nerf.fused_training_pass = False          # (the operator graph: see _build)
     return nerf
 
 
@@ -659,13 +664,14 @@ def test_hydra_command_line_builds_the_model_and_trains(tmp_path, capsys):
     line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
     rec = _json.loads(line)
     assert rec["iteration"] == 3 and np.isfinite(rec["test_psnr"])
-    written = yaml_config._load(os.path.join(base, "run", "config.yaml"))
+    # (train.py:193,226: the log folder is <scene>_<expname>; the synthetic stand-in has no scene directory: its dataset_name)
+    written = yaml_config._load(os.path.join(base, "synthetic_orbit_run", "config.yaml"))
     want = yaml_config.compose(None, ["dataset=s2_orbit", "field.grid_size=[16,16,16]", "model.arch.bg_module.bg_resolution=16",
                                       "dataset.views=3", "dataset.res=16", "dataset.test_views=1",
                                       "model.arch.model.rays_per_ray=16", f"basedir={base}", "expname=run"])
     assert written == want and written["model"]["arch"]["rf"]["grid_size"] == [16, 16, 16]
     assert got["model"]["arch"]["model"]["brdf"]["bias"] != 0                # the calibrated biases went into the saved config
-    nerf = TensorNeRF.load(os.path.join(base, "run", "run.th"), near_far=[2.5, 7.0], device=DEV)
+    nerf = TensorNeRF.load(os.path.join(base, "synthetic_orbit_run", "synthetic_orbit_run.th"), near_far=[2.5, 7.0], device=DEV)
     assert int(nerf.rf.density_rf.app_plane[0].shape[-1]) == 16 and nerf.model.rays_per_ray == 16
 
 
@@ -696,7 +702,40 @@ def test_scene_in_nerf_synthetic_format_trains_from_the_command_line(tmp_path, c
     recs = [_json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
     assert [r["iteration"] for r in recs] == [30, 60]
     assert np.isfinite(recs[-1]["test_psnr"]) and recs[-1]["test_psnr"] > recs[0]["test_psnr"] - 0.5 and recs[-1]["test_psnr"] > 12.0
-    assert os.path.exists(tmp_path / "log" / "s1" / "config.yaml") and os.path.exists(tmp_path / "log" / "s1" / "s1.th")
+    assert os.path.exists(tmp_path / "log" / "lego_s1" / "config.yaml") and os.path.exists(tmp_path / "log" / "lego_s1" / "lego_s1.th")
+
+
+def test_hydra_multirun_runs_the_sweep_job_by_job(tmp_path, capsys):
+    """`python train.py -m expname=... dataset=a,b ...` (README.md:10, hydra's basic sweeper): the comma-separated values span the
+    sweep, the jobs run one after the other, each into its own <scene>_<expname> folder (train.py:193,226), a path-like directory
+    name that YAML would read as a number stays a string."""
+    import importlib.util
+    import json as _json
+    from nmf_amd import train as T
+    spec = importlib.util.spec_from_file_location("make_blender_scene", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                                     "tools", "make_blender_scene.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for scene in ("lego", "ship"):
+        mk.main(["--out", str(tmp_path / "nerf_synthetic" / scene), "--views", "4", "--test-views", "1", "--res", "24", "--grid", "16",
+                 "--bg", "16"])
+    capsys.readouterr()
+    cfgs = T.main(["-m", "expname=sweep", "dataset=lego,ship", f"datadir={tmp_path}", "field.grid_size=[16,16,16]",
+                   "model.arch.bg_module.bg_resolution=16", "model.arch.model.rays_per_ray=16,32", "N_vis=1",
+                   f"basedir={tmp_path / 'log'}", "--iters", "2", "--eval-every", "2"])
+    out = [_json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    jobs = [r for r in out if "multirun_job" in r]
+    assert len(cfgs) == 4 and [j["multirun_job"] for j in jobs] == [0, 1, 2, 3]
+    assert [(c["dataset"]["scenedir"].split("/")[-1], c["model"]["arch"]["model"]["rays_per_ray"]) for c in cfgs] == \
+        [("lego", 16), ("lego", 32), ("ship", 16), ("ship", 32)]
+    assert len([r for r in out if r.get("iteration") == 2]) == 4
+    for scene in ("lego", "ship"):
+        assert os.path.exists(tmp_path / "log" / f"{scene}_sweep" / "config.yaml")
+    # --datadir: the two path components are set on the composed tree, not parsed as YAML values
+    num = tmp_path / "007"
+    mk.main(["--out", str(num), "--views", "3", "--test-views", "1", "--res", "16", "--grid", "16", "--bg", "16"])
+    cfg = T.main(["--datadir", str(num), "--iters", "1", "--eval-every", "1", "--grid", "16", "--bg", "16", "--no-config-file"])
+    assert cfg["dataset"]["scenedir"] == "007" and cfg["datadir"] == str(tmp_path) and cfg["N_vis"] == 4
 
 
 def test_train_cli_on_a_blender_scene(tmp_path, capsys):
@@ -1011,6 +1050,71 @@ def test_tape_free_training_pass_equals_autograd_path(phase):
             setattr(fast_step, name, v)
 
 
+def test_reference_style_loop_enters_the_fused_pass_and_accumulates_like_autograd():
+    """The reference's own training loop (train.py:497-747, restated in bench.reference_style_step: forward, the loss in plain torch
+    operations from every statistic train.py reads, density_L1, backward(), optimizer.step()) on the drop-in TensorNeRF: every chunk
+    is ONE ChunkPass node over the C++ pass, and the gradients left in .grad after two chunks of one optimizer step equal the ones
+    Trainer.step hands to Adam for the same chunks and noise -- including the density_L1 term that rides on the node and the
+    accumulation over the chunks without a zero_grad in between.  Then the foreign-gradient case: a tensor somebody else put into
+    .grad before the backward is added to, not overwritten."""
+    import bench
+    from nmf_amd import fast_step
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    grads, calls = {}, []
+    grid_saved = bench.GRID
+    for mode in ("trainer", "loop", "loop_foreign"):
+        try:
+            bench.GRID = 64
+            torch.manual_seed(3)
+            nerf, params = bench.build(dev)
+        finally:
+            bench.GRID = grid_saved
+        tr = Trainer(nerf, params)
+        tr.optimizer.step = lambda: None
+        rays, focal = synthetic.camera_rays(2048, seed=21)
+        rays = rays.to(dev)
+        gt = torch.rand(2048, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+        noise = DeviceNoise(dev, seed=77, pooled=False)
+        if mode == "trainer":
+            out = tr.step(rays, gt, focal, noise=noise, update_controllers=False, fixed_chunk=1024)
+            assert out["chunks"] == 2
+        else:
+            orig = fast_step.ChunkPass.backward
+            fast_step.ChunkPass.backward = staticmethod(lambda ctx, *g: (calls.append(mode), orig(ctx, *g))[1])
+            try:
+                if mode == "loop_foreign":
+                    extra = {k: torch.full_like(p, 0.25) for k, p in nerf.named_parameters()
+                             if k in ("rf.basis_mat.weight", "model.brdf.mlp.0.weight", "rf.density_rf.app_line.0")}
+                    zero = tr.optimizer.zero_grad
+                    def zero_then_seed(set_to_none=True):
+                        zero(set_to_none=set_to_none)
+                        for k, p in nerf.named_parameters():
+                            if k in extra:
+                                p.grad = extra[k].clone()
+                    tr.optimizer.zero_grad = zero_then_seed
+                used, n_samples, photo = bench.reference_style_step(nerf, tr.optimizer, rays, gt, focal, params, noise, 1024)
+            finally:
+                fast_step.ChunkPass.backward = orig
+            assert used == 2048 and len(n_samples) == 2
+        grads[mode] = {k: p.grad.detach().clone() for k, p in nerf.named_parameters() if p.grad is not None}
+    assert calls.count("loop") == 2 and calls.count("loop_foreign") == 2, calls          # one node per chunk, both ran
+    ref = grads["trainer"]
+    for mode in ("loop", "loop_foreign"):
+        got = grads[mode]
+        assert set(ref) <= set(got), set(ref) - set(got)
+        for k, a in ref.items():
+            f = got[k].double()
+            if mode == "loop_foreign" and k in ("rf.basis_mat.weight", "model.brdf.mlp.0.weight", "rf.density_rf.app_line.0"):
+                # (the sum 0.25 + g was formed in fp32: 3e-8 absolute per element)
+                err = float((f - 0.25 - a.double()).abs().max())
+                assert err <= 1e-7 + 2e-5 * float(a.abs().max()), (mode, k, err)
+                continue
+            rel = float((a.double() - f).norm() / a.double().norm().clip(min=1e-30))
+            assert rel <= 2e-5, (mode, k, rel)
+
+
 def _tape_free_vs_autograd(phase):
     import bench
     from nmf_amd.noise import DeviceNoise
@@ -1018,7 +1122,7 @@ def _tape_free_vs_autograd(phase):
     dev = torch.device("cuda", 0)
     grid_saved = bench.GRID
     grads = {}
-    for mode in ("autograd", "tape_free"):
+    for mode in ("autograd", "tape_free", "node"):
         try:
             bench.GRID = 128 if phase == "steady_full" else 64
             torch.manual_seed(3)
@@ -1029,8 +1133,12 @@ def _tape_free_vs_autograd(phase):
             nerf.model.max_retrace_rays = [1500]
         nerf.model.detach_N = phase == "steady_detachN"
         tr = Trainer(nerf, params)
-        if mode == "autograd":
+        if mode == "autograd":            # TensorNeRF.forward builds the operator graph of nmf_amd/functional.py
             tr.fast = None
+            nerf.fused_training_pass = False
+        elif mode == "node":              # TensorNeRF.forward + backward(): the C++ pass as ONE autograd node per chunk (the path of
+            tr.fast = None                # the reference's own training loop)
+            assert nerf.fused_training_pass
         else:
             assert tr.fast is not None and tr.fast.supported()
         tr.optimizer.step = lambda: None                      # keep the gradients, leave the parameters alone
@@ -1042,15 +1150,17 @@ def _tape_free_vs_autograd(phase):
         assert out["chunks"] == (2 if phase == "two_chunks" else 1)
         grads[mode] = ({k: p.grad.detach().clone() for k, p in nerf.named_parameters() if p.grad is not None},
                        out["n_samples"], out["loss"], out["rays"])
-    ga, gf = grads["autograd"], grads["tape_free"]
-    assert ga[1] == gf[1] and ga[3] == gf[3], (ga[1], gf[1])
-    assert abs(ga[2] - gf[2]) <= 1e-5 * abs(ga[2]), (ga[2], gf[2])
-    for k in ga[0]:
-        a, f = ga[0][k], gf[0].get(k)
-        if f is None:                                         # lr-0 scalars are not produced by the tape-free pass
-            assert k in ("bg_module.brightness", "bg_module.mul"), k
-            continue
-        assert a.shape == f.shape and a.stride() == f.stride(), (k, a.stride(), f.stride())
-        rel = float((a.double() - f.double()).norm() / a.double().norm().clip(min=1e-30))
-        assert rel <= 2e-5, (k, rel)
-    assert set(gf[0]) <= set(ga[0])
+    ga = grads["autograd"]
+    for other in ("tape_free", "node"):
+        gf = grads[other]
+        assert ga[1] == gf[1] and ga[3] == gf[3], (other, ga[1], gf[1])
+        assert abs(ga[2] - gf[2]) <= 1e-5 * abs(ga[2]), (other, ga[2], gf[2])
+        for k in ga[0]:
+            a, f = ga[0][k], gf[0].get(k)
+            if f is None:                                         # lr-0 scalars are not produced by the tape-free pass
+                assert k in ("bg_module.brightness", "bg_module.mul"), (other, k)
+                continue
+            assert a.shape == f.shape and a.stride() == f.stride(), (other, k, a.stride(), f.stride())
+            rel = float((a.double() - f.double()).norm() / a.double().norm().clip(min=1e-30))
+            assert rel <= 2e-5, (other, k, rel)
+        assert set(gf[0]) <= set(ga[0])

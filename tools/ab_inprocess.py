@@ -86,10 +86,10 @@ def main():
         if hi is not None:
             with torch.cuda.stream(hi):
                 for i in range(n):
-                    tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK, next_rays=batches[(i + 1) % 16][0])
+                    tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
             return
         for i in range(n):
-            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK, next_rays=batches[(i + 1) % 16][0])
+            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
 
     for v in vals:
         set_variant(v)

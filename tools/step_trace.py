@@ -35,7 +35,7 @@ def main():
 
     def run(n):
         for i in range(n):
-            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK, next_rays=batches[(i + 1) % 16][0])
+            tr.step(*batches[i % 16], focal, noise=noise, update_controllers=False, fixed_chunk=bench.CHUNK)
 
     run(warm)
     torch.cuda.synchronize()
