@@ -597,10 +597,21 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["reference_loop"] = reference_loop_ms(60, 20, True)
     out["reference_loop"]["note"] = ("the loop of the reference's train.py:497-747 (bench.reference_style_step: TensorNeRF.forward, loss in torch "
                                      "operations incl. every statistic train.py reads, total_loss.backward(), FusedAdam.step()) on the drop-in "
-                                     "operator classes: one autograd node per chunk over the C++ pass; `value` is nmf_amd.trainer.Trainer")
-    out["module_path"] = reference_loop_ms(30, 8, False)
-    out["module_path"]["note"] = ("the same loop with nerf.fused_training_pass = False: the autograd operator graph of nmf_amd/functional.py "
-                                  "(what rounds 1-4 delivered to that loop)")
+                                     "operator classes: one autograd node per chunk over the C++ pass; ~40 small torch launches of loss "
+                                     "arithmetic per chunk are the loop's own")
+    # the same C++ pass entered through TensorNeRF.forward + backward() from nmf_amd.trainer.Trainer's loop (fused loss functions):
+    # what `extras.module_path` has meant since round 3
+    tr_ = Trainer(nerf, params, tape_free=False)
+    batches_, f_ = make_batches(nerf, 80, CHUNK, 0, device, distinct=12)
+    dt_, rays_, last_, _ = time_train(tr_, batches_, f_, DeviceNoise(device, seed=5), 20, 60, CHUNK, sync)
+    out["module_path"] = dict(ms_per_step=1e3 * dt_ / 60, rays_per_s=rays_ / dt_, samples_per_chunk=last_["n_samples"], steps=60,
+                              rays_per_step=CHUNK,
+                              note="Trainer(tape_free=False): TensorNeRF.forward + backward() through torch.autograd + FusedAdam -- the drop-in "
+                                   "operator classes under a training loop that calls forward and backward itself; one ChunkPass node per chunk")
+    del tr_
+    out["operator_graph"] = reference_loop_ms(20, 6, False)
+    out["operator_graph"]["note"] = ("the reference-style loop with nerf.fused_training_pass = False: the autograd operator graph of "
+                                     "nmf_amd/functional.py (what rounds 1-4 delivered to that loop; still the path of debug maps / regulariser gradients)")
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays

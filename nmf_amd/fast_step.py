@@ -129,6 +129,8 @@ class TrainPass:
         self._core_retrace = None
         self.last_sizes = None            # sizes of the last chunk the C++ pass ran (reports)
         self._delivered = None            # [(parameter, gradient tensor, its version)] the autograd node left in .grad
+        self._prefetch_registered = False
+        self._autograd_chunks = 0         # ChunkPass backwards since the last optimizer step
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -416,6 +418,25 @@ class TrainPass:
             raise Unsupported("configuration")
         return self._core_chunk(self.core(), rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
 
+    def _register_prefetch(self):
+        """a training loop that is not the Trainer (the reference's train.py) steps its optimizer itself: behind FusedAdam.step()
+        the next step's derived tables are queued on their side stream, as Trainer.step does after its own optimizer call"""
+        if self._prefetch_registered:
+            return
+        self._prefetch_registered = True
+        import weakref
+        from . import optim
+        ref = weakref.ref(self)
+
+        def cb():
+            tp = ref()
+            if tp is None:
+                optim.AFTER_STEP.remove(cb)
+            elif tp._delivered is not None or tp._autograd_chunks:
+                tp._autograd_chunks = 0
+                tp.prefetch()
+        optim.AFTER_STEP.append(cb)
+
     # ---- one chunk as ONE autograd node: what TensorNeRF.forward(is_train=True) returns to a caller that forms its own loss -----
     def forward_autograd(self, rays, focal, noise):
         """-> (rgb_map [b,3], acc [b], ori [b], out dict of StepCore.train_forward) with rgb_map / acc / ori attached to a ChunkPass
@@ -499,6 +520,8 @@ class TrainPass:
             a.l1_dev = d_l1 if a.l1_dev is None else a.l1_dev + d_l1
             holder.l1 = None
         holder.done = True
+        self._autograd_chunks += 1
+        self._register_prefetch()
         c.env_keep_sat = True                   # (more chunks of this step may follow: the env-map adjoint table stays a sum)
         try:
             c.train_backward(d_rgb, d_acc, d_ori, True)

@@ -2,8 +2,6 @@
 sample -> density -> weights -> appearance + normals -> microfacet shading (recursive) -> composite ->
 tonemap, with the same constructor keywords, __call__ signature, returned image / statistics keys and
 state_dict layout.  Every stage runs on the compact sample list produced by the HIP sampler."""
-import os
-
 import torch
 
 from .. import hip
@@ -46,6 +44,7 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         # EVERY sample; the fused pass evaluates them on the bounce rows only and reports 0 for the three (their weights are 0 in
         # microfacet_tensorf2.yaml:208-214).  True: the operator graph, which evaluates them (differentiably) on first read.
         self.regulariser_stats = False
+        self.fused_eval_pass = True                 # renderer.render_images: evaluation chunks as one C++ call each
         self._fused_pass = None
 
     def get_device(self):
@@ -125,7 +124,7 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         if (recur == 0 and is_train and self.fused_training_pass and not self.regulariser_stats and rays.is_cuda
                 and torch.is_grad_enabled() and start_mipval is None and stepmul == 1 and override_near is None and output_alpha is None
                 and dynamic_batch_size and gt_normals is None and override_alpha_thres is None and not ndc_ray and N_samples == -1
-                and tonemap and max_weight_N == -1 and bg_col is not None and os.environ.get("NMF_FAST_STEP", "1") != "0"):
+                and tonemap and max_weight_N == -1 and bg_col is not None):
             out = self._forward_fused(rays, focal, bg_col, noise)
             if out is not None:
                 return out

@@ -12,6 +12,11 @@ import torch
 from . import hip
 
 
+# callables run behind every FusedAdam.step() (not step_unhooked: the Trainer prefetches itself).  nmf_amd/fast_step.py registers
+# the table prefetch of a pass that serves TensorNeRF.forward under a foreign training loop (weak references: a dead pass drops out)
+AFTER_STEP = []
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
@@ -31,6 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
             raise hip.NmfHipError("FusedAdam.step does not take a closure")
         if not self._step_planned():
             self._step_checked()
+        for cb in AFTER_STEP:           # e.g. a fused training pass queues the next step's derived tables on its side stream
+            cb()
 
     def step_unhooked(self):
         """The same update without torch.optim.Optimizer's per-call wrapper around `step` (profiler record + the pre / post

@@ -84,13 +84,15 @@ def render_images(nerf, rays, focal, chunk=None, noise=None, keys=("rgb_map",), 
 
 
 def _eval_pass(nerf):
-    """the tape-free pass of nmf_amd/fast_step.py, forward only (NMF_FAST_STEP=0: always the module path)"""
-    import os
-    if os.environ.get("NMF_FAST_STEP", "1") == "0":
+    """the C++ pass of nmf_amd/fast_step.py, forward only (nerf.fused_eval_pass = False: always the module path)"""
+    if not getattr(nerf, "fused_eval_pass", True):
         return None
-    fp = getattr(nerf, "_eval_fast_pass", None)
+    fp = getattr(nerf, "_fused_pass", None)
     if fp is None:
         from .fast_step import TrainPass
         fp = TrainPass(nerf)
-        object.__setattr__(nerf, "_eval_fast_pass", fp)
+        if hasattr(nerf, "_fused_pass"):
+            nerf._fused_pass = fp
+        else:
+            object.__setattr__(nerf, "_fused_pass", fp)
     return fp if fp.supported() else None

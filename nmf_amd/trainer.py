@@ -246,7 +246,7 @@ def agree(value, op="min", group=None, device=None):
 
 
 class Trainer:
-    def __init__(self, nerf, params, world_size=1, rank=0):
+    def __init__(self, nerf, params, world_size=1, rank=0, tape_free=True):
         self.nerf = nerf
         self.p = params
         self.world_size, self.rank = world_size, rank
@@ -261,11 +261,11 @@ class Trainer:
         self.pred_decay = math.exp(math.log(fp / self.pred_lambda) / n_it) if self.pred_lambda > 0 and fp is not None else 1.0
         self._make_optimizer()
         # tape-free training pass (nmf_amd/fast_step.py over csrc/step_core.inc): forward + loss head + backward of a chunk in one C++
-        # call.  NMF_FAST_STEP=0: every chunk goes through TensorNeRF.forward + backward() instead -- the loop of the reference's
+        # call.  tape_free=False: every chunk goes through TensorNeRF.forward + backward() instead -- the loop of the reference's
         # train.py, which enters the same C++ pass through ONE autograd node per chunk (or, with nerf.fused_training_pass = False, the
         # operator graph of nmf_amd/functional.py)
         self.fast = None
-        if os.environ.get("NMF_FAST_STEP", "1") != "0":
+        if tape_free:
             from .fast_step import TrainPass
             self.fast = TrainPass(nerf)
         # The step allocates a few hundred short-lived Python containers; a full (generation-2) collection walks every
@@ -406,8 +406,9 @@ class Trainer:
             self.batch.reset()
             nerf.model.reset_counter()
         self.iteration += 1
-        if fast is not None:
-            fast.prefetch()           # next step's derived tables, on a side stream behind this optimizer update
+        pre = fast if fast is not None else getattr(nerf, "_fused_pass", None)
+        if pre is not None:
+            pre.prefetch()            # next step's derived tables, on a side stream behind this optimizer update
         return StepStats(losses, rays=used_rays, n_samples=n_samples_last, comm_bytes=comm_bytes, chunks=n_chunks,
                          reduce=self.reduce)
 

@@ -1008,9 +1008,9 @@ def test_tape_free_evaluation_forward_equals_the_module(monkeypatch):
     rays = rays.to(dev)
     for retrace in (1000, int(nerf.model.max_brdf_rays[0])):
         nerf.model.max_retrace_rays = [retrace]
-        monkeypatch.setenv("NMF_FAST_STEP", "0")
+        nerf.fused_eval_pass = False
         ref = render_images(nerf, rays, focal, 2048, DeviceNoise(dev, seed=5), keys=("rgb_map", "acc_map"))
-        monkeypatch.setenv("NMF_FAST_STEP", "1")
+        nerf.fused_eval_pass = True
         calls = []
         fp = __import__("nmf_amd.renderer", fromlist=["_eval_pass"])._eval_pass(nerf)
         orig = fp.render_chunk
