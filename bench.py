@@ -897,6 +897,9 @@ def main():
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                        "backend": backend if (world > 1 or single_rank_comm) else None,
                        "comm_ms_per_step": comm_ms, "comm_bytes_per_step": last["comm_bytes"],
+                       # time the main stream waited for the step's collectives: what is left of the early bucket (BRDF MLP, heads,
+                       # environment map: started inside the last chunk's backward, next to the field walks) + the late bucket
+                       "comm_exposed_ms": (last["comm_exposed_ms"] if last["comm_bytes"] else None),
                        "host_cpu_ms_per_step": last.get("host_cpu_ms_per_step"),
                        "host_pass": "C++ (csrc/step_core.inc)" if (trainer.fast is not None and trainer.fast.core() is not None) else "python"},
             "roofline": roof,

@@ -129,6 +129,7 @@ class TrainPass:
         self._core_retrace = None
         self.last_sizes = None            # sizes of the last chunk the C++ pass ran (reports)
         self._delivered = None            # [(parameter, gradient tensor, its version)] the autograd node left in .grad
+        self._acc_empty = False
         self._prefetch_registered = False
         self._autograd_chunks = 0         # ChunkPass backwards since the last optimizer step
 
@@ -330,6 +331,7 @@ class TrainPass:
     # ---- accumulators of one optimizer step ------------------------------------------------------------------------
     def begin_step(self):
         self.acc = None
+        self._acc_empty = False
         self._early_env = None
         self.n_loss_chunks = 0
         self.l1_scale = 0.0
@@ -371,7 +373,7 @@ class TrainPass:
                 o += p_
             c = _ns(key=key, flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], g_apl=v[6:9], g_ali=v[9:12], g_basis=v[12],
                     g_mlp=v[13:19], g_hW=v[19], g_hb=v[20], d_sat=v[21], d_pole=v[22], d_mip=v[23], used_env=False,
-                    pairs=None, gp=None, gl=None, d_bg=None, d_bg_view=None, l1=None, l1_dev=None)
+                    pairs=None, gp=None, gl=None, d_bg=None, d_bg_view=None, l1=None, l1_dev=None, early_pairs=None)
             self._acc_cache = c
             self._delivered = None
         if zero:
@@ -410,13 +412,49 @@ class TrainPass:
 
     # ---- one chunk: forward, loss, backward (nmf_amd.trainer.Trainer) ------------------------------------------------------
     @torch.no_grad()
-    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False):
+    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False, early=None):
         """wts = (w_photo, w_l1, w_ori, w_acc).  Returns dict(loss 0-d tensor, kept, n_samples) -- loss None when the chunk
         had no sample (train.py:567-568 skips it).  want_total: also evaluate the chunk's total loss value (the gradients do
         not need it: every term enters linearly with a constant weight)."""
         if not self.supported():
             raise Unsupported("configuration")
-        return self._core_chunk(self.core(), rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
+        c = self.core()
+        # early = (callable, raw comm stream): called from the last chunk's backward when the non-field gradients are final
+        c.early_cb, c.comm_stream = (early[0], int(early[1])) if (early is not None and last) else (None, 0)
+        try:
+            return self._core_chunk(c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
+        finally:
+            c.early_cb = None
+
+    # ---- data parallel: the gradients that are final before the walks of the last chunk ------------------------------------------
+    def early_pairs(self, dev):
+        """[(parameter, accumulator tensor)] of the BRDF MLP, the material heads and the environment map: what no field walk writes.
+        The tensors are the ones end_step hands to the optimizer as .grad (views of the flat buffer, the env-map table gradient, the
+        fp32 mip-bias adjoint), so a sum over the ranks written into them in place is what Adam reads.  A step whose chunks never
+        looked the environment map up has a zero table gradient."""
+        a = self.acc
+        if a is None:                       # no chunk of this step reached the fused backward: zeros travel, .grad stays None here
+            a = self._accumulators(dev)
+            self._acc_empty = True
+        n = self.nerf
+        bgm = n.bg_module
+        used = bool(self._core.env_was_used()) if self._core else bool(a.used_env)
+        if a.early_pairs is not None and a.d_bg is not None:
+            if not used:
+                a.d_bg.zero_()
+            return a.early_pairs
+        m = n.model.brdf.mlp
+        pairs = list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
+        hps = n.model.diffuse_module._head_params()
+        for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
+            pairs += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
+        if a.d_bg is None:
+            a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
+        if not used:
+            a.d_bg.zero_()
+        pairs += [(bgm.bg_mat, a.d_bg), (bgm.mipbias, a.d_mip)]
+        a.early_pairs = [(prm, g) for prm, g in pairs if prm.requires_grad]
+        return a.early_pairs
 
     def _register_prefetch(self):
         """a training loop that is not the Trainer (the reference's train.py) steps its optimizer itself: behind FusedAdam.step()
@@ -599,6 +637,9 @@ class TrainPass:
         """Trainer.step, after the last chunk: the accumulators of the step become (or are added to) the parameters' .grad"""
         a = self.acc
         if a is None:
+            return
+        if self._acc_empty:                 # accumulators that only exist to enter the ranks' early collective with zeros
+            self.acc, self._acc_empty = None, False
             return
         l1 = None
         if self.l1_scale != 0.0:

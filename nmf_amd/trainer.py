@@ -83,9 +83,12 @@ def rank_slice(n_total, world_size, rank):
 
 
 class FlatGradAllReduce:
-    """One collective per optimizer step: gradients are packed into a flat fp32 buffer (14 MB at 128^3, 50 MB at
-    300^3), summed over ranks (RCCL over xGMI when backend='nccl', gloo on CPU) and unpacked.  A single bucket:
-    at 7 x ~153 GB/s per GPU the ring time (<1 ms) is far below the step time, so overlap buys nothing here.
+    """Gradients are packed into flat fp32 buffers (14 MB at 128^3, 50 MB at 300^3), summed over ranks (RCCL over xGMI when
+    backend='nccl', gloo on CPU) and unpacked.  TWO buckets since round 5 (at a 1.4 ms step a 0.1-0.6 ms collective on
+    the serial tail is 7-40 % exposed): `early()` takes the gradients that are final before the field walks of the last chunk --
+    BRDF MLP, material heads, environment map: 6.4 of the 14.3 MB -- and sums them on a communication stream NEXT TO those walks;
+    `__call__` sums the field tables behind them.  Both buckets are entered exactly once per step by every rank (a rank whose last
+    chunk did not run the fused pass enters the early one behind its chunks): the collectives of the ranks always pair up.
 
     The buffer layout is FIXED: [gradients | one has-gradient flag per parameter | the step's guard value].  Every parameter
     owns its slot whether or not this rank produced a gradient for it in this step (a rank whose chunk spawned no bounce
@@ -110,6 +113,75 @@ class FlatGradAllReduce:
         # identity): exercises RCCL, the pack / unpack launches and their ordering against the training pass's side streams
         # on a 1-GPU box, and gives a first comm_ms_per_step (bench.py with NMF_BENCH_BACKEND=nccl)
         self.single_rank = os.environ.get("NMF_ALLREDUCE_SINGLE_RANK") == "1"
+        self._early = None                # the early bucket of the running step: dict(pairs, buf, work, stream, events)
+        self._early_key = None
+        self._late_key = None
+        self.buf_early = None
+        self._slots_early = None
+        self._exposed = None              # (main stream ready, collectives done) events of the last step
+
+    # ---- the early bucket -----------------------------------------------------------------------------------------------------
+    def begin_step(self):
+        self._early = None
+
+    def early(self, pairs, comm_stream, group=None):
+        """pairs [(parameter, gradient tensor)]: packed and all-reduced on `comm_stream` NOW (the stream already waits for the
+        producers of the tensors); the sums are written back into the same tensors by finish_early().  A gradient some chunk left in
+        .grad outside the accumulators (a chunk that went through the operator graph) is folded in first."""
+        if self._early is not None or not self.active(group) or not pairs:
+            return
+        from . import hip
+        main = torch.cuda.current_stream()
+        torch.cuda.set_stream(comm_stream)
+        try:
+            for prm, g in pairs:
+                if prm.grad is not None and prm.grad.data_ptr() != g.data_ptr():
+                    g.add_(prm.grad.reshape(g.shape).to(g.dtype))
+                    prm.grad = None
+            key = tuple(g.data_ptr() for _, g in pairs)
+            if self._early_key != key:          # (the accumulator tensors are persistent: the slot tables stand from step to step)
+                n = sum(g.numel() for _, g in pairs)
+                if self.buf_early is None or self.buf_early.numel() != n or self.buf_early.device != pairs[0][1].device:
+                    self.buf_early = torch.empty(n, dtype=torch.float32, device=pairs[0][1].device)
+                self._slots_early = ((hip.CopySlot * len(pairs))(), (hip.CopySlot * len(pairs))())
+                base, off = self.buf_early.data_ptr(), 0
+                for i, (_, g) in enumerate(pairs):
+                    if not g.is_contiguous() or g.dtype != torch.float32:
+                        raise hip.NmfHipError("early gradient bucket: dense fp32 tensors")
+                    a, b = self._slots_early[0][i], self._slots_early[1][i]
+                    a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = g.data_ptr(), base + 4 * off, g.numel(), 0, 0
+                    b.src, b.dst, b.numel, b.src_is_f64, b.dst_is_f64 = base + 4 * off, g.data_ptr(), g.numel(), 0, 0
+                    off += g.numel()
+                self._early_key, self._early_n = key, n
+                self._early_ids = {id(p) for p, _ in pairs}
+            n = self._early_n
+            hip.multi_copy(self._slots_early[0], len(pairs))
+            ev = self._early_events = getattr(self, "_early_events", None) or tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ev[0].record()
+            work = dist.all_reduce(self.buf_early, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            self._early = dict(pairs=pairs, work=work, stream=comm_stream, ev=ev, bytes=4 * n, ids=self._early_ids)
+        finally:
+            torch.cuda.set_stream(main)
+
+    def finish_early(self):
+        """the early sums land in the tensors they were packed from (the communication stream unpacks; the current stream then waits
+        for it): call before anything reads those tensors -- end_step's conversion into .grad"""
+        e = self._early
+        if e is None or e.get("done"):
+            return
+        from . import hip
+        main = torch.cuda.current_stream()
+        ready = e["ev"][2]
+        ready.record(main)                     # from here on the main stream would idle if the collective were not finished
+        torch.cuda.set_stream(e["stream"])
+        try:
+            e["work"].wait()
+            hip.multi_copy(self._slots_early[1], len(e["pairs"]))
+            e["ev"][1].record()
+        finally:
+            torch.cuda.set_stream(main)
+        main.wait_event(e["ev"][1])
+        e["done"], e["ready"] = True, ready
 
     def active(self, group=None):
         return (dist.is_available() and dist.is_initialized() and self.numel > 0
@@ -121,6 +193,9 @@ class FlatGradAllReduce:
         self.guard = guard
         if not self.active(group):
             return 0
+        early = self._early
+        if early is not None:
+            return self._call_late(group, guard, early)
         ps, n = self.params, self.numel
         dev = ps[0].device
         total = n + len(ps) + 1
@@ -166,13 +241,78 @@ class FlatGradAllReduce:
             self.guard = self.buf[total - 1]
         return n * 4
 
-    def _pack_device(self, ps, n, have, guard):
+    def _call_late(self, group, guard, early):
+        """the second bucket of a step whose early bucket is under way: [gradients of the remaining parameters | one has-gradient flag
+        per parameter (all of them) | guard].  An early parameter has a gradient on a rank iff .grad is set there (end_step sets it
+        from the accumulator tensor the early sum was written into); where no rank had one it stays None."""
+        from . import hip
+        self.finish_early()
+        ps = self.params
+        late = [p for p in ps if id(p) not in early["ids"]]
+        n = sum(p.numel() for p in late)
+        dev = ps[0].device
+        total = n + len(ps) + 1
+        if self.buf is None or self.buf.device != dev or self.buf.numel() != total:
+            self.buf = torch.empty(total, dtype=torch.float32, device=dev)
+        have_all = [p.grad is not None for p in ps]
+        have = [p.grad is not None for p in late]
+        # the fused pass hands over the SAME gradient tensors every step: the slot tables of pack and unpack stand until a pointer moves
+        key = (tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in late), tuple(have_all),
+               None if guard is None else guard.data_ptr(), self.buf.data_ptr())
+        planned = all(have_all) and key == self._late_key
+        if planned:
+            hip.multi_copy(self._slots[0], self._late_counts[0])
+        else:
+            self._pack_device(late, n, have, guard, flags=have_all)
+            self._late_key = None
+        ev = self._events = getattr(self, "_events", None) or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        ev[1].record()
+        self.last_comm_ms = ev
+        self._exposed = (early["ready"], early["ev"][1], ev)
+        anyone_all = have_all
+        if not all(have_all):
+            self.mask_reads += 1
+            anyone_all = [f > 0.0 for f in self.buf[n:n + len(ps)].tolist()]
+        by_early = {id(p): g for p, g in early["pairs"]}
+        anyone = []
+        for p, h, a in zip(ps, have_all, anyone_all):
+            if id(p) in by_early:
+                if a and not h:                # another rank produced it: the sum is in the early tensor
+                    g = by_early[id(p)]
+                    p.grad = g.reshape(p.shape).to(p.dtype) if (g.shape != p.shape or g.dtype != p.dtype) else g
+            else:
+                anyone.append(a)
+        if planned:
+            hip.multi_copy(self._slots[1], self._late_counts[1])
+        else:
+            self._unpack_device(late, n, have, anyone)
+            if all(have_all) and guard is not None:
+                self._late_key, self._late_counts = key, (self._pack_count, self._unpack_count)
+        if guard is not None:
+            self.guard = self.buf[total - 1]
+        self._early = None
+        return n * 4 + early["bytes"]
+
+    def exposed_ms(self):
+        """time the main stream waited for the step's collectives: the early bucket's remainder behind the walks + the late bucket
+        (blocks until they have finished); None without an overlapped step"""
+        x = self._exposed
+        if x is None:
+            return None
+        ready, early_done, late = x
+        late[1].synchronize()
+        return max(ready.elapsed_time(early_done), 0.0) + late[0].elapsed_time(late[1])
+
+    def _pack_device(self, ps, n, have, guard, flags=None):
         """one launch: nmf_multi_copy over all gradients (each in its own memory order), the flags and the guard"""
         from . import hip
         from .optim import _dense
         k = len(ps)
-        if self._slots is None or len(self._slots[0]) < 2 * k + 1:
-            self._slots = ((hip.CopySlot * (2 * k + 1))(), (hip.CopySlot * k)())
+        nf = len(flags) if flags is not None else k
+        if self._slots is None or len(self._slots[0]) < k + nf + 1:
+            self._slots = ((hip.CopySlot * (len(self.params) * 2 + 1))(), (hip.CopySlot * len(self.params))())
         if self._consts is None or self._consts.device != self.buf.device:
             self._consts = torch.tensor([0.0, 1.0], dtype=torch.float32, device=self.buf.device)
         pack = self._slots[0]
@@ -190,10 +330,17 @@ class FlatGradAllReduce:
                 m += 1
             else:
                 missing.append((off, p.numel()))
-            a = pack[m]
-            a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = (one if h else zero), base + 4 * (n + i), 1, 0, 0
-            m += 1
+            if flags is None:
+                a = pack[m]
+                a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = (one if h else zero), base + 4 * (n + i), 1, 0, 0
+                m += 1
             off += p.numel()
+        if flags is not None:                    # flags of ALL parameters behind the gradients of the packed ones
+            for i, h in enumerate(flags):
+                a = pack[m]
+                a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = (one if h else zero), base + 4 * (n + i), 1, 0, 0
+                m += 1
+        k = nf
         if guard is not None:
             if guard.dtype not in (torch.float32, torch.float64) or guard.numel() != 1:
                 raise hip.NmfHipError("the guard is a single fp32 / fp64 device value")
@@ -207,6 +354,7 @@ class FlatGradAllReduce:
         for off_, cnt in missing:                # slots of gradients this rank does not have travel as zeros
             self.buf[off_:off_ + cnt].zero_()
         hip.multi_copy(pack, m)
+        self._pack_count = m
 
     def _unpack_device(self, ps, n, have, anyone):
         from . import hip
@@ -224,6 +372,7 @@ class FlatGradAllReduce:
             off += p.numel()
         if m:
             hip.multi_copy(unpack, m)
+        self._unpack_count = m
 
     def comm_ms(self):
         """duration of the last device collective (blocks until it has finished); None if there was none"""
@@ -282,7 +431,15 @@ class Trainer:
         lam = lambda s: float(learning_rate_decay(s, p["lr_init"], p["lr_final"], p["n_iters"], p["lr_delay_steps"],  # noqa: E731
                                                   p["lr_delay_mult"]))
         self.scheduler = DecayLR(self.optimizer, lam)
-        self.reduce = FlatGradAllReduce([q for g in self.optimizer.param_groups for q in g["params"]])
+        # The all-reduce covers the parameters that can move: a group with learning rate 0 (env-map brightness / mul,
+        # microfacet_tensorf2.yaml:150-151) stays where it is whatever its gradient, and dbasis_mat is not part of the model with
+        # dbasis = False (fields/tensoRF.py:117).  They never have a gradient on any rank -- and a parameter WITHOUT a local gradient
+        # makes the reducer read the ranks' has-gradient flags back, a host synchronisation per step (rounds 3-4 paid it every step:
+        # +0.39 ms at one rank).
+        dead = {id(q) for q in getattr(self.nerf.rf, "dbasis_mat", torch.nn.Identity()).parameters()} \
+            if not getattr(self.nerf.rf, "dbasis", False) else set()
+        self.reduce = FlatGradAllReduce([q for g in self.optimizer.param_groups if g.get("initial_lr", g["lr"]) != 0
+                                         for q in g["params"] if id(q) not in dead])
 
     @property
     def num_rays(self):
@@ -315,6 +472,16 @@ class Trainer:
         fast = self.fast if (self.fast is not None and self.fast.supported()) else None
         if fast is not None:
             fast.begin_step()
+        # data parallel: the gradients no field walk writes (BRDF MLP, material heads, environment map) are summed over the ranks on
+        # a communication stream from inside the last chunk's backward, next to the walks that end it (FlatGradAllReduce.early)
+        self.reduce.begin_step()
+        early = None
+        if fast is not None and self.reduce.active() and rays is not None and rays.is_cuda:
+            comm = fast._side.get("comm")
+            if comm is None:
+                comm = fast._side["comm"] = torch.cuda.Stream()
+            dev_ = rays.device
+            early = (lambda: self.reduce.early(fast.early_pairs(dev_), comm), comm.cuda_stream)
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
             if fetch is not None:
@@ -332,7 +499,7 @@ class Trainer:
                 try:
                     out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
                                      (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
-                                     want_total=trace is not None, last=pos >= n_total)
+                                     want_total=trace is not None, last=pos >= n_total, early=early)
                 except Unsupported:
                     out = None                      # this chunk goes through the autograd path below
                 if out is not None:
@@ -381,6 +548,11 @@ class Trainer:
             if update_controllers:                                                               # train.py:618-627
                 self.batch.update(kept, n_samples[0])
                 nerf.model.update_n_samples(n_samples[1:])
+        if early is not None:
+            if self.reduce._early is None:        # the last chunk did not run the fused backward: the early bucket behind the chunks
+                comm.wait_stream(torch.cuda.current_stream())
+                early[0]()
+            self.reduce.finish_early()            # the sums are in the accumulator tensors before end_step turns them into .grad
         if fast is not None:
             fast.end_step()
         # NaN guard (train.py:704-705 reads the loss back and skips a NaN chunk): the summed loss of the step stays on the
@@ -423,8 +595,11 @@ class StepStats(dict):
         self._losses = losses
 
     def __missing__(self, key):
-        if key == "comm_ms":             # duration of this step's gradient all-reduce (device events; waits for it)
+        if key == "comm_ms":             # duration of this step's (late) gradient all-reduce (device events; waits for it)
             self[key] = self["reduce"].comm_ms() if self.get("reduce") is not None and self["comm_bytes"] else None
+            return self[key]
+        if key == "comm_exposed_ms":     # time the main stream waited for the step's collectives (early remainder + late bucket)
+            self[key] = self["reduce"].exposed_ms() if self.get("reduce") is not None and self["comm_bytes"] else None
             return self[key]
         if key not in ("loss", "psnr"):
             raise KeyError(key)

@@ -154,3 +154,77 @@ def test_two_ranks_on_one_gpu_equal_one_process_with_two_chunks():
     assert err <= 2e-5 * float(one.abs().max()) + 1e-9, (err, float(one.abs().max()))
     rel = float((one - two).norm() / one.norm())
     assert rel < 1e-5, rel
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_amd.trainer import FlatGradAllReduce
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1, 16, 24, 24), (1, 16, 24, 1), (64, 66), (64,), (11, 24), (3, 32, 64), (1,), (24, 72)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    early_ids = (2, 3, 4, 5, 6)                      # "BRDF MLP, heads, environment map, mip bias": final before the field walks
+    gr = torch.Generator().manual_seed(100 + rank)
+
+    def fresh():
+        gs = [torch.randn(s, generator=gr).to(dev) for s in shapes]
+        if rank == 1:
+            gs[7] = None                              # a parameter only rank 0 has a gradient for
+        gs[1] = None                                  # ... and one nobody has
+        return gs
+    grads = fresh()
+    comm = torch.cuda.Stream()
+    res = {}
+    for mode in ("flat", "bucketed"):
+        red = FlatGradAllReduce(params)
+        red.begin_step()
+        acc = [None if t is None else t.clone() for t in grads]
+        for p in params:
+            p.grad = None
+        guard = torch.tensor(1.5 + rank, device=dev)
+        if mode == "bucketed":
+            comm.wait_stream(torch.cuda.current_stream())
+            red.early([(params[i], acc[i]) for i in early_ids], comm)
+            red.finish_early()
+        for p, t in zip(params, acc):                 # "end_step": the accumulator tensors become .grad
+            if t is not None:
+                p.grad = t
+        n = red(guard=guard)
+        torch.cuda.synchronize()
+        res[mode] = dict(bytes=n, guard=float(red.guard), grads=[None if p.grad is None else p.grad.detach().cpu().clone() for p in params],
+                         exposed=red.exposed_ms())
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_is_bit_identical_to_the_flat_one():
+    """FlatGradAllReduce with the early bucket (the gradients that are final before the field walks, summed on a communication stream
+    next to them) against the single flat collective of rounds 1-4, two ranks: the same bytes travel, every gradient and the
+    step's guard come back bit for bit, a parameter only one rank has a gradient for gets the sum on both, a parameter no rank has one
+    for keeps .grad = None, and both replicas agree."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        res = dict(out)
+    for rank in (0, 1):
+        flat, buck = res[rank]["flat"], res[rank]["bucketed"]
+        assert flat["bytes"] == buck["bytes"] and flat["guard"] == buck["guard"] == 4.0
+        assert flat["exposed"] is None and buck["exposed"] is not None and buck["exposed"] >= 0.0
+        for a, b in zip(flat["grads"], buck["grads"]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+        assert flat["grads"][1] is None and flat["grads"][7] is not None
+    for a, b in zip(res[0]["bucketed"]["grads"], res[1]["bucketed"]["grads"]):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))

@@ -211,8 +211,10 @@ def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
         inner, seen = tr.reduce, []
 
         class Checked:
-            comm_ms, active, params = inner.comm_ms, inner.active, inner.params
             guard = None
+
+            def __getattr__(self, name):          # (the early bucket, timings, parameters: the real reducer's)
+                return getattr(inner, name)
 
             def __call__(self, group=None, guard=None):
                 ps = [p for p in inner.params if p.grad is not None]
@@ -231,12 +233,59 @@ def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
             out = tr.step(rays.to(dev), gt, focal, noise=DeviceNoise(dev, seed=70 + it), update_controllers=False, fixed_chunk=1024)
             assert out["comm_bytes"] == 4 * inner.numel and out["comm_bytes"] > 1e6
             assert out["comm_ms"] is not None and out["comm_ms"] > 0
+            # the early bucket (BRDF MLP, heads, environment map) went out from inside the last chunk's backward, next to the walks
+            assert out["comm_exposed_ms"] is not None and 0 < out["comm_exposed_ms"] < 5.0
+            assert inner.buf_early is not None and inner.buf_early.numel() * 4 + inner.buf.numel() * 4 > out["comm_bytes"]
         torch.cuda.synchronize()
+        assert inner.mask_reads == 0          # no has-gradient flags read back: no host synchronisation in the steady state
         assert len(seen) == 3
         for n, n_grads, same, nonzero in seen:
             assert n_grads >= 25 and same and nonzero >= 25, (n_grads, same, nonzero)
     finally:
         dist.destroy_process_group()
+
+
+def test_step_of_32768_rays_per_gpu_as_eight_chunks():
+    """BASELINE configs[3]'s per-GPU workload at its size: ONE optimizer step over 32 768 rays = 8 chunks of 4096 under the reference's
+    per-chunk budgets (train.py:509-712 accumulates the chunks' gradients), 128^3, steady state.  Every ray is used, every chunk keeps
+    its ~1 M samples, the accumulated gradients are finite and non-zero, the step moves the parameters once, and the gradient of the
+    eight chunks is eight times as large as one chunk's to within their Monte-Carlo spread."""
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    nerf, params = bench.build(dev)
+    tr = Trainer(nerf, params)
+    assert tr.fast is not None and tr.fast.supported()
+    rays, focal = synthetic.camera_rays(32768, seed=91)
+    rays = rays.to(dev)
+    gt = torch.rand(32768, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    before = {k: p.detach().clone() for k, p in nerf.named_parameters()}
+    trace = []
+    out = tr.step(rays, gt, focal, noise=DeviceNoise(dev, seed=9), update_controllers=False, fixed_chunk=4096, trace=trace)
+    assert out["chunks"] == 8 and out["rays"] == 32768 and len(trace) == 8
+    for rec in trace:
+        assert rec["kept"] == 4096 and 1.2e5 < rec["n_samples"][0] < 2.0e5 and 6e5 < rec["n_samples"][1] < 1.3e6, rec
+    assert np.isfinite(out["loss"]) and out["loss"] > 0
+    grads = {k: p.grad for k, p in nerf.named_parameters() if p.grad is not None}
+    assert len(grads) >= 29
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()), k
+    assert sum(float(g.abs().max()) > 0 for g in grads.values()) >= 27      # (the tint head of scene S1 has no gradient)
+    moved = [k for k, p in nerf.named_parameters() if k in grads and not torch.equal(p.detach(), before[k])]
+    assert set(moved) == {k for k, g in grads.items() if float(g.abs().max()) > 0}, set(grads) - set(moved)
+    assert tr.iteration == 1 and all(st["step"] == 1 for st in tr.optimizer.state.values())
+    g8 = {k: g.detach().double().clone() for k, g in grads.items()}
+    # one chunk of the same rays and the same normaliser: an eighth of the sum, as one Monte-Carlo estimate of it
+    nerf2, params2 = bench.build(dev)
+    tr2 = Trainer(nerf2, params2)
+    tr2.optimizer.step = lambda: None
+    tr2.optimizer.step_unhooked = lambda: None
+    tr2.step(rays[:4096], gt[:4096], focal, noise=DeviceNoise(dev, seed=9), update_controllers=False, fixed_chunk=4096, global_rays=32768)
+    for k in ("rf.basis_mat.weight", "model.brdf.mlp.0.weight", "rf.app_rf.app_line.0"):
+        g1 = dict(nerf2.named_parameters())[k].grad.double()
+        ratio = float(g8[k].norm() / g1.norm())
+        assert 2.0 < ratio < 16.0, (k, ratio)
 
 
 def test_scaled_budgets_run_the_same_step_in_one_larger_chunk():
