@@ -105,7 +105,7 @@ FP32_PEAK, BF16_PEAK, HBM_PEAK, LANE_OP_PEAK, ATOMIC_PEAK = 157.3e12, 2500.0e12,
 MFMA_F32_PEAK_TFLOPS, MFMA_BF16_PEAK_TFLOPS = 157.3, 2500.0
 # csrc/brdf_mlp.hip: v_mfma_f32_32x32x16_bf16 (2 x 32 x 32 x 16 FLOP each) issued per 32-ray tile
 MLP_FWD_ISSUED_FLOP = 108 * 32768 / 32
-MLP_BWD_ISSUED_FLOP = 186 * 32768 / 32
+MLP_BWD_ISSUED_FLOP = 150 * 32768 / 32      # (R5: 186 before the transposes moved from selector-matrix products into the LDS reads)
 ADAM_BYTES_PER_PARAM = 28
 TAPCH_VALUE, TAPCH_GRAD, TAPCH_APP = 288, 480, 432
 FWD_VALUE = 2 * TAPCH_VALUE + 48                          # FLOP per sample: density value
@@ -557,21 +557,7 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
                     steps=steps, rays_per_step=rays_per_gpu)
 
     nerf, _ = build(device)
-    dt, n, chunk, cold = time_infer(nerf, device, frames=2)
-    out["inference"] = dict(rays_per_s=n / dt, s_per_frame=dt / 2, first_frame_s=cold, frame=f"{FRAME}x{FRAME}", chunk=chunk,
-                            note="eval mode, render to completion (renderer.py:56-106), rgb/acc outputs, S1 at 128^3; one "
-                                 "whole warm-up frame (first_frame_s: the caching allocator grows its pools), two timed")
-    # eval_batch_size is a key of the reference's model config (4096 in microfacet_tensorf2.yaml): the evaluation path has no
-    # sample budget, so larger chunks only amortise the ~45 dependent launches and four size read-backs of a chunk
-    by_chunk = {}
-    for c in (16384, 32768):
-        dtc, nc, _, _ = time_infer(nerf, device, frames=2, chunk=c)
-        by_chunk[str(c)] = nc / dtc
-    out["inference"]["rays_per_s_by_eval_batch_size"] = by_chunk
-    nerf.model.max_retrace_rays = [1000]
-    out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
-    out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
-    nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
+    # (first: these legs are bound by the host, and a process that has been through the larger legs below issues more slowly)
     # what a maintainer of the reference gets who swaps the operator classes in and keeps train.py's loop:
     # reference_style_step above -- TensorNeRF.forward, the loss in torch operations, total_loss.backward(), optimizer.step() --
     # steady state, 4096 rays.  The forward / backward of a chunk enter the same C++ pass as `value` through ONE autograd node.
@@ -612,6 +598,21 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["operator_graph"] = reference_loop_ms(20, 6, False)
     out["operator_graph"]["note"] = ("the reference-style loop with nerf.fused_training_pass = False: the autograd operator graph of "
                                      "nmf_amd/functional.py (what rounds 1-4 delivered to that loop; still the path of debug maps / regulariser gradients)")
+    dt, n, chunk, cold = time_infer(nerf, device, frames=2)
+    out["inference"] = dict(rays_per_s=n / dt, s_per_frame=dt / 2, first_frame_s=cold, frame=f"{FRAME}x{FRAME}", chunk=chunk,
+                            note="eval mode, render to completion (renderer.py:56-106), rgb/acc outputs, S1 at 128^3; one "
+                                 "whole warm-up frame (first_frame_s: the caching allocator grows its pools), two timed")
+    # eval_batch_size is a key of the reference's model config (4096 in microfacet_tensorf2.yaml): the evaluation path has no
+    # sample budget, so larger chunks only amortise the ~45 dependent launches and four size read-backs of a chunk
+    by_chunk = {}
+    for c in (16384, 32768):
+        dtc, nc, _, _ = time_infer(nerf, device, frames=2, chunk=c)
+        by_chunk[str(c)] = nc / dtc
+    out["inference"]["rays_per_s_by_eval_batch_size"] = by_chunk
+    nerf.model.max_retrace_rays = [1000]
+    out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
+    out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
+    nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
@@ -818,10 +819,13 @@ def main():
     if timed_calls:                       # (every rank: the steps contain the gradient all-reduce)
         n_inst = 30
         main_id = torch.cuda.current_stream().cuda_stream
+        sync()
+        t_inst = time.perf_counter()
         fx.kernel_timing_begin()
         for i in range(n_inst):
             trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
-        timing = fx.kernel_timing_end()
+        timing = fx.kernel_timing_end()                # (waits for the recorded events)
+        wall_inst_us = 1e6 * (time.perf_counter() - t_inst) / n_inst
         if f"@{main_id}" in timing:
             main_stream_us = 1e3 * timing[f"@{main_id}"][0] / n_inst
         ls = trainer.fast.last_sizes
@@ -869,7 +873,9 @@ def main():
                 "step": {"wall_us": round(1e3 * ms_step, 1), "main_stream_kernel_us": round(main_stream_us, 1) if main_stream_us else None,
                          # the main stream carries the dependency chain of the step (side streams only ever run next to it): the share
                          # of the wall time in which a kernel of the chain is executing
-                         "critical_path_frac": round(main_stream_us / (1e3 * ms_step), 4) if main_stream_us else None,
+                         # (both from the instrumented steps: an event pair around every launch stretches them)
+                         "wall_us_instrumented": round(wall_inst_us, 1),
+                         "critical_path_frac": round(min(main_stream_us / wall_inst_us, 1.0), 4) if main_stream_us else None,
                          "device_time_sum_us": dev_sum,
                          "survey_8d_bytes": survey_b, "survey_8d_over_hbm": survey_b / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
                          "needed_bytes": needed_b, "needed_over_l2": needed_b / (ms_step * 1e-3) / (L2_PEAK_GBS * 1e9),

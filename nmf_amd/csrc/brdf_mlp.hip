@@ -21,11 +21,12 @@
 //   W0[:, :24]^T) are staged once per workgroup in LDS and shared by its waves.
 // * Layer products are "swapped" (D^T[unit][ray] = W . act^T): a lane then holds 4 CONSECUTIVE units of its ray per
 //   accumulator quad = one ds_write_b64 into the row-major plane the next product reads.
-// * Weight gradients (K = rays) need the activations with the unit per lane and the rays along the registers.  That
-//   transposition is done by the matrix core too: D = act . E with E a 0/1 selector matrix (exact: every output is one
-//   bf16 input), which lands in exactly the register layout an MFMA operand of the dW products wants.  Any bijection
-//   between (lane half, element) and k is fine as long as both operands of a product use the same one, so none of this
-//   depends on how the hardware orders k inside an operand register.
+// * Weight gradients (K = rays) need the activations with the unit per lane and the rays along the registers.  R5: that
+//   transposition is the LDS read itself -- ds_read_b64_tr_b16 (gfx950) hands a group of 16 lanes the transpose of the
+//   4 x 16 block of 16-bit values they address (lanes 4k .. 4k+3 supply row k, lane n receives column n: measured,
+//   tools/ub/tr_read.hip), so two of them deliver 8 consecutive rays of one unit per lane = an MFMA operand of the dW
+//   products straight from the row-major planes.  (R3-R4 transposed on the matrix core with 0/1 selector matrices: 34 of
+//   the 186 matrix instructions of a tile and a conversion of every transposed value.)
 // * dW2, dW0 accumulate in MFMA accumulators over ALL tiles of a wave (the 5 trailing input columns through a
 //   transposed product whose 4 useful rows are kept), dW4 / db2 / db4 on the VALU; one LDS reduction over the waves
 //   and one atomic flush per workgroup at the end.  b0 rides as an input column that is 1.0.
@@ -138,6 +139,8 @@ __device__ __forceinline__ floatx16 mfma(bf16x8 a, bf16x8 b, floatx16 c) {
 // them (built with -amdgpu-mfma-vgpr-form the compiler's own MFMAs write VGPRs; without the flag it would route EVERY
 // MFMA result of a 512-register kernel through AGPRs and copy it out).  The accumulators are read only after the loop.
 __device__ __forceinline__ void mfma_acc(floatx16& c, bf16x8 a, bf16x8 b) {
+    // (R5: with the operands coming out of LDS reads instead of VALU conversions the padding measured as unnecessary -- 80.1 us with,
+    //  81.1 / 80.7 without or as a movable statement at 242 k rays -- and stays as the conservative form)
     asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // c += a b with the terms down to 2^-9 NP, smallest first: NP = 2: lh hl hh; NP = 3: lh hl mm mh hm hh  (a index, b index)
@@ -504,28 +507,43 @@ k_brdf_mlp_fwd(MlpW w, const float* __restrict__ half_v, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The operand registers of a 64-wide activation tile (rows = rays, 16-column blocks) -> the same tile with the UNIT on
-// the lane and the rays along the registers, as operand registers of the weight-gradient products ([kp] = the
-// accumulator registers 8 kp .. 8 kp + 7).  sum (optional) += the column sums (a bias gradient).
+// A 32-column block of a row-major activation plane [ray][column] with the COLUMN on the lane and the rays along the registers:
+// the operand layout of the weight-gradient products (K = rays).  [kp]: rays 16 kp .. 16 kp + 15, lane half h holding 8 h .. 8 h + 7
+// of them in order; .p[i]: bf16 plane i.  Two transposing LDS reads per operand register pair (see the header).
 struct UOp {
     Op<2> k[2];
 };
-__device__ __forceinline__ UOp transpose_block(const Op<2>& c0, const Op<2>& c1, bf16x8 e0, bf16x8 e1, float* sum) {
-    floatx16 th = {0}, tl = {0};
-    th = mfma(c0.p[0], e0, th);
-    tl = mfma(c0.p[1], e0, tl);
-    th = mfma(c1.p[0], e1, th);
-    tl = mfma(c1.p[1], e1, tl);
-    if (sum) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += th[r] + tl[r];
-        *sum += s;
-    }
+typedef short short4v __attribute__((ext_vector_type(4)));
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 ld_tr8(const char* at) {
+    typedef __attribute__((address_space(3))) short4v* lds_p;
+    union { short4v s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(at));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(at + 4 * STRIDE));
+    return u.v;
+}
+// lane part of a transposing read's address: lanes 4 k .. 4 k + 3 of a 16-lane group address row k (4 columns each), the groups of a
+// lane half take columns 0-15 / 16-31, the upper lane half the rays 8 .. 15 of the 16
+template <int STRIDE>
+__device__ __forceinline__ int tr_lane_offset(int lane) {
+    return (8 * (lane >> 5) + ((lane & 15) >> 2)) * STRIDE + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+}
+// columns [col0, col0 + 32) of the two planes at `pl` (plane stride `plane`), lane offset from tr_lane_offset<STRIDE>
+template <int STRIDE>
+__device__ __forceinline__ UOp ld_uop(const char* pl, int plane, int col0, int lane_off) {
     UOp u;
-    u.k[0].p[0] = pack8(th, 0); u.k[1].p[0] = pack8(th, 8);
-    u.k[0].p[1] = pack8(tl, 0); u.k[1].p[1] = pack8(tl, 8);
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u.k[kp].p[i] = ld_tr8<STRIDE>(pl + i * plane + kp * 16 * STRIDE + 2 * col0 + lane_off);
     return u;
+}
+// sum of the 8 values of an operand register set (a bias gradient: column sums over the rays)
+__device__ __forceinline__ float sum8(bf16x8 v) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (float)v[i];
+    return s;
 }
 
 constexpr int N_PERSIST = 64 + 64 + 8 + 6 + 2 + 3;   // per-lane partial sums that are reduced over the waves at the end
@@ -605,15 +623,9 @@ k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* 
     float* gs = reinterpret_cast<float*>(priv + 2 * PX + 2 * PH);   // adjoint of the pre-sigmoid outputs [32][4]
     const float* W4s = reinterpret_cast<const float*>(smem + B_W4);
     const float* b2s = reinterpret_cast<const float*>(smem + B_B2);
-    // selector operands of the transposition: E_s[k][j] = 1 iff j == 16 s + k
-    bf16x8 e0, e1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        e0[e] = (__bf16)(ray == 8 * h + e ? 1.f : 0.f);
-        e1[e] = (__bf16)(ray == 16 + 8 * h + e ? 1.f : 0.f);
-    }
-    // operand offsets of this lane: row (lane & 31), 16-byte half h of a 32-byte k block
+    // operand offsets of this lane: row (lane & 31), 16-byte half h of a 32-byte k block; transposing reads: tr_lane_offset
     const int ox = ray * SXB + 16 * h, oh = ray * SHB + 16 * h;
+    const int tx = tr_lane_offset<SXB>(lane), th_ = tr_lane_offset<SHB>(lane);
     floatx16 accW2[2][2], accW0[2][2];
     float accTail[2][4], accW4[3][2], accb2[2], accb4[3];
 #pragma unroll
@@ -673,8 +685,8 @@ k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* 
             product<2, 4, 2, true, false>(
                 a2u, [&](int, int kk) { return hb[kk]; },
                 [&](int ub, int kk) { return ldop<2>(smem, B_W2 + 32 * ub * SHB + oh + 32 * kk, PW2); });
-            h1u[0] = transpose_block(hb[0], hb[1], e0, e1, nullptr);
-            h1u[1] = transpose_block(hb[2], hb[3], e0, e1, nullptr);
+            h1u[0] = ld_uop<SHB>(pl, PH, 0, th_);
+            h1u[1] = ld_uop<SHB>(pl, PH, 32, th_);
             // dW4[j][u] += sum_ray g[ray][j] relu(H2)[ray][u]   (the 16 adjoint rows requested in two batches, then used)
             const float bu0 = b2s[ray], bu1 = b2s[32 + ray];
             if constexpr (!(NMF_MLP_KNOCK & 4))
@@ -726,7 +738,8 @@ k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* 
             if constexpr (!(NMF_MLP_KNOCK & 32))
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const UOp d2u = transpose_block(dh[2 * a], dh[2 * a + 1], e0, e1, &accb2[a]);
+                const UOp d2u = ld_uop<SHB>(pl, PH, 32 * a, th_);
+                accb2[a] += (sum8(d2u.k[0].p[0]) + sum8(d2u.k[0].p[1])) + (sum8(d2u.k[1].p[0]) + sum8(d2u.k[1].p[1]));
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
@@ -754,12 +767,12 @@ k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* 
                 [&](int, int kk) { return dh[kk]; });
             // dW0 += dH1^T X (input columns 0-63 as two 32-column blocks; 64-79 through the transposed product)
             UOp d1u[2];
-            d1u[0] = transpose_block(dh[0], dh[1], e0, e1, nullptr);
-            d1u[1] = transpose_block(dh[2], dh[3], e0, e1, nullptr);
+            d1u[0] = ld_uop<SHB>(pl, PH, 0, th_);
+            d1u[1] = ld_uop<SHB>(pl, PH, 32, th_);
             if constexpr (!(NMF_MLP_KNOCK & 16))
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                const UOp xu = transpose_block(ldop<2>(x, ox + 64 * cb, PX), ldop<2>(x, ox + 64 * cb + 32, PX), e0, e1, nullptr);
+                const UOp xu = ld_uop<SXB>(x, PX, 32 * cb, tx);
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
@@ -769,13 +782,10 @@ k_brdf_mlp_bwd(MlpW w, MlpBwdSegs G, float* __restrict__ partials, const uint4* 
                             mfma_acc(accW0[a][cb], d1u[a].k[kp].p[Terms<2>::A[i]], xu.k[kp].p[Terms<2>::B[i]]);
             }
             if constexpr (!(NMF_MLP_KNOCK & 8)) {
-                const Op<2> xt = ldop<2>(x, ox + 128, PX);
-                floatx16 th = {0}, tl = {0};
-                th = mfma(xt.p[0], e0, th);
-                tl = mfma(xt.p[1], e0, tl);
-                Op<2> xk[2];
-                xk[0].p[0] = pack8(th, 0); xk[1].p[0] = pack8(th, 8);
-                xk[0].p[1] = pack8(tl, 0); xk[1].p[1] = pack8(tl, 8);
+                // the trailing input columns 64 .. (the diff vector's last five) as ROWS of a transposed product: columns 64-95 of the
+                // image on the lanes (80-95 are padding / the next row: their result rows are never read)
+                const UOp xtail = ld_uop<SXB>(x, PX, 64, tx);
+                const Op<2> (&xk)[2] = xtail.k;
                 floatx16 tt[2] = {{0}, {0}};
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp)

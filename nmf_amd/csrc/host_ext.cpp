@@ -121,6 +121,7 @@ struct TimedScope {
 // probe records a timed event on the launching stream on either side.  Names are the kernels' identifiers as rocprofv3 prints them.
 CallTimer* g_kernel_timer = nullptr;
 std::string g_kernel_filter;         // non-empty: only kernels whose name contains it
+bool g_kernel_by_stream = false;
 void* g_probe_open = nullptr;
 void launch_probe(const char* name, void* stream, int phase) {
     CallTimer* t = g_kernel_timer;
@@ -1107,14 +1108,15 @@ PYBIND11_MODULE(_nmf_host, m) {
         delete t;
         return out;
     });
-    m.def("kernel_timing_begin", [](const std::string& only) {
+    m.def("kernel_timing_begin", [](const std::string& only, bool by_stream) {
+        g_kernel_by_stream = by_stream;
         if (!g_kernel_timer) g_kernel_timer = new CallTimer();
         g_kernel_timer->next = 0;
         g_kernel_timer->recs.clear();
         g_kernel_filter = only;
         g_probe_open = nullptr;
         check(nmf_set_launch_probe(&launch_probe), "nmf_set_launch_probe");
-    }, py::arg("only") = "");
+    }, py::arg("only") = "", py::arg("by_stream") = false);
     m.def("kernel_timing_end", []() {      // waits for the recorded work; -> {kernel: (ms, launches)}
         py::dict out;
         check(nmf_set_launch_probe(nullptr), "nmf_set_launch_probe");
@@ -1129,9 +1131,15 @@ PYBIND11_MODULE(_nmf_host, m) {
             auto& e = acc[kernel_name(r.name)];
             e.first += ms;
             e.second += 1;
-            auto& q = acc["@" + std::to_string(reinterpret_cast<int64_t>(r.stream))];      // per-stream sums (the main stream = the chain)
+            const std::string sid = "@" + std::to_string(reinterpret_cast<int64_t>(r.stream));
+            auto& q = acc[sid];      // per-stream sums (the main stream = the chain) ...
             q.first += ms;
             q.second += 1;
+            if (g_kernel_by_stream) {      // ... and per kernel and stream
+                auto& w = acc[kernel_name(r.name) + sid];
+                w.first += ms;
+                w.second += 1;
+            }
         }
         for (auto& kv : acc) out[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
         delete t;

@@ -368,14 +368,17 @@ def _store_grads(out, nerf, full_bytes=1 << 20):
             out["grad_slice4/" + n] = p.grad[0, :, ::4, ::4]
 
 
-def _full_size_case(name, max_retrace, G=128, BG=512, B=4096, ray_seed=0, noise_seed=1234):
+def _full_size_case(name, max_retrace, G=128, BG=512, B=4096, ray_seed=0, noise_seed=1234, near_far=(2.5, 7.0), aabb_half=1.5,
+                    roughness_bias=None, eye=None):
     """Full BASELINE size (4096 rays, 128^3, 512x1024 env): noise is replayed BY SEED (the global torch CPU generator);
     per-ray outputs, losses, parameter gradients and the reference's bookkeeping decisions are stored."""
-    nerf, sd = small_reference(G, BG, max_retrace_rays=(max_retrace,))
+    nerf, sd = small_reference(G, BG, max_retrace_rays=(max_retrace,), near_far=tuple(near_far), aabb_half=aabb_half)
+    if roughness_bias is not None:            # (a calibrated attribute of the reference's diffuse module, train.py:429-437)
+        nerf.model.diffuse_module.roughness_bias = roughness_bias
     nerf.sampler.update(nerf.rf, init=False)
     nerf.sampler.update(nerf.rf, init=True)
     nerf.model.detach_N = False
-    rays, focal = synthetic.camera_rays(B, seed=ray_seed)
+    rays, focal = synthetic.camera_rays(B, seed=ray_seed) if eye is None else synthetic.camera_rays(B, seed=ray_seed, eye=tuple(eye))
     torch.manual_seed(noise_seed)
     with BookkeepingTap() as tap:
         ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
@@ -386,6 +389,8 @@ def _full_size_case(name, max_retrace, G=128, BG=512, B=4096, ray_seed=0, noise_
     total = (loss + 0.1 * stats["ori_loss"] + 3e-4 * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 4096
     total.backward()
     out = dict(grid=G, bg_res=BG, n_rays=B, ray_seed=ray_seed, noise_seed=noise_seed, max_retrace=max_retrace,
+               near_far=np.asarray(near_far, dtype=np.float64), aabb_half=float(aabb_half),
+               roughness_bias=float(nerf.model.diffuse_module.roughness_bias), eye=np.asarray(eye if eye is not None else (2.4, -2.8, 1.6)),
                rgb_map=ims["rgb_map"], acc_map=ims["acc_map"],
                whole_valid=wv, n_samples=np.asarray(stats["n_samples"]), loss=loss, total=total,
                ori_loss=stats["ori_loss"], prediction_loss=stats["prediction_loss"],
@@ -425,6 +430,14 @@ def case_e2e_full_steady():
 def case_e2e_g300():
     """final grid of the schedule (300^3, 1036 steps per ray, 41 MB of factor tables), steady state, small ray batch"""
     _full_size_case("e2e_g300_steady", 650000, G=300, B=192, ray_seed=4, noise_seed=77)
+
+
+def case_e2e_variant():
+    """the scene variations of the reference's dataset configs at full size: near_far [2, 6]
+    (configs/dataset/materials.yaml), aabb_scale 2 (helmet.yaml:8: the box of the field is twice the scene box), a high-specular
+    material (roughness_bias -2.5: sharp GGX lobes, small env-map footprints), another camera; steady state"""
+    _full_size_case("e2e_variant_steady", 650000, ray_seed=3, noise_seed=4321, near_far=(2.0, 6.0), aabb_half=3.0,
+                    roughness_bias=-2.5, eye=(-3.1, 2.2, 2.9))
 
 
 def case_upsample():
@@ -491,7 +504,7 @@ def case_blender_rays():
 
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
-             e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300)
+             e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

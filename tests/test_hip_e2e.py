@@ -165,10 +165,20 @@ def test_e2e_small_eval():
     assert_close(ims["world_normal"].cpu(), g["world_normal"], rtol=1e-4, atol=2e-5, what="world_normal")
 
 
+def _fixture_rays(g):
+    """the rays of a full-size fixture: camera of tests/golden/make_golden.py:_full_size_case (the variant fixtures carry their eye)"""
+    kw = dict(eye=tuple(float(v) for v in g.np("eye"))) if "eye" in g else {}
+    return synthetic.camera_rays(g["n_rays"], seed=g["ray_seed"], **kw)
+
+
 def _full_size_model(g):
     from nmf_amd.config import build_model
     G, BG = g["grid"], g["bg_res"]
-    nerf, _ = build_model(grid=G, bg_resolution=BG, device=DEV, overrides={"model.max_retrace_rays": [g["max_retrace"]]})
+    # scene variations of the dataset configs (near_far, aabb_scale, a calibrated roughness bias): stored by the newer fixtures
+    kw = dict(near_far=tuple(float(v) for v in g.np("near_far")), aabb_half=float(g["aabb_half"])) if "near_far" in g else {}
+    nerf, _ = build_model(grid=G, bg_resolution=BG, device=DEV, overrides={"model.max_retrace_rays": [g["max_retrace"]]}, **kw)
+    if "roughness_bias" in g:
+        nerf.model.diffuse_module.roughness_bias = float(g["roughness_bias"])
     nerf.load_state_dict(synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0), strict=False)
     nerf.train()
     nerf.sampler.update(nerf.rf, init=False)
@@ -181,7 +191,7 @@ def _full_size_model(g):
 
 def _seeded_render(nerf, g, pins=None):
     from nmf_amd.noise import ReplayNoise
-    rays, focal = synthetic.camera_rays(g["n_rays"], seed=g["ray_seed"])
+    rays, focal = _fixture_rays(g)
     torch.manual_seed(g["noise_seed"])
     return nerf(rays.to(DEV), focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=ReplayNoise(DEV, None, pins=pins))
 
@@ -206,14 +216,21 @@ def _check_loss_and_gradients(nerf, g, ims, st, full_tol=5e-3, loss_tol=1e-4):
     _check_gradients(nerf, g, full_tol)
 
 
-def _check_gradients(nerf, g, full_tol=5e-3):
-    """the .grad of every parameter against the reference's: norms, FULL tensors (<= 1 MiB) and strided slices"""
+def _check_gradients(nerf, g, full_tol=5e-3, loose=None):
+    """the .grad of every parameter against the reference's: norms, FULL tensors (<= 1 MiB) and strided slices.
+    loose: {name substring: tolerance} for tensors whose gradient is ill-conditioned in a fixture (stated where it is passed)"""
+    def tol_of(name):
+        t = max(2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3, full_tol)
+        for key, v in (loose or {}).items():
+            if key in name:
+                t = max(t, v)
+        return t
     params = dict(nerf.named_parameters())
     bad, rows = [], []
     for k in g.keys("gradnorm/"):
         name = k[len("gradnorm/"):]
         ref, got = float(g[k]), float(params[name].grad.norm())
-        tol = max(2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3, full_tol)
+        tol = tol_of(name)
         rows.append(f"  |grad| {name:48s} {got:.6e} vs {ref:.6e}  ({got / max(ref, 1e-30) - 1:+.2e})")
         if abs(got - ref) > tol * ref + 1e-12:
             bad.append(rows[-1])
@@ -224,7 +241,7 @@ def _check_gradients(nerf, g, full_tol=5e-3):
         got = (gr if k.startswith("grad/") else gr[0, :, ::4, ::4]).detach().cpu()
         ref = torch.as_tensor(g[k]).reshape(got.shape)
         scale = float(ref.abs().max())
-        tol = max(2e-2 if ("roughness" in name or "mipbias" in name) else 5e-3, full_tol)
+        tol = tol_of(name)
         # the whole tensor: relative L2 error (catches sign / layout / scale errors of any element group) ...
         rel = float((got.double() - ref.double()).norm() / ref.double().norm().clip(min=1e-30))
         # ... and no single element further off than a few per cent of the largest entry
@@ -794,6 +811,43 @@ def test_render_cli_with_relighting(tmp_path, capsys):
     a = np.asarray(Image.open(tmp_path / "imgs" / "000.png")).astype(np.float32)
     b = np.asarray(Image.open(tmp_path / "relit" / "000.png")).astype(np.float32)
     assert a.shape == (48, 48, 3) and np.isfinite(b).all() and np.abs(a - b).mean() > 0.5       # lighting changed
+
+
+def test_relit_frame_at_full_size(tmp_path):
+    """BASELINE configs[4] at its size: `render_only=True fixed_bg=<env>.th` (train.py:64-190, README.md:22-24) -- a checkpoint of
+    the 128^3 scene, ONE full 800 x 800 frame rendered to completion at eval_batch_size, once with its own environment map and once
+    with a fixed_bg of ANOTHER resolution (256 x 512 against 512 x 1024: the reference hard-codes 512).  Every pixel
+    finite, the silhouette (accumulated opacity, i.e. geometry) untouched by the relighting, the radiance changed, rays/s reported."""
+    import bench
+    from nmf_amd import render as R
+    from nmf_amd.modules.integral_equirect import IntegralEquirect
+    dev = torch.device("cuda", 0)
+    nerf, cfg = bench.build(dev)
+    ck = str(tmp_path / "s1.th")
+    nerf.save(ck, cfg["arch"] if "arch" in cfg else __import__("nmf_amd.config", fromlist=["resolved_config"]).resolved_config()["arch"])
+    del nerf
+    torch.cuda.empty_cache()
+    rec = R.main(["--ckpt", ck, "--views", "1", "--res", "800", "--out", str(tmp_path / "own")])
+    assert rec["frames"] == 1 and rec["rays_per_s"] > 1e5 and not rec.get("relit")
+    other = IntegralEquirect(bg_resolution=256, init_val=0.0, activation="exp", mipbias=0)
+    with torch.no_grad():                       # a sky gradient + a sun: nothing like the learned map
+        H, W = other.bg_mat.shape[-2:]
+        v = torch.linspace(1.0, -2.5, H)[None, None, :, None].expand(1, 3, H, W).clone()
+        v[:, :, 40:56, 100:132] = 3.0
+        other.bg_mat.copy_(v * torch.tensor([0.9, 1.0, 1.3])[None, :, None, None])
+    torch.save(other.state_dict(), tmp_path / "forest.th")
+    rec2 = R.main(["--ckpt", ck, "--views", "1", "--res", "800", "--fixed-bg", str(tmp_path / "forest.th"), "--out", str(tmp_path / "relit")])
+    assert rec2["relit"] and rec2["frames"] == 1 and rec2["rays_per_s"] > 1e5
+    from PIL import Image
+    a = np.asarray(Image.open(tmp_path / "own" / "000.png")).astype(np.float32)
+    b = np.asarray(Image.open(tmp_path / "relit" / "000.png")).astype(np.float32)
+    assert a.shape == (800, 800, 3) and b.shape == a.shape and np.isfinite(a).all() and np.isfinite(b).all()
+    obj = (a < 254).any(-1) | (b < 254).any(-1)                      # the white background stays white (bg_col = 1)
+    assert 0.05 < obj.mean() < 0.8
+    assert np.abs(a - b)[obj].mean() > 2.0                           # the lighting changed on the object ...
+    assert np.abs(a - b)[~obj].max() <= 1                            # ... and nowhere else (one 8-bit step on the silhouette)
+    mse = ((a - b) ** 2).mean() / 255.0 ** 2
+    assert -10 * np.log10(mse) < 35.0                                # PSNR of the relit frame against the own-light frame
 
 
 @pytest.mark.gpu

@@ -11,7 +11,7 @@ import torch
 from conftest import Golden, assert_close
 from nmf_amd import synthetic
 from oracle import nmf_oracle as O
-from test_hip_e2e import (DEV, _check_gradients, _early_phase_order, _frac_close, _full_size_model,
+from test_hip_e2e import (DEV, _check_gradients, _fixture_rays, _early_phase_order, _frac_close, _full_size_model,
                           _pin_reference_bookkeeping)
 from test_hip_parity import _field_tables, _hip
 
@@ -41,7 +41,7 @@ def _timed_step(nerf, g, pins, n_rays=None):
 
     tr.fast.chunk = chunk
     B = g["n_rays"]
-    rays, focal = synthetic.camera_rays(B, seed=g["ray_seed"])
+    rays, focal = _fixture_rays(g)
     gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(9)).to(DEV)       # as make_golden.py draws it
     torch.manual_seed(g["noise_seed"])
     rec = []
@@ -51,9 +51,11 @@ def _timed_step(nerf, g, pins, n_rays=None):
     return out, rec[0]
 
 
-@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_full_seeded"])
+@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_full_seeded", "e2e_variant_steady"])
 def test_timed_path_vs_reference(name):
-    """Trainer.step (tape-free) on the reference's 4096-ray / 128^3 steady-state run, its 300^3 run and its early-phase run:
+    """Trainer.step (tape-free) on the reference's 4096-ray / 128^3 steady-state run, its 300^3 run, its early-phase run and the
+    scene-variation run (near_far [2, 6] as configs/dataset/materials.yaml, aabb_scale 2 as helmet.yaml:8, a high-specular material
+    with roughness_bias -2.5, another camera):
     sample counts and the budget mask bit-exact, radiance 1e-4, loss 1e-4, FULL parameter gradients at the tolerances of the
     module-path tests (tests/test_hip_e2e.py::_check_loss_and_gradients)."""
     g = Golden(name)
@@ -75,10 +77,27 @@ def test_timed_path_vs_reference(name):
     assert_close(tr["acc_map0"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     frac, worst = _frac_close(tr["rgb_map0"].cpu(), g["rgb_map"], 1e-4, 1e-4)
     print(f"{name} (tape-free pass): rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
-    assert frac == 1.0 and worst < 1e-4, (frac, worst)       # EVERY ray (measured worst: 4.9e-5 at 128^3, 1.6e-5 at 300^3)
-    assert_close(torch.tensor(out["loss"]), g["loss"], rtol=1e-4, what="loss")
-    assert_close(rec["total"].cpu().reshape(()), g["total"], rtol=1e-4, what="total")
-    _check_gradients(nerf, g, full_tol=3e-2 if "g300" in name else 5e-3)
+    if "variant" in name:
+        # The high-specular variant looks the environment map up through footprints of a fraction of a texel: a box value is
+        # (S(tr) + S(bl) - S(tl) - S(br)) * 1000 / size with |S| up to ~300 in fp32, so one ulp of a table entry or of a
+        # corner position is a visible change of that lookup -- the reference's OWN arithmetic does not reproduce to 1e-4 there: the
+        # CPU oracle, same libm, differs from it by up to 1.4e-3 on this fixture (tests/test_oracle_golden.py).  The GPU's expf differs
+        # from the CPU's in the last bit of ~1 % of the texels.  Checked: no ray further off than 2e-3, no bias, most rays at 1e-4.
+        d = (tr["rgb_map0"].cpu().double() - g["rgb_map"].double())
+        print(f"   mean |d| {float(d.abs().mean()):.2e}, mean d {float(d.mean()):+.2e}, median |d| {float(d.abs().median()):.2e}")
+        assert worst < 2e-3 and frac >= 0.6 and float(d.abs().mean()) < 1e-4 and abs(float(d.mean())) < 2e-5, (frac, worst)
+    else:
+        assert frac == 1.0 and worst < 1e-4, (frac, worst)       # EVERY ray (measured worst: 4.9e-5 at 128^3, 1.6e-5 at 300^3)
+    loss_tol = 1e-3 if "variant" in name else 1e-4
+    assert_close(torch.tensor(out["loss"]), g["loss"], rtol=loss_tol, what="loss")
+    assert_close(rec["total"].cpu().reshape(()), g["total"], rtol=loss_tol, what="total")
+    # The variant's gradients THROUGH the derivative of the sharp env-map lookups -- density factors (via the normals), roughness head,
+    # mip bias -- are ill-conditioned in the reference's own arithmetic: one-ulp moves of 1 % of the env-map activations change them
+    # by 0.4-1.5 % on the CPU (tools/sat_sensitivity.py: density planes 5e-3 / 1.5e-2, roughness 1.2e-2, mip bias 4e-3, while the BRDF
+    # MLP and the env map itself move by 2e-5 / 3e-5); the GPU differs from the CPU in expf, atan2, log, pow and the order of every
+    # atomic sum at once: measured 4-10 % / 12 % / 6 % on those tensors, 1e-4 ... 1e-2 on all others.
+    loose = {"density_rf": 0.15, "roughness": 0.2, "mipbias": 0.1} if "variant" in name else None
+    _check_gradients(nerf, g, full_tol=3e-2 if "g300" in name else (2e-2 if "variant" in name else 5e-3), loose=loose)
 
 
 @pytest.mark.parametrize("G,M,seed", [(128, 60000, 2), (300, 20000, 3)])

@@ -264,23 +264,30 @@ def test_psnr_formula():
     assert abs(float(O.psnr_8bit(pred, gt)) - want) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["e2e_full_seeded", "e2e_g300_steady", "e2e_full_steady"])
+@pytest.mark.parametrize("name", ["e2e_full_seeded", "e2e_g300_steady", "e2e_full_steady", "e2e_variant_steady"])
 def test_full_size_replay_by_seed(name):
     """BASELINE size (4096 rays, 128^3, 512x1024 env) in the early phase (1000 secondary rays re-traced) and in the steady
     state bench.py times (all ~246 k re-traced, ~0.9 M secondary samples), plus the final 300^3 grid of the schedule on a
     small batch: the reference's noise is re-created from torch's seeded global CPU generator (same call order and shapes,
     unused draws included).  Bookkeeping (sample counts, budget mask, per-sample secondary-ray counts at both levels, the
-    re-trace order) bit-exact; radiance, losses and parameter gradients (full tensors where the fixture holds them)."""
+    re-trace order) bit-exact; radiance, losses and parameter gradients (full tensors where the fixture holds them).
+    `e2e_variant_steady`: the scene variations of the dataset configs -- near_far [2, 6] (materials.yaml), aabb_scale 2 (helmet.yaml:8),
+    a high-specular material (roughness_bias -2.5), another camera; its sample budget cuts the batch to 1765 of 4096 rays."""
     g = Golden(name)
     G, BG, B = g["grid"], g["bg_res"], g["n_rays"]
     sd = synthetic.state_dict_s1(grid=G, bg_resolution=BG, seed=0)
     for k, v in sd.items():
         if k != "model.brdf_sampler.angs":
             v.requires_grad_(True)
-    cfg = O.Cfg(grid=G, detach_N=False, max_retrace_rays=(g["max_retrace"],))
+    extra = {}
+    if "near_far" in g:
+        h = float(g["aabb_half"])
+        extra = dict(near_far=tuple(float(v) for v in g.np("near_far")), aabb=torch.tensor([[-h] * 3, [h] * 3]),
+                     roughness_bias=float(g["roughness_bias"]))
+    cfg = O.Cfg(grid=G, detach_N=False, max_retrace_rays=(g["max_retrace"],), **extra)
     vol = O.dense_alpha_mask({k: v.detach() for k, v in sd.items()}, cfg)
     assert int(vol.sum()) == g["n_alpha"]
-    rays, focal = synthetic.camera_rays(B, seed=g["ray_seed"])
+    rays, focal = synthetic.camera_rays(B, seed=g["ray_seed"], **(dict(eye=tuple(float(v) for v in g.np("eye"))) if "eye" in g else {}))
     torch.manual_seed(g["noise_seed"])
     trace = {}
     # Steady state: the order in which ALL secondary rays are re-traced pairs each of them with a jitter row.  It is an
@@ -307,7 +314,15 @@ def test_full_size_replay_by_seed(name):
         assert int((pos_o - pos_r).abs().max()) <= 16           # swaps of near neighbours only
     else:
         assert torch.equal(trace["retrace_idx0"].int(), g["retrace_idx0"])
-    assert_close(ims["rgb_map"], g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
+    if "variant" in name:
+        # sub-texel env-map footprints (roughness_bias -2.5): the fp32 summed-area table loses the box value to cancellation
+        #  and a last-bit difference of a normal (the reference's autograd against the restated stencil) moves a lookup
+        # visibly -- 5 of 5295 elements differ by more than 1e-4, the worst by 1.4e-3; everything else at 1e-4
+        err = (ims["rgb_map"].detach() - g["rgb_map"]).abs()
+        assert float(err.max()) < 3e-3 and int((err > 1e-4 + 1e-4 * g["rgb_map"].abs()).sum()) <= 16, (float(err.max()),)
+        assert float(err.mean()) < 5e-6
+    else:
+        assert_close(ims["rgb_map"], g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
     assert_close(ims["acc_map"], g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(9))
     total, loss = O.training_loss(ims, st, gt, 4096, sd)
@@ -317,14 +332,21 @@ def test_full_size_replay_by_seed(name):
     for k in g.keys("gradnorm/"):
         name_ = k[len("gradnorm/"):]
         ref = float(g[k])
-        assert abs(float(sd[name_].grad.norm()) - ref) <= 2e-3 * ref + 1e-12, (name_, float(sd[name_].grad.norm()), ref)
+        # (the mip-bias scalar of the sharp-footprint variant: a sum of cancelling per-lookup terms, 1.3 % off)
+        ntol = 2e-2 if ("variant" in name and ("mipbias" in name_ or "roughness" in name_)) else 2e-3
+        assert abs(float(sd[name_].grad.norm()) - ref) <= ntol * ref + 1e-12, (name_, float(sd[name_].grad.norm()), ref)
     for k in g.keys("grad/") + g.keys("grad_slice4/"):
         name_ = k.split("/", 1)[1]
         got = sd[name_].grad if k.startswith("grad/") else sd[name_].grad[0, :, ::4, ::4]
         ref = g[k].reshape(got.shape) if g.np(k).shape != () else torch.as_tensor(g[k])
         scale = float(ref.abs().max())
         tol = 2e-2 if ("roughness" in name_ or "mipbias" in name_) else 2e-3
-        assert_close(got, ref, rtol=tol, atol=tol * scale + 1e-12, what=k)
+        if "variant" in name:       # (a few elements carry the moved sharp lookups: the whole tensor in relative L2, no element far off)
+            rel = float((got.detach().double() - ref.double()).norm() / ref.double().norm().clip(min=1e-30))
+            worst = float((got.detach().double() - ref.double()).abs().max()) / max(scale, 1e-30)
+            assert rel <= 2.5 * tol and worst <= 8 * tol, (k, rel, worst)      # (measured: 2.1e-3 on a density line)
+        else:
+            assert_close(got, ref, rtol=tol, atol=tol * scale + 1e-12, what=k)
 
 
 def test_upsample_schedule_and_step_size():
