@@ -245,12 +245,8 @@ __global__ void __launch_bounds__(256) k_segment_sum_group(const float* __restri
 // Lanes per ray of the large batches.  The BACKWARD takes 16 (R4): 23 k of the 247 k re-traced rays of a step keep more than 8
 // samples (11 k more than 16, the longest 200) and a wave is as slow as its longest ray -- every chunk of a ray beyond the first
 // costs four dependent memory round trips there; 41 -> 34 us, the same bits (tools/composite_bench.py).  The forward stays at 8:
-// no faster with 16, and its per-ray opacity sum would change its association.  NMF_COMPOSITE_W = 8 / 16 forces both (tuning knob).
-static int group_width(int dflt) {
-    const char* e = getenv("NMF_COMPOSITE_W");
-    const int w = e ? atoi(e) : 0;
-    return (w == 8 || w == 16) ? w : dflt;
-}
+// no faster with 16, and its per-ray opacity sum would change its association.
+static int group_width(int dflt) { return dflt; }
 
 extern "C" int nmf_composite_fwd(const float* sigma, const float* dist, const int64_t* offsets, int64_t b,
                                  float distance_scale, float* weight, float* acc, void* stream) {

@@ -1730,10 +1730,6 @@ extern "C" int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, 
 // counter copies per brick (power of two; measured on S1: 1 -> 64 us, 4 -> 45 us, 8 -> 64 us of binning per 0.88 M
 // samples, the scan growing with the copies): 4 while the single-workgroup scan over [brick][copy] stays short
 static int bin_copies(int64_t nb) {
-    if (const char* ev = getenv("NMF_BIN_COPIES")) {   // tuning knob: 1, 2, 4 or 8
-        const int k = atoi(ev);
-        if (k == 1 || k == 2 || k == 4 || k == 8) return k;
-    }
     return nb <= 32768 ? 4 : 1;
 }
 
@@ -1763,7 +1759,6 @@ PlanLayout plan_layout(void* base, int64_t M, int32_t grid) {
     L.nb = L.nbx * L.nbx * L.nbx;
     L.kc = bin_copies(L.nb);
     int item_size = M > 400000 ? BWD_ITEM : BWD_ITEM / 2;   // measured: profiles/README.md (r01_i)
-    if (const char* ev = getenv("NMF_BWD_ITEM")) item_size = atoi(ev) >= BWD_ITEM_MIN ? atoi(ev) : item_size;   // tuning knob
     L.item_size = (item_size + 3) & ~3;
     L.max_items = M / BWD_ITEM_MIN + L.nb + 1;
     L.n_chunks = (L.nb + SB_CHUNK - 1) / SB_CHUNK;
@@ -1840,10 +1835,9 @@ int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg
 // place = false: the caller follows with k_place_records (the walk that sorts inside its own call)
 // clean: L.counts / L.scan_state point into the caller's kept scratch (zero now, zero again afterwards): no memset
 int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false) {
-    const char* ev2 = getenv("NMF_BINS_TWO_PASS");       // tuning knob: 1 = k_bins_partial + k_bins_final
-    const bool two_pass = ev2 && atoi(ev2) == 1;
-    // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU)
-    const bool lookback = (!two_pass || clean) && L.n_scan_chunks <= 2048;
+    // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU); grids beyond ~500^3 take
+    // the two-launch scan (k_bins_partial + k_bins_final)
+    const bool lookback = L.n_scan_chunks <= 2048;
     const size_t count_bytes = sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc;
     if (!clean || !lookback) {
         hipError_t e = hipMemsetAsync(L.counts, 0, clean ? count_bytes : L.zero_bytes, st);
@@ -1975,7 +1969,6 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
     const int nz = (want_d ? 1 : 0) + (want_a ? 1 : 0);
     const int z_density = want_d ? 0 : -1, z_app = want_a ? (want_d ? 1 : 0) : -1;
     int64_t gcap = 16384;
-    if (const char* ev = getenv("NMF_BWD_GRID")) gcap = atoi(ev) > 0 ? atoi(ev) : gcap;   // tuning knob
     const int64_t max_items = M / L.item_size + L.nb + 1;
     const int64_t grid_x = max_items < gcap ? max_items : gcap;       // single-wave workgroups per plane
     const dim3 grid((unsigned)grid_x, (unsigned)(3 * nz)), block(BWD_THREADS);

@@ -645,11 +645,11 @@ def sat_lookup_fwd(sat, dirs, sa, mipbias, pole_rows, sc=None):
 # lookups per call from which the table adjoint is binned (three more launches than the direct scatter; measured with
 # tools/env_bwd_bench.py: 47 k lookups 53-73 us against 51 direct, 247 k lookups 138 against 176; in the training step the call
 # sits on a side stream and the step time is the same either way, tools/ab_inprocess.py hip:ENV_BINNED_MIN_LOOKUPS).
-# NMF_ENV_BINNED=0 keeps the direct scatter, =1 bins whatever the count -- tests compare the two
+# (a module constant: tests and tools/env_bwd_bench.py set it to compare the two forms)
 # (from 30 k lookups: alone the two forms take the same time at 47 k -- 51 / 52 us -- but in the backward of a training step the leaf
 # level's adjoint runs next to the binned adjoint of the level above, the value walk and the MLP backward, and the direct form's
 # float atomics queue behind theirs at the memory side: 1.375 -> 1.361 ms per step)
-ENV_BINNED_MIN_LOOKUPS = {"0": 1 << 62, "1": 1}.get(os.environ.get("NMF_ENV_BINNED", ""), 30000)
+ENV_BINNED_MIN_LOOKUPS = 30000
 
 
 def _cdiv(a, b):

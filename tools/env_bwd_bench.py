@@ -7,8 +7,6 @@ import argparse
 import os
 import sys
 
-os.environ["NMF_STEP_CORE"] = "0"      # the Python pass: its calls go through hip.sat_lookup_bwd, where the spy sits
-
 import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +24,8 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     nerf, params = bench.build(dev, grid=a.grid)
-    tr = Trainer(nerf, params)
+    nerf.fused_training_pass = False        # the operator graph: its calls go through hip.sat_lookup_bwd, where the spy sits
+    tr = Trainer(nerf, params, tape_free=False)
     batches, focal = bench.make_batches(nerf, 3, bench.CHUNK, 0, dev)
     noise = DeviceNoise(dev, seed=1)
     for i in range(2):
