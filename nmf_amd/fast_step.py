@@ -360,20 +360,29 @@ class TrainPass:
         key = (dev, G, H, W) + tuple(id(q) for q in n.rf._param_list()) + tuple(id(d[k]) for d, k in sl[1])
         c = self._acc_cache
         if c is None or c.key != key:
-            shapes = ([(G, G, 48)] * 3 + [(G, 32)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)]      # field (packed)
-                      + [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)]                                    # BRDF MLP
-                      + [(11, 24), (11,)]                                                                     # stacked heads
-                      + [(H, W, 4), (2, 3), (1,)])                                                            # d_sat, d_pole, d_mip
+            # Layout of the flat buffer.  What the optimizer reads as .grad lies in two CONTIGUOUS regions, so that the data-parallel
+            # trainer sums each over the ranks in place, without packing: `late` = the field's gradients in parameter layout (the
+            # unpacked density gradients, appearance tables, basis matrix) + a tail of [has-gradient flag, has-env flag, guard, pad];
+            # `early` = everything no field walk writes (BRDF MLP, stacked heads, mip bias, the env-map table gradient).
+            shapes = ([(G, G, 48)] * 3 + [(G, 32)] * 3                                                        # 0-5   packed density accumulators
+                      + [(G, G, 16)] * 3 + [(G, 16)] * 3 + [(G, G, 24)] * 3 + [(G, 24)] * 3 + [(24, 72)] + [(4,)]      # 6-19  late region
+                      + [(64, 66), (64,), (64, 64), (64,), (4, 64), (4,)] + [(11, 24), (11,)] + [(1,)] + [(3, H, W)]   # 20-29 early region
+                      + [(H, W, 4), (2, 3)])                                                                  # 30-31 d_sat, d_pole
             sizes = [int(torch.Size(s_).numel()) for s_ in shapes]
             pad = [(s_ + 3) & ~3 for s_ in sizes]                      # every view 16-byte aligned
             flat = torch.zeros(sum(pad), dtype=torch.float32, device=dev)
-            v, o = [], 0
+            v, o, offs = [], 0, []
             for s_, sh, p_ in zip(sizes, shapes, pad):
+                offs.append(o)
                 v.append(flat[o:o + s_].view(sh))
                 o += p_
-            c = _ns(key=key, flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], g_apl=v[6:9], g_ali=v[9:12], g_basis=v[12],
-                    g_mlp=v[13:19], g_hW=v[19], g_hb=v[20], d_sat=v[21], d_pole=v[22], d_mip=v[23], used_env=False,
-                    pairs=None, gp=None, gl=None, d_bg=None, d_bg_view=None, l1=None, l1_dev=None, early_pairs=None)
+            offs.append(o)
+            gp = [t.view(1, G, G, 16).permute(0, 3, 1, 2) for t in v[6:9]]      # [1,16,G,G] over [G][G][16] storage (channels last)
+            gl = [t.view(1, G, 1, 16).permute(0, 3, 1, 2) for t in v[9:12]]     # [1,16,G,1] over [G][16]
+            c = _ns(key=key, flat=flat, g_dpk=v[0:3], g_dlk=v[3:6], gp=gp, gl=gl, g_apl=v[12:15], g_ali=v[15:18], g_basis=v[18],
+                    tail=v[19], g_mlp=v[20:26], g_hW=v[26], g_hb=v[27], d_mip=v[28], d_bg=v[29], d_sat=v[30], d_pole=v[31],
+                    late=flat[offs[6]:offs[20]], early=flat[offs[20]:offs[30]], used_env=False,
+                    pairs=None, d_bg_view=None, l1=None, l1_dev=None, early_pairs=None)
             self._acc_cache = c
             self._delivered = None
         if zero:
@@ -439,20 +448,14 @@ class TrainPass:
         n = self.nerf
         bgm = n.bg_module
         used = bool(self._core.env_was_used()) if self._core else bool(a.used_env)
-        if a.early_pairs is not None and a.d_bg is not None:
-            if not used:
-                a.d_bg.zero_()
+        if a.early_pairs is not None:
             return a.early_pairs
         m = n.model.brdf.mlp
         pairs = list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
         hps = n.model.diffuse_module._head_params()
         for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
             pairs += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
-        if a.d_bg is None:
-            a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
-        if not used:
-            a.d_bg.zero_()
-        pairs += [(bgm.bg_mat, a.d_bg), (bgm.mipbias, a.d_mip)]
+        pairs += [(bgm.bg_mat, a.d_bg), (bgm.mipbias, a.d_mip)]     # (a step that never looked the env map up: the zeros of the step's fill)
         a.early_pairs = [(prm, g) for prm, g in pairs if prm.requires_grad]
         return a.early_pairs
 
@@ -515,9 +518,6 @@ class TrainPass:
             self._core_acc = a
             c.g_dpk, c.g_dlk, c.g_apl, c.g_ali, c.g_mlp = list(a.g_dpk), list(a.g_dlk), list(a.g_apl), list(a.g_ali), list(a.g_mlp)
             c.g_basis, c.g_hW, c.g_hb, c.d_sat, c.d_pole, c.d_mip = a.g_basis, a.g_hW, a.g_hb, a.d_sat, a.d_pole, a.d_mip
-            bgm = self.nerf.bg_module
-            if a.d_bg is None:
-                a.d_bg = torch.empty_like(bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1]))
             c.d_bg_out = a.d_bg if self.overlap else None
 
     @torch.no_grad()
@@ -596,10 +596,7 @@ class TrainPass:
         l1 = None
         if l1_scale is not None:          # the L1 term's gradient rides in the unpack launch (one launch less on the step's tail)
             l1 = ([x.detach() for x in list(rf.density_rf.app_plane) + list(rf.density_rf.app_line)], l1_scale)
-        if a.gp is None:
-            a.gp, a.gl = hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, l1=l1)
-        else:
-            hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, out=(a.gp, a.gl), l1=l1)
+        hip.vm_unpack_density_grad(p, a.g_dpk, a.g_dlk, out=(a.gp, a.gl), l1=l1)
         gp, gl = a.gp, a.gl
         if a.pairs is None:       # (parameter, gradient tensor) of everything that lives in the persistent buffers
             pairs = list(zip(rf._param_list(), rf._grads_to_param_layout(gp, gl, a.g_apl, a.g_ali, a.g_basis)))
@@ -647,9 +644,53 @@ class TrainPass:
                 a.l1 = (self.l1_scale, torch.full((), self.l1_scale, dtype=torch.float32, device=a.flat.device))
             l1 = a.l1[1]
         for prm, g in self._finish_grads(a, l1):
-            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+            if prm.grad is not None and prm.grad is not g:      # a chunk of this step went through the operator graph: folded INTO the
+                g.add_(prm.grad.reshape(g.shape).to(g.dtype))   # pass's tensor (the data-parallel trainer sums these tensors in place)
+            prm.grad = g
         self._delivered = None
         self.acc = None
+
+    def comm_regions(self):
+        """(early, late, tail) of the accumulators of the step that end_step has just closed (or that early_pairs opened): the two
+        contiguous slices of the flat buffer the data-parallel trainer sums over the ranks in place, and the late slice's tail
+        [has-gradient flag, has-env flag, guard, pad]"""
+        a = self._acc_cache
+        return a.early, a.late, a.tail
+
+    def fold_foreign(self):
+        """a gradient a chunk left in .grad OUTSIDE the accumulators (a chunk that went through the operator graph) on a rank whose
+        fused chunks produced none: moved into the accumulator tensor, which is what the ranks sum"""
+        a = self._acc_cache
+        self.assign_reduced(False, False)          # (builds the pairs)
+        bgm = self.nerf.bg_module
+        for prm, g in a.pairs + [(bgm.bg_mat, a.d_bg)]:
+            if prm.grad is not None and prm.grad.data_ptr() != g.data_ptr():
+                g.add_(prm.grad.reshape(g.shape).to(g.dtype))
+                prm.grad = g.reshape(prm.shape) if g.shape != prm.shape else g
+
+    def assign_reduced(self, field, env):
+        """a rank that had no gradient of its own (no chunk with a sample / no env-map lookup) takes the ranks' sums: .grad of the
+        field + shading parameters (`field`) / of the env map (`env`) from the accumulator tensors the collectives summed into"""
+        a = self._acc_cache
+        if a.pairs is None:
+            n = self.nerf
+            rf, model = n.rf, n.model
+            pairs = list(zip(rf._param_list(), rf._grads_to_param_layout(a.gp, a.gl, a.g_apl, a.g_ali, a.g_basis)))
+            m = model.brdf.mlp
+            pairs += list(zip((m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias), a.g_mlp))
+            hps = model.diffuse_module._head_params()
+            for i, (lo, hi) in enumerate(((0, 3), (3, 6), (6, 9), (9, 11))):
+                pairs += [(hps[2 * i], a.g_hW[lo:hi]), (hps[2 * i + 1], a.g_hb[lo:hi])]
+            a.pairs = [(prm, g) for prm, g in pairs if prm.requires_grad]
+        if field:
+            for prm, g in a.pairs:
+                prm.grad = g
+        if env:
+            bgm = self.nerf.bg_module
+            if bgm.bg_mat.requires_grad:
+                bgm.bg_mat.grad = a.d_bg.reshape(bgm.bg_mat.shape)
+            if bgm.mipbias.requires_grad:
+                bgm.mipbias.grad = a.d_mip.to(torch.float64).reshape(())
 
 
 _CONST = {}

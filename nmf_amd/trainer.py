@@ -163,11 +163,75 @@ class FlatGradAllReduce:
         finally:
             torch.cuda.set_stream(main)
 
+    def early_inplace(self, region, pairs, comm_stream, group=None):
+        """the early bucket WITHOUT packing: `region` is the contiguous slice of the pass's flat accumulator that holds every early
+        gradient (fast_step.TrainPass.comm_regions), summed in place on `comm_stream` (which already waits for its producers).
+        pairs [(parameter, tensor inside region)]: a gradient a chunk left in .grad outside the accumulators is folded in first."""
+        if self._early is not None or not self.active(group):
+            return
+        main = torch.cuda.current_stream()
+        torch.cuda.set_stream(comm_stream)
+        try:
+            for prm, g in pairs:
+                if prm.grad is not None and prm.grad.data_ptr() != g.data_ptr():
+                    g.add_(prm.grad.reshape(g.shape).to(g.dtype))
+                    prm.grad = None
+            ev = self._early_events = getattr(self, "_early_events", None) or tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+            ev[0].record()
+            work = dist.all_reduce(region, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            self._early = dict(inplace=True, work=work, stream=comm_stream, ev=ev, bytes=4 * region.numel())
+        finally:
+            torch.cuda.set_stream(main)
+
+    def late_inplace(self, region, tail, has_grad, has_env, guard, group=None):
+        """the late bucket in place: `region` = the field's gradients + `tail` = [has-gradient flag, has-env flag, guard, pad] (its
+        last four floats).  -> (bytes exchanged, any rank had field gradients, any rank had env gradients); self.guard = the summed
+        guard.  The flags are read back (a host synchronisation) only by a rank that lacks one of the two itself."""
+        from . import hip
+        self.finish_early()
+        early = self._early
+        if self._consts is None or self._consts.device != region.device:
+            self._consts = torch.tensor([0.0, 1.0], dtype=torch.float32, device=region.device)
+        zero, one = self._consts.data_ptr(), self._consts.data_ptr() + 4
+        key = (tail.data_ptr(), bool(has_grad), bool(has_env), None if guard is None else guard.data_ptr())
+        if self._late_key != key:
+            self._tail_slots = (hip.CopySlot * 3)()
+            srcs = (one if has_grad else zero, one if has_env else zero, zero if guard is None else guard.data_ptr())
+            for i, src in enumerate(srcs):
+                a = self._tail_slots[i]
+                a.src, a.dst, a.numel, a.src_is_f64, a.dst_is_f64 = src, tail.data_ptr() + 4 * i, 1, \
+                    (1 if (i == 2 and guard is not None and guard.dtype == torch.float64) else 0), 0
+            self._late_key = key
+        self._keep_guard = guard
+        hip.multi_copy(self._tail_slots, 3)
+        ev = self._events = getattr(self, "_events", None) or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        dist.all_reduce(region, op=dist.ReduceOp.SUM, group=group)
+        ev[1].record()
+        self.last_comm_ms = ev
+        if early is not None:
+            self._exposed = (early["ready"], early["ev"][1], ev)
+        any_grad, any_env = bool(has_grad), bool(has_env)
+        if not (has_grad and has_env):
+            self.mask_reads += 1
+            f = tail[:2].tolist()
+            any_grad, any_env = f[0] > 0.0, f[1] > 0.0
+        self.guard = tail[2]
+        self._early = None
+        return 4 * region.numel() + (early["bytes"] if early is not None else 0), any_grad, any_env
+
     def finish_early(self):
         """the early sums land in the tensors they were packed from (the communication stream unpacks; the current stream then waits
         for it): call before anything reads those tensors -- end_step's conversion into .grad"""
         e = self._early
         if e is None or e.get("done"):
+            return
+        if e.get("inplace"):                   # nothing to unpack: the current stream waits for the collective itself
+            ready = e["ev"][2]
+            ready.record()
+            e["work"].wait()
+            e["ev"][1].record()
+            e["done"], e["ready"] = True, ready
             return
         from . import hip
         main = torch.cuda.current_stream()
@@ -481,7 +545,10 @@ class Trainer:
             if comm is None:
                 comm = fast._side["comm"] = torch.cuda.Stream()
             dev_ = rays.device
-            early = (lambda: self.reduce.early(fast.early_pairs(dev_), comm), comm.cuda_stream)
+            def start_early():
+                pairs = fast.early_pairs(dev_)          # (opens zeroed accumulators on a rank whose chunks never reached the backward)
+                self.reduce.early_inplace(fast.comm_regions()[0], pairs, comm)
+            early = (start_early, comm.cuda_stream)
         while pos < n_total:
             chunk = fixed_chunk if fixed_chunk is not None else max(int(self.num_rays), 1)
             if fetch is not None:
@@ -562,7 +629,17 @@ class Trainer:
         guard = None if not losses else (losses[0] if len(losses) == 1 else torch.stack(losses).sum())
         if self.reduce.active() and guard is None and len(self.reduce.params):
             guard = _zero_scalar(self.reduce.params[0].device)          # this rank's chunks were all empty: a finite contribution
-        comm_bytes = self.reduce(guard=guard)
+        if early is not None:
+            # the fused pass keeps every gradient in two contiguous regions of its flat buffer: summed in place, nothing is packed
+            fast.fold_foreign()
+            _e, late, tail = fast.comm_regions()
+            has_grad = any(q.grad is not None for q in self.reduce.params)
+            has_env = nerf.bg_module.bg_mat.grad is not None
+            comm_bytes, any_grad, any_env = self.reduce.late_inplace(late, tail, has_grad, has_env, guard)
+            if (any_grad and not has_grad) or (any_env and not has_env):
+                fast.assign_reduced(any_grad and not has_grad, any_env and not has_env)
+        else:
+            comm_bytes = self.reduce(guard=guard)
         if comm_bytes:
             guard = self.reduce.guard
         if p.get("clip_grad") is not None:                                                       # train.py:744-745

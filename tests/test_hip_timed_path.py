@@ -228,33 +228,27 @@ def test_rccl_all_reduce_on_one_rank_keeps_the_gradients_bit_for_bit():
         tr.optimizer.step_unhooked = lambda: None
         tr.reduce.single_rank = True
         inner, seen = tr.reduce, []
+        late = inner.late_inplace
 
-        class Checked:
-            guard = None
+        def checked_late(region, tail, has_grad, has_env, guard, group=None):
+            ps = [p for p in inner.params if p.grad is not None]
+            before = [p.grad.clone() for p in ps]                      # queued on the stream the collective is queued on
+            out = late(region, tail, has_grad, has_env, guard, group)
+            # compared right away: the gradient tensors of the tape-free pass are persistent buffers, the next step reuses them
+            seen.append((out[0], len(ps), all(torch.equal(p.grad, b) and bool(torch.isfinite(b).all()) for p, b in zip(ps, before)),
+                         sum(float(b.abs().max()) > 0 for b in before)))
+            return out
 
-            def __getattr__(self, name):          # (the early bucket, timings, parameters: the real reducer's)
-                return getattr(inner, name)
-
-            def __call__(self, group=None, guard=None):
-                ps = [p for p in inner.params if p.grad is not None]
-                before = [p.grad.clone() for p in ps]                      # queued on the stream the collective is queued on
-                n = inner(group, guard=guard)
-                self.guard = inner.guard
-                # compared right away: the gradient tensors of the tape-free pass are persistent buffers, the next step reuses them
-                seen.append((n, len(ps), all(torch.equal(p.grad, b) and bool(torch.isfinite(b).all()) for p, b in zip(ps, before)),
-                             sum(float(b.abs().max()) > 0 for b in before)))
-                return n
-
-        tr.reduce = Checked()
+        inner.late_inplace = checked_late
         rays, focal = synthetic.camera_rays(2048, seed=21)
         gt = torch.rand(2048, 3, generator=torch.Generator().manual_seed(5)).to(dev)
         for it in range(3):
             out = tr.step(rays.to(dev), gt, focal, noise=DeviceNoise(dev, seed=70 + it), update_controllers=False, fixed_chunk=1024)
-            assert out["comm_bytes"] == 4 * inner.numel and out["comm_bytes"] > 1e6
+            assert out["comm_bytes"] >= 4 * inner.numel and out["comm_bytes"] > 1e6      # (the two regions incl. their padding / tail)
             assert out["comm_ms"] is not None and out["comm_ms"] > 0
             # the early bucket (BRDF MLP, heads, environment map) went out from inside the last chunk's backward, next to the walks
             assert out["comm_exposed_ms"] is not None and 0 < out["comm_exposed_ms"] < 5.0
-            assert inner.buf_early is not None and inner.buf_early.numel() * 4 + inner.buf.numel() * 4 > out["comm_bytes"]
+            assert inner.buf_early is None and inner.buf is None              # summed in place: nothing was packed
         torch.cuda.synchronize()
         assert inner.mask_reads == 0          # no has-gradient flags read back: no host synchronisation in the steady state
         assert len(seen) == 3
