@@ -491,6 +491,10 @@ struct EnvBwdArgs {
     uint32_t* blockres;                 // [lookup workgroups][nt]: where in its tile's range a workgroup's records start (pass 1 -> pass 2)
 };
 
+// where the dual-number role leaves its mip-bias adjoint: one atomic per wave on d_mipbias / in the 64 slots of the header (riders of
+// passes 1 and 2) / one atomic per workgroup on d_mipbias
+constexpr int ENV_MIP_DIRECT = 0, ENV_MIP_SLOTS = 1, ENV_MIP_WORKGROUP = 2;
+
 // dual-number role with the channels contracted: q(x, y) = sum_c go[c] * S_c(x, y)
 template <int LAYOUT>
 struct SumAccQ {
@@ -545,7 +549,7 @@ struct SumAccQ {
 constexpr int ENV_DIRS_LDS = (int)sizeof(EnvQueue) + 8 + 256 * (25 + 3 + 4) * 4;
 
 template <int LAYOUT>
-__device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem, bool to_slots) {
+__device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block, unsigned char* smem, int mip_mode) {
     typedef Dual<4> D;
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[25] = reinterpret_cast<float (*)[25]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
@@ -636,8 +640,18 @@ __device__ __forceinline__ void env_role_dirs(const EnvBwdArgs& A, int64_t block
         // the 3.8 k waves of a 0.24 M-lookup launch, all of what this role used to cost next to the passes): spread over 64
         // slots of the header here, summed by pass 3 (riders of pass 3 itself -- none with today's shares -- go direct)
         for (int d = 32; d > 0; d >>= 1) dm += __shfl_down(dm, d, 64);
-        if (lane_id() == 0 && dm != 0.f) {
-            if (to_slots) atomicAdd(&A.hdr->mip_slots[(block * (ENV_BWD_THREADS / 64) + (threadIdx.x >> 6)) & 63], dm);
+        if (mip_mode == ENV_MIP_WORKGROUP) {      // the role as a launch of its own (k_env_dirs): one atomic per workgroup
+            __shared__ float s_dm[ENV_BWD_THREADS / 64];
+            if (lane_id() == 0) s_dm[threadIdx.x >> 6] = dm;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < ENV_BWD_THREADS / 64; ++w) t += s_dm[w];
+                if (t != 0.f) atomicAdd(A.d_mipbias, t);
+            }
+        } else if (lane_id() == 0 && dm != 0.f) {
+            if (mip_mode == ENV_MIP_SLOTS) atomicAdd(&A.hdr->mip_slots[(block * (ENV_BWD_THREADS / 64) + (threadIdx.x >> 6)) & 63], dm);
             else atomicAdd(A.d_mipbias, dm);
         }
     }
@@ -687,12 +701,20 @@ __device__ __forceinline__ bool env_walk_main(const EnvBwdArgs& A, int64_t r, En
     return true;
 }
 
+// the dual-number role as a launch of its own (nmf_sat_lookup_bwd_dirs): a caller whose dependency chain needs d_dirs only runs this
+// on the chain and the table role (the three passes, no riders) on another stream
+template <int LAYOUT>
+__global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_dirs(EnvBwdArgs A) {
+    __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS];
+    env_role_dirs<LAYOUT>(A, blockIdx.x, smem, ENV_MIP_WORKGROUP);
+}
+
 // pass 1
 template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_count(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, true); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, ENV_MIP_SLOTS); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     uint32_t* hist = reinterpret_cast<uint32_t*>(geo + 256);
@@ -816,7 +838,7 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_scatter(EnvBwdArgs A, int own_blocks, int dirs_blocks, int64_t dirs_block0) {
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > ENV_SCATTER_LDS ? ENV_DIRS_LDS : ENV_SCATTER_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, true); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, ENV_MIP_SLOTS); return; }
     EnvQueue& Q = *reinterpret_cast<EnvQueue*>(smem);
     float (*geo)[5] = reinterpret_cast<float (*)[5]>(smem + ((sizeof(EnvQueue) + 15) & ~15));
     float (*gs)[3] = reinterpret_cast<float (*)[3]>(geo + 256);
@@ -879,7 +901,7 @@ __global__ void __launch_bounds__(ENV_BWD_THREADS) k_env_bin_accum(EnvBwdArgs A,
     constexpr int OWN_LDS = ENV_WIN * 8 + (2 * ENV_MAX_TILES + 2 + 8) * 4;
     __shared__ __align__(16) unsigned char smem[ENV_DIRS_LDS > OWN_LDS ? ENV_DIRS_LDS : OWN_LDS];
     int64_t blk;
-    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, false); return; }
+    if (env_role(own_blocks, dirs_blocks, blk)) { env_role_dirs<LAYOUT>(A, dirs_block0 + blk, smem, ENV_MIP_DIRECT); return; }
     if (blk == 0 && A.d_mipbias && threadIdx.x < 64) {      // the mip-bias adjoint the riders of passes 1 and 2 left in 64 slots
         float v = A.hdr->mip_slots[threadIdx.x];
         for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
@@ -1131,13 +1153,19 @@ extern "C" int64_t nmf_sat_lookup_bwd_workspace_bytes(int64_t R) {
     return (int64_t)sizeof(EnvBinHeader) + cdiv(r, ENV_BWD_THREADS) * ENV_MAX_TILES * 4 + r * 12 * (int64_t)sizeof(CornerRec);
 }
 
+// (Round 5, tools/env_bwd_bench.py: pass 3 takes 43 us at 1.1 M records and 31 us at 0.2 M, with items of 512 .. 4096 records and with
+// four record loads of a lane in flight alike -- its time is the flush: every touched tile adds its whole 33 x 65 x 3 window to dSAT
+// with memory-side float atomics, 1.6 M lane-atomics for the 256 tiles of a 512 x 1024 map at the 156 G/s of tools/ub/atom2.hip, and
+// smaller items only flush more windows.)
 extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld,
                                          const float* sa, int64_t R, float mipbias, const float* scalars_dev, int32_t layout,
                                          const float* d_out, float* d_sat, float* d_pole, float* d_dirs, float* d_mipbias,
                                          void* workspace, int64_t workspace_bytes, void* stream) {
     NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: R < 0");
     if (R == 0) return NMF_OK;
-    NMF_REQUIRE(sat && dirs && sa && d_out && d_pole && d_sat && workspace, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: null");
+    NMF_REQUIRE(sat && dirs && sa && d_out && d_sat && workspace, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: null");
+    // d_pole null: the table role alone (its other half is nmf_sat_lookup_bwd_dirs: pole rows, d_dirs, d_mipbias)
+    NMF_REQUIRE(d_pole || (!d_dirs && !d_mipbias), NMF_EINVAL, "nmf_sat_lookup_bwd_binned: d_dirs / d_mipbias need d_pole");
     NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: dirs_ld must be 3 or 6");
     const int ntx = (int)cdiv(W, ENV_TILE_W), nty = (int)cdiv(H, ENV_TILE_H);
     NMF_REQUIRE(ntx * nty <= ENV_MAX_TILES, NMF_EINVAL, "nmf_sat_lookup_bwd_binned: map larger than 1024 tiles of 32 x 64");
@@ -1161,8 +1189,8 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
     // arithmetic fills it.  Measured on the 247 k lookups of a steady-state step (tools/env_bwd_bench.py, us): all next to pass 1
     // 98, 50 / 50 next to passes 1 / 2 101, 80 / 20 104, all next to pass 2 111, all behind pass 3 155 (direct scatter: 176).
     // (Round 4 read the split from the environment on every call; the measurement is in, the split is fixed.)
-    const int split1 = 100, split2 = 0;
-    const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = nb - d1 - d2;
+    const int split1 = d_pole ? 100 : 0, split2 = 0;
+    const int64_t d1 = nb * split1 / 100, d2 = std::min(nb - d1, nb * split2 / 100), d3 = d_pole ? nb - d1 - d2 : 0;
     const int accum_blocks = (int)(d3 > 768 ? d3 : 768);      // (env_role needs at least as many pass workgroups as riders)
     if (layout == 1) {
         NMF_LAUNCH(k_env_bin_count<1>, dim3((unsigned)(nb + d1)), dim3(ENV_BWD_THREADS), 0, st, A, (int)nb, (int)d1, (int64_t)0);
@@ -1174,6 +1202,24 @@ extern "C" int nmf_sat_lookup_bwd_binned(const float* sat, int32_t H, int32_t W,
         NMF_LAUNCH(k_env_bin_accum<0>, dim3((unsigned)(accum_blocks + d3)), dim3(ENV_BWD_THREADS), 0, st, A, accum_blocks, (int)d3, d1 + d2);
     }
     NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd_binned");
+    return NMF_OK;
+}
+
+extern "C" int nmf_sat_lookup_bwd_dirs(const float* sat, int32_t H, int32_t W, const float* dirs, int32_t dirs_ld, const float* sa,
+                                       int64_t R, float mipbias, const float* scalars_dev, int32_t layout, const float* d_out,
+                                       float* d_pole, float* d_dirs, float* d_mipbias, void* stream) {
+    NMF_REQUIRE(R >= 0, NMF_EINVAL, "nmf_sat_lookup_bwd_dirs: R < 0");
+    if (R == 0) return NMF_OK;
+    NMF_REQUIRE(sat && dirs && sa && d_out && d_pole, NMF_EINVAL, "nmf_sat_lookup_bwd_dirs: null");
+    NMF_REQUIRE(dirs_ld == 3 || dirs_ld == 6, NMF_EINVAL, "nmf_sat_lookup_bwd_dirs: dirs_ld must be 3 or 6");
+    EnvBwdArgs A{};
+    A.tab = EnvTab{sat, H, W, layout == 1};
+    A.dirs = dirs; A.ld = dirs_ld; A.sa = sa; A.R = R; A.mipbias = mipbias; A.sc = scalars_dev; A.d_out = d_out;
+    A.d_pole = d_pole; A.d_dirs = d_dirs; A.d_mipbias = d_mipbias;
+    const dim3 grid((unsigned)cdiv(R, ENV_BWD_THREADS));
+    if (layout == 1) NMF_LAUNCH(k_env_dirs<1>, grid, dim3(ENV_BWD_THREADS), 0, (hipStream_t)stream, A);
+    else NMF_LAUNCH(k_env_dirs<0>, grid, dim3(ENV_BWD_THREADS), 0, (hipStream_t)stream, A);
+    NMF_CHECK_LAUNCH("nmf_sat_lookup_bwd_dirs");
     return NMF_OK;
 }
 

@@ -382,23 +382,96 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
     }
 }
 
+// ---- brick binning helpers (the backward walks sort their samples by brick; the value query of the re-traced samples can count
+//      them on the way: k_vm_sigma<TT, true>) ---------------------------------------------------------------------------------------
+constexpr int BASIS_COPIES = 16;   // scratch copies of the basis_mat gradient (power of two), see vm_bwd_app2
+constexpr int BR = 4;             // brick edge in texels (R2: 4 -> 5x5 = 25 tile cells = 2 MFMA row blocks instead of 6)
+constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
+
+__device__ __forceinline__ int axis_floor(const nmf_vm_params& p, float xn_a) {
+    float ix = ((xn_a + 1.f) * 0.5f) * (float)(p.grid - 1);      // identical to make_tap*
+    return (int)floorf(ix);
+}
+
+__device__ __forceinline__ int brick_of(const nmf_vm_params& p, const float (&xn)[3], int nbx) {
+    int b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int x0 = axis_floor(p, xn[a]);
+        x0 = x0 < 0 ? 0 : (x0 > p.grid - 1 ? p.grid - 1 : x0);
+        b[a] = x0 / BR;
+    }
+    return (b[2] * nbx + b[1]) * nbx + b[0];
+}
+
+// Samples arrive in (ray, step) order, so consecutive lanes mostly fall into the same brick: one atomic per RUN of equal
+// brick ids inside a wave instead of one per sample (~10x fewer contended atomics on the hot surface bricks).
+struct RunInfo {
+    bool head;
+    int len, off;   // run length (valid on the head lane) and this lane's offset inside its run
+};
+__device__ __forceinline__ RunInfo wave_runs(int key, bool active) {
+    const int lane = lane_id();
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = active && (lane == 0 || prev != key || !__shfl_up((int)active, 1, 64));
+    const uint64_t H = __ballot(head);
+    const uint64_t A = __ballot(active);
+    RunInfo r;
+    r.head = head;
+    const uint64_t below = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int my_head = below ? 63 - __clzll(below) : lane;
+    const uint64_t above = (lane == 63) ? 0ull : (H >> (lane + 1));
+    int next_head = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+    // a run ends at the next head or at the first inactive lane
+    const uint64_t inact_above = (lane == 63) ? 0ull : ((~A) >> (lane + 1));
+    const int next_inact = inact_above ? lane + 1 + (__ffsll((long long)inact_above) - 1) : 64;
+    next_head = next_head < next_inact ? next_head : next_inact;
+    r.len = next_head - my_head;
+    r.off = lane - my_head;
+    return r;
+}
+
+// Counter copies: the hot bricks (the visible surface) are few and neighbours share 128-byte lines, and L2 executes the
+// atomics of one line one after the other -- 0.24 M runs of the 0.88 M secondary-ray samples on ~100 hot lines cost 84 us
+// in the histogram and 90 us in the scatter.  Every brick therefore has KC counters (wave w of the launch uses copy
+// w % KC, the same wave in both kernels); the scan runs over the flat [brick][copy] array, so copy k of a brick owns the
+// slice of the brick's segment that follows copies < k.
+__device__ __forceinline__ int bin_copy(int kc) { return (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kc - 1)); }
+
+
 // ------------------------------------------------------------------------------------------------
 // forward, density value only (no gradient / normal): the samples of the re-traced rays need normals on their bounce rows
 // alone (nmf_amd/fast_step.py, "sparse normals"), so the 0.9 M-sample query of a training level reads the value third of
 // every texel (16 of 48 floats) and of every line entry (16 of 32).  Same taps, same order of the sums as k_vm_fwd, the
 // value path of both written with explicit fma: sigma_feat and sigma are identical bits.
 // ------------------------------------------------------------------------------------------------
-template <class TT>
+// HIST (R5): the brick histogram of the value-only WALK that will follow in the backward is taken here, where every sample is visited
+// anyway: the counter add of a run of equal bricks is issued as soon as the position is known and its result (the sample's rank in
+// its brick) is consumed behind the 72 table loads -- the round trip of the atomic, which is all k_plan_hist consisted of (21 us
+// alone, ~80 us inside the saturated backward window for the 0.85 M re-traced samples of a step), hides behind them.  counts: the
+// kept zero scratch of the walk (nmf_vm_bwd_clean_bytes); keyrank [M]: (brick * kc + counter copy, rank) as k_plan_hist writes it.
+template <class TT, bool HIST = false>
 __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
                                                   PtrsT3<TT> dpk, PtrsT3<TT> dlk, int plane_stride, int line_stride,
-                                                  float* __restrict__ sigma_feat, float* __restrict__ sigma) {
+                                                  float* __restrict__ sigma_feat, float* __restrict__ sigma,
+                                                  int32_t* __restrict__ counts = nullptr, int2* __restrict__ keyrank = nullptr,
+                                                  int nbx = 0, int kc = 1) {
     // plane_stride / line_stride: elements per texel / line entry of the tables handed in -- DP / DL for the packed value +
     // derivative tables, CD for the density factors themselves (nmf_vm_query_sigma: a third of the cache lines)
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    const bool active = m < M;
+    if (!HIST && !active) return;
     const int G = p.grid;
     float xn[3];
-    normalized(p, xyzt[m], xn);
+    normalized(p, xyzt[active ? m : M - 1], xn);
+    int hist_key = 0, hist_base = 0;
+    RunInfo hist_run = {false, 0, 0};
+    if constexpr (HIST) {
+        const int b = active ? brick_of(p, xn, nbx) : -1;
+        hist_run = wave_runs(b, active);
+        hist_key = b * kc + bin_copy(kc);
+        if (hist_run.head) hist_base = atomicAdd(counts + hist_key, hist_run.len);
+    }
     float sf = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -429,6 +502,11 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
             s_pl = fmaf(w_, a, s_pl);
         }
         sf += s_pl;
+    }
+    if constexpr (HIST) {
+        hist_base = __shfl(hist_base, lane_id() - hist_run.off, 64);
+        if (active) keyrank[m] = make_int2(hist_key, hist_base + hist_run.off);
+        if (!active) return;
     }
     if (sigma_feat) sigma_feat[m] = sf;
     if (sigma) {
@@ -614,60 +692,6 @@ __global__ void __launch_bounds__(256) k_vm_app_rows(nmf_vm_params p, const floa
 // tile is 2 MFMA row blocks of 16, against 6 for the 81 cells of an 8^3 brick, so the walk issues a
 // third of the matrix instructions per sample for ~2x the flush atomics (measured 498 -> 318 us).
 // ------------------------------------------------------------------------------------------------
-constexpr int BASIS_COPIES = 16;   // scratch copies of the basis_mat gradient (power of two), see vm_bwd_app2
-constexpr int BR = 4;             // brick edge in texels (R2: 4 -> 5x5 = 25 tile cells = 2 MFMA row blocks instead of 6)
-constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
-
-__device__ __forceinline__ int axis_floor(const nmf_vm_params& p, float xn_a) {
-    float ix = ((xn_a + 1.f) * 0.5f) * (float)(p.grid - 1);      // identical to make_tap*
-    return (int)floorf(ix);
-}
-
-__device__ __forceinline__ int brick_of(const nmf_vm_params& p, const float (&xn)[3], int nbx) {
-    int b[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        int x0 = axis_floor(p, xn[a]);
-        x0 = x0 < 0 ? 0 : (x0 > p.grid - 1 ? p.grid - 1 : x0);
-        b[a] = x0 / BR;
-    }
-    return (b[2] * nbx + b[1]) * nbx + b[0];
-}
-
-// Samples arrive in (ray, step) order, so consecutive lanes mostly fall into the same brick: one atomic per RUN of equal
-// brick ids inside a wave instead of one per sample (~10x fewer contended atomics on the hot surface bricks).
-struct RunInfo {
-    bool head;
-    int len, off;   // run length (valid on the head lane) and this lane's offset inside its run
-};
-__device__ __forceinline__ RunInfo wave_runs(int key, bool active) {
-    const int lane = lane_id();
-    const int prev = __shfl_up(key, 1, 64);
-    const bool head = active && (lane == 0 || prev != key || !__shfl_up((int)active, 1, 64));
-    const uint64_t H = __ballot(head);
-    const uint64_t A = __ballot(active);
-    RunInfo r;
-    r.head = head;
-    const uint64_t below = H & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int my_head = below ? 63 - __clzll(below) : lane;
-    const uint64_t above = (lane == 63) ? 0ull : (H >> (lane + 1));
-    int next_head = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-    // a run ends at the next head or at the first inactive lane
-    const uint64_t inact_above = (lane == 63) ? 0ull : ((~A) >> (lane + 1));
-    const int next_inact = inact_above ? lane + 1 + (__ffsll((long long)inact_above) - 1) : 64;
-    next_head = next_head < next_inact ? next_head : next_inact;
-    r.len = next_head - my_head;
-    r.off = lane - my_head;
-    return r;
-}
-
-// Counter copies: the hot bricks (the visible surface) are few and neighbours share 128-byte lines, and L2 executes the
-// atomics of one line one after the other -- 0.24 M runs of the 0.88 M secondary-ray samples on ~100 hot lines cost 84 us
-// in the histogram and 90 us in the scatter.  Every brick therefore has KC counters (wave w of the launch uses copy
-// w % KC, the same wave in both kernels); the scan runs over the flat [brick][copy] array, so copy k of a brick owns the
-// slice of the brick's segment that follows copies < k.
-__device__ __forceinline__ int bin_copy(int kc) { return (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kc - 1)); }
-
 // The samples of one walk may come from up to four caller arrays ("segments": the sample sets of the primary and of the
 // re-traced rays of one training pass are walked together, so that bricks both touch are flushed once).  Sample m of
 // the concatenation lives in segment sg at row m - start[sg].
@@ -1834,16 +1858,18 @@ int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg
 
 // place = false: the caller follows with k_place_records (the walk that sorts inside its own call)
 // clean: L.counts / L.scan_state point into the caller's kept scratch (zero now, zero again afterwards): no memset
-int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false) {
+// hist = false: the counters and keyrank[] were filled by the forward (nmf_vm_query_sigma_hist) -- needs the clean scratch
+int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false,
+                bool hist = true) {
     // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU); grids beyond ~500^3 take
     // the two-launch scan (k_bins_partial + k_bins_final)
     const bool lookback = L.n_scan_chunks <= 2048;
     const size_t count_bytes = sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc;
-    if (!clean || !lookback) {
+    if (hist && (!clean || !lookback)) {
         hipError_t e = hipMemsetAsync(L.counts, 0, clean ? count_bytes : L.zero_bytes, st);
         if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
     }
-    NMF_LAUNCH(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+    if (hist) NMF_LAUNCH(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
     if (lookback) {
         NMF_LAUNCH(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
                            L.cursor, L.item_size, L.items, L.n_items, clean ? 1 : 0);
@@ -1895,7 +1921,8 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
                        const float* const dlk[3], const float* const app_planes[3], const float* const app_lines[3],
                        const float* basis, float* const g_dpk[3], float* const g_dlk[3], float* const g_app_planes[3],
                        float* const g_app_lines[3], float* g_basis, const void* plan, int64_t plan_bytes, void* workspace,
-                       int64_t workspace_bytes, void* stream, void* clean = nullptr, int64_t clean_bytes = 0) {
+                       int64_t workspace_bytes, void* stream, void* clean = nullptr, int64_t clean_bytes = 0,
+                       const void* prehist = nullptr) {
     NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
                 "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
     NMF_REQUIRE(!clean || (!plan && clean_bytes >= clean_layout(nullptr, p->grid).bytes && ((uintptr_t)clean & 15) == 0), NMF_EINVAL,
@@ -1939,7 +1966,12 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
             L.counts = C.counts;
             L.scan_state = C.scan_state;
         }
-        const int rc = launch_plan(p, sg, M, L, st, false, clean != nullptr);
+        if (prehist) {          // the histogram of these samples was taken by the forward query into `clean`'s counters
+            NMF_REQUIRE(clean && n == 1 && L.n_scan_chunks <= 2048, NMF_EINVAL,
+                        "nmf_vm_query_bwd_segments_prehist: one sample set, the kept scratch, a grid the one-launch scan covers");
+            L.keyrank = (int2*)const_cast<void*>(prehist);
+        }
+        const int rc = launch_plan(p, sg, M, L, st, false, clean != nullptr, prehist == nullptr);
         if (rc != NMF_OK) return rc;
         walk_ws = (char*)workspace + L.bytes;
         walk_bytes = workspace_bytes - L.bytes;
@@ -1993,6 +2025,49 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
 }
 
 extern "C" int64_t nmf_vm_bwd_clean_bytes(int32_t grid) { return clean_layout(nullptr, grid).bytes; }
+
+extern "C" int nmf_vm_query_sigma_hist(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
+                                       const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma,
+                                       void* clean, int64_t clean_bytes, void* keyrank, void* stream) {
+    NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_sigma_hist: params");
+    if (M == 0) return NMF_OK;
+    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_sigma_hist: M >= 2^31");
+    NMF_REQUIRE(xyzt && planes && lines && planes[0] && planes[1] && planes[2] && lines[0] && lines[1] && lines[2] &&
+                    (sigma_feat || sigma) && keyrank,
+                NMF_EINVAL, "nmf_vm_query_sigma_hist: null");
+    NMF_REQUIRE(clean && clean_bytes >= clean_layout(nullptr, p->grid).bytes && ((uintptr_t)clean & 15) == 0, NMF_EINVAL,
+                "nmf_vm_query_sigma_hist: scratch too small (nmf_vm_bwd_clean_bytes) or not 16-byte aligned");
+    const PlanLayout L = plan_layout(nullptr, 0, p->grid);
+    int32_t* counts = clean_layout(clean, p->grid).counts;
+    if (tables_bf16) {
+        const uint16_t* pl[3] = {(const uint16_t*)planes[0], (const uint16_t*)planes[1], (const uint16_t*)planes[2]};
+        const uint16_t* li[3] = {(const uint16_t*)lines[0], (const uint16_t*)lines[1], (const uint16_t*)lines[2]};
+        NMF_LAUNCH_NAMED("k_vm_sigma<unsigned short, true>", (k_vm_sigma<uint16_t, true>), dim3((unsigned)cdiv(M, 256)), dim3(256), 0,
+                         (hipStream_t)stream, *p, (const float4*)xyzt, M, mkT<uint16_t>(pl, true), mkT<uint16_t>(li, true), CD, CD,
+                         sigma_feat, sigma, counts, (int2*)keyrank, L.nbx, L.kc);
+    } else {
+        const float* pl[3] = {(const float*)planes[0], (const float*)planes[1], (const float*)planes[2]};
+        const float* li[3] = {(const float*)lines[0], (const float*)lines[1], (const float*)lines[2]};
+        NMF_LAUNCH_NAMED("k_vm_sigma<float, true>", (k_vm_sigma<float, true>), dim3((unsigned)cdiv(M, 256)), dim3(256), 0,
+                         (hipStream_t)stream, *p, (const float4*)xyzt, M, mkT<float>(pl, true), mkT<float>(li, true), CD, CD, sigma_feat,
+                         sigma, counts, (int2*)keyrank, L.nbx, L.kc);
+    }
+    NMF_CHECK_LAUNCH("nmf_vm_query_sigma_hist");
+    return NMF_OK;
+}
+
+
+extern "C" int nmf_vm_query_bwd_segments_prehist(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
+                                                 const float* const dpk[3], const float* const dlk[3],
+                                                 const float* const app_planes[3], const float* const app_lines[3],
+                                                 const float* basis, float* const g_dpk[3], float* const g_dlk[3],
+                                                 float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
+                                                 void* clean, int64_t clean_bytes, const void* keyrank, void* workspace,
+                                                 int64_t workspace_bytes, void* stream) {
+    NMF_REQUIRE(clean && keyrank, NMF_EINVAL, "nmf_vm_query_bwd_segments_prehist: scratch / keyrank null");
+    return vm_bwd_impl(p, segs, n_segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis,
+                       nullptr, 0, workspace, workspace_bytes, stream, clean, clean_bytes, keyrank);
+}
 
 extern "C" int nmf_vm_query_bwd_segments_clean(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
                                                const float* const dpk[3], const float* const dlk[3],

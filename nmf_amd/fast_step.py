@@ -141,7 +141,7 @@ class TrainPass:
                 and self.core() is not None)
 
     # ---- the C++ pass ----------------------------------------------------------------------------------------------
-    _CORE_STREAMS = (("mlp", 0), ("mlp", 1), ("env", 0), ("env", 1), ("walk", 1), "sat_bwd")
+    _CORE_STREAMS = (("mlp", 0), ("mlp", 1), ("env", 0), ("env", 1), ("walk", 1), "sat_bwd", "env_table")
 
     def core(self):
         """-> lib/_nmf_host.so's StepCore configured for this model, or None (Python pass)"""

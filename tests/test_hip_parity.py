@@ -569,6 +569,27 @@ def test_env_binned_table_adjoint(H, R, monkeypatch):
                                               cc.data_ptr(), d_sat.data_ptr(), d_pole.data_ptr(), d_dirs.data_ptr(), d_mip.data_ptr(),
                                               ws.data_ptr(), 8720 + res_bytes, hip._stream()) != 0
     assert_close(d_sat.cpu(), res["direct"][1].cpu(), rtol=1e-4, atol=2e-6 * float(res["direct"][1].abs().max()), what="d_sat, small pool")
+    # the two halves as calls of their own (nmf_sat_lookup_bwd_dirs on the chain, the table role without riders elsewhere: R5) add
+    # what the one call adds: d_dirs bit for bit (the same dual-number code), the sums to round-off
+    for ld in (3, 6):
+        rows_l = rows if ld == 3 else torch.cat([torch.randn(R, 3, generator=gen), dirs], dim=1).to(DEV).contiguous()
+        full = [torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV), torch.full((R, ld), 7.0, device=DEV)]
+        half = [torch.zeros(H, W, 4, device=DEV), torch.zeros(2, 3, device=DEV), torch.zeros(1, device=DEV), torch.full((R, ld), 7.0, device=DEV)]
+        nb_full = int(hip._lib.nmf_sat_lookup_bwd_workspace_bytes(C.c_int64(R)))
+        wsf = torch.empty(nb_full, dtype=torch.uint8, device=DEV)
+        common = (sat4.data_ptr(), H, W, rows_l.data_ptr(), ld, sa_d.data_ptr(), R, C.c_float(0.3), None, 1, cc.data_ptr())
+        assert hip._lib.nmf_sat_lookup_bwd_binned(*common, full[0].data_ptr(), full[1].data_ptr(), full[3].data_ptr(), full[2].data_ptr(),
+                                                  wsf.data_ptr(), nb_full, hip._stream()) == 0
+        assert hip._lib.nmf_sat_lookup_bwd_dirs(*common, half[1].data_ptr(), half[3].data_ptr(), half[2].data_ptr(), hip._stream()) == 0
+        assert hip._lib.nmf_sat_lookup_bwd_binned(*common, half[0].data_ptr(), None, None, None, wsf.data_ptr(), nb_full, hip._stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(half[3], full[3])
+        assert_close(half[0].cpu(), full[0].cpu(), rtol=1e-4, atol=2e-6 * float(full[0].abs().max()), what="d_sat, table role alone")
+        assert_close(half[1].cpu(), full[1].cpu(), rtol=1e-5, atol=1e-6 * float(full[1].abs().max()), what="d_pole, dirs role alone")
+        assert abs(float(half[2]) - float(full[2])) <= 1e-4 * abs(float(full[2])) + 1e-5 * scale
+        # d_dirs / d_mipbias without the pole rows' accumulator are refused
+        assert hip._lib.nmf_sat_lookup_bwd_binned(*common, half[0].data_ptr(), None, half[3].data_ptr(), None, wsf.data_ptr(), nb_full,
+                                                  hip._stream()) != 0
     if H == 32:                      # the golden fixture's size: the map gradient against the oracle's autograd
         sd = _env_sd(bg.cpu().clone().requires_grad_(True))
         sd["bg_module.mipbias"] = torch.tensor(0.3, dtype=torch.float64)
@@ -1648,6 +1669,52 @@ def test_vm_backward_segments_equal_concatenation(with_app):
     with pytest.raises(hip.NmfHipError):                       # mixed adjoint sets are rejected
         bad = [segs[0], (segs[3][0], None, None, None, None, None, None)]
         hip.vm_query_bwd_segments(p, bad, dpk, dlk, apl, ali, basis, a[0], a[1], a[2], a[3], None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,M", [(32, 70000), (128, 300001)])
+def test_value_query_takes_the_histogram_of_the_value_only_walk(G, M):
+    """nmf_vm_query_sigma_hist + nmf_vm_query_bwd_segments_prehist (R5): the density-value query of the re-traced samples counts them
+    per brick on the way (into the kept scratch of the walk) and the value-only walk of the backward starts at the counter scan --
+    same sigma bits as nmf_vm_query_sigma, the gradients of the self-sorting walk (autograd of fields/tensoRF.py:181-190), the scratch
+    handed back zero, walk after walk."""
+    import ctypes as C
+    from nmf_amd import hip, synthetic
+    fx = hip.HOST_EXT
+    if fx is None or not hasattr(fx, "vm_query_bwd_prehist"):
+        pytest.skip("host extension not built")
+    cfg = O.Cfg(grid=G)
+    sd = synthetic.state_dict_s1(grid=G, bg_resolution=8, seed=3)
+    p, dpk, dlk, apl, ali, basis = _field_tables(hip, sd, cfg)
+    dpl = [_cl(sd[f"rf.density_rf.app_plane.{i}"].detach()) for i in range(3)]
+    dli = [_cl(sd[f"rf.density_rf.app_line.{i}"].detach()).reshape(G, 16) for i in range(3)]
+    g = torch.Generator().manual_seed(11)
+    c = (torch.rand(M // 40 + 1, 3, generator=g) * 2 - 1) * 1.45            # ray-like runs of nearby samples + points outside the box
+    x = c.repeat_interleave(40, 0)[:M] + 0.015 * torch.randn(M, 3, generator=g)
+    x[::211] *= 1.3
+    xyz = torch.cat([x, torch.zeros(M, 1)], 1).to(DEV).contiguous()
+    pa = C.addressof(p)
+    st = torch.cuda.current_stream().cuda_stream
+    z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=DEV)  # noqa: E731
+    clean = hip.vm_bwd_clean_scratch(p, DEV)
+    sf0, sg0 = fx.vm_query_sigma(pa, xyz, dpl, dli, st)
+    for rep in range(3):
+        keyrank = torch.empty((M, 2), dtype=torch.int32, device=DEV)
+        sf1, sg1 = fx.vm_query_sigma(pa, xyz, dpl, dli, st, clean, keyrank)
+        assert torch.equal(sf0, sf1) and torch.equal(sg0, sg1)
+        assert int(clean.view(torch.int32).sum()) == M                                                # every sample counted once
+        d_sigma = torch.randn(M, generator=torch.Generator().manual_seed(rep)).to(DEV)
+        seg = [(xyz, sf1, None, d_sigma, None, None, None)]
+        a = ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)])
+        b = ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)])
+        hip.vm_query_bwd_segments(p, seg, dpk, dlk, apl, ali, basis, a[0], a[1], [z(G, G, 24)] * 3, [z(G, 24)] * 3, None)
+        fx.vm_query_bwd_prehist(pa, seg, dpk, dlk, apl, ali, basis, b[0], b[1], [], [], None, clean, keyrank, st)
+        torch.cuda.synchronize()
+        fa = torch.cat([t.reshape(-1) for t in a[0] + a[1]]).cpu()
+        fb = torch.cat([t.reshape(-1) for t in b[0] + b[1]]).cpu()
+        assert fa.abs().max() > 0
+        assert_close(fb, fa, rtol=2e-5, atol=2e-5 * float(fa.abs().max()), what="walk on the forward's histogram vs self-sorting walk")
+        assert int(clean.count_nonzero()) == 0                                  # handed back zero
 
 
 @pytest.mark.gpu

@@ -6,6 +6,7 @@ thermal drift and box-to-box differences (4 % between `python bench.py` runs on 
 <what>:
     NAME                 os.environ[NAME] = value            (knobs that are read at call time)
     obj:ATTR             TrainPass attribute, as bool        (obj:overlap 0,1   obj:sparse_normals 0,1)
+    core:ATTR            StepCore attribute, as bool         (core:value_hist 0,1)
     attr:NAME            nmf_amd.fast_step module constant   (attr:MLP_SIDE_WGS 64,128,256)
     hip:NAME             nmf_amd.hip module constant         (hip:ENV_BINNED_MIN_LOOKUPS 16384,4611686018427387904)
     calldelay:NAME       busy-wait of <value> us on the host in front of every call of the C++ wrapper NAME (csrc/host_ext.cpp)
@@ -71,6 +72,9 @@ def main():
             delay_us[0] = float(v)
         elif var.startswith("obj:"):
             setattr(tr.fast, var[4:], bool(int(v)))
+        elif var.startswith("core:"):
+            torch.cuda.synchronize()
+            setattr(tr.fast.core(), var[5:], bool(int(v)))
         elif var.startswith("attr:"):
             setattr(fast_step, var[5:], int(v))
         elif var.startswith("hip:"):

@@ -2,7 +2,8 @@
 hip.sat_lookup_bwd call of one bench step are captured and replayed (HIP events, nothing else on the device).
 
     python tools/env_bwd_bench.py [--reps 20]
-Prints per captured call: lookups, direct scatter us, binned us, binned without the direction adjoint us."""
+Prints per captured call: lookups, direct scatter us, binned us, binned without the direction adjoint us; the two halves of the
+binned call on their own (nmf_sat_lookup_bwd_dirs / the table role without riders) and the per-kernel times (launch probe)."""
 import argparse
 import os
 import sys
@@ -63,7 +64,24 @@ def main():
                 continue
             hip.ENV_BINNED_MIN_LOOKUPS = thr
             out[name] = timed(lambda: orig(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip if wd else None, wd, None, sc))
+        fx = hip.HOST_EXT
+        st = torch.cuda.current_stream().cuda_stream
+        go = d_out.contiguous()
+        t_dirs = timed(lambda: fx.sat_lookup_bwd_dirs(sat, dirs, sa, float(mipbias), go, d_pole, d_mip, sc, st))
+        t_table = timed(lambda: fx.sat_lookup_bwd_table(sat, dirs, sa, float(mipbias), go, d_sat, sc, st))
+        per = {}
+        for name, fn in (("binned", lambda: orig(sat, dirs, sa, mipbias, d_out, d_sat, d_pole, d_mip, True, None, sc)),
+                         ("table", lambda: fx.sat_lookup_bwd_table(sat, dirs, sa, float(mipbias), go, d_sat, sc, st))):
+            hip.ENV_BINNED_MIN_LOOKUPS = 1
+            torch.cuda.synchronize()
+            fx.kernel_timing_begin("", False)
+            for _ in range(a.reps):
+                fn()
+            t = fx.kernel_timing_end()
+            per[name] = "  ".join(f"{k.replace('k_env_bin_', '')} {1e3 * v[0] / a.reps:.1f}" for k, v in sorted(t.items()) if k.startswith("k_env"))
         torch.cuda.synchronize()
+        print(f"   the halves (R5): dirs role alone {t_dirs:7.1f} us   table role alone {t_table:7.1f} us")
+        print(f"   per kernel, one call: {per['binned']}   | table role alone: {per['table']}")
         print(f"lookups {dirs.shape[0]:7d}  sa mean {float(sa.mean()):6.2f}  direct {out['direct']:7.1f} us  binned {out['binned']:7.1f} us  "
               f"binned without d_dirs {out['binned_no_dirs']:7.1f} us")
 
