@@ -132,6 +132,7 @@ def kernel_models(sz, n_params):
         "k_vm_bwd_brick<false, 1>": ("mfma", float(BWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
         "k_vm_fwd<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * M0), FP32_PEAK, F),
         "k_vm_sigma<float>": ("valu", float(FWD_VALUE * M1), FP32_PEAK, F),
+        "k_vm_sigma<float, true>": ("valu", float(FWD_VALUE * M1), FP32_PEAK, F),      # (+ the brick histogram: StepCore.value_hist)
         "k_vm_rows_dn<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * Mb1), FP32_PEAK, F),
         "k_vm_app_rows<float>": ("valu", float(FWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
         "k_march_count16": ("valu", float(MARCH_LANE_OPS) * R0 * N, LANE_OP_PEAK, "T lane-ops/s"),
@@ -719,6 +720,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", default=None, help="W,K: W warm-up + K timed CPU steps per phase, no time budget")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--core", action="append", default=[], metavar="ATTR=0|1",
+                    help="A/B only: a switch of the C++ pass (csrc/step_core.inc: env_split, value_hist, overlap ...) set before the warm-up; "
+                         "named in config.core_switches")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -815,6 +819,9 @@ def main():
         return
 
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
+    for kv in args.core:
+        k, v = kv.split("=")
+        setattr(trainer.fast.core(), k, bool(int(v)))
     noise = DeviceNoise(device, seed=1000 + rank)
     batches, focal = make_batches(nerf, args.warmup + args.steps, args.rays_per_gpu, rank, device)
     fx = hip_mod.HOST_EXT
@@ -828,7 +835,9 @@ def main():
         trainer.step(*batches[i % len(batches)], focal, noise=noise, update_controllers=False, fixed_chunk=chunk_rays)
     if n_probe:
         probe = {k: v for k, v in fx.kernel_timing_end().items() if not k.startswith("@")}
-        dominant = max(probe.items(), key=lambda kv: kv[1][0])[0]
+        # (among the kernels kernel_models() prices: a latency-bound kernel without a work model has no fraction to report)
+        priced = {k for k in kernel_models(dict.fromkeys(("B", "M0", "M1", "R0", "R1", "Mb0", "Mb1", "N"), 1), 1) if not k.startswith("group:")}
+        dominant = max(({k: v for k, v in probe.items() if k in priced} or probe).items(), key=lambda kv: kv[1][0])[0]
     sync()
     timer.enabled = True
     if dominant:
@@ -943,7 +952,8 @@ def main():
                        # environment map: started inside the last chunk's backward, next to the field walks) + the late bucket
                        "comm_exposed_ms": (last["comm_exposed_ms"] if last["comm_bytes"] else None),
                        "host_cpu_ms_per_step": last.get("host_cpu_ms_per_step"),
-                       "host_pass": "C++ (csrc/step_core.inc)" if (trainer.fast is not None and trainer.fast.core() is not None) else "python"},
+                       "host_pass": "C++ (csrc/step_core.inc)" if (trainer.fast is not None and trainer.fast.core() is not None) else "python",
+                       **({"core_switches": args.core} if args.core else {})},
             "roofline": roof,
         }
         if world == 1 and not args.no_extras and args.rays_per_gpu == CHUNK and args.grid == GRID and args.budget_scale == 1 \

@@ -18,7 +18,7 @@ from test_hip_parity import _field_tables, _hip
 pytestmark = pytest.mark.gpu
 
 
-def _timed_step(nerf, g, pins, n_rays=None):
+def _timed_step(nerf, g, pins, n_rays=None, core_switches=()):
     """one Trainer.step on the fixture's rays with the optimizer update switched off -> (StepStats, trace record, calls)"""
     from nmf_amd.config import resolved_config
     from nmf_amd.noise import ReplayNoise
@@ -29,6 +29,8 @@ def _timed_step(nerf, g, pins, n_rays=None):
     assert tr.fast is not None and tr.fast.supported()
     if nerf.rf.table_dtype == "f32":
         assert tr.fast.core() is not None, "the C++ pass (lib/_nmf_host.so StepCore) is what bench.py times: it must be the one tested"
+    for k in core_switches:                                         # a switch of the C++ pass that is off by default (value_hist)
+        setattr(tr.fast.core(), k, True)
     tr.optimizer.step = lambda: None                               # keep the gradients, leave the parameters alone
     tr.optimizer.step_unhooked = lambda: None
     calls = []
@@ -51,19 +53,21 @@ def _timed_step(nerf, g, pins, n_rays=None):
     return out, rec[0]
 
 
-@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_full_seeded", "e2e_variant_steady"])
+@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_full_seeded", "e2e_variant_steady", "e2e_full_steady+value_hist"])
 def test_timed_path_vs_reference(name):
     """Trainer.step (tape-free) on the reference's 4096-ray / 128^3 steady-state run, its 300^3 run, its early-phase run and the
     scene-variation run (near_far [2, 6] as configs/dataset/materials.yaml, aabb_scale 2 as helmet.yaml:8, a high-specular material
     with roughness_bias -2.5, another camera):
     sample counts and the budget mask bit-exact, radiance 1e-4, loss 1e-4, FULL parameter gradients at the tolerances of the
-    module-path tests (tests/test_hip_e2e.py::_check_loss_and_gradients)."""
+    module-path tests (tests/test_hip_e2e.py::_check_loss_and_gradients).  "+value_hist": the same step with the brick histogram of the
+    value-only walk taken by the value query of the forward (StepCore.value_hist, off by default: measured neutral)."""
+    name, _, switch = name.partition("+")
     g = Golden(name)
     nerf = _full_size_model(g)
     pins = _pin_reference_bookkeeping(g, order=name != "e2e_full_seeded")
     if name == "e2e_full_seeded":
         pins.retrace_order[0] = _early_phase_order(g)
-    out, rec = _timed_step(nerf, g, pins)
+    out, rec = _timed_step(nerf, g, pins, core_switches=(switch,) if switch else ())
     tr = pins.trace
     assert list(rec["n_samples"]) == [int(v) for v in g.np("n_samples")]
     assert torch.equal(tr["whole_valid0"].cpu(), g["whole_valid"]) and rec["kept"] == int(g["whole_valid"].sum())
