@@ -653,14 +653,16 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["early_phase"] = train_ms(nerf, CHUNK, 40, 10)
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
     nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
-    out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 2)
+    out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 4)
     out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
     # [650 000, 450 000]: sized for a 24 GB card) scaled by 4: two chunks of 16 384 rays, 2.3 GiB peak -- per-ray statistics
     # unchanged (the bounce budget grows with the chunk's weight total), the ~115 dependent launches of a chunk paid twice
     # instead of eight times (tools/big_chunk.py: x2 / x4 / x8)
     scale_budgets(nerf, 4)
-    out["rays_32768_per_gpu_budgets_x4"] = train_ms(nerf, 32768, 8, 2, chunk=4 * CHUNK)
+    # (five warm-up steps: the allocator's pools for the 4 x larger buffers are still growing in the first ones -- with two, one box of
+    #  round 5 timed 10.9 ms here where fresh processes give 6.7-6.8)
+    out["rays_32768_per_gpu_budgets_x4"] = train_ms(nerf, 32768, 8, 5, chunk=4 * CHUNK)
     out["rays_32768_per_gpu_budgets_x4"]["note"] = ("the same 32 768-ray optimizer step as 2 chunks of 16 384 rays: sampler.max_samples / "
                                                     "model.max_brdf_rays x 4 (config keys of the reference; `bench.py --budget-scale 4`)")
     del nerf
