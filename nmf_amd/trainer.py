@@ -532,6 +532,7 @@ class Trainer:
         n_total = rays.shape[0] if rays is not None else self.lbatch_size()
         lbatch = global_rays if global_rays is not None else n_total * self.world_size
         pos, used_rays, losses, n_samples_last, n_chunks = 0, 0, [], None, 0
+        went_graph = False
         bg = None
         fast = self.fast if (self.fast is not None and self.fast.supported()) else None
         if fast is not None:
@@ -584,6 +585,7 @@ class Trainer:
                         self.batch.update(out["kept"], n_samples[0])
                         nerf.model.update_n_samples(n_samples[1:])
                     continue
+            went_graph = True                        # this chunk's gradients land in .grad outside the pass's accumulators
             ims, st = nerf(r, focal, bg_col=bg, is_train=True, ndc_ray=False, noise=noise)
             n_samples = st["n_samples"]
             if trace is not None:
@@ -631,7 +633,8 @@ class Trainer:
             guard = _zero_scalar(self.reduce.params[0].device)          # this rank's chunks were all empty: a finite contribution
         if early is not None:
             # the fused pass keeps every gradient in two contiguous regions of its flat buffer: summed in place, nothing is packed
-            fast.fold_foreign()
+            if went_graph:
+                fast.fold_foreign()
             _e, late, tail = fast.comm_regions()
             has_grad = any(q.grad is not None for q in self.reduce.params)
             has_env = nerf.bg_module.bg_mat.grad is not None

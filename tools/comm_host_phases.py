@@ -26,7 +26,7 @@ def wrap(obj, name, key=None):
 for i in range(40): tr.step(*batches[i % 12], f, noise=nz, update_controllers=False, fixed_chunk=4096)
 wrap(tr.fast, "chunk"); wrap(tr.fast, "end_step"); wrap(tr.fast, "prefetch"); wrap(tr.fast, "early_pairs")
 red = tr.reduce
-wrap(red, "early"); wrap(red, "finish_early"); wrap(red, "_call_late"); wrap(tr.optimizer, "step_unhooked"); wrap(dist, "all_reduce", "dist.all_reduce")
+wrap(red, "early_inplace"); wrap(red, "late_inplace"); wrap(red, "finish_early"); wrap(tr.optimizer, "step_unhooked"); wrap(dist, "all_reduce", "dist.all_reduce")
 for mode in (True, False):
     red.single_rank = mode
     for i in range(20): tr.step(*batches[i % 12], f, noise=nz, update_controllers=False, fixed_chunk=4096)
