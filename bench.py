@@ -542,7 +542,9 @@ def psnr_runs(device, seeds):
             rays_seen += st["rays"]
             if it + 1 in at:
                 nerf.eval()
-                pred = render_images(nerf, rays_te, focal, 4096, noise, draw_debug=True)
+                # 800 rays per evaluation chunk, as the reference runs of the fixture (make_train_trace.py test_psnr): the per-CHUNK
+                # budgets (max_retrace_rays, max_brdf_rays[1]) make the rendering depend on the chunk size
+                pred = render_images(nerf, rays_te, focal, 800, noise, draw_debug=True)
                 nerf.train()
                 pv, gv = pred.reshape(n_views, -1, 3), rgb_te.reshape(n_views, -1, 3)
                 row.append(float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(n_views)]).mean()))
