@@ -305,6 +305,89 @@ def cpu_baseline(budget_s=150.0, warm=1, timed=3):
                               "213 rays/s steady state, 634 rays/s early phase; `python bench.py --cpu-baseline-steps 3,10`)")
 
 
+LINE_LIMIT = 6144           # bytes: the driver keeps an 8 KB tail of stdout and parses the last line out of it (round 5's 21 KB line was not parsed)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(x, nd=4):
+    """Numbers of the line rounded to `nd` significant digits below 1e4 (and to integers above), recursively."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{nd}g}") if abs(x) < 1e4 else round(x)
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact_line(out, detail_path=DETAIL_FILE):
+    """The ONE JSON line of the contract, from the full result dict `out`: the contract's keys, `roofline` of the dominant kernel,
+    `cpu_baseline`, `psnr_at_iter` and ONE number per extras leg.  Everything else (the per-kernel table, notes, the long legs)
+    is in `detail_path`, which the line names.  Kept below LINE_LIMIT bytes (tests/test_bench_line.py)."""
+    cfg = dict(out.get("config") or {})
+    wl = str(cfg.get("workload", ""))
+    keep_cfg = ("rays_per_gpu", "chunks_per_step", "chunks_in_flight", "grid", "samples_per_chunk", "parallelism", "ranks_seen", "backend",
+                "comm_ms_per_step", "comm_bytes_per_step", "comm_exposed_ms", "host_cpu_ms_per_step", "startup_steps", "host_pass",
+                "core_switches", "operator_graph_fallbacks")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": wl if len(wl) <= 300 else wl[:297] + "...", **{k: cfg[k] for k in keep_cfg if k in cfg}}
+    roof = out.get("roofline") or {}
+    if "kernel" in roof:
+        st = roof.get("step") or {}
+        line["roofline"] = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "issued_bf16_frac", "traffic",
+                                                     "avg_launch_us", "launches", "sizes_per_step")}
+        line["roofline"]["counters_of_kernel"] = roof.get("counters_of_kernel")
+        line["roofline"]["step"] = {k: st.get(k) for k in ("wall_us", "main_stream_kernel_us", "critical_path_frac", "device_time_sum_us",
+                                                           "survey_8d_over_hbm", "needed_over_l2")}
+        groups = {k[6:]: v.get("us_per_step") for k, v in (roof.get("per_kernel") or {}).items() if k.startswith("group:")}
+        if groups:
+            line["roofline"]["group_us_per_step"] = groups
+    elif roof:
+        line["roofline"] = {"note": str(roof.get("note", ""))[:200]}
+    cb = out.get("cpu_baseline")
+    if cb:
+        ss = cb.get("steady_state") or {}
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": f"B={CHUNK} rays of S1 at 128^3, fwd+bwd of the training loss, steady state, "
+                                          f"{ss.get('warmup_steps')}+{ss.get('timed_steps')} steps of {ss.get('s_per_step', 0):.1f} s",
+                                "protocol": cb.get("protocol"),
+                                "early_phase_rays_per_s": (cb.get("early_phase") or {}).get("rays_per_s")}
+    ps = out.get("psnr_at_iter")
+    if ps:
+        line["psnr_at_iter"] = {k: ps.get(k) for k in ("test_psnr_db", "reference_mean_db", "delta_db", "delta_stderr_db", "seeds",
+                                                       "reference_seeds", "error") if k in ps}
+    ex = out.get("extras")
+    if ex:
+        one = {}
+        for k, v in ex.items():
+            if k == "psnr_at_iter" or not isinstance(v, dict):
+                continue
+            if "error" in v:
+                one[k] = "error"
+            elif k == "schedule_weighted":
+                one[k + "_rays_per_s"] = v.get("rays_per_s")
+            elif "ms_per_step" in v and k not in ("rays_32768_per_gpu", "rays_32768_per_gpu_budgets_x4", "inference", "grid_300"):
+                one[k + "_ms"] = v["ms_per_step"]
+            else:
+                one[k + "_rays_per_s"] = v.get("rays_per_s")
+        line["extras"] = one
+    line["detail"] = detail_path
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                     # never an unparsable line: drop the optional objects, largest first
+        for k in ("extras", "psnr_at_iter"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
 def counters_summary():
     """Counter-backed per-kernel figures written by tools/profile_round.sh + tools/roofline_metrics.py at the profiled commit
     (rocprofv3 --pmc passes, one counter group per run): profiles/<tag>_roofline.json.  The `roofline` object of the bench line
@@ -756,6 +839,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", default=None, help="W,K: W warm-up + K timed CPU steps per phase, no time budget")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--detail-dir", default=None, help=f"where {DETAIL_FILE} (the full result: per-kernel table, notes, every leg) is written; default: next to bench.py")
     ap.add_argument("--leg", default=None, help="internal: `host_paths` = the host-bound legs of `extras` in this (fresh) process, one JSON line")
     ap.add_argument("--core", action="append", default=[], metavar="ATTR=0|1",
                     help="A/B only: a switch of the C++ pass (csrc/step_core.inc: env_split, value_hist, overlap ...) set before the warm-up; "
@@ -836,7 +920,7 @@ def main():
         nerf.model.max_retrace_rays = [args.retrace]
     timer = RebuildCounter()
     from nmf_amd import hip as hip_mod
-    workload = (f"S1 solid-cube scene, TensoRF {args.grid}^3 (16+24 comps, {args.table_dtype} tables), env 512x1024, "
+    workload = (f"S1 (solid cube, SURVEY 8d), TensoRF {args.grid}^3 (16+24 comps, {args.table_dtype} tables), env 512x1024, "
                 f"800x800 camera")
 
     if args.mode == "infer":
@@ -990,13 +1074,17 @@ def main():
             "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.table_dtype == "f32" else "bf16 tables / f32 arithmetic",
             "data": "synthetic",
-            "config": {"workload": workload + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {chunk_rays}"
-                                   + (f" (per-chunk budgets x{args.budget_scale})" if args.budget_scale > 1 else "") + ", "
-                                   "fwd+bwd+all-reduce+Adam, " + ("all secondary rays re-traced (steady state: the a20 score + sort of models/microfacet.py:475-537 "
-                                                                  "selects every ray and is skipped)" if args.retrace is None
-                                                                  else f"{args.retrace} secondary rays re-traced") +
-                                   f"; stands in for BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] (lego / ship are not "
-                                   "available offline: scene S1 of SURVEY 8d)",
+            # (<= 300 characters: compact_line keeps it whole; the a20 note -- in the steady state the score + sort of
+            #  models/microfacet.py:475-537 selects every secondary ray and is skipped -- is `config.retrace` in the detail file)
+            "config": {"workload": f"BASELINE configs[{1 if args.rays_per_gpu == CHUNK else 3}] on scene " + workload
+                                   + f", {args.rays_per_gpu} rays/GPU/step in {chunks_per_step} chunk(s) of {chunk_rays}"
+                                   + (f" (per-chunk budgets x{args.budget_scale})" if args.budget_scale > 1 else "")
+                                   + ", fwd+bwd+all-reduce+Adam, "
+                                   + ("steady state (all secondary rays re-traced)" if args.retrace is None
+                                      else f"{args.retrace} secondary rays re-traced"),
+                       "retrace": ("all secondary rays re-traced: the a20 score + sort of models/microfacet.py:475-537 selects every ray in "
+                                   "the steady state and is skipped" if args.retrace is None else f"{args.retrace} secondary rays re-traced")
+                                  + "; lego / ship are not available offline: scene S1 of SURVEY 8(d)",
                        "rays_per_gpu": args.rays_per_gpu, "chunks_per_step": chunks_per_step, "grid": args.grid,
                        "samples_per_chunk": last["n_samples"], "samples_per_chunk_first_step": last["first_n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
@@ -1031,7 +1119,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(budget_s=None, warm=w_, timed=k_)
             else:
                 out["cpu_baseline"] = cpu_baseline()
-        line = json.dumps(out)
+        detail = os.path.join(args.detail_dir or ROOT, DETAIL_FILE)
+        try:
+            with open(detail, "w") as f:
+                json.dump(out, f, indent=1)
+            shown = os.path.relpath(detail, ROOT) if detail.startswith(ROOT) else detail
+        except OSError as e:                       # (a read-only checkout: the line still goes out)
+            shown = f"not written ({e.__class__.__name__})"
+        line = compact_line(out, shown)
     else:
         line = None
     # The JSON line is the LAST thing this job writes to stdout: RCCL prints a version banner through C stdio (buffered when

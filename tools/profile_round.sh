@@ -17,6 +17,8 @@ if [ -n "$BENCH_ARGS" ]; then
 else
   python "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 fi
+# (the line is the compact one; the per-kernel table and every leg are in the detail file it names)
+cp "$ROOT/bench_detail.json" "$OUT/${TAG}_bench_detail.json" 2>/dev/null
 rm -rf /tmp/prof_ks
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > "$OUT/${TAG}_prof_bench.log" 2>&1
 cp "$(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
