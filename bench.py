@@ -953,7 +953,7 @@ def main():
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
     for kv in args.core:
         k, v = kv.split("=")
-        setattr(trainer.fast.core(), k, bool(int(v)))
+        trainer.fast.set_switch(k, bool(int(v)))
     noise = DeviceNoise(device, seed=1000 + rank)
     batches, focal = make_batches(nerf, args.warmup + args.steps, args.rays_per_gpu, rank, device)
     fx = hip_mod.HOST_EXT

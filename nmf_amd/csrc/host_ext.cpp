@@ -1311,7 +1311,7 @@ PYBIND11_MODULE(_nmf_host, m) {
         .def("env_was_used", &StepCore::env_was_used)
         .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
 #define RW(name) .def_readwrite(#name, &StepCore::name)
-        RW(env_keep_sat) RW(value_hist) RW(env_split) RW(early_cb) RW(comm_stream) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
+        RW(env_keep_sat) RW(value_hist) RW(env_split) RW(early_cb) RW(comm_stream) RW(peer_streams) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
         RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws) RW(mlp_image)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)

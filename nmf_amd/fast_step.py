@@ -21,6 +21,7 @@ removed in round 5 -- three orchestrations of one step were one too many.)"""
 import ctypes
 import os
 import types
+import weakref
 
 import torch
 
@@ -48,6 +49,13 @@ MLP_SIDE_WGS = 192      # persistent workgroups of a BRDF-MLP backward that shar
                         # LDS the kernels of the main stream cannot use (round 2, fp32 kernel: 192 / 256 best)
 
 
+# Chunk contexts: the chunks of ONE optimizer step are independent given the parameters (the reference runs them one after another,
+# train.py:509-712, and sums their gradients); with two contexts -- a StepCore, a main stream and a set of side streams each -- chunk
+# k + 1's forward (latency bound: four size read-backs) is queued and runs while chunk k's backward fills the chip.  A step of one
+# chunk only ever uses context 0 = torch's current stream, exactly as before.  VERDICT r05 item 2; NMF_CHUNK_CONTEXTS=1 switches it off.
+N_CONTEXTS = max(1, int(os.environ.get("NMF_CHUNK_CONTEXTS", "2")))
+
+
 def _ns(**kw):
     return types.SimpleNamespace(**kw)
 
@@ -55,10 +63,11 @@ def _ns(**kw):
 class _ChunkHolder:
     """what functional.L1Mean needs of a pass to hand its gradient over (GradPass's l1 / used / done): the density_L1 term of a chunk
     rides in the unpack launch of that chunk's ChunkPass node"""
-    __slots__ = ("l1", "used", "done", "chunk_pass")
+    __slots__ = ("l1", "used", "done", "chunk_pass", "serial", "__weakref__")
 
-    def __init__(self):
+    def __init__(self, serial=0):
         self.l1, self.used, self.done, self.chunk_pass = None, True, False, True
+        self.serial = serial            # which training forward of the pass this node belongs to (TrainPass._pending)
 
 
 class ChunkPass(torch.autograd.Function):
@@ -115,23 +124,25 @@ class TrainPass:
         self._main = None
         # the same pass as ONE C++ call per chunk (csrc/step_core.inc, in lib/_nmf_host.so): the methods below stay the
         # specification and the path for bf16 tables / NMF_STEP_CORE=0 / a missing host extension
-        self._core = None
-        self._core_key = None
-        self._core_keep = None
+        self._core = None               # context 0's StepCore (None: not created yet, False: no host extension)
+        self._ctxs = []                 # chunk contexts: _ns(index, core, main (torch Stream; None = torch's current stream), ...)
+        self._ctx_used = []             # contexts with chunks of the running optimizer step in flight
+        self._switches = {}
+        self.n_contexts = N_CONTEXTS if self.overlap else 1
         self._mlp_image = None          # hip.brdf_mlp_pack of the MLP weights, rewritten with the per-step tables
-        self._core_acc = None
-        self._march_blocks = None
         self._token_params = None
         self._token_plist = None
         self._tables_token = None
+        self._tables_cur = None         # what the last _core_tables built: bound to each context's StepCore (_bind_tables)
+        self._tables_serial = 0
         self._table_events = None
-        self._core_static = None
-        self._core_retrace = None
         self.last_sizes = None            # sizes of the last chunk the C++ pass ran (reports)
         self._delivered = None            # [(parameter, gradient tensor, its version)] the autograd node left in .grad
         self._acc_empty = False
         self._prefetch_registered = False
         self._autograd_chunks = 0         # ChunkPass backwards since the last optimizer step
+        self._fwd_serial = 0              # training forwards handed out as autograd nodes
+        self._pending = None              # (serial, weakref to its holder) of the forward whose tape the C++ pass keeps
 
     # ------------------------------------------------------------------------------------------------------------
     def supported(self):
@@ -143,17 +154,44 @@ class TrainPass:
     # ---- the C++ pass ----------------------------------------------------------------------------------------------
     _CORE_STREAMS = (("mlp", 0), ("mlp", 1), ("env", 0), ("env", 1), ("walk", 1), "sat_bwd", "env_table")
 
-    def core(self):
-        """-> lib/_nmf_host.so's StepCore configured for this model, or None (Python pass)"""
+    def context(self, i=0):
+        """-> chunk context i (created on first use), or None without the host extension.  Context 0 works on torch's current
+        stream and the process-wide side streams; context i > 0 on a main stream and side streams of its own."""
         if self._core is False:
             return None
-        if self._core is None:
+        while len(self._ctxs) <= i:
             fx = hip.HOST_EXT
             if fx is None or not hasattr(fx, "StepCore"):
                 self._core = False
                 return None
-            self._core = fx.StepCore()
-        return self._core
+            k = len(self._ctxs)
+            main = None
+            if k > 0:
+                main = self._side.get(("ctx", k, "main"))
+                if main is None:
+                    main = self._side[("ctx", k, "main")] = torch.cuda.Stream()
+            self._ctxs.append(_ns(index=k, core=fx.StepCore(), main=main, key=None, keep=None, static=None, march_blocks=None,
+                                  retrace=None, acc=None, bound=-1))
+            for name, v in self._switches.items():
+                setattr(self._ctxs[-1].core, name, v)
+            if k == 0:
+                self._core = self._ctxs[0].core
+        return self._ctxs[i]
+
+    def core(self, i=0):
+        """-> lib/_nmf_host.so's StepCore of chunk context i, configured for this model, or None (no host extension)"""
+        cx = self.context(i)
+        return None if cx is None else cx.core
+
+    def cores(self):
+        return [cx.core for cx in self._ctxs]
+
+    def set_switch(self, name, value):
+        """a boolean switch of the C++ pass (env_split, value_hist, ...: A/B runs and tests) on every chunk context, present and future"""
+        self._switches[name] = value
+        if self.context(0) is not None:
+            for cx in self._ctxs:
+                setattr(cx.core, name, value)
 
     def _param_token(self):
         """(version, storage) of every parameter the derived tables are built from: equal token = equal tables"""
@@ -173,7 +211,7 @@ class TrainPass:
         first env-map use).  Called by prefetch() right after the optimizer step -- the device then rebuilds while the host
         prepares the next step and the sampler of the next step starts without the ~130 us of rebuild kernels in front of it --
         or by the first chunk that finds its tables stale."""
-        c, n = self._core, self.nerf
+        n = self.nerf
         rf, model, bgm, smp = n.rf, n.model, n.bg_module, n.sampler
         main = torch.cuda.current_stream()
         if self.overlap:
@@ -209,10 +247,25 @@ class TrainPass:
         finally:
             if self.overlap:
                 torch.cuda.set_stream(main)
+        self._tables_cur = (tab, hp, hW, hb, mlp_ws, mlp_bias, env, sc, conv)
+        self._tables_serial += 1
+        self._tables_token = self._param_token()
+        if not self._ctxs:
+            self.context(0)
+        for cx in self._ctxs:
+            self._bind_tables(cx, dev)
+
+    def _bind_tables(self, cx, dev):
+        """what _core_tables built -> the attributes of chunk context `cx`'s StepCore: everything when a table moved (a new grid, a
+        new stream), else the few per-step values"""
+        tab, hp, hW, hb, mlp_ws, mlp_bias, env, sc, conv = self._tables_cur
+        c, n = cx.core, self.nerf
+        rf, model, bgm, smp = n.rf, n.model, n.bg_module, n.sampler
+        main = cx.main if cx.main is not None else torch.cuda.current_stream()
         key = (ctypes.addressof(tab[0]), tab[1][0].data_ptr(), tab[3][0].data_ptr(), tab[5].data_ptr(), bgm._cache[1][3].data_ptr(),
                hW.data_ptr(), mlp_ws[0].data_ptr(), model.brdf_sampler.angs.data_ptr(), main.cuda_stream, self.overlap, id(smp))
-        if self._core_key != key:
-            self._core_key = key
+        if cx.key != key:
+            cx.key = key
             p, dpk, dlk, apl, ali, basis = rf._tables()          # fp32 masters: the backward walks
             c.vm_p, c.dpk, c.dlk, c.apl, c.ali, c.basis = ctypes.addressof(p), list(dpk), list(dlk), list(apl), list(ali), basis
             if rf.table_dtype == "f32":
@@ -226,7 +279,7 @@ class TrainPass:
             c.env_table, c.env_pole, c.env_act = bgm._cache[1][3], env[2], env[0]
             c.env_bg = bgm.bg_mat.detach().reshape(3, bgm.bg_mat.shape[-2], bgm.bg_mat.shape[-1])
             c.white, c.one = _white(dev), _one(dev)
-            c.select_ws = hip.select_total_workspace(dev)
+            c.select_ws = hip.select_total_workspace(dev, main)          # (one per stream: chunks of two contexts overlap)
             c.scale = float(rf.distance_scale)
             c.max_brdf_rays = [int(v) for v in model.max_brdf_rays]
             c.rays_per_ray, c.test_rays_per_ray = float(model.rays_per_ray), float(model.test_rays_per_ray)
@@ -234,14 +287,15 @@ class TrainPass:
             c.overlap = bool(self.overlap)
             c.main_stream, c.main_stream_obj, c.set_stream = main.cuda_stream, main, torch.cuda.set_stream
             if self.overlap:
-                for k in self._CORE_STREAMS:
+                roles = [k if cx.index == 0 else ("ctx", cx.index, k) for k in self._CORE_STREAMS]
+                for k in roles:
                     if k not in self._side:
                         self._side[k] = torch.cuda.Stream()
-                objs = [self._side[k] for k in self._CORE_STREAMS]
+                objs = [self._side[k] for k in roles]
                 c.side_stream_objs, c.side_streams = objs, [o.cuda_stream for o in objs]
             else:
                 c.side_stream_objs, c.side_streams = [], []
-            self._core_keep = (tab, env, hW, hb, mlp_ws, main)
+            cx.keep = (tab, env, hW, hb, mlp_ws, main)
         c.head_p, c.mlp_bias = [float(v) for v in hp], float(mlp_bias)
         c.mlp_image = self._mlp_image
         c.env_sc, c.sh_conv = sc, conv
@@ -249,7 +303,7 @@ class TrainPass:
             c.wait_tables, c.wait_env = self._table_events[0].cuda_event, self._table_events[1].cuda_event
         else:
             c.wait_tables, c.wait_env = 0, 0
-        self._tables_token = self._param_token()
+        cx.bound = self._tables_serial
 
     @torch.no_grad()
     def prefetch(self):
@@ -258,45 +312,51 @@ class TrainPass:
             return
         self._core_tables(self._acc_cache.flat.device)
 
-    def _core_sync(self, dev, focal, is_train):
-        """hands the C++ pass what it reads: the tables (rebuilt here only when no prefetch() left them current), then the few
-        per-chunk values"""
-        c, n = self._core, self.nerf
+    def _core_sync(self, dev, focal, is_train, cx=None):
+        """hands the C++ pass of chunk context `cx` what it reads: the tables (rebuilt here only when no prefetch() left them
+        current), then the few per-chunk values"""
+        cx = cx if cx is not None else self.context(0)
+        c, n = cx.core, self.nerf
         model, smp = n.model, n.sampler
         if self._tables_token is None or self._tables_token != self._param_token():
+            if cx.main is not None:                   # (the rebuild is queued behind the optimizer update: the caller's stream)
+                raise hip.NmfHipError("derived tables are rebuilt from context 0 (a chunk context > 0 never runs the first chunk of a step)")
             self._core_tables(dev)
+        if cx.bound != self._tables_serial:
+            self._bind_tables(cx, dev)
         st = (self.sparse_normals, MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV, WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS,
               int(hip.ENV_BINNED_MIN_LOOKUPS), int(smp.max_samples), float(model.anoise))
-        if st != self._core_static:
-            self._core_static = st
+        if st != cx.static:
+            cx.static = st
             c.sparse_normals = bool(self.sparse_normals)
             c.mlp_side_min_rays, c.mlp_side_min_env_rays, c.mlp_side_wgs_env = MLP_SIDE_MIN_RAYS, MLP_SIDE_MIN_ENV_RAYS, MLP_SIDE_WGS_ENV
             c.walk_side_min_samples, c.mlp_side_wgs, c.env_binned_from = WALK_SIDE_MIN_SAMPLES, MLP_SIDE_WGS, int(hip.ENV_BINNED_MIN_LOOKUPS)
             c.max_samples, c.anoise = int(smp.max_samples), float(model.anoise)
         packed, blk0 = smp.params_block(focal, None, is_train)
         _, blk1 = smp.params_block(focal, 3 * float(hip.host(smp.stepsize)), is_train)
-        if self._march_blocks is None or self._march_blocks[0] is not blk0 or self._march_blocks[1] is not blk1:
-            self._march_blocks = (blk0, blk1, packed)
+        if cx.march_blocks is None or cx.march_blocks[0] is not blk0 or cx.march_blocks[1] is not blk1:
+            cx.march_blocks = (blk0, blk1, packed)
             c.march_p0, c.march_p1 = ctypes.addressof(blk0[1]), ctypes.addressof(blk1[1])
             c.alpha_bits, c.alpha_coarse = (packed[1], packed[2]) if packed is not None else (None, None)
         c.min_rough, c.detach_n = float(model.min_rough), bool(model.detach_N)
         mr = [int(v) for v in model.max_retrace_rays]
-        if mr != self._core_retrace:
-            self._core_retrace = mr
+        if mr != cx.retrace:
+            cx.retrace = mr
             c.max_retrace_rays = mr
         return c
 
-    def _core_chunk(self, c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last):
+    def _core_chunk(self, cx, rays, gt, focal, noise, inv_lbatch, wts, want_total, last):
+        c = cx.core
         rf = self.nerf.rf
         dev = rays.device
         mods = [m for m in (rf, self.nerf.bg_module, self.nerf.model.brdf, self.nerf.model.diffuse_module) if hasattr(m, "begin_pass")]
         for m in mods:
             m.begin_pass()
         try:
-            self._core_sync(dev, focal, True)
+            self._core_sync(dev, focal, True, cx)
             c.white = _white(dev)
             a = self._accumulators(dev)
-            self._bind_accumulators(c, a)
+            self._bind_accumulators(cx, a)
             c.used_env = bool(a.used_env)
 
             def total_of(loss, ori, acc):
@@ -311,9 +371,9 @@ class TrainPass:
                 if "Unsupported" in str(e):
                     raise Unsupported(str(e)) from None
                 raise
-            a.used_env = bool(c.env_was_used())
+            a.used_env = bool(a.used_env) or bool(c.env_was_used())
             if c.env_table_backward_queued():
-                self._early_env = ("core", a.d_bg)
+                self._early_env = (c, a.d_bg)
             if out["loss"] is None:
                 return dict(loss=None, kept=out["kept"], n_samples=[0])
             pins = getattr(noise, "pins", None)
@@ -335,8 +395,9 @@ class TrainPass:
         self._early_env = None
         self.n_loss_chunks = 0
         self.l1_scale = 0.0
-        if self._core:
-            self._core.begin_step()
+        self._ctx_used = []
+        for cx in self._ctxs:
+            cx.core.begin_step()
 
     def _accumulators(self, dev, zero=True):
         """The gradient state of an optimizer step.  Allocated ONCE per (grid, env size): the flat accumulator buffer, its
@@ -421,33 +482,83 @@ class TrainPass:
 
     # ---- one chunk: forward, loss, backward (nmf_amd.trainer.Trainer) ------------------------------------------------------
     @torch.no_grad()
-    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False, early=None):
+    def chunk(self, rays, gt, focal, noise, inv_lbatch, wts, want_total=False, last=False, early=None, ctx=0):
         """wts = (w_photo, w_l1, w_ori, w_acc).  Returns dict(loss 0-d tensor, kept, n_samples) -- loss None when the chunk
         had no sample (train.py:567-568 skips it).  want_total: also evaluate the chunk's total loss value (the gradients do
         not need it: every term enters linearly with a constant weight)."""
         if not self.supported():
             raise Unsupported("configuration")
-        c = self.core()
+        cx = self.context(ctx if ctx < self.n_contexts else 0)
+        c = cx.core
         # early = (callable, raw comm stream): called from the last chunk's backward when the non-field gradients are final
         c.early_cb, c.comm_stream = (early[0], int(early[1])) if (early is not None and last) else (None, 0)
+        cur = torch.cuda.current_stream()
+        first_use = cx not in self._ctx_used
+        if first_use:
+            self._ctx_used.append(cx)
+        # what ends the step in the last chunk's backward (env-map table backward, early all-reduce) waits for the other contexts too
+        c.peer_streams = [(o.main.cuda_stream if o.main is not None else cur.cuda_stream) for o in self._ctx_used if o is not cx] if last else []
+        if cx.main is not None:
+            if first_use:
+                cx.main.wait_stream(cur)          # the zero fill of the step's accumulators, the optimizer update before it
+            torch.cuda.set_stream(cx.main)
         try:
-            return self._core_chunk(c, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
+            return self._core_chunk(cx, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
         finally:
             c.early_cb = None
+            if cx.main is not None:
+                torch.cuda.set_stream(cur)
+
+    def join_contexts(self):
+        """torch's current stream waits for everything the chunk contexts of this step have queued on streams of their own"""
+        cur = None
+        for cx in self._ctx_used:
+            if cx.main is not None:
+                cur = cur or torch.cuda.current_stream()
+                cur.wait_stream(cx.main)
 
     # ---- data parallel: the gradients that are final before the walks of the last chunk ------------------------------------------
+    @torch.no_grad()
+    def prepare_early(self, dev, behind_chunks=False):
+        """Data parallel, in front of the early collective: everything it sums exists and is queued on the CURRENT stream.
+        (1) A rank none of whose chunks reached the fused backward opens zeroed accumulators (zeros travel).  (2) The env-map table
+        gradient d_bg: the last chunk's backward queues the table backward itself (StepCore: last chunk, env map used, overlap); when
+        it did not -- that chunk kept no sample, left the fused pass, NMF_OVERLAP=0 -- while a chunk of the step did look the map up,
+        it is run here, so that the collective sums it and end_step does not write it AFTER the sum.  -> True when anything was queued."""
+        queued = False
+        if behind_chunks:                   # (not from inside the last chunk's backward: there StepCore waits for its peers itself)
+            self.join_contexts()
+        a = self.acc
+        if a is None:                       # no chunk of this step reached the fused backward: zeros travel, .grad stays None here
+            a = self._accumulators(dev)
+            self._acc_empty = True
+            queued = True
+        cores = self._cores_in_use()
+        used = any(bool(c.env_was_used()) for c in cores) or bool(a.used_env)
+        # (called from inside the last chunk's backward, `_early_env` is not set yet: the cores themselves know what they queued)
+        if used and self._early_env is None and not any(c.env_table_backward_queued() for c in cores):
+            bgm = self.nerf.bg_module
+            act, _sat, _pole = bgm._tables()
+            hip.sat_build_bwd(a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=bgm._dev_scalars(), out=a.d_bg)
+            a.used_env = True
+            self._early_env = ("done", a.d_bg)
+            queued = True
+        return queued
+
+    def _cores_in_use(self):
+        return [cx.core for cx in self._ctxs]
+
     def early_pairs(self, dev):
         """[(parameter, accumulator tensor)] of the BRDF MLP, the material heads and the environment map: what no field walk writes.
         The tensors are the ones end_step hands to the optimizer as .grad (views of the flat buffer, the env-map table gradient, the
         fp32 mip-bias adjoint), so a sum over the ranks written into them in place is what Adam reads.  A step whose chunks never
         looked the environment map up has a zero table gradient."""
         a = self.acc
-        if a is None:                       # no chunk of this step reached the fused backward: zeros travel, .grad stays None here
+        if a is None:                       # (prepare_early opens them in front of the collective's stream dependency)
             a = self._accumulators(dev)
             self._acc_empty = True
         n = self.nerf
         bgm = n.bg_module
-        used = bool(self._core.env_was_used()) if self._core else bool(a.used_env)
         if a.early_pairs is not None:
             return a.early_pairs
         m = n.model.brdf.mlp
@@ -465,7 +576,6 @@ class TrainPass:
         if self._prefetch_registered:
             return
         self._prefetch_registered = True
-        import weakref
         from . import optim
         ref = weakref.ref(self)
 
@@ -487,6 +597,15 @@ class TrainPass:
         c = self.core()
         dev = rays.device
         rf = self.nerf.rf
+        # ONE training forward may be pending per model (the C++ pass keeps one tape).  A second forward while the first one's graph is
+        # still alive and has not run its backward -- a multi-chunk `chunk_renderer(..., is_train=True)` whose loss is formed over all
+        # chunks, as the reference's renderer allows -- goes through the operator graph instead of superseding the first;
+        # a forward whose outputs were dropped without a backward (its holder is gone) is simply replaced.
+        if self._pending is not None:
+            h = self._pending[1]()
+            if h is not None and not h.done and c.has_pending():
+                raise Unsupported("another training forward of this model is pending (one tape per model)")
+            self._pending = None
         if hasattr(rf, "flush_pending_l1"):
             rf.flush_pending_l1()               # a density_L1 term whose pass never ran its backward
         mods = [m for m in (rf, self.nerf.bg_module, self.nerf.model.brdf, self.nerf.model.diffuse_module) if hasattr(m, "begin_pass")]
@@ -494,8 +613,9 @@ class TrainPass:
             m.begin_pass()
         try:
             self._core_sync(dev, focal, True)
-            self._bind_accumulators(c, self._accumulators(dev, zero=False))
-            holder = _ChunkHolder()
+            self._bind_accumulators(self.context(0), self._accumulators(dev, zero=False))
+            self._fwd_serial += 1
+            holder = _ChunkHolder(self._fwd_serial)
             try:
                 out = c.train_forward(rays.detach(), float(focal), noise)
             except RuntimeError as e:
@@ -507,15 +627,17 @@ class TrainPass:
             self.last_sizes = dict(rays=int(out["kept"]), n_samples=list(out["n_samples"]), n_rays=list(out["n_rays"]),
                                    n_rows=list(out["n_rows"]))
             rgb, acc, ori = ChunkPass.apply(self, holder, _token(dev), out["rgb_map"], out["acc"], out["ori"])
+            self._pending = (holder.serial, weakref.ref(holder))
             rf._last_holder = holder            # density_L1() of this chunk rides on the node (fields/tensoRF.py)
             return rgb, acc, ori, out
         finally:
             for m in mods:
                 m.end_pass()
 
-    def _bind_accumulators(self, c, a):
-        if self._core_acc is not a:
-            self._core_acc = a
+    def _bind_accumulators(self, cx, a):
+        c = cx.core
+        if cx.acc is not a:
+            cx.acc = a
             c.g_dpk, c.g_dlk, c.g_apl, c.g_ali, c.g_mlp = list(a.g_dpk), list(a.g_dlk), list(a.g_apl), list(a.g_ali), list(a.g_mlp)
             c.g_basis, c.g_hW, c.g_hb, c.d_sat, c.d_pole, c.d_mip = a.g_basis, a.g_hW, a.g_hb, a.d_sat, a.d_pole, a.d_mip
             c.d_bg_out = a.d_bg if self.overlap else None
@@ -527,9 +649,10 @@ class TrainPass:
         left there continues the sum in the accumulators (no copy, no add launch per parameter); anything else -- somebody wrote
         into .grad in between -- is added to out of place."""
         c = self.core()
-        if not c.has_pending():
+        if not c.has_pending() or self._pending is None or self._pending[0] != holder.serial:
             raise RuntimeError("backward of a TensorNeRF training forward whose chunk was superseded by a later forward (one "
                                "training forward may be pending per model)")
+        self._pending = None
         a = self._acc_cache
         pairs = self._delivered
         state = "fresh"
@@ -542,10 +665,15 @@ class TrainPass:
                 state = "detach"
         elif any(prm.grad is not None for prm in self._grad_params()):
             state = "detach"
-        if state == "detach" and pairs is not None:
-            for (prm, g, v), m in zip(pairs, mine):
-                if m:
-                    prm.grad = g.clone()          # what this pass had summed so far becomes an ordinary gradient tensor
+        if state == "detach":
+            # what this pass had summed so far becomes an ordinary gradient tensor: every .grad that still ALIASES the flat buffer (by
+            # address -- a delivered tensor somebody modified in place fails the identity / version test above and is still a view of it)
+            lo = a.flat.data_ptr()
+            hi = lo + 4 * a.flat.numel()
+            for prm in self._grad_params():
+                g = prm.grad
+                if g is not None and lo <= g.data_ptr() < hi:
+                    prm.grad = g.clone()
         if state != "continue":
             a.flat.zero_()
             a.used_env = False
@@ -567,7 +695,7 @@ class TrainPass:
             c.env_keep_sat = False
         a.used_env = bool(c.env_was_used())
         if c.env_table_backward_queued():
-            self._early_env = ("core", a.d_bg)
+            self._early_env = (c, a.d_bg)
         grads = self._finish_grads(a, (None if a.l1_dev is None else a.l1_dev), keep_sat=True)
         if state == "detach":
             for prm, g in grads:
@@ -592,6 +720,11 @@ class TrainPass:
         buffer for everything else, the env-map table backward (joined if it was queued on its side stream)"""
         nerf = self.nerf
         rf, model, bgm = nerf.rf, nerf.model, nerf.bg_module
+        early_env = self._early_env
+        self._early_env = None
+        if early_env is not None and early_env[0] != "done":       # queued by a StepCore on its side stream: its main stream waits for it,
+            early_env[0].join_early_env()
+        self.join_contexts()                                        # ... and this stream for every chunk context's main stream
         p = rf._tables()[0]
         l1 = None
         if l1_scale is not None:          # the L1 term's gradient rides in the unpack launch (one launch less on the step's tail)
@@ -610,10 +743,8 @@ class TrainPass:
         if a.used_env:
             act, sat, pole = bgm._tables()
             sc = bgm._dev_scalars()
-            if self._early_env is not None:
-                _fork, d_bg = self._early_env
-                self._core.join_early_env()
-                self._early_env = None
+            if early_env is not None:
+                d_bg = early_env[1]
             else:
                 d_bg = a.d_bg = hip.sat_build_bwd(a.d_sat.clone() if keep_sat else a.d_sat, bgm.bg_mat.detach(), act, a.d_pole, sc=sc,
                                                   out=a.d_bg)

@@ -699,10 +699,10 @@ def select_bounces(weights, u, mode, mul, add=0.0, sum_w=1.0):
 _select_ws = {}
 
 
-def select_total_workspace(dev):
+def select_total_workspace(dev, stream=None):
     """the partial-sum / ticket workspace of nmf_select_total: one per (device, stream) -- launches on different streams (the
-    chunks of a frame rendered by two host threads, nmf_amd/renderer.py) must not share it"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    chunk contexts of an optimizer step, nmf_amd/fast_step.py) must not share it"""
+    key = (dev, (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream)
     ws = _select_ws.get(key)
     if ws is None:
         ws = _select_ws[key] = torch.zeros(258, dtype=torch.float64, device=dev)       # zeroed once; the kernel resets it

@@ -11,6 +11,8 @@ from .tonemap import SRGBTonemap
 
 
 class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
+    _warned_fallback = False            # the one-time warning of a training forward that left the fused pass (process-wide)
+
     def __init__(self, rf, model, aabb, near_far, sampler, tonemap=None, bg_module=None, normal_module=None,
                  alphaMask=None, infinity_border=False, recur_stepmul=1, recur_alpha_thres=1e-3, detach_inter=False,
                  hdr=False, bg_noise=0, bg_noise_decay=0.999, use_predicted_normals=True, orient_world_normals=False,
@@ -46,6 +48,8 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
         self.regulariser_stats = False
         self.fused_eval_pass = True                 # renderer.render_images: evaluation chunks as one C++ call each
         self._fused_pass = None
+        self.operator_graph_forwards = 0        # training forwards (recur 0, CUDA, grad mode) that built the operator graph
+        self.regulariser_weights = None         # optional {stat name: weight} of the caller's loss: a fused forward refuses a non-zero one
 
     def get_device(self):
         return self.rf.units.device
@@ -122,12 +126,23 @@ class TensorNeRF(FastPrivateAttrs, torch.nn.Module):
                 override_alpha_thres=None, is_train=False, ndc_ray=False, N_samples=-1, tonemap=True, draw_debug=True,
                 max_weight_N=-1, noise=None):
         if (recur == 0 and is_train and self.fused_training_pass and not self.regulariser_stats and rays.is_cuda
-                and torch.is_grad_enabled() and start_mipval is None and stepmul == 1 and override_near is None and output_alpha is None
+                and torch.is_grad_enabled() and start_mipval is None and stepmul == 1 and override_near is None
                 and dynamic_batch_size and gt_normals is None and override_alpha_thres is None and not ndc_ray and N_samples == -1
                 and tonemap and max_weight_N == -1 and bg_col is not None):
+            # (`output_alpha` -- train.py:525-534 passes it for every RGBA dataset -- is ignored by the reference module, and here)
             out = self._forward_fused(rays, focal, bg_col, noise)
             if out is not None:
                 return out
+        if recur == 0 and is_train and rays.is_cuda and torch.is_grad_enabled():
+            # A training forward that leaves the fused pass builds the operator graph of nmf_amd/functional.py (~3.5 x the cost):
+            # counted, and said once, so that a caller knows (bench.py asserts 0 in its fused legs)
+            self.operator_graph_forwards += 1
+            if self.fused_training_pass and not self.regulariser_stats and not TensorNeRF._warned_fallback:
+                TensorNeRF._warned_fallback = True
+                import warnings
+                warnings.warn("TensorNeRF.forward(is_train=True) left the fused training pass for the operator graph (a call outside "
+                              "the pass: non-default arguments, no host extension, a chunk without bounce rows, or a second pending "
+                              "forward); `nerf.operator_graph_forwards` counts these calls", RuntimeWarning, stacklevel=3)
         if recur == 0:          # one gradient pass: primary and re-traced rays share the table-gradient nodes
             passes = [m for m in (self.rf, self.bg_module, getattr(self.model, "brdf", None),
                                   getattr(self.model, "diffuse_module", None)) if hasattr(m, "begin_pass")]
@@ -317,6 +332,11 @@ class LazyStats(dict):
         elif key == "distortion_loss":
             v = torch.zeros((), device=dev)
         elif shaded is None:        # the fused training pass (TensorNeRF.regulariser_stats): the three zero-weight regularisers
+            # (a loop that gives one of them a non-zero weight says so: nerf.regulariser_weights = dict(envmap_reg=..., ...) makes the
+            #  read fail instead of training without the term)
+            if (getattr(nerf, "regulariser_weights", None) or {}).get(key):
+                raise RuntimeError(f"stats['{key}'] has a non-zero weight but the fused training pass does not evaluate it: set "
+                                   "nerf.regulariser_stats = True (operator graph)")
             v = torch.zeros((), device=dev)
         elif key == "envmap_reg":
             v = (nerf.bg_module.mean_color().mean() - 0.05).clip(min=0)

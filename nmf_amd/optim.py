@@ -36,7 +36,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise hip.NmfHipError("FusedAdam.step does not take a closure")
         if not self._step_planned():
             self._step_checked()
-        for cb in AFTER_STEP:           # e.g. a fused training pass queues the next step's derived tables on its side stream
+        for cb in list(AFTER_STEP):     # (a copy: a callback of a dead pass removes itself)  e.g. a fused training pass queues the next step's derived tables on its side stream
             cb()
 
     def step_unhooked(self):

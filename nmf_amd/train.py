@@ -200,6 +200,12 @@ def main(argv=None):
         xyz[:, 3] *= 0
         feat = nerf.rf.compute_appfeature(xyz)
         nerf.model.calibrate(None, xyz, feat, nerf.bg_module.mean_color().mean())
+    if world > 1:
+        # the calibrated biases come from random points (models/microfacet.py:79-96) -- rank 0's replica, biases
+        # included, is what every rank trains (the seeds above make them equal already on equal devices; this makes them equal)
+        from .trainer import broadcast_replica, check_replicas
+        broadcast_replica(nerf, src=0)
+        check_replicas(nerf, what="after the start-up broadcast")
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
     noise = DeviceNoise(dev, seed=1000 + rank)
     g = torch.Generator(device=dev).manual_seed(seed)        # same permutation on every rank

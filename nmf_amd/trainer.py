@@ -458,14 +458,118 @@ def agree(value, op="min", group=None, device=None):
     return int(round(v)) if isinstance(value, int) else v
 
 
+# ---- data parallel: identical replicas at start-up, and a check that they stay identical -------------------------------------------
+_CALIBRATED = (("model.brdf", "bias"), ("model.diffuse_module", "diffuse_bias"), ("model.diffuse_module", "roughness_bias"))
+
+
+def _attr_path(obj, path):
+    for k in path.split("."):
+        obj = getattr(obj, k)
+    return obj
+
+
+def _replica_group(group):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def broadcast_replica(nerf, src=0, group=None):
+    """after construction and calibration every rank takes rank `src`'s replica -- every parameter and buffer of the
+    module (field tables, BRDF MLP, heads, env map, the Sobol table `angs`, the alpha volume) and the three CALIBRATED biases, which
+    are Python floats computed from random points (models/microfacet.py:79-96, train.py:429-437) and therefore the one piece of
+    state that "same seed on every rank" does not pin across devices.  A buffer whose shape differs on a rank (an alpha volume
+    rebuilt at another size) is an error, not something to paper over.  -> number of bytes broadcast (0 without a process group)."""
+    if not _replica_group(group):
+        return 0
+    import zlib
+    dev = nerf.get_device()
+    n = 0
+    with torch.no_grad():
+        names = sorted(nerf.state_dict().keys())        # the same tensors on every rank, or the broadcasts below would not pair up
+        sig = torch.tensor([len(names), zlib.crc32("\n".join(names).encode())], dtype=torch.int64, device=dev)
+        ref = torch.cat([sig, -sig])                    # (max, -min) in ONE collective: EVERY rank learns of a mismatch and raises
+        dist.all_reduce(ref, op=dist.ReduceOp.MAX, group=group)
+        if ref[:2].tolist() != (-ref[2:]).tolist():
+            raise RuntimeError(f"broadcast_replica: the ranks' modules do not hold the same set of state tensors ({len(names)} here; "
+                               "an alpha mask built on one rank only?)")
+        for name, t in sorted(nerf.state_dict().items()):
+            shape = torch.tensor(list(t.shape) + [-1] * (8 - t.dim()), dtype=torch.int64, device=dev)
+            ref = shape.clone()
+            dist.broadcast(ref, src=src, group=group)
+            if not torch.equal(ref.cpu(), shape.cpu()):
+                raise RuntimeError(f"broadcast_replica: {name} has shape {tuple(t.shape)} here and {ref.tolist()} on rank {src}")
+            if t.numel() == 0:
+                continue
+            buf = t.detach().clone().contiguous()
+            dist.broadcast(buf, src=src, group=group)
+            if dist.get_rank(group) != src:
+                t.detach().copy_(buf)          # (copy_ moves the version counter: caches keyed on it -- packed alpha bits, derived tables -- rebuild)
+            n += t.numel() * t.element_size()
+        bias = torch.tensor([float(getattr(_attr_path(nerf, m), k)) for m, k in _CALIBRATED], dtype=torch.float64, device=dev)
+        dist.broadcast(bias, src=src, group=group)
+        for (m, k), v in zip(_CALIBRATED, bias.tolist()):
+            setattr(_attr_path(nerf, m), k, v)
+    if hasattr(nerf.sampler, "update"):          # derived sampler state (bit-packed alpha mask, step size) follows the broadcast volume
+        nerf.sampler.update(nerf.rf, init=True)
+    return n + 24
+
+
+def replica_checksum(nerf):
+    """-> float64 device tensor [2]: (sum of the fp64 sums of every parameter, buffer and calibrated bias; the same with position-dependent weights, so that two
+    replicas whose differences cancel in the plain sum still differ).  Deterministic on equal bits: equal replicas give equal
+    numbers, and the replicas of a data-parallel run ARE equal bit for bit (the same summed gradient into the same Adam)."""
+    dev = nerf.get_device()
+    parts = []
+    with torch.no_grad():
+        for i, (name, t) in enumerate(sorted(nerf.state_dict().items())):
+            if t.numel() == 0 or not (t.is_floating_point() or t.dtype in (torch.int32, torch.int64, torch.uint8, torch.bool)):
+                continue
+            s = t.detach().to(torch.float64).sum()
+            parts.append(torch.stack([s, s * (1.0 + 0.001 * (i + 1))]))
+        b = torch.tensor([float(getattr(_attr_path(nerf, m), k)) for m, k in _CALIBRATED], dtype=torch.float64, device=dev)
+        parts.append(torch.stack([b.sum(), (b * torch.tensor([3.0, 5.0, 7.0], dtype=torch.float64, device=dev)).sum()]))
+    return torch.stack(parts).sum(0)
+
+
+class ReplicaDivergence(RuntimeError):
+    pass
+
+
+def check_replicas(nerf, group=None, what=""):
+    """all-reduce (min, max) of replica_checksum: any difference between the ranks' replicas raises ReplicaDivergence on EVERY rank
+    (one collective of four doubles + one host read-back: run every K steps, Trainer(check_every=K)).  -> the checksum pair."""
+    cs = replica_checksum(nerf)
+    if not _replica_group(group):
+        return cs.tolist()
+    v = torch.cat([cs, -cs])                   # max of (x, -x) = (max, -min): ONE collective
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = v[:2].tolist(), (-v[2:]).tolist()
+    if hi != lo:
+        raise ReplicaDivergence(f"data-parallel replicas differ{' ' + what if what else ''}: checksum min {lo} max {hi} "
+                                f"(this rank {cs.tolist()}); parameters, buffers or calibrated biases are no longer identical")
+    return hi
+
+
 class Trainer:
-    def __init__(self, nerf, params, world_size=1, rank=0, tape_free=True):
+    def __init__(self, nerf, params, world_size=1, rank=0, tape_free=True, check_every=None):
         self.nerf = nerf
         self.p = params
         self.world_size, self.rank = world_size, rank
+        # The loss of microfacet_tensorf2.yaml:196-232: photometric + density_L1 + orientation + accumulated opacity.  The terms that
+        # file gives weight 0 are not assembled here -- a run that switches one on must not train silently without it.
+        on = [k for k in ("TV_weight_density", "TV_weight_app", "TV_weight_bg", "envmap_lambda", "diffuse_lambda", "brdf_lambda",
+                          "normal_err_lambda", "distortion_lambda", "visibility_lambda", "ortho_weight") if params.get(k)]
+        if on or params.get("charbonier_loss"):
+            raise NotImplementedError(f"Trainer.step does not assemble the loss terms {on or ['charbonier_loss']} (weight 0 in "
+                                      "microfacet_tensorf2.yaml); the reference-style loop over TensorNeRF.forward with "
+                                      "nerf.regulariser_stats = True evaluates envmap_reg / brdf_reg / diffuse_reg")
         self.batch = RayBatchController(params)          # train.py:504-507,618-626 (num_rays / lbatch_size)
         self.iteration = 0
         self.reduce = None
+        # data parallel: every `check_every` steps (and before the first one) the replicas' checksums are compared over the ranks and a
+        # mismatch raises ReplicaDivergence everywhere.  Default 500 (NMF_REPLICA_CHECK_EVERY; 0: never): 30 000 iterations = 60
+        # checks of ~35 small launches + one read-back each.
+        self.check_every = int(os.environ.get("NMF_REPLICA_CHECK_EVERY", "500")) if check_every is None else int(check_every)
+        self.replica_checks = 0
         # train.py:470-481,748-749: exponential decay of the two regulariser weights towards their final values
         self.ori_lambda, self.pred_lambda = float(params["ori_lambda"]), float(params["pred_lambda"])
         n_it = params["n_iters"]
@@ -528,6 +632,9 @@ class Trainer:
         Returns a stats dict (python scalars)."""
         p = self.p
         nerf = self.nerf
+        if self.world_size > 1 and self.check_every > 0 and self.iteration % self.check_every == 0 and _replica_group(None):
+            check_replicas(nerf, what=f"before iteration {self.iteration}")
+            self.replica_checks += 1
         self.optimizer.zero_grad(set_to_none=True)
         n_total = rays.shape[0] if rays is not None else self.lbatch_size()
         lbatch = global_rays if global_rays is not None else n_total * self.world_size
@@ -546,8 +653,14 @@ class Trainer:
             if comm is None:
                 comm = fast._side["comm"] = torch.cuda.Stream()
             dev_ = rays.device
-            def start_early():
-                pairs = fast.early_pairs(dev_)          # (opens zeroed accumulators on a rank whose chunks never reached the backward)
+            def start_early(behind_chunks=False):
+                # What the collective reads must be complete and ordered in front of it: the zero fill of accumulators opened here (a rank
+                # whose chunks never reached the backward) and the env-map table gradient when the last chunk's backward did not queue
+                # it (that chunk kept no sample / left the fused pass / NMF_OVERLAP=0) while earlier chunks looked the map up -- both are
+                # queued on the current stream by prepare_early, and the communication stream then waits for it.
+                if fast.prepare_early(dev_, behind_chunks) or behind_chunks:
+                    comm.wait_stream(torch.cuda.current_stream())
+                pairs = fast.early_pairs(dev_)
                 self.reduce.early_inplace(fast.comm_regions()[0], pairs, comm)
             early = (start_early, comm.cuda_stream)
         while pos < n_total:
@@ -567,7 +680,8 @@ class Trainer:
                 try:
                     out = fast.chunk(r, gt, focal, noise, 1.0 / lbatch,
                                      (1.0, p["L1_weight_initial"], self.ori_lambda, 2.0 * self.pred_lambda),
-                                     want_total=trace is not None, last=pos >= n_total, early=early)
+                                     want_total=trace is not None, last=pos >= n_total, early=early,
+                                     ctx=(n_chunks - 1) % fast.n_contexts)      # chunk k + 1's forward next to chunk k's backward
                 except Unsupported:
                     out = None                      # this chunk goes through the autograd path below
                 if out is not None:
@@ -619,8 +733,7 @@ class Trainer:
                 nerf.model.update_n_samples(n_samples[1:])
         if early is not None:
             if self.reduce._early is None:        # the last chunk did not run the fused backward: the early bucket behind the chunks
-                comm.wait_stream(torch.cuda.current_stream())
-                early[0]()
+                early[0](True)
             self.reduce.finish_early()            # the sums are in the accumulator tensors before end_step turns them into .grad
         if fast is not None:
             fast.end_step()

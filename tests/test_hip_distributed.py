@@ -228,3 +228,85 @@ def test_bucketed_all_reduce_is_bit_identical_to_the_flat_one():
         assert flat["grads"][1] is None and flat["grads"][7] is not None
     for a, b in zip(res[0]["bucketed"]["grads"], res[1]["bucketed"]["grads"]):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
+def _miss_rays(n, dev):
+    o = torch.tensor([[4.0, 4.0, 4.0]]).expand(n, 3)
+    d = torch.nn.functional.normalize(torch.tensor([[1.0, 0.2, 0.1]]), dim=-1).expand(n, 3)      # pointing away from the box
+    return torch.cat([o, d], -1).to(dev).contiguous()
+
+
+def _empty_last_worker(rank, world, port, out, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", NMF_OVERLAP=overlap)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer, check_replicas
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    nerf, params = _build(dev)
+    tr = Trainer(nerf, params, world_size=world, rank=rank, check_every=1)
+    rays, gt, focal = _data(dev)
+    half = CHUNK // 2
+    mine = rays[rank * CHUNK:(rank + 1) * CHUNK].clone()
+    if rank == 1:
+        mine[half:] = _miss_rays(CHUNK - half, dev)        # this rank's LAST chunk keeps no sample; its first one looks the env map up
+    res = {}
+    noise = _PerChunkNoise([DeviceNoise(dev, seed=300 + 2 * rank), DeviceNoise(dev, seed=301 + 2 * rank)])
+    st = tr.step(mine, gt[rank * CHUNK:(rank + 1) * CHUNK], focal, noise=noise, update_controllers=False, fixed_chunk=half,
+                 global_rays=2 * CHUNK)
+    res["chunks"] = st["chunks"]
+    res["bg"] = nerf.bg_module.bg_mat.grad.detach().float().reshape(-1).cpu()
+    res["mlp"] = nerf.model.brdf.mlp[0].weight.grad.detach().float().reshape(-1).cpu()
+    res["grad"] = _flat_grad(tr).cpu()
+    for it in range(2):                                     # the replicas stay identical (check_every=1 compares them before each step)
+        tr.step(mine, gt[rank * CHUNK:(rank + 1) * CHUNK], focal, noise=noise, update_controllers=False, fixed_chunk=half,
+                global_rays=2 * CHUNK)
+    check_replicas(nerf, what="after the steps with an empty last chunk")
+    res["checks"] = tr.replica_checks
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_env_gradient_is_reduced_when_the_last_chunk_of_a_rank_is_empty(overlap, monkeypatch):
+    """the env-map table gradient is produced by the LAST chunk's backward; a rank whose last chunk kept no
+    sample (or NMF_OVERLAP=0) used to enter the early in-place all-reduce with a zero d_bg and write its LOCAL gradient over the sum
+    afterwards -- bg_mat.grad then differed between the ranks and the env maps drifted apart silently.  Two ranks x two chunks, rank
+    1's last chunk empty: both ranks hold the same bg_mat gradient, it is the one-process sum over the three non-empty chunks,
+    and the replicas' checksums agree step after step."""
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_empty_last_worker, args=(r, 2, port, out, overlap)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        res = dict(out)
+    a, b = res[0], res[1]
+    assert a["chunks"] == b["chunks"] == 2 and a["checks"] == b["checks"] == 3
+    assert float(a["bg"].abs().max()) > 0
+    assert torch.equal(a["bg"], b["bg"]) and torch.equal(a["mlp"], b["mlp"]) and torch.equal(a["grad"], b["grad"])
+    # ---- one process: the same four chunks in one step (chunk k of rank r with that chunk's noise source)
+    monkeypatch.setenv("NMF_OVERLAP", overlap)
+    dev = torch.device("cuda", 0)
+    nerf, params = _build(dev)
+    tr = Trainer(nerf, params)
+    rays, gt, focal = _data(dev)
+    half = CHUNK // 2
+    allr = rays.clone()
+    allr[CHUNK + half:] = _miss_rays(CHUNK - half, dev)
+    noise = _PerChunkNoise([DeviceNoise(dev, seed=300 + k) for k in range(4)])
+    tr.step(allr, gt, focal, noise=noise, update_controllers=False, fixed_chunk=half)
+    one_bg = nerf.bg_module.bg_mat.grad.detach().float().reshape(-1).cpu()
+    one = _flat_grad(tr).cpu()
+    err = float((one_bg - a["bg"]).abs().max())
+    assert err <= 2e-5 * float(one_bg.abs().max()) + 1e-9, (err, float(one_bg.abs().max()))
+    rel = float((one - a["grad"]).norm() / one.norm())
+    assert rel < 1e-5, rel

@@ -30,7 +30,7 @@ def _timed_step(nerf, g, pins, n_rays=None, core_switches=()):
     if nerf.rf.table_dtype == "f32":
         assert tr.fast.core() is not None, "the C++ pass (lib/_nmf_host.so StepCore) is what bench.py times: it must be the one tested"
     for k in core_switches:                                         # a switch of the C++ pass that is off by default (value_hist)
-        setattr(tr.fast.core(), k, True)
+        tr.fast.set_switch(k, True)
     tr.optimizer.step = lambda: None                               # keep the gradients, leave the parameters alone
     tr.optimizer.step_unhooked = lambda: None
     calls = []

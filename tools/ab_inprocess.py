@@ -74,7 +74,7 @@ def main():
             setattr(tr.fast, var[4:], bool(int(v)))
         elif var.startswith("core:"):
             torch.cuda.synchronize()
-            setattr(tr.fast.core(), var[5:], bool(int(v)))
+            tr.fast.set_switch(var[5:], bool(int(v)))
         elif var.startswith("attr:"):
             setattr(fast_step, var[5:], int(v))
         elif var.startswith("hip:"):
