@@ -371,7 +371,8 @@ def compact_line(out, detail_path=DETAIL_FILE):
                 one[k] = "error"
             elif k == "schedule_weighted":
                 one[k + "_rays_per_s"] = v.get("rays_per_s")
-            elif "ms_per_step" in v and k not in ("rays_32768_per_gpu", "rays_32768_per_gpu_budgets_x4", "inference", "grid_300"):
+            elif "ms_per_step" in v and k not in ("rays_32768_per_gpu", "rays_32768_per_gpu_sequential", "rays_32768_per_gpu_budgets_x4",
+                                                   "inference", "grid_300"):
                 one[k + "_ms"] = v["ms_per_step"]
             else:
                 one[k + "_rays_per_s"] = v.get("rays_per_s")
@@ -684,6 +685,7 @@ def host_path_legs(device, params):
     def reference_loop_ms(steps, warmup, fused):
         from nmf_amd.optim import FusedAdam
         nerf.fused_training_pass = fused
+        graph0 = nerf.operator_graph_forwards
         opt = FusedAdam(nerf.get_optparam_groups(), betas=tuple(params["betas"]), eps=params["eps"], weight_decay=params["weight_decay"])
         batches, f = make_batches(nerf, steps + warmup, CHUNK, 0, device, distinct=12)
         nz = DeviceNoise(device, seed=5)
@@ -698,7 +700,11 @@ def host_path_legs(device, params):
         sync()
         dt = time.perf_counter() - t0
         nerf.fused_training_pass = True
-        return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=n_samples, steps=steps, rays_per_step=CHUNK)
+        left = nerf.operator_graph_forwards - graph0
+        if fused and left:                 # (a fused leg that silently times the operator graph is not that leg)
+            raise SystemExit(f"reference_loop: {left} of {steps + warmup} training forwards left the fused pass for the operator graph")
+        return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=n_samples, steps=steps, rays_per_step=CHUNK,
+                    operator_graph_forwards=left)
 
     out["reference_loop"] = reference_loop_ms(60, 20, True)
     out["reference_loop"]["note"] = ("the loop of the reference's train.py:497-747 (bench.reference_style_step: TensorNeRF.forward, loss in torch "
@@ -709,7 +715,10 @@ def host_path_legs(device, params):
     # what `extras.module_path` has meant since round 3
     tr_ = Trainer(nerf, params, tape_free=False)
     batches_, f_ = make_batches(nerf, 80, CHUNK, 0, device, distinct=12)
+    graph0_ = nerf.operator_graph_forwards
     dt_, rays_, last_, _ = time_train(tr_, batches_, f_, DeviceNoise(device, seed=5), 20, 60, CHUNK, sync)
+    if nerf.operator_graph_forwards != graph0_:
+        raise SystemExit(f"module_path: {nerf.operator_graph_forwards - graph0_} training forwards left the fused pass for the operator graph")
     out["module_path"] = dict(ms_per_step=1e3 * dt_ / 60, rays_per_s=rays_ / dt_, samples_per_chunk=last_["n_samples"], steps=60,
                               rays_per_step=CHUNK,
                               note="Trainer(tape_free=False): TensorNeRF.forward + backward() through torch.autograd + FusedAdam -- the drop-in "
@@ -731,8 +740,10 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     def sync():
         torch.cuda.synchronize()
 
-    def train_ms(nerf, rays_per_gpu, steps, warmup, chunk=CHUNK):
+    def train_ms(nerf, rays_per_gpu, steps, warmup, chunk=CHUNK, contexts=None):
         tr = Trainer(nerf, params)
+        if contexts is not None and tr.fast is not None:
+            tr.fast.n_contexts = contexts
         batches, f = make_batches(nerf, steps + warmup, rays_per_gpu, 0, device, distinct=12)
         dt, rays_done, last, _ = time_train(tr, batches, f, DeviceNoise(device, seed=5), warmup, steps, chunk, sync)
         return dict(ms_per_step=1e3 * dt / steps, rays_per_s=rays_done / dt, samples_per_chunk=last["n_samples"],
@@ -768,7 +779,11 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
     out["early_phase"]["note"] = "max_retrace_rays = 1000 (first 19 chunks after every (re)start, SURVEY F9)"
     nerf.model.max_retrace_rays = [nerf.model.max_brdf_rays[0]]
     out["rays_32768_per_gpu"] = train_ms(nerf, 32768, 8, 4)
-    out["rays_32768_per_gpu"]["note"] = "BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays, one optimizer step"
+    out["rays_32768_per_gpu"]["note"] = ("BASELINE configs[3] per-GPU workload: 8 chunks of 4096 rays under the reference's per-chunk budgets, "
+                                         "one optimizer step; the chunks alternate between two chunk contexts (nmf_amd/fast_step.py: the "
+                                         "forward of chunk k + 1 next to the backward of chunk k)")
+    out["rays_32768_per_gpu_sequential"] = train_ms(nerf, 32768, 8, 4, contexts=1)
+    out["rays_32768_per_gpu_sequential"]["note"] = "the same step with ONE chunk context: the chunks strictly one after another (round 5)"
     # the same step with the per-chunk budgets of the reference's config (sampler.max_samples 200 000, model.max_brdf_rays
     # [650 000, 450 000]: sized for a 24 GB card) scaled by 4: two chunks of 16 384 rays, 2.3 GiB peak -- per-ray statistics
     # unchanged (the bounce budget grows with the chunk's weight total), the ~115 dependent launches of a chunk paid twice
@@ -839,6 +854,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", default=None, help="W,K: W warm-up + K timed CPU steps per phase, no time budget")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--contexts", type=int, default=None, help="chunk contexts of a multi-chunk step (default: NMF_CHUNK_CONTEXTS or 2; 1 = sequential)")
     ap.add_argument("--detail-dir", default=None, help=f"where {DETAIL_FILE} (the full result: per-kernel table, notes, every leg) is written; default: next to bench.py")
     ap.add_argument("--leg", default=None, help="internal: `host_paths` = the host-bound legs of `extras` in this (fresh) process, one JSON line")
     ap.add_argument("--core", action="append", default=[], metavar="ATTR=0|1",
@@ -951,6 +967,8 @@ def main():
         return
 
     trainer = Trainer(nerf, params, world_size=world, rank=rank)
+    if args.contexts is not None and trainer.fast is not None:
+        trainer.fast.n_contexts = max(1, args.contexts)
     for kv in args.core:
         k, v = kv.split("=")
         trainer.fast.set_switch(k, bool(int(v)))
@@ -1086,6 +1104,8 @@ def main():
                                    "the steady state and is skipped" if args.retrace is None else f"{args.retrace} secondary rays re-traced")
                                   + "; lego / ship are not available offline: scene S1 of SURVEY 8(d)",
                        "rays_per_gpu": args.rays_per_gpu, "chunks_per_step": chunks_per_step, "grid": args.grid,
+                       "chunks_in_flight": min(chunks_per_step, trainer.fast.n_contexts) if trainer.fast is not None else 1,
+                       "operator_graph_fallbacks": int(nerf.operator_graph_forwards),
                        "samples_per_chunk": last["n_samples"], "samples_per_chunk_first_step": last["first_n_samples"],
                        "table_rebuilds_in_timed_region": dict(timer.rebuilds),
                        "parallelism": f"dp{world}", "ranks_seen": ranks_seen,

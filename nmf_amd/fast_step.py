@@ -454,10 +454,11 @@ class TrainPass:
 
     # ---- evaluation: forward only ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def render_chunk(self, rays, focal, noise):
+    def render_chunk(self, rays, focal, noise, want_maps=False):
         """`TensorNeRF.forward(rays, focal, bg_col=white, is_train=False, draw_debug=False)` as one C++ call:
-        -> (rgb_map [b,3], acc_map [b], b = rays the sampler kept, n_samples).  Raises Unsupported (configuration, no sample, no
-        bounce row): the caller renders that chunk through the module."""
+        -> (rgb_map [b,3], acc_map [b], b = rays the sampler kept, n_samples) + (depth [b], world_normal [b,3]) with want_maps (the two
+        maps of the reference's evaluation branch that need no dense appearance pass, modules/tensor_nerf.py:480-501).  Raises
+        Unsupported (configuration, no sample, no bounce row): the caller renders that chunk through the module."""
         nerf = self.nerf
         if not self.supported():
             raise Unsupported("configuration")
@@ -468,14 +469,14 @@ class TrainPass:
             core = self.core()
             self._core_sync(rays.device, focal, False)
             try:
-                out = core.render(rays, float(focal), noise)
+                out = core.render(rays, float(focal), noise, bool(want_maps))
             except RuntimeError as e:
                 if "Unsupported" in str(e):
                     raise Unsupported(str(e)) from None
                 raise
             if out is None:
                 raise Unsupported("no sample")
-            return out[0], out[1], out[2], list(out[3])
+            return (out[0], out[1], out[2], list(out[3])) + ((out[4], out[5]) if want_maps else ())
         finally:
             for m in mods:
                 m.end_pass()

@@ -62,7 +62,8 @@ def render_images(nerf, rays, focal, chunk=None, noise=None, keys=("rgb_map",), 
     kw.setdefault("draw_debug", False)
     module_kw = dict(bg_col=torch.ones(3, device=rays.device), is_train=False, ndc_ray=False, noise=noise, **kw)
     tensorf = nerf
-    fast = _eval_pass(nerf) if (rays.is_cuda and not kw["draw_debug"] and set(keys) <= {"rgb_map", "acc_map"}
+    maps = bool(set(keys) & {"depth", "world_normal"})
+    fast = _eval_pass(nerf) if (rays.is_cuda and not kw["draw_debug"] and set(keys) <= {"rgb_map", "acc_map", "depth", "world_normal"}
                                 and len(kw) == 1) else None
     if fast is not None:
         from .fast_step import Unsupported
@@ -75,10 +76,13 @@ def render_images(nerf, rays, focal, chunk=None, noise=None, keys=("rgb_map",), 
                         from .noise import DeviceNoise
                         nerf._noise = DeviceNoise(pending.device, seed=20211200)
                     nz = nerf._noise
-                rgb, acc, kept, n_samples = fast.render_chunk(pending, focal_, nz)
+                out = fast.render_chunk(pending, focal_, nz, want_maps=maps)
             except Unsupported:
-                return nerf(pending, focal_, **module_kw)
-            return dict(rgb_map=rgb, acc_map=acc), dict(rays_kept=kept, n_samples=n_samples)
+                return nerf(pending, focal_, **(dict(module_kw, draw_debug=True) if maps else module_kw))
+            ims_ = dict(rgb_map=out[0], acc_map=out[1])
+            if maps:
+                ims_.update(depth=out[4], world_normal=out[5])
+            return ims_, dict(rays_kept=out[2], n_samples=out[3])
     ims, _ = chunk_renderer(rays, tensorf, focal, keys=keys, chunk=chunk, render2completion=True, **module_kw)
     return ims["rgb_map"] if tuple(keys) == ("rgb_map",) else ims
 

@@ -440,6 +440,55 @@ def case_e2e_variant():
                     roughness_bias=-2.5, eye=(-3.1, 2.2, 2.9))
 
 
+def _full_size_eval_case(name, G=128, BG=512, B=4096, ray_seed=0, noise_seed=2468, max_retrace=650000):
+    """the reference's `is_train=False` forward at full size (modules/tensor_nerf.py:210-674 with the evaluation
+    branches :480-566 -- depth, world_normal, debug maps; renderer.py:56-106 calls it chunk by chunk), steady re-trace state.  Stored:
+    rgb_map, acc_map, depth, world_normal per ray, n_samples, whole_valid, and the run's bookkeeping decisions (bounce counts,
+    occupancy bits of the secondary rays, the re-trace argsort) like the training fixtures; noise replayed BY SEED."""
+    nerf, sd = small_reference(G, BG, max_retrace_rays=(max_retrace,))
+    nerf.sampler.update(nerf.rf, init=False)
+    nerf.sampler.update(nerf.rf, init=True)
+    nerf.model.detach_N = False
+    nerf.eval()
+    rays, focal = synthetic.camera_rays(B, seed=ray_seed)
+    torch.manual_seed(noise_seed)
+    with torch.no_grad(), BookkeepingTap() as tap:
+        ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=False, ndc_ray=False)
+    wv = stats["whole_valid"]
+    out = dict(grid=G, bg_res=BG, n_rays=B, ray_seed=ray_seed, noise_seed=noise_seed, max_retrace=max_retrace,
+               near_far=np.asarray((2.5, 7.0), dtype=np.float64), aabb_half=1.5,
+               roughness_bias=float(nerf.model.diffuse_module.roughness_bias), eye=np.asarray((2.4, -2.8, 1.6)),
+               rgb_map=ims["rgb_map"], acc_map=ims["acc_map"], depth=ims["depth"], world_normal=ims["world_normal"],
+               whole_valid=wv, n_samples=np.asarray(stats["n_samples"]),
+               n_alpha=int(nerf.sampler.alphaMask.alpha_volume.sum()))
+    for k in ("diffuse", "roughness", "albedo"):          # three of the per-ray debug maps of the evaluation branch
+        out["debug/" + k] = ims[k]
+    for lvl, c in enumerate(tap.counts):
+        assert int(c.max()) < 32768
+        out[f"counts{lvl}"] = c.to(torch.int16)
+    assert len(tap.valid) == 2
+    out["valid1"] = np.packbits(tap.valid[1].numpy().reshape(-1))
+    out["valid1_shape"] = np.asarray(tap.valid[1].shape)
+    assert len(tap.orders) == 1
+    order = tap.orders[0]
+    R = order.shape[0]
+    out["n_secondary"] = R
+    assert max_retrace >= R
+    out["retrace_order0"] = order.int()
+    print(name, "n_samples", stats["n_samples"], "R", R, "kept", int(wv.sum()))
+    save(name, out)
+
+
+def case_e2e_full_eval():
+    """4096 rays, 128^3: the chunk `extras.inference` of bench.py renders 157 times per 800 x 800 frame"""
+    _full_size_eval_case("e2e_full_eval")
+
+
+def case_e2e_g300_eval():
+    """300^3, 1024 rays: the level-1 walks / queries of the final grid under a realistic load (e2e_g300_steady has 192 rays)"""
+    _full_size_eval_case("e2e_g300_eval", G=300, B=1024, ray_seed=6, noise_seed=1357)
+
+
 def case_upsample():
     """a25: TensoRF.upsample + update_stepSize + the voxel schedule (fields/tensoRF.py:207-227,
     fields/tensor_base.py:194-243, utils.py:55-58): factors before / after one scheduled upsample."""
@@ -504,7 +553,8 @@ def case_blender_rays():
 
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
-             e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant)
+             e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant,
+             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -305,6 +305,117 @@ def test_step_of_32768_rays_per_gpu_as_eight_chunks():
         assert 2.0 < ratio < 16.0, (k, ratio)
 
 
+@pytest.mark.parametrize("name", ["e2e_full_eval", "e2e_g300_eval"])
+def test_fused_eval_pass_vs_reference_eval_fixture(name):
+    """the FUSED evaluation pass (`TrainPass.render_chunk` = one C++ call per chunk, what bench.py's
+    `extras.inference` times and `render.py` renders frames with) against the reference's own `is_train=False` forward at full size
+    (tests/golden/make_golden.py:_full_size_eval_case: modules/tensor_nerf.py:210-674 with the evaluation branch :480-566, the chunk
+    renderer.py:56-106 submits): 4096 rays at 128^3, and 1024 rays at 300^3 (57 k secondary rays, 0.32 M level-1 samples: the final
+    grid's queries under a realistic load).  Noise by seed, the reference's bookkeeping decisions replayed (and the pass's own
+    decisions compared with them): sample counts bit-exact, accumulated opacity 1e-5, radiance / depth / world normal 1e-4."""
+    from nmf_amd.noise import ReplayNoise
+    from nmf_amd.renderer import _eval_pass, render_images
+    g = Golden(name)
+    nerf = _full_size_model(g)
+    nerf.eval()
+    fp = _eval_pass(nerf)
+    assert fp is not None and fp.core() is not None, "the fused evaluation pass is what the bench times: it must be the one tested"
+    pins = _pin_reference_bookkeeping(g)
+    rays, focal = _fixture_rays(g)
+    torch.manual_seed(g["noise_seed"])
+    rgb, acc, kept, n_samples, depth, wn = fp.render_chunk(rays.to(DEV), focal, ReplayNoise(DEV, None, pins=pins), want_maps=True)
+    assert list(n_samples) == [int(v) for v in g.np("n_samples")]
+    assert kept == g["n_rays"] == int(g["whole_valid"].sum())          # no sample budget at evaluation: every ray kept
+    n_cand = int(np.prod(g.np("valid1_shape")))
+    assert pins.valid_flips <= max(4, n_cand // 10_000_000), pins.valid_flips
+    tr = pins.trace
+    for lvl in (0, 1):
+        own, pinned = tr[f"counts_own{lvl}"].cpu(), pins.counts[lvl]
+        flips = int((own != pinned).sum())
+        assert flips <= max(8, own.shape[0] // 20000) and int((own - pinned).abs().max()) <= 1, (lvl, flips)
+    assert_close(acc.cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
+    assert_close(rgb.cpu(), g["rgb_map"], rtol=1e-4, atol=1e-4, what="rgb_map")
+    assert_close(depth.cpu(), g["depth"], rtol=1e-4, atol=1e-4, what="depth")
+    assert_close(wn.cpu(), g["world_normal"], rtol=1e-4, atol=1e-4, what="world_normal")
+    assert float(g["rgb_map"].std()) > 0.05 and float(g["depth"].max()) > 1.0
+    # ... and the public route: renderer.render_images with the same keys enters the same pass (own noise: statistics only)
+    calls = []
+    orig = fp.render_chunk
+    fp.render_chunk = lambda *a, **k: (calls.append(k.get("want_maps")), orig(*a, **k))[1]
+    try:
+        ims = render_images(nerf, rays.to(DEV), focal, 4096, None, keys=("rgb_map", "acc_map", "depth", "world_normal"))
+    finally:
+        fp.render_chunk = orig
+    assert calls and all(calls)
+    assert ims["depth"].shape == (g["n_rays"],) and ims["world_normal"].shape == (g["n_rays"], 3)
+    assert float((ims["rgb_map"].cpu() - g["rgb_map"]).abs().mean()) < 2e-2          # another noise stream, the same image
+    assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map (own noise)")
+    assert_close(ims["depth"].cpu(), g["depth"], rtol=1e-4, atol=1e-4, what="depth (own noise)")
+
+
+@pytest.mark.parametrize("contexts", [2, 3])
+def test_concurrent_chunk_contexts_equal_the_sequential_step(contexts):
+    """the chunks of one optimizer step alternate between chunk contexts (a StepCore + a set of streams each,
+    nmf_amd/fast_step.py), so that chunk k + 1's forward runs next to chunk k's backward.  24 576 rays = 6 chunks of 4096 at 128^3 under
+    the reference's per-chunk budgets, the same noise source: per chunk the kept rays and sample counts are bit-identical to the
+    sequential step (one context), the loss is, and the accumulated gradients agree to the order of the float atomics.  Then three real
+    optimizer steps each way: the parameters move the same way (a missing stream dependency at the step boundary -- Adam, the table
+    rebuild, the zero fill of the accumulators -- would not survive this)."""
+    import bench
+    from nmf_amd.noise import DeviceNoise
+    from nmf_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    n = 6 * 4096
+    rays, focal = synthetic.camera_rays(n, seed=123)
+    rays = rays.to(dev)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    res = {}
+    for k in (1, contexts):
+        nerf, params = bench.build(dev)
+        tr = Trainer(nerf, params)
+        assert tr.fast is not None and tr.fast.supported()
+        tr.fast.n_contexts = k
+        step, step_u = tr.optimizer.step, tr.optimizer.step_unhooked
+        tr.optimizer.step = lambda: None
+        tr.optimizer.step_unhooked = lambda: None
+        trace = []
+        out = tr.step(rays, gt, focal, noise=DeviceNoise(dev, seed=31), update_controllers=False, fixed_chunk=4096, trace=trace)
+        assert out["chunks"] == 6 and len(tr.fast._ctxs) == k and nerf.operator_graph_forwards == 0
+        if k > 1:
+            assert [cx.main is not None for cx in tr.fast._ctxs] == [False] + [True] * (k - 1)
+            assert len({cx.core.main_stream for cx in tr.fast._ctxs}) == k
+        grads = {name: p.grad.detach().double().clone() for name, p in nerf.named_parameters() if p.grad is not None}
+        res[k] = dict(kept=[r["kept"] for r in trace], n_samples=[list(r["n_samples"]) for r in trace], loss=out["loss"], grads=grads)
+        # ---- three real steps
+        tr.optimizer.step, tr.optimizer.step_unhooked = step, step_u
+        p0 = {name: p.detach().clone() for name, p in nerf.named_parameters()}
+        noise = DeviceNoise(dev, seed=32)
+        for it in range(3):
+            o = tr.step(rays, gt, focal, noise=noise, update_controllers=False, fixed_chunk=4096)
+            assert o["chunks"] == 6 and np.isfinite(o["loss"])
+        res[k]["delta"] = {name: (p.detach() - p0[name]).double() for name, p in nerf.named_parameters()}
+        del tr, nerf
+    a, b = res[1], res[contexts]
+    assert a["kept"] == b["kept"] == [4096] * 6
+    assert a["n_samples"] == b["n_samples"], (a["n_samples"], b["n_samples"])
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
+    assert set(a["grads"]) == set(b["grads"]) and len(a["grads"]) >= 29
+    for name, ga in a["grads"].items():
+        gb = b["grads"][name]
+        # (the order of the float atomics differs between any two runs; the density factors' gradients are sums of large terms of
+        #  both signs -- tools/sat_sensitivity.py -- and move by ~2e-4 of their largest entry, everything else by ~1e-6)
+        scale = float(ga.abs().max())
+        assert float((ga - gb).abs().max()) <= 1e-3 * scale + 1e-12, (name, float((ga - gb).abs().max()), scale)
+        if scale > 0:
+            assert float((ga - gb).norm() / ga.norm()) < 5e-4, (name, float((ga - gb).norm() / ga.norm()))
+    for name, da in a["delta"].items():
+        db = b["delta"][name]
+        if float(da.norm()) > 0:
+            assert float((da - db).norm() / da.norm()) < 0.05, (name, float((da - db).norm() / da.norm()))
+        else:
+            assert float(db.norm()) == 0.0, name
+
+
 def test_scaled_budgets_run_the_same_step_in_one_larger_chunk():
     """The per-chunk budgets are configuration (sampler.max_samples, model.max_brdf_rays: sized for a 24 GB card in the
     reference's yaml).  16 384 rays at BASELINE size once as four chunks under the reference's budgets and once as ONE chunk
