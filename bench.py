@@ -576,10 +576,13 @@ def reference_psnr_seeds():
     return np.stack(rows), [int(v) for v in g["psnr_at"]]
 
 
-def psnr_runs(device, seeds):
+def psnr_runs(device, seeds, traj=None):
     """One 300-iteration training of the S2 configuration per seed, each from a FRESH initialisation (the constructors' random
     initial parameters under torch.manual_seed(seed), calibration as train.py:429-437), device noise, the data set of the fixture
-    -> test PSNR [seed, evaluation] (8-bit formula, renderer.py:399-401), rays per second incl. the evaluations"""
+    -> test PSNR [seed, evaluation] (8-bit formula, renderer.py:399-401), rays per second incl. the evaluations.
+    traj (a list): receives one dict per seed with the run's TRAJECTORY in the layout of tests/golden/make_psnr_traj.py (per chunk: loss
+    back-propagated, num_rays, rays in / kept, n_samples, max_retrace; per iteration: global batch, learning rates, gradient and
+    parameter norms) -- tools/psnr_trajectory.py compares the seed means of the two sides"""
     import numpy as np
     import torch
     from nmf_amd.config import build_model, resolved_config
@@ -616,14 +619,36 @@ def psnr_runs(device, seeds):
         noise = DeviceNoise(device, seed=5000 + seed)
         gen = torch.Generator(device=device).manual_seed(seed)
         perm, cur, row = torch.randperm(n_total, device=device, generator=gen), 0, []
+        T = None
+        if traj is not None:
+            T = dict(chunk_num_rays=[], chunk_rays_in=[], chunk_kept=[], chunk_n_samples=[], chunk_iter=[], chunk_loss=[],
+                     chunk_max_retrace=[], iter_lbatch=[], iter_lr=[], iter_max_retrace=[], iter_num_chunks=[], iter_gradnorm=[],
+                     iter_param_norm=[])
+            names = sorted(n_ for n_, _ in nerf.named_parameters())
+            byname = dict(nerf.named_parameters())
         for it in range(at[-1]):
             nb = tr.lbatch_size()
             if cur + nb > n_total:
                 perm, cur = torch.randperm(n_total, device=device, generator=gen), 0
             ids = perm[cur:cur + nb]
             cur += nb
-            st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
+            rec = [] if T is not None else None
+            if T is not None:
+                T["iter_lr"].append([float(g_["lr"]) for g_ in tr.optimizer.param_groups])
+            st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb, trace=rec)
             rays_seen += st["rays"]
+            if T is not None:
+                for r_ in rec:
+                    if "total" not in r_:               # a chunk without a sample: train.py:567-568 skips it before the backward
+                        continue
+                    ns = list(r_["n_samples"])
+                    T["chunk_num_rays"].append(r_["num_rays"]); T["chunk_rays_in"].append(r_["rays_in"]); T["chunk_kept"].append(r_["kept"])
+                    T["chunk_n_samples"].append(ns + [0] * (2 - len(ns))); T["chunk_iter"].append(it)
+                    T["chunk_loss"].append(float(r_["total"])); T["chunk_max_retrace"].append(int(r_["max_retrace"][0]))
+                T["iter_lbatch"].append(nb); T["iter_num_chunks"].append(len(rec))
+                T["iter_max_retrace"].append(int(nerf.model.max_retrace_rays[0]))
+                T["iter_gradnorm"].append([float(byname[n_].grad.norm()) if byname[n_].grad is not None else float("nan") for n_ in names])
+                T["iter_param_norm"].append([float(byname[n_].detach().double().norm()) for n_ in names])
             if it + 1 in at:
                 nerf.eval()
                 # 800 rays per evaluation chunk, as the reference runs of the fixture (make_train_trace.py test_psnr): the per-CHUNK
@@ -633,6 +658,10 @@ def psnr_runs(device, seeds):
                 pv, gv = pred.reshape(n_views, -1, 3), rgb_te.reshape(n_views, -1, 3)
                 row.append(float(torch.stack([psnr_8bit(pv[i], gv[i]) for i in range(n_views)]).mean()))
         out.append(row)
+        if T is not None:
+            T = {k_: np.asarray(v_) for k_, v_ in T.items()}
+            T.update(test_psnr=np.asarray(row), names=names, seed=seed)
+            traj.append(T)
         del tr, nerf
     torch.cuda.synchronize()
     return np.asarray(out), rays_seen / (time.perf_counter() - t0), (G0, BG, res, mn)
@@ -934,6 +963,10 @@ def main():
         scale_budgets(nerf, args.budget_scale)
     if args.retrace is not None:
         nerf.model.max_retrace_rays = [args.retrace]
+    if world > 1:          # every rank trains rank 0's replica; checked (a mismatch raises on every rank)
+        from nmf_amd.trainer import broadcast_replica, check_replicas
+        broadcast_replica(nerf, src=0)
+        check_replicas(nerf, what="after the start-up broadcast")
     timer = RebuildCounter()
     from nmf_amd import hip as hip_mod
     workload = (f"S1 (solid cube, SURVEY 8d), TensoRF {args.grid}^3 (16+24 comps, {args.table_dtype} tables), env 512x1024, "

@@ -287,6 +287,20 @@ def run(**knobs):
         out["init/" + k] = v
     out["params_params"] = np.asarray([args.model.params[k] for k in ("min_batch_size", "max_batch_size", "starting_batch_size",
                                                                       "target_num_samples")])
+    if K["light"] == "traj":
+        # the run's TRAJECTORY and nothing heavy (make_psnr_traj.py): per chunk the loss / ray controller / re-trace controller /
+        # sample counts, per iteration the global batch and the learning-rate factor, the test PSNR at the evaluations
+        traj = dict(seed=SEED, test_psnr=np.asarray(T["test_psnr"]), psnr_at=np.asarray(PSNR_AT))
+        for k in ("chunk_num_rays", "chunk_rays_in", "chunk_kept", "chunk_n_samples", "chunk_iter", "chunk_loss", "chunk_max_retrace",
+                  "iter_lbatch", "iter_lr", "iter_max_retrace", "iter_num_chunks"):
+            traj[k] = np.asarray(T[k])
+        names = sorted({n for d in T["iter_gradnorm"] for n in d})
+        traj["gradnorm_names"] = "\n".join(names)
+        traj["iter_gradnorm"] = np.asarray([[d.get(n, np.nan) for n in names] for d in T["iter_gradnorm"]], dtype=np.float32)
+        pnames = sorted(T["iter_checksum"][0])
+        traj["param_names"] = "\n".join(pnames)
+        traj["iter_param_norm"] = np.asarray([[d[n][1] for n in pnames] for d in T["iter_checksum"]], dtype=np.float32)
+        return traj
     if K["light"]:
         print("test psnr per image at", PSNR_AT, np.round(np.asarray(T["test_psnr"]), 3).tolist(), flush=True)
         return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
