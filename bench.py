@@ -83,7 +83,7 @@ class RebuildCounter:
 # ---- per-kernel roofline models ------------------------------------------------------------------------------------------
 # Every kernel launch of libnmf_hip.so is timed with HIP events on the stream it is launched on (nmf_set_launch_probe -> the
 # kernel timer of csrc/host_ext.cpp); names are the kernels' own (what rocprofv3 --kernel-trace prints).  A kernel with a
-# model gets frac = USEFUL work / its own duration / peak, with the work stated per unit below and in DESIGN.md section 0.R5, so that
+# model gets frac = USEFUL work / its own duration / peak, with the work stated per unit below and in DESIGN.md section 4, so that
 # every fraction can be recomputed by hand from `sizes_per_step` and profiles/<tag>_steady_state_per_step.csv and is <= 1 by
 # construction (useful <= issued <= peak x time).  The arithmetic of the path is fp32; MI355X's fp32 vector rate and its
 # fp32-input matrix rate are the same 157.3 TFLOP/s (MI355X_MICROARCH.md), so that ONE peak prices VALU, MFMA and mixed
@@ -863,7 +863,7 @@ def extras(device, params, focal, main_ms=None, main_rays=None):
                                   note=("BASELINE configs[1]: factor tables read as bf16 by the forward queries (fp32 master copy "
                                         "for Adam and the backward walks, fp32 arithmetic); both numbers are `python bench.py "
                                         "--table-dtype bf16|f32 --steps 80 --warmup 20` in a fresh process each (the workload of "
-                                        "the headline number); PSNR delta in DESIGN.md"))
+                                        "the headline number); PSNR delta in docs/DESIGN_rounds_1-5.md"))
     return out
 
 
@@ -1103,7 +1103,7 @@ def main():
                 "counters_of_kernel": {k: ck.get("derived", {}).get(k) for k in ("alu_busy", "mfma_busy", "waves_per_simd", "hbm_frac", "l2_frac")} if ck else None,
                 "launches": dom_live[1] if dom_live else None, "avg_launch_us": live_us,
                 "useful_work_per_chunk": work,
-                "work_model": "kernel_models() in bench.py / DESIGN.md section 0.R5: SURVEY 8(d)'s FLOP per unit x the units of `sizes_per_step`",
+                "work_model": "kernel_models() in bench.py / DESIGN.md section 4: SURVEY 8(d)'s FLOP per unit x the units of `sizes_per_step`",
                 "per_kernel": table, "sizes_per_step": sizes,
                 "step": {"wall_us": round(1e3 * ms_step, 1), "main_stream_kernel_us": round(main_stream_us, 1) if main_stream_us else None,
                          # the main stream carries the dependency chain of the step (side streams only ever run next to it): the share

@@ -103,7 +103,7 @@ class TrainPass:
         # The BRDF-MLP backward of a level needs only d_brdf; it runs on a side stream next to the adjoint of that level's
         # bounce rays (level 0: the whole backward of level 1), capped to MLP_SIDE_WGS persistent workgroups so that it
         # leaves registers and LDS on every CU to the main stream -- uncapped it holds both and nothing overlaps.  The
-        # kernels it runs next to are latency- or atomic-bound: 2.19 - 2.25 -> 2.12 - 2.18 ms per step.
+        # kernels it runs next to are latency- or atomic-bound (docs/DESIGN_rounds_1-5.md section 5.1): 2.19 - 2.25 -> 2.12 - 2.18 ms per step.
         # The environment adjoint of a level's own rays (atomic-bound scatter, result first used when the level returns) runs
         # on another side stream next to the rest of that level's backward: 2.12 - 2.18 -> 2.07 - 2.11 ms.
         # Measured and dropped: the appearance walk next to the density walk and the level-1 density walk started early (no

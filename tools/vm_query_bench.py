@@ -1,4 +1,4 @@
-"""Field query variants on ray-ordered samples at 128^3 and 300^3: lane per sample (k_vm_fwd, density + normal), 16 lanes per
+"""Field query variants on ray-ordered samples at 128^3 and 300^3 (docs/DESIGN_rounds_1-5.md section 0.1): lane per sample (k_vm_fwd, density + normal), 16 lanes per
 sample (k_vm_rows_dn, same bits), and the value-only query on the packed tables vs on the density factors themselves.
 
     python tools/vm_query_bench.py
