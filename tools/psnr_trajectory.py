@@ -63,6 +63,7 @@ def load_reference():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=32)
+    ap.add_argument("--window", type=int, default=25)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_trajectory.txt"))
     a = ap.parse_args()
     import torch
@@ -93,12 +94,27 @@ def main():
              "# z = (mean here - mean reference) / standard error of that difference, per iteration; `>3` = iterations with |z| > 3",
              f"{'quantity':44s} {'it':>4s} " + " ".join(f"{'ref@' + str(i):>11s} {'here@' + str(i):>11s}" for i in (10, 50, 100, 150, 200, 299)) + "   max|z| at   >3"]
     at = (10, 50, 100, 150, 200, 299)
+    W = a.window
+    def blocks(x):                       # [runs, 300] -> means over windows of W iterations (per run: the unit of the statistics is the run)
+        n = (x.shape[1] // W) * W
+        return x[:, :n].reshape(x.shape[0], -1, W).mean(-1)
+    block_rows = []
     for k in keys:
         r = np.stack([d[k] for d in R])
         h = np.stack([d[k] for d in H])
         ok = np.isfinite(r).all(0) & np.isfinite(h).all(0)
         se = np.sqrt(r.var(0, ddof=1) / len(R) + h.var(0, ddof=1) / len(H))
-        dz = np.where(ok & (se > 0), (h.mean(0) - r.mean(0)) / np.where(se > 0, se, 1), 0.0)
+        diff = h.mean(0) - r.mean(0)
+        same = np.abs(diff) <= 1e-5 * np.maximum(np.abs(r.mean(0)), 1e-30)          # equal up to float rounding (learning rates, batch sizes)
+        dz = np.where(ok & (se > 0) & ~same, diff / np.where(se > 0, se, 1), 0.0)
+        if np.isfinite(r).all() and np.isfinite(h).all():
+            rb, hb = blocks(r), blocks(h)
+            seb = np.sqrt(rb.var(0, ddof=1) / len(R) + hb.var(0, ddof=1) / len(H))
+            db = hb.mean(0) - rb.mean(0)
+            sameb = np.abs(db) <= 1e-5 * np.maximum(np.abs(rb.mean(0)), 1e-30)
+            zb = np.where((seb > 0) & ~sameb, db / np.where(seb > 0, seb, 1), 0.0)
+            rel = db / np.maximum(np.abs(rb.mean(0)), 1e-30)
+            block_rows.append((k, zb, rel))
         big = np.nonzero(np.abs(dz) > 3)[0]
         rng = ""
         if big.size:
@@ -111,6 +127,15 @@ def main():
         imax = int(np.abs(dz).argmax())
         lines.append(f"{k[:44]:44s} {'':4s} " + " ".join(f"{r.mean(0)[i]:11.5g} {h.mean(0)[i]:11.5g}" for i in at)
                      + f"   {abs(dz[imax]):5.1f} @{imax:<4d} {len(big):3d} {rng}")
+    lines.append("")
+    lines.append(f"# the same as means over windows of {W} iterations (per run first): z per window, and below it the relative difference "
+                 "(here - reference) / |reference| in per cent")
+    lines.append(f"{'quantity':44s} " + " ".join(f"{i * W:>6d}" for i in range(n_it // W)))
+    for k, zb, rel in block_rows:
+        if np.abs(zb).max() == 0:
+            continue
+        lines.append(f"{k[:44]:44s} " + " ".join(f"{v:6.1f}" for v in zb))
+        lines.append(f"{'   rel %':44s} " + " ".join(f"{100 * v:6.2f}" for v in rel))
     text = "\n".join(lines)
     print(text)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
