@@ -135,7 +135,6 @@ def kernel_models(sz, n_params):
         "k_vm_bwd_brick<false, 1>": ("mfma", float(BWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
         "k_vm_fwd<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * M0), FP32_PEAK, F),
         "k_vm_sigma<float>": ("valu", float(FWD_VALUE * M1), FP32_PEAK, F),
-        "k_vm_sigma<float, true>": ("valu", float(FWD_VALUE * M1), FP32_PEAK, F),      # (+ the brick histogram: StepCore.value_hist)
         "k_vm_rows_dn<float>": ("valu", float((FWD_VALUE + FWD_GRAD) * Mb1), FP32_PEAK, F),
         "k_vm_app_rows<float>": ("valu", float(FWD_APP * (Mb0 + Mb1)), FP32_PEAK, F),
         "k_march_count16": ("valu", float(MARCH_LANE_OPS) * R0 * N, LANE_OP_PEAK, "T lane-ops/s"),
@@ -887,7 +886,7 @@ def main():
     ap.add_argument("--detail-dir", default=None, help=f"where {DETAIL_FILE} (the full result: per-kernel table, notes, every leg) is written; default: next to bench.py")
     ap.add_argument("--leg", default=None, help="internal: `host_paths` = the host-bound legs of `extras` in this (fresh) process, one JSON line")
     ap.add_argument("--core", action="append", default=[], metavar="ATTR=0|1",
-                    help="A/B only: a switch of the C++ pass (csrc/step_core.inc: env_split, value_hist, overlap ...) set before the warm-up; "
+                    help="A/B only: a switch of the C++ pass (csrc/step_core.inc: env_split, overlap ...) set before the warm-up; "
                          "named in config.core_switches")
     args = ap.parse_args()
 

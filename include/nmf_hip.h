@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped with every incompatible change of a prototype or of a workspace size.  nmf_version() returns the value the LIBRARY
  * was built with; a separately built caller (nmf_amd/lib/_nmf_host.so) compares it with the value it was compiled against. */
-#define NMF_ABI_VERSION 115
+#define NMF_ABI_VERSION 116
 int nmf_version(void);
 const char* nmf_last_error_string(void);
 
@@ -175,15 +175,6 @@ int nmf_vm_query_fwd_bf16(const nmf_vm_params* p, const float* xyzt, int64_t M, 
  * numbers over.  tables_bf16 != 0: bfloat16 copies of the factors. */
 int nmf_vm_query_sigma(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
                        const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma, void* stream);
-/* nmf_vm_query_sigma that also takes the brick HISTOGRAM of its samples for the backward walk over them (autograd of
- * fields/tensoRF.py:181-190 for the re-traced samples of a training pass): the counters of `clean` (the kept zero scratch of
- * nmf_vm_query_bwd_segments_clean, nmf_vm_bwd_clean_bytes) are incremented and keyrank [M][2] int32 receives (brick x copies + copy,
- * rank inside it) per sample -- what the walk's own histogram launch would compute, at no cost here (the atomic's round trip hides
- * behind the table loads).  The walk MUST follow as nmf_vm_query_bwd_segments_prehist over exactly these samples with the same
- * `clean` before the scratch is used for anything else (it hands the scratch back zero).  Same sigma bits as nmf_vm_query_sigma. */
-int nmf_vm_query_sigma_hist(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
-                            const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma,
-                            void* clean, int64_t clean_bytes, void* keyrank, void* stream);
 /* The density part of the query (value, sigma, gradient, normal; any output may be NULL) for a FEW rows -- the bounce rows
  * of a re-traced level, where the training pass needs normals (fields/tensor_base.py:66-129 on xyz[bounce_mask]) -- with
  * 16 lanes per row (one per plane tap); the sums are combined in nmf_vm_query_fwd's order: identical bits.
@@ -243,16 +234,6 @@ int nmf_vm_query_bwd_segments_clean(const nmf_vm_params* p, const nmf_vm_bwd_seg
                                     const float* basis, float* const g_dpk[3], float* const g_dlk[3],
                                     float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
                                     void* clean, int64_t clean_bytes, void* workspace, int64_t workspace_bytes, void* stream);
-/* ... for ONE sample set whose histogram nmf_vm_query_sigma_hist took in the forward (into `clean`, with `keyrank`): the walk starts
- * at the counter scan.  Grids whose brick count exceeds the one-launch scan (> ~500^3) are refused. */
-int nmf_vm_query_bwd_segments_prehist(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs /*HOST array*/, int32_t n_segs,
-                                      const float* const dpk[3], const float* const dlk[3],
-                                      const float* const app_planes[3], const float* const app_lines[3],
-                                      const float* basis, float* const g_dpk[3], float* const g_dlk[3],
-                                      float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
-                                      void* clean, int64_t clean_bytes, const void* keyrank, void* workspace,
-                                      int64_t workspace_bytes, void* stream);
-
 /* The brick sort of a walk as a PLAN: it depends on the sample positions alone (not on the adjoints), so a training pass
  * builds it when the positions become known -- under its forward, on a side stream -- and the backward only permutes the
  * adjoints (autograd of fields/tensoRF.py:181-205 sees the same sample set twice: forward and backward).

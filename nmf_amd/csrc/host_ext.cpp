@@ -748,9 +748,8 @@ void vm_query_bwd_impl(const char* name, int64_t p_addr, const std::vector<Seg>&
                        const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
                        const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
                        const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis, const OT& plan,
-                       int64_t stream, const OT& clean = c10::nullopt, const OT& keyrank = c10::nullopt) {
-    // clean: the kept zero scratch of nmf_vm_query_bwd_segments_clean (a walk without a plan); keyrank: the walk's histogram was taken
-    // by vm_query_sigma_hist into that scratch (nmf_vm_query_bwd_segments_prehist)
+                       int64_t stream, const OT& clean = c10::nullopt) {
+    // clean: the kept zero scratch of nmf_vm_query_bwd_segments_clean (a walk without a plan)
     TimedScope _ts(name, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     if (segs.size() > NMF_VM_MAX_SEGMENTS) fail("at most " + std::to_string(NMF_VM_MAX_SEGMENTS) + " segments per walk");
@@ -790,13 +789,6 @@ void vm_query_bwd_impl(const char* name, int64_t p_addr, const std::vector<Seg>&
                                        want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, vptr(plan), plan->numel() * 4,
                                        ws.data_ptr(), nbytes, st(stream)),
               "nmf_vm_query_bwd_planned");
-    else if (clean.has_value() && clean->defined() && keyrank.has_value())
-        check(nmf_vm_query_bwd_segments_prehist(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
-                                                want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
-                                                want_d ? ga : nullptr, want_d ? gb : nullptr, want_a ? gc : nullptr, want_a ? gd : nullptr,
-                                                want_a ? static_cast<float*>(vptr(g_basis)) : nullptr, clean->data_ptr(), clean->numel(),
-                                                vptr(keyrank), ws.data_ptr(), nbytes, st(stream)),
-              "nmf_vm_query_bwd_segments_prehist");
     else if (clean.has_value() && clean->defined())
         check(nmf_vm_query_bwd_segments_clean(p, arr, (int32_t)segs.size(), want_d ? a.p : nullptr, want_d ? b.p : nullptr,
                                               want_a ? c.p : nullptr, want_a ? d.p : nullptr, want_a ? of32(basis) : nullptr,
@@ -828,16 +820,6 @@ void vm_query_bwd_clean(int64_t p_addr, const std::vector<Seg>& segs, const std:
     if (clean.scalar_type() != at::kByte || !clean.is_contiguous() || !clean.is_cuda()) fail("vm_query_bwd_clean: scratch must be a device uint8 tensor");
     vm_query_bwd_impl("vm_query_bwd_segments", p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(), stream,
                       OT(clean));
-}
-
-void vm_query_bwd_prehist(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
-                          const std::vector<Tensor>& dlk, const std::vector<Tensor>& apl, const std::vector<Tensor>& ali,
-                          const OT& basis, const std::vector<Tensor>& g_dpk, const std::vector<Tensor>& g_dlk,
-                          const std::vector<Tensor>& g_apl, const std::vector<Tensor>& g_ali, const OT& g_basis,
-                          const Tensor& clean, const Tensor& keyrank, int64_t stream) {
-    if (clean.scalar_type() != at::kByte || !clean.is_contiguous() || !clean.is_cuda()) fail("vm_query_bwd_prehist: scratch must be a device uint8 tensor");
-    vm_query_bwd_impl("vm_query_bwd_segments", p_addr, segs, dpk, dlk, apl, ali, basis, g_dpk, g_dlk, g_apl, g_ali, g_basis, OT(), stream,
-                      OT(clean), OT(keyrank));
 }
 
 void vm_query_bwd_planned(int64_t p_addr, const std::vector<Seg>& segs, const std::vector<Tensor>& dpk,
@@ -903,10 +885,8 @@ std::tuple<Tensor, Tensor, Tensor> vm_query_rows(int64_t p_addr, const Tensor& x
 }
 
 // density value of all samples from the density factors themselves: -> (sigma_feat [M], sigma [M])
-// clean + keyrank given: the brick histogram of the samples is taken on the way (nmf_vm_query_sigma_hist)
 std::tuple<Tensor, Tensor> vm_query_sigma(int64_t p_addr, const Tensor& xyzt, const std::vector<Tensor>& planes,
-                                          const std::vector<Tensor>& lines, int64_t stream, const OT& clean = c10::nullopt,
-                                          const OT& keyrank = c10::nullopt) {
+                                          const std::vector<Tensor>& lines, int64_t stream) {
     TimedScope _ts(__func__, stream);
     const auto* p = reinterpret_cast<const nmf_vm_params*>(p_addr);
     const int64_t M = xyzt.size(0);
@@ -922,14 +902,7 @@ std::tuple<Tensor, Tensor> vm_query_sigma(int64_t p_addr, const Tensor& xyzt, co
         b[i] = vptr(lines[i]);
     }
     Tensor sf = fe(xyzt, {M}), sg = fe(xyzt, {M});
-    if (clean.has_value() && keyrank.has_value()) {
-        if (keyrank->scalar_type() != at::kInt || keyrank->numel() < 2 * M || !keyrank->is_contiguous()) fail("vm_query_sigma: keyrank [M,2] int32");
-        check(nmf_vm_query_sigma_hist(p, f32(xyzt), M, a, b, bf16 ? 1 : 0, out(sf), out(sg), clean->data_ptr(), clean->numel(),
-                                      keyrank->data_ptr(), st(stream)),
-              "nmf_vm_query_sigma_hist");
-    } else {
-        check(nmf_vm_query_sigma(p, f32(xyzt), M, a, b, bf16 ? 1 : 0, out(sf), out(sg), st(stream)), "nmf_vm_query_sigma");
-    }
+    check(nmf_vm_query_sigma(p, f32(xyzt), M, a, b, bf16 ? 1 : 0, out(sf), out(sg), st(stream)), "nmf_vm_query_sigma");
     return {sf, sg};
 }
 
@@ -1284,9 +1257,7 @@ PYBIND11_MODULE(_nmf_host, m) {
     m.def("sh_project_into", &sh_project_into);
     m.def("vm_pack_density_into", &vm_pack_density_into);
     m.def("vm_query_rows", &vm_query_rows);
-    m.def("vm_query_sigma", &vm_query_sigma, py::arg("p"), py::arg("xyzt"), py::arg("planes"), py::arg("lines"), py::arg("stream"),
-          py::arg("clean") = py::none(), py::arg("keyrank") = py::none());
-    m.def("vm_query_bwd_prehist", &vm_query_bwd_prehist);
+    m.def("vm_query_sigma", &vm_query_sigma);
     m.def("sat_lookup_bwd_dirs", &sat_lookup_bwd_dirs);
     m.def("sat_lookup_bwd_table", &sat_lookup_bwd_table);
     m.def("loss_head", &loss_head);
@@ -1311,7 +1282,7 @@ PYBIND11_MODULE(_nmf_host, m) {
         .def("env_was_used", &StepCore::env_was_used)
         .def("env_table_backward_queued", &StepCore::env_table_backward_queued)
 #define RW(name) .def_readwrite(#name, &StepCore::name)
-        RW(env_keep_sat) RW(value_hist) RW(env_split) RW(early_cb) RW(comm_stream) RW(peer_streams) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
+        RW(env_keep_sat) RW(env_split) RW(early_cb) RW(comm_stream) RW(peer_streams) RW(main_stream) RW(side_streams) RW(set_stream) RW(main_stream_obj) RW(side_stream_objs) RW(overlap) RW(sparse_normals)
         RW(mlp_side_min_rays) RW(mlp_side_min_env_rays) RW(mlp_side_wgs_env) RW(walk_side_min_samples) RW(mlp_side_wgs)
         RW(env_binned_from) RW(vm_p) RW(dpk) RW(dlk) RW(dpl) RW(dli) RW(f_dpk) RW(f_dlk) RW(f_apl) RW(f_ali) RW(apl) RW(ali) RW(basis) RW(head_p) RW(head_W) RW(head_b) RW(mlp_ws) RW(mlp_image)
         RW(mlp_bias) RW(sobol) RW(env_table) RW(env_pole) RW(env_sc) RW(env_act) RW(env_bg) RW(sh_conv) RW(march_p0) RW(march_p1)

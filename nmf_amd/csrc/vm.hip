@@ -382,8 +382,7 @@ __global__ void __launch_bounds__(256) k_vm_fwd(nmf_vm_params p, const float4* _
     }
 }
 
-// ---- brick binning helpers (the backward walks sort their samples by brick; the value query of the re-traced samples can count
-//      them on the way: k_vm_sigma<TT, true>) ---------------------------------------------------------------------------------------
+// ---- brick binning helpers (the backward walks sort their samples by brick) --------------------------------------------------------
 constexpr int BASIS_COPIES = 16;   // scratch copies of the basis_mat gradient (power of two), see vm_bwd_app2
 constexpr int BR = 4;             // brick edge in texels (R2: 4 -> 5x5 = 25 tile cells = 2 MFMA row blocks instead of 6)
 constexpr int TL = BR + 1;        // tile edge incl. the +1 halo of the bilinear footprint
@@ -445,33 +444,17 @@ __device__ __forceinline__ int bin_copy(int kc) { return (int)((blockIdx.x * (bl
 // every texel (16 of 48 floats) and of every line entry (16 of 32).  Same taps, same order of the sums as k_vm_fwd, the
 // value path of both written with explicit fma: sigma_feat and sigma are identical bits.
 // ------------------------------------------------------------------------------------------------
-// HIST (R5): the brick histogram of the value-only WALK that will follow in the backward is taken here, where every sample is visited
-// anyway: the counter add of a run of equal bricks is issued as soon as the position is known and its result (the sample's rank in
-// its brick) is consumed behind the 72 table loads -- the round trip of the atomic, which is all k_plan_hist consisted of (21 us
-// alone, ~80 us inside the saturated backward window for the 0.85 M re-traced samples of a step), hides behind them.  counts: the
-// kept zero scratch of the walk (nmf_vm_bwd_clean_bytes); keyrank [M]: (brick * kc + counter copy, rank) as k_plan_hist writes it.
-template <class TT, bool HIST = false>
+template <class TT>
 __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4* __restrict__ xyzt, int64_t M,
                                                   PtrsT3<TT> dpk, PtrsT3<TT> dlk, int plane_stride, int line_stride,
-                                                  float* __restrict__ sigma_feat, float* __restrict__ sigma,
-                                                  int32_t* __restrict__ counts = nullptr, int2* __restrict__ keyrank = nullptr,
-                                                  int nbx = 0, int kc = 1) {
+                                                  float* __restrict__ sigma_feat, float* __restrict__ sigma) {
     // plane_stride / line_stride: elements per texel / line entry of the tables handed in -- DP / DL for the packed value +
     // derivative tables, CD for the density factors themselves (nmf_vm_query_sigma: a third of the cache lines)
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = m < M;
-    if (!HIST && !active) return;
+    if (m >= M) return;
     const int G = p.grid;
     float xn[3];
-    normalized(p, xyzt[active ? m : M - 1], xn);
-    int hist_key = 0, hist_base = 0;
-    RunInfo hist_run = {false, 0, 0};
-    if constexpr (HIST) {
-        const int b = active ? brick_of(p, xn, nbx) : -1;
-        hist_run = wave_runs(b, active);
-        hist_key = b * kc + bin_copy(kc);
-        if (hist_run.head) hist_base = atomicAdd(counts + hist_key, hist_run.len);
-    }
+    normalized(p, xyzt[m], xn);
     float sf = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -502,11 +485,6 @@ __global__ void __launch_bounds__(256) k_vm_sigma(nmf_vm_params p, const float4*
             s_pl = fmaf(w_, a, s_pl);
         }
         sf += s_pl;
-    }
-    if constexpr (HIST) {
-        hist_base = __shfl(hist_base, lane_id() - hist_run.off, 64);
-        if (active) keyrank[m] = make_int2(hist_key, hist_base + hist_run.off);
-        if (!active) return;
     }
     if (sigma_feat) sigma_feat[m] = sf;
     if (sigma) {
@@ -1858,18 +1836,16 @@ int64_t gather_segments(const nmf_vm_bwd_segment* segs, int32_t n_segs, Segs& sg
 
 // place = false: the caller follows with k_place_records (the walk that sorts inside its own call)
 // clean: L.counts / L.scan_state point into the caller's kept scratch (zero now, zero again afterwards): no memset
-// hist = false: the counters and keyrank[] were filled by the forward (nmf_vm_query_sigma_hist) -- needs the clean scratch
-int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false,
-                bool hist = true) {
+int launch_plan(const nmf_vm_params* p, const Segs& sg, int64_t M, const PlanLayout& L, hipStream_t st, bool place, bool clean = false) {
     // the look-back needs its chunks' workgroups resident together: 2048 of them fit the chip (8 per CU); grids beyond ~500^3 take
     // the two-launch scan (k_bins_partial + k_bins_final)
     const bool lookback = L.n_scan_chunks <= 2048;
     const size_t count_bytes = sizeof(int32_t) * (size_t)(L.nb + 1) * L.kc;
-    if (hist && (!clean || !lookback)) {
+    if (!clean || !lookback) {
         hipError_t e = hipMemsetAsync(L.counts, 0, clean ? count_bytes : L.zero_bytes, st);
         if (e != hipSuccess) return nmf_fail((int)e, "nmf_vm_bin_plan: memset");
     }
-    if (hist) NMF_LAUNCH(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
+    NMF_LAUNCH(k_plan_hist, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, *p, sg, M, L.nbx, L.kc, L.counts, L.keyrank);
     if (lookback) {
         NMF_LAUNCH(k_bins_scan, dim3(L.n_scan_chunks), dim3(SC_THREADS), 0, st, L.counts, L.nb, L.kc, L.scan_state, L.offsets,
                            L.cursor, L.item_size, L.items, L.n_items, clean ? 1 : 0);
@@ -1921,8 +1897,7 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
                        const float* const dlk[3], const float* const app_planes[3], const float* const app_lines[3],
                        const float* basis, float* const g_dpk[3], float* const g_dlk[3], float* const g_app_planes[3],
                        float* const g_app_lines[3], float* g_basis, const void* plan, int64_t plan_bytes, void* workspace,
-                       int64_t workspace_bytes, void* stream, void* clean = nullptr, int64_t clean_bytes = 0,
-                       const void* prehist = nullptr) {
+                       int64_t workspace_bytes, void* stream, void* clean = nullptr, int64_t clean_bytes = 0) {
     NMF_REQUIRE(p && n_segs >= 0 && n_segs <= MAX_SEG && (segs || n_segs == 0), NMF_EINVAL,
                 "nmf_vm_query_bwd: params / segment count (at most NMF_VM_MAX_SEGMENTS)");
     NMF_REQUIRE(!clean || (!plan && clean_bytes >= clean_layout(nullptr, p->grid).bytes && ((uintptr_t)clean & 15) == 0), NMF_EINVAL,
@@ -1966,12 +1941,7 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
             L.counts = C.counts;
             L.scan_state = C.scan_state;
         }
-        if (prehist) {          // the histogram of these samples was taken by the forward query into `clean`'s counters
-            NMF_REQUIRE(clean && n == 1 && L.n_scan_chunks <= 2048, NMF_EINVAL,
-                        "nmf_vm_query_bwd_segments_prehist: one sample set, the kept scratch, a grid the one-launch scan covers");
-            L.keyrank = (int2*)const_cast<void*>(prehist);
-        }
-        const int rc = launch_plan(p, sg, M, L, st, false, clean != nullptr, prehist == nullptr);
+        const int rc = launch_plan(p, sg, M, L, st, false, clean != nullptr);
         if (rc != NMF_OK) return rc;
         walk_ws = (char*)workspace + L.bytes;
         walk_bytes = workspace_bytes - L.bytes;
@@ -2025,49 +1995,6 @@ static int vm_bwd_impl(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, i
 }
 
 extern "C" int64_t nmf_vm_bwd_clean_bytes(int32_t grid) { return clean_layout(nullptr, grid).bytes; }
-
-extern "C" int nmf_vm_query_sigma_hist(const nmf_vm_params* p, const float* xyzt, int64_t M, const void* const planes[3],
-                                       const void* const lines[3], int32_t tables_bf16, float* sigma_feat, float* sigma,
-                                       void* clean, int64_t clean_bytes, void* keyrank, void* stream) {
-    NMF_REQUIRE(p && M >= 0, NMF_EINVAL, "nmf_vm_query_sigma_hist: params");
-    if (M == 0) return NMF_OK;
-    NMF_REQUIRE(M < (1ll << 31), NMF_ERANGE, "nmf_vm_query_sigma_hist: M >= 2^31");
-    NMF_REQUIRE(xyzt && planes && lines && planes[0] && planes[1] && planes[2] && lines[0] && lines[1] && lines[2] &&
-                    (sigma_feat || sigma) && keyrank,
-                NMF_EINVAL, "nmf_vm_query_sigma_hist: null");
-    NMF_REQUIRE(clean && clean_bytes >= clean_layout(nullptr, p->grid).bytes && ((uintptr_t)clean & 15) == 0, NMF_EINVAL,
-                "nmf_vm_query_sigma_hist: scratch too small (nmf_vm_bwd_clean_bytes) or not 16-byte aligned");
-    const PlanLayout L = plan_layout(nullptr, 0, p->grid);
-    int32_t* counts = clean_layout(clean, p->grid).counts;
-    if (tables_bf16) {
-        const uint16_t* pl[3] = {(const uint16_t*)planes[0], (const uint16_t*)planes[1], (const uint16_t*)planes[2]};
-        const uint16_t* li[3] = {(const uint16_t*)lines[0], (const uint16_t*)lines[1], (const uint16_t*)lines[2]};
-        NMF_LAUNCH_NAMED("k_vm_sigma<unsigned short, true>", (k_vm_sigma<uint16_t, true>), dim3((unsigned)cdiv(M, 256)), dim3(256), 0,
-                         (hipStream_t)stream, *p, (const float4*)xyzt, M, mkT<uint16_t>(pl, true), mkT<uint16_t>(li, true), CD, CD,
-                         sigma_feat, sigma, counts, (int2*)keyrank, L.nbx, L.kc);
-    } else {
-        const float* pl[3] = {(const float*)planes[0], (const float*)planes[1], (const float*)planes[2]};
-        const float* li[3] = {(const float*)lines[0], (const float*)lines[1], (const float*)lines[2]};
-        NMF_LAUNCH_NAMED("k_vm_sigma<float, true>", (k_vm_sigma<float, true>), dim3((unsigned)cdiv(M, 256)), dim3(256), 0,
-                         (hipStream_t)stream, *p, (const float4*)xyzt, M, mkT<float>(pl, true), mkT<float>(li, true), CD, CD, sigma_feat,
-                         sigma, counts, (int2*)keyrank, L.nbx, L.kc);
-    }
-    NMF_CHECK_LAUNCH("nmf_vm_query_sigma_hist");
-    return NMF_OK;
-}
-
-
-extern "C" int nmf_vm_query_bwd_segments_prehist(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
-                                                 const float* const dpk[3], const float* const dlk[3],
-                                                 const float* const app_planes[3], const float* const app_lines[3],
-                                                 const float* basis, float* const g_dpk[3], float* const g_dlk[3],
-                                                 float* const g_app_planes[3], float* const g_app_lines[3], float* g_basis,
-                                                 void* clean, int64_t clean_bytes, const void* keyrank, void* workspace,
-                                                 int64_t workspace_bytes, void* stream) {
-    NMF_REQUIRE(clean && keyrank, NMF_EINVAL, "nmf_vm_query_bwd_segments_prehist: scratch / keyrank null");
-    return vm_bwd_impl(p, segs, n_segs, dpk, dlk, app_planes, app_lines, basis, g_dpk, g_dlk, g_app_planes, g_app_lines, g_basis,
-                       nullptr, 0, workspace, workspace_bytes, stream, clean, clean_bytes, keyrank);
-}
 
 extern "C" int nmf_vm_query_bwd_segments_clean(const nmf_vm_params* p, const nmf_vm_bwd_segment* segs, int32_t n_segs,
                                                const float* const dpk[3], const float* const dlk[3],

@@ -187,7 +187,7 @@ class TrainPass:
         return [cx.core for cx in self._ctxs]
 
     def set_switch(self, name, value):
-        """a boolean switch of the C++ pass (env_split, value_hist, ...: A/B runs and tests) on every chunk context, present and future"""
+        """a boolean switch of the C++ pass (env_split, ...: A/B runs and tests) on every chunk context, present and future"""
         self._switches[name] = value
         if self.context(0) is not None:
             for cx in self._ctxs:

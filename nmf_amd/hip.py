@@ -62,7 +62,7 @@ class CopySlot(C.Structure):
 EXPORTS = [
     "nmf_version", "nmf_last_error_string", "nmf_event_create", "nmf_event_create_timed", "nmf_event_elapsed_ms", "nmf_event_destroy", "nmf_event_record", "nmf_event_synchronize",
     "nmf_stream_wait_event", "nmf_memcpy_d2h_async", "nmf_host_alloc_mapped", "nmf_host_free_mapped", "nmf_publish_i64x2", "nmf_wait_seq", "nmf_set_launch_probe", "nmf_alpha_pack", "nmf_march_count", "nmf_march_scan", "nmf_march_scan_workspace_bytes", "nmf_march_scan_publish", "nmf_bounce_index_publish", "nmf_bounce_index_live", "nmf_vm_query_fwd_live",
-    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_sigma", "nmf_sat_lookup_bwd_dirs", "nmf_vm_query_sigma_hist", "nmf_vm_query_bwd_segments_prehist", "nmf_vm_query_bwd",
+    "nmf_march_fill", "nmf_march_dense", "nmf_vm_pack_density", "nmf_vm_query_fwd", "nmf_vm_query_fwd_bf16", "nmf_vm_query_rows", "nmf_vm_query_sigma", "nmf_sat_lookup_bwd_dirs", "nmf_vm_query_bwd",
     "nmf_vm_unpack_density_grad", "nmf_vm_bwd_workspace_bytes", "nmf_composite_fwd", "nmf_composite_bwd", "nmf_segment_sum",
     "nmf_sat_build", "nmf_sat_build_bwd", "nmf_sat_lookup_fwd", "nmf_sat_lookup_bwd", "nmf_sat_lookup_bwd_binned",
     "nmf_sat_lookup_bwd_workspace_bytes",

@@ -432,6 +432,12 @@ def case_e2e_g300():
     _full_size_case("e2e_g300_steady", 650000, G=300, B=192, ray_seed=4, noise_seed=77)
 
 
+def case_e2e_g300_1k():
+    """the same at a realistic load: 1024 rays at 300^3, steady state -- 57 k secondary rays and 0.3 M
+    level-1 samples through the walks of the final grid, against 10 k in e2e_g300_steady"""
+    _full_size_case("e2e_g300_steady_1k", 650000, G=300, B=1024, ray_seed=5, noise_seed=99)
+
+
 def case_e2e_variant():
     """the scene variations of the reference's dataset configs at full size: near_far [2, 6]
     (configs/dataset/materials.yaml), aabb_scale 2 (helmet.yaml:8: the box of the field is twice the scene box), a high-specular
@@ -554,7 +560,7 @@ def case_blender_rays():
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
              e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant,
-             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval)
+             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -336,7 +336,7 @@ def test_e2e_full_size_seeded_pinned_order():
     _check_loss_and_gradients(nerf, g, ims, st)
 
 
-@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady"])
+@pytest.mark.parametrize("name", ["e2e_full_steady", "e2e_g300_steady", "e2e_g300_steady_1k"])
 def test_e2e_steady_state_vs_reference(name):
     """The regime bench.py times -- every secondary ray re-traced (~0.18 M primary + ~0.9 M secondary samples
     at 4096 rays / 128^3) -- and the final 300^3 grid of the schedule, against the reference run with the same seed.

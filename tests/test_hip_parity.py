@@ -1672,52 +1672,6 @@ def test_vm_backward_segments_equal_concatenation(with_app):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,M", [(32, 70000), (128, 300001)])
-def test_value_query_takes_the_histogram_of_the_value_only_walk(G, M):
-    """nmf_vm_query_sigma_hist + nmf_vm_query_bwd_segments_prehist (R5): the density-value query of the re-traced samples counts them
-    per brick on the way (into the kept scratch of the walk) and the value-only walk of the backward starts at the counter scan --
-    same sigma bits as nmf_vm_query_sigma, the gradients of the self-sorting walk (autograd of fields/tensoRF.py:181-190), the scratch
-    handed back zero, walk after walk."""
-    import ctypes as C
-    from nmf_amd import hip, synthetic
-    fx = hip.HOST_EXT
-    if fx is None or not hasattr(fx, "vm_query_bwd_prehist"):
-        pytest.skip("host extension not built")
-    cfg = O.Cfg(grid=G)
-    sd = synthetic.state_dict_s1(grid=G, bg_resolution=8, seed=3)
-    p, dpk, dlk, apl, ali, basis = _field_tables(hip, sd, cfg)
-    dpl = [_cl(sd[f"rf.density_rf.app_plane.{i}"].detach()) for i in range(3)]
-    dli = [_cl(sd[f"rf.density_rf.app_line.{i}"].detach()).reshape(G, 16) for i in range(3)]
-    g = torch.Generator().manual_seed(11)
-    c = (torch.rand(M // 40 + 1, 3, generator=g) * 2 - 1) * 1.45            # ray-like runs of nearby samples + points outside the box
-    x = c.repeat_interleave(40, 0)[:M] + 0.015 * torch.randn(M, 3, generator=g)
-    x[::211] *= 1.3
-    xyz = torch.cat([x, torch.zeros(M, 1)], 1).to(DEV).contiguous()
-    pa = C.addressof(p)
-    st = torch.cuda.current_stream().cuda_stream
-    z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=DEV)  # noqa: E731
-    clean = hip.vm_bwd_clean_scratch(p, DEV)
-    sf0, sg0 = fx.vm_query_sigma(pa, xyz, dpl, dli, st)
-    for rep in range(3):
-        keyrank = torch.empty((M, 2), dtype=torch.int32, device=DEV)
-        sf1, sg1 = fx.vm_query_sigma(pa, xyz, dpl, dli, st, clean, keyrank)
-        assert torch.equal(sf0, sf1) and torch.equal(sg0, sg1)
-        assert int(clean.view(torch.int32).sum()) == M                                                # every sample counted once
-        d_sigma = torch.randn(M, generator=torch.Generator().manual_seed(rep)).to(DEV)
-        seg = [(xyz, sf1, None, d_sigma, None, None, None)]
-        a = ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)])
-        b = ([z(G, G, 48) for _ in range(3)], [z(G, 32) for _ in range(3)])
-        hip.vm_query_bwd_segments(p, seg, dpk, dlk, apl, ali, basis, a[0], a[1], [z(G, G, 24)] * 3, [z(G, 24)] * 3, None)
-        fx.vm_query_bwd_prehist(pa, seg, dpk, dlk, apl, ali, basis, b[0], b[1], [], [], None, clean, keyrank, st)
-        torch.cuda.synchronize()
-        fa = torch.cat([t.reshape(-1) for t in a[0] + a[1]]).cpu()
-        fb = torch.cat([t.reshape(-1) for t in b[0] + b[1]]).cpu()
-        assert fa.abs().max() > 0
-        assert_close(fb, fa, rtol=2e-5, atol=2e-5 * float(fa.abs().max()), what="walk on the forward's histogram vs self-sorting walk")
-        assert int(clean.count_nonzero()) == 0                                  # handed back zero
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("with_app", [False, True])
 @pytest.mark.parametrize("grid", [32, 57])
 def test_vm_backward_with_a_plan_of_the_forward_equals_the_self_sorting_walk(with_app, grid):

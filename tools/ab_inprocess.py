@@ -6,7 +6,7 @@ thermal drift and box-to-box differences (4 % between `python bench.py` runs on 
 <what>:
     NAME                 os.environ[NAME] = value            (knobs that are read at call time)
     obj:ATTR             TrainPass attribute, as bool        (obj:overlap 0,1   obj:sparse_normals 0,1)
-    core:ATTR            StepCore attribute, as bool         (core:value_hist 0,1)
+    core:ATTR            StepCore attribute, as bool         (core:env_split 0,1)
     attr:NAME            nmf_amd.fast_step module constant   (attr:MLP_SIDE_WGS 64,128,256)
     hip:NAME             nmf_amd.hip module constant         (hip:ENV_BINNED_MIN_LOOKUPS 16384,4611686018427387904)
     calldelay:NAME       busy-wait of <value> us on the host in front of every call of the C++ wrapper NAME (csrc/host_ext.cpp)

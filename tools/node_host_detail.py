@@ -42,7 +42,7 @@ class CW:
             return w
         return v
     def __setattr__(s, n, v): setattr(s.c, n, v)
-tp._core = CW(c)
+tp._core = tp.context(0).core = CW(c)          # (round 6: the pass reaches its StepCore through its chunk context 0)
 wrap(opt, "_step_planned")
 from nmf_amd import hip
 for n in ("vm_pack_density", "brdf_mlp_pack", "sat_build", "sh_project", "sat_lookup_fwd", "vm_unpack_density_grad", "multi_copy"):
