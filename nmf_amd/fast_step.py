@@ -500,8 +500,11 @@ class TrainPass:
         # what ends the step in the last chunk's backward (env-map table backward, early all-reduce) waits for the other contexts too
         c.peer_streams = [(o.main.cuda_stream if o.main is not None else cur.cuda_stream) for o in self._ctx_used if o is not cx] if last else []
         if cx.main is not None:
-            if first_use:
-                cx.main.wait_stream(cur)          # the zero fill of the step's accumulators, the optimizer update before it
+            # the caller's stream carries what this chunk reads: the zero fill of the step's accumulators and the optimizer update before
+            # it (first use), the chunk's rays when the caller gathers them per chunk (Trainer.step(fetch=...), train.py:509-512)
+            cx.main.wait_stream(cur)
+            rays.record_stream(cx.main)           # (made on the caller's stream, read by this context's kernels until its backward ends)
+            gt.record_stream(cx.main)
             torch.cuda.set_stream(cx.main)
         try:
             return self._core_chunk(cx, rays, gt, focal, noise, inv_lbatch, wts, want_total, last)
