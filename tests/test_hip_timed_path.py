@@ -11,7 +11,7 @@ import torch
 from conftest import Golden, assert_close
 from nmf_amd import synthetic
 from oracle import nmf_oracle as O
-from test_hip_e2e import (DEV, _check_gradients, _fixture_rays, _early_phase_order, _frac_close, _full_size_model,
+from test_hip_e2e import (DEV, G300_1K_LOOSE, _check_gradients, _fixture_rays, _early_phase_order, _frac_close, _full_size_model,
                           _pin_reference_bookkeeping)
 from test_hip_parity import _field_tables, _hip
 
@@ -107,6 +107,8 @@ def test_timed_path_vs_reference(name):
     # MLP and the env map itself move by 2e-5 / 3e-5); the GPU differs from the CPU in expf, atan2, log, pow and the order of every
     # atomic sum at once: measured 4-10 % / 12 % / 6 % on those tensors, 1e-4 ... 1e-2 on all others.
     loose = {"density_rf": 0.15, "roughness": 0.2, "mipbias": 0.1} if "variant" in name else None
+    if name == "e2e_g300_steady_1k":
+        loose = G300_1K_LOOSE
     _check_gradients(nerf, g, full_tol=3e-2 if "g300" in name else (2e-2 if "variant" in name else 5e-3), loose=loose)
 
 

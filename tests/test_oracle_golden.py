@@ -264,7 +264,7 @@ def test_psnr_formula():
     assert abs(float(O.psnr_8bit(pred, gt)) - want) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["e2e_full_seeded", "e2e_g300_steady", "e2e_full_steady", "e2e_variant_steady"])
+@pytest.mark.parametrize("name", ["e2e_full_seeded", "e2e_g300_steady", "e2e_g300_steady_1k", "e2e_full_steady", "e2e_variant_steady"])
 def test_full_size_replay_by_seed(name):
     """BASELINE size (4096 rays, 128^3, 512x1024 env) in the early phase (1000 secondary rays re-traced) and in the steady
     state bench.py times (all ~246 k re-traced, ~0.9 M secondary samples), plus the final 300^3 grid of the schedule on a
