@@ -569,7 +569,9 @@ def reference_psnr_seeds():
     import numpy as np
     g = np.load(os.path.join(ROOT, "tests", "golden", "psnr_trace.npz"))
     rows = [g[f"s{s_}/test_psnr"].mean(-1) for s_ in range(int(g["n_seeds"]))]
-    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "psnr_ref_more*.npz"))):
+    # (+ round 6: the runs that also keep their trajectories, tests/golden/make_psnr_traj.py)
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "psnr_ref_more*.npz"))
+                    + glob.glob(os.path.join(ROOT, "tests", "golden", "psnr_ref_traj_*.npz"))):
         with np.load(f) as z:
             rows += [z[k].mean(-1) for k in sorted(z.files) if k.endswith("/test_psnr")]
     return np.stack(rows), [int(v) for v in g["psnr_at"]]

@@ -399,7 +399,7 @@ def test_concurrent_chunk_contexts_equal_the_sequential_step(contexts):
             assert len({cx.core.main_stream for cx in tr.fast._ctxs}) == k
         grads = {name: p.grad.detach().double().clone() for name, p in nerf.named_parameters() if p.grad is not None}
         res[k] = dict(kept=[r["kept"] for r in trace], n_samples=[list(r["n_samples"]) for r in trace], loss=out["loss"], grads=grads)
-        if k > 1:
+        if True:        # (for one context too: both runs take the same sequence of steps, the schedules advance alike)
             # the same step with the chunks' rays GATHERED per chunk on the caller's stream (Trainer.step(fetch=...), train.py:509-512):
             # a context's stream waits for the caller's at every chunk and keeps the gathered tensors alive until its backward has read them
             pos = [0]

@@ -64,6 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=32)
     ap.add_argument("--window", type=int, default=25)
+    ap.add_argument("--save", default=None, help="npz that receives this build's trajectories")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_trajectory.txt"))
     a = ap.parse_args()
     import torch
@@ -74,6 +75,14 @@ def main():
     n_it = 300
     mine = []
     hip, _, _ = bench.psnr_runs(torch.device("cuda", 0), range(a.seeds), traj=mine)
+    if a.save:          # the build's own runs, for offline analysis next to the reference's files
+        flat = {}
+        for i, t in enumerate(mine):
+            for k, v in t.items():
+                if k != "names":
+                    flat[f"s{i}/{k}"] = np.asarray(v)
+        flat["names"] = np.asarray("\n".join(mine[0]["names"]))
+        np.savez_compressed(a.save, **flat)
     R = [per_iter(t, n_it) for t in ref]
     H = [per_iter(t, n_it) for t in mine]
     # gradient / parameter norms by parameter name (the reference's names = this build's: the state_dict contract)
