@@ -577,7 +577,7 @@ def reference_psnr_seeds():
     return np.stack(rows), [int(v) for v in g["psnr_at"]]
 
 
-def psnr_runs(device, seeds, traj=None):
+def psnr_runs(device, seeds, traj=None, params_over=None):
     """One 300-iteration training of the S2 configuration per seed, each from a FRESH initialisation (the constructors' random
     initial parameters under torch.manual_seed(seed), calibration as train.py:429-437), device noise, the data set of the fixture
     -> test PSNR [seed, evaluation] (8-bit formula, renderer.py:399-401), rays per second incl. the evaluations.
@@ -601,6 +601,7 @@ def psnr_runs(device, seeds, traj=None):
     mn, mx, start, target = (int(v) for v in g["params_params"])
     params = dict(resolved_config()["params"], n_iters=int(ov["model.params.n_iters"]), batch_size=mn, min_batch_size=mn,
                   max_batch_size=mx, starting_batch_size=start, target_num_samples=target)
+    params.update(params_over or {})              # (factor experiments of tools/psnr_trajectory.py, e.g. ori_lambda = 0)
     rays_tr, rgb_tr = torch.as_tensor(g["rays_train"]).to(device), torch.as_tensor(g["rgb_train"]).to(device)
     rays_te, rgb_te = torch.as_tensor(g["rays_test"]).to(device), torch.as_tensor(g["rgb_test"]).to(device)
     focal, n_views = float(g["focal"]), rays_te.shape[0] // (res * res)

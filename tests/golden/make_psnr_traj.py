@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--out", default=os.path.join(HERE, "psnr_ref_traj.npz"))
+    ap.add_argument("--override", action="append", default=[], help="extra hydra override of the reference run, e.g. model.params.ori_lambda=0 "
+                    "(a factor experiment: give --out another name, the files psnr_ref_traj_*.npz are the unmodified configuration)")
     a = ap.parse_args()
     done = {}
     if os.path.exists(a.out):
@@ -40,7 +42,7 @@ def main():
         r = mt.run(grid0=48, grid1=48, teacher_grid=48, bg=32, upsample_at=(1000000,), n_iters=30000, stop_at=300, psnr_at=(100, 200, 300),
                    res=32, train_views=24, test_views=3, seed=20211200 + s, batch=1024, max_batch=2048, max_samples=40000,
                    max_brdf_rays=(80000, 40000), target_num_samples=80000, max_retrace=1000, rays_per_ray=128, light="traj",
-                   threads=a.threads)
+                   threads=a.threads, extra_overrides=tuple(a.override))
         for k, v in r.items():
             if k in ("psnr_at", "gradnorm_names", "param_names"):
                 done[k] = np.asarray(v)

@@ -145,7 +145,7 @@ def run(**knobs):
         f"model.params.n_iters={N_ITERS}", f"model.params.batch_size={K['batch']}", f"model.params.min_batch_size={K['batch']}",
         f"model.params.max_batch_size={K['max_batch']}", "model.params.starting_batch_size=100",
         f"model.params.target_num_samples={K['max_samples']}",
-    ]
+    ] + list(K.get("extra_overrides", ()))          # (e.g. "model.params.ori_lambda=0": make_psnr_traj.py --override)
     cfg = yaml_config.compose(os.path.join(rh.REF, "configs"), small)
     args = wrap(cfg)
     tmp = tempfile.mkdtemp(prefix="nmf_trace_")

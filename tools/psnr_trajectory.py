@@ -46,9 +46,9 @@ def per_iter(T, n_it):
     return out
 
 
-def load_reference():
+def load_reference(pattern="psnr_ref_traj_*.npz"):
     runs, names, pnames = [], None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "psnr_ref_traj_*.npz"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", pattern))):
         with np.load(f) as z:
             seeds = sorted({k.split("/")[0] for k in z.files if "/" in k})
             names = str(z["gradnorm_names"]).split("\n") if "gradnorm_names" in z.files else names
@@ -65,16 +65,22 @@ def main():
     ap.add_argument("--seeds", type=int, default=32)
     ap.add_argument("--window", type=int, default=25)
     ap.add_argument("--save", default=None, help="npz that receives this build's trajectories")
+    ap.add_argument("--ref-glob", default="psnr_ref_traj_*.npz", help="reference files under tests/golden")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="model.params key changed for this build's runs")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_trajectory.txt"))
     a = ap.parse_args()
     import torch
     import bench
-    ref, gnames, pnames = load_reference()
+    ref, gnames, pnames = load_reference(a.ref_glob)
     if not ref:
-        raise SystemExit("no tests/golden/psnr_ref_traj_*.npz")
+        raise SystemExit(f"no tests/golden/{a.ref_glob}")
+    over = {}
+    for kv in a.param:                     # a factor experiment: the same key changed on both sides (make_psnr_traj.py --override)
+        k, v = kv.split("=")
+        over[k] = float(v)
     n_it = 300
     mine = []
-    hip, _, _ = bench.psnr_runs(torch.device("cuda", 0), range(a.seeds), traj=mine)
+    hip, _, _ = bench.psnr_runs(torch.device("cuda", 0), range(a.seeds), traj=mine, params_over=over)
     if a.save:          # the build's own runs, for offline analysis next to the reference's files
         flat = {}
         for i, t in enumerate(mine):
