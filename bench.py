@@ -577,7 +577,7 @@ def reference_psnr_seeds():
     return np.stack(rows), [int(v) for v in g["psnr_at"]]
 
 
-def psnr_runs(device, seeds, traj=None, params_over=None):
+def psnr_runs(device, seeds, traj=None, params_over=None, on_iter=None):
     """One 300-iteration training of the S2 configuration per seed, each from a FRESH initialisation (the constructors' random
     initial parameters under torch.manual_seed(seed), calibration as train.py:429-437), device noise, the data set of the fixture
     -> test PSNR [seed, evaluation] (8-bit formula, renderer.py:399-401), rays per second incl. the evaluations.
@@ -639,6 +639,8 @@ def psnr_runs(device, seeds, traj=None, params_over=None):
                 T["iter_lr"].append([float(g_["lr"]) for g_ in tr.optimizer.param_groups])
             st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb, trace=rec)
             rays_seen += st["rays"]
+            if on_iter is not None:                 # (tools/trained_state_dump.py: the model after a given iteration)
+                on_iter(seed, it, nerf, tr)
             if T is not None:
                 for r_ in rec:
                     if "total" not in r_:               # a chunk without a sample: train.py:567-568 skips it before the backward

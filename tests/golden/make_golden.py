@@ -438,6 +438,97 @@ def case_e2e_g300_1k():
     _full_size_case("e2e_g300_steady_1k", 650000, G=300, B=1024, ray_seed=5, noise_seed=99)
 
 
+def case_trained_step():
+    """Round 6: ONE training chunk of the reference from a TRAINED state -- the model of this build's own S2 training after 100
+    iterations (tests/golden/trained_state_it100.npz, written on the GPU by tools/trained_state_dump.py; 48^3, 32 x 64 env map, the
+    configuration of the PSNR runs: max_samples 40 000, max_brdf_rays [80 000, 40 000], partial re-trace).  Every fixture before this one
+    sits at scene S1's synthetic state; the question here is whether the two sides' single-step gradients also agree where training
+    takes the model (sharp roughness, a learnt env map, density factors that are no longer an indicator function)."""
+    st = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "trained_state_it100.npz"))
+    tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "psnr_trace.npz"))
+    G, BG, B = 48, 32, int(st["num_rays"])
+    max_retrace = int(st["max_retrace"])
+    nerf = rh.build_reference(grid=G, bg_resolution=BG, max_samples=40000, max_brdf_rays=(80000, 40000),
+                              max_retrace_rays=(max_retrace,), target_num_samples=(80000,))
+    sd = {k[3:]: torch.as_tensor(st[k]) for k in st.files if k.startswith("sd/")}
+    missing, unexpected = nerf.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "alphaMask" not in k], missing
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in st["biases"])
+    nerf.sampler.update(nerf.rf, init=True)                     # no alpha mask before iteration 2000 (sampler.update_list)
+    nerf.model.detach_N = False
+    nerf.model.min_rough = float(st["min_rough"])
+    rays, gt, focal = torch.as_tensor(tr["rays_train"][:B]), torch.as_tensor(tr["rgb_train"][:B]), float(tr["focal"])
+    ori_lambda, pred_lambda, noise_seed = float(st["ori_lambda"]), float(st["pred_lambda"]), 5150
+    torch.manual_seed(noise_seed)
+    with BookkeepingTap() as tap:
+        ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
+    wv = stats["whole_valid"]
+    loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()                       # train.py:598-601
+    total = (loss + ori_lambda * stats["ori_loss"] + pred_lambda * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 1024
+    total.backward()
+    out = dict(grid=G, bg_res=BG, n_rays=B, noise_seed=noise_seed, max_retrace=max_retrace, focal=focal, rays=rays, gt=gt,
+               ori_lambda=ori_lambda, pred_lambda=pred_lambda, min_rough=float(st["min_rough"]), biases=st["biases"],
+               rgb_map=ims["rgb_map"], acc_map=ims["acc_map"], whole_valid=wv, n_samples=np.asarray(stats["n_samples"]),
+               loss=loss, total=total, ori_loss=stats["ori_loss"], prediction_loss=stats["prediction_loss"])
+    for lvl, c in enumerate(tap.counts):
+        out[f"counts{lvl}"] = c.to(torch.int16)
+    assert len(tap.valid) == 2 and len(tap.orders) == 1
+    out["valid1"] = np.packbits(tap.valid[1].numpy().reshape(-1))
+    out["valid1_shape"] = np.asarray(tap.valid[1].shape)
+    order = tap.orders[0]
+    R = order.shape[0]
+    out["n_secondary"] = R
+    out["retrace_order0"] = order.int()          # the full argsort: [not re-traced | re-traced], both in the reference's order
+    for n, p in nerf.named_parameters():
+        if p.grad is not None:
+            out["gradnorm/" + n] = p.grad.norm()
+            out["grad/" + n] = p.grad                                  # 48^3: every gradient in full
+    for k, v in sd.items():
+        out["sd/" + k] = v
+    print("trained_step: n_samples", stats["n_samples"], "R", R, "kept", int(wv.sum()), "of", B, "max_retrace", max_retrace)
+    save("trained_step", out)
+
+
+def case_trained_step_stats(K=40):
+    """the chunk of case_trained_step K times with the reference's OWN noise (torch's global generator, seeds 0 .. K-1): per run the
+    loss terms, the sample counts and the norm of every parameter gradient -- the DISTRIBUTION of a training chunk's gradient at a
+    trained state (tools/trained_step_stats.py draws the same statistics from this build with its production noise source)"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    st = np.load(os.path.join(here, "trained_state_it100.npz"))
+    tr = np.load(os.path.join(here, "psnr_trace.npz"))
+    G, BG, B = 48, 32, int(st["num_rays"])
+    max_retrace = int(st["max_retrace"])
+    nerf = rh.build_reference(grid=G, bg_resolution=BG, max_samples=40000, max_brdf_rays=(80000, 40000),
+                              max_retrace_rays=(max_retrace,), target_num_samples=(80000,))
+    sd = {k[3:]: torch.as_tensor(st[k]) for k in st.files if k.startswith("sd/")}
+    nerf.load_state_dict(sd, strict=False)
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in st["biases"])
+    nerf.sampler.update(nerf.rf, init=True)
+    nerf.model.detach_N = False
+    nerf.model.min_rough = float(st["min_rough"])
+    rays, gt, focal = torch.as_tensor(tr["rays_train"][:B]), torch.as_tensor(tr["rgb_train"][:B]), float(tr["focal"])
+    ori_lambda, pred_lambda = float(st["ori_lambda"]), float(st["pred_lambda"])
+    names = [n for n, _ in nerf.named_parameters()]
+    rows, losses, ns = [], [], []
+    for k in range(K):
+        for p in nerf.parameters():
+            p.grad = None
+        torch.manual_seed(1000 + k)
+        nerf.model.max_retrace_rays = [max_retrace]
+        ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
+        wv = stats["whole_valid"]
+        loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
+        total = (loss + ori_lambda * stats["ori_loss"] + pred_lambda * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 1024
+        total.backward()
+        g = dict(nerf.named_parameters())
+        rows.append([float(g[n].grad.norm()) if g[n].grad is not None else np.nan for n in names])
+        losses.append([float(loss), float(stats["ori_loss"]), float(stats["prediction_loss"]), float(total)])
+        ns.append([int(v) for v in stats["n_samples"]] + [int(wv.sum())])
+        print(k, losses[-1], ns[-1], flush=True)
+    save("trained_step_stats", dict(names="\n".join(names), gradnorm=np.asarray(rows), losses=np.asarray(losses), n_samples=np.asarray(ns),
+                                    max_retrace=max_retrace, n_rays=B))
+
+
 def case_e2e_variant():
     """the scene variations of the reference's dataset configs at full size: near_far [2, 6]
     (configs/dataset/materials.yaml), aabb_scale 2 (helmet.yaml:8: the box of the field is twice the scene box), a high-specular
@@ -560,7 +651,7 @@ def case_blender_rays():
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
              e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant,
-             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k)
+             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k, trained_step=case_trained_step, trained_step_stats=case_trained_step_stats)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -384,6 +384,55 @@ def test_e2e_steady_state_vs_reference(name):
                               loose=G300_1K_LOOSE if name == "e2e_g300_steady_1k" else None)
 
 
+def test_trained_state_single_step_vs_reference():
+    """Round 6: ONE training chunk at a TRAINED state against the reference (tests/golden/make_golden.py trained_step): the model of
+    this build's own S2 training after 100 iterations (48^3, the configuration of the PSNR runs, partial re-trace: 2286 of 31 k secondary
+    rays), 471 rays, noise by seed, the reference's bookkeeping replayed.  Every other fixture sits at scene S1's synthetic state; this
+    one asks whether the single-step gradients of the two sides also agree where training takes the model -- the PSNR trajectories of
+    the two sides differ slightly (loss 2-6 % lower here between iterations 25 and 250), and a state-dependent
+    difference of the gradients would have been the cause.  Sample counts bit-exact, radiance 1e-4, loss 1e-4, FULL gradients."""
+    from nmf_amd.config import build_model
+    from nmf_amd.noise import ReplayNoise
+    g = Golden("trained_step")
+    G, BG = g["grid"], g["bg_res"]
+    over = {"sampler.update_list": [10 ** 9], "rf.upsamp_list": [10 ** 9], "rf.N_voxel_init": G ** 3, "rf.N_voxel_final": G ** 3,
+            "sampler.max_samples": 40000, "model.max_brdf_rays": [80000, 40000], "model.target_num_samples": [80000],
+            "model.max_retrace_rays": [g["max_retrace"]], "model.rays_per_ray": 128}
+    nerf, _ = build_model(grid=G, bg_resolution=BG, device=DEV, overrides=over)
+    sd = {k[3:]: g[k] if g.np(k).shape != () else torch.as_tensor(g.np(k)) for k in g.keys("sd/")}
+    missing, unexpected = nerf.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if "alphaMask" not in k], (missing, unexpected)
+    nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in g.np("biases"))
+    nerf.train()
+    nerf.sampler.update(nerf.rf, init=True)
+    nerf.model.detach_N = False
+    nerf.model.min_rough = float(g["min_rough"])
+    nerf.fused_training_pass = False
+    pins = _pin_reference_bookkeeping(g)
+    torch.manual_seed(g["noise_seed"])
+    ims, st = nerf(g["rays"].to(DEV), float(g["focal"]), bg_col=torch.ones(3), is_train=True, ndc_ray=False,
+                   noise=ReplayNoise(DEV, None, pins=pins))
+    assert list(st["n_samples"]) == [int(v) for v in g.np("n_samples")]
+    assert torch.equal(st["whole_valid"].cpu(), g["whole_valid"])
+    for lvl in (0, 1):
+        own, pinned = pins.trace[f"counts_own{lvl}"].cpu(), pins.counts[lvl]
+        flips = int((own != pinned).sum())
+        assert flips <= max(8, own.shape[0] // 20000) and int((own - pinned).abs().max()) <= 1, (lvl, flips)
+    assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
+    frac, worst = _frac_close(ims["rgb_map"].detach().cpu(), g["rgb_map"], 1e-4, 1e-4)
+    print(f"trained_step: rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
+    assert frac >= 0.99 and worst < 2e-3, (frac, worst)
+    wv = st["whole_valid"]
+    gt = g["gt"].to(DEV)
+    loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
+    total = (loss + float(g["ori_lambda"]) * st["ori_loss"] + float(g["pred_lambda"]) * st["prediction_loss"]
+             + 8e-5 * nerf.rf.density_L1()) / 1024
+    assert_close(loss.detach().cpu(), g["loss"], rtol=1e-4, what="loss")
+    assert_close(total.detach().cpu(), g["total"], rtol=1e-4, what="total")
+    total.backward()
+    _check_gradients(nerf, g, full_tol=5e-3)
+
+
 def test_retrace_order_steady_state_own_vs_reference():
     """a20 in the steady state, nothing pinned but the counts: the HIP path sorts its OWN scores (exact_retrace_order:
     retrace_scores + nmf_argsort_f32 over all ~246 k secondary rays, as models/microfacet.py:506-509 does even when every
