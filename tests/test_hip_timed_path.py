@@ -447,7 +447,9 @@ def test_concurrent_chunk_contexts_equal_the_sequential_step(contexts):
     for name, da in a["delta"].items():
         db = b["delta"][name]
         if float(da.norm()) > 0:
-            assert float((da - db).norm() / da.norm()) < 0.05, (name, float((da - db).norm() / da.norm()))
+            # (Adam turns the atomics-order noise of near-zero gradient entries into steps of full size: 2-7 % of a density plane's
+            #  three-step movement between two runs of the SAME configuration; a missing stream dependency gives differences of order 1)
+            assert float((da - db).norm() / da.norm()) < 0.2, (name, float((da - db).norm() / da.norm()))
         else:
             assert float(db.norm()) == 0.0, name
 
