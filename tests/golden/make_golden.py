@@ -438,6 +438,18 @@ def case_e2e_g300_1k():
     _full_size_case("e2e_g300_steady_1k", 650000, G=300, B=1024, ray_seed=5, noise_seed=99)
 
 
+def case_init_step():
+    """the same single chunk from an INITIAL state: the freshly constructed and calibrated model of the reference's own S2 run 0
+    (tests/golden/psnr_trace.npz s0/init/*, s0/biases), max_retrace_rays 1000 as at the start of a run.  Round 6: the seed-mean gradient
+    norm of the density planes differs between the two sides already in iterations 0-7 (profiles/r06_psnr_trajectory.txt)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    tr = np.load(os.path.join(here, "psnr_trace.npz"))
+    st = {"sd/" + k[len("s0/init/"):]: tr[k] for k in tr.files if k.startswith("s0/init/")}
+    st.update(biases=tr["s0/biases"], max_retrace=np.asarray(1000), num_rays=np.asarray(471), min_rough=np.asarray(0.0),
+              ori_lambda=np.asarray(0.1), pred_lambda=np.asarray(3e-4))
+    _state_step("init_step", st, noise_seed=6161)
+
+
 def case_trained_step():
     """Round 6: ONE training chunk of the reference from a TRAINED state -- the model of this build's own S2 training after 100
     iterations (tests/golden/trained_state_it100.npz, written on the GPU by tools/trained_state_dump.py; 48^3, 32 x 64 env map, the
@@ -445,12 +457,16 @@ def case_trained_step():
     sits at scene S1's synthetic state; the question here is whether the two sides' single-step gradients also agree where training
     takes the model (sharp roughness, a learnt env map, density factors that are no longer an indicator function)."""
     st = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "trained_state_it100.npz"))
+    _state_step("trained_step", {k: st[k] for k in st.files}, noise_seed=5150)
+
+
+def _state_step(name, st, noise_seed):
     tr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "psnr_trace.npz"))
     G, BG, B = 48, 32, int(st["num_rays"])
     max_retrace = int(st["max_retrace"])
     nerf = rh.build_reference(grid=G, bg_resolution=BG, max_samples=40000, max_brdf_rays=(80000, 40000),
                               max_retrace_rays=(max_retrace,), target_num_samples=(80000,))
-    sd = {k[3:]: torch.as_tensor(st[k]) for k in st.files if k.startswith("sd/")}
+    sd = {k[3:]: torch.as_tensor(st[k]) for k in st if k.startswith("sd/")}
     missing, unexpected = nerf.load_state_dict(sd, strict=False)
     assert not [k for k in missing if "alphaMask" not in k], missing
     nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in st["biases"])
@@ -458,7 +474,7 @@ def case_trained_step():
     nerf.model.detach_N = False
     nerf.model.min_rough = float(st["min_rough"])
     rays, gt, focal = torch.as_tensor(tr["rays_train"][:B]), torch.as_tensor(tr["rgb_train"][:B]), float(tr["focal"])
-    ori_lambda, pred_lambda, noise_seed = float(st["ori_lambda"]), float(st["pred_lambda"]), 5150
+    ori_lambda, pred_lambda = float(st["ori_lambda"]), float(st["pred_lambda"])
     torch.manual_seed(noise_seed)
     with BookkeepingTap() as tap:
         ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
@@ -485,28 +501,29 @@ def case_trained_step():
             out["grad/" + n] = p.grad                                  # 48^3: every gradient in full
     for k, v in sd.items():
         out["sd/" + k] = v
-    print("trained_step: n_samples", stats["n_samples"], "R", R, "kept", int(wv.sum()), "of", B, "max_retrace", max_retrace)
-    save("trained_step", out)
+    print(name, ": n_samples", stats["n_samples"], "R", R, "kept", int(wv.sum()), "of", B, "max_retrace", max_retrace)
+    save(name, out)
 
 
-def case_trained_step_stats(K=40):
-    """the chunk of case_trained_step K times with the reference's OWN noise (torch's global generator, seeds 0 .. K-1): per run the
-    loss terms, the sample counts and the norm of every parameter gradient -- the DISTRIBUTION of a training chunk's gradient at a
-    trained state (tools/trained_step_stats.py draws the same statistics from this build with its production noise source)"""
+def _step_stats(name, st, K, chunks):
+    """`chunks` = [(first ray, last ray)] of tests/golden/psnr_trace.npz's training rays: ONE optimizer step's worth of chunks, their
+    gradients accumulated as train.py:509-712 does (each chunk's loss / 1024), K times with the reference's OWN noise (torch's global
+    generator, seeds 1000 .. 1000 + K - 1): per run the loss terms and sample counts of the first chunk and the norm of every parameter's
+    accumulated gradient -- the DISTRIBUTION of a step's gradient at a given state (tools/trained_step_stats.py draws the same from this
+    build with its production noise source)"""
     here = os.path.dirname(os.path.abspath(__file__))
-    st = np.load(os.path.join(here, "trained_state_it100.npz"))
     tr = np.load(os.path.join(here, "psnr_trace.npz"))
-    G, BG, B = 48, 32, int(st["num_rays"])
+    G, BG = 48, 32
     max_retrace = int(st["max_retrace"])
     nerf = rh.build_reference(grid=G, bg_resolution=BG, max_samples=40000, max_brdf_rays=(80000, 40000),
                               max_retrace_rays=(max_retrace,), target_num_samples=(80000,))
-    sd = {k[3:]: torch.as_tensor(st[k]) for k in st.files if k.startswith("sd/")}
+    sd = {k[3:]: torch.as_tensor(st[k]) for k in st if k.startswith("sd/")}
     nerf.load_state_dict(sd, strict=False)
     nerf.model.brdf.bias, nerf.model.diffuse_module.diffuse_bias, nerf.model.diffuse_module.roughness_bias = (float(v) for v in st["biases"])
     nerf.sampler.update(nerf.rf, init=True)
     nerf.model.detach_N = False
     nerf.model.min_rough = float(st["min_rough"])
-    rays, gt, focal = torch.as_tensor(tr["rays_train"][:B]), torch.as_tensor(tr["rgb_train"][:B]), float(tr["focal"])
+    focal = float(tr["focal"])
     ori_lambda, pred_lambda = float(st["ori_lambda"]), float(st["pred_lambda"])
     names = [n for n, _ in nerf.named_parameters()]
     rows, losses, ns = [], [], []
@@ -514,19 +531,40 @@ def case_trained_step_stats(K=40):
         for p in nerf.parameters():
             p.grad = None
         torch.manual_seed(1000 + k)
-        nerf.model.max_retrace_rays = [max_retrace]
-        ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
-        wv = stats["whole_valid"]
-        loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
-        total = (loss + ori_lambda * stats["ori_loss"] + pred_lambda * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 1024
-        total.backward()
+        for ci, (lo, hi) in enumerate(chunks):
+            rays, gt = torch.as_tensor(tr["rays_train"][lo:hi]), torch.as_tensor(tr["rgb_train"][lo:hi])
+            nerf.model.max_retrace_rays = [max_retrace]
+            ims, stats = nerf(rays, focal, bg_col=torch.ones(3), is_train=True, ndc_ray=False)
+            wv = stats["whole_valid"]
+            loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
+            total = (loss + ori_lambda * stats["ori_loss"] + pred_lambda * stats["prediction_loss"] + 8e-5 * nerf.rf.density_L1()) / 1024
+            total.backward()
+            if ci == 0:
+                losses.append([float(loss), float(stats["ori_loss"]), float(stats["prediction_loss"]), float(total)])
+                ns.append([int(v) for v in stats["n_samples"]] + [int(wv.sum())])
         g = dict(nerf.named_parameters())
         rows.append([float(g[n].grad.norm()) if g[n].grad is not None else np.nan for n in names])
-        losses.append([float(loss), float(stats["ori_loss"]), float(stats["prediction_loss"]), float(total)])
-        ns.append([int(v) for v in stats["n_samples"]] + [int(wv.sum())])
         print(k, losses[-1], ns[-1], flush=True)
-    save("trained_step_stats", dict(names="\n".join(names), gradnorm=np.asarray(rows), losses=np.asarray(losses), n_samples=np.asarray(ns),
-                                    max_retrace=max_retrace, n_rays=B))
+    save(name, dict(names="\n".join(names), gradnorm=np.asarray(rows), losses=np.asarray(losses), n_samples=np.asarray(ns),
+                    max_retrace=max_retrace, chunks=np.asarray(chunks)))
+
+
+def case_trained_step_stats(K=40):
+    """the chunk of case_trained_step K times with the reference's own noise"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    st = np.load(os.path.join(here, "trained_state_it100.npz"))
+    _step_stats("trained_step_stats", {k: st[k] for k in st.files}, K, [(0, int(st["num_rays"]))])
+
+
+def case_init_step3_stats(K=40):
+    """a whole optimizer step (three chunks: 471 + 471 + 82 of the first 1024 training rays) from the INITIAL state of the reference's
+    run 0, K times: the gradient a first iteration hands to Adam"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    tr = np.load(os.path.join(here, "psnr_trace.npz"))
+    st = {"sd/" + k[len("s0/init/"):]: tr[k] for k in tr.files if k.startswith("s0/init/")}
+    st.update(biases=tr["s0/biases"], max_retrace=np.asarray(1000), min_rough=np.asarray(0.0), ori_lambda=np.asarray(0.1),
+              pred_lambda=np.asarray(3e-4))
+    _step_stats("init_step3_stats", st, K, [(0, 471), (471, 942), (942, 1024)])
 
 
 def case_e2e_variant():
@@ -651,7 +689,7 @@ def case_blender_rays():
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
              e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant,
-             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k, trained_step=case_trained_step, trained_step_stats=case_trained_step_stats)
+             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k, trained_step=case_trained_step, init_step=case_init_step, trained_step_stats=case_trained_step_stats, init_step3_stats=case_init_step3_stats)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -384,8 +384,10 @@ def test_e2e_steady_state_vs_reference(name):
                               loose=G300_1K_LOOSE if name == "e2e_g300_steady_1k" else None)
 
 
-def test_trained_state_single_step_vs_reference():
-    """Round 6: ONE training chunk at a TRAINED state against the reference (tests/golden/make_golden.py trained_step): the model of
+@pytest.mark.parametrize("name", ["trained_step", "init_step"])
+def test_trained_state_single_step_vs_reference(name):
+    """Round 6: ONE training chunk at a TRAINED state -- and ("init_step") at a freshly constructed and calibrated one, the reference's own
+    run 0 of tests/golden/psnr_trace.npz -- against the reference (tests/golden/make_golden.py trained_step / init_step): the model of
     this build's own S2 training after 100 iterations (48^3, the configuration of the PSNR runs, partial re-trace: 2286 of 31 k secondary
     rays), 471 rays, noise by seed, the reference's bookkeeping replayed.  Every other fixture sits at scene S1's synthetic state; this
     one asks whether the single-step gradients of the two sides also agree where training takes the model -- the PSNR trajectories of
@@ -393,7 +395,7 @@ def test_trained_state_single_step_vs_reference():
     difference of the gradients would have been the cause.  Sample counts bit-exact, radiance 1e-4, loss 1e-4, FULL gradients."""
     from nmf_amd.config import build_model
     from nmf_amd.noise import ReplayNoise
-    g = Golden("trained_step")
+    g = Golden(name)
     G, BG = g["grid"], g["bg_res"]
     over = {"sampler.update_list": [10 ** 9], "rf.upsamp_list": [10 ** 9], "rf.N_voxel_init": G ** 3, "rf.N_voxel_final": G ** 3,
             "sampler.max_samples": 40000, "model.max_brdf_rays": [80000, 40000], "model.target_num_samples": [80000],
@@ -420,7 +422,7 @@ def test_trained_state_single_step_vs_reference():
         assert flips <= max(8, own.shape[0] // 20000) and int((own - pinned).abs().max()) <= 1, (lvl, flips)
     assert_close(ims["acc_map"].cpu(), g["acc_map"], rtol=1e-5, atol=1e-5, what="acc_map")
     frac, worst = _frac_close(ims["rgb_map"].detach().cpu(), g["rgb_map"], 1e-4, 1e-4)
-    print(f"trained_step: rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
+    print(f"{name}: rgb within 1e-4 on {frac:.5f} of the rays (worst {worst:.2e})")
     assert frac >= 0.99 and worst < 2e-3, (frac, worst)
     wv = st["whole_valid"]
     gt = g["gt"].to(DEV)

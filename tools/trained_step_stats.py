@@ -18,9 +18,14 @@ from nmf_amd.config import build_model  # noqa: E402
 from nmf_amd.noise import DeviceNoise  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+STATE = sys.argv[2] if len(sys.argv) > 2 else "trained_step"            # fixture that holds the state: trained_step | init_step
+STATS = sys.argv[3] if len(sys.argv) > 3 else "trained_step_stats"      # the reference's statistics: trained_step_stats | init_step3_stats
+FUSED = len(sys.argv) > 4 and sys.argv[4] == "fused"                    # chunks through the fused pass (ChunkPass) instead of the operator graph
 DEV = "cuda"
-g = Golden("trained_step")
-ref = np.load(os.path.join(ROOT, "tests", "golden", "trained_step_stats.npz"))
+g = Golden(STATE)
+ref = np.load(os.path.join(ROOT, "tests", "golden", STATS + ".npz"))
+trace = np.load(os.path.join(ROOT, "tests", "golden", "psnr_trace.npz"))
+chunks = [tuple(int(v) for v in c) for c in ref["chunks"]] if "chunks" in ref.files else [(0, int(g["n_rays"]))]
 G, BG = g["grid"], g["bg_res"]
 over = {"sampler.update_list": [10 ** 9], "rf.upsamp_list": [10 ** 9], "rf.N_voxel_init": G ** 3, "rf.N_voxel_final": G ** 3,
         "sampler.max_samples": 40000, "model.max_brdf_rays": [80000, 40000], "model.target_num_samples": [80000],
@@ -33,8 +38,8 @@ nerf.train()
 nerf.sampler.update(nerf.rf, init=True)
 nerf.model.detach_N = False
 nerf.model.min_rough = float(g["min_rough"])
-nerf.fused_training_pass = False
-rays, gt = g["rays"].to(DEV), g["gt"].to(DEV)
+nerf.fused_training_pass = FUSED
+rays_all, gt_all = torch.as_tensor(trace["rays_train"][:chunks[-1][1]]).to(DEV), torch.as_tensor(trace["rgb_train"][:chunks[-1][1]]).to(DEV)
 names = str(ref["names"]).split("\n")
 params = dict(nerf.named_parameters())
 noise = DeviceNoise(torch.device(DEV), seed=77)
@@ -42,21 +47,24 @@ rows, losses, ns = [], [], []
 for k in range(K):
     for p in nerf.parameters():
         p.grad = None
-    nerf.model.max_retrace_rays = [int(g["max_retrace"])]
-    ims, st = nerf(rays, float(g["focal"]), bg_col=torch.ones(3), is_train=True, ndc_ray=False, noise=noise)
-    wv = st["whole_valid"]
-    loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
-    total = (loss + float(g["ori_lambda"]) * st["ori_loss"] + float(g["pred_lambda"]) * st["prediction_loss"]
-             + 8e-5 * nerf.rf.density_L1()) / 1024
-    total.backward()
+    for ci, (lo, hi) in enumerate(chunks):
+        rays, gt = rays_all[lo:hi], gt_all[lo:hi]
+        nerf.model.max_retrace_rays = [int(g["max_retrace"])]
+        ims, st = nerf(rays, float(g["focal"]), bg_col=torch.ones(3, device=DEV), is_train=True, ndc_ray=False, noise=noise)
+        wv = st["whole_valid"]
+        loss = ((ims["rgb_map"].clip(0, 1) - gt[wv].clip(0, 1)) ** 2).sum()
+        total = (loss + float(g["ori_lambda"]) * st["ori_loss"] + float(g["pred_lambda"]) * st["prediction_loss"]
+                 + 8e-5 * nerf.rf.density_L1()) / 1024
+        total.backward()
+        if ci == 0:
+            losses.append([float(loss.detach()), float(st["ori_loss"].detach()), float(st["prediction_loss"].detach()), float(total.detach())])
+            ns.append([int(v) for v in st["n_samples"]] + [int(wv.sum())])
     rows.append([float(params[n].grad.norm()) if params[n].grad is not None else np.nan for n in names])
-    losses.append([float(loss), float(st["ori_loss"]), float(st["prediction_loss"]), float(total)])
-    ns.append([int(v) for v in st["n_samples"]] + [int(wv.sum())])
 H, R = np.asarray(rows), ref["gradnorm"]
 HL, RL = np.asarray(losses), ref["losses"]
 HN, RN = np.asarray(ns, dtype=np.float64), ref["n_samples"].astype(np.float64)
 se = lambda x: x.std(0, ddof=1) / np.sqrt(x.shape[0])  # noqa: E731
-print(f"trained state, one chunk of {int(g['n_rays'])} rays: reference {R.shape[0]} runs (its generator), this build {K} runs (DeviceNoise)")
+print(f"state {STATE}, chunks {chunks} accumulated ({'fused pass' if FUSED else 'operator graph'}): reference {R.shape[0]} runs (its generator), this build {K} runs (DeviceNoise)")
 print(f"{'quantity':48s} {'reference mean':>15s} {'here mean':>13s} {'rel diff %':>11s} {'z':>7s}   {'ref std/mean':>12s} {'here std/mean':>13s}")
 def row(name, r, h):
     if not (np.isfinite(r).all() and np.isfinite(h).all()) or r.mean() == 0:
