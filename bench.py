@@ -577,13 +577,16 @@ def reference_psnr_seeds():
     return np.stack(rows), [int(v) for v in g["psnr_at"]]
 
 
-def psnr_runs(device, seeds, traj=None, params_over=None, on_iter=None):
+def psnr_runs(device, seeds, traj=None, params_over=None, on_iter=None, sampler="reference"):
     """One 300-iteration training of the S2 configuration per seed, each from a FRESH initialisation (the constructors' random
     initial parameters under torch.manual_seed(seed), calibration as train.py:429-437), device noise, the data set of the fixture
     -> test PSNR [seed, evaluation] (8-bit formula, renderer.py:399-401), rays per second incl. the evaluations.
     traj (a list): receives one dict per seed with the run's TRAJECTORY in the layout of tests/golden/make_psnr_traj.py (per chunk: loss
     back-propagated, num_rays, rays in / kept, n_samples, max_retrace; per iteration: global batch, learning rates, gradient and
-    parameter norms) -- tools/psnr_trajectory.py compares the seed means of the two sides"""
+    parameter norms) -- tools/psnr_trajectory.py compares the seed means of the two sides.
+    sampler: "reference" = which rays a chunk gets as train.py:34-51 decides it (nmf_amd.controllers.SimpleSampler: overlapping chunks,
+    what `python -m nmf_amd.train` does in one process); "disjoint" = consecutive slices of a permutation (rounds 2-5 of this file: the
+    cause of the +0.17 dB at 200 iterations)"""
     import numpy as np
     import torch
     from nmf_amd.config import build_model, resolved_config
@@ -628,16 +631,27 @@ def psnr_runs(device, seeds, traj=None, params_over=None, on_iter=None):
                      iter_param_norm=[])
             names = sorted(n_ for n_, _ in nerf.named_parameters())
             byname = dict(nerf.named_parameters())
+        ref_sampler = None
+        if sampler == "reference":          # train.py:34-51: one nextids() per chunk, the cursor moved before the slice (overlapping chunks)
+            from nmf_amd.controllers import SimpleSampler
+            ref_sampler = SimpleSampler(n_total, mn, lambda n_: torch.randperm(n_, device=device, generator=gen))
+
+            def fetch(n_):
+                ids_ = ref_sampler.nextids(n_)
+                return rays_tr[ids_], rgb_tr[ids_]
         for it in range(at[-1]):
             nb = tr.lbatch_size()
-            if cur + nb > n_total:
-                perm, cur = torch.randperm(n_total, device=device, generator=gen), 0
-            ids = perm[cur:cur + nb]
-            cur += nb
             rec = [] if T is not None else None
             if T is not None:
                 T["iter_lr"].append([float(g_["lr"]) for g_ in tr.optimizer.param_groups])
-            st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb, trace=rec)
+            if ref_sampler is not None:
+                st = tr.step(None, None, focal, noise=noise, global_rays=nb, trace=rec, fetch=fetch)
+            else:
+                if cur + nb > n_total:
+                    perm, cur = torch.randperm(n_total, device=device, generator=gen), 0
+                ids = perm[cur:cur + nb]
+                cur += nb
+                st = tr.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb, trace=rec)
             rays_seen += st["rays"]
             if on_iter is not None:                 # (tools/trained_state_dump.py: the model after a given iteration)
                 on_iter(seed, it, nerf, tr)
@@ -692,7 +706,7 @@ def psnr_at_iter(device, n_seeds=16):
                 reference_mean_db=r3(ref.mean(0)), reference_seed_stderr_db=r3(se(ref)), reference_seeds=int(ref.shape[0]),
                 delta_db=r3(delta), delta_stderr_db=r3(dse),
                 train_rays_per_s_incl_evals=round(rays_per_s, 1),
-                config=f"S2 orbit, TensoRF {G0}^3, env {BG}x{2 * BG}, {res}x{res} views, {mn}-ray batches; {hip.shape[0]} trainings here "
+                config=f"S2 orbit, TensoRF {G0}^3, env {BG}x{2 * BG}, {res}x{res} views, {mn}-ray batches, the reference's ray sampler; {hip.shape[0]} trainings here "
                        f"(fresh initialisations) against {ref.shape[0]} runs of the reference's own loop; means over seeds, delta = here - "
                        "reference with the standard error of that difference")
 

@@ -4,6 +4,7 @@ can be replayed against a recorded reference run (tests/golden/train_trace.npz, 
   RayBatchController   train.py:504-507,618-626,813   rays per chunk from the kept-rays / primary-samples ratio
   RetraceController    models/microfacet.py:236-269    how many secondary rays are re-traced, from rays / secondary samples
   learning_rate_decay  utils.py:327-359               log-linear decay with a sine warm-up, restarted at every upsample
+  SimpleSampler        train.py:34-51                 which rays a chunk gets (the cursor moves BEFORE the slice is taken)
 """
 import math
 
@@ -67,3 +68,26 @@ class RetraceController:
         self.max_retrace_rays = [min(int(t * r + 1), mx) if r is not None else prev for t, r, mx, prev in
                                  zip(self.target, self.mean_ratios, self.max_brdf_rays[:-1], self.max_retrace_rays)]
         return self.max_retrace_rays
+
+
+class SimpleSampler:
+    """train.py:34-51, statement for statement: the ray ids of the next `batch` rays of a permutation of `total` rays that is redrawn
+    when it runs out.  The reference advances its cursor BEFORE it takes the slice -- `curr += batch; ids[curr : curr + batch]` -- and
+    calls nextids once per CHUNK with that chunk's size (train.py:509-512), so that consecutive chunks of different sizes overlap: a
+    chunk of b2 rays behind one of b1 > b2 rays starts b1 - b2 rays INSIDE the previous chunk's range.  With the steady chunk sizes of a
+    run (e.g. 471 + 471 + 82 of a 1024-ray batch) the small tail chunk of every iteration repeats rays of the chunk before it, and the
+    chunk after a small one skips rays: 8 % of a batch are duplicates.  Kept as it is -- it decides which rays a training sees, i.e. the
+    PSNR after equal iterations.  `randperm(n) -> permutation` is the caller's generator (device or CPU)."""
+
+    def __init__(self, total, batch, randperm):
+        self.total, self.batch, self.randperm = total, batch, randperm
+        self.curr = total
+        self.ids = None
+
+    def nextids(self, batch=None):
+        batch = self.batch if batch is None else batch
+        self.curr += batch
+        if self.curr + batch > self.total:
+            self.ids = self.randperm(self.total)
+            self.curr = 0
+        return self.ids[self.curr:self.curr + batch]

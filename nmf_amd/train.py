@@ -211,16 +211,30 @@ def main(argv=None):
     g = torch.Generator(device=dev).manual_seed(seed)        # same permutation on every rank
     n_total = rays_tr.shape[0]
     perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
+    # Which rays a chunk gets.  One process: train.py:34-51 as it is (controllers.SimpleSampler: one nextids() per chunk, the cursor moved
+    # before the slice -- chunks of different sizes overlap, 8 % of a steady batch are repeated rays; it decides the PSNR after equal
+    # iterations).  Data parallel (the reference has none): disjoint shards of one global permutation.
+    sampler = None
+    if world == 1 and not args.rays_per_gpu:
+        from .controllers import SimpleSampler
+        sampler = SimpleSampler(n_total, int(params["batch_size"]), lambda n_: torch.randperm(n_, device=dev, generator=g))
+
+        def fetch(n_):
+            ids_ = sampler.nextids(n_)
+            return rays_tr[ids_], rgb_tr[ids_]
     t0, rays_seen = time.time(), 0
     for it in range(n_iters):
         # The global batch must be the same number on every rank (it sizes the shards, advances the shared permutation and
         # normalises the loss, train.py:504-507,703) while each rank's ray controller follows its own chunks: agree on it.
         nb = world * args.rays_per_gpu if args.rays_per_gpu else agree(trainer.lbatch_size(), "min", device=dev)
-        if cur + nb > n_total:
-            perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
-        ids = perm[cur:cur + nb][rank_slice(nb, world, rank)]      # SimpleSampler (train.py:36-51), sharded over ranks
-        cur += nb
-        out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
+        if sampler is not None:
+            out = trainer.step(None, None, focal, noise=noise, global_rays=nb, fetch=fetch)
+        else:
+            if cur + nb > n_total:
+                perm, cur = torch.randperm(n_total, device=dev, generator=g), 0
+            ids = perm[cur:cur + nb][rank_slice(nb, world, rank)]      # one global permutation, sharded over ranks
+            cur += nb
+            out = trainer.step(rays_tr[ids], rgb_tr[ids], focal, noise=noise, global_rays=nb)
         rays_seen += out["rays"] * world
         if (it + 1) % eval_every == 0 or it + 1 == n_iters:
             nerf.eval()

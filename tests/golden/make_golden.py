@@ -567,6 +567,25 @@ def case_init_step3_stats(K=40):
     _step_stats("init_step3_stats", st, K, [(0, 471), (471, 942), (942, 1024)])
 
 
+def case_simple_sampler():
+    """train.py:34-51 as it is: the ids of a sequence of nextids() calls with the chunk sizes of a run (100, then 471 + 453, then
+    471 + 471 + 82 per iteration ...) over 5000 rays, torch seeded -- incl. the overlap of consecutive chunks of different sizes and a
+    re-permutation"""
+    rh.install_stubs()
+    import sys as _sys
+    _sys.modules["hydra"].utils = _sys.modules["hydra.utils"]
+    import types as _types
+    tb = _types.ModuleType("torch.utils.tensorboard")          # (train.py imports SummaryWriter: absent here, no arithmetic in it)
+    tb.SummaryWriter = rh._Anything
+    _sys.modules["torch.utils.tensorboard"] = tb
+    import train as ref_train
+    torch.manual_seed(77)
+    smp = ref_train.SimpleSampler(5000, 1024)
+    sizes = [100, 471, 453] + [471, 471, 82] * 5 + [1024, 7, 300]
+    ids = [smp.nextids(b)[0].clone() for b in sizes]
+    save("simple_sampler", dict(total=5000, batch=1024, seed=77, sizes=np.asarray(sizes), ids=torch.cat(ids), curr=smp.curr))
+
+
 def case_e2e_variant():
     """the scene variations of the reference's dataset configs at full size: near_far [2, 6]
     (configs/dataset/materials.yaml), aabb_scale 2 (helmet.yaml:8: the box of the field is twice the scene box), a high-specular
@@ -689,7 +708,7 @@ def case_blender_rays():
 CASES = dict(blender_rays=case_blender_rays, upsample=case_upsample, sampler=case_sampler, field=case_field, alpha_mask=case_alpha_mask, env=case_env,
              shading_parts=case_shading_parts, e2e_small=case_e2e_small, e2e_full=case_e2e_full,
              e2e_full_steady=case_e2e_full_steady, e2e_g300=case_e2e_g300, e2e_variant=case_e2e_variant,
-             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k, trained_step=case_trained_step, init_step=case_init_step, trained_step_stats=case_trained_step_stats, init_step3_stats=case_init_step3_stats)
+             e2e_full_eval=case_e2e_full_eval, e2e_g300_eval=case_e2e_g300_eval, e2e_g300_1k=case_e2e_g300_1k, trained_step=case_trained_step, init_step=case_init_step, trained_step_stats=case_trained_step_stats, init_step3_stats=case_init_step3_stats, simple_sampler=case_simple_sampler)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

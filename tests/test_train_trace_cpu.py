@@ -63,3 +63,22 @@ def test_learning_rates_follow_the_reference_run():
         step += 1
         if it == up:
             step = 0                                                    # optimizer + LambdaLR re-created (train.py:806-809)
+
+
+def test_simple_sampler_is_the_references_incl_its_overlapping_chunks():
+    """train.py:34-51 (tests/golden/make_golden.py simple_sampler: the reference's own class, torch seeded): nmf_amd.controllers.
+    SimpleSampler returns the same ids call by call -- the cursor moves BEFORE the slice is taken, so a chunk that is smaller than the
+    one before it starts inside that chunk's range: with the steady chunk sizes of a run (471 + 471 + 82) the tail chunk of every
+    iteration repeats 82 rays of the chunk before it.  Round 6: this is what separated the two sides' PSNR trajectories."""
+    import os
+    import torch
+    from nmf_amd.controllers import SimpleSampler
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simple_sampler.npz"))
+    torch.manual_seed(int(g["seed"]))
+    smp = SimpleSampler(int(g["total"]), int(g["batch"]), lambda n: torch.randperm(n, dtype=torch.long))
+    got = [smp.nextids(int(b)) for b in g["sizes"]]
+    assert torch.equal(torch.cat(got), torch.as_tensor(g["ids"])) and smp.curr == int(g["curr"])
+    # the overlap, spelled out on the first full iteration (calls 3, 4, 5 = 471 + 471 + 82 rays): the 82-ray chunk lies inside the second
+    a, b, c = got[3], got[4], got[5]
+    assert len(set(a.tolist()) & set(b.tolist())) == 0
+    assert set(c.tolist()) <= set(b.tolist()) and c.shape[0] == 82

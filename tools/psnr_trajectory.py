@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--window", type=int, default=25)
     ap.add_argument("--save", default=None, help="npz that receives this build's trajectories")
     ap.add_argument("--ref-glob", default="psnr_ref_traj_*.npz", help="reference files under tests/golden")
+    ap.add_argument("--sampler", default="reference", choices=("disjoint", "reference"),
+                    help="which rays a chunk gets: disjoint slices of a permutation, or train.py:34-51 as it is (overlapping chunks)")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="model.params key changed for this build's runs")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_trajectory.txt"))
     a = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
         over[k] = float(v)
     n_it = 300
     mine = []
-    hip, _, _ = bench.psnr_runs(torch.device("cuda", 0), range(a.seeds), traj=mine, params_over=over)
+    hip, _, _ = bench.psnr_runs(torch.device("cuda", 0), range(a.seeds), traj=mine, params_over=over, sampler=a.sampler)
     if a.save:          # the build's own runs, for offline analysis next to the reference's files
         flat = {}
         for i, t in enumerate(mine):
