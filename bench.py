@@ -685,7 +685,7 @@ def psnr_runs(device, seeds, traj=None, params_over=None, on_iter=None, sampler=
     return np.asarray(out), rays_seen / (time.perf_counter() - t0), (G0, BG, res, mn)
 
 
-def psnr_at_iter(device, n_seeds=16):
+def psnr_at_iter(device, n_seeds=32):
     """BASELINE metric, second half ("PSNR@iter") and north_star's "PSNR within 0.05 dB of reference after equal iterations": the
     300-iteration S2 orbit training (48^3, 24 views of 32 x 32, 1024-ray batches, 128 secondary rays per sample, the reference's lr
     schedule) as a comparison of two DISTRIBUTIONS over seeds -- every training is its own realisation of a stochastic optimisation
