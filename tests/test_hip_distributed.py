@@ -310,3 +310,38 @@ def test_env_gradient_is_reduced_when_the_last_chunk_of_a_rank_is_empty(overlap,
     assert err <= 2e-5 * float(one_bg.abs().max()) + 1e-9, (err, float(one_bg.abs().max()))
     rel = float((one - a["grad"]).norm() / one.norm())
     assert rel < 1e-5, rel
+
+
+def _rccl_one_rank_worker(port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+    import nmf_amd.trainer as T
+    nerf, _ = _build(dev)
+    T._replica_group = lambda group: True          # a group of one rank still issues every collective
+    before = T.replica_checksum(nerf).tolist()
+    dtypes = sorted({str(t.dtype) for t in nerf.state_dict().values()})
+    nbytes = T.broadcast_replica(nerf, src=0)
+    after = T.check_replicas(nerf)
+    torch.cuda.synchronize()
+    out.update(before=before, after=after, nbytes=nbytes, dtypes=dtypes)
+    dist.destroy_process_group()
+
+
+def test_replica_broadcast_and_check_over_rccl():
+    """What a 1-GPU box can show of the start-up broadcast over the production backend: a process group of ONE rank over RCCL runs
+    every collective of broadcast_replica / check_replicas (int64 max all-reduce of the key-set signature, int64 shape broadcasts,
+    one broadcast per parameter / buffer in its own dtype, the float64 biases, the float64 checksum all-reduce) and leaves the
+    replica as it was.  (Two ranks: tests/test_distributed_cpu.py over gloo; RCCL refuses two ranks on one device.)"""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), out))
+        p.start()
+        p.join(600)
+        assert p.exitcode == 0
+        res = dict(out)
+    assert res["before"] == res["after"]
+    assert res["nbytes"] > 1 << 20 and "torch.float32" in res["dtypes"]
